@@ -1,0 +1,437 @@
+// gemm.hip -- K1/K3/K4 dense contractions + their gradients for the LAS hot path (gfx950).
+//
+// Two arithmetic modes behind one entry point (include/las_hip.h: las_gemm):
+//   LAS_PREC_F32  : exact fp32 FMA chains on the VALU (64x64x16 LDS tile, 4x4 per thread).
+//   LAS_PREC_BF16 : operands rounded to bf16 while they are staged into LDS, fp32 accumulation on
+//                   the matrix cores (v_mfma_f32_16x16x32_bf16), 64-wide waves, WM x WN waves per
+//                   workgroup, TM x TN MFMA tiles per wave.
+// Both take fp32 tensors with arbitrary (row,k) strides so the same kernel serves  x.W  (NN),
+// dY.W^T (NT) and X^T.dY (TN), with a fused bias + tanh epilogue, batching (blockIdx.z) and a
+// deterministic split-K (partials to workspace, fixed-order reduce) for the tall-K weight gradients.
+#include "las_common.h"
+
+struct GemmArgs {
+    int M, N, K;
+    float alpha, beta;
+    const float* A; long long rsA, ksA, strideA;   // op(A)(m,k) = A[m*rsA + k*ksA]
+    const float* B; long long rsB, ksB, strideB;   // op(B)(k,n) = B[n*rsB + k*ksB]
+    float* C; int ldc; long long strideC;
+    const float* bias; int act;
+    int mask_period, mask_skip;                    // zero contraction rows k with k % period == skip
+    int vecA, vecB;                                // 16-byte vector loads legal
+    int splitk, kchunk;                            // split-K: blockIdx.z = split, K range [z*kchunk, ..)
+    float* partial;                                // [splitk][M][N] when splitk > 1
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) { return act == LAS_ACT_TANH ? tanhf(v) : v; }
+
+// ------------------------------------------------------------------------------------------------
+// generic tile loader: ROWS x 32 (bf16 path) of a strided fp32 operand into registers
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int NT>
+struct TileRegs { float4 v[(ROWS * 8 + NT - 1) / NT]; };
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void tile_gload(TileRegs<ROWS, NT>& r, const float* __restrict__ X, long long rs,
+                                           long long ks, int row0, int k0, int R, int Kend, int vec,
+                                           int mperiod, int mskip) {
+    constexpr int NCH = ROWS * 8;
+    constexpr int RQ = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+        const int c = threadIdx.x + i * NT;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < NCH) {
+            if (ks == 1) {  // contraction index contiguous in memory
+                const int row = c >> 3, kq = (c & 7) * 4;
+                const int gr = row0 + row, gk = k0 + kq;
+                if (gr < R && gk < Kend) {
+                    const float* p = X + (long long)gr * rs + gk;
+                    if (vec && gk + 3 < Kend) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        v.x = p[0];
+                        if (gk + 1 < Kend) v.y = p[1];
+                        if (gk + 2 < Kend) v.z = p[2];
+                        if (gk + 3 < Kend) v.w = p[3];
+                    }
+                }
+            } else {        // row index contiguous in memory (rs == 1)
+                const int k = c / RQ, rq = (c % RQ) * 4;
+                const int gr = row0 + rq, gk = k0 + k;
+                if (gk < Kend && gr < R && !(mperiod > 0 && (gk % mperiod) == mskip)) {
+                    const float* p = X + (long long)gk * ks + gr;
+                    if (vec && gr + 3 < R) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        v.x = p[0];
+                        if (gr + 1 < R) v.y = p[1];
+                        if (gr + 2 < R) v.z = p[2];
+                        if (gr + 3 < R) v.w = p[3];
+                    }
+                }
+            }
+        }
+        r.v[i] = v;
+    }
+}
+
+constexpr int LDK = 40;  // bf16 elements per LDS row: 32 + 8 pad (80 B, keeps 16-B alignment)
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void tile_sstore(unsigned short* S, const TileRegs<ROWS, NT>& r, long long ks) {
+    constexpr int NCH = ROWS * 8;
+    constexpr int RQ = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (c < NCH) {
+            const float4 v = r.v[i];
+            if (ks == 1) {
+                const int row = c >> 3, kq = (c & 7) * 4;
+                u16x4_t pk;
+                pk.x = f2bf(v.x); pk.y = f2bf(v.y); pk.z = f2bf(v.z); pk.w = f2bf(v.w);
+                *reinterpret_cast<u16x4_t*>(&S[row * LDK + kq]) = pk;
+            } else {
+                const int k = c / RQ, rq = (c % RQ) * 4;
+                S[(rq + 0) * LDK + k] = f2bf(v.x);
+                S[(rq + 1) * LDK + k] = f2bf(v.y);
+                S[(rq + 2) * LDK + k] = f2bf(v.z);
+                S[(rq + 3) * LDK + k] = f2bf(v.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[(BM + BN) * LDK];
+    unsigned short* As = lds;
+    unsigned short* Bs = lds + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)blockIdx.z * g.strideA;
+        B += (long long)blockIdx.z * g.strideB;
+        C += (long long)blockIdx.z * g.strideC;
+    }
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    TileRegs<BM, NT> ra;
+    TileRegs<BN, NT> rb;
+    if (kbeg < kend) {
+        tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend, g.vecB, 0, 0);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();
+        tile_sstore<BM, NT>(As, ra, g.ksA);
+        tile_sstore<BN, NT>(Bs, rb, g.ksB);
+        __syncthreads();
+        if (k0 + 32 < kend) {  // next tile's global loads fly under this tile's MFMAs
+            tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+            tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend, g.vecB, 0, 0);
+        }
+        u16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const u16x8_t*>(&As[((wm * TM + i) * 16 + (lane & 15)) * LDK + (lane >> 4) * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const u16x8_t*>(&Bs[((wn * TN + j) * 16 + (lane & 15)) * LDK + (lane >> 4) * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+    }
+
+    // epilogue: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M && col < g.N) {
+                    if (g.splitk > 1) {
+                        g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r];
+                        if (g.bias) v += g.bias[col];
+                        float* cp = C + (long long)row * g.ldc + col;
+                        if (g.beta != 0.f) v += g.beta * (*cp);
+                        *cp = apply_act(v, g.act);
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 VALU kernel (parity mode)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = 16;
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Bs[BK][BN + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)blockIdx.z * g.strideA;
+        B += (long long)blockIdx.z * g.strideB;
+        C += (long long)blockIdx.z * g.strideC;
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (g.ksA == 1) { k = tid & 15; m = (tid >> 4) + 16 * i; }
+            else            { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < g.M && gk < kend && !(g.mask_period > 0 && (gk % g.mask_period) == g.mask_skip))
+                v = A[(long long)gm * g.rsA + (long long)gk * g.ksA];
+            As[k][m] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int n, k;
+            if (g.ksB == 1) { k = tid & 15; n = (tid >> 4) + 16 * i; }
+            else            { n = tid & 63; k = (tid >> 6) + 4 * i; }
+            const int gn = n0 + n, gk = k0 + k;
+            float v = 0.f;
+            if (gn < g.N && gk < kend) v = B[(long long)gn * g.rsB + (long long)gk * g.ksB];
+            Bs[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = m0 + ty * 4 + i, col = n0 + tx * 4 + j;
+            if (row < g.M && col < g.N) {
+                if (g.splitk > 1) {
+                    g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j];
+                } else {
+                    float v = g.alpha * acc[i][j];
+                    if (g.bias) v += g.bias[col];
+                    float* cp = C + (long long)row * g.ldc + col;
+                    if (g.beta != 0.f) v += g.beta * (*cp);
+                    *cp = apply_act(v, g.act);
+                }
+            }
+        }
+}
+
+// fixed-order reduction of the split-K partials + epilogue
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int row = (int)(idx / g.N), col = (int)(idx % g.N);
+        float s = 0.f;
+        for (int z = 0; z < g.splitk; ++z) s += g.partial[(long long)z * total + idx];
+        float v = g.alpha * s;
+        if (g.bias) v += g.bias[col];
+        float* cp = g.C + (long long)row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        *cp = apply_act(v, g.act);
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_bf16(const GemmArgs& g, int zdim, hipStream_t st) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim);
+    hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN>), grid, dim3(WM * WN * 64), 0, st, g);
+    return 0;
+}
+
+extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                        int lda, long long strideA, const float* B, int ldb, long long strideB, float beta,
+                        float* C, int ldc, long long strideC, const float* bias, int act, int batch,
+                        int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(prec == LAS_PREC_F32 || prec == LAS_PREC_BF16, "las_gemm: bad prec %d", prec);
+    LAS_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "las_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    LAS_ARG(A && B && C, "las_gemm: null operand");
+    LAS_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "las_gemm: leading dimension too small");
+    LAS_ARG(a_mask_period == 0 || transA == 1, "las_gemm: a_mask_period needs transA=1");
+    LAS_ARG(act == LAS_ACT_NONE || act == LAS_ACT_TANH, "las_gemm: bad act %d", act);
+    if (M == 0 || N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.A = A; g.B = B; g.C = C; g.ldc = ldc;
+    g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+    g.rsA = transA ? 1 : lda;  g.ksA = transA ? lda : 1;
+    g.rsB = transB ? ldb : 1;  g.ksB = transB ? 1 : ldb;
+    g.bias = bias; g.act = act;
+    g.mask_period = a_mask_period; g.mask_skip = a_mask_skip;
+    g.vecA = ((lda % 4) == 0) && (((uintptr_t)A & 15) == 0) && ((strideA % 4) == 0);
+    g.vecB = ((ldb % 4) == 0) && (((uintptr_t)B & 15) == 0) && ((strideB % 4) == 0);
+    g.splitk = 1; g.kchunk = K; g.partial = nullptr;
+
+    // tile configuration
+    int BM, BN;
+    int cfg;
+    if (prec == LAS_PREC_F32) { cfg = 0; BM = 64; BN = 64; }
+    else if (M <= 48)         { cfg = 3; BM = 48; BN = 64; }
+    else if (M < 128 || N < 128) { cfg = 2; BM = 64; BN = 64; }
+    else                      { cfg = 1; BM = 128; BN = 128; }
+    const long long tiles = (long long)cdiv(M, BM) * cdiv(N, BN);
+
+    // deterministic split-K for tall contractions that would leave most of the 256 CUs idle
+    if (batch == 1 && ws && K >= 2048 && tiles < 256) {
+        int want = (int)((512 + tiles - 1) / tiles);
+        int maxs = K / 512;
+        int s = want < maxs ? want : maxs;
+        while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
+        if (s > 1) {
+            int kchunk = ((K + s - 1) / s + 31) / 32 * 32;
+            s = (K + kchunk - 1) / kchunk;
+            g.splitk = s; g.kchunk = kchunk; g.partial = (float*)ws;
+        }
+    }
+    const int zdim = g.splitk > 1 ? g.splitk : batch;
+
+    if (K == 0 && g.splitk == 1) {
+        // empty contraction: C = act(beta*C + bias); run the kernel with no k-tiles
+    }
+    switch (cfg) {
+        case 0: {
+            dim3 grid(cdiv(N, 64), cdiv(M, 64), zdim);
+            hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
+        } break;
+        case 1: launch_bf16<2, 2, 4, 4>(g, zdim, st); break;
+        case 2: launch_bf16<2, 2, 2, 2>(g, zdim, st); break;
+        default: launch_bf16<1, 4, 3, 1>(g, zdim, st); break;
+    }
+    LAS_LAUNCHED();
+    if (g.splitk > 1) {
+        int nb = cdiv((long long)M * N, 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, g);
+        LAS_LAUNCHED();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (BiasAdd gradient), deterministic two-stage
+// ------------------------------------------------------------------------------------------------
+constexpr int CS_SPLITS = 64;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int rows, int cols, int ldx,
+                                                             float* __restrict__ part, int nsplit) {
+    // block: 64 columns x 4 row lanes; blockIdx.y = row split
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int per = (rows + nsplit - 1) / nsplit;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + rl; r < r1; r += 4) s += X[(long long)r * ldx + c];
+    __shared__ float red[4][64];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols)
+        part[(long long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int cols, int nsplit, float beta,
+                                                           float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * cols + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+}
+
+extern "C" size_t las_colsum_workspace_bytes(int cols) { return (size_t)CS_SPLITS * cols * sizeof(float); }
+
+extern "C" int las_colsum(const float* X, int rows, int cols, int ldx, float beta, float* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+    LAS_ARG(X && out && rows >= 0 && cols > 0 && ldx >= cols, "las_colsum: bad arguments");
+    LAS_ARG(ws && ws_bytes >= las_colsum_workspace_bytes(cols), "las_colsum: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int nsplit = rows >= CS_SPLITS * 8 ? CS_SPLITS : 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), nsplit), dim3(256), 0, st, X, rows, cols, ldx,
+                       (float*)ws, nsplit);
+    LAS_LAUNCHED();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, cols, nsplit,
+                       beta, out);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tanh gradient
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ dY,
+                                                       int lddy, float* __restrict__ dX, int lddx, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long r = idx / cols;
+        const int c = (int)(idx % cols);
+        const float y = Y[r * ldy + c];
+        dX[r * lddx + c] = dY[r * lddy + c] * (1.f - y * y);
+    }
+}
+
+extern "C" int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, int lddx, int rows,
+                            int cols, void* stream) {
+    LAS_ARG(Y && dY && dX && rows >= 0 && cols >= 0, "las_tanh_bwd: bad arguments");
+    if (rows == 0 || cols == 0) return 0;
+    int nb = cdiv((long long)rows * cols, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Y, ldy, dY, lddy, dX, lddx, rows,
+                       cols);
+    LAS_LAUNCHED();
+    return 0;
+}

@@ -1,0 +1,84 @@
+// las_common.h -- shared device/host helpers for liblas_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/las_hip.h"
+
+// ---- error reporting (thread-local message, negative return codes) ----------------------------
+void las_set_error(const char* fmt, ...);
+
+#define LAS_ARG(cond, ...)                                   \
+    do { if (!(cond)) { las_set_error(__VA_ARGS__); return -1; } } while (0)
+#define LAS_HIP(expr)                                        \
+    do { hipError_t e__ = (expr);                            \
+         if (e__ != hipSuccess) { las_set_error("%s -> %s", #expr, hipGetErrorString(e__)); \
+                                  return (int)e__; } } while (0)
+#define LAS_LAUNCHED() LAS_HIP(hipGetLastError())
+
+// ---- vector types for MFMA --------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// fp32 -> bf16 bits, round to nearest even (finite inputs; NaN stays NaN-ish).
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// D = A(16x32 bf16) . B(32x16 bf16) + C.  Lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15],
+// C/D[(l>>4)*4+r][l&15]  (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x4_t mfma_bf16_16x16x32(u16x8_t a, u16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ---- activations --------------------------------------------------------------------------------
+// accurate forms (fp32 parity mode)
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
+// fast forms (speed mode): one v_exp + one v_rcp
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+template <bool FAST> __device__ __forceinline__ float sigm(float x) { return FAST ? sigmoid_fast(x) : sigmoid_acc(x); }
+template <bool FAST> __device__ __forceinline__ float tanhx(float x) { return FAST ? tanh_fast(x) : tanh_acc(x); }
+
+// ---- wave / block reductions (wave = 64) --------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x == NT (multiple of 64); red must hold NT/64 floats. All threads get the result.
+template <int NT> __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+template <int NT> __device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

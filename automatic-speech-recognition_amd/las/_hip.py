@@ -1,0 +1,165 @@
+"""ctypes binding of liblas_hip.so (the C ABI declared in include/las_hip.h).
+
+This is the only place the Python host code touches native code.  There is NO fallback: if the
+shared library is missing or a call fails, a RuntimeError is raised (the product path never
+routes through the CPU oracle).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t,
+                    c_void_p)
+
+import torch
+
+PREC_F32, PREC_BF16 = 0, 1
+CELL_RNN, CELL_LSTM = 0, 1
+ACT_NONE, ACT_TANH = 0, 1
+ATT_ADD, ATT_LOC = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblas_hip.so")
+_lib = None
+
+
+class SpellerFwdArgs(Structure):
+    _fields_ = [(n, c_int) for n in ("B", "Tp", "Hd", "A", "D", "NL", "E", "V", "U", "cell", "mode", "prec", "Kc", "C")] + [
+        ("enc", c_void_p), ("keys", c_void_p), ("enc_len", c_void_p),
+        ("Ws", c_void_p), ("u", c_void_p), ("emb", c_void_p), ("Wv", c_void_p), ("bv", c_void_p),
+        ("loc_w", c_void_p), ("loc_b", c_void_p), ("Wf", c_void_p),
+        ("cellW", POINTER(c_void_p)), ("cellb", POINTER(c_void_p)),
+        ("tokens_in", c_void_p), ("tokens_out", c_void_p),
+        ("logits", c_void_p), ("alphas", c_void_p),
+        ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("ctx", c_void_p), ("xin0", c_void_p),
+        ("ws", c_void_p), ("ws_bytes", c_size_t)]
+
+
+class SpellerBwdArgs(Structure):
+    _fields_ = [("f", SpellerFwdArgs), ("dlogits", c_void_p),
+                ("d_enc", c_void_p), ("d_keys", c_void_p), ("dWs", c_void_p), ("du", c_void_p),
+                ("demb", c_void_p), ("dWv", c_void_p), ("dbv", c_void_p),
+                ("dloc_w", c_void_p), ("dloc_b", c_void_p), ("dWf", c_void_p),
+                ("dcellW", POINTER(c_void_p)), ("dcellb", POINTER(c_void_p))]
+
+
+_SIGS = {
+    "las_version": (c_int, []),
+    "las_last_error": (c_char_p, []),
+    "las_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_longlong,
+                         c_void_p, c_int, c_longlong, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
+                         c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_colsum_workspace_bytes": (c_size_t, [c_int]),
+    "las_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "las_tanh_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "las_rnn_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "las_rnn_seq_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int, c_longlong, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "las_rnn_seq_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
+                                c_float, c_void_p, c_size_t, c_void_p]),
+    "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
+    "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
+    "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
+    "las_ce_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                            c_void_p, c_void_p]),
+    "las_sumsq_workspace_bytes": (c_size_t, [c_longlong]),
+    "las_sumsq": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
+                              c_float, c_float, c_float, c_void_p]),
+    "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load liblas_hip.so once; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liblas_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C automatic-speech-recognition_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        missing = []
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name, None)
+            if fn is None:
+                missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        if missing and not os.environ.get("LAS_ALLOW_PARTIAL"):
+            raise RuntimeError("liblas_hip.so does not export: %s" % ", ".join(missing))
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().las_last_error()
+        raise RuntimeError("liblas_hip %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("las HIP path needs tensors on a ROCm device (got %s); there is no CPU fallback"
+                               % t.device)
+
+
+def p(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# thin typed wrappers
+# ------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def workspace(dev, nbytes, tag="default"):
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (str(dev), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+GEMM_WS_BYTES = 256 << 20
+
+
+def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
+         alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, batch=1, strideA=0, strideB=0, strideC=0,
+         mask_period=0, mask_skip=0, a_off=0, b_off=0, c_off=0):
+    """C = act(alpha * op(A).op(B) + beta*C + bias).  A,B,C are fp32 tensors; *_off are element offsets."""
+    require_gpu(A, B, C, bias)
+    ws = workspace(C.device, GEMM_WS_BYTES, "gemm")
+    rc = lib().las_gemm(prec, int(transA), int(transB), M, N, K, alpha,
+                        c_void_p(A.data_ptr() + 4 * a_off), lda, strideA,
+                        c_void_p(B.data_ptr() + 4 * b_off), ldb, strideB, beta,
+                        c_void_p(C.data_ptr() + 4 * c_off), ldc, strideC, p(bias), act, batch,
+                        mask_period, mask_skip, p(ws), ws.numel(), stream())
+    check(rc, "las_gemm")
+
+
+def colsum(X, rows, cols, ldx, out, beta=0.0, x_off=0):
+    require_gpu(X, out)
+    nb = lib().las_colsum_workspace_bytes(cols)
+    ws = workspace(X.device, nb, "colsum")
+    check(lib().las_colsum(c_void_p(X.data_ptr() + 4 * x_off), rows, cols, ldx, beta, p(out), p(ws), ws.numel(),
+                           stream()), "las_colsum")
+
+
+def tanh_bwd(Y, ldy, dY, lddy, dX, lddx, rows, cols):
+    require_gpu(Y, dY, dX)
+    check(lib().las_tanh_bwd(p(Y), ldy, p(dY), lddy, p(dX), lddx, rows, cols, stream()), "las_tanh_bwd")

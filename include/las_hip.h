@@ -1,0 +1,186 @@
+/* las_hip.h -- C ABI of liblas_hip.so, the MI355X (gfx950) engine behind the LAS hot path.
+ *
+ * The reference (30stomercury/Automatic-Speech-Recognition) has no FFI: its hot path sits
+ * behind the TensorFlow session boundary  sess.run(fetches, feed_dict)  (train.py:115-117,
+ * test.py:107, las/beam_search.py:209,222).  This header is what replaces that boundary: each
+ * entry point names the reference graph fragment (file:line) whose stock TF ops it stands in for.
+ *
+ * Conventions
+ *   - extern "C"; raw DEVICE pointers owned by the caller; the library never allocates or frees
+ *     caller tensors.  Scratch is passed in explicitly (ws, ws_bytes), sized by *_workspace_bytes.
+ *   - every dimension / leading dimension is an explicit int; tensors are fp32 in HBM, row-major,
+ *     batch-major [B,T,C] exactly as the reference lays them out (time_major=False,
+ *     las/layers.py:24,53).  Weights keep the TF layout [in,out] with the [x;h] row concat and
+ *     gate order i,j,f,o.
+ *   - `prec` selects the arithmetic of the contractions:  LAS_PREC_F32 = exact fp32 FMA chains
+ *     (parity mode), LAS_PREC_BF16 = operands rounded to bf16 (RNE), fp32 MFMA accumulation
+ *     (speed mode).  State, activations, gradients and optimiser math are always fp32.
+ *   - `stream` is a hipStream_t (passed as void*); all work is enqueued asynchronously on it,
+ *     no hidden synchronisation, no global mutable state besides an init-once attribute cache.
+ *   - return value: 0 ok; <0 invalid argument / unsupported shape (message via las_last_error());
+ *     >0 a hipError_t.
+ */
+#ifndef LAS_HIP_H
+#define LAS_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LAS_PREC_F32 = 0, LAS_PREC_BF16 = 1 };
+enum { LAS_CELL_RNN = 0, LAS_CELL_LSTM = 1 };   /* BasicRNNCell (las/layers.py:31) / BasicLSTMCell */
+enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
+enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
+
+int         las_version(void);
+const char* las_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K3/K4  dense contractions  (tf.layers.dense / Tensordot->MatMul+BiasAdd(+Tanh):
+ * las/layers.py:71-74, :89-93, :250-251, :305; the input half of the cell MatMul las/layers.py:31;
+ * and every matmul gradient of those ops).
+ *   C[b] = act( alpha * op(A[b]) . op(B[b]) + beta * C[b] + bias )      b = 0..batch-1
+ * op(A) is M x K, op(B) is K x N.  transX=0: X stored row-major as written; transX=1: stored
+ * transposed (A as K x M, B as N x K).  bias (length N) may be NULL.
+ * a_mask_period > 0: logical rows r of the CONTRACTION index of a transA=1 product with
+ * (r % a_mask_period) == a_mask_skip contribute zero -- used for dW_hh = sum_t h_{t-1}^T dG_t where
+ * the t=0 (fw) / t=T-1 (bw) frame has no predecessor inside its utterance.
+ * ws (optional, may be NULL): scratch for a deterministic split-K of tall contractions
+ * (partials [s][M][N] reduced in fixed order); without it the product runs unsplit.
+ */
+int las_gemm(int prec, int transA, int transB, int M, int N, int K,
+             float alpha, const float* A, int lda, long long strideA,
+             const float* B, int ldb, long long strideB,
+             float beta, float* C, int ldc, long long strideC,
+             const float* bias, int act, int batch,
+             int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream);
+
+/* out[j] = beta*out[j] + sum_r X[r*ldx + j],  r < rows, j < cols   (BiasAdd gradient);
+ * fixed-order two-stage reduction, ws >= las_colsum_workspace_bytes(cols). */
+size_t las_colsum_workspace_bytes(int cols);
+int las_colsum(const float* X, int rows, int cols, int ldx, float beta, float* out,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* dX = dY * (1 - Y*Y)   elementwise over rows x cols (Tanh gradient of dense(.., tanh)). */
+int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, int lddx,
+                 int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2/K2b  recurrent sweep of one bidirectional layer
+ * (tf.nn.bidirectional_dynamic_rnn without sequence_length, las/layers.py:49-53: every padded
+ * frame is run; zero initial state; bw runs t=T-1..0).
+ *
+ * gates : [B,T,2,G*H]  (G=1 rnn, 4 lstm; dir 0 = fw, 1 = bw).
+ *         fwd in : x_t . W_ih + bias (the K1 product).   fwd out (lstm): activated i,j,f,o.
+ *         bwd in : what fwd left.                        bwd out: d(pre-activation) for K1's bwd.
+ * whh_* : [H, G*H] recurrent half of the TF kernel (row stride ldw).
+ * out   : h for both directions, element (b,t,dir*H+u) at out[b*out_bstride + t*ld_out + dir*H + u]
+ *         (ld_out = 2H; out_bstride lets the caller keep a zero pad frame per utterance so the
+ *         pyramid concat of las/layers.py:83-88 is a pure view).
+ * cstate: lstm only, [B,T,2,H] cell states (saved for bwd).
+ * dout  : gradient w.r.t. out, same addressing scheme.
+ */
+size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H);
+int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates,
+                    const float* whh_fw, const float* whh_bw, int ldw,
+                    float* out, int ld_out, long long out_bstride, float* cstate,
+                    float forget_bias, void* ws, size_t ws_bytes, void* stream);
+int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates,
+                    const float* whh_fw, const float* whh_bw, int ldw,
+                    const float* out, int ld_out, long long out_bstride, const float* cstate,
+                    const float* dout, int ld_dout, long long dout_bstride,
+                    float forget_bias, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4-K7  Speller: the whole decode loop of Speller.__call__ (las/las.py:72-143) with
+ * Speller.decode (las/las.py:145-160), AdditiveAttention / LocationAwareAttention
+ * (las/layers.py:234-257 / :281-311), BaseAttention.mask/attend (las/layers.py:172-213).
+ * One call enqueues all U steps.  All pointers device.  Layouts:
+ *   enc   [B,Tp,Hd]   encoder output h           keys [B,Tp,A]  hoisted dense(hidden) (K4, las_gemm)
+ *   enc_len int32 [B] (already int-cast as las/layers.py:193 does)
+ *   Ws [S,A] (S=D*NL)  u [A]   emb [V,E]   Wv [D,V]  bv [V]
+ *   loc_w [Kc,C], loc_b [C], Wf [C,A] (mode LOC only, else NULL)
+ *   cellW[l] [(I_l+D), G*D], cellb[l] [G*D]  with I_0 = E+Hd, I_l = D   (device pointer arrays
+ *   passed as HOST arrays of device pointers)
+ *   tokens_in int32 [U,B]: the token whose embedding enters step t  (t=0: SOS; teacher forcing:
+ *   teacher[:,t-1]; scheduled sampling las/las.py:101-105 resolved by the caller or, where
+ *   tokens_in[t][b] < 0, by this call: greedy argmax of step t-1 (inference, las/las.py:111)).
+ * Saved for backward (caller-allocated):
+ *   hs  [NL,U+1,B,D]  h states (slot 0 = zero state)    cs [NL,U+1,B,D] (lstm)
+ *   gates [NL,U,B,G*D] activated gates (lstm) / unused (rnn: h is enough)
+ *   ctx [U,B,Hd]   xin0 [U,B,E+Hd+D]  first-layer cell input rows
+ * Outputs: logits [B,U,V], alphas [B,U,Tp], tokens_out int32 [U,B] = argmax of each step.
+ */
+typedef struct {
+    int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C;
+    const float *enc, *keys; const int* enc_len;
+    const float *Ws, *u, *emb, *Wv, *bv, *loc_w, *loc_b, *Wf;
+    const float* const* cellW; const float* const* cellb;   /* host arrays [NL] of device ptrs */
+    int* tokens_in; int* tokens_out;
+    float *logits, *alphas;
+    float *hs, *cs, *gates, *ctx, *xin0;
+    void* ws; size_t ws_bytes;
+} las_speller_fwd_args;
+size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
+int las_speller_fwd(const las_speller_fwd_args* a, void* stream);
+
+/* Backward of the loop above for teacher-forced / externally sampled tokens (gradients do not flow
+ * through the sampled token, as in tf.distributions.Categorical.sample, las/las.py:170-175).
+ *   dlogits [B,U,V] in.   Accumulates (+=) into the caller-zeroed gradient buffers:
+ *   d_enc [B,Tp,Hd], d_keys [B,Tp,A], dWs, du, demb [V,E], dWv, dbv, dcellW[l], dcellb[l],
+ *   dloc_w, dloc_b, dWf.
+ */
+typedef struct {
+    las_speller_fwd_args f;           /* the forward arguments, with saved buffers filled in */
+    const float* dlogits;
+    float *d_enc, *d_keys, *dWs, *du, *demb, *dWv, *dbv, *dloc_w, *dloc_b, *dWf;
+    float* const* dcellW; float* const* dcellb;              /* host arrays [NL] of device ptrs */
+} las_speller_bwd_args;
+int las_speller_bwd(const las_speller_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K8  LAS._get_loss (las/las.py:320-333) + label_smoothing (las/utils.py:5-12), forward and
+ * gradient in one pass.  logits [B,U,V] (row stride V), y int32 [B,ldy] (first U columns used).
+ * sums[0] += sum(ce*mask), sums[1] += sum(mask)   (caller zeroes sums; the division
+ * sum/(n+1e-9) is the caller's so that data-parallel ranks can all-reduce both terms first).
+ * dlogits = scale_ptr[0] * mask * (softmax - smoothed_onehot)    (scale = 1/(n_total+1e-9), a
+ * device scalar; NULL dlogits skips the gradient).
+ */
+int las_ce_loss(const float* logits, const int* y, int ldy, int B, int U, int V, float epsilon,
+                float* sums, const float* scale_ptr, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9  tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients (las/las.py:272-283) on one
+ * flat fp32 parameter bucket.  las_sumsq: out[0] = sum g^2 (deterministic two-stage reduction;
+ * ws >= las_sumsq_workspace_bytes(n)).  las_clip_adam: theta,m,v updated in place;
+ * g *= clip/max(sqrt(sumsq[0]),clip) when clip>0;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
+ * caller;  theta -= lr_t * m / (sqrt(v) + eps)   (TF "epsilon-hat" placement).
+ */
+size_t las_sumsq_workspace_bytes(long long n);
+int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream);
+int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
+                  const float* sumsq, float clip, float lr_t, float beta1, float beta2, float eps,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K10  one pruning step of BeamSearch.decode (las/beam_search.py:119-152, :297-312) for `nutt`
+ * utterances at once.  Per utterance: nlive live hypotheses, logits [nlive,V] (raw logits are the
+ * scores, las/beam_search.py:123-124); expansion of each hypothesis to its top `topn` tokens
+ * (ascending, np.argsort(...)[-64:]), SOS skipped after t=0, only hypothesis 0 expanded at t=0;
+ * candidates ranked by (score+logit)/len (len = tokens after SOS incl. the new one), best
+ * `beam` kept in ascending order (ties: lower candidate index first, the stable order).
+ *   logits   [nutt, beam, V]      score f64 [nutt, beam]   length int32 [nutt, beam]
+ *   nlive int32 [nutt]            t: step index
+ * Outputs per utterance, ascending by normalised score, count in out_n[nutt]:
+ *   out_parent int32 [nutt,beam], out_token int32 [nutt,beam], out_score f64 [nutt,beam]
+ */
+int las_beam_step(const float* logits, const double* score, const int* length, const int* nlive,
+                  int nutt, int beam, int V, int topn, int t, int start_id,
+                  int* out_parent, int* out_token, double* out_score, int* out_n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAS_HIP_H */

@@ -1,0 +1,92 @@
+"""K1/K3/K4 parity: las_gemm (C ABI) vs an fp64 torch-CPU contraction of the same operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(A, B, tA, tB, alpha, beta, C0, bias, act, mask_period=0, mask_skip=0):
+    a = A.double().cpu()
+    b = B.double().cpu()
+    a = a.transpose(-1, -2) if tA else a
+    b = b.transpose(-1, -2) if tB else b
+    if mask_period:
+        K = a.shape[-1]
+        keep = torch.tensor([(k % mask_period) != mask_skip for k in range(K)], dtype=torch.float64)
+        a = a * keep
+    r = alpha * (a @ b)
+    if beta:
+        r = r + beta * C0.double().cpu()
+    if bias is not None:
+        r = r + bias.double().cpu()
+    if act:
+        r = torch.tanh(r)
+    return r
+
+
+CASES = [
+    # M, N, K, tA, tB
+    (48, 64, 39, 0, 0), (130, 70, 100, 0, 0), (256, 256, 512, 0, 0), (300, 512, 64, 0, 1),
+    (512, 1024, 3000, 1, 0), (128, 30, 512, 0, 0), (48, 2048, 1152, 0, 0), (48, 1152, 2048, 0, 1),
+    (39, 256, 2500, 1, 0), (7, 5, 3, 0, 0), (1, 128, 64, 0, 0), (200, 200, 33, 1, 1),
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("case", CASES)
+def test_gemm_matches_fp64(prec, case):
+    from las import _hip
+    M, N, K, tA, tB = case
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).cuda()
+    B = torch.randn((N, K) if tB else (K, N), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+    C = C0.clone()
+    act = 1 if (M + N) % 2 else 0
+    scale = 1.0 / (K ** 0.5) if act else 1.0
+    _hip.gemm(prec, A, B, C, bool(tA), bool(tB), M, N, K, A.shape[1], B.shape[1], N,
+              alpha=scale, beta=0.5, bias=bias, act=act)
+    ref = _ref(A, B, tA, tB, scale, 0.5, C0, bias, act)
+    err = (C.double().cpu() - ref).abs().max().item()
+    mag = ref.abs().max().item() + 1e-9
+    # tolerance: fp32 FMA chains ~1e-6*sqrt(K); bf16 operands ~ 2^-9 relative per product
+    tol = (2e-5 if prec == 0 else 2e-2) * max(1.0, mag)
+    assert err < tol, (case, prec, err, mag)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_gemm_batched_strided_and_mask(prec):
+    from las import _hip
+    g = torch.Generator().manual_seed(5)
+    # batched TN:  C[b] = A[b]^T . B[b]   A [bt, K, M], B [bt, K, N]
+    bt, K, M, N = 5, 70, 96, 40
+    A = torch.randn(bt, K, M, generator=g).cuda()
+    B = torch.randn(bt, K, N, generator=g).cuda()
+    C = torch.zeros(bt, M, N).cuda()
+    _hip.gemm(prec, A, B, C, True, False, M, N, K, M, N, N, batch=bt, strideA=K * M, strideB=K * N, strideC=M * N)
+    ref = A.double().cpu().transpose(1, 2) @ B.double().cpu()
+    assert (C.double().cpu() - ref).abs().max().item() < (1e-4 if prec == 0 else 0.3)
+    # masked TN with element offsets (the dW_hh form): rows k with k % 10 == 0 dropped
+    K, M, N = 4000, 64, 128
+    A = torch.randn(K + 1, M, generator=g).cuda()
+    B = torch.randn(K, N, generator=g).cuda()
+    C = torch.zeros(M, N).cuda()
+    _hip.gemm(prec, A, B, C, True, False, M, N, K, M, N, N, mask_period=10, mask_skip=0, a_off=0)
+    ref = _ref(A[:K], B, 1, 0, 1.0, 0.0, None, None, 0, 10, 0)
+    assert (C.double().cpu() - ref).abs().max().item() < (1e-3 if prec == 0 else 2.0)
+
+
+def test_colsum_and_tanh_bwd():
+    from las import _hip
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(5000, 300, generator=g).cuda()
+    out = torch.ones(300).cuda()
+    _hip.colsum(X, 5000, 300, 300, out, beta=2.0)
+    ref = 2.0 + X.double().cpu().sum(0)
+    assert (out.double().cpu() - ref).abs().max().item() < 1e-3
+    Y = torch.tanh(torch.randn(77, 130, generator=g)).cuda()
+    dY = torch.randn(77, 130, generator=g).cuda()
+    dX = torch.empty_like(Y)
+    _hip.tanh_bwd(Y, 130, dY, 130, dX, 130, 77, 130)
+    assert torch.allclose(dX.cpu(), (dY * (1 - Y * Y)).cpu(), atol=1e-6)
