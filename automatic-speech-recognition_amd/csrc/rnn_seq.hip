@@ -1,0 +1,620 @@
+// rnn_seq.hip -- K2 / K2b: the recurrent sweep of one bidirectional layer, forward and BPTT.
+//
+// Replaces tf.nn.bidirectional_dynamic_rnn's per-step while-loop (reference las/layers.py:49-53,
+// cell las/layers.py:31) -- ~6 tiny TF kernels per time step -- by ONE persistent launch per layer:
+// a workgroup owns (direction, batch tile) for all T steps, h/c never leave the CU (LDS + VGPRs),
+// the input projection x.W_ih+b was hoisted into one big K1 GEMM and arrives through `gates`.
+//
+//   LAS_PREC_F32 : fp32 FMA chains on the VALU, any H (parity mode).  Thread = hidden unit,
+//                  8 batch rows per workgroup, h broadcast from LDS, W_hh streamed from L2.
+//   LAS_PREC_BF16: v_mfma_f32_16x16x32_bf16.  16 batch rows per workgroup (one MFMA M-tile),
+//                  4 waves x 64 hidden units; every wave owns all G gates of its units so the gate
+//                  nonlinearity is lane-local on the accumulator layout.  W_hh is pre-packed into
+//                  MFMA B-fragment order (1 KiB contiguous per wave-load); as many fragments as fit
+//                  stay resident in LDS for the whole sweep, the rest stream from L2 each step.
+//                  Next step's x-projection is prefetched under the current step's MFMAs.
+// No grid barrier, no inter-workgroup traffic: directions and batch tiles are independent.
+#include "las_common.h"
+
+struct RnnArgs {
+    int B, T, H;
+    float* gates;
+    const float* whh[2];
+    int ldw;
+    float* out; int ld_out; long long obs;
+    float* cstate;
+    const float* dout; int ld_dout; long long dobs;
+    float fb;
+    const void* wpack;
+};
+
+// ------------------------------------------------------------------------------------------------
+// fp32 VALU kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int F32_BT = 8;    // batch rows per workgroup
+constexpr int F32_UPT = 4;   // hidden units per thread (H <= 1024)
+
+template <int CELL>
+__global__ __launch_bounds__(256) void rnn_seq_fwd_f32_kernel(RnnArgs a) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    constexpr int BT = F32_BT, UPT = F32_UPT;
+    extern __shared__ __attribute__((aligned(16))) float hs[];  // [H][BT]
+    const int tid = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * BT;
+    const int H = a.H, T = a.T, B = a.B, GH = G * H;
+    const float* __restrict__ W = a.whh[dir];
+    float cst[UPT][BT];
+#pragma unroll
+    for (int ui = 0; ui < UPT; ++ui)
+#pragma unroll
+        for (int r = 0; r < BT; ++r) cst[ui][r] = 0.f;
+    for (int i = tid; i < H * BT; i += 256) hs[i] = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        float hnew[UPT][BT];
+#pragma unroll
+        for (int ui = 0; ui < UPT; ++ui) {
+            const int u = tid + ui * 256;
+#pragma unroll
+            for (int r = 0; r < BT; ++r) hnew[ui][r] = 0.f;
+            if (u < H) {
+                float acc[G][BT];
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int r = 0; r < BT; ++r) acc[q][r] = 0.f;
+                for (int k = 0; k < H; ++k) {
+                    float w[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) w[q] = W[(long long)k * a.ldw + q * H + u];
+                    const float4 h0 = *reinterpret_cast<const float4*>(&hs[k * BT]);
+                    const float4 h1 = *reinterpret_cast<const float4*>(&hs[k * BT + 4]);
+                    const float hk[BT] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+#pragma unroll
+                        for (int r = 0; r < BT; ++r) acc[q][r] = fmaf(hk[r], w[q], acc[q][r]);
+                }
+#pragma unroll
+                for (int r = 0; r < BT; ++r) {
+                    const int b = b0 + r;
+                    if (b < B) {
+                        const long long fr = ((long long)b * T + t) * 2 + dir;
+                        float* gp = a.gates + fr * GH + u;
+                        float h;
+                        if (CELL == LAS_CELL_LSTM) {
+                            const float gi = sigmoid_acc(acc[0][r] + gp[0]);
+                            const float gj = tanh_acc(acc[G > 1 ? 1 : 0][r] + gp[H]);
+                            const float gf = sigmoid_acc(acc[G > 2 ? 2 : 0][r] + gp[2 * H] + a.fb);
+                            const float go = sigmoid_acc(acc[G > 3 ? 3 : 0][r] + gp[3 * H]);
+                            const float c = cst[ui][r] * gf + gi * gj;
+                            h = tanh_acc(c) * go;
+                            cst[ui][r] = c;
+                            gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                            a.cstate[fr * H + u] = c;
+                        } else {
+                            h = tanh_acc(acc[0][r] + gp[0]);
+                        }
+                        a.out[(long long)b * a.obs + (long long)t * a.ld_out + dir * H + u] = h;
+                        hnew[ui][r] = h;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every thread is done reading h_{t-1}
+#pragma unroll
+        for (int ui = 0; ui < UPT; ++ui) {
+            const int u = tid + ui * 256;
+            if (u < H) {
+                *reinterpret_cast<float4*>(&hs[u * BT]) = make_float4(hnew[ui][0], hnew[ui][1], hnew[ui][2], hnew[ui][3]);
+                *reinterpret_cast<float4*>(&hs[u * BT + 4]) = make_float4(hnew[ui][4], hnew[ui][5], hnew[ui][6], hnew[ui][7]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// BPTT.  a.wpack = W_hh^T as fp32 [2][G*H][H] (coalesced over the output unit).
+template <int CELL>
+__global__ __launch_bounds__(256) void rnn_seq_bwd_f32_kernel(RnnArgs a) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    constexpr int BT = F32_BT, UPT = F32_UPT;
+    extern __shared__ __attribute__((aligned(16))) float dps[];  // [G*H][BT]
+    const int tid = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * BT;
+    const int H = a.H, T = a.T, B = a.B, GH = G * H;
+    const float* __restrict__ WT = reinterpret_cast<const float*>(a.wpack) + (long long)dir * GH * H;
+    float dhr[UPT][BT], dcc[UPT][BT];
+#pragma unroll
+    for (int ui = 0; ui < UPT; ++ui)
+#pragma unroll
+        for (int r = 0; r < BT; ++r) { dhr[ui][r] = 0.f; dcc[ui][r] = 0.f; }
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;          // reverse of the forward order
+        const int tp = dir ? t + 1 : t - 1;         // the step that ran before t in the forward sweep
+        const bool hasp = tp >= 0 && tp < T;
+#pragma unroll
+        for (int ui = 0; ui < UPT; ++ui) {
+            const int u = tid + ui * 256;
+            if (u < H) {
+#pragma unroll
+                for (int r = 0; r < BT; ++r) {
+                    const int b = b0 + r;
+                    float dz[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) dz[q] = 0.f;
+                    if (b < B) {
+                        const long long fr = ((long long)b * T + t) * 2 + dir;
+                        const float dh = a.dout[(long long)b * a.dobs + (long long)t * a.ld_dout + dir * H + u] + dhr[ui][r];
+                        float* gp = a.gates + fr * GH + u;
+                        if (CELL == LAS_CELL_LSTM) {
+                            const float gi = gp[0], gj = gp[H], gf = gp[2 * H], go = gp[3 * H];
+                            const float c = a.cstate[fr * H + u];
+                            const float cp = hasp ? a.cstate[(((long long)b * T + tp) * 2 + dir) * H + u] : 0.f;
+                            const float tc = tanh_acc(c);
+                            const float dc = dcc[ui][r] + dh * go * (1.f - tc * tc);
+                            dcc[ui][r] = dc * gf;
+                            dz[0] = dc * gj * gi * (1.f - gi);
+                            dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
+                            dz[G > 2 ? 2 : 0] = dc * cp * gf * (1.f - gf);
+                            dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
+                        } else {
+                            const float h = a.out[(long long)b * a.obs + (long long)t * a.ld_out + dir * H + u];
+                            dz[0] = dh * (1.f - h * h);
+                        }
+#pragma unroll
+                        for (int q = 0; q < G; ++q) gp[q * H] = dz[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < G; ++q) dps[(q * H + u) * BT + r] = dz[q];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ui = 0; ui < UPT; ++ui) {
+            const int u = tid + ui * 256;
+            if (u < H) {
+                float acc[BT];
+#pragma unroll
+                for (int r = 0; r < BT; ++r) acc[r] = 0.f;
+                for (int col = 0; col < GH; ++col) {
+                    const float w = WT[(long long)col * H + u];
+                    const float4 d0 = *reinterpret_cast<const float4*>(&dps[col * BT]);
+                    const float4 d1 = *reinterpret_cast<const float4*>(&dps[col * BT + 4]);
+                    acc[0] = fmaf(d0.x, w, acc[0]); acc[1] = fmaf(d0.y, w, acc[1]);
+                    acc[2] = fmaf(d0.z, w, acc[2]); acc[3] = fmaf(d0.w, w, acc[3]);
+                    acc[4] = fmaf(d1.x, w, acc[4]); acc[5] = fmaf(d1.y, w, acc[5]);
+                    acc[6] = fmaf(d1.z, w, acc[6]); acc[7] = fmaf(d1.w, w, acc[7]);
+                }
+#pragma unroll
+                for (int r = 0; r < BT; ++r) dhr[ui][r] = acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_whh_kernel(const float* W0, const float* W1, int ldw, int H, int GH,
+                                                            float* out) {
+    const long long total = 2LL * GH * H;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int u = (int)(idx % H);
+        const int col = (int)((idx / H) % GH);
+        const int dir = (int)(idx / ((long long)H * GH));
+        const float* W = dir ? W1 : W0;
+        out[idx] = W[(long long)u * ldw + col];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int CELL, int UT>
+struct RnnCfg {
+    static constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    static constexpr int H = UT * 64, GH = G * H;
+    static constexpr int KS = H / 32;            // k-steps of the forward product (K = H)
+    static constexpr int NFW = G * UT * KS;      // B fragments per wave, forward
+    static constexpr int LDH = H + 8;            // bf16 row pitch of the h tile
+    static constexpr int HS_BYTES = 2 * 16 * LDH * 2;
+    static constexpr int LF = cmin(NFW, (150 * 1024 - HS_BYTES) / 4096);   // fragments/wave resident in LDS
+    static constexpr int KSB = GH / 32;          // k-steps of the backward product (K = G*H)
+    static constexpr int NFB = UT * KSB;
+    static constexpr int LDG = GH + 8;
+    static constexpr int DP_BYTES = 2 * 16 * LDG * 2;
+    static constexpr int LFB = cmax(0, cmin(NFB, (150 * 1024 - DP_BYTES) / 4096));
+    static constexpr int FWD_LDS = HS_BYTES + 4 * LF * 1024;
+    static constexpr int BWD_LDS = DP_BYTES + 4 * LFB * 1024;
+};
+
+template <int CELL, int UT>
+__global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
+    using C = RnnCfg<CELL, UT>;
+    constexpr int G = C::G, H = C::H, GH = C::GH, KS = C::KS, NFW = C::NFW, LDH = C::LDH, LF = C::LF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* hs = reinterpret_cast<unsigned short*>(smem);               // [2][16][LDH]
+    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::HS_BYTES);               // [4][LF][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16, T = a.T, B = a.B;
+    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 + w) * NFW * 64;
+
+#pragma unroll 4
+    for (int fi = 0; fi < LF; ++fi) wl[(w * LF + fi) * 64 + lane] = Wp[fi * 64 + lane];
+    for (int i = tid; i < 16 * LDH; i += 256) hs[i] = 0;
+    __syncthreads();
+
+    long long rowoff[4];
+    bool rv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + g * 4 + r;
+        rv[r] = b < B;
+        rowoff[r] = (long long)(b < B ? b : B - 1);
+    }
+    float cst[UT][4];
+#pragma unroll
+    for (int j = 0; j < UT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
+
+    float xn[G][UT][4];
+    {
+        const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < UT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xn[q][j][r] = a.gates[((rowoff[r] * T + t0) * 2 + dir) * GH + q * H + w * (16 * UT) + j * 16 + c];
+    }
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        float xc[G][UT][4];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < UT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xc[q][j][r] = xn[q][j][r];
+        if (s + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int j = 0; j < UT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        xn[q][j][r] = a.gates[((rowoff[r] * T + tn) * 2 + dir) * GH + q * H + w * (16 * UT) + j * 16 + c];
+        }
+        f32x4_t acc[G][UT];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < UT; ++j) acc[q][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const unsigned short* hcur = hs + cur * 16 * LDH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int j = 0; j < UT; ++j) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int fi = (q * UT + j) * KS + ks;
+                    const u16x8_t bv = fi < LF ? wl[(w * LF + fi) * 64 + lane] : Wp[fi * 64 + lane];
+                    acc[q][j] = mfma_bf16_16x16x32(av, bv, acc[q][j]);
+                }
+        }
+        unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
+#pragma unroll
+        for (int j = 0; j < UT; ++j) {
+            const int unit = w * (16 * UT) + j * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float h;
+                const long long fr = (rowoff[r] * T + t) * 2 + dir;
+                if (CELL == LAS_CELL_LSTM) {
+                    const float gi = sigm<true>(acc[0][j][r] + xc[0][j][r]);
+                    const float gj = tanhx<true>(acc[G > 1 ? 1 : 0][j][r] + xc[G > 1 ? 1 : 0][j][r]);
+                    const float gf = sigm<true>(acc[G > 2 ? 2 : 0][j][r] + xc[G > 2 ? 2 : 0][j][r] + a.fb);
+                    const float go = sigm<true>(acc[G > 3 ? 3 : 0][j][r] + xc[G > 3 ? 3 : 0][j][r]);
+                    const float cc = cst[j][r] * gf + gi * gj;
+                    cst[j][r] = cc;
+                    h = tanhx<true>(cc) * go;
+                    if (rv[r]) {
+                        float* gp = a.gates + fr * GH + unit;
+                        gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+                        a.cstate[fr * H + unit] = cc;
+                    }
+                } else {
+                    h = tanhx<true>(acc[0][j][r] + xc[0][j][r]);
+                }
+                hnext[(g * 4 + r) * LDH + unit] = f2bf(h);
+                if (rv[r]) a.out[rowoff[r] * a.obs + (long long)t * a.ld_out + dir * H + unit] = h;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int CELL, int UT>
+__global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
+    using C = RnnCfg<CELL, UT>;
+    constexpr int G = C::G, H = C::H, GH = C::GH, KSB = C::KSB, NFB = C::NFB, LDG = C::LDG, LFB = C::LFB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* dps = reinterpret_cast<unsigned short*>(smem);              // [2][16][LDG]
+    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::DP_BYTES);               // [4][LFB][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16, T = a.T, B = a.B;
+    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 + w) * NFB * 64;
+
+#pragma unroll 4
+    for (int fi = 0; fi < LFB; ++fi) wl[(w * LFB + fi) * 64 + lane] = Wp[fi * 64 + lane];
+
+    long long rowoff[4];
+    bool rv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + g * 4 + r;
+        rv[r] = b < B;
+        rowoff[r] = (long long)(b < B ? b : B - 1);
+    }
+    f32x4_t dhr[UT];
+    float dcc[UT][4];
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+        dhr[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dcc[j][r] = 0.f;
+    }
+
+    // per-step operands (prefetched one step ahead): dout, activated gates, c_t, c_prev  |  h_t (rnn)
+    constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
+    float n_do[UT][4], n_g[NG][UT][4], n_c[UT][4], n_cp[UT][4];
+    auto load_step = [&](int t) {
+        const int tp = dir ? t + 1 : t - 1;
+        const bool hasp = tp >= 0 && tp < T;
+#pragma unroll
+        for (int j = 0; j < UT; ++j) {
+            const int unit = w * (16 * UT) + j * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long fr = (rowoff[r] * T + t) * 2 + dir;
+                n_do[j][r] = a.dout[rowoff[r] * a.dobs + (long long)t * a.ld_dout + dir * H + unit];
+                if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) n_g[q][j][r] = a.gates[fr * GH + q * H + unit];
+                    n_c[j][r] = a.cstate[fr * H + unit];
+                    n_cp[j][r] = hasp ? a.cstate[((rowoff[r] * T + tp) * 2 + dir) * H + unit] : 0.f;
+                } else {
+                    n_g[0][j][r] = a.out[rowoff[r] * a.obs + (long long)t * a.ld_out + dir * H + unit];
+                    n_c[j][r] = 0.f; n_cp[j][r] = 0.f;
+                }
+            }
+        }
+    };
+    load_step(dir ? 0 : T - 1);
+    __syncthreads();  // LDS weight fragments visible
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;
+        float c_do[UT][4], c_g[NG][UT][4], c_c[UT][4], c_cp[UT][4];
+#pragma unroll
+        for (int j = 0; j < UT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c_do[j][r] = n_do[j][r]; c_c[j][r] = n_c[j][r]; c_cp[j][r] = n_cp[j][r];
+#pragma unroll
+                for (int q = 0; q < NG; ++q) c_g[q][j][r] = n_g[q][j][r];
+            }
+        if (s + 1 < T) load_step(dir ? t + 1 : t - 1);
+
+        unsigned short* dpc = dps + cur * 16 * LDG;
+#pragma unroll
+        for (int j = 0; j < UT; ++j) {
+            const int unit = w * (16 * UT) + j * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dh = c_do[j][r] + dhr[j][r];
+                float dz[G];
+                if (CELL == LAS_CELL_LSTM) {
+                    const float gi = c_g[0][j][r], gj = c_g[NG > 1 ? 1 : 0][j][r], gf = c_g[NG > 2 ? 2 : 0][j][r],
+                                go = c_g[NG > 3 ? 3 : 0][j][r];
+                    const float tc = tanhx<true>(c_c[j][r]);
+                    const float dc = dcc[j][r] + dh * go * (1.f - tc * tc);
+                    dcc[j][r] = dc * gf;
+                    dz[0] = dc * gj * gi * (1.f - gi);
+                    dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
+                    dz[G > 2 ? 2 : 0] = dc * c_cp[j][r] * gf * (1.f - gf);
+                    dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
+                } else {
+                    const float h = c_g[0][j][r];
+                    dz[0] = dh * (1.f - h * h);
+                }
+                const long long fr = (rowoff[r] * T + t) * 2 + dir;
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    dpc[(g * 4 + r) * LDG + q * H + unit] = f2bf(dz[q]);
+                    if (rv[r]) a.gates[fr * GH + q * H + unit] = dz[q];
+                }
+            }
+        }
+        __syncthreads();
+        f32x4_t acc[UT];
+#pragma unroll
+        for (int j = 0; j < UT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dpc[c * LDG + ks * 32 + g * 8]);
+#pragma unroll
+            for (int j = 0; j < UT; ++j) {
+                const int fi = j * KSB + ks;
+                const u16x8_t bv = fi < LFB ? wl[(w * LFB + fi) * 64 + lane] : Wp[fi * 64 + lane];
+                acc[j] = mfma_bf16_16x16x32(av, bv, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UT; ++j) dhr[j] = acc[j];
+        cur ^= 1;
+    }
+}
+
+// W_hh (fp32 [H, G*H]) -> bf16 MFMA B-fragment order.
+//  fwd: frag (dir,w,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + w*64 + j*16 + (lane&15)]
+//  bwd: frag (dir,w,j,ks):   B[k][n] = W[w*64 + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const float* W1, int ldw, int H, int G,
+                                                       int bwd, unsigned short* out) {
+    const int UT = H / 64, GH = G * H;
+    const int KS = bwd ? GH / 32 : H / 32;
+    const int NF = bwd ? UT * KS : G * UT * KS;
+    const long long total = 2LL * H * GH;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long rest = idx >> 9;
+        const int fi = (int)(rest % NF);
+        const int w = (int)((rest / NF) % 4);
+        const int dir = (int)(rest / ((long long)NF * 4));
+        const float* W = dir ? W1 : W0;
+        const int ks = fi % KS, qj = fi / KS;
+        int row, col;
+        if (!bwd) {
+            const int j = qj % UT, q = qj / UT;
+            row = ks * 32 + (lane >> 4) * 8 + e;
+            col = q * H + w * (16 * UT) + j * 16 + (lane & 15);
+        } else {
+            const int j = qj;
+            row = w * (16 * UT) + j * 16 + (lane & 15);
+            col = ks * 32 + (lane >> 4) * 8 + e;
+        }
+        out[idx] = f2bf(W[(long long)row * ldw + col]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool mfma_shape_ok(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
+
+extern "C" size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H) {
+    const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
+    // f32: W^T copy (bwd).  bf16: packed fragments.  Report the larger so one buffer serves both modes.
+    return 2 * G * H * H * sizeof(float) + 256;
+}
+
+template <typename K>
+static int set_lds(K kern, int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int CELL, int UT>
+static int launch_fwd_bf16(const RnnArgs& a, hipStream_t st) {
+    using C = RnnCfg<CELL, UT>;
+    static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT>, C::FWD_LDS);
+    if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd) failed: %d", attr); return attr; }
+    hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT>), dim3(cdiv(a.B, 16), 2), dim3(256), C::FWD_LDS, st, a);
+    return 0;
+}
+template <int CELL, int UT>
+static int launch_bwd_bf16(const RnnArgs& a, hipStream_t st) {
+    using C = RnnCfg<CELL, UT>;
+    static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT>, C::BWD_LDS);
+    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd) failed: %d", attr); return attr; }
+    hipLaunchKernelGGL((rnn_seq_bwd_bf16_kernel<CELL, UT>), dim3(cdiv(a.B, 16), 2), dim3(256), C::BWD_LDS, st, a);
+    return 0;
+}
+
+template <int CELL>
+static int dispatch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
+    switch (a.H) {
+        case 64:  return bwd ? launch_bwd_bf16<CELL, 1>(a, st) : launch_fwd_bf16<CELL, 1>(a, st);
+        case 128: return bwd ? launch_bwd_bf16<CELL, 2>(a, st) : launch_fwd_bf16<CELL, 2>(a, st);
+        case 256: return bwd ? launch_bwd_bf16<CELL, 4>(a, st) : launch_fwd_bf16<CELL, 4>(a, st);
+        default:  return bwd ? launch_bwd_bf16<CELL, 8>(a, st) : launch_fwd_bf16<CELL, 8>(a, st);
+    }
+}
+
+static int check_common(const char* who, int cell, int prec, int B, int T, int H, const void* gates, const void* w0,
+                        const void* w1, int ldw, const void* out, int ld_out, const void* cstate) {
+    LAS_ARG(cell == LAS_CELL_RNN || cell == LAS_CELL_LSTM, "%s: bad cell %d", who, cell);
+    LAS_ARG(prec == LAS_PREC_F32 || prec == LAS_PREC_BF16, "%s: bad prec %d", who, prec);
+    LAS_ARG(B > 0 && T > 0 && H > 0 && H <= 256 * F32_UPT, "%s: bad dims B=%d T=%d H=%d", who, B, T, H);
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1;
+    LAS_ARG(gates && w0 && w1 && out, "%s: null pointer", who);
+    LAS_ARG(ldw >= G * H && ld_out >= 2 * H, "%s: leading dimension too small", who);
+    LAS_ARG(cell == LAS_CELL_RNN || cstate, "%s: lstm needs cstate", who);
+    return 0;
+}
+
+extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, float* out, int ld_out, long long out_bstride,
+                               float* cstate, float forget_bias, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1;
+    RnnArgs a;
+    a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
+    a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
+    a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
+    if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
+        LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * 2, "las_rnn_seq_fwd: workspace too small");
+        hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw, H,
+                           G, 0, (unsigned short*)ws);
+        LAS_LAUNCHED();
+        int rc = cell == LAS_CELL_LSTM ? dispatch_bf16<LAS_CELL_LSTM>(false, a, st) : dispatch_bf16<LAS_CELL_RNN>(false, a, st);
+        if (rc) return rc;
+    } else {
+        const size_t lds = (size_t)H * F32_BT * sizeof(float);
+        dim3 grid(cdiv(B, F32_BT), 2);
+        if (cell == LAS_CELL_LSTM) hipLaunchKernelGGL(rnn_seq_fwd_f32_kernel<LAS_CELL_LSTM>, grid, dim3(256), lds, st, a);
+        else                       hipLaunchKernelGGL(rnn_seq_fwd_f32_kernel<LAS_CELL_RNN>, grid, dim3(256), lds, st, a);
+    }
+    LAS_LAUNCHED();
+    return 0;
+}
+
+extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
+                               const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
+                               float forget_bias, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
+    LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
+    hipStream_t st = (hipStream_t)stream;
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1;
+    RnnArgs a;
+    a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
+    a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
+    a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
+    if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
+        LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * 2, "las_rnn_seq_bwd: workspace too small");
+        hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw, H,
+                           G, 1, (unsigned short*)ws);
+        LAS_LAUNCHED();
+        int rc = cell == LAS_CELL_LSTM ? dispatch_bf16<LAS_CELL_LSTM>(true, a, st) : dispatch_bf16<LAS_CELL_RNN>(true, a, st);
+        if (rc) return rc;
+    } else {
+        LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * sizeof(float), "las_rnn_seq_bwd: workspace too small");
+        hipLaunchKernelGGL(transpose_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw,
+                           H, G * H, (float*)ws);
+        LAS_LAUNCHED();
+        const size_t lds = (size_t)G * H * F32_BT * sizeof(float);
+        if (lds > 64 * 1024) {
+            static int a1 = set_lds(rnn_seq_bwd_f32_kernel<LAS_CELL_LSTM>, 160 * 1024 - 1024);
+            static int a2 = set_lds(rnn_seq_bwd_f32_kernel<LAS_CELL_RNN>, 160 * 1024 - 1024);
+            LAS_ARG(a1 == 0 && a2 == 0 && lds <= 159 * 1024, "las_rnn_seq_bwd: H too large for the fp32 kernel");
+        }
+        dim3 grid(cdiv(B, F32_BT), 2);
+        if (cell == LAS_CELL_LSTM) hipLaunchKernelGGL(rnn_seq_bwd_f32_kernel<LAS_CELL_LSTM>, grid, dim3(256), lds, st, a);
+        else                       hipLaunchKernelGGL(rnn_seq_bwd_f32_kernel<LAS_CELL_RNN>, grid, dim3(256), lds, st, a);
+    }
+    LAS_LAUNCHED();
+    return 0;
+}

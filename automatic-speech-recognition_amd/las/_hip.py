@@ -163,3 +163,26 @@ def colsum(X, rows, cols, ldx, out, beta=0.0, x_off=0):
 def tanh_bwd(Y, ldy, dY, lddy, dX, lddx, rows, cols):
     require_gpu(Y, dY, dX)
     check(lib().las_tanh_bwd(p(Y), ldy, p(dY), lddy, p(dX), lddx, rows, cols, stream()), "las_tanh_bwd")
+
+
+def rnn_seq_ws(cell, prec, H, dev):
+    return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H), "rnn_seq")
+
+
+def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
+                forget_bias=1.0, wf_off=0, wb_off=0):
+    require_gpu(gates, whh_fw, whh_bw, out, cstate)
+    ws = rnn_seq_ws(cell, prec, H, gates.device)
+    check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                p(cstate), forget_bias, p(ws), ws.numel(), stream()), "las_rnn_seq_fwd")
+
+
+def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
+                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0):
+    require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
+    ws = rnn_seq_ws(cell, prec, H, gates.device)
+    check(lib().las_rnn_seq_bwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(ws), ws.numel(),
+                                stream()), "las_rnn_seq_bwd")

@@ -1,0 +1,77 @@
+"""K2/K2b parity: the persistent recurrent sweep (C ABI las_rnn_seq_fwd/bwd) vs the oracle's
+bidirectional_dynamic_rnn restatement (oracle.las_oracle._run_dir, reference las/layers.py:28-54)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (cell, prec, B, T, H)
+CASES = [
+    ("rnn", 0, 5, 7, 48), ("lstm", 0, 5, 7, 48), ("rnn", 0, 9, 12, 100), ("lstm", 0, 17, 9, 64),
+    ("rnn", 1, 5, 7, 64), ("lstm", 1, 5, 7, 64), ("rnn", 1, 20, 33, 128), ("lstm", 1, 20, 33, 128),
+    ("rnn", 1, 48, 40, 256), ("lstm", 1, 48, 40, 256), ("lstm", 0, 48, 20, 256), ("rnn", 1, 3, 5, 512),
+]
+
+
+def _oracle_sweep(xp, whh, cell, double=True):
+    """xp [B,T,2,GH] pre-activations; whh [2][H,GH].  Returns out [B,T,2H] and grads hook inputs."""
+    from oracle import las_oracle as O
+    dt = torch.float64 if double else torch.float32
+    GH = xp.shape[-1]
+    outs = []
+    for d in range(2):
+        kernel = torch.cat([torch.eye(GH, dtype=dt), whh[d].to(dt)], 0)
+        outs.append(O._run_dir(xp[:, :, d].to(dt), kernel, torch.zeros(GH, dtype=dt), cell, reverse=bool(d)))
+    return torch.cat(outs, -1)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rnn_seq_fwd_bwd(case):
+    from las import _hip
+    cell, prec, B, T, H = case
+    G = 4 if cell == "lstm" else 1
+    GH = G * H
+    g = torch.Generator().manual_seed(B * 131 + T * 7 + H)
+    xp = torch.randn(B, T, 2, GH, generator=g) * 0.8
+    lim = (6.0 / (H + GH)) ** 0.5 * 1.5
+    whh = [(torch.rand(H, GH, generator=g) * 2 - 1) * lim for _ in range(2)]
+    R = torch.randn(B, T, 2 * H, generator=g)
+
+    xpl = xp.clone().double().requires_grad_(True)
+    wl = [w.clone().double().requires_grad_(True) for w in whh]
+    ref = _oracle_sweep(xpl, wl, cell)
+    (ref * R.double()).sum().backward()
+
+    dev = "cuda"
+    gates = xp.to(dev).contiguous()
+    w0, w1 = whh[0].to(dev), whh[1].to(dev)
+    Tpad = T + (T % 2)                       # exercise the pad-frame batch stride
+    out = torch.zeros(B, Tpad, 2 * H, device=dev)
+    cst = torch.zeros(B, T, 2, H, device=dev) if cell == "lstm" else None
+    c = _hip.CELL_LSTM if cell == "lstm" else _hip.CELL_RNN
+    _hip.rnn_seq_fwd(c, prec, B, T, H, gates, w0, w1, GH, out, 2 * H, Tpad * 2 * H, cst)
+    got = out[:, :T].cpu().double()
+    tol = 2e-5 if prec == 0 else 4e-2
+    err = (got - ref.detach()).abs().max().item()
+    assert err < tol, ("fwd", case, err)
+    if T % 2:
+        assert out[:, T:].abs().max().item() == 0.0   # pad frame untouched
+
+    dout = torch.zeros(B, Tpad, 2 * H, device=dev)
+    dout[:, :T] = R.to(dev)
+    _hip.rnn_seq_bwd(c, prec, B, T, H, gates, w0, w1, GH, out, 2 * H, Tpad * 2 * H, cst, dout, 2 * H, Tpad * 2 * H)
+    dg = gates.cpu().double()
+    refg = xpl.grad
+    err = (dg - refg).abs().max().item()
+    scale = refg.abs().max().item()
+    tolb = (5e-5 if prec == 0 else 6e-2) * max(1.0, scale)
+    assert err < tolb, ("bwd", case, err, scale)
+
+
+def test_rnn_seq_rejects_bad_args():
+    from las import _hip
+    x = torch.zeros(4, device="cuda")
+    with pytest.raises(RuntimeError):
+        _hip.rnn_seq_fwd(0, 0, 0, 4, 8, x, x, x, 8, x, 16, 0, None)     # B = 0
+    with pytest.raises(RuntimeError):
+        _hip.rnn_seq_fwd(1, 0, 1, 1, 1, x, x, x, 4, x, 2, 0, None)      # lstm without cstate
