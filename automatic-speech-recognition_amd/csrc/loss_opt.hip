@@ -1,0 +1,174 @@
+// loss_opt.hip -- K8 (label-smoothed masked cross-entropy, fwd + grad in one pass) and
+// K9 (clip_by_global_norm + TF-style Adam on one flat bucket).  HBM-bound streaming kernels:
+// vectorised, fixed-order reductions (no atomics -> bit-reproducible training steps).
+#include "las_common.h"
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------------
+// K8: LAS._get_loss (reference las/las.py:320-333) + label_smoothing (las/utils.py:5-12)
+//   soft = (1-eps)*onehot + eps/V ;  ce = -sum_k soft_k * log_softmax(l)_k ; mask = (y != 0)
+//   d l_k = scale * mask * (softmax_k - soft_k)
+// one wave per (b,t) row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, long long sb, long long st,
+                                                      const int* __restrict__ y, int ldy, int B, int U, int V, float eps,
+                                                      int smooth, const float* __restrict__ scale_ptr,
+                                                      float* __restrict__ dlogits, float* __restrict__ row_ce,
+                                                      float* __restrict__ row_mask) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * U) return;
+    const int b = (int)(row / U), t = (int)(row % U);
+    const float* lp = logits + b * sb + t * st;
+    const int label = y[(long long)b * ldy + t];
+    const float mask = label != 0 ? 1.f : 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    for (int k = lane; k < V; k += 64) { const float l = lp[k]; m = fmaxf(m, l); lsum += l; }
+    m = wave_max(m);
+    lsum = wave_sum(lsum);
+    float se = 0.f;
+    for (int k = lane; k < V; k += 64) se += expf(lp[k] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    const float e = smooth ? eps : 0.f;
+    const float ly = (label >= 0 && label < V) ? lp[label] : 0.f;
+    const float ce = lse - (1.f - e) * ly - (e / V) * lsum;
+    if (lane == 0) { row_ce[row] = ce * mask; row_mask[row] = mask; }
+    if (dlogits) {
+        const float sc = scale_ptr[0] * mask;
+        float* dp = dlogits + b * sb + t * st;
+        for (int k = lane; k < V; k += 64) {
+            const float p = expf(lp[k] - lse);
+            const float soft = (k == label ? (1.f - e) : 0.f) + e / V;
+            dp[k] = sc * (p - soft);
+        }
+    }
+}
+
+// fixed-order sum of n values (single workgroup), out[0] += sum(a), out[1] += sum(b)
+__global__ __launch_bounds__(1024) void sum2_kernel(const float* __restrict__ a, const float* __restrict__ b2, long long n,
+                                                    float* __restrict__ out) {
+    __shared__ float red[2][16];
+    float s0 = 0.f, s1 = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) { s0 += a[i]; if (b2) s1 += b2[i]; }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int i = 0; i < 16; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
+        out[0] += t0;
+        if (b2) out[1] += t1;
+    }
+}
+
+extern "C" size_t las_ce_loss_workspace_bytes(int B, int U) { return (size_t)2 * B * U * sizeof(float) + 256; }
+
+extern "C" int las_ce_loss(const float* logits, long long sb, long long st, const int* y, int ldy, int B, int U, int V,
+                           float epsilon, int smooth, float* sums, const float* scale_ptr, float* dlogits, void* ws,
+                           size_t ws_bytes, void* stream) {
+    LAS_ARG(logits && y && sums && B > 0 && U > 0 && V > 0 && ldy >= U, "las_ce_loss: bad arguments");
+    LAS_ARG(!dlogits || scale_ptr, "las_ce_loss: dlogits needs scale_ptr");
+    LAS_ARG(ws && ws_bytes >= las_ce_loss_workspace_bytes(B, U), "las_ce_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* row_ce = (float*)ws;
+    float* row_mask = row_ce + (size_t)B * U;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv((long long)B * U, 4)), dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V,
+                       epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
+    LAS_LAUNCHED();
+    hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_ce, (const float*)row_mask, (long long)B * U, sums);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: tf.clip_by_global_norm + AdamOptimizer.apply_gradients (reference las/las.py:272-283)
+// ------------------------------------------------------------------------------------------------
+constexpr int SS_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long n4 = n / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0) for (long long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 16; ++i) t += red[i]; out[0] = t; }
+}
+
+extern "C" size_t las_sumsq_workspace_bytes(long long n) { (void)n; return SS_BLOCKS * sizeof(float); }
+
+extern "C" int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(g && out && n >= 0, "las_sumsq: bad arguments");
+    LAS_ARG(ws && ws_bytes >= las_sumsq_workspace_bytes(n), "las_sumsq: workspace too small");
+    LAS_ARG((((uintptr_t)g) & 15) == 0, "las_sumsq: g must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SS_BLOCKS), dim3(256), 0, s, g, n, (float*)ws);
+    LAS_LAUNCHED();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, SS_BLOCKS, out);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n,
+                                                        const float* __restrict__ sumsq, float clip, float lr_t, float b1,
+                                                        float b2, float eps) {
+    float gs = 1.f;
+    if (clip > 0.f) {   // g * clip / max(norm, clip)   
+        const float nrm = sqrtf(sumsq[0]);
+        gs = clip / fmaxf(nrm, clip);
+    }
+    const long long n4 = n / 4;
+    float4* t4 = reinterpret_cast<float4*>(theta);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 th = t4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#define ADAM1(c)                                                \
+        { const float gc = gg.c * gs;                           \
+          mm.c = b1 * mm.c + (1.f - b1) * gc;                   \
+          vv.c = b2 * vv.c + (1.f - b2) * gc * gc;              \
+          th.c -= lr_t * mm.c / (sqrtf(vv.c) + eps); }
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        t4[i] = th; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float gc = g[i] * gs;
+            const float mm = b1 * m[i] + (1.f - b1) * gc;
+            const float vv = b2 * v[i] + (1.f - b2) * gc * gc;
+            m[i] = mm; v[i] = vv;
+            theta[i] -= lr_t * mm / (sqrtf(vv) + eps);
+        }
+}
+
+extern "C" int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n, const float* sumsq, float clip,
+                             float lr_t, float beta1, float beta2, float eps, void* stream) {
+    LAS_ARG(theta && g && m && v && n >= 0, "las_clip_adam: bad arguments");
+    LAS_ARG(clip <= 0.f || sumsq, "las_clip_adam: clipping needs sumsq");
+    LAS_ARG(((((uintptr_t)theta) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
+            "las_clip_adam: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    int nb = cdiv(n / 4 + 1, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, sumsq, clip, lr_t,
+                       beta1, beta2, eps);
+    LAS_LAUNCHED();
+    return 0;
+}

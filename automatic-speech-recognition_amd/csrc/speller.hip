@@ -1,0 +1,733 @@
+// speller.hip -- K4-K7: the Speller decode loop (reference las/las.py:72-160) and its gradient.
+//
+// The reference runs U iterations of a tf.while_loop whose body re-projects the keys
+// (las/layers.py:250), runs ~20 tiny TF ops and grows its outputs by concat (las/las.py:114-115).
+// Here the key projection is hoisted (one K4 GEMM by the caller), the outputs are preallocated,
+// and each step is TWO launches enqueued by one C call:
+//   dec_step_fwd_kernel (one workgroup per utterance; everything row-local stays in LDS):
+//       finish the previous step's cell (gate nonlinearity, h/c, [vocab logits, argmax, Gumbel
+//       sample]) -> query projection s.Ws -> [location conv] -> energies u.tanh(K+q+f) ->
+//       -1e8 replace-mask -> softmax -> context -> cell input row [emb ; ctx ; h_prev]
+//   las_gemm: the cell contraction [B, E+Hd+D] x [E+Hd+D, G*D] (weight-streaming, skinny-M MFMA tile)
+// The gradient mirrors it in reverse: dec_step_bwd_kernel (attention backward of step t+1 fused with
+// the gate backward of step t) + one las_gemm (dG.W^T) per step; every weight gradient is a single
+// tall contraction after the loop (split-K, deterministic).  No atomics anywhere.
+#include "las_common.h"
+#include <math.h>
+
+#define LAS_MAX_NL 4
+
+struct DecDev {
+    int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits;
+    float fb;
+    unsigned long long seed;
+    const float *enc, *keys; const int* enc_len;
+    const float *Ws, *u, *emb, *Wv, *bv, *loc_w, *loc_b, *Wf;
+    int *tok_in, *tok_out;
+    const float* align0;
+    float *logits, *alphas, *hs, *cs, *gates, *xin0;
+    // backward
+    const float* dHl;      // [U,B,D]   dlogits . Wv^T
+    float *dH, *dC;        // [NL,B,D]
+    float* dXin0;          // [U,B,I0D]
+    float *Q, *dQ;         // [U,B,A]
+    float* duRows;         // [B,A]
+    float* dAext;          // [B,Tp]   grad wrt alpha_t arriving from step t+1's location conv
+    float* dKeys;          // [B,Tp,A]
+    float *dlocwRows, *dlocbRows, *dWfRows;   // [B,Kc*C], [B,C], [B,C*A]
+    const float* rec[LAS_MAX_NL]; int recLd[LAS_MAX_NL]; int recOff[LAS_MAX_NL];
+};
+
+__device__ __forceinline__ float gumbel_noise(unsigned long long seed, int t, int b, int v) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(((long long)t * 1000003 + b) * 65537 + v + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    const float u01 = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    return -logf(-logf(u01));
+}
+
+// argmax with first-index tie-break across the block; all threads receive the index
+__device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    float bv = redv[0]; int bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+    return bi;
+}
+
+__device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane half-wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LDS carve shared by the forward and backward row kernels
+struct RowLds {
+    float *s_state, *qv, *part, *ev, *hl, *aprev, *fc, *red, *x0, *x1, *x2;
+    int* redi;
+};
+__device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
+    RowLds r;
+    const int S = a.D * a.NL;
+    float* p = sm;
+    r.s_state = p; p += S;
+    r.qv = p;      p += a.A;
+    r.part = p;    p += 8 * a.A;
+    r.ev = p;      p += a.Tp;
+    r.hl = p;      p += a.D;
+    r.aprev = p;   p += a.Tp;
+    r.fc = p;      p += (a.mode == LAS_ATT_LOC ? a.Tp * a.C : 0);
+    r.red = p;     p += 16;
+    r.redi = reinterpret_cast<int*>(p); p += 16;
+    r.x0 = p; r.x1 = p; r.x2 = p;
+    if (bwd) {
+        r.x0 = p; p += a.Hd;                 // dctx
+        r.x1 = p; p += a.Tp;                 // dalpha / de
+        r.x2 = p; p += (a.mode == LAS_ATT_LOC ? a.Tp * a.C : 0);   // dfc
+    }
+    return r;
+}
+static size_t row_lds_bytes(const DecDev& a, bool bwd) {
+    size_t n = (size_t)a.D * a.NL + a.A + 8 * a.A + a.Tp + a.D + a.Tp + 32;
+    if (a.mode == LAS_ATT_LOC) n += (size_t)a.Tp * a.C;
+    if (bwd) n += a.Hd + a.Tp + (a.mode == LAS_ATT_LOC ? (size_t)a.Tp * a.C : 0);
+    return n * sizeof(float) + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward row kernel
+// ------------------------------------------------------------------------------------------------
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const RowLds L = carve(sm, a, false);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, NL = a.NL, E = a.E, V = a.V, U = a.U;
+    const int S = D * NL, TOP = NL - 1, GD = G * D, I0D = E + Hd + D;
+    int greedy_tok = 1, sample_tok = 1;
+
+    if (t > 0) {  // ---- finish the top layer's cell of step t-1
+        float* gp = a.gates + (((size_t)TOP * U + (t - 1)) * B + b) * GD;
+        float* hnew = a.hs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+        for (int d = tid; d < D; d += 256) {
+            float h;
+            if (CELL == LAS_CELL_LSTM) {
+                const float* cprev = a.cs + (((size_t)TOP * (U + 1) + (t - 1)) * B + b) * D;
+                float* cnew = a.cs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+                const float gi = sigm<FAST>(gp[d]);
+                const float gj = tanhx<FAST>(gp[D + d]);
+                const float gf = sigm<FAST>(gp[2 * D + d] + a.fb);
+                const float go = sigm<FAST>(gp[3 * D + d]);
+                const float c = cprev[d] * gf + gi * gj;
+                h = tanhx<FAST>(c) * go;
+                gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+                cnew[d] = c;
+            } else {
+                h = tanhx<FAST>(gp[d]);
+            }
+            hnew[d] = h;
+            L.hl[d] = h;
+        }
+        __syncthreads();
+        if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+            float bestv = -INFINITY, bests = -INFINITY;
+            int besti = 0x7fffffff, bestsi = 0x7fffffff;
+            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
+            for (int v = tid; v < V; v += 256) {
+                float acc = a.bv[v];
+                for (int d = 0; d < D; ++d) acc = fmaf(L.hl[d], a.Wv[(size_t)d * V + v], acc);
+                lrow[v] = acc;
+                if (acc > bestv) { bestv = acc; besti = v; }
+                const float sc = acc + gumbel_noise(a.seed, t, b, v);
+                if (sc > bests) { bests = sc; bestsi = v; }
+            }
+            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
+            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
+            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+        }
+    }
+    if (t >= U) return;
+
+    int tok = a.tok_in[(size_t)t * B + b];
+    if (tok == -1) tok = greedy_tok;
+    else if (tok == -2) tok = sample_tok;
+    if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
+
+    for (int i = tid; i < S; i += 256) {
+        const int l = i / D, d = i % D;
+        L.s_state[i] = (l == TOP && t > 0) ? L.hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
+    }
+    if (a.mode == LAS_ATT_LOC)
+        for (int i = tid; i < Tp; i += 256)
+            L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+    __syncthreads();
+
+    {   // query projection q = s . Ws   (wave w takes rows k = w, w+4, ..; lanes run over the A outputs)
+        const int w = tid >> 6, lane = tid & 63;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = w; k < S; k += 4) {
+            const float sk = L.s_state[k];
+            const float* wr = a.Ws + (size_t)k * A;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int ai = lane + 64 * sl;
+                if (ai < A) acc[sl] = fmaf(sk, wr[ai], acc[sl]);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int ai = lane + 64 * sl;
+            if (ai < A) L.part[w * A + ai] = acc[sl];
+        }
+    }
+    if (a.mode == LAS_ATT_LOC) {  // f = conv1d(prev_align) (SAME, cross-correlation, bias): las/layers.py:295-296
+        const int pad = (a.Kc - 1) / 2;
+        for (int i = tid; i < Tp * a.C; i += 256) {
+            const int tt = i / a.C, c = i % a.C;
+            float acc = a.loc_b[c];
+            for (int k = 0; k < a.Kc; ++k) {
+                const int src = tt + k - pad;
+                if (src >= 0 && src < Tp) acc = fmaf(L.aprev[src], a.loc_w[k * a.C + c], acc);
+            }
+            L.fc[i] = acc;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < A; i += 256) L.qv[i] = L.part[i] + L.part[A + i] + L.part[2 * A + i] + L.part[3 * A + i];
+    __syncthreads();
+
+    const int len = a.enc_len[b];
+    {   // energies: a 32-lane half-wave per encoder frame, float4 over the attention dim
+        const int sl = tid & 31, grp = tid >> 5;
+        for (int tt = grp; tt < Tp; tt += 8) {
+            const float4* kp = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A);
+            float part = 0.f;
+            for (int a4 = sl; a4 < A / 4; a4 += 32) {
+                const float4 k4 = kp[a4];
+                const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+                float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+                if (a.mode == LAS_ATT_LOC) {
+                    for (int c = 0; c < a.C; ++c) {
+                        const float f = L.fc[tt * a.C + c];
+                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                        p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+                    }
+                }
+                part += u4.x * tanhx<FAST>(p.x) + u4.y * tanhx<FAST>(p.y) + u4.z * tanhx<FAST>(p.z) + u4.w * tanhx<FAST>(p.w);
+            }
+            part = sub32_sum(part);
+            if (sl == 0) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < Tp; i += 256) m = fmaxf(m, L.ev[i]);
+    m = block_max<256>(m, L.red);
+    float ssum = 0.f;
+    for (int i = tid; i < Tp; i += 256) { const float e = expf(L.ev[i] - m); L.ev[i] = e; ssum += e; }
+    ssum = block_sum<256>(ssum, L.red);
+    const float inv = 1.0f / ssum;
+    float* arow = a.alphas + ((size_t)t * B + b) * Tp;
+    for (int i = tid; i < Tp; i += 256) { const float al = L.ev[i] * inv; L.ev[i] = al; arow[i] = al; }
+    __syncthreads();
+
+    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
+    for (int hd = tid; hd < Hd; hd += 256) {
+        const float* ep = a.enc + (size_t)b * Tp * Hd + hd;
+        float acc = 0.f;
+        for (int tt = 0; tt < lim; ++tt) acc = fmaf(L.ev[tt], ep[(size_t)tt * Hd], acc);
+        xrow[E + hd] = acc;
+    }
+    for (int i = tid; i < E; i += 256) xrow[i] = a.emb[(size_t)tok * E + i];
+    for (int i = tid; i < D; i += 256) xrow[E + Hd + i] = L.s_state[i];
+}
+
+// gate nonlinearity of a non-top layer (multi-layer Speller only)
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void dec_pointwise_fwd_kernel(DecDev a, int layer, int t) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const int b = blockIdx.x, B = a.B, D = a.D, U = a.U, GD = G * D;
+    float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;
+    float* hnew = a.hs + (((size_t)layer * (U + 1) + t + 1) * B + b) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float h;
+        if (CELL == LAS_CELL_LSTM) {
+            const float* cprev = a.cs + (((size_t)layer * (U + 1) + t) * B + b) * D;
+            float* cnew = a.cs + (((size_t)layer * (U + 1) + t + 1) * B + b) * D;
+            const float gi = sigm<FAST>(gp[d]), gj = tanhx<FAST>(gp[D + d]);
+            const float gf = sigm<FAST>(gp[2 * D + d] + a.fb), go = sigm<FAST>(gp[3 * D + d]);
+            const float c = cprev[d] * gf + gi * gj;
+            h = tanhx<FAST>(c) * go;
+            gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+            cnew[d] = c;
+        } else {
+            h = tanhx<FAST>(gp[d]);
+        }
+        hnew[d] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward row kernels
+// ------------------------------------------------------------------------------------------------
+// gate backward of `layer` at step t for one row: dh = dH[layer] + extra ; writes d(pre-act) over gates
+template <int CELL, bool FAST>
+__device__ __forceinline__ void cell_bwd_row(const DecDev& a, int layer, int t, int b, const float* extra, int extra_ld) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const int B = a.B, D = a.D, U = a.U, GD = G * D;
+    float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;
+    const float* dHr = a.dH + ((size_t)layer * B + b) * D;
+    float* dCr = a.dC + ((size_t)layer * B + b) * D;
+    const float* ex = extra + (size_t)b * extra_ld;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float dh = dHr[d] + ex[d];
+        if (CELL == LAS_CELL_LSTM) {
+            const float gi = gp[d], gj = gp[D + d], gf = gp[2 * D + d], go = gp[3 * D + d];
+            const float c = a.cs[(((size_t)layer * (U + 1) + t + 1) * B + b) * D + d];
+            const float cp = a.cs[(((size_t)layer * (U + 1) + t) * B + b) * D + d];
+            const float tc = tanhx<FAST>(c);
+            const float dc = dCr[d] + dh * go * (1.f - tc * tc);
+            dCr[d] = dc * gf;
+            gp[d] = dc * gj * gi * (1.f - gi);
+            gp[D + d] = dc * gi * (1.f - gj * gj);
+            gp[2 * D + d] = dc * cp * gf * (1.f - gf);
+            gp[3 * D + d] = dh * tc * go * (1.f - go);
+        } else {
+            const float h = a.hs[(((size_t)layer * (U + 1) + t + 1) * B + b) * D + d];
+            gp[d] = dh * (1.f - h * h);
+        }
+    }
+}
+
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void dec_pointwise_bwd_kernel(DecDev a, int layer, int t, const float* extra, int extra_ld) {
+    cell_bwd_row<CELL, FAST>(a, layer, t, blockIdx.x, extra, extra_ld);
+}
+
+// Part A: attention backward of step t_att (if >= 0); Part B: top-layer gate backward of step t_cell (if >= 0).
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, int t_cell) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const RowLds L = carve(sm, a, true);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, NL = a.NL, E = a.E, U = a.U;
+    const int S = D * NL, I0D = E + Hd + D;
+    const bool loc = a.mode == LAS_ATT_LOC;
+    float* dctx = L.x0;
+    float* dal = L.x1;
+    float* dfc = L.x2;
+
+    if (t_att >= 0) {
+        const int t = t_att;
+        const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D;
+        for (int i = tid; i < Hd; i += 256) dctx[i] = dxr[E + i];
+        for (int i = tid; i < Tp; i += 256) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
+        for (int i = tid; i < A; i += 256) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
+        if (loc) for (int i = tid; i < Tp; i += 256)
+            L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+        __syncthreads();
+        if (loc) {
+            const int pad = (a.Kc - 1) / 2;
+            for (int i = tid; i < Tp * a.C; i += 256) {
+                const int tt = i / a.C, c = i % a.C;
+                float acc = a.loc_b[c];
+                for (int k = 0; k < a.Kc; ++k) {
+                    const int src = tt + k - pad;
+                    if (src >= 0 && src < Tp) acc = fmaf(L.aprev[src], a.loc_w[k * a.C + c], acc);
+                }
+                L.fc[i] = acc;
+                dfc[i] = 0.f;
+            }
+        }
+        const int len = a.enc_len[b];
+        const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
+        {   // dalpha[t'] = dctx . enc[b,t',:]   (+ what step t+1's location conv sent back)
+            const int w = tid >> 6, lane = tid & 63;
+            for (int tt = w; tt < Tp; tt += 4) {
+                float acc = 0.f;
+                if (tt < lim) {
+                    const float* ep = a.enc + ((size_t)b * Tp + tt) * Hd;
+                    for (int hd = lane; hd < Hd; hd += 64) acc = fmaf(dctx[hd], ep[hd], acc);
+                    acc = wave_sum(acc);
+                }
+                if (lane == 0) {
+                    if (loc && t + 1 < U) acc += a.dAext[(size_t)b * Tp + tt];
+                    dal[tt] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        float dot = 0.f;
+        for (int i = tid; i < Tp; i += 256) dot = fmaf(L.ev[i], dal[i], dot);
+        dot = block_sum<256>(dot, L.red);
+        for (int i = tid; i < Tp; i += 256) dal[i] = L.ev[i] * (dal[i] - dot);   // d energy (0 where masked: alpha = 0)
+        __syncthreads();
+
+        // energies backward: half-wave per frame; per-lane partials of du, dq (and dWf) over its frames
+        const int sl = tid & 31, grp = tid >> 5;
+        float du_acc[8], dq_acc[8];    // A <= 256 -> at most 2 float4 per lane
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { du_acc[i] = 0.f; dq_acc[i] = 0.f; }
+        for (int tt = grp; tt < Tp; tt += 8) {
+            const float de = dal[tt];
+            const float4* kp = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A);
+            float4* dkp = reinterpret_cast<float4*>(a.dKeys + ((size_t)b * Tp + tt) * A);
+            float dfc_l[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dfc_l[c] = 0.f;
+            int slot = 0;
+            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot) {
+                const float4 k4 = kp[a4];
+                const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+                float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+                if (loc) {
+                    for (int c = 0; c < a.C; ++c) {
+                        const float f = L.fc[tt * a.C + c];
+                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                        p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+                    }
+                }
+                const float vx = tanhx<FAST>(p.x), vy = tanhx<FAST>(p.y), vz = tanhx<FAST>(p.z), vw = tanhx<FAST>(p.w);
+                const float4 dv = make_float4(de * u4.x * (1.f - vx * vx), de * u4.y * (1.f - vy * vy),
+                                              de * u4.z * (1.f - vz * vz), de * u4.w * (1.f - vw * vw));
+                du_acc[slot * 4 + 0] += de * vx; du_acc[slot * 4 + 1] += de * vy;
+                du_acc[slot * 4 + 2] += de * vz; du_acc[slot * 4 + 3] += de * vw;
+                dq_acc[slot * 4 + 0] += dv.x; dq_acc[slot * 4 + 1] += dv.y;
+                dq_acc[slot * 4 + 2] += dv.z; dq_acc[slot * 4 + 3] += dv.w;
+                if (de != 0.f) {
+                    float4 dk = dkp[a4];
+                    dk.x += dv.x; dk.y += dv.y; dk.z += dv.z; dk.w += dv.w;
+                    dkp[a4] = dk;
+                }
+                if (loc) {
+                    for (int c = 0; c < a.C && c < 16; ++c) {
+                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                        dfc_l[c] += dv.x * w4.x + dv.y * w4.y + dv.z * w4.z + dv.w * w4.w;
+                        // dWf[c, a] += fc[t',c] * dv[a]   (row-private accumulation, reduced over rows after the loop)
+                        float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * 8 + grp) * a.C + c) * A) + a4;
+                        const float f = L.fc[tt * a.C + c];
+                        float4 o = *wr;
+                        o.x = fmaf(f, dv.x, o.x); o.y = fmaf(f, dv.y, o.y); o.z = fmaf(f, dv.z, o.z); o.w = fmaf(f, dv.w, o.w);
+                        *wr = o;
+                    }
+                }
+            }
+            if (loc) {
+                for (int c = 0; c < a.C && c < 16; ++c) {
+                    const float s = sub32_sum(dfc_l[c]);
+                    if (sl == 0) dfc[tt * a.C + c] = s;
+                }
+            }
+        }
+        // reduce the 8 half-wave partials of du / dq through LDS
+        __syncthreads();
+        {
+            int slot = 0;
+            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = dq_acc[slot * 4 + e];
+        }
+        __syncthreads();
+        for (int i = tid; i < A; i += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) s += L.part[g8 * A + i];
+            L.qv[i] = s;                                   // qv now holds dq
+            a.dQ[((size_t)t * B + b) * A + i] = s;
+        }
+        __syncthreads();
+        {
+            int slot = 0;
+            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = du_acc[slot * 4 + e];
+        }
+        __syncthreads();
+        for (int i = tid; i < A; i += 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) s += L.part[g8 * A + i];
+            a.duRows[(size_t)b * A + i] += s;
+        }
+        // d state = dq . Ws^T ; total gradient of the states consumed at step t
+        for (int i = tid; i < S; i += 256) {
+            const float4* wr = reinterpret_cast<const float4*>(a.Ws + (size_t)i * A);
+            float acc = 0.f;
+            for (int a4 = 0; a4 < A / 4; ++a4) {
+                const float4 w4 = wr[a4];
+                const float4 d4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                acc += w4.x * d4.x + w4.y * d4.y + w4.z * d4.z + w4.w * d4.w;
+            }
+            const int l = i / D, d = i % D;
+            a.dH[((size_t)l * B + b) * D + d] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d] + acc;
+        }
+        if (loc) {   // conv1d backward: filter / bias partials per row, and d alpha_{t-1}
+            const int pad = (a.Kc - 1) / 2;
+            for (int i = tid; i < a.Kc * a.C; i += 256) {
+                const int k = i / a.C, c = i % a.C;
+                float acc = 0.f;
+                for (int tt = 0; tt < Tp; ++tt) {
+                    const int src = tt + k - pad;
+                    if (src >= 0 && src < Tp) acc = fmaf(dfc[tt * a.C + c], L.aprev[src], acc);
+                }
+                a.dlocwRows[(size_t)b * a.Kc * a.C + i] += acc;
+            }
+            for (int c = tid; c < a.C; c += 256) {
+                float acc = 0.f;
+                for (int tt = 0; tt < Tp; ++tt) acc += dfc[tt * a.C + c];
+                a.dlocbRows[(size_t)b * a.C + c] += acc;
+            }
+            for (int src = tid; src < Tp; src += 256) {
+                float acc = 0.f;
+                for (int k = 0; k < a.Kc; ++k) {
+                    const int tt = src - k + pad;
+                    if (tt >= 0 && tt < Tp)
+                        for (int c = 0; c < a.C; ++c) acc = fmaf(dfc[tt * a.C + c], a.loc_w[k * a.C + c], acc);
+                }
+                a.dAext[(size_t)b * Tp + src] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (t_cell >= 0) cell_bwd_row<CELL, FAST>(a, NL - 1, t_cell, b, a.dHl + (size_t)t_cell * B * D, D);
+}
+
+// demb[v,:] += sum over (t,b) with token v of dXin0[t,b,0:E]
+__global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const float* dXin0, int n, int ld, int E, float* demb) {
+    const int v = blockIdx.x;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i)
+            if (tok[i] == v) acc += dXin0[(size_t)i * ld + e];
+        demb[(size_t)v * E + e] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BwdWs {
+    size_t dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+};
+static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
+    BwdWs w; size_t o = 0;
+    const size_t f = sizeof(float);
+    const size_t I0D = (size_t)E + Hd + D;
+    w.dHl = o;    o += align256((size_t)U * B * D * f);
+    w.dH = o;     o += align256((size_t)NL * B * D * f);
+    w.dC = o;     o += align256((size_t)NL * B * D * f);
+    w.dXin0 = o;  o += align256((size_t)U * B * I0D * f);
+    w.Q = o;      o += align256((size_t)U * B * A * f);
+    w.dQ = o;     o += align256((size_t)U * B * A * f);
+    w.duRows = o; o += align256((size_t)B * A * f);
+    w.dAext = o;  o += align256((size_t)B * Tp * f);
+    w.tmp = o;    o += align256((size_t)NL * B * 2 * D * f);
+    w.dlocw = o;  o += align256((size_t)B * (Kc > 0 ? Kc : 1) * (C > 0 ? C : 1) * f);
+    w.dlocb = o;  o += align256((size_t)B * (C > 0 ? C : 1) * f);
+    w.dWf = o;    o += align256((size_t)B * 8 * (C > 0 ? C : 1) * A * f);   // one slice per half-wave group
+    w.gemm = o;
+    size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
+    if ((size_t)D * V > big) big = (size_t)D * V;
+    o += align256(big * 8 * f);
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell) {
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1;
+    return bwd_layout(B, Tp, Hd, A, D, NL, E, V, U, G, 256, 16).total;
+}
+
+static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
+    LAS_ARG(f, "speller: null args");
+    LAS_ARG(f->B > 0 && f->Tp > 0 && f->Hd > 0 && f->A > 0 && f->D > 0 && f->E > 0 && f->V > 0 && f->U > 0,
+            "speller: non-positive dimension");
+    LAS_ARG(f->NL >= 1 && f->NL <= LAS_MAX_NL, "speller: NL=%d unsupported (1..%d)", f->NL, LAS_MAX_NL);
+    LAS_ARG(f->D % 4 == 0 && f->Hd % 4 == 0, "speller: D and Hd must be multiples of 4");
+    LAS_ARG(f->A % 4 == 0 && f->A <= 256, "speller: attention size must be a multiple of 4 and <= 256 (got %d)", f->A);
+    LAS_ARG(f->cell == LAS_CELL_RNN || f->cell == LAS_CELL_LSTM, "speller: bad cell");
+    LAS_ARG(f->mode == LAS_ATT_ADD || f->mode == LAS_ATT_LOC, "speller: bad attention mode");
+    LAS_ARG(f->mode == LAS_ATT_ADD || (f->loc_w && f->loc_b && f->Wf && f->Kc > 0 && f->Kc <= 256 && f->C > 0 && f->C <= 16),
+            "speller: location-aware attention needs loc_w/loc_b/Wf, Kc<=256, C<=16");
+    LAS_ARG(f->enc && f->keys && f->enc_len && f->Ws && f->u && f->emb && f->Wv && f->bv && f->cellW && f->cellb,
+            "speller: null parameter pointer");
+    LAS_ARG(f->tokens_in && f->logits && f->alphas && f->hs && f->gates && f->xin0, "speller: null buffer pointer");
+    LAS_ARG(f->cell == LAS_CELL_RNN || f->cs, "speller: lstm needs cs");
+    LAS_ARG(!f->step_logits || f->tokens_out, "speller: step_logits needs tokens_out");
+    LAS_ARG((((uintptr_t)f->keys | (uintptr_t)f->u | (uintptr_t)f->Ws) & 15) == 0, "speller: keys/u/Ws must be 16-byte aligned");
+    d.B = f->B; d.Tp = f->Tp; d.Hd = f->Hd; d.A = f->A; d.D = f->D; d.NL = f->NL; d.E = f->E; d.V = f->V; d.U = f->U;
+    d.mode = f->mode; d.Kc = f->mode == LAS_ATT_LOC ? f->Kc : 0; d.C = f->mode == LAS_ATT_LOC ? f->C : 0;
+    d.step_logits = f->step_logits; d.fb = f->forget_bias; d.seed = f->seed;
+    d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
+    d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
+    d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.logits = f->logits; d.alphas = f->alphas;
+    d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
+    d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
+    d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
+    for (int l = 0; l < LAS_MAX_NL; ++l) { d.rec[l] = nullptr; d.recLd[l] = 0; d.recOff[l] = 0; }
+    return 0;
+}
+
+#define GEMM_OK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+
+template <int CELL, bool FAST>
+static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipStream_t st) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const int B = d.B, D = d.D, NL = d.NL, U = d.U, E = d.E, Hd = d.Hd, V = d.V;
+    const int GD = G * D, I0D = E + Hd + D;
+    const size_t lds = row_lds_bytes(d, false);
+    LAS_ARG(lds <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds);
+    for (int l = 0; l < NL && !f->keep_state0; ++l) {
+        LAS_HIP(hipMemsetAsync(d.hs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
+        if (CELL == LAS_CELL_LSTM) LAS_HIP(hipMemsetAsync(d.cs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
+    }
+    for (int t = 0; t <= U; ++t) {
+        hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), lds, st, d, t);
+        LAS_LAUNCHED();
+        if (t == U) break;
+        GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, I0D, 1.f, d.xin0 + (size_t)t * B * I0D, I0D, 0, f->cellW[0], GD, 0, 0.f,
+                         d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+        for (int l = 1; l < NL; ++l) {
+            hipLaunchKernelGGL((dec_pointwise_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, l - 1, t);
+            LAS_LAUNCHED();
+            float* gl = d.gates + ((size_t)l * U + t) * B * GD;
+            GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, D, 1.f, d.hs + ((size_t)(l - 1) * (U + 1) + t + 1) * B * D, D, 0,
+                             f->cellW[l], GD, 0, 0.f, gl, GD, 0, f->cellb[l], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+            GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, D, 1.f, d.hs + ((size_t)l * (U + 1) + t) * B * D, D, 0,
+                             f->cellW[l] + (size_t)D * GD, GD, 0, 1.f, gl, GD, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+        }
+    }
+    if (!d.step_logits) {  // vocab projection of all steps at once (dense MFMA work): las/las.py:156-158
+        GEMM_OK(las_gemm(f->prec, 0, 0, U * B, V, D, 1.f, d.hs + ((size_t)(NL - 1) * (U + 1) + 1) * B * D, D, 0, d.Wv, V, 0,
+                         0.f, d.logits, V, 0, d.bv, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+    }
+    return 0;
+}
+
+extern "C" int las_speller_fwd(const las_speller_fwd_args* f, void* stream) {
+    DecDev d;
+    if (int rc = fill_dev(f, d)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = f->prec == LAS_PREC_BF16;
+    if (f->cell == LAS_CELL_LSTM)
+        return fast ? speller_fwd_impl<LAS_CELL_LSTM, true>(f, d, st) : speller_fwd_impl<LAS_CELL_LSTM, false>(f, d, st);
+    return fast ? speller_fwd_impl<LAS_CELL_RNN, true>(f, d, st) : speller_fwd_impl<LAS_CELL_RNN, false>(f, d, st);
+}
+
+template <int CELL, bool FAST>
+static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_t st) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const las_speller_fwd_args* f = &bk->f;
+    const int B = d.B, D = d.D, NL = d.NL, U = d.U, E = d.E, Hd = d.Hd, V = d.V, A = d.A, Tp = d.Tp;
+    const int GD = G * D, I0D = E + Hd + D, TOP = NL - 1, prec = f->prec;
+    const bool loc = d.mode == LAS_ATT_LOC;
+    const BwdWs w = bwd_layout(B, Tp, Hd, A, D, NL, E, V, U, G, d.Kc, d.C);
+    LAS_ARG(f->ws && f->ws_bytes >= w.total, "las_speller_bwd: workspace too small (%zu < %zu)", f->ws_bytes, w.total);
+    char* base = (char*)f->ws;
+    float* dHl = (float*)(base + w.dHl);
+    d.dHl = dHl; d.dH = (float*)(base + w.dH); d.dC = (float*)(base + w.dC); d.dXin0 = (float*)(base + w.dXin0);
+    d.Q = (float*)(base + w.Q); d.dQ = (float*)(base + w.dQ); d.duRows = (float*)(base + w.duRows);
+    d.dAext = (float*)(base + w.dAext); d.dKeys = bk->d_keys;
+    d.dlocwRows = (float*)(base + w.dlocw); d.dlocbRows = (float*)(base + w.dlocb); d.dWfRows = (float*)(base + w.dWf);
+    float* tmp = (float*)(base + w.tmp);          // [NL][B][2D] input/recurrent grads of layers >= 1
+    void* gws = base + w.gemm;
+    const size_t gws_bytes = f->ws_bytes - w.gemm;
+    const size_t lds = row_lds_bytes(d, true);
+    LAS_ARG(lds <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
+
+    d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
+    for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
+
+    LAS_HIP(hipMemsetAsync(base + w.dH, 0, w.dXin0 - w.dH, st));                      // dH, dC
+    LAS_HIP(hipMemsetAsync(base + w.duRows, 0, w.gemm - w.duRows, st));               // duRows .. dWfRows (incl. tmp)
+    // dlogits . Wv^T for every step, and the queries Q = S . Ws, as dense GEMMs up front
+    GEMM_OK(las_gemm(prec, 0, 1, U * B, D, V, 1.f, bk->dlogits, V, 0, d.Wv, V, 0, 0.f, dHl, D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0,
+                     nullptr, 0, st));
+    for (int l = 0; l < NL; ++l)
+        GEMM_OK(las_gemm(prec, 0, 0, U * B, A, D, 1.f, d.hs + (size_t)l * (U + 1) * B * D, D, 0, d.Ws + (size_t)l * D * A, A, 0,
+                         l ? 1.f : 0.f, d.Q, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+
+    for (int t = U - 1; t >= -1; --t) {
+        DecDev ds = d;
+        if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
+        hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST>), dim3(B), dim3(256), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        LAS_LAUNCHED();
+        if (t < 0) break;
+        for (int l = TOP; l >= 0; --l) {
+            const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
+            if (l == 0) {
+                GEMM_OK(las_gemm(prec, 0, 1, B, I0D, GD, 1.f, dG, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0 + (size_t)t * B * I0D,
+                                 I0D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+            } else {
+                float* tl = tmp + (size_t)l * B * 2 * D;
+                GEMM_OK(las_gemm(prec, 0, 1, B, 2 * D, GD, 1.f, dG, GD, 0, f->cellW[l], GD, 0, 0.f, tl, 2 * D, 0, nullptr,
+                                 LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+                hipLaunchKernelGGL((dec_pointwise_bwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, l - 1, t, (const float*)tl, 2 * D);
+                LAS_LAUNCHED();
+            }
+        }
+    }
+
+    // ---- weight gradients: one tall contraction each (K = U*B), deterministic split-K
+    const int UB = U * B;
+    GEMM_OK(las_gemm(prec, 1, 0, I0D, GD, UB, 1.f, d.xin0, I0D, 0, d.gates, GD, 0, 1.f, bk->dcellW[0], GD, 0, nullptr,
+                     LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
+    for (int l = 0; l < NL; ++l) {
+        const float* dG = d.gates + (size_t)l * U * B * GD;
+        GEMM_OK(las_colsum(dG, UB, GD, GD, 1.f, bk->dcellb[l], gws, gws_bytes, st));
+        if (l > 0) {
+            GEMM_OK(las_gemm(prec, 1, 0, D, GD, UB, 1.f, d.hs + ((size_t)(l - 1) * (U + 1) + 1) * B * D, D, 0, dG, GD, 0, 1.f,
+                             bk->dcellW[l], GD, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
+            GEMM_OK(las_gemm(prec, 1, 0, D, GD, UB, 1.f, d.hs + (size_t)l * (U + 1) * B * D, D, 0, dG, GD, 0, 1.f,
+                             bk->dcellW[l] + (size_t)D * GD, GD, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
+        }
+        GEMM_OK(las_gemm(prec, 1, 0, D, A, UB, 1.f, d.hs + (size_t)l * (U + 1) * B * D, D, 0, d.dQ, A, 0, 1.f,
+                         bk->dWs + (size_t)l * D * A, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
+    }
+    GEMM_OK(las_gemm(prec, 1, 0, D, V, UB, 1.f, d.hs + ((size_t)TOP * (U + 1) + 1) * B * D, D, 0, bk->dlogits, V, 0, 1.f,
+                     bk->dWv, V, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
+    GEMM_OK(las_colsum(bk->dlogits, UB, V, V, 1.f, bk->dbv, gws, gws_bytes, st));
+    GEMM_OK(las_colsum(d.duRows, B, A, A, 1.f, bk->du, gws, gws_bytes, st));
+    hipLaunchKernelGGL(emb_grad_kernel, dim3(V), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D, E, bk->demb);
+    LAS_LAUNCHED();
+    // d_enc[b] += alphas[:,b,:]^T . dctx[:,b,:]   (batched over utterances; contraction over the U steps)
+    GEMM_OK(las_gemm(prec, 1, 0, Tp, Hd, U, 1.f, d.alphas, B * Tp, Tp, d.dXin0 + E, B * I0D, I0D, 1.f, bk->d_enc, Hd,
+                     (long long)Tp * Hd, nullptr, LAS_ACT_NONE, B, 0, 0, nullptr, 0, st));
+    if (loc) {
+        GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
+        GEMM_OK(las_colsum(d.dlocbRows, B, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
+        GEMM_OK(las_colsum(d.dWfRows, B * 8, d.C * A, d.C * A, 1.f, bk->dWf, gws, gws_bytes, st));
+    }
+    return 0;
+}
+
+extern "C" int las_speller_bwd(const las_speller_bwd_args* bk, void* stream) {
+    LAS_ARG(bk, "las_speller_bwd: null args");
+    DecDev d;
+    if (int rc = fill_dev(&bk->f, d)) return rc;
+    LAS_ARG(bk->dlogits && bk->d_enc && bk->d_keys && bk->dWs && bk->du && bk->demb && bk->dWv && bk->dbv && bk->dcellW && bk->dcellb,
+            "las_speller_bwd: null gradient pointer");
+    LAS_ARG(bk->f.mode == LAS_ATT_ADD || (bk->dloc_w && bk->dloc_b && bk->dWf), "las_speller_bwd: null location gradient pointer");
+    LAS_ARG((((uintptr_t)bk->d_keys) & 15) == 0, "las_speller_bwd: d_keys must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = bk->f.prec == LAS_PREC_BF16;
+    if (bk->f.cell == LAS_CELL_LSTM)
+        return fast ? speller_bwd_impl<LAS_CELL_LSTM, true>(bk, d, st) : speller_bwd_impl<LAS_CELL_LSTM, false>(bk, d, st);
+    return fast ? speller_bwd_impl<LAS_CELL_RNN, true>(bk, d, st) : speller_bwd_impl<LAS_CELL_RNN, false>(bk, d, st);
+}

@@ -22,14 +22,16 @@ _lib = None
 
 
 class SpellerFwdArgs(Structure):
-    _fields_ = [(n, c_int) for n in ("B", "Tp", "Hd", "A", "D", "NL", "E", "V", "U", "cell", "mode", "prec", "Kc", "C")] + [
+    _fields_ = [(n, c_int) for n in ("B", "Tp", "Hd", "A", "D", "NL", "E", "V", "U", "cell", "mode", "prec", "Kc", "C",
+                                     "step_logits", "keep_state0")] + [
+        ("forget_bias", c_float), ("seed", ctypes.c_ulonglong),
         ("enc", c_void_p), ("keys", c_void_p), ("enc_len", c_void_p),
         ("Ws", c_void_p), ("u", c_void_p), ("emb", c_void_p), ("Wv", c_void_p), ("bv", c_void_p),
         ("loc_w", c_void_p), ("loc_b", c_void_p), ("Wf", c_void_p),
         ("cellW", POINTER(c_void_p)), ("cellb", POINTER(c_void_p)),
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
-        ("logits", c_void_p), ("alphas", c_void_p),
-        ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("ctx", c_void_p), ("xin0", c_void_p),
+        ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p),
+        ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p),
         ("ws", c_void_p), ("ws_bytes", c_size_t)]
 
 
@@ -59,8 +61,9 @@ _SIGS = {
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
-    "las_ce_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
-                            c_void_p, c_void_p]),
+    "las_ce_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "las_ce_loss": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_sumsq_workspace_bytes": (c_size_t, [c_longlong]),
     "las_sumsq": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,

@@ -1,0 +1,561 @@
+"""las.las -- Listener / Attention / Speller / LAS with the reference's construction API
+(reference las/las.py) on the MI355X engine.
+
+Semantic shift: the reference builds a TF graph once (`las.train(xs, ys)` at
+train.py:75) and `sess.run`s its handles; here `LAS.train(xs, ys)` EXECUTES one optimisation step and
+returns the same 7-tuple with concrete values, `LAS.inference(xs)` executes greedy decoding.  All
+arithmetic runs in liblas_hip.so (`las._hip`); there is no CPU path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from las import _hip
+from las import layers as L
+from las import variables as V
+from las.layers import AdditiveAttention, LocationAwareAttention, pBLSTMLayer, CNNLayer  # noqa: F401
+from las.utils import convert_idx_to_token_tensor
+
+SOS_ID = 1  # tf.ones(...) look-up at reference las/las.py:81
+
+
+class Listener:
+    """reference las/las.py:6-36."""
+
+    def __init__(self, args):
+        self.args = args
+
+    def __call__(self, inputs, audiolen, encoder='cnn', is_training=True):
+        if encoder == 'pblstm':
+            x = inputs.reshape(inputs.shape[0], -1, self.args.feat_dim * 3)            # las/las.py:14
+            # NB the reference passes a 7th positional `apply_bn` here (las/las.py:15-21) which
+            # pBLSTMLayer's signature (las/layers.py:56) does not accept; dropped.
+            enc_out, enc_state, enc_len = pBLSTMLayer(x, audiolen, self.args.num_enc_layers, self.args.enc_units,
+                                                      self.args.dropout_rate, is_training, scope="Listener")
+        elif encoder == 'cnn':
+            enc_out, enc_state, enc_len = CNNLayer(inputs, audiolen, self.args.num_enc_layers, self.args.feat_dim,
+                                                   self.args.enc_units, self.args.num_enc_channels,
+                                                   self.args.dropout_rate, self.args.apply_bn, is_training)
+        else:
+            raise NotImplementedError
+        return enc_out, enc_state, enc_len
+
+
+class Attention:
+    """reference las/las.py:39-54."""
+
+    def __init__(self, h_dim, s_dim, att_size, kernel_size, num_channels, mode='add'):
+        self.mode = mode
+        if self.mode == 'add':
+            self.att_layer = AdditiveAttention(h_dim, s_dim, att_size)
+        elif self.mode == 'loc':
+            self.att_layer = LocationAwareAttention(h_dim, s_dim, att_size, kernel_size, num_channels)
+        else:
+            raise NotImplementedError
+
+    def __call__(self, hidden, state, align, seqlen):
+        return self.att_layer(hidden, state, align, seqlen)
+
+
+# ------------------------------------------------------------------------------------------------
+# the fused decode loop
+# ------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
+                   keep_state0=False, align0=None):
+    for k, v in dims.items():
+        setattr(fa, k, v)
+    fa.step_logits = int(step_logits)
+    fa.keep_state0 = int(keep_state0)
+    fa.forget_bias = 1.0
+    fa.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    fa.enc, fa.keys, fa.enc_len = enc.data_ptr(), keys.data_ptr(), enc_len_i32.data_ptr()
+    fa.Ws, fa.u, fa.emb = P["Ws"].data_ptr(), P["u"].data_ptr(), P["emb"].data_ptr()
+    fa.Wv, fa.bv = P["Wv"].data_ptr(), P["bv"].data_ptr()
+    if dims["mode"] == _hip.ATT_LOC:
+        fa.loc_w, fa.loc_b, fa.Wf = P["loc_w"].data_ptr(), P["loc_b"].data_ptr(), P["Wf"].data_ptr()
+    else:
+        fa.loc_w = fa.loc_b = fa.Wf = None
+    keep = (_ptr_array(P["cellW"]), _ptr_array(P["cellb"]))   # caller must hold these until the C call returns
+    fa.cellW, fa.cellb = keep
+    fa.tokens_in = tokens_in.data_ptr()
+    fa.tokens_out = tokens_out.data_ptr() if tokens_out is not None else None
+    fa.logits, fa.alphas = bufs["logits"].data_ptr(), bufs["alphas"].data_ptr()
+    fa.align0 = align0.data_ptr() if align0 is not None else None
+    fa.hs = bufs["hs"].data_ptr()
+    fa.cs = bufs["cs"].data_ptr() if bufs["cs"] is not None else None
+    fa.gates, fa.xin0 = bufs["gates"].data_ptr(), bufs["xin0"].data_ptr()
+    fa.ws, fa.ws_bytes = None, 0
+    return keep
+
+
+def _alloc_bufs(dims, dev):
+    B, Tp, Hd, D, NL, E, V_, U = (dims[k] for k in ("B", "Tp", "Hd", "D", "NL", "E", "V", "U"))
+    G = 4 if dims["cell"] == _hip.CELL_LSTM else 1
+    return {
+        "logits": torch.empty(U, B, V_, device=dev), "alphas": torch.empty(U, B, Tp, device=dev),
+        "hs": torch.empty(NL, U + 1, B, D, device=dev),
+        "cs": torch.empty(NL, U + 1, B, D, device=dev) if G == 4 else None,
+        "gates": torch.empty(NL, U, B, G * D, device=dev), "xin0": torch.empty(U, B, E + Hd + D, device=dev),
+    }
+
+
+class _SpellerLoop(torch.autograd.Function):
+    """K4 (hoisted key projection) + las_speller_fwd / las_speller_bwd."""
+
+    @staticmethod
+    def forward(ctx, enc, Wh, Ws, u, emb, Wv, bv, loc_w, loc_b, Wf, cfg, enc_len_i32, tokens_in, *cell_params):
+        dims, prec, step_logits, seed = cfg
+        dev = enc.device
+        enc = enc.contiguous()
+        B, Tp, Hd = enc.shape
+        A = Wh.shape[1]
+        NL = dims["NL"]
+        keys = torch.empty(B, Tp, A, device=dev)
+        _hip.gemm(prec, enc, Wh, keys, False, False, B * Tp, A, Hd, Hd, A, A)          # dense(hidden), hoisted
+        P = {"Ws": Ws, "u": u, "emb": emb, "Wv": Wv, "bv": bv, "loc_w": loc_w, "loc_b": loc_b, "Wf": Wf,
+             "cellW": list(cell_params[:NL]), "cellb": list(cell_params[NL:])}
+        bufs = _alloc_bufs(dims, dev)
+        tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
+        fa = _hip.SpellerFwdArgs()
+        keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
+        _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+        del keep
+        ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed)
+        ctx.mark_non_differentiable(bufs["alphas"])
+        ctx.tokens_out = tokens_out
+        return bufs["logits"], bufs["alphas"]
+
+    @staticmethod
+    def backward(ctx, dlogits, _dalphas):
+        enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed = ctx.saved
+        dev = enc.device
+        B, Tp, Hd = enc.shape
+        A = Wh.shape[1]
+        NL, U, V_ = dims["NL"], dims["U"], dims["V"]
+        dlogits = dlogits.contiguous()
+        z = lambda t: torch.zeros_like(t)
+        d_enc = torch.zeros(B, Tp, Hd, device=dev)
+        d_keys = torch.zeros(B, Tp, A, device=dev)
+        g = {"Ws": z(P["Ws"]), "u": z(P["u"]), "emb": z(P["emb"]), "Wv": z(P["Wv"]), "bv": z(P["bv"])}
+        loc = dims["mode"] == _hip.ATT_LOC
+        if loc:
+            g.update(loc_w=z(P["loc_w"]), loc_b=z(P["loc_b"]), Wf=z(P["Wf"]))
+        dcW = [z(t) for t in P["cellW"]]
+        dcb = [z(t) for t in P["cellb"]]
+        nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], V_, U, dims["cell"])
+        ws = _hip.workspace(dev, nbytes, "speller")
+        ba = _hip.SpellerBwdArgs()
+        keepf = _fill_fwd_args(ba.f, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
+        ba.f.ws, ba.f.ws_bytes = ws.data_ptr(), ws.numel()
+        ba.dlogits = dlogits.data_ptr()
+        ba.d_enc, ba.d_keys = d_enc.data_ptr(), d_keys.data_ptr()
+        ba.dWs, ba.du, ba.demb, ba.dWv, ba.dbv = (g[k].data_ptr() for k in ("Ws", "u", "emb", "Wv", "bv"))
+        if loc:
+            ba.dloc_w, ba.dloc_b, ba.dWf = g["loc_w"].data_ptr(), g["loc_b"].data_ptr(), g["Wf"].data_ptr()
+        keep = (_ptr_array(dcW), _ptr_array(dcb))
+        ba.dcellW, ba.dcellb = keep
+        _hip.check(_hip.lib().las_speller_bwd(ctypes.byref(ba), _hip.stream()), "las_speller_bwd")
+        del keep, keepf
+        # key projection backward (K4): dWh = enc^T . d_keys ; d_enc += d_keys . Wh^T
+        dWh = torch.empty_like(Wh)
+        _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A)
+        _hip.gemm(prec, d_keys, Wh, d_enc, False, True, B * Tp, Hd, A, A, A, Hd, beta=1.0)
+        return (d_enc, dWh, g["Ws"], g["u"], g["emb"], g["Wv"], g["bv"], g.get("loc_w"), g.get("loc_b"), g.get("Wf"),
+                None, None, None, *dcW, *dcb)
+
+
+class Speller:
+    """reference las/las.py:57-207."""
+
+    def __init__(self, args):
+        self.args = args
+        # reference: hidden_dim = enc_units (las/las.py:61) although pBLSTMLayer emits 2*enc_units
+        # (las/layers.py:66) -- SURVEY quirk Q2.  The pblstm listener needs 2*enc_units.
+        self.hidden_dim = self.args.enc_units * (2 if str(getattr(args, "enc_type", "cnn")).lower() == "pblstm" else 1)
+        self.state_dim = self.args.dec_units * self.args.num_dec_layers
+        self.cell = L.get_cell()
+        self._build_decoder_cell()
+        self._build_embeddings()
+        self.att_layer = Attention(h_dim=self.hidden_dim, s_dim=self.state_dim, att_size=self.args.attention_size,
+                                   kernel_size=self.args.loc_kernel_size, num_channels=self.args.loc_num_channels,
+                                   mode=self.args.mode)
+        self.last_tokens_out = None
+
+    # -- variables ---------------------------------------------------------------------------------
+    def _build_decoder_cell(self):
+        """las/las.py:191-199: BasicRNNCell(dec_units) or MultiRNNCell of them (or the LSTM variant)."""
+        a = self.args
+        G = 4 if self.cell == "lstm" else 1
+        cs = L.cell_scope(self.cell)
+        self.dec_cell = []
+        self._cell_shapes = []
+        for l in range(a.num_dec_layers):
+            I = (a.embedding_size + self.hidden_dim) if l == 0 else a.dec_units
+            base = ("Speller/decode/%s/" % cs) if a.num_dec_layers == 1 else \
+                ("Speller/decode/multi_rnn_cell/cell_%d/%s/" % (l, cs))
+            self._cell_shapes.append((base, (I + a.dec_units, G * a.dec_units)))
+
+    def _build_embeddings(self):
+        """las/las.py:201-207 (scope 'embedding', U(-1,1))."""
+        self._emb_shape = (self.args.vocab_size, self.args.embedding_size)
+
+    @property
+    def embedding_matrix(self):
+        return V.default_store().get("embedding/embedding_matrix", self._emb_shape, init="uniform1")
+
+    def _params(self):
+        st = V.default_store()
+        a = self.args
+        P = dict(self.att_layer.att_layer.params())
+        P["emb"] = self.embedding_matrix
+        P["cellW"] = [st.get(b + "kernel", s) for b, s in self._cell_shapes]
+        P["cellb"] = [st.get(b + "bias", (s[1],), init="zeros") for b, s in self._cell_shapes]
+        P["Wv"] = st.get("Speller/decode/dense/kernel", (a.dec_units, a.vocab_size))
+        P["bv"] = st.get("Speller/decode/dense/bias", (a.vocab_size,), init="zeros")
+        return P
+
+    def _dims(self, B, Tp, U):
+        a = self.args
+        return {"B": B, "Tp": Tp, "Hd": self.hidden_dim, "A": a.attention_size, "D": a.dec_units,
+                "NL": a.num_dec_layers, "E": a.embedding_size, "V": a.vocab_size, "U": int(U),
+                "cell": L._cellid(self.cell), "mode": _hip.ATT_LOC if a.mode == "loc" else _hip.ATT_ADD,
+                "prec": L._prec(), "Kc": a.loc_kernel_size if a.mode == "loc" else 0,
+                "C": a.loc_num_channels if a.mode == "loc" else 0}
+
+    # -- schedules ---------------------------------------------------------------------------------
+    def _scheduled_sampling(self, step=None):
+        """las/las.py:177-183 (float32 arithmetic as in the TF graph)."""
+        a = self.args
+        step = np.float32(V.default_store().global_step if step is None else step)
+        progress = min((step - np.float32(a.warmup_step)) / np.float32(float(a.max_step - a.warmup_step)), np.float32(1.0))
+        return float(min(np.float32(1.0), np.float32(1.0) - np.float32(progress) * np.float32(1.0 - a.min_rate)))
+
+    # -- the loop ----------------------------------------------------------------------------------
+    def __call__(self, enc_out, enc_len, dec_steps, teacher=None, is_training=True, coins=None, sampled=None):
+        """reference las/las.py:72-143.  Returns (logits [B,U,V], ctc_logits, alphas [B,U,T']).
+
+        coins / sampled are test hooks: coins[t] True = teacher forcing at step t (one scalar coin
+        per step for the whole batch, las/las.py:101); sampled [B,U] supplies the Categorical draws."""
+        a = self.args
+        _hip.require_gpu(enc_out)
+        if a.ctc:
+            raise NotImplementedError("CTC head (las/las.py:75-77,335-349): README 'not yet fully tested', out of scope (SURVEY T5)")
+        if a.add_vn:
+            raise NotImplementedError("variational noise (las/las.py:164-166) is not built yet")
+        if is_training and a.dropout_rate:
+            raise NotImplementedError("embedding dropout (las/las.py:107-108) is not built yet; use --dropout_rate 0")
+        dev = enc_out.device
+        B, Tp, _ = enc_out.shape
+        U = int(dec_steps)
+        enc_len_i32 = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).to(dev).contiguous()   # las/layers.py:193
+        st = V.default_store()
+        tokens_in = torch.full((U, B), -1, dtype=torch.int32, device=dev)
+        tokens_in[0] = SOS_ID
+        step_logits = True
+        if is_training:
+            tf_rate = self._scheduled_sampling() if a.scheduled_sampling else 1.0          # las/las.py:87-90
+            y = torch.as_tensor(teacher).to(dev).to(torch.int32)
+            if coins is None:
+                # one coin per step, shared by every data-parallel rank (seeded by the global step)
+                rng = np.random.RandomState((1234567 + 7919 * st.global_step) % (2 ** 31))
+                coins = tf_rate > rng.uniform(0.0, 1.0, size=U).astype(np.float32)
+            coins = np.asarray(coins, bool)
+            if U > 1:
+                tokens_in[1:] = y[:, :U - 1].t()
+                if not coins[:U - 1].all():
+                    idx = torch.as_tensor(np.nonzero(~coins[:U - 1])[0] + 1, device=dev)
+                    if sampled is not None:
+                        sm = torch.as_tensor(sampled).to(dev).to(torch.int32)
+                        tokens_in[idx] = sm[:, :U - 1].t()[idx - 1]
+                    else:
+                        tokens_in[idx] = -2
+            step_logits = bool((tokens_in < 0).any().item()) if not coins[:max(U - 1, 0)].all() else False
+        P = self._params()
+        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, 977 + st.global_step)
+        cp = list(P["cellW"]) + list(P["cellb"])
+        logits_tm, alphas_tm = _SpellerLoop.apply(enc_out, P["Wh"], P["Ws"], P["u"], P["emb"], P["Wv"], P["bv"],
+                                                  P.get("loc_w"), P.get("loc_b"), P.get("Wf"), cfg, enc_len_i32,
+                                                  tokens_in, *cp)
+        self.last_tokens_in = tokens_in
+        return logits_tm.permute(1, 0, 2), None, alphas_tm.permute(1, 0, 2)
+
+    def decode(self, enc_out, enc_len, dec_state, prev_token, prev_align, is_training, keys=None, token_ids=None):
+        """One decode step, reference las/las.py:145-160 -- forward only (beam search).
+
+        dec_state: tuple over layers of h [N,D] (rnn) or (c,h) (lstm).  prev_token: embedded token
+        [N,E] (as `_look_up` returns) -- or pass token_ids to skip the host-side embedding match.
+        Returns (cur_token logits [N,V], new dec_state, alphas [N,T'])."""
+        return _decode_step(self, enc_out, enc_len, dec_state, prev_token, prev_align, keys, token_ids)
+
+    def _look_up(self, token):
+        """las/las.py:162-168 (add_vn unsupported)."""
+        return self.embedding_matrix.detach()[torch.as_tensor(token).long()]
+
+    def _get_hidden_state(self, dec_state):
+        """las/las.py:185-189: concat of the layers' states (h only for the lstm variant)."""
+        hs = [s if not isinstance(s, (tuple, list)) else s[1] for s in dec_state]
+        return torch.cat(hs, -1)
+
+    def zero_state(self, n, device):
+        D, NL = self.args.dec_units, self.args.num_dec_layers
+        z = lambda: torch.zeros(n, D, device=device)
+        return tuple((z(), z()) if self.cell == "lstm" else z() for _ in range(NL))
+
+
+def _decode_step(sp, enc_out, enc_len, dec_state, prev_token, prev_align, keys=None, token_ids=None):
+    a = sp.args
+    dev = enc_out.device
+    N, Tp, Hd = enc_out.shape
+    P = sp._params()
+    prec = L._prec()
+    enc = enc_out.contiguous()
+    if keys is None:
+        keys = torch.empty(N, Tp, a.attention_size, device=dev)
+        _hip.gemm(prec, enc, P["Wh"].detach(), keys, False, False, N * Tp, a.attention_size, Hd, Hd, a.attention_size,
+                  a.attention_size)
+    dims = sp._dims(N, Tp, 1)
+    bufs = _alloc_bufs(dims, dev)
+    for l, s in enumerate(dec_state):
+        if sp.cell == "lstm":
+            bufs["cs"][l, 0].copy_(s[0])
+            bufs["hs"][l, 0].copy_(s[1])
+        else:
+            bufs["hs"][l, 0].copy_(s)
+    if token_ids is None:
+        # recover the id from the embedded vector (API parity with the reference's decode signature)
+        emb = P["emb"].detach()
+        token_ids = torch.cdist(prev_token.to(dev), emb).argmin(-1)
+    tokens_in = torch.as_tensor(token_ids).to(dev).to(torch.int32).reshape(1, N).contiguous()
+    tokens_out = torch.zeros(1, N, dtype=torch.int32, device=dev)
+    enc_len_i32 = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).to(dev).contiguous()
+    align0 = None if prev_align is None else torch.as_tensor(prev_align).to(dev).float().contiguous()
+    fa = _hip.SpellerFwdArgs()
+    Pd = {k: (v.detach() if torch.is_tensor(v) else [t.detach() for t in v]) for k, v in P.items()}
+    keep = _fill_fwd_args(fa, dims, Pd, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, True, 0, keep_state0=True,
+                          align0=align0)
+    _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+    del keep
+    NL = a.num_dec_layers
+    if sp.cell == "lstm":
+        new_state = tuple((bufs["cs"][l, 1], bufs["hs"][l, 1]) for l in range(NL))
+    else:
+        new_state = tuple(bufs["hs"][l, 1] for l in range(NL))
+    return bufs["logits"][0], new_state, bufs["alphas"][0]
+
+
+def attention_forward_step(att, hidden, state, align, seqlen):
+    """AdditiveAttention / LocationAwareAttention.__call__ (reference las/layers.py:234-257 / :281-311) for ONE
+    step, forward only, through the same fused row kernel as the Speller loop (U=1, throw-away cell)."""
+    dev = hidden.device
+    _hip.require_gpu(hidden, state)
+    N, Tp, Hd = hidden.shape
+    P = att.params()
+    A = att.att_size
+    S = att.s_dim
+    prec = L._prec()
+    enc = hidden.contiguous()
+    keys = torch.empty(N, Tp, A, device=dev)
+    _hip.gemm(prec, enc, P["Wh"].detach(), keys, False, False, N * Tp, A, Hd, Hd, A, A)
+    E, Vv = 4, 4
+    loc = att.mode == "loc"
+    dims = {"B": N, "Tp": Tp, "Hd": Hd, "A": A, "D": S, "NL": 1, "E": E, "V": Vv, "U": 1, "cell": _hip.CELL_RNN,
+            "mode": _hip.ATT_LOC if loc else _hip.ATT_ADD, "prec": prec, "Kc": att.kernel_size if loc else 0,
+            "C": att.num_channels if loc else 0}
+    bufs = _alloc_bufs(dims, dev)
+    bufs["hs"][0, 0].copy_(state.reshape(N, S))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    Pd = {"Ws": P["Ws"].detach(), "u": P["u"].detach(), "emb": z(Vv, E), "Wv": z(S, Vv), "bv": z(Vv),
+          "cellW": [z(E + Hd + S, S)], "cellb": [z(S)]}
+    if loc:
+        Pd.update(loc_w=P["loc_w"].detach(), loc_b=P["loc_b"].detach(), Wf=P["Wf"].detach())
+    tokens_in = torch.zeros(1, N, dtype=torch.int32, device=dev)
+    enc_len_i32 = torch.as_tensor(seqlen).to(torch.float64).to(torch.int32).to(dev).contiguous()
+    align0 = None if (align is None or not loc) else torch.as_tensor(align).to(dev).float().contiguous()
+    fa = _hip.SpellerFwdArgs()
+    keep = _fill_fwd_args(fa, dims, Pd, enc, keys, enc_len_i32, tokens_in, None, bufs, False, 0, keep_state0=True,
+                          align0=align0)
+    _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+    del keep
+    return bufs["xin0"][0, :, E:E + Hd], bufs["alphas"][0]
+
+
+# ------------------------------------------------------------------------------------------------
+# loss / optimiser
+# ------------------------------------------------------------------------------------------------
+class _CELoss(torch.autograd.Function):
+    """K8: label-smoothed masked CE over the Speller's time-major logits, value + gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, logits_bt, y_i32, V_, smooth, scale):
+        # logits_bt is the [B,U,V] VIEW of the time-major buffer; consume it in place through strides
+        B, U, _ = logits_bt.shape
+        sb, st_, sv = logits_bt.stride()
+        assert sv == 1
+        dev = logits_bt.device
+        sums = torch.zeros(2, device=dev)
+        dl = torch.empty_strided(logits_bt.shape, logits_bt.stride(), device=dev)
+        nb = _hip.lib().las_ce_loss_workspace_bytes(B, U)
+        ws = _hip.workspace(dev, nb, "ce")
+        _hip.check(_hip.lib().las_ce_loss(_hip.p(logits_bt), sb, st_, _hip.p(y_i32), y_i32.shape[1], B, U, V_, 0.01,
+                                          int(bool(smooth)), _hip.p(sums), _hip.p(scale), _hip.p(dl), _hip.p(ws), ws.numel(),
+                                          _hip.stream()), "las_ce_loss")
+        ctx.save_for_backward(dl)
+        ctx.sums = sums
+        return sums[0] * scale[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None
+
+
+class LAS:
+    """reference las/las.py:209-369."""
+
+    def __init__(self, args, Listener, Speller, id_to_token):
+        self.args = args
+        self.listener = Listener(args)
+        self.speller = Speller(args)
+        self.id_to_token = id_to_token
+        self.dp = None            # optional las.parallel.DataParallel (set by train.py)
+        self.last = {}
+
+    # -- helpers -----------------------------------------------------------------------------------
+    @staticmethod
+    def _to_dev(x, dev, dtype=None):
+        t = torch.as_tensor(x)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(dev)
+
+    def _device(self):
+        st = V.default_store()
+        if st.device is None:
+            st.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if st.device is None or st.device.type != "cuda":
+            raise RuntimeError("LAS needs a ROCm device: the hot path runs in liblas_hip.so and has no CPU fallback")
+        return st.device
+
+    def build_variables(self):
+        """Create every variable up front (all shapes follow from args) and flatten the store, so that
+        parameters, gradients and Adam slots live in flat buckets before the first step."""
+        st = V.default_store()
+        if st.flat is not None:
+            return
+        self._device()
+        a = self.args
+        if a.enc_type.lower() == "pblstm":
+            H = a.enc_units
+            cell = L.get_cell()
+            scopes = ["Listener/blstm"] + ["Listener/pyramid_blstm_%d" % l for l in range(a.num_enc_layers)]
+            for i, sc in enumerate(scopes):
+                L._blstm_params(sc, a.feat_dim * 3 if i == 0 else 2 * H, H, cell)
+                st.get(sc + "/dense/kernel", (2 * H if i == 0 else 4 * H, 2 * H))
+                st.get(sc + "/dense/bias", (2 * H,), init="zeros")
+        self.speller._params()
+        st.flatten()
+
+    def _get_loss(self, logits, y, n_total=None):
+        """las/las.py:320-333.  n_total (device scalar) overrides the local non-PAD count so that
+        data-parallel ranks normalise by the GLOBAL token count."""
+        B, U, V_ = logits.shape
+        y = y[:, :U].contiguous()
+        if n_total is None:
+            n_total = (y != 0).sum().to(torch.float32)
+        scale = (1.0 / (n_total + 1e-9)).reshape(1).to(torch.float32)
+        return _CELoss.apply(logits, y, V_, self.args.label_smoothing, scale)
+
+    def _scheduled_learning_rate(self, start=50000, decay_step=100000, decay_rate=0.5, min_rate=0.01, global_step=0):
+        """las/las.py:351-369 (non-staircase exponential decay)."""
+        gs = max(global_step - start, 0)
+        return max(self.args.lr * decay_rate ** (gs / decay_step), min_rate * self.args.lr)
+
+    # -- one optimisation step ---------------------------------------------------------------------
+    def train(self, xs, ys, coins=None, sampled=None):
+        """reference las/las.py:226-304, executed eagerly.
+
+        Returns (loss, train_op, global_step, logits, alphas, summaries, sample_rate) -- `train_op`
+        is None (the update has already been applied), `summaries` a dict of the quantities the
+        reference attaches to tf.summary (las/las.py:292-299)."""
+        dev = self._device()
+        st = V.default_store()
+        self.build_variables()
+        audio, audiolen = xs
+        y, tokenlen = ys
+        audio = self._to_dev(audio, dev, torch.float32)
+        y = self._to_dev(y, dev, torch.int32)
+        dec_steps = int(torch.as_tensor(tokenlen).max())                                  # las/las.py:248
+        enc_type = self.args.enc_type.lower()
+        h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)                  # is_training default True
+        logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled)
+
+        n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
+        n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
+        loss = self._get_loss(logits, y, n_total)                                         # sum_local / n_total
+
+        st.flatten()
+        st.zero_grad()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.all_reduce_(st.flat_grad)                                             # one flat bucket (C1)
+            loss_val = self.dp.all_reduce_scalar(loss.detach())
+        else:
+            loss_val = loss.detach()
+
+        lr = self._scheduled_learning_rate(start=50000, decay_step=100000, decay_rate=0.5, min_rate=0.01,
+                                           global_step=st.global_step)
+        self._apply_adam(st, lr)
+        st.global_step += 1
+        sample_rate = self.speller._scheduled_sampling()
+        summaries = {"loss": loss_val, "global_step": st.global_step, "lr": lr}
+        self.last = {"logits": logits, "y": y}
+        return loss_val, None, st.global_step, logits.detach(), alphas.detach(), summaries, sample_rate
+
+    def _apply_adam(self, st, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """clip_by_global_norm + Adam (las/las.py:272-283; TF epsilon-hat form)."""
+        t = st.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        n = st.flat.numel()
+        dev = st.flat.device
+        sumsq = torch.empty(1, device=dev)
+        clip = float(self.args.grad_clip)
+        lib = _hip.lib()
+        if clip > 0:
+            ws = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
+            _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(ws), ws.numel(), _hip.stream()), "las_sumsq")
+        _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n,
+                                     _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps, _hip.stream()),
+                   "las_clip_adam")
+        self.last_grad_sumsq = sumsq
+
+    def sample_texts(self):
+        """The HYP / REF strings the reference builds for its text summaries (las/las.py:286-289)."""
+        logits, y = self.last["logits"], self.last["y"]
+        hyp = convert_idx_to_token_tensor(torch.argmax(logits[0], -1).cpu().numpy(), self.id_to_token, self.args.unit)
+        ref = convert_idx_to_token_tensor(y[0].cpu().numpy(), self.id_to_token, self.args.unit)
+        return hyp, ref
+
+    # -- greedy inference --------------------------------------------------------------------------
+    def inference(self, xs):
+        """reference las/las.py:306-318.  The reference hard-codes encoder='cnn' here;
+        this build honours --enc_type so that the trained listener is the one evaluated."""
+        dev = self._device()
+        audio, audiolen = xs
+        audio = self._to_dev(audio, dev, torch.float32)
+        mx = float(torch.as_tensor(audiolen).max())
+        dec_steps = int(np.int32(np.float32(self.args.convert_rate) * np.float32(mx)))     # las/las.py:310-312
+        dec_steps = max(dec_steps, 1)
+        with torch.no_grad():
+            h, enc_state, enc_len = self.listener(audio, audiolen, encoder=self.args.enc_type.lower(), is_training=False)
+            logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, is_training=False)
+        y_hat = torch.argmax(logits, -1)
+        return logits, y_hat

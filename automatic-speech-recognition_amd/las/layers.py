@@ -1,0 +1,303 @@
+"""las.layers -- the reference's layer library (reference las/layers.py) on the MI355X engine.
+
+Same names and call signatures as the reference (`blstm`, `pBLSTMLayer`, `BaseAttention`,
+`AdditiveAttention`, `LocationAwareAttention`, ...), eager execution on ROCm tensors; every
+contraction / recurrence / attention step runs in liblas_hip.so through `las._hip` (no CPU
+fallback).  TF-1.13 variable scoping becomes names in `las.variables`.
+
+Two module-level knobs select what the reference cannot express:
+    set_cell('rnn'|'lstm')   'rnn' = tf.contrib.rnn.BasicRNNCell, what the reference actually builds
+                             (reference las/layers.py:31); 'lstm' = BasicLSTMCell (north-star).
+    set_precision('f32'|'bf16')  arithmetic of the contractions (see include/las_hip.h).
+"""
+import torch
+
+from las import _hip
+from las import variables as V
+
+_CFG = {"cell": "rnn", "prec": "f32"}
+
+
+def set_cell(cell):
+    assert cell in ("rnn", "lstm")
+    _CFG["cell"] = cell
+
+
+def set_precision(prec):
+    assert prec in ("f32", "bf16")
+    _CFG["prec"] = prec
+
+
+def get_cell():
+    return _CFG["cell"]
+
+
+def _prec():
+    return _hip.PREC_BF16 if _CFG["prec"] == "bf16" else _hip.PREC_F32
+
+
+def _cellid(cell):
+    return _hip.CELL_LSTM if cell == "lstm" else _hip.CELL_RNN
+
+
+def cell_scope(cell):
+    return "basic_lstm_cell" if cell == "lstm" else "basic_rnn_cell"
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd nodes (coarse: one node per layer, not per time step)
+# ------------------------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    """tf.layers.dense on the last axis (+ optional tanh): y = act(x.W + b)."""
+
+    @staticmethod
+    def forward(ctx, x2d, W, b, act, prec):
+        M, K = x2d.shape
+        N = W.shape[1]
+        y = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+        _hip.gemm(prec, x2d, W, y, False, False, M, N, K, K, N, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
+        ctx.save_for_backward(x2d, W, y)
+        ctx.act, ctx.prec, ctx.has_b = act, prec, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W, y = ctx.saved_tensors
+        M, K = x2d.shape
+        N = W.shape[1]
+        dy = dy.contiguous()
+        if ctx.act:
+            dpre = torch.empty_like(dy)
+            _hip.tanh_bwd(y, N, dy, N, dpre, N, M, N)
+        else:
+            dpre = dy
+        dW = torch.empty_like(W)
+        _hip.gemm(ctx.prec, x2d, dpre, dW, True, False, K, N, M, K, N, N)
+        db = None
+        if ctx.has_b:
+            db = torch.empty(N, device=dy.device, dtype=torch.float32)
+            _hip.colsum(dpre, M, N, N, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2d)
+            _hip.gemm(ctx.prec, dpre, W, dx, False, True, M, K, N, N, N, K)
+        return dx, dW, db, None, None
+
+
+def dense(x, W, b=None, tanh=False):
+    """x [..., K] -> [..., N]  (tf.layers.dense on a rank-3 input = same weights at every t, App. A.13)"""
+    _hip.require_gpu(x, W)
+    shp = x.shape
+    x2d = x.reshape(-1, shp[-1])
+    if not x2d.is_contiguous():
+        x2d = x2d.contiguous()
+    y = _Dense.apply(x2d, W, b, bool(tanh), _prec())
+    return y.view(*shp[:-1], W.shape[1])
+
+
+class _BLSTM(torch.autograd.Function):
+    """One bidirectional recurrent layer: K1 input projection + K2 persistent sweep (+ K2b BPTT)."""
+
+    @staticmethod
+    def forward(ctx, x, kfw, bfw, kbw, bbw, cell, prec, H, pad_even):
+        B, T, I = x.shape
+        G = 4 if cell == "lstm" else 1
+        GH = G * H
+        dev = x.device
+        x = x.contiguous()
+        gates = torch.empty(B, T, 2, GH, device=dev, dtype=torch.float32)
+        for d, (k, b) in enumerate(((kfw, bfw), (kbw, bbw))):
+            # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H])
+            _hip.gemm(prec, x, k, gates, False, False, B * T, GH, I, I, GH, 2 * GH, bias=b, c_off=d * GH)
+        Tp = T + (T % 2) if pad_even else T
+        out = torch.zeros(B, Tp, 2 * H, device=dev) if Tp != T else torch.empty(B, T, 2 * H, device=dev)
+        cst = torch.empty(B, T, 2, H, device=dev) if cell == "lstm" else None
+        _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
+                         1.0, wf_off=I * GH, wb_off=I * GH)
+        ctx.save_for_backward(x, kfw, kbw, gates, out, cst)
+        ctx.cfg = (cell, prec, H, Tp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, kfw, kbw, gates, out, cst = ctx.saved_tensors
+        cell, prec, H, Tp = ctx.cfg
+        B, T, I = x.shape
+        G = 4 if cell == "lstm" else 1
+        GH = G * H
+        dev = x.device
+        dout = dout.contiguous()
+        # gates: activated gates -> d(pre-activation), in place
+        _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
+                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I * GH, wb_off=I * GH)
+        grads = []
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        part = torch.empty(B, H, GH, device=dev) if T > 1 else None
+        for d, k in enumerate((kfw, kbw)):
+            dk = torch.empty_like(k)
+            # dW_ih = x^T . dG_d        (contraction over all B*T frames; split-K inside las_gemm)
+            _hip.gemm(prec, x, gates, dk, True, False, I, GH, B * T, I, 2 * GH, GH, b_off=d * GH)
+            # dW_hh = sum_b sum_t h_prev^T . dG_d : per-utterance products (fw pairs h[t-1] with dG[t],
+            # bw pairs h[t+1] with dG[t]), then a fixed-order sum over utterances
+            if T > 1:
+                a_off = d * H + (0 if d == 0 else 2 * H)
+                b_off = d * GH + (2 * GH if d == 0 else 0)
+                _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
+                          strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
+                whh = torch.empty(H * GH, device=dev)
+                _hip.colsum(part, B, H * GH, H * GH, whh)
+                dk[I:] = whh.view(H, GH)
+            else:
+                dk[I:] = 0
+            db = torch.empty(GH, device=dev)
+            _hip.colsum(gates, B * T, GH, 2 * GH, db, x_off=d * GH)
+            if dx is not None:
+                _hip.gemm(prec, gates, k, dx, False, True, B * T, I, GH, 2 * GH, GH, I, beta=1.0 if d else 0.0,
+                          a_off=d * GH)
+            grads += [dk, db]
+        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None)
+
+
+def _blstm_params(scope, I, H, cell):
+    st = V.default_store()
+    G = 4 if cell == "lstm" else 1
+    cs = cell_scope(cell)
+    out = []
+    for d in ("fw", "bw"):
+        base = "%s/bidirectional_rnn/%s/%s/" % (scope, d, cs)
+        out.append(st.get(base + "kernel", (I + H, G * H)))
+        out.append(st.get(base + "bias", (G * H,), init="zeros"))
+    return out
+
+
+def blstm(inputs, cell_units, dropout_rate, is_training, scope="blstm"):
+    """reference las/layers.py:28-54.  Returns ((out_fw, out_bw), (state_fw, state_bw)) like
+    tf.nn.bidirectional_dynamic_rnn; no sequence_length: every padded frame is run."""
+    outputs, states, _ = _blstm_full(inputs, cell_units, dropout_rate, is_training, scope)
+    return outputs, states
+
+
+def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pad_even=False):
+    """blstm() plus the already-concatenated [B,T(+pad),2H] buffer the kernels wrote (the
+    tf.concat(rnn_out, -1) of las/layers.py:69,81 is free: both directions share one tensor)."""
+    _hip.require_gpu(inputs)
+    if is_training is True and dropout_rate:
+        raise NotImplementedError("DropoutWrapper(input_keep_prob<1) (las/layers.py:37-42) is not built yet; "
+                                  "run with --dropout_rate 0 as run.sh:69 does")
+    cell = _CFG["cell"]
+    H = int(cell_units)
+    I = inputs.shape[-1]
+    kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
+    out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even)
+    T = inputs.shape[1]
+    fw, bw = out[..., :H], out[..., H:]
+    states = (fw[:, T - 1], bw[:, 0])
+    return (fw, bw), states, out
+
+
+def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_training, scope="Listener"):
+    """Pyramidal BLSTM, reference las/layers.py:56-95 (the 7-argument call-site bug of las/las.py:15-21
+    is fixed at the caller).  Returns (rnn_out [B,ceil(T/2^L),2H], states, audiolen float64)."""
+    H = int(cell_units)
+    st = V.default_store()
+    sc = scope + "/blstm"
+    _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)
+    rnn_out = dense(out, st.get(sc + "/dense/kernel", (2 * H, 2 * H)),
+                    st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True)       # :71-74
+    audiolen = torch.as_tensor(audiolen).to(torch.float64)
+    states = None
+    for l in range(num_layers):
+        sc = scope + "/pyramid_blstm_%d" % l
+        _, states, out = _blstm_full(rnn_out, H, dropout_rate, is_training, scope=sc, pad_even=True)
+        B, Tp, _ = out.shape
+        # Eq (5): pad T to even, concat frame pairs -- a pure view of the zero-padded buffer (:83-88)
+        pairs = out.view(B, Tp // 2, 4 * H)
+        rnn_out = dense(pairs, st.get(sc + "/dense/kernel", (4 * H, 2 * H)),
+                        st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True)   # :89-93
+        audiolen = (audiolen + audiolen % 2) / 2                                          # :94
+    return rnn_out, states, audiolen
+
+
+def conv2d(*a, **k):
+    raise NotImplementedError("CNN listener (reference las/layers.py:97-163) is scheduled as SURVEY 8(f) row F2")
+
+
+def bn(*a, **k):
+    raise NotImplementedError("batch norm belongs to the CNN listener (SURVEY 8(f) row F2)")
+
+
+def CNNLayer(*a, **k):
+    raise NotImplementedError("CNN listener (reference las/layers.py:118-163) is scheduled as SURVEY 8(f) row F2; "
+                              "use --enc_type pblstm")
+
+
+# ------------------------------------------------------------------------------------------------
+# attention (forward-only single-step objects; training goes through las.las.Speller's fused loop)
+# ------------------------------------------------------------------------------------------------
+class BaseAttention:
+    """reference las/layers.py:165-213."""
+
+    def __init__(self, att_size, smoothing):
+        self.att_size = att_size
+        self.smoothing = smoothing
+
+    def mask(self, original_len, padded_len):
+        """mask[b,t] = float(t+1 <= int32(len[b]))   (las/layers.py:172-197)"""
+        ln = torch.as_tensor(original_len)
+        y = torch.arange(1, int(padded_len) + 1, dtype=torch.int32, device=ln.device)[None, :]
+        return (y <= ln.to(torch.int32)[:, None]).to(torch.float32)
+
+    def attend(self, inputs, energy, seqlen):
+        """las/layers.py:199-213 (torch elementwise ops: a convenience entry, not the hot path --
+        the hot path fuses this into the K5 row kernel)."""
+        m = self.mask(seqlen, inputs.shape[1]).to(energy.device)
+        energy = torch.where(m == 0, torch.full_like(energy, -1e8), energy)
+        alphas = torch.softmax(energy, -1)
+        return (inputs * alphas[..., None]).sum(1), alphas
+
+
+class _AttentionStep(BaseAttention):
+    mode = "add"
+
+    def __init__(self, h_dim, s_dim, att_size, kernel_size=10, num_channels=201, smoothing=False,
+                 scope="Speller/decode/attention"):
+        super().__init__(att_size, smoothing)
+        self.h_dim, self.s_dim = h_dim, s_dim
+        self.kernel_size, self.num_channels = kernel_size, num_channels
+        self.scope = scope
+
+    def params(self):
+        """Variables with the reference's TF names (las/layers.py:248-251,295-306;
+        `u` lives at Speller/while/decode/attention/Variable, las/beam_search.py:257,264)."""
+        st = V.default_store()
+        sc = self.scope
+        p = {"Wh": st.get(sc + "/dense/kernel", (self.h_dim, self.att_size)),
+             "Ws": st.get(sc + "/dense_1/kernel", (self.s_dim, self.att_size)),
+             "u": st.get("Speller/while/decode/attention/Variable", (self.att_size,), init="uniform1")}
+        if self.mode == "loc":
+            Kc, C = self.kernel_size, self.num_channels
+            p["loc_w"] = st.get(sc + "/conv1d/kernel", (Kc, 1, C), fan=(Kc, Kc * C))
+            p["loc_b"] = st.get(sc + "/conv1d/bias", (C,), init="zeros")
+            p["Wf"] = st.get(sc + "/dense_2/kernel", (C, self.att_size))
+        return p
+
+    def __call__(self, hidden, state, align, seqlen):
+        """(context [B,h_dim], alphas [B,T]) for one decode step -- forward only."""
+        from las.las import attention_forward_step
+        return attention_forward_step(self, hidden, state, align, seqlen)
+
+
+class AdditiveAttention(_AttentionStep):
+    """Bahdanau attention, reference las/layers.py:215-257."""
+    mode = "add"
+
+    def __init__(self, h_dim, s_dim, att_size, smoothing=False):
+        super().__init__(h_dim, s_dim, att_size, smoothing=smoothing)
+
+
+class LocationAwareAttention(_AttentionStep):
+    """Location-aware attention, reference las/layers.py:259-311."""
+    mode = "loc"
+
+    def __init__(self, h_dim, s_dim, att_size, kernel_size=10, num_channels=201, smoothing=False):
+        super().__init__(h_dim, s_dim, att_size, kernel_size, num_channels, smoothing)

@@ -1,0 +1,42 @@
+"""las.parallel -- data-parallel exchange for the train step.
+
+The reference is single-device (train.py:23).  Here every rank (one process per GPU) runs the same
+step on its own utterance shard; the ONLY exchanges are
+  * a 1-float all-reduce of the non-PAD token count before backward (so the loss/gradient is
+    normalised by the GLOBAL count, which makes N-rank training equal single-rank training on the
+    concatenated batch: the reference divides by the batch's own count, las/las.py:329-331), and
+  * ONE all-reduce(sum) over the flat fp32 gradient bucket (RCCL over xGMI; backend 'nccl' on ROCm,
+    'gloo' in the CPU tests).
+Clip + Adam then run replicated on every rank from identical inputs."""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_(self, flat):
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def all_reduce_scalar(self, x):
+        x = x.detach().clone().reshape(1)
+        if self.world > 1:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x[0]
+
+    def broadcast_(self, flat, src=0):
+        if self.world > 1:
+            dist.broadcast(flat, src=src, group=self.group)
+        return flat
+
+
+def shard(items, rank, world):
+    """Round-robin shard of a (length-sorted) utterance list -- replicas-only decode/eval."""
+    return items[rank::world]

@@ -97,38 +97,47 @@ int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates,
  * K4-K7  Speller: the whole decode loop of Speller.__call__ (las/las.py:72-143) with
  * Speller.decode (las/las.py:145-160), AdditiveAttention / LocationAwareAttention
  * (las/layers.py:234-257 / :281-311), BaseAttention.mask/attend (las/layers.py:172-213).
- * One call enqueues all U steps.  All pointers device.  Layouts:
+ * One call enqueues all U steps (per step: one fused row kernel = finish previous cell +
+ * [vocab logits/argmax/sample] + query projection + energies + mask + softmax + context + cell
+ * input assembly, then the cell contraction through las_gemm).  All pointers device.  Layouts:
  *   enc   [B,Tp,Hd]   encoder output h           keys [B,Tp,A]  hoisted dense(hidden) (K4, las_gemm)
  *   enc_len int32 [B] (already int-cast as las/layers.py:193 does)
  *   Ws [S,A] (S=D*NL)  u [A]   emb [V,E]   Wv [D,V]  bv [V]
  *   loc_w [Kc,C], loc_b [C], Wf [C,A] (mode LOC only, else NULL)
- *   cellW[l] [(I_l+D), G*D], cellb[l] [G*D]  with I_0 = E+Hd, I_l = D   (device pointer arrays
- *   passed as HOST arrays of device pointers)
- *   tokens_in int32 [U,B]: the token whose embedding enters step t  (t=0: SOS; teacher forcing:
- *   teacher[:,t-1]; scheduled sampling las/las.py:101-105 resolved by the caller or, where
- *   tokens_in[t][b] < 0, by this call: greedy argmax of step t-1 (inference, las/las.py:111)).
+ *   cellW[l] [(I_l+D), G*D], cellb[l] [G*D]  with I_0 = E+Hd, I_l = D   (HOST arrays of device ptrs)
+ *   tokens_in int32 [U,B]: the token whose embedding enters step t (t=0: SOS; teacher forcing:
+ *   teacher[:,t-1]).  -1 = greedy argmax of step t-1 (inference, las/las.py:111); -2 = a sample
+ *   from Categorical(logits of step t-1) (scheduled sampling, las/las.py:101-105,170-175; Gumbel
+ *   arg-max driven by `seed`).  Resolved tokens are written back in place.  Any negative entry
+ *   requires step_logits=1.
+ * Time-major internal results (the Python boundary returns [B,U,.] views):
+ *   logits [U,B,V]   alphas [U,B,Tp]   tokens_out int32 [U,B] (argmax per step; step_logits=1 only)
  * Saved for backward (caller-allocated):
- *   hs  [NL,U+1,B,D]  h states (slot 0 = zero state)    cs [NL,U+1,B,D] (lstm)
- *   gates [NL,U,B,G*D] activated gates (lstm) / unused (rnn: h is enough)
- *   ctx [U,B,Hd]   xin0 [U,B,E+Hd+D]  first-layer cell input rows
- * Outputs: logits [B,U,V], alphas [B,U,Tp], tokens_out int32 [U,B] = argmax of each step.
+ *   hs  [NL,U+1,B,D]  h states (slot 0 = initial state: zeroed by the call, or supplied by the
+ *       caller when keep_state0=1 -- single-step use by beam search)   cs [NL,U+1,B,D] (lstm)
+ *   gates [NL,U,B,G*D] activated gates (lstm) / pre-activation scratch (rnn)
+ *   xin0 [U,B,E+Hd+D]  first-layer cell input rows  [emb(token) ; context ; h_prev]
  */
 typedef struct {
-    int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C;
+    int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
+    float forget_bias;
+    unsigned long long seed;
     const float *enc, *keys; const int* enc_len;
     const float *Ws, *u, *emb, *Wv, *bv, *loc_w, *loc_b, *Wf;
     const float* const* cellW; const float* const* cellb;   /* host arrays [NL] of device ptrs */
     int* tokens_in; int* tokens_out;
     float *logits, *alphas;
-    float *hs, *cs, *gates, *ctx, *xin0;
+    const float* align0;           /* optional [B,Tp]: previous alignment entering step 0 (else zeros) */
+    float *hs, *cs, *gates, *xin0;
     void* ws; size_t ws_bytes;
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
 int las_speller_fwd(const las_speller_fwd_args* a, void* stream);
 
-/* Backward of the loop above for teacher-forced / externally sampled tokens (gradients do not flow
- * through the sampled token, as in tf.distributions.Categorical.sample, las/las.py:170-175).
- *   dlogits [B,U,V] in.   Accumulates (+=) into the caller-zeroed gradient buffers:
+/* Backward of the loop above for the tokens recorded in tokens_in (gradients do not flow through
+ * sampled tokens, as with tf.distributions.Categorical.sample, las/las.py:170-175).
+ *   dlogits [U,B,V] in.   `gates` is overwritten with d(pre-activation).
+ *   Accumulates (+=) into caller-zeroed gradient buffers:
  *   d_enc [B,Tp,Hd], d_keys [B,Tp,A], dWs, du, demb [V,E], dWv, dbv, dcellW[l], dcellb[l],
  *   dloc_w, dloc_b, dWf.
  */
@@ -142,14 +151,19 @@ int las_speller_bwd(const las_speller_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  LAS._get_loss (las/las.py:320-333) + label_smoothing (las/utils.py:5-12), forward and
- * gradient in one pass.  logits [B,U,V] (row stride V), y int32 [B,ldy] (first U columns used).
+ * gradient in one pass.  logits element (b,t,v) at logits[b*sb + t*st + v] (so the Speller's
+ * time-major [U,B,V] buffer is consumed in place: sb=V, st=B*V); dlogits uses the same strides.
+ * y int32 [B,ldy] (first U columns used).
  * sums[0] += sum(ce*mask), sums[1] += sum(mask)   (caller zeroes sums; the division
  * sum/(n+1e-9) is the caller's so that data-parallel ranks can all-reduce both terms first).
  * dlogits = scale_ptr[0] * mask * (softmax - smoothed_onehot)    (scale = 1/(n_total+1e-9), a
  * device scalar; NULL dlogits skips the gradient).
  */
-int las_ce_loss(const float* logits, const int* y, int ldy, int B, int U, int V, float epsilon,
-                float* sums, const float* scale_ptr, float* dlogits, void* stream);
+size_t las_ce_loss_workspace_bytes(int B, int U);
+int las_ce_loss(const float* logits, long long sb, long long st, const int* y, int ldy,
+                int B, int U, int V, float epsilon, int smooth,
+                float* sums, const float* scale_ptr, float* dlogits,
+                void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9  tf.clip_by_global_norm + tf.train.AdamOptimizer.apply_gradients (las/las.py:272-283) on one
@@ -166,19 +180,21 @@ int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
 
 /* ------------------------------------------------------------------------------------------
  * K10  one pruning step of BeamSearch.decode (las/beam_search.py:119-152, :297-312) for `nutt`
- * utterances at once.  Per utterance: nlive live hypotheses, logits [nlive,V] (raw logits are the
- * scores, las/beam_search.py:123-124); expansion of each hypothesis to its top `topn` tokens
- * (ascending, np.argsort(...)[-64:]), SOS skipped after t=0, only hypothesis 0 expanded at t=0;
- * candidates ranked by (score+logit)/len (len = tokens after SOS incl. the new one), best
- * `beam` kept in ascending order (ties: lower candidate index first, the stable order).
- *   logits   [nutt, beam, V]      score f64 [nutt, beam]   length int32 [nutt, beam]
- *   nlive int32 [nutt]            t: step index
- * Outputs per utterance, ascending by normalised score, count in out_n[nutt]:
- *   out_parent int32 [nutt,beam], out_token int32 [nutt,beam], out_score f64 [nutt,beam]
+ * utterances at once.  Per utterance: nlive live hypotheses with raw logits [nlive,V] (raw logits
+ * are the scores, las/beam_search.py:123-124), running float32 score (0 + np.float32 sums stay
+ * float32 in BeamState.update, :27) and length (tokens after SOS so far).  Only hypothesis 0 is
+ * expanded at t=0 (:119); SOS is skipped after t=0 (:127-128); candidates are ranked by
+ * (score+logit)/(length+1) in float32 (:306) and the best `beam` are returned in ASCENDING order
+ * (best last, :310-312).  Ties follow a stable ascending sort of the reference's candidate bank:
+ * (key, hypothesis index, logit, token id).  The per-hypothesis top-`topn` cut (:123, 64) cannot
+ * bind while beam < topn, which this entry point requires.
+ *   logits [nutt,beam,V]   score f32 [nutt,beam]   length int32 [nutt,beam]   nlive int32 [nutt]
+ * Outputs (count in out_n[nutt]): out_parent, out_token int32 [nutt,beam]; out_score f32 [nutt,beam]
+ * = new running sums.
  */
-int las_beam_step(const float* logits, const double* score, const int* length, const int* nlive,
+int las_beam_step(const float* logits, const float* score, const int* length, const int* nlive,
                   int nutt, int beam, int V, int topn, int t, int start_id,
-                  int* out_parent, int* out_token, double* out_score, int* out_n, void* stream);
+                  int* out_parent, int* out_token, float* out_score, int* out_n, void* stream);
 
 #ifdef __cplusplus
 }
