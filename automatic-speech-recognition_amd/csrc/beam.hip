@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
                                                         int beam, int V, int t, int start_id, int* __restrict__ out_parent,
                                                         int* __restrict__ out_token, float* __restrict__ out_score,
                                                         int* __restrict__ out_n) {
-    __shared__ float r_norm[4], r_l[4];
-    __shared__ int r_i[4], r_v[4], r_has[4];
+    __shared__ float s_norm[256], s_l[256];
+    __shared__ int s_i[256], s_v[256];
     __shared__ BKey picks[64];
     __shared__ int s_count;
     const int u = blockIdx.x, tid = threadIdx.x;
@@ -43,36 +43,36 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     for (int pick = 0; pick < beam; ++pick) {
         BKey best = {0.f, -1, 0.f, 0};
         bool has = false;
-        for (long long idx = tid; idx < (long long)nb * V; idx += 256) {
-            const int i = (int)(idx / V), v = (int)(idx % V);
+        const int ncand = nb * V;
+        for (int idx = tid; idx < ncand; idx += 256) {
+            const int i = idx / V;
+            const int v = idx - i * V;
             if (t > 0 && v == start_id) continue;      // las/beam_search.py:127-128
-            const float l = lg[(size_t)i * V + v];
+            const float l = lg[idx];
             BKey k;
             k.norm = (sc[i] + l) / (float)(ln[i] + 1);  // float32 sum, float32 divide (las/beam_search.py:27,306)
-            k.i = i; k.l = l; k.v = v;
+            k.i = i; k.l = l; k.v = idx;                // v carries the flat candidate id until the very end
             if (!(k.norm == k.norm)) continue;          // NaN never ranks
             if (pick > 0 && !bless(k, last)) continue;
             if (!has || bless(best, k)) { best = k; has = true; }
         }
-        // wave reduce
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            BKey ok;
-            ok.norm = __shfl_xor(best.norm, o, 64); ok.i = __shfl_xor(best.i, o, 64);
-            ok.l = __shfl_xor(best.l, o, 64);       ok.v = __shfl_xor(best.v, o, 64);
-            const int oh = __shfl_xor((int)has, o, 64);
-            if (oh && (!has || bless(best, ok))) { best = ok; has = true; }
-        }
+        // block reduce through LDS (tree over 256 slots)
         __syncthreads();
-        if ((tid & 63) == 0) { r_norm[tid >> 6] = best.norm; r_i[tid >> 6] = best.i; r_l[tid >> 6] = best.l; r_v[tid >> 6] = best.v; r_has[tid >> 6] = has; }
+        s_norm[tid] = best.norm; s_i[tid] = has ? best.i : -1; s_l[tid] = best.l; s_v[tid] = best.v;
         __syncthreads();
-        has = false;
-        for (int w = 0; w < 4; ++w) {
-            if (!r_has[w]) continue;
-            BKey k = {r_norm[w], r_i[w], r_l[w], r_v[w]};
-            if (!has || bless(best, k)) { best = k; has = true; }
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                const BKey x = {s_norm[tid], s_i[tid], s_l[tid], s_v[tid]};
+                const BKey y = {s_norm[tid + off], s_i[tid + off], s_l[tid + off], s_v[tid + off]};
+                if (y.i >= 0 && (x.i < 0 || bless(x, y))) {
+                    s_norm[tid] = y.norm; s_i[tid] = y.i; s_l[tid] = y.l; s_v[tid] = y.v;
+                }
+            }
+            __syncthreads();
         }
-        if (!has) break;                                 // uniform: every thread sees the same r_* values
+        best.norm = s_norm[0]; best.i = s_i[0]; best.l = s_l[0]; best.v = s_v[0];
+        has = best.i >= 0;
+        if (!has) break;                                 // uniform: every thread reads slot 0
         last = best;
         if (tid == 0) picks[pick] = best;
         count = pick + 1;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     for (int j = tid; j < count; j += 256) {             // ascending, best last (las/beam_search.py:310-312)
         const BKey k = picks[count - 1 - j];
         out_parent[(size_t)u * beam + j] = k.i;
-        out_token[(size_t)u * beam + j] = k.v;
+        out_token[(size_t)u * beam + j] = k.v - k.i * V;
         out_score[(size_t)u * beam + j] = sc[k.i] + k.l;
     }
 }

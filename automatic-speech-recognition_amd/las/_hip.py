@@ -168,6 +168,41 @@ def tanh_bwd(Y, ldy, dY, lddy, dX, lddx, rows, cols):
     check(lib().las_tanh_bwd(p(Y), ldy, p(dY), lddy, p(dX), lddx, rows, cols, stream()), "las_tanh_bwd")
 
 
+# ---- optional per-call device timing (bench.py roofline leg): HIP events on the launch stream -----
+_PROF = None
+
+
+def prof_begin():
+    global _PROF
+    _PROF = {}
+
+
+def prof_end():
+    """-> {name: [ms, ...]} ; call after torch.cuda.synchronize()."""
+    global _PROF
+    out = {k: [a.elapsed_time(b) for a, b in v] for k, v in (_PROF or {}).items()}
+    _PROF = None
+    return out
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            self.e1.record()
+            _PROF.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 def rnn_seq_ws(cell, prec, H, dev):
     return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H), "rnn_seq")
 
@@ -176,16 +211,18 @@ def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
                 forget_bias=1.0, wf_off=0, wb_off=0):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
     ws = rnn_seq_ws(cell, prec, H, gates.device)
-    check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
-                                c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
-                                p(cstate), forget_bias, p(ws), ws.numel(), stream()), "las_rnn_seq_fwd")
+    with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
+        check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                    c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                    p(cstate), forget_bias, p(ws), ws.numel(), stream()), "las_rnn_seq_fwd")
 
 
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0):
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, gates.device)
-    check(lib().las_rnn_seq_bwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
-                                c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
-                                p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(ws), ws.numel(),
-                                stream()), "las_rnn_seq_bwd")
+    with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
+        check(lib().las_rnn_seq_bwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                    c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                    p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(ws), ws.numel(),
+                                    stream()), "las_rnn_seq_bwd")

@@ -127,7 +127,8 @@ class _SpellerLoop(torch.autograd.Function):
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
         keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
-        _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+        with _hip._timed("speller_fwd[U=%d]" % dims["U"]):
+            _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
         del keep
         ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed)
         ctx.mark_non_differentiable(bufs["alphas"])
@@ -163,7 +164,8 @@ class _SpellerLoop(torch.autograd.Function):
             ba.dloc_w, ba.dloc_b, ba.dWf = g["loc_w"].data_ptr(), g["loc_b"].data_ptr(), g["Wf"].data_ptr()
         keep = (_ptr_array(dcW), _ptr_array(dcb))
         ba.dcellW, ba.dcellb = keep
-        _hip.check(_hip.lib().las_speller_bwd(ctypes.byref(ba), _hip.stream()), "las_speller_bwd")
+        with _hip._timed("speller_bwd[U=%d]" % dims["U"]):
+            _hip.check(_hip.lib().las_speller_bwd(ctypes.byref(ba), _hip.stream()), "las_speller_bwd")
         del keep, keepf
         # key projection backward (K4): dWh = enc^T . d_keys ; d_enc += d_keys . Wh^T
         dWh = torch.empty_like(Wh)

@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- utterances/sec of one full LAS train step (fwd + bwd + clip + Adam [+ all-reduce]).
+
+Workload (BASELINE.json configs[1]): LibriSpeech-100 char LAS, 3 x pBLSTM-256 Listener (+ first BLSTM),
+1 x LSTM-512 Speller, additive attention, bf16 contractions, on the reference's own bucket shape
+B=48, T=1274 (tfrecord_data_loader.py:75,83), synthetic MFCC-39 cube and labels per SURVEY.md 8(d).
+
+    python bench.py --gpus N --steps K --warmup W
+N>1 is launched by torch.distributed.run (one rank per GPU over RCCL): every rank trains on its own
+48-utterance shard (weak scaling), one flat-bucket all-reduce per step.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream around
+the dominant kernel (the recurrent sweep); `cpu_baseline` times the oracle restatement of the reference
+graph AS WRITTEN (un-hoisted key projection, per-step cells) on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "automatic-speech-recognition_amd"), os.path.join(ROOT, "tests"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def bench_args(cell):
+    from helpers import make_args
+    return make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128,
+                     attention_size=128, mode="add", lr=1e-3, grad_clip=5.0, label_smoothing=True,
+                     scheduled_sampling=True, vocab_size=30)
+
+
+def sweep_bytes(B, T, H, G, bwd):
+    """ALGORITHMIC HBM bytes of one recurrent sweep launch (both directions), fp32 tensors in HBM:
+    fwd: read x-projection, write activated gates + cell state + h; W_hh fragments once.
+    bwd: read activated gates, c_t, c_prev, dout; write d(pre-activation)."""
+    f = 4
+    gates = B * T * 2 * G * H * f
+    h = B * T * 2 * H * f
+    w = 2 * H * G * H * 2
+    if not bwd:
+        return gates * 2 + (h if G == 4 else 0) + h + w
+    return gates * 2 + (2 * h if G == 4 else h) + h + w
+
+
+def cpu_baseline(cell, seconds_budget=30.0):
+    """Reference-equivalent CPU path (restated; TensorFlow 1.13 is not installable offline)."""
+    from helpers import synthetic_batch
+    from oracle import las_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    args = bench_args(cell)
+    Bs, T = 4, 1274
+    xs, ys = synthetic_batch(Bs, T, 256, args.vocab_size, seed=0)
+    p0 = O.init_params(args, seed=0, cell=cell)
+    po = O.to_torch(p0, requires_grad=True)
+    z1 = {k: torch.zeros_like(v) for k, v in po.items()}
+    z2 = {k: torch.zeros_like(v) for k, v in po.items()}
+    t0 = time.time()
+    O.train_step(po, z1, z2, 0, (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, hoist=False)
+    dt = time.time() - t0
+    return {"value": Bs / dt, "unit": "utterances/s", "cores": ncores, "kind": "port",
+            "sample": "1 train step of the oracle (reference graph as written, torch-CPU fp32, %s cells) on %d "
+                      "utterances of the same T=1274 workload: %.1f s" % (cell, Bs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cell", default="lstm", choices=["lstm", "rnn"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=48)
+    ap.add_argument("--frames", type=int, default=1274)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from helpers import synthetic_batch
+    from las import _hip
+    from las import layers as L
+    from las import variables as V
+    from las.las import LAS, Listener, Speller
+    from las.parallel import DataParallel
+
+    dp = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dp = DataParallel()
+
+    L.set_cell(a.cell)
+    L.set_precision(a.dtype)
+    V.reset_default_store(device=dev, seed=0)
+    args = bench_args(a.cell)
+    las = LAS(args, Listener, Speller, {})
+    las.dp = dp
+    las.build_variables()
+    st = V.default_store()
+    if dp is not None:
+        dp.broadcast_(st.flat)
+
+    B, T = a.batch, a.frames
+    xs, ys = synthetic_batch(B, T, 256, args.vocab_size, seed=rank, min_frac=0.834)   # lengths within the bucket
+    xs = (torch.tensor(xs[0], device=dev), xs[1])
+    ys = (torch.tensor(ys[0], device=dev), ys[1])
+    U = int(ys[1].max())
+
+    def sync():
+        torch.cuda.synchronize()
+        if dp is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        las.train(xs, ys)
+    sync()
+    _hip.prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = las.train(xs, ys)[0]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dp is not None:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    prof = _hip.prof_end()
+    loss = float(loss)
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        value = world * B * a.steps / elapsed
+        G = 4 if a.cell == "lstm" else 1
+        H = args.enc_units
+        per = {k: (sum(v) / len(v), len(v)) for k, v in prof.items()}
+        # dominant kernel = the recurrent sweep with the largest total time in the timed region
+        sweeps = {k: v for k, v in per.items() if k.startswith("rnn_seq")}
+        dom = max(sweeps, key=lambda k: sweeps[k][0] * sweeps[k][1]) if sweeps else None
+        roof = None
+        if dom:
+            Tl = int(dom.split("T=")[1].split(",")[0])
+            bwd = dom.startswith("rnn_seq_bwd")
+            by = sweep_bytes(B, Tl, H, G, bwd)
+            avg_ms = sweeps[dom][0]
+            ach = by / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_bf16_kernel" if a.dtype == "bf16"
+                    else ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_f32_kernel",
+                    "launch": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(avg_ms, 4),
+                    "us_per_recurrent_step": round(avg_ms * 1e3 / Tl, 3)}
+        out = {
+            "metric": "utterances/sec (train step) LibriSpeech-360 char-LAS @1/2/4/8 GPU; dev-clean WER",
+            "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype if a.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "LibriSpeech-100 char LAS (BASELINE configs[1]): 3xpBLSTM-256 listener + 1x%s-512 "
+                                   "speller, additive attention, MFCC-39, bucket B=%d T=%d, U=%d, V=30; full train "
+                                   "step fwd+bwd+clip+Adam" % (a.cell.upper(), B, T, U),
+                       "cell": a.cell, "per_gpu_batch": B, "global_batch": B * world, "frames": T, "dec_steps": U,
+                       "parallelism": "dp%d" % world, "params": st.num_params()},
+            "roofline": roof,
+            "loss": round(loss, 4),
+            "kernel_ms": {k: [round(v[0], 3), v[1] // a.steps] for k, v in sorted(per.items())},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cell)
+        print(json.dumps(out))
+    if dp is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
