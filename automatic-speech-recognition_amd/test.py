@@ -1,0 +1,61 @@
+"""test.py -- greedy evaluation entry point (counterpart of the reference's test.py: same flags, same
+artefacts log_dir/test_pred.txt + test_gt.txt, same corpus-WER arithmetic test.py:127-136)."""
+import logging
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from las import checkpoint, layers, variables                      # noqa: E402
+from las.arguments import parse_args                               # noqa: E402
+from las.las import LAS, Listener, Speller                         # noqa: E402
+from las.utils import convert_idx_to_string, edit_distance        # noqa: E402
+from utils.tokenizer import CharEncoder, SubwordEncoder            # noqa: E402
+
+
+def corpus_wer(texts_gt, texts_pred):
+    error, N = 0, 0
+    for ref, hyp in zip(texts_gt, texts_pred):
+        e, n = edit_distance(ref.split(" "), hyp.split(" "))
+        error += e
+        N += n
+    return error / N
+
+
+def main():
+    import torch
+    args = parse_args()
+    logging.basicConfig(stream=sys.stdout, format='%(asctime)s %(levelname)s:%(message)s', level=logging.INFO, datefmt='%I:%M:%S')
+    tokenizer = CharEncoder() if args.unit.lower() == "char" else SubwordEncoder(args.subword_dir)
+    args.vocab_size = tokenizer.get_vocab_size()
+    id_to_token = tokenizer.id_to_token
+    layers.set_cell(args.cell)
+    layers.set_precision(args.dtype)
+    variables.reset_default_store(device=torch.device("cuda", 0), seed=args.seed)
+    las = LAS(args, Listener, Speller, id_to_token)
+    las.build_variables()
+    ckpt = checkpoint.restore(args.save_dir, args.restore_epoch)
+    logging.info("restored: {}".format(ckpt))
+    if not args.synthetic:
+        raise SystemExit("TFRecord input is SURVEY 8(f) row F1; run with --synthetic True")
+    from data import SyntheticBatches
+    batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed + 1, batch_scale=0.25, max_frames=700)
+    output_id, gt_id = [], []
+    for _ in range(4 if args.max_steps < 0 else args.max_steps):
+        xs, ys = next(batches)
+        _, y_hat = las.inference(xs)
+        output_id += y_hat.cpu().numpy().tolist()
+        gt_id += ys[0].tolist()
+    texts_pred = [convert_idx_to_string(o, id_to_token, args.unit) for o in output_id]
+    texts_gt = [convert_idx_to_string(g, id_to_token, args.unit) for g in gt_id]
+    os.makedirs(args.log_dir, exist_ok=True)
+    with open(os.path.join(args.log_dir, "test_pred.txt"), 'w') as fout:
+        fout.write("\n".join(texts_pred))
+    with open(os.path.join(args.log_dir, "test_gt.txt"), 'w') as fout:
+        fout.write("\n".join(texts_gt))
+    logging.info("total utterances: {}, WER: {}".format(len(texts_gt), corpus_wer(texts_gt, texts_pred)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""train.py -- training entry point (counterpart of the reference's train.py, same flags and log lines).
+
+    python train.py --enc_type pblstm --feat_dim 13 --unit char --dropout_rate 0 --synthetic True ...
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...   # data parallel
+
+Replaces the `sess.run` step loop of train.py:114-133: every iteration is one eager `las.train(xs, ys)` on
+this rank's batch; with WORLD_SIZE>1 the gradient bucket is all-reduced over RCCL (las/parallel.py)."""
+import json
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from las import checkpoint, layers, variables                      # noqa: E402
+from las.arguments import parse_args                               # noqa: E402
+from las.las import LAS, Listener, Speller                         # noqa: E402
+from las.utils import convert_idx_to_string                        # noqa: E402
+from utils.tokenizer import CharEncoder, SubwordEncoder            # noqa: E402
+
+
+def main():
+    args = parse_args()
+    logging.basicConfig(stream=sys.stdout, format='%(asctime)s %(levelname)s:%(message)s', level=logging.INFO,
+                        datefmt='%I:%M:%S')
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        print('=' * 60 + '\n')
+        logging.info('Parameters are:\n%s\n', json.dumps(vars(args), sort_keys=False, indent=4))
+        print('=' * 60 + '\n')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        from las.parallel import DataParallel
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dp = DataParallel()
+
+    # tokenizer (the reference always builds SubwordEncoder, train.py:60 -- SURVEY Q15; --unit is honoured here)
+    tokenizer = CharEncoder() if args.unit.lower() == "char" else SubwordEncoder(args.subword_dir)
+    args.vocab_size = tokenizer.get_vocab_size()
+    id_to_token = tokenizer.id_to_token
+
+    layers.set_cell(args.cell)
+    layers.set_precision(args.dtype)
+    variables.reset_default_store(device=dev, seed=args.seed)
+    las = LAS(args, Listener, Speller, id_to_token)
+    las.dp = dp
+    las.build_variables()
+    st = variables.default_store()
+    os.makedirs(args.save_dir, exist_ok=True)
+    ckpt = checkpoint.restore(args.save_dir, -1)                  # restore latest or init (train.py:84-90)
+    if dp is not None:
+        dp.broadcast_(st.flat)
+
+    if not args.synthetic:
+        raise SystemExit("TFRecord input (reference tfrecord_data_loader.py) is SURVEY 8(f) row F1; run with --synthetic True")
+    from data import SyntheticBatches
+    batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
+
+    if rank == 0:
+        logging.info("Total weights: {}".format(st.num_params()))
+    num_train_batches = 2619                                      # train.py:108
+    training_steps = num_train_batches * args.epoch if args.max_steps < 0 else args.max_steps
+    if rank == 0:
+        logging.info("Total num train batches: {}".format(num_train_batches))
+        logging.info("Training...")
+    loss_ = []
+    for step in range(training_steps):
+        xs, ys = next(batches)
+        batch_loss, _, gs, logits, alphas, _, tfrate = las.train(xs, ys)
+        batch_loss = float(batch_loss)
+        if rank == 0:
+            if args.verbose > 0:
+                logging.info("HYP: {}".format(convert_idx_to_string(torch.argmax(logits[0], -1).cpu().numpy(), id_to_token, args.unit)))
+                logging.info("REF: {}\n".format(convert_idx_to_string(ys[0][0], id_to_token, args.unit)))
+            logging.info("Step: {}, Loss: {:.3f}, tf rate: {:.3f}".format(gs, batch_loss, tfrate))
+        loss_.append(batch_loss)
+        if gs and gs % num_train_batches == 0:
+            e_ = gs // num_train_batches
+            if rank == 0:
+                logging.info('=' * 19 + ' Epoch %d, Step %d, Ave loss %f' + '=' * 19 + '\n', e_, gs, np.mean(loss_))
+                checkpoint.save(args.save_dir, e_)
+            loss_ = []
+    if rank == 0 and args.max_steps >= 0:
+        checkpoint.save(args.save_dir, max(1, st.global_step // num_train_batches))
+
+
+if __name__ == "__main__":
+    main()
