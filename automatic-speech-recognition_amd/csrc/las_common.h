@@ -41,9 +41,13 @@ __device__ __forceinline__ f32x4_t mfma_bf16_16x16x32(u16x8_t a, u16x8_t b, f32x
 // accurate forms (fp32 parity mode)
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float tanh_acc(float x) { return tanhf(x); }
-// fast forms (speed mode): one v_exp + one v_rcp
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// fast forms (speed mode): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp), no correctly-rounded division sequence
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 template <bool FAST> __device__ __forceinline__ float sigm(float x) { return FAST ? sigmoid_fast(x) : sigmoid_acc(x); }
 template <bool FAST> __device__ __forceinline__ float tanhx(float x) { return FAST ? tanh_fast(x) : tanh_acc(x); }

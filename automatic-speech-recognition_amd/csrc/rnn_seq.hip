@@ -15,6 +15,7 @@
 //                  Next step's x-projection is prefetched under the current step's MFMAs.
 // No grid barrier, no inter-workgroup traffic: directions and batch tiles are independent.
 #include "las_common.h"
+#include <stdlib.h>
 
 struct RnnArgs {
     int B, T, H;
@@ -26,7 +27,20 @@ struct RnnArgs {
     const float* dout; int ld_dout; long long dobs;
     float fb;
     const void* wpack;
+    long long* dbg;   // LAS_PROF builds only: device buffer for s_memtime stamps (env LAS_DBG_PTR)
+    unsigned long long* xbuf; int* err;     // cluster exchange granules / bounded-spin error flag
+    int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
+// every recurrent step on the completion of that step's global stores and of the NEXT step's x-projection
+// prefetch (cdna_hip_programming.md section 5, "Pipelining across barriers").  Cross-wave data here travels
+// through LDS exclusively; global traffic is per-lane private within a sweep.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // ------------------------------------------------------------------------------------------------
 // fp32 VALU kernels
@@ -214,37 +228,81 @@ __global__ __launch_bounds__(256) void transpose_whh_kernel(const float* W0, con
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int CELL, int UT>
+// ---- cluster exchange ---------------------------------------------------------------------------------
+// With P > 1 the hidden units of one (direction, batch tile) are split over P workgroups (= P CUs), each
+// keeping ITS slice of W_hh resident on chip for the whole sweep (streaming W_hh into one CU tops out at
+// ~25-90 GB/s per CU and would cost 4-15 us per step).  Every step each member needs all H values of
+// h_t (fwd) / all G*H values of d(pre-activation) (bwd): members publish their slice as 8-byte granules
+// {tag = step+1, payload = 2 x bf16} with ONE relaxed agent-scope (sc1, write-through) store per granule,
+// and read the others' granules with relaxed agent-scope loads until the tag matches -- the data IS the
+// flag, no fence, placement independent (cdna_hip_programming.md G16, recipe R2).  Two slots alternate
+// (a member can be at most one step ahead of the slowest reader).  The buffer is zeroed by a memset node
+// before every launch; spins are bounded and report through err[0].
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+#define LAS_SPIN_BUDGET (1 << 22)
+
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned tag, unsigned val) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err) {
+    unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int budget = *err ? 1 : LAS_SPIN_BUDGET;          // sticky: after one timeout never wait again (no hang)
+    while ((unsigned)(x >> 32) != tag) {
+        if (--budget == 0) { *err = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+        x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (unsigned)x;
+}
+
+template <int CELL, int UT, int P>
 struct RnnCfg {
     static constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     static constexpr int H = UT * 64, GH = G * H;
-    static constexpr int KS = H / 32;            // k-steps of the forward product (K = H)
-    static constexpr int NFW = G * UT * KS;      // B fragments per wave, forward
-    static constexpr int LDH = H + 8;            // bf16 row pitch of the h tile
+    static constexpr int UTP = UT / P;            // 16-unit tiles owned by one wave of one member
+    static constexpr int UPM = H / P;             // hidden units owned by one member
+    static constexpr int KS = H / 32;             // k-steps of the forward product (K = H)
+    static constexpr int NFW = G * UTP * KS;      // B fragments per wave, forward
+    static constexpr int LDH = H + 8;             // bf16 row pitch of the h tile
     static constexpr int HS_BYTES = 2 * 16 * LDH * 2;
     static constexpr int LF = cmin(NFW, (150 * 1024 - HS_BYTES) / 4096);   // fragments/wave resident in LDS
-    static constexpr int KSB = GH / 32;          // k-steps of the backward product (K = G*H)
-    static constexpr int NFB = UT * KSB;
+    static constexpr int RF = NFW - LF;           // fragments/wave pinned in VGPR/AGPRs (must stay <= ~48)
+    static constexpr int KSB = GH / 32;           // k-steps of the backward product (K = G*H)
+    static constexpr int NFB = UTP * KSB;
     static constexpr int LDG = GH + 8;
     static constexpr int DP_BYTES = 2 * 16 * LDG * 2;
     static constexpr int LFB = cmax(0, cmin(NFB, (150 * 1024 - DP_BYTES) / 4096));
+    static constexpr int RFB = NFB - LFB;
     static constexpr int FWD_LDS = HS_BYTES + 4 * LF * 1024;
     static constexpr int BWD_LDS = DP_BYTES + 4 * LFB * 1024;
+    static constexpr int GPM_F = 16 * UPM / 2;        // granules one member publishes per step, forward
+    static constexpr int GPM_B = 16 * G * UPM / 2;    // ... backward
+    static constexpr bool OK = (UT % P == 0) && RF <= 48 && RFB <= 48;
 };
 
-template <int CELL, int UT>
+template <int CELL, int UT, int P>
 __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
-    using C = RnnCfg<CELL, UT>;
-    constexpr int G = C::G, H = C::H, GH = C::GH, KS = C::KS, NFW = C::NFW, LDH = C::LDH, LF = C::LF;
+    using C = RnnCfg<CELL, UT, P>;
+    constexpr int G = C::G, H = C::H, GH = C::GH, KS = C::KS, NFW = C::NFW, LDH = C::LDH, LF = C::LF, RF = C::RF;
+    constexpr int UTP = C::UTP, UPM = C::UPM, GPM = C::GPM_F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* hs = reinterpret_cast<unsigned short*>(smem);               // [2][16][LDH]
     u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::HS_BYTES);               // [4][LF][64]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int dir = blockIdx.y, b0 = blockIdx.x * 16, T = a.T, B = a.B;
-    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 + w) * NFW * 64;
+    const int T = a.T, B = a.B;
+    const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;         // cluster, member
+    if (cl >= a.ncl) return;
+    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int vw = pm * 4 + w;                                                   // virtual wave: owns units [vw*16*UTP, ..)
+    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFW * 64;
+    unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;                 // [2 slots][P][GPM]
+    int errflag = 0;
 
 #pragma unroll 4
     for (int fi = 0; fi < LF; ++fi) wl[(w * LF + fi) * 64 + lane] = Wp[fi * 64 + lane];
+    u16x8_t wreg[RF > 0 ? RF : 1];
+#pragma unroll
+    for (int r = 0; r < RF; ++r) wreg[r] = Wp[(LF + r) * 64 + lane];
     for (int i = tid; i < 16 * LDH; i += 256) hs[i] = 0;
     __syncthreads();
 
@@ -256,48 +314,50 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
         rv[r] = b < B;
         rowoff[r] = (long long)(b < B ? b : B - 1);
     }
-    float cst[UT][4];
+    float cst[UTP][4];
 #pragma unroll
-    for (int j = 0; j < UT; ++j)
+    for (int j = 0; j < UTP; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
 
-    float xn[G][UT][4];
+    // x-projection of the step about to run; it seeds the accumulators (acc = x.W_ih + b, then += h.W_hh)
+    f32x4_t xn[G][UTP];
     {
         const int t0 = dir ? T - 1 : 0;
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
-            for (int j = 0; j < UT; ++j)
+            for (int j = 0; j < UTP; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    xn[q][j][r] = a.gates[((rowoff[r] * T + t0) * 2 + dir) * GH + q * H + w * (16 * UT) + j * 16 + c];
+                    xn[q][j][r] = a.gates[((rowoff[r] * T + t0) * 2 + dir) * GH + q * H + vw * (16 * UTP) + j * 16 + c];
     }
     int cur = 0;
+#ifdef LAS_PROF
+    const bool prof = a.dbg && blockIdx.x == 0 && tid == 0;
+    if (prof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (prof && s >= 200 && s < 208) a.dbg[8 + (s - 200) * 8 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(k)
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
-        float xc[G][UT][4];
+        STAMP(0);
+        f32x4_t acc[G][UTP];
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
-            for (int j = 0; j < UT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xc[q][j][r] = xn[q][j][r];
-        if (s + 1 < T) {
+            for (int j = 0; j < UTP; ++j) acc[q][j] = xn[q][j];
+        if (s + 1 < T) {   // next step's x-projection flies under this step's MFMAs
             const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
-                for (int j = 0; j < UT; ++j)
+                for (int j = 0; j < UTP; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        xn[q][j][r] = a.gates[((rowoff[r] * T + tn) * 2 + dir) * GH + q * H + w * (16 * UT) + j * 16 + c];
+                        xn[q][j][r] = a.gates[((rowoff[r] * T + tn) * 2 + dir) * GH + q * H + vw * (16 * UTP) + j * 16 + c];
         }
-        f32x4_t acc[G][UT];
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-#pragma unroll
-            for (int j = 0; j < UT; ++j) acc[q][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const unsigned short* hcur = hs + cur * 16 * LDH;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -305,26 +365,32 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
-                for (int j = 0; j < UT; ++j) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int fi = (q * UT + j) * KS + ks;
-                    const u16x8_t bv = fi < LF ? wl[(w * LF + fi) * 64 + lane] : Wp[fi * 64 + lane];
+                for (int j = 0; j < UTP; ++j) {
+                    const int fi = (q * UTP + j) * KS + ks;
+                    const u16x8_t bv = fi < LF ? wl[(w * LF + fi) * 64 + lane] : wreg[fi - LF < RF ? (fi - LF >= 0 ? fi - LF : 0) : 0];
                     acc[q][j] = mfma_bf16_16x16x32(av, bv, acc[q][j]);
                 }
         }
+        STAMP(1);
+#ifdef LAS_PROF
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[G - 1][UTP - 1][3]));
+#endif
+        STAMP(2);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
+        unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
 #pragma unroll
-        for (int j = 0; j < UT; ++j) {
-            const int unit = w * (16 * UT) + j * 16 + c;
+        for (int j = 0; j < UTP; ++j) {
+            const int unit = vw * (16 * UTP) + j * 16 + c;
+            unsigned short hb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float h;
                 const long long fr = (rowoff[r] * T + t) * 2 + dir;
                 if (CELL == LAS_CELL_LSTM) {
-                    const float gi = sigm<true>(acc[0][j][r] + xc[0][j][r]);
-                    const float gj = tanhx<true>(acc[G > 1 ? 1 : 0][j][r] + xc[G > 1 ? 1 : 0][j][r]);
-                    const float gf = sigm<true>(acc[G > 2 ? 2 : 0][j][r] + xc[G > 2 ? 2 : 0][j][r] + a.fb);
-                    const float go = sigm<true>(acc[G > 3 ? 3 : 0][j][r] + xc[G > 3 ? 3 : 0][j][r]);
+                    const float gi = sigm<true>(acc[0][j][r]);
+                    const float gj = tanhx<true>(acc[G > 1 ? 1 : 0][j][r]);
+                    const float gf = sigm<true>(acc[G > 2 ? 2 : 0][j][r] + a.fb);
+                    const float go = sigm<true>(acc[G > 3 ? 3 : 0][j][r]);
                     const float cc = cst[j][r] * gf + gi * gj;
                     cst[j][r] = cc;
                     h = tanhx<true>(cc) * go;
@@ -334,30 +400,70 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
                         a.cstate[fr * H + unit] = cc;
                     }
                 } else {
-                    h = tanhx<true>(acc[0][j][r] + xc[0][j][r]);
+                    h = tanhx<true>(acc[0][j][r]);
                 }
-                hnext[(g * 4 + r) * LDH + unit] = f2bf(h);
+                hb[r] = f2bf(h);
+                hnext[(g * 4 + r) * LDH + unit] = hb[r];
                 if (rv[r]) a.out[rowoff[r] * a.obs + (long long)t * a.ld_out + dir * H + unit] = h;
             }
+            if (P > 1 && s + 1 < T) {   // publish this wave's slice: 2 granules per lane per tile (rows g*4+{0,1}, g*4+{2,3})
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    granule_store(xslot + (size_t)pm * GPM + ((w * UTP + j) * 2 + k) * 64 + lane, (unsigned)(s + 1),
+                                  (unsigned)hb[2 * k] | ((unsigned)hb[2 * k + 1] << 16));
+            }
         }
-        __syncthreads();
+        STAMP(3);
+        if (P > 1 && s + 1 < T) {       // gather the other members' slices of h_t into the LDS tile
+#pragma unroll 1
+            for (int mo = 1; mo < P; ++mo) {
+                const int m = (pm + mo) % P;
+                const unsigned long long* src = xslot + (size_t)m * GPM;
+#pragma unroll
+                for (int i = 0; i < GPM / 256; ++i) {
+                    const int gi_ = tid + i * 256;
+                    const unsigned v = granule_wait(src + gi_, (unsigned)(s + 1), &errflag);
+                    const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, wj = gi_ >> 7;     // wj = w'*UTP + j'
+                    const int unit = m * UPM + wj * 16 + (l2 & 15);
+                    const int row = (l2 >> 4) * 4 + 2 * k;
+                    hnext[row * LDH + unit] = (unsigned short)(v & 0xffffu);
+                    hnext[(row + 1) * LDH + unit] = (unsigned short)(v >> 16);
+                }
+            }
+        }
+        lds_barrier();
+        STAMP(4);
         cur ^= 1;
     }
+    if (errflag && a.err) a.err[0] = 1;
+#ifdef LAS_PROF
+    if (prof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#endif
 }
 
-template <int CELL, int UT>
+template <int CELL, int UT, int P>
 __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
-    using C = RnnCfg<CELL, UT>;
-    constexpr int G = C::G, H = C::H, GH = C::GH, KSB = C::KSB, NFB = C::NFB, LDG = C::LDG, LFB = C::LFB;
+    using C = RnnCfg<CELL, UT, P>;
+    constexpr int G = C::G, H = C::H, GH = C::GH, KSB = C::KSB, NFB = C::NFB, LDG = C::LDG, LFB = C::LFB, RFB = C::RFB;
+    constexpr int UTP = C::UTP, UPM = C::UPM, GPM = C::GPM_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* dps = reinterpret_cast<unsigned short*>(smem);              // [2][16][LDG]
     u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::DP_BYTES);               // [4][LFB][64]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int dir = blockIdx.y, b0 = blockIdx.x * 16, T = a.T, B = a.B;
-    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 + w) * NFB * 64;
+    const int T = a.T, B = a.B;
+    const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
+    if (cl >= a.ncl) return;
+    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int vw = pm * 4 + w;
+    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFB * 64;
+    unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;
+    int errflag = 0;
 
 #pragma unroll 4
     for (int fi = 0; fi < LFB; ++fi) wl[(w * LFB + fi) * 64 + lane] = Wp[fi * 64 + lane];
+    u16x8_t wreg[RFB > 0 ? RFB : 1];
+#pragma unroll
+    for (int r = 0; r < RFB; ++r) wreg[r] = Wp[(LFB + r) * 64 + lane];
 
     long long rowoff[4];
     bool rv[4];
@@ -367,24 +473,25 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
         rv[r] = b < B;
         rowoff[r] = (long long)(b < B ? b : B - 1);
     }
-    f32x4_t dhr[UT];
-    float dcc[UT][4];
+    f32x4_t dhr[UTP];
+    float dcc[UTP][4];
 #pragma unroll
-    for (int j = 0; j < UT; ++j) {
+    for (int j = 0; j < UTP; ++j) {
         dhr[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) dcc[j][r] = 0.f;
     }
 
-    // per-step operands (prefetched one step ahead): dout, activated gates, c_t, c_prev  |  h_t (rnn)
+    // per-step operands, ONE register set: loaded for step s+1 right after step s's gate math consumed
+    // them, so the loads fly under the dG.W^T MFMAs.   dout, activated gates, c_t, c_prev | h_t (rnn)
     constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
-    float n_do[UT][4], n_g[NG][UT][4], n_c[UT][4], n_cp[UT][4];
+    float n_do[UTP][4], n_g[NG][UTP][4], n_c[UTP][4], n_cp[UTP][4];
     auto load_step = [&](int t) {
         const int tp = dir ? t + 1 : t - 1;
         const bool hasp = tp >= 0 && tp < T;
 #pragma unroll
-        for (int j = 0; j < UT; ++j) {
-            const int unit = w * (16 * UT) + j * 16 + c;
+        for (int j = 0; j < UTP; ++j) {
+            const int unit = vw * (16 * UTP) + j * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long fr = (rowoff[r] * T + t) * 2 + dir;
@@ -407,92 +514,112 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     int cur = 0;
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s;
-        float c_do[UT][4], c_g[NG][UT][4], c_c[UT][4], c_cp[UT][4];
-#pragma unroll
-        for (int j = 0; j < UT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                c_do[j][r] = n_do[j][r]; c_c[j][r] = n_c[j][r]; c_cp[j][r] = n_cp[j][r];
-#pragma unroll
-                for (int q = 0; q < NG; ++q) c_g[q][j][r] = n_g[q][j][r];
-            }
-        if (s + 1 < T) load_step(dir ? t + 1 : t - 1);
-
         unsigned short* dpc = dps + cur * 16 * LDG;
+        unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
 #pragma unroll
-        for (int j = 0; j < UT; ++j) {
-            const int unit = w * (16 * UT) + j * 16 + c;
+        for (int j = 0; j < UTP; ++j) {
+            const int unit = vw * (16 * UTP) + j * 16 + c;
+            unsigned short zb[G][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dh = c_do[j][r] + dhr[j][r];
+                const float dh = n_do[j][r] + dhr[j][r];
                 float dz[G];
                 if (CELL == LAS_CELL_LSTM) {
-                    const float gi = c_g[0][j][r], gj = c_g[NG > 1 ? 1 : 0][j][r], gf = c_g[NG > 2 ? 2 : 0][j][r],
-                                go = c_g[NG > 3 ? 3 : 0][j][r];
-                    const float tc = tanhx<true>(c_c[j][r]);
+                    const float gi = n_g[0][j][r], gj = n_g[NG > 1 ? 1 : 0][j][r], gf = n_g[NG > 2 ? 2 : 0][j][r],
+                                go = n_g[NG > 3 ? 3 : 0][j][r];
+                    const float tc = tanhx<true>(n_c[j][r]);
                     const float dc = dcc[j][r] + dh * go * (1.f - tc * tc);
                     dcc[j][r] = dc * gf;
                     dz[0] = dc * gj * gi * (1.f - gi);
                     dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
-                    dz[G > 2 ? 2 : 0] = dc * c_cp[j][r] * gf * (1.f - gf);
+                    dz[G > 2 ? 2 : 0] = dc * n_cp[j][r] * gf * (1.f - gf);
                     dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
                 } else {
-                    const float h = c_g[0][j][r];
+                    const float h = n_g[0][j][r];
                     dz[0] = dh * (1.f - h * h);
                 }
                 const long long fr = (rowoff[r] * T + t) * 2 + dir;
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
-                    dpc[(g * 4 + r) * LDG + q * H + unit] = f2bf(dz[q]);
+                    zb[q][r] = f2bf(dz[q]);
+                    dpc[(g * 4 + r) * LDG + q * H + unit] = zb[q][r];
                     if (rv[r]) a.gates[fr * GH + q * H + unit] = dz[q];
                 }
             }
-        }
-        __syncthreads();
-        f32x4_t acc[UT];
+            if (P > 1) {   // publish: per (gate q, tile j): 2 granules per lane
 #pragma unroll
-        for (int j = 0; j < UT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        granule_store(xslot + (size_t)pm * GPM + (((w * UTP + j) * G + q) * 2 + k) * 64 + lane, (unsigned)(s + 1),
+                                      (unsigned)zb[q][2 * k] | ((unsigned)zb[q][2 * k + 1] << 16));
+            }
+        }
+        if (s + 1 < T) load_step(dir ? t + 1 : t - 1);
+        if (P > 1) {
+#pragma unroll 1
+            for (int mo = 1; mo < P; ++mo) {
+                const int m = (pm + mo) % P;
+                const unsigned long long* src = xslot + (size_t)m * GPM;
+#pragma unroll
+                for (int i = 0; i < GPM / 256; ++i) {
+                    const int gi_ = tid + i * 256;
+                    const unsigned v = granule_wait(src + gi_, (unsigned)(s + 1), &errflag);
+                    const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, rest = gi_ >> 7;   // rest = (w'*UTP + j')*G + q
+                    const int q = rest % G, wj = rest / G;
+                    const int col = q * H + m * UPM + wj * 16 + (l2 & 15);
+                    const int row = (l2 >> 4) * 4 + 2 * k;
+                    dpc[row * LDG + col] = (unsigned short)(v & 0xffffu);
+                    dpc[(row + 1) * LDG + col] = (unsigned short)(v >> 16);
+                }
+            }
+        }
+        lds_barrier();
+        f32x4_t acc[UTP];
+#pragma unroll
+        for (int j = 0; j < UTP; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dpc[c * LDG + ks * 32 + g * 8]);
 #pragma unroll
-            for (int j = 0; j < UT; ++j) {
+            for (int j = 0; j < UTP; ++j) {
                 const int fi = j * KSB + ks;
-                const u16x8_t bv = fi < LFB ? wl[(w * LFB + fi) * 64 + lane] : Wp[fi * 64 + lane];
+                const u16x8_t bv = fi < LFB ? wl[(w * LFB + fi) * 64 + lane] : wreg[fi - LFB < RFB ? (fi - LFB >= 0 ? fi - LFB : 0) : 0];
                 acc[j] = mfma_bf16_16x16x32(av, bv, acc[j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < UT; ++j) dhr[j] = acc[j];
+        for (int j = 0; j < UTP; ++j) dhr[j] = acc[j];
         cur ^= 1;
     }
+    if (errflag && a.err) a.err[0] = 1;
 }
 
-// W_hh (fp32 [H, G*H]) -> bf16 MFMA B-fragment order.
-//  fwd: frag (dir,w,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + w*64 + j*16 + (lane&15)]
-//  bwd: frag (dir,w,j,ks):   B[k][n] = W[w*64 + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
+// W_hh (fp32 [H, G*H]) -> bf16 MFMA B-fragment order for 4*P "virtual waves" of 16*UTP units each.
+//  fwd: frag (dir,vw,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + vw*16*UTP + j*16 + (lane&15)]
+//  bwd: frag (dir,vw,j,ks):   B[k][n] = W[vw*16*UTP + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
 __global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const float* W1, int ldw, int H, int G,
-                                                       int bwd, unsigned short* out) {
-    const int UT = H / 64, GH = G * H;
+                                                       int bwd, int P, unsigned short* out) {
+    const int UTP = H / 64 / P, GH = G * H, NVW = 4 * P;
     const int KS = bwd ? GH / 32 : H / 32;
-    const int NF = bwd ? UT * KS : G * UT * KS;
+    const int NF = bwd ? UTP * KS : G * UTP * KS;
     const long long total = 2LL * H * GH;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const long long rest = idx >> 9;
         const int fi = (int)(rest % NF);
-        const int w = (int)((rest / NF) % 4);
-        const int dir = (int)(rest / ((long long)NF * 4));
+        const int vw = (int)((rest / NF) % NVW);
+        const int dir = (int)(rest / ((long long)NF * NVW));
         const float* W = dir ? W1 : W0;
         const int ks = fi % KS, qj = fi / KS;
         int row, col;
         if (!bwd) {
-            const int j = qj % UT, q = qj / UT;
+            const int j = qj % UTP, q = qj / UTP;
             row = ks * 32 + (lane >> 4) * 8 + e;
-            col = q * H + w * (16 * UT) + j * 16 + (lane & 15);
+            col = q * H + vw * (16 * UTP) + j * 16 + (lane & 15);
         } else {
             const int j = qj;
-            row = w * (16 * UT) + j * 16 + (lane & 15);
+            row = vw * (16 * UTP) + j * 16 + (lane & 15);
             col = ks * 32 + (lane >> 4) * 8 + e;
         }
         out[idx] = f2bf(W[(long long)row * ldw + col]);
@@ -504,10 +631,35 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const fl
 // ------------------------------------------------------------------------------------------------
 static bool mfma_shape_ok(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
 
-extern "C" size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H) {
+// cluster width: enough members that each keeps its W_hh slice resident (LDS + <=48 register fragments)
+static int pick_cluster(int cell, int H) {
+    int P;
+    if (cell == LAS_CELL_LSTM) P = H >= 512 ? 8 : (H >= 256 ? 4 : (H >= 128 ? 2 : 1));
+    else                       P = H >= 512 ? 2 : 1;
+    if (const char* e = getenv(cell == LAS_CELL_LSTM ? "LAS_LSTM_P" : "LAS_RNN_P")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
+    }
+    return P;
+}
+
+struct SeqWs { size_t pack, err, xbuf, total; };
+static SeqWs seq_ws_layout(int cell, int H, int B) {
     const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
-    // f32: W^T copy (bwd).  bf16: packed fragments.  Report the larger so one buffer serves both modes.
-    return 2 * G * H * H * sizeof(float) + 256;
+    SeqWs w;
+    w.pack = 0;
+    size_t o = (2 * G * H * H * sizeof(float) + 255) & ~(size_t)255;   // f32: W^T copy; bf16: packed fragments (half of it)
+    w.err = o; o += 256;
+    w.xbuf = o;
+    const size_t ncl = (size_t)((B + 15) / 16) * 2;
+    o += ncl * 2 * (8 * G * H) * sizeof(unsigned long long);           // [ncl][2 slots][P*GPM_B = 8*G*H]
+    w.total = o + 256;
+    return w;
+}
+
+extern "C" size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B) {
+    (void)prec;
+    return seq_ws_layout(cell, H, B > 0 ? B : 1).total;
 }
 
 template <typename K>
@@ -515,30 +667,46 @@ static int set_lds(K kern, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int CELL, int UT>
-static int launch_fwd_bf16(const RnnArgs& a, hipStream_t st) {
-    using C = RnnCfg<CELL, UT>;
-    static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT>, C::FWD_LDS);
-    if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd) failed: %d", attr); return attr; }
-    hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT>), dim3(cdiv(a.B, 16), 2), dim3(256), C::FWD_LDS, st, a);
-    return 0;
-}
-template <int CELL, int UT>
-static int launch_bwd_bf16(const RnnArgs& a, hipStream_t st) {
-    using C = RnnCfg<CELL, UT>;
-    static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT>, C::BWD_LDS);
-    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd) failed: %d", attr); return attr; }
-    hipLaunchKernelGGL((rnn_seq_bwd_bf16_kernel<CELL, UT>), dim3(cdiv(a.B, 16), 2), dim3(256), C::BWD_LDS, st, a);
-    return 0;
+template <int CELL, int UT, int P>
+static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
+    using C = RnnCfg<CELL, UT, P>;
+    if constexpr (!C::OK) {
+        las_set_error("rnn_seq: cluster width %d cannot keep W_hh resident for H=%d", P, C::H);
+        return -2;
+    } else {
+        dim3 grid(a.ncl_pad * P);
+        if (!bwd) {
+            static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT, P>, C::FWD_LDS);
+            if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd) failed: %d", attr); return attr; }
+            hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P>), grid, dim3(256), C::FWD_LDS, st, a);
+        } else {
+            static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT, P>, C::BWD_LDS);
+            if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd) failed: %d", attr); return attr; }
+            hipLaunchKernelGGL((rnn_seq_bwd_bf16_kernel<CELL, UT, P>), grid, dim3(256), C::BWD_LDS, st, a);
+        }
+        return 0;
+    }
 }
 
-template <int CELL>
-static int dispatch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
-    switch (a.H) {
-        case 64:  return bwd ? launch_bwd_bf16<CELL, 1>(a, st) : launch_fwd_bf16<CELL, 1>(a, st);
-        case 128: return bwd ? launch_bwd_bf16<CELL, 2>(a, st) : launch_fwd_bf16<CELL, 2>(a, st);
-        case 256: return bwd ? launch_bwd_bf16<CELL, 4>(a, st) : launch_fwd_bf16<CELL, 4>(a, st);
-        default:  return bwd ? launch_bwd_bf16<CELL, 8>(a, st) : launch_fwd_bf16<CELL, 8>(a, st);
+static int dispatch_bf16(int cell, int P, bool bwd, const RnnArgs& a, hipStream_t st) {
+    const int key = (cell == LAS_CELL_LSTM ? 1000 : 0) + (a.H / 64) * 10 + P;
+    switch (key) {
+        case 1011: return launch_bf16<LAS_CELL_LSTM, 1, 1>(bwd, a, st);
+        case 1021: return launch_bf16<LAS_CELL_LSTM, 2, 1>(bwd, a, st);
+        case 1022: return launch_bf16<LAS_CELL_LSTM, 2, 2>(bwd, a, st);
+        case 1042: return launch_bf16<LAS_CELL_LSTM, 4, 2>(bwd, a, st);
+        case 1044: return launch_bf16<LAS_CELL_LSTM, 4, 4>(bwd, a, st);
+        case 1088: return launch_bf16<LAS_CELL_LSTM, 8, 8>(bwd, a, st);
+        case 11:   return launch_bf16<LAS_CELL_RNN, 1, 1>(bwd, a, st);
+        case 21:   return launch_bf16<LAS_CELL_RNN, 2, 1>(bwd, a, st);
+        case 41:   return launch_bf16<LAS_CELL_RNN, 4, 1>(bwd, a, st);
+        case 42:   return launch_bf16<LAS_CELL_RNN, 4, 2>(bwd, a, st);
+        case 44:   return launch_bf16<LAS_CELL_RNN, 4, 4>(bwd, a, st);
+        case 82:   return launch_bf16<LAS_CELL_RNN, 8, 2>(bwd, a, st);
+        case 84:   return launch_bf16<LAS_CELL_RNN, 8, 4>(bwd, a, st);
+        default:
+            las_set_error("rnn_seq: no bf16 kernel for cell=%d H=%d P=%d", cell, a.H, P);
+            return -2;
     }
 }
 
@@ -554,23 +722,51 @@ static int check_common(const char* who, int cell, int prec, int B, int T, int H
     return 0;
 }
 
+// bf16 path: pack W_hh, zero the exchange granules, launch the (clustered) persistent sweep
+static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float* w1, int ldw, void* ws, size_t ws_bytes,
+                    hipStream_t st) {
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1, H = a.H;
+    const SeqWs L = seq_ws_layout(cell, H, a.B);
+    LAS_ARG(ws && ws_bytes >= L.total, "las_rnn_seq: workspace too small (%zu < %zu)", ws_bytes, L.total);
+    int P = pick_cluster(cell, H);
+    char* base = (char*)ws;
+    a.wpack = base + L.pack;
+    a.err = (int*)(base + L.err);
+    a.xbuf = (unsigned long long*)(base + L.xbuf);
+    a.ncl = cdiv(a.B, 16) * 2;
+    a.ncl_pad = (a.ncl + 7) / 8 * 8;
+    if ((long long)a.ncl_pad * P > 256) P = 1;          // every member must be co-resident (1 workgroup per CU)
+    hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
+                       (unsigned short*)a.wpack);
+    LAS_LAUNCHED();
+    if (P > 1) LAS_HIP(hipMemsetAsync(base + L.err, 0, L.total - L.err, st));
+    int rc = dispatch_bf16(cell, P, bwd, a, st);
+    if (rc == -2 && P != 1) {                            // fall back to the widest supported cluster
+        for (int q = 8; q >= 1 && rc == -2; q >>= 1) {
+            if (q == P || (long long)a.ncl_pad * q > 256) continue;
+            hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G,
+                               bwd ? 1 : 0, q, (unsigned short*)a.wpack);
+            rc = dispatch_bf16(cell, q, bwd, a, st);
+        }
+    }
+    return rc;
+}
+
 extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, float* out, int ld_out, long long out_bstride,
                                float* cstate, float forget_bias, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int G = cell == LAS_CELL_LSTM ? 4 : 1;
     RnnArgs a;
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
     a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.ncl = a.ncl_pad = 0;
+#ifdef LAS_PROF
+    if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);
+#endif
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
-        LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * 2, "las_rnn_seq_fwd: workspace too small");
-        hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw, H,
-                           G, 0, (unsigned short*)ws);
-        LAS_LAUNCHED();
-        int rc = cell == LAS_CELL_LSTM ? dispatch_bf16<LAS_CELL_LSTM>(false, a, st) : dispatch_bf16<LAS_CELL_RNN>(false, a, st);
-        if (rc) return rc;
+        if (int rc = run_bf16(false, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
     } else {
         const size_t lds = (size_t)H * F32_BT * sizeof(float);
         dim3 grid(cdiv(B, F32_BT), 2);
@@ -593,13 +789,9 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
     a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.ncl = a.ncl_pad = 0;
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
-        LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * 2, "las_rnn_seq_bwd: workspace too small");
-        hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw, H,
-                           G, 1, (unsigned short*)ws);
-        LAS_LAUNCHED();
-        int rc = cell == LAS_CELL_LSTM ? dispatch_bf16<LAS_CELL_LSTM>(true, a, st) : dispatch_bf16<LAS_CELL_RNN>(true, a, st);
-        if (rc) return rc;
+        if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
     } else {
         LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * sizeof(float), "las_rnn_seq_bwd: workspace too small");
         hipLaunchKernelGGL(transpose_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw,

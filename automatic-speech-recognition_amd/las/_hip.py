@@ -52,7 +52,7 @@ _SIGS = {
     "las_colsum_workspace_bytes": (c_size_t, [c_int]),
     "las_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_tanh_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "las_rnn_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "las_rnn_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "las_rnn_seq_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_longlong, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
@@ -203,14 +203,14 @@ class _timed:
         return False
 
 
-def rnn_seq_ws(cell, prec, H, dev):
-    return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H), "rnn_seq")
+def rnn_seq_ws(cell, prec, H, B, dev):
+    return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H, B), "rnn_seq")
 
 
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 forget_bias=1.0, wf_off=0, wb_off=0):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
-    ws = rnn_seq_ws(cell, prec, H, gates.device)
+    ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                     c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
@@ -220,7 +220,7 @@ def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0):
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
-    ws = rnn_seq_ws(cell, prec, H, gates.device)
+    ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_bwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                     c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,

@@ -82,7 +82,7 @@ int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, 
  * cstate: lstm only, [B,T,2,H] cell states (saved for bwd).
  * dout  : gradient w.r.t. out, same addressing scheme.
  */
-size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H);
+size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
 int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
                     float* out, int ld_out, long long out_bstride, float* cstate,

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(libpath):
     assert l.las_version() >= 100
     assert l.las_last_error() is not None
     # workspace queries are pure host arithmetic: callable without a GPU
-    assert l.las_rnn_seq_workspace_bytes(1, 1, 256) >= 2 * 4 * 256 * 256 * 4
+    assert l.las_rnn_seq_workspace_bytes(1, 1, 256, 48) >= 2 * 4 * 256 * 256 * 4
     assert l.las_colsum_workspace_bytes(100) == 64 * 100 * 4
     assert l.las_speller_workspace_bytes(48, 160, 512, 128, 512, 1, 128, 30, 200, 1) > 0
 
