@@ -255,6 +255,34 @@ __device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, un
     return (unsigned)x;
 }
 
+// Fetch this thread's N granules (all loads in flight at once), then re-poll only the stale ones.
+template <int N, int P, int GPM>
+__device__ __forceinline__ void gather_granules(unsigned long long (&xv)[N], const unsigned long long* xslot, int pm, int tid,
+                                                unsigned tag, int& errflag) {
+    constexpr int PER = GPM / 256;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int m = (pm + 1 + n / PER) % P;
+        xv[n] = __hip_atomic_load(xslot + (size_t)m * GPM + tid + (n % PER) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int n = 0; n < N; ++n) ok &= (unsigned)(xv[n] >> 32) == tag;
+        if (ok) break;
+        if (--budget <= 0) { errflag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            if ((unsigned)(xv[n] >> 32) != tag) {
+                const int m = (pm + 1 + n / PER) % P;
+                xv[n] = __hip_atomic_load(xslot + (size_t)m * GPM + tid + (n % PER) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 template <int CELL, int UT, int P>
 struct RnnCfg {
     static constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
@@ -265,19 +293,22 @@ struct RnnCfg {
     static constexpr int NFW = G * UTP * KS;      // B fragments per wave, forward
     static constexpr int LDH = H + 8;             // bf16 row pitch of the h tile
     static constexpr int HS_BYTES = 2 * 16 * LDH * 2;
-    static constexpr int LF = cmin(NFW, (150 * 1024 - HS_BYTES) / 4096);   // fragments/wave resident in LDS
-    static constexpr int RF = NFW - LF;           // fragments/wave pinned in VGPR/AGPRs (must stay <= ~48)
+    // W_hh slice placement: VGPR/AGPRs first (one wave per SIMD owns 512 registers per lane; an MFMA B operand
+    // that already sits in a register costs no LDS cycle and no latency), LDS for the remainder.
+    static constexpr int RCAP = 64;               // fragments (x4 registers) a wave may pin
+    static constexpr int RF = cmin(NFW, RCAP);
+    static constexpr int LF = cmin(NFW - RF, (150 * 1024 - HS_BYTES) / 4096);
     static constexpr int KSB = GH / 32;           // k-steps of the backward product (K = G*H)
     static constexpr int NFB = UTP * KSB;
     static constexpr int LDG = GH + 8;
     static constexpr int DP_BYTES = 2 * 16 * LDG * 2;
-    static constexpr int LFB = cmax(0, cmin(NFB, (150 * 1024 - DP_BYTES) / 4096));
-    static constexpr int RFB = NFB - LFB;
+    static constexpr int RFB = cmin(NFB, RCAP);
+    static constexpr int LFB = cmax(0, cmin(NFB - RFB, (150 * 1024 - DP_BYTES) / 4096));
     static constexpr int FWD_LDS = HS_BYTES + 4 * LF * 1024;
     static constexpr int BWD_LDS = DP_BYTES + 4 * LFB * 1024;
     static constexpr int GPM_F = 16 * UPM / 2;        // granules one member publishes per step, forward
     static constexpr int GPM_B = 16 * G * UPM / 2;    // ... backward
-    static constexpr bool OK = (UT % P == 0) && RF <= 48 && RFB <= 48;
+    static constexpr bool OK = (UT % P == 0) && (RF + LF == NFW) && (RFB + LFB == NFB);
 };
 
 template <int CELL, int UT, int P>
@@ -298,21 +329,32 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;                 // [2 slots][P][GPM]
     int errflag = 0;
 
-#pragma unroll 4
-    for (int fi = 0; fi < LF; ++fi) wl[(w * LF + fi) * 64 + lane] = Wp[fi * 64 + lane];
     u16x8_t wreg[RF > 0 ? RF : 1];
 #pragma unroll
-    for (int r = 0; r < RF; ++r) wreg[r] = Wp[(LF + r) * 64 + lane];
+    for (int r = 0; r < RF; ++r) wreg[r] = Wp[r * 64 + lane];
+#pragma unroll 4
+    for (int fi = 0; fi < LF; ++fi) wl[(w * LF + fi) * 64 + lane] = Wp[(RF + fi) * 64 + lane];
     for (int i = tid; i < 16 * LDH; i += 256) hs[i] = 0;
     __syncthreads();
 
-    long long rowoff[4];
+    // per-lane running pointers (rows g*4+r of the tile, this wave's first unit column); they advance by one
+    // frame per step, so the loop body carries no 64-bit index arithmetic
+    const int t0 = dir ? T - 1 : 0;
+    const long long tstep = dir ? -1 : 1;
+    const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out;
+    float* gptr[4];
+    float* cptr[4];
+    float* optr[4];
     bool rv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + g * 4 + r;
         rv[r] = b < B;
-        rowoff[r] = (long long)(b < B ? b : B - 1);
+        const long long row = (long long)(b < B ? b : B - 1);
+        const int u0 = vw * (16 * UTP) + c;
+        gptr[r] = a.gates + ((row * T + t0) * 2 + dir) * GH + u0;
+        cptr[r] = a.cstate ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : nullptr;
+        optr[r] = a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0;
     }
     float cst[UTP][4];
 #pragma unroll
@@ -322,16 +364,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 
     // x-projection of the step about to run; it seeds the accumulators (acc = x.W_ih + b, then += h.W_hh)
     f32x4_t xn[G][UTP];
-    {
-        const int t0 = dir ? T - 1 : 0;
 #pragma unroll
-        for (int q = 0; q < G; ++q)
+    for (int q = 0; q < G; ++q)
 #pragma unroll
-            for (int j = 0; j < UTP; ++j)
+        for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xn[q][j][r] = a.gates[((rowoff[r] * T + t0) * 2 + dir) * GH + q * H + vw * (16 * UTP) + j * 16 + c];
-    }
+            for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][q * H + j * 16];
     int cur = 0;
 #ifdef LAS_PROF
     const bool prof = a.dbg && blockIdx.x == 0 && tid == 0;
@@ -341,7 +379,6 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #define STAMP(k)
 #endif
     for (int s = 0; s < T; ++s) {
-        const int t = dir ? T - 1 - s : s;
         STAMP(0);
         f32x4_t acc[G][UTP];
 #pragma unroll
@@ -349,14 +386,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
             for (int j = 0; j < UTP; ++j) acc[q][j] = xn[q][j];
         if (s + 1 < T) {   // next step's x-projection flies under this step's MFMAs
-            const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
                 for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        xn[q][j][r] = a.gates[((rowoff[r] * T + tn) * 2 + dir) * GH + q * H + vw * (16 * UTP) + j * 16 + c];
+                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][gstep + q * H + j * 16];
         }
         const unsigned short* hcur = hs + cur * 16 * LDH;
 #pragma unroll
@@ -367,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
                 for (int j = 0; j < UTP; ++j) {
                     const int fi = (q * UTP + j) * KS + ks;
-                    const u16x8_t bv = fi < LF ? wl[(w * LF + fi) * 64 + lane] : wreg[fi - LF < RF ? (fi - LF >= 0 ? fi - LF : 0) : 0];
+                    const u16x8_t bv = fi < RF ? wreg[fi < RF ? fi : 0] : wl[(w * LF + (fi - RF)) * 64 + lane];
                     acc[q][j] = mfma_bf16_16x16x32(av, bv, acc[q][j]);
                 }
         }
@@ -385,7 +420,6 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float h;
-                const long long fr = (rowoff[r] * T + t) * 2 + dir;
                 if (CELL == LAS_CELL_LSTM) {
                     const float gi = sigm<true>(acc[0][j][r]);
                     const float gj = tanhx<true>(acc[G > 1 ? 1 : 0][j][r]);
@@ -395,16 +429,16 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
                     cst[j][r] = cc;
                     h = tanhx<true>(cc) * go;
                     if (rv[r]) {
-                        float* gp = a.gates + fr * GH + unit;
+                        float* gp = gptr[r] + j * 16;
                         gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
-                        a.cstate[fr * H + unit] = cc;
+                        cptr[r][j * 16] = cc;
                     }
                 } else {
                     h = tanhx<true>(acc[0][j][r]);
                 }
                 hb[r] = f2bf(h);
                 hnext[(g * 4 + r) * LDH + unit] = hb[r];
-                if (rv[r]) a.out[rowoff[r] * a.obs + (long long)t * a.ld_out + dir * H + unit] = h;
+                if (rv[r]) optr[r][j * 16] = h;
             }
             if (P > 1 && s + 1 < T) {   // publish this wave's slice: 2 granules per lane per tile (rows g*4+{0,1}, g*4+{2,3})
 #pragma unroll
@@ -415,22 +449,23 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
         }
         STAMP(3);
         if (P > 1 && s + 1 < T) {       // gather the other members' slices of h_t into the LDS tile
-#pragma unroll 1
-            for (int mo = 1; mo < P; ++mo) {
-                const int m = (pm + mo) % P;
-                const unsigned long long* src = xslot + (size_t)m * GPM;
+            constexpr int PER = GPM / 256, NGT = (P > 1 ? (P - 1) * PER : 1);
+            unsigned long long xv[NGT];
+            gather_granules<NGT, P, GPM>(xv, xslot, pm, tid, (unsigned)(s + 1), errflag);
 #pragma unroll
-                for (int i = 0; i < GPM / 256; ++i) {
-                    const int gi_ = tid + i * 256;
-                    const unsigned v = granule_wait(src + gi_, (unsigned)(s + 1), &errflag);
-                    const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, wj = gi_ >> 7;     // wj = w'*UTP + j'
-                    const int unit = m * UPM + wj * 16 + (l2 & 15);
-                    const int row = (l2 >> 4) * 4 + 2 * k;
-                    hnext[row * LDH + unit] = (unsigned short)(v & 0xffffu);
-                    hnext[(row + 1) * LDH + unit] = (unsigned short)(v >> 16);
-                }
+            for (int n = 0; n < NGT; ++n) {
+                const int m = (pm + 1 + n / PER) % P;
+                const int gi_ = tid + (n % PER) * 256;
+                const unsigned v = (unsigned)xv[n];
+                const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, wj = gi_ >> 7;     // wj = w'*UTP + j'
+                const int unit = m * UPM + wj * 16 + (l2 & 15);
+                const int row = (l2 >> 4) * 4 + 2 * k;
+                hnext[row * LDH + unit] = (unsigned short)(v & 0xffffu);
+                hnext[(row + 1) * LDH + unit] = (unsigned short)(v >> 16);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gptr[r] += gstep; optr[r] += ostep; if (CELL == LAS_CELL_LSTM) cptr[r] += cstep; }
         lds_barrier();
         STAMP(4);
         cur ^= 1;
@@ -459,19 +494,32 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;
     int errflag = 0;
 
-#pragma unroll 4
-    for (int fi = 0; fi < LFB; ++fi) wl[(w * LFB + fi) * 64 + lane] = Wp[fi * 64 + lane];
     u16x8_t wreg[RFB > 0 ? RFB : 1];
 #pragma unroll
-    for (int r = 0; r < RFB; ++r) wreg[r] = Wp[(LFB + r) * 64 + lane];
+    for (int r = 0; r < RFB; ++r) wreg[r] = Wp[r * 64 + lane];
+#pragma unroll 4
+    for (int fi = 0; fi < LFB; ++fi) wl[(w * LFB + fi) * 64 + lane] = Wp[(RFB + fi) * 64 + lane];
 
-    long long rowoff[4];
+    // the sweep visits t in the REVERSE of the forward order; the next visited frame t+tstep is also the
+    // forward predecessor of t, so c_prev(t) is simply c(t+tstep) -- loaded one step further ahead
+    const int t0 = dir ? 0 : T - 1;
+    const long long tstep = dir ? 1 : -1;
+    const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
+    float* gptr[4];
+    const float* cptr[4];
+    const float* optr[4];
+    const float* dptr[4];
     bool rv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + g * 4 + r;
         rv[r] = b < B;
-        rowoff[r] = (long long)(b < B ? b : B - 1);
+        const long long row = (long long)(b < B ? b : B - 1);
+        const int u0 = vw * (16 * UTP) + c;
+        gptr[r] = a.gates + ((row * T + t0) * 2 + dir) * GH + u0;
+        cptr[r] = a.cstate ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : nullptr;
+        optr[r] = a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0;
+        dptr[r] = a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0;
     }
     f32x4_t dhr[UTP];
     float dcc[UTP][4];
@@ -482,38 +530,29 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
         for (int r = 0; r < 4; ++r) dcc[j][r] = 0.f;
     }
 
-    // per-step operands, ONE register set: loaded for step s+1 right after step s's gate math consumed
-    // them, so the loads fly under the dG.W^T MFMAs.   dout, activated gates, c_t, c_prev | h_t (rnn)
+    // per-step operands, ONE register set, refilled for step s+1 right after step s's gate math consumed
+    // them, so the loads fly under the dG.W^T MFMAs:  dout, activated gates (lstm) | h_t (rnn), c_t, c_next
     constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
-    float n_do[UTP][4], n_g[NG][UTP][4], n_c[UTP][4], n_cp[UTP][4];
-    auto load_step = [&](int t) {
-        const int tp = dir ? t + 1 : t - 1;
-        const bool hasp = tp >= 0 && tp < T;
+    float n_do[UTP][4], n_g[NG][UTP][4], n_c[UTP][4], n_cn[UTP][4];
 #pragma unroll
-        for (int j = 0; j < UTP; ++j) {
-            const int unit = vw * (16 * UTP) + j * 16 + c;
+    for (int j = 0; j < UTP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long fr = (rowoff[r] * T + t) * 2 + dir;
-                n_do[j][r] = a.dout[rowoff[r] * a.dobs + (long long)t * a.ld_dout + dir * H + unit];
-                if (CELL == LAS_CELL_LSTM) {
+        for (int r = 0; r < 4; ++r) {
+            n_do[j][r] = dptr[r][j * 16];
+            if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
-                    for (int q = 0; q < NG; ++q) n_g[q][j][r] = a.gates[fr * GH + q * H + unit];
-                    n_c[j][r] = a.cstate[fr * H + unit];
-                    n_cp[j][r] = hasp ? a.cstate[((rowoff[r] * T + tp) * 2 + dir) * H + unit] : 0.f;
-                } else {
-                    n_g[0][j][r] = a.out[rowoff[r] * a.obs + (long long)t * a.ld_out + dir * H + unit];
-                    n_c[j][r] = 0.f; n_cp[j][r] = 0.f;
-                }
+                for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
+                n_c[j][r] = cptr[r][j * 16];
+                n_cn[j][r] = T > 1 ? cptr[r][cstep + j * 16] : 0.f;
+            } else {
+                n_g[0][j][r] = optr[r][j * 16];
+                n_c[j][r] = 0.f; n_cn[j][r] = 0.f;
             }
         }
-    };
-    load_step(dir ? 0 : T - 1);
     __syncthreads();  // LDS weight fragments visible
 
     int cur = 0;
     for (int s = 0; s < T; ++s) {
-        const int t = dir ? s : T - 1 - s;
         unsigned short* dpc = dps + cur * 16 * LDG;
         unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
 #pragma unroll
@@ -527,23 +566,23 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
                 if (CELL == LAS_CELL_LSTM) {
                     const float gi = n_g[0][j][r], gj = n_g[NG > 1 ? 1 : 0][j][r], gf = n_g[NG > 2 ? 2 : 0][j][r],
                                 go = n_g[NG > 3 ? 3 : 0][j][r];
+                    const float cprev = (s + 1 < T) ? n_cn[j][r] : 0.f;
                     const float tc = tanhx<true>(n_c[j][r]);
                     const float dc = dcc[j][r] + dh * go * (1.f - tc * tc);
                     dcc[j][r] = dc * gf;
                     dz[0] = dc * gj * gi * (1.f - gi);
                     dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
-                    dz[G > 2 ? 2 : 0] = dc * n_cp[j][r] * gf * (1.f - gf);
+                    dz[G > 2 ? 2 : 0] = dc * cprev * gf * (1.f - gf);
                     dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
                 } else {
                     const float h = n_g[0][j][r];
                     dz[0] = dh * (1.f - h * h);
                 }
-                const long long fr = (rowoff[r] * T + t) * 2 + dir;
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     zb[q][r] = f2bf(dz[q]);
                     dpc[(g * 4 + r) * LDG + q * H + unit] = zb[q][r];
-                    if (rv[r]) a.gates[fr * GH + q * H + unit] = dz[q];
+                    if (rv[r]) gptr[r][q * H + j * 16] = dz[q];
                 }
             }
             if (P > 1) {   // publish: per (gate q, tile j): 2 granules per lane
@@ -555,23 +594,40 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
                                       (unsigned)zb[q][2 * k] | ((unsigned)zb[q][2 * k + 1] << 16));
             }
         }
-        if (s + 1 < T) load_step(dir ? t + 1 : t - 1);
-        if (P > 1) {
-#pragma unroll 1
-            for (int mo = 1; mo < P; ++mo) {
-                const int m = (pm + mo) % P;
-                const unsigned long long* src = xslot + (size_t)m * GPM;
+        // advance to the next visited frame and refill the operand registers
 #pragma unroll
-                for (int i = 0; i < GPM / 256; ++i) {
-                    const int gi_ = tid + i * 256;
-                    const unsigned v = granule_wait(src + gi_, (unsigned)(s + 1), &errflag);
-                    const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, rest = gi_ >> 7;   // rest = (w'*UTP + j')*G + q
-                    const int q = rest % G, wj = rest / G;
-                    const int col = q * H + m * UPM + wj * 16 + (l2 & 15);
-                    const int row = (l2 >> 4) * 4 + 2 * k;
-                    dpc[row * LDG + col] = (unsigned short)(v & 0xffffu);
-                    dpc[(row + 1) * LDG + col] = (unsigned short)(v >> 16);
+        for (int r = 0; r < 4; ++r) { gptr[r] += gstep; optr[r] += ostep; dptr[r] += dstep; if (CELL == LAS_CELL_LSTM) cptr[r] += cstep; }
+        if (s + 1 < T) {
+#pragma unroll
+            for (int j = 0; j < UTP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    n_do[j][r] = dptr[r][j * 16];
+                    if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
+                        n_c[j][r] = n_cn[j][r];
+                        n_cn[j][r] = (s + 2 < T) ? cptr[r][cstep + j * 16] : 0.f;
+                    } else {
+                        n_g[0][j][r] = optr[r][j * 16];
+                    }
                 }
+        }
+        if (P > 1) {
+            constexpr int PER = GPM / 256, NGT = (P > 1 ? (P - 1) * PER : 1);
+            unsigned long long xv[NGT];
+            gather_granules<NGT, P, GPM>(xv, xslot, pm, tid, (unsigned)(s + 1), errflag);
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int m = (pm + 1 + n / PER) % P;
+                const int gi_ = tid + (n % PER) * 256;
+                const unsigned v = (unsigned)xv[n];
+                const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, rest = gi_ >> 7;   // rest = (w'*UTP + j')*G + q
+                const int q = rest % G, wj = rest / G;
+                const int col = q * H + m * UPM + wj * 16 + (l2 & 15);
+                const int row = (l2 >> 4) * 4 + 2 * k;
+                dpc[row * LDG + col] = (unsigned short)(v & 0xffffu);
+                dpc[(row + 1) * LDG + col] = (unsigned short)(v >> 16);
             }
         }
         lds_barrier();
@@ -584,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
             for (int j = 0; j < UTP; ++j) {
                 const int fi = j * KSB + ks;
-                const u16x8_t bv = fi < LFB ? wl[(w * LFB + fi) * 64 + lane] : wreg[fi - LFB < RFB ? (fi - LFB >= 0 ? fi - LFB : 0) : 0];
+                const u16x8_t bv = fi < RFB ? wreg[fi < RFB ? fi : 0] : wl[(w * LFB + (fi - RFB)) * 64 + lane];
                 acc[j] = mfma_bf16_16x16x32(av, bv, acc[j]);
             }
         }
