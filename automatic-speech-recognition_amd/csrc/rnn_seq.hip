@@ -29,6 +29,7 @@ struct RnnArgs {
     const void* wpack;
     long long* dbg;   // LAS_PROF builds only: device buffer for s_memtime stamps (env LAS_DBG_PTR)
     unsigned long long* xbuf; int* err;     // cluster exchange granules / bounded-spin error flag
+    float* sink;                             // scratch rows for the padded part of a ragged batch tile
     int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
 };
 
@@ -342,19 +343,21 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
     const int t0 = dir ? T - 1 : 0;
     const long long tstep = dir ? -1 : 1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out;
+    // rows past the end of a ragged batch tile read/write a scratch row (no exec-mask branches in the loop)
     float* gptr[4];
     float* cptr[4];
     float* optr[4];
-    bool rv[4];
+    long long gst[4], cst_[4], ost[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + g * 4 + r;
-        rv[r] = b < B;
-        const long long row = (long long)(b < B ? b : B - 1);
+        const bool valid = b < B;
+        const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = a.gates + ((row * T + t0) * 2 + dir) * GH + u0;
-        cptr[r] = a.cstate ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : nullptr;
-        optr[r] = a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0;
+        gptr[r] = valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0;
+        cptr[r] = (valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0;
+        optr[r] = valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0;
+        gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0;
     }
     float cst[UTP][4];
 #pragma unroll
@@ -391,19 +394,21 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
                 for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][gstep + q * H + j * 16];
+                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][gst[r] + q * H + j * 16];
         }
         const unsigned short* hcur = hs + cur * 16 * LDH;
+        u16x8_t av[KS];                  // all A fragments of h_{t-1} up front: one LDS round trip, then MFMAs back to back
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
                 for (int j = 0; j < UTP; ++j) {
                     const int fi = (q * UTP + j) * KS + ks;
                     const u16x8_t bv = fi < RF ? wreg[fi < RF ? fi : 0] : wl[(w * LF + (fi - RF)) * 64 + lane];
-                    acc[q][j] = mfma_bf16_16x16x32(av, bv, acc[q][j]);
+                    acc[q][j] = mfma_bf16_16x16x32(av[ks], bv, acc[q][j]);
                 }
         }
         STAMP(1);
@@ -413,6 +418,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
         STAMP(2);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
         unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
+        float sv_h[UTP][4], sv_g[G][UTP][4];     // results kept in registers; written to HBM after the exchange
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
             const int unit = vw * (16 * UTP) + j * 16 + c;
@@ -428,17 +434,13 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
                     const float cc = cst[j][r] * gf + gi * gj;
                     cst[j][r] = cc;
                     h = tanhx<true>(cc) * go;
-                    if (rv[r]) {
-                        float* gp = gptr[r] + j * 16;
-                        gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
-                        cptr[r][j * 16] = cc;
-                    }
+                    sv_g[0][j][r] = gi; sv_g[G > 1 ? 1 : 0][j][r] = gj; sv_g[G > 2 ? 2 : 0][j][r] = gf; sv_g[G > 3 ? 3 : 0][j][r] = go;
                 } else {
                     h = tanhx<true>(acc[0][j][r]);
                 }
+                sv_h[j][r] = h;
                 hb[r] = f2bf(h);
                 hnext[(g * 4 + r) * LDH + unit] = hb[r];
-                if (rv[r]) optr[r][j * 16] = h;
             }
             if (P > 1 && s + 1 < T) {   // publish this wave's slice: 2 granules per lane per tile (rows g*4+{0,1}, g*4+{2,3})
 #pragma unroll
@@ -464,10 +466,23 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
                 hnext[(row + 1) * LDH + unit] = (unsigned short)(v >> 16);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { gptr[r] += gstep; optr[r] += ostep; if (CELL == LAS_CELL_LSTM) cptr[r] += cstep; }
         lds_barrier();
         STAMP(4);
+        // bulk results of this step: nobody waits on these stores (the next vmcnt wait is a whole step away)
+#pragma unroll
+        for (int j = 0; j < UTP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (CELL == LAS_CELL_LSTM) {
+                    float* gp = gptr[r] + j * 16;
+                    gp[0] = sv_g[0][j][r]; gp[H] = sv_g[G > 1 ? 1 : 0][j][r]; gp[2 * H] = sv_g[G > 2 ? 2 : 0][j][r];
+                    gp[3 * H] = sv_g[G > 3 ? 3 : 0][j][r];
+                    cptr[r][j * 16] = cst[j][r];
+                }
+                optr[r][j * 16] = sv_h[j][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gptr[r] += gst[r]; optr[r] += ost[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         cur ^= 1;
     }
     if (errflag && a.err) a.err[0] = 1;
@@ -509,17 +524,18 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     const float* cptr[4];
     const float* optr[4];
     const float* dptr[4];
-    bool rv[4];
+    long long gst[4], cst_[4], ost[4], dst[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + g * 4 + r;
-        rv[r] = b < B;
-        const long long row = (long long)(b < B ? b : B - 1);
+        const bool valid = b < B;
+        const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = a.gates + ((row * T + t0) * 2 + dir) * GH + u0;
-        cptr[r] = a.cstate ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : nullptr;
-        optr[r] = a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0;
-        dptr[r] = a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0;
+        gptr[r] = valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0;
+        cptr[r] = (valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0;
+        optr[r] = valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0;
+        dptr[r] = valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0;
+        gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
     }
     f32x4_t dhr[UTP];
     float dcc[UTP][4];
@@ -543,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
                 for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
                 n_c[j][r] = cptr[r][j * 16];
-                n_cn[j][r] = T > 1 ? cptr[r][cstep + j * 16] : 0.f;
+                n_cn[j][r] = T > 1 ? cptr[r][cst_[r] + j * 16] : 0.f;
             } else {
                 n_g[0][j][r] = optr[r][j * 16];
                 n_c[j][r] = 0.f; n_cn[j][r] = 0.f;
@@ -555,6 +571,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     for (int s = 0; s < T; ++s) {
         unsigned short* dpc = dps + cur * 16 * LDG;
         unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
+        float sv_z[G][UTP][4];
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
             const int unit = vw * (16 * UTP) + j * 16 + c;
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
                 for (int q = 0; q < G; ++q) {
                     zb[q][r] = f2bf(dz[q]);
                     dpc[(g * 4 + r) * LDG + q * H + unit] = zb[q][r];
-                    if (rv[r]) gptr[r][q * H + j * 16] = dz[q];
+                    sv_z[q][j][r] = dz[q];
                 }
             }
             if (P > 1) {   // publish: per (gate q, tile j): 2 granules per lane
@@ -594,9 +611,11 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
                                       (unsigned)zb[q][2 * k] | ((unsigned)zb[q][2 * k + 1] << 16));
             }
         }
-        // advance to the next visited frame and refill the operand registers
+        // advance to the next visited frame and refill the operand registers (dz of this step is written
+        // to HBM after the exchange; the pointers keep the previous frame in gprev)
+        float* gprev[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { gptr[r] += gstep; optr[r] += ostep; dptr[r] += dstep; if (CELL == LAS_CELL_LSTM) cptr[r] += cstep; }
+        for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         if (s + 1 < T) {
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
                         for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
                         n_c[j][r] = n_cn[j][r];
-                        n_cn[j][r] = (s + 2 < T) ? cptr[r][cstep + j * 16] : 0.f;
+                        n_cn[j][r] = (s + 2 < T) ? cptr[r][cst_[r] + j * 16] : 0.f;
                     } else {
                         n_g[0][j][r] = optr[r][j * 16];
                     }
@@ -631,6 +650,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
             }
         }
         lds_barrier();
+#pragma unroll
+        for (int j = 0; j < UTP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < G; ++q) gprev[r][q * H + j * 16] = sv_z[q][j][r];
         f32x4_t acc[UTP];
 #pragma unroll
         for (int j = 0; j < UTP; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -699,13 +724,14 @@ static int pick_cluster(int cell, int H) {
     return P;
 }
 
-struct SeqWs { size_t pack, err, xbuf, total; };
+struct SeqWs { size_t pack, err, sink, xbuf, total; };
 static SeqWs seq_ws_layout(int cell, int H, int B) {
     const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
     SeqWs w;
     w.pack = 0;
     size_t o = (2 * G * H * H * sizeof(float) + 255) & ~(size_t)255;   // f32: W^T copy; bf16: packed fragments (half of it)
     w.err = o; o += 256;
+    w.sink = o; o += ((size_t)(G * H + 64) * sizeof(float) + 255) & ~(size_t)255;
     w.xbuf = o;
     const size_t ncl = (size_t)((B + 15) / 16) * 2;
     o += ncl * 2 * (8 * G * H) * sizeof(unsigned long long);           // [ncl][2 slots][P*GPM_B = 8*G*H]
@@ -788,6 +814,7 @@ static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float
     char* base = (char*)ws;
     a.wpack = base + L.pack;
     a.err = (int*)(base + L.err);
+    a.sink = (float*)(base + L.sink);
     a.xbuf = (unsigned long long*)(base + L.xbuf);
     a.ncl = cdiv(a.B, 16) * 2;
     a.ncl_pad = (a.ncl + 7) / 8 * 8;
@@ -795,7 +822,7 @@ static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float
     hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
                        (unsigned short*)a.wpack);
     LAS_LAUNCHED();
-    if (P > 1) LAS_HIP(hipMemsetAsync(base + L.err, 0, L.total - L.err, st));
+    LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
     int rc = dispatch_bf16(cell, P, bwd, a, st);
     if (rc == -2 && P != 1) {                            // fall back to the widest supported cluster
         for (int q = 8; q >= 1 && rc == -2; q >>= 1) {
@@ -817,7 +844,7 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
     a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.ncl = a.ncl_pad = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);
 #endif
@@ -845,7 +872,7 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
     a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.ncl = a.ncl_pad = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0;
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
         if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
     } else {
