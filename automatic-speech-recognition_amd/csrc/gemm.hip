@@ -435,3 +435,119 @@ extern "C" int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, 
     LAS_LAUNCHED();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// skinny-M contraction with pre-packed bf16 weights (see las_common.h)
+// fragment (ct, ks): lane l holds B[ks*32 + 8*(l>>4) + e][ct*16 + (l&15)], e = 0..7   (zero past K / N)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void skinny_pack_kernel(const float* __restrict__ W, int ldw, int K, int N, int transposed,
+                                                          int KS, unsigned short* __restrict__ out, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long f = idx >> 9;
+        const int ks = (int)(f % KS), ct = (int)(f / KS);
+        const int k = ks * 32 + (lane >> 4) * 8 + e, n = ct * 16 + (lane & 15);
+        float v = 0.f;
+        if (k < K && n < N) v = transposed ? W[(long long)n * ldw + k] : W[(long long)k * ldw + n];
+        out[idx] = f2bf(v);
+    }
+}
+
+size_t las_skinny_pack_bytes(int K, int N) { return (size_t)cdiv(N, 16) * cdiv(K, 32) * 1024; }
+
+int las_skinny_pack(const float* W, int ldw, int K, int N, int transposed, void* packed, hipStream_t st) {
+    const int KS = cdiv(K, 32);
+    const long long total = (long long)cdiv(N, 16) * KS * 512;
+    int nb = cdiv(total, 256 * 8);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(skinny_pack_kernel, dim3(nb), dim3(256), 0, st, W, ldw, K, N, transposed, KS, (unsigned short*)packed, total);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
+    return M >= 1 && M <= 64 && (K % 8) == 0 && (lda % 4) == 0 && (((uintptr_t)A) & 15) == 0 && N >= 1;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void skinny_gemm_kernel(const float* __restrict__ A, int lda, int M, int K,
+                                                             const u16x8_t* __restrict__ Bp, int KS, int N,
+                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias) {
+    __shared__ float red[4][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ct = blockIdx.x;
+    const int KSW = (KS + 3) / 4;
+    const int ks0 = w * KSW, ks1 = min(KS, ks0 + KSW);
+    const u16x8_t* bp = Bp + (size_t)ct * KS * 64 + lane;
+    const float* ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int row = mt * 16 + c;
+        if (row >= M) row = M - 1;                 // padded rows compute garbage that is never stored
+        ap[mt] = A + (long long)row * lda + g * 8;
+    }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int UN = 3;                          // k-steps whose loads are all in flight together
+    for (int ks = ks0; ks < ks1; ks += UN) {
+        u16x8_t bv[UN];
+        float4 a0[UN][MT], a1[UN][MT];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = ks + u;
+            const bool on = kk < ks1;
+            bv[u] = on ? bp[(size_t)kk * 64] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            const bool ka = on && (kk * 32 + g * 8 + 8 <= K);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (ka) {
+                    a0[u][mt] = *reinterpret_cast<const float4*>(ap[mt] + kk * 32);
+                    a1[u][mt] = *reinterpret_cast<const float4*>(ap[mt] + kk * 32 + 4);
+                } else {
+                    a0[u][mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    a1[u][mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                u16x8_t av;
+                av[0] = f2bf(a0[u][mt].x); av[1] = f2bf(a0[u][mt].y); av[2] = f2bf(a0[u][mt].z); av[3] = f2bf(a0[u][mt].w);
+                av[4] = f2bf(a1[u][mt].x); av[5] = f2bf(a1[u][mt].y); av[6] = f2bf(a1[u][mt].z); av[7] = f2bf(a1[u][mt].w);
+                acc[mt] = mfma_bf16_16x16x32(av, bv[u], acc[mt]);
+            }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][mt][lane][r] = acc[mt][r];
+    __syncthreads();
+    for (int idx = tid; idx < MT * 256; idx += 256) {
+        const int mt = idx >> 8, r16 = (idx >> 4) & 15, c16 = idx & 15;
+        const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
+        const int row = mt * 16 + r16, col = ct * 16 + c16;
+        if (row < M && col < N) {
+            float v = red[0][mt][l2][reg] + red[1][mt][l2][reg] + red[2][mt][l2][reg] + red[3][mt][l2][reg];
+            if (bias) v += bias[col];
+            C[(long long)row * ldc + col] = v;
+        }
+    }
+}
+
+int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
+                    hipStream_t st) {
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    const u16x8_t* Bp = reinterpret_cast<const u16x8_t*>(packed);
+    switch (MT) {
+        case 1: hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        case 2: hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        case 3: hipLaunchKernelGGL(skinny_gemm_kernel<3>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        default: hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+    }
+    LAS_LAUNCHED();
+    return 0;
+}

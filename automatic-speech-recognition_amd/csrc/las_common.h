@@ -86,3 +86,12 @@ template <int NT> __device__ __forceinline__ float block_max(float v, float* red
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- skinny-M contraction (gemm.hip): C[M<=64, N] = A[M,K] . B + bias with B pre-packed to bf16 MFMA
+// fragments.  Used by the Speller's per-step cell products, where M = batch rows and the weights are re-read
+// every step: packing once per call makes every weight load a 1 KiB coalesced wave access.
+size_t las_skinny_pack_bytes(int K, int N);
+int las_skinny_pack(const float* W, int ldw, int K, int N, int transposed, void* packed, hipStream_t st);
+int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
+                    const float* bias, hipStream_t st);
+bool las_skinny_ok(int M, int K, int N, int lda, const void* A);

@@ -73,7 +73,7 @@ __device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane hal
 
 // LDS carve shared by the forward and backward row kernels
 struct RowLds {
-    float *s_state, *qv, *part, *ev, *hl, *aprev, *fc, *red, *x0, *x1, *x2;
+    float *s_state, *qv, *part, *ev, *hl, *aprev, *fc, *red, *x0, *x1, *x2, *ctxp;
     int* redi;
 };
 __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
@@ -89,6 +89,7 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
     r.fc = p;      p += (a.mode == LAS_ATT_LOC ? a.Tp * a.C : 0);
     r.red = p;     p += 16;
     r.redi = reinterpret_cast<int*>(p); p += 16;
+    r.ctxp = p; p += 2 * a.Hd;
     r.x0 = p; r.x1 = p; r.x2 = p;
     if (bwd) {
         r.x0 = p; p += a.Hd;                 // dctx
@@ -98,7 +99,7 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
     return r;
 }
 static size_t row_lds_bytes(const DecDev& a, bool bwd) {
-    size_t n = (size_t)a.D * a.NL + a.A + 8 * a.A + a.Tp + a.D + a.Tp + 32;
+    size_t n = (size_t)a.D * a.NL + a.A + 8 * a.A + a.Tp + a.D + a.Tp + 32 + 2 * a.Hd;
     if (a.mode == LAS_ATT_LOC) n += (size_t)a.Tp * a.C;
     if (bwd) n += a.Hd + a.Tp + (a.mode == LAS_ATT_LOC ? (size_t)a.Tp * a.C : 0);
     return n * sizeof(float) + 64;
@@ -173,22 +174,29 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
             L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
     __syncthreads();
 
-    {   // query projection q = s . Ws   (wave w takes rows k = w, w+4, ..; lanes run over the A outputs)
-        const int w = tid >> 6, lane = tid & 63;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = w; k < S; k += 4) {
-            const float sk = L.s_state[k];
-            const float* wr = a.Ws + (size_t)k * A;
+    {   // query projection q = s . Ws : 8 k-groups x 32 float4 lanes over A, 8 independent 16-byte loads in flight per thread
+        const int a4 = tid & 31, kg = tid >> 5;
+        for (int a0 = a4; a0 < A / 4; a0 += 32) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4* wp = reinterpret_cast<const float4*>(a.Ws) + a0;
+            int k = kg;
+            for (; k + 56 < S; k += 64) {
+                float4 wv[8];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const int ai = lane + 64 * sl;
-                if (ai < A) acc[sl] = fmaf(sk, wr[ai], acc[sl]);
+                for (int u = 0; u < 8; ++u) wv[u] = wp[(size_t)(k + 8 * u) * (A / 4)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float sk = L.s_state[k + 8 * u];
+                    acc.x = fmaf(sk, wv[u].x, acc.x); acc.y = fmaf(sk, wv[u].y, acc.y);
+                    acc.z = fmaf(sk, wv[u].z, acc.z); acc.w = fmaf(sk, wv[u].w, acc.w);
+                }
             }
-        }
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            const int ai = lane + 64 * sl;
-            if (ai < A) L.part[w * A + ai] = acc[sl];
+            for (; k < S; k += 8) {
+                const float4 wv = wp[(size_t)k * (A / 4)];
+                const float sk = L.s_state[k];
+                acc.x = fmaf(sk, wv.x, acc.x); acc.y = fmaf(sk, wv.y, acc.y); acc.z = fmaf(sk, wv.z, acc.z); acc.w = fmaf(sk, wv.w, acc.w);
+            }
+            reinterpret_cast<float4*>(L.part + kg * A)[a0] = acc;
         }
     }
     if (a.mode == LAS_ATT_LOC) {  // f = conv1d(prev_align) (SAME, cross-correlation, bias): las/layers.py:295-296
@@ -204,31 +212,49 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < A; i += 256) L.qv[i] = L.part[i] + L.part[A + i] + L.part[2 * A + i] + L.part[3 * A + i];
+    for (int i = tid; i < A; i += 256) {
+        float q = 0.f;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) q += L.part[k8 * A + i];
+        L.qv[i] = q;
+    }
     __syncthreads();
 
     const int len = a.enc_len[b];
-    {   // energies: a 32-lane half-wave per encoder frame, float4 over the attention dim
+    {   // energies: a 32-lane half-wave per encoder frame, float4 over the attention dim, 4 frames in flight
         const int sl = tid & 31, grp = tid >> 5;
-        for (int tt = grp; tt < Tp; tt += 8) {
-            const float4* kp = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A);
-            float part = 0.f;
+        const bool loc = a.mode == LAS_ATT_LOC;
+        for (int tb = grp; tb < Tp; tb += 32) {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
             for (int a4 = sl; a4 < A / 4; a4 += 32) {
-                const float4 k4 = kp[a4];
+                float4 k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = tb + 8 * u;
+                    k4[u] = tt < Tp ? reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A)[a4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
                 const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
-                float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
-                if (a.mode == LAS_ATT_LOC) {
-                    for (int c = 0; c < a.C; ++c) {
-                        const float f = L.fc[tt * a.C + c];
-                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
-                        p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = tb + 8 * u;
+                    float4 p = make_float4(k4[u].x + q4.x, k4[u].y + q4.y, k4[u].z + q4.z, k4[u].w + q4.w);
+                    if (loc && tt < Tp) {
+                        for (int c = 0; c < a.C; ++c) {
+                            const float f = L.fc[tt * a.C + c];
+                            const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                            p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+                        }
                     }
+                    part[u] += u4.x * tanhx<FAST>(p.x) + u4.y * tanhx<FAST>(p.y) + u4.z * tanhx<FAST>(p.z) + u4.w * tanhx<FAST>(p.w);
                 }
-                part += u4.x * tanhx<FAST>(p.x) + u4.y * tanhx<FAST>(p.y) + u4.z * tanhx<FAST>(p.z) + u4.w * tanhx<FAST>(p.w);
             }
-            part = sub32_sum(part);
-            if (sl == 0) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = tb + 8 * u;
+                const float e = sub32_sum(part[u]);
+                if (sl == 0 && tt < Tp) L.ev[tt] = (tt < len) ? e : -1e8f;   // replace-mask, las/layers.py:205-207
+            }
         }
     }
     __syncthreads();
@@ -245,11 +271,32 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
 
     float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
-    for (int hd = tid; hd < Hd; hd += 256) {
-        const float* ep = a.enc + (size_t)b * Tp * Hd + hd;
-        float acc = 0.f;
-        for (int tt = 0; tt < lim; ++tt) acc = fmaf(L.ev[tt], ep[(size_t)tt * Hd], acc);
-        xrow[E + hd] = acc;
+    {   // context = sum_t alpha[t] * enc[b,t,:]  : 128 float4 lanes over Hd x 2 frame groups, 8 loads in flight
+        const int h4 = tid & 127, half = tid >> 7;
+        for (int h0 = h4; h0 < Hd / 4; h0 += 128) {
+            const float4* ep = reinterpret_cast<const float4*>(a.enc + (size_t)b * Tp * Hd) + h0;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int tt = half;
+            for (; tt + 14 < lim; tt += 16) {
+                float4 ev4[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ev4[u] = ep[(size_t)(tt + 2 * u) * (Hd / 4)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float al = L.ev[tt + 2 * u];
+                    acc.x = fmaf(al, ev4[u].x, acc.x); acc.y = fmaf(al, ev4[u].y, acc.y);
+                    acc.z = fmaf(al, ev4[u].z, acc.z); acc.w = fmaf(al, ev4[u].w, acc.w);
+                }
+            }
+            for (; tt < lim; tt += 2) {
+                const float4 e4 = ep[(size_t)tt * (Hd / 4)];
+                const float al = L.ev[tt];
+                acc.x = fmaf(al, e4.x, acc.x); acc.y = fmaf(al, e4.y, acc.y); acc.z = fmaf(al, e4.z, acc.z); acc.w = fmaf(al, e4.w, acc.w);
+            }
+            reinterpret_cast<float4*>(L.ctxp + half * Hd)[h0] = acc;
+        }
+        __syncthreads();
+        for (int hd = tid; hd < Hd; hd += 256) xrow[E + hd] = L.ctxp[hd] + L.ctxp[Hd + hd];
     }
     for (int i = tid; i < E; i += 256) xrow[i] = a.emb[(size_t)tok * E + i];
     for (int i = tid; i < D; i += 256) xrow[E + Hd + i] = L.s_state[i];
@@ -523,12 +570,14 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
     const size_t f = sizeof(float);
     const size_t I0D = (size_t)E + Hd + D;
+    w.packF = o;  o += align256(las_skinny_pack_bytes((int)I0D, G * D));      // W0 fragments (step product)
+    w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
     w.dHl = o;    o += align256((size_t)U * B * D * f);
     w.dH = o;     o += align256((size_t)NL * B * D * f);
     w.dC = o;     o += align256((size_t)NL * B * D * f);
@@ -597,12 +646,23 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipS
         LAS_HIP(hipMemsetAsync(d.hs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
         if (CELL == LAS_CELL_LSTM) LAS_HIP(hipMemsetAsync(d.cs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
     }
+    // per-step cell product: with bf16 arithmetic the weights are packed once into MFMA fragments and every
+    // step runs the skinny-M kernel (M = batch rows); fp32 mode keeps the generic exact path
+    const BwdWs wl_ = bwd_layout(B, d.Tp, Hd, d.A, D, NL, E, V, U, G, d.Kc, d.C);
+    const bool skinny = FAST && f->ws && f->ws_bytes >= wl_.packB && las_skinny_ok(B, I0D, GD, I0D, d.xin0);
+    void* packF = skinny ? (char*)f->ws + wl_.packF : nullptr;
+    if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     for (int t = 0; t <= U; ++t) {
         hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
-        GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, I0D, 1.f, d.xin0 + (size_t)t * B * I0D, I0D, 0, f->cellW[0], GD, 0, 0.f,
-                         d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+        if (skinny) {
+            GEMM_OK(las_skinny_gemm(d.xin0 + (size_t)t * B * I0D, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD,
+                                    f->cellb[0], st));
+        } else {
+            GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, I0D, 1.f, d.xin0 + (size_t)t * B * I0D, I0D, 0, f->cellW[0], GD, 0, 0.f,
+                             d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+        }
         for (int l = 1; l < NL; ++l) {
             hipLaunchKernelGGL((dec_pointwise_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, l - 1, t);
             LAS_LAUNCHED();
@@ -651,6 +711,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     const size_t lds = row_lds_bytes(d, true);
     LAS_ARG(lds <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
 
+    const bool skinny = FAST && las_skinny_ok(B, GD, I0D, GD, d.gates);
+    void* packB = base + w.packB;
+    if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
 
@@ -671,7 +734,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
         if (t < 0) break;
         for (int l = TOP; l >= 0; --l) {
             const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
-            if (l == 0) {
+            if (l == 0 && skinny) {
+                GEMM_OK(las_skinny_gemm(dG, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, st));
+            } else if (l == 0) {
                 GEMM_OK(las_gemm(prec, 0, 1, B, I0D, GD, 1.f, dG, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0 + (size_t)t * B * I0D,
                                  I0D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
             } else {

@@ -127,6 +127,9 @@ class _SpellerLoop(torch.autograd.Function):
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
         keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
+        nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], dims["V"], dims["U"], dims["cell"])
+        ws = _hip.workspace(dev, nbytes, "speller")
+        fa.ws, fa.ws_bytes = ws.data_ptr(), ws.numel()
         with _hip._timed("speller_fwd[U=%d]" % dims["U"]):
             _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
         del keep
