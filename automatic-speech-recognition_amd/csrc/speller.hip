@@ -17,6 +17,13 @@
 
 #define LAS_MAX_NL 4
 
+// The decoder row kernels run ONE workgroup per utterance and are bound by L2/MALL latency (each step re-reads
+// that utterance's keys / encoder rows / Ws): 16 waves per CU keep enough loads in flight to cover it.
+constexpr int RNT = 1024;          // threads per row workgroup
+constexpr int RNG = RNT / 32;      // 32-lane half-wave groups
+constexpr int RNW = RNT / 64;      // waves
+constexpr int RNH = RNT / 128;     // frame groups of the context reduction
+
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits;
     float fb;
@@ -60,7 +67,7 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* re
     __syncthreads();
     float bv = redv[0]; int bi = redi[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < RNW; ++w)
         if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
     return bi;
 }
@@ -82,14 +89,14 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
     float* p = sm;
     r.s_state = p; p += S;
     r.qv = p;      p += a.A;
-    r.part = p;    p += 8 * a.A;
+    r.part = p;    p += RNG * a.A;
     r.ev = p;      p += a.Tp;
     r.hl = p;      p += a.D;
     r.aprev = p;   p += a.Tp;
     r.fc = p;      p += (a.mode == LAS_ATT_LOC ? a.Tp * a.C : 0);
-    r.red = p;     p += 16;
-    r.redi = reinterpret_cast<int*>(p); p += 16;
-    r.ctxp = p; p += 2 * a.Hd;
+    r.red = p;     p += 32;
+    r.redi = reinterpret_cast<int*>(p); p += 32;
+    r.ctxp = p; p += RNH * a.Hd;
     r.x0 = p; r.x1 = p; r.x2 = p;
     if (bwd) {
         r.x0 = p; p += a.Hd;                 // dctx
@@ -99,7 +106,7 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
     return r;
 }
 static size_t row_lds_bytes(const DecDev& a, bool bwd) {
-    size_t n = (size_t)a.D * a.NL + a.A + 8 * a.A + a.Tp + a.D + a.Tp + 32 + 2 * a.Hd;
+    size_t n = (size_t)a.D * a.NL + a.A + RNG * a.A + a.Tp + a.D + a.Tp + 64 + RNH * a.Hd;
     if (a.mode == LAS_ATT_LOC) n += (size_t)a.Tp * a.C;
     if (bwd) n += a.Hd + a.Tp + (a.mode == LAS_ATT_LOC ? (size_t)a.Tp * a.C : 0);
     return n * sizeof(float) + 64;
@@ -108,8 +115,8 @@ static size_t row_lds_bytes(const DecDev& a, bool bwd) {
 // ------------------------------------------------------------------------------------------------
 // forward row kernel
 // ------------------------------------------------------------------------------------------------
-template <int CELL, bool FAST>
-__global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
+template <int CELL, bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const RowLds L = carve(sm, a, false);
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
     if (t > 0) {  // ---- finish the top layer's cell of step t-1
         float* gp = a.gates + (((size_t)TOP * U + (t - 1)) * B + b) * GD;
         float* hnew = a.hs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
-        for (int d = tid; d < D; d += 256) {
+        for (int d = tid; d < D; d += RNT) {
             float h;
             if (CELL == LAS_CELL_LSTM) {
                 const float* cprev = a.cs + (((size_t)TOP * (U + 1) + (t - 1)) * B + b) * D;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
             float bestv = -INFINITY, bests = -INFINITY;
             int besti = 0x7fffffff, bestsi = 0x7fffffff;
             float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
-            for (int v = tid; v < V; v += 256) {
+            for (int v = tid; v < V; v += RNT) {
                 float acc = a.bv[v];
                 for (int d = 0; d < D; ++d) acc = fmaf(L.hl[d], a.Wv[(size_t)d * V + v], acc);
                 lrow[v] = acc;
@@ -165,33 +172,33 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
     else if (tok == -2) tok = sample_tok;
     if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
 
-    for (int i = tid; i < S; i += 256) {
+    for (int i = tid; i < S; i += RNT) {
         const int l = i / D, d = i % D;
         L.s_state[i] = (l == TOP && t > 0) ? L.hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
     }
-    if (a.mode == LAS_ATT_LOC)
-        for (int i = tid; i < Tp; i += 256)
+    if (LOC)
+        for (int i = tid; i < Tp; i += RNT)
             L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
     __syncthreads();
 
-    {   // query projection q = s . Ws : 8 k-groups x 32 float4 lanes over A, 8 independent 16-byte loads in flight per thread
+    {   // query projection q = s . Ws : RNG k-groups x 32 float4 lanes over A, 8 independent 16-byte loads in flight per thread
         const int a4 = tid & 31, kg = tid >> 5;
         for (int a0 = a4; a0 < A / 4; a0 += 32) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4* wp = reinterpret_cast<const float4*>(a.Ws) + a0;
             int k = kg;
-            for (; k + 56 < S; k += 64) {
+            for (; k + 7 * RNG < S; k += 8 * RNG) {
                 float4 wv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = wp[(size_t)(k + 8 * u) * (A / 4)];
+                for (int u = 0; u < 8; ++u) wv[u] = wp[(size_t)(k + RNG * u) * (A / 4)];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float sk = L.s_state[k + 8 * u];
+                    const float sk = L.s_state[k + RNG * u];
                     acc.x = fmaf(sk, wv[u].x, acc.x); acc.y = fmaf(sk, wv[u].y, acc.y);
                     acc.z = fmaf(sk, wv[u].z, acc.z); acc.w = fmaf(sk, wv[u].w, acc.w);
                 }
             }
-            for (; k < S; k += 8) {
+            for (; k < S; k += RNG) {
                 const float4 wv = wp[(size_t)k * (A / 4)];
                 const float sk = L.s_state[k];
                 acc.x = fmaf(sk, wv.x, acc.x); acc.y = fmaf(sk, wv.y, acc.y); acc.z = fmaf(sk, wv.z, acc.z); acc.w = fmaf(sk, wv.w, acc.w);
@@ -199,9 +206,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
             reinterpret_cast<float4*>(L.part + kg * A)[a0] = acc;
         }
     }
-    if (a.mode == LAS_ATT_LOC) {  // f = conv1d(prev_align) (SAME, cross-correlation, bias): las/layers.py:295-296
+    if (LOC) {  // f = conv1d(prev_align) (SAME, cross-correlation, bias): las/layers.py:295-296
         const int pad = (a.Kc - 1) / 2;
-        for (int i = tid; i < Tp * a.C; i += 256) {
+        for (int i = tid; i < Tp * a.C; i += RNT) {
             const int tt = i / a.C, c = i % a.C;
             float acc = a.loc_b[c];
             for (int k = 0; k < a.Kc; ++k) {
@@ -212,10 +219,10 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < A; i += 256) {
+    for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) q += L.part[k8 * A + i];
+        for (int k8 = 0; k8 < RNG; ++k8) q += L.part[k8 * A + i];
         L.qv[i] = q;
     }
     __syncthreads();
@@ -223,21 +230,21 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
     const int len = a.enc_len[b];
     {   // energies: a 32-lane half-wave per encoder frame, float4 over the attention dim, 4 frames in flight
         const int sl = tid & 31, grp = tid >> 5;
-        const bool loc = a.mode == LAS_ATT_LOC;
-        for (int tb = grp; tb < Tp; tb += 32) {
+        const bool loc = LOC;
+        for (int tb = grp; tb < Tp; tb += 4 * RNG) {
             float part[4] = {0.f, 0.f, 0.f, 0.f};
             for (int a4 = sl; a4 < A / 4; a4 += 32) {
                 float4 k4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int tt = tb + 8 * u;
+                    const int tt = tb + RNG * u;
                     k4[u] = tt < Tp ? reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A)[a4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
                 const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int tt = tb + 8 * u;
+                    const int tt = tb + RNG * u;
                     float4 p = make_float4(k4[u].x + q4.x, k4[u].y + q4.y, k4[u].z + q4.z, k4[u].w + q4.w);
                     if (loc && tt < Tp) {
                         for (int c = 0; c < a.C; ++c) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int tt = tb + 8 * u;
+                const int tt = tb + RNG * u;
                 const float e = sub32_sum(part[u]);
                 if (sl == 0 && tt < Tp) L.ev[tt] = (tt < len) ? e : -1e8f;   // replace-mask, las/layers.py:205-207
             }
@@ -259,36 +266,36 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int i = tid; i < Tp; i += 256) m = fmaxf(m, L.ev[i]);
-    m = block_max<256>(m, L.red);
+    for (int i = tid; i < Tp; i += RNT) m = fmaxf(m, L.ev[i]);
+    m = block_max<RNT>(m, L.red);
     float ssum = 0.f;
-    for (int i = tid; i < Tp; i += 256) { const float e = expf(L.ev[i] - m); L.ev[i] = e; ssum += e; }
-    ssum = block_sum<256>(ssum, L.red);
+    for (int i = tid; i < Tp; i += RNT) { const float e = expf(L.ev[i] - m); L.ev[i] = e; ssum += e; }
+    ssum = block_sum<RNT>(ssum, L.red);
     const float inv = 1.0f / ssum;
     float* arow = a.alphas + ((size_t)t * B + b) * Tp;
-    for (int i = tid; i < Tp; i += 256) { const float al = L.ev[i] * inv; L.ev[i] = al; arow[i] = al; }
+    for (int i = tid; i < Tp; i += RNT) { const float al = L.ev[i] * inv; L.ev[i] = al; arow[i] = al; }
     __syncthreads();
 
     float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
-    {   // context = sum_t alpha[t] * enc[b,t,:]  : 128 float4 lanes over Hd x 2 frame groups, 8 loads in flight
+    {   // context = sum_t alpha[t] * enc[b,t,:]  : 128 float4 lanes over Hd x RNH frame groups, 8 loads in flight
         const int h4 = tid & 127, half = tid >> 7;
         for (int h0 = h4; h0 < Hd / 4; h0 += 128) {
             const float4* ep = reinterpret_cast<const float4*>(a.enc + (size_t)b * Tp * Hd) + h0;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int tt = half;
-            for (; tt + 14 < lim; tt += 16) {
+            for (; tt + 7 * RNH < lim; tt += 8 * RNH) {
                 float4 ev4[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) ev4[u] = ep[(size_t)(tt + 2 * u) * (Hd / 4)];
+                for (int u = 0; u < 8; ++u) ev4[u] = ep[(size_t)(tt + RNH * u) * (Hd / 4)];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float al = L.ev[tt + 2 * u];
+                    const float al = L.ev[tt + RNH * u];
                     acc.x = fmaf(al, ev4[u].x, acc.x); acc.y = fmaf(al, ev4[u].y, acc.y);
                     acc.z = fmaf(al, ev4[u].z, acc.z); acc.w = fmaf(al, ev4[u].w, acc.w);
                 }
             }
-            for (; tt < lim; tt += 2) {
+            for (; tt < lim; tt += RNH) {
                 const float4 e4 = ep[(size_t)tt * (Hd / 4)];
                 const float al = L.ev[tt];
                 acc.x = fmaf(al, e4.x, acc.x); acc.y = fmaf(al, e4.y, acc.y); acc.z = fmaf(al, e4.z, acc.z); acc.w = fmaf(al, e4.w, acc.w);
@@ -296,10 +303,15 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(DecDev a, int t) {
             reinterpret_cast<float4*>(L.ctxp + half * Hd)[h0] = acc;
         }
         __syncthreads();
-        for (int hd = tid; hd < Hd; hd += 256) xrow[E + hd] = L.ctxp[hd] + L.ctxp[Hd + hd];
+        for (int hd = tid; hd < Hd; hd += RNT) {
+            float cv = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < RNH; ++hh) cv += L.ctxp[hh * Hd + hd];
+            xrow[E + hd] = cv;
+        }
     }
-    for (int i = tid; i < E; i += 256) xrow[i] = a.emb[(size_t)tok * E + i];
-    for (int i = tid; i < D; i += 256) xrow[E + Hd + i] = L.s_state[i];
+    for (int i = tid; i < E; i += RNT) xrow[i] = a.emb[(size_t)tok * E + i];
+    for (int i = tid; i < D; i += RNT) xrow[E + Hd + i] = L.s_state[i];
 }
 
 // gate nonlinearity of a non-top layer (multi-layer Speller only)
@@ -339,7 +351,7 @@ __device__ __forceinline__ void cell_bwd_row(const DecDev& a, int layer, int t, 
     const float* dHr = a.dH + ((size_t)layer * B + b) * D;
     float* dCr = a.dC + ((size_t)layer * B + b) * D;
     const float* ex = extra + (size_t)b * extra_ld;
-    for (int d = threadIdx.x; d < D; d += 256) {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
         const float dh = dHr[d] + ex[d];
         if (CELL == LAS_CELL_LSTM) {
             const float gi = gp[d], gj = gp[D + d], gf = gp[2 * D + d], go = gp[3 * D + d];
@@ -365,14 +377,14 @@ __global__ __launch_bounds__(256) void dec_pointwise_bwd_kernel(DecDev a, int la
 }
 
 // Part A: attention backward of step t_att (if >= 0); Part B: top-layer gate backward of step t_cell (if >= 0).
-template <int CELL, bool FAST>
-__global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, int t_cell) {
+template <int CELL, bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, int t_cell) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const RowLds L = carve(sm, a, true);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, NL = a.NL, E = a.E, U = a.U;
     const int S = D * NL, I0D = E + Hd + D;
-    const bool loc = a.mode == LAS_ATT_LOC;
+    constexpr bool loc = LOC;
     float* dctx = L.x0;
     float* dal = L.x1;
     float* dfc = L.x2;
@@ -380,15 +392,15 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, 
     if (t_att >= 0) {
         const int t = t_att;
         const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D;
-        for (int i = tid; i < Hd; i += 256) dctx[i] = dxr[E + i];
-        for (int i = tid; i < Tp; i += 256) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
-        for (int i = tid; i < A; i += 256) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
-        if (loc) for (int i = tid; i < Tp; i += 256)
+        for (int i = tid; i < Hd; i += RNT) dctx[i] = dxr[E + i];
+        for (int i = tid; i < Tp; i += RNT) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
+        for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
+        if (loc) for (int i = tid; i < Tp; i += RNT)
             L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
         __syncthreads();
         if (loc) {
             const int pad = (a.Kc - 1) / 2;
-            for (int i = tid; i < Tp * a.C; i += 256) {
+            for (int i = tid; i < Tp * a.C; i += RNT) {
                 const int tt = i / a.C, c = i % a.C;
                 float acc = a.loc_b[c];
                 for (int k = 0; k < a.Kc; ++k) {
@@ -402,25 +414,52 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, 
         const int len = a.enc_len[b];
         const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
         {   // dalpha[t'] = dctx . enc[b,t',:]   (+ what step t+1's location conv sent back)
-            const int w = tid >> 6, lane = tid & 63;
-            for (int tt = w; tt < Tp; tt += 4) {
-                float acc = 0.f;
-                if (tt < lim) {
-                    const float* ep = a.enc + ((size_t)b * Tp + tt) * Hd;
-                    for (int hd = lane; hd < Hd; hd += 64) acc = fmaf(dctx[hd], ep[hd], acc);
-                    acc = wave_sum(acc);
+            // half-wave per frame, float4 over Hd, two frames (8 x 16-byte loads) in flight per lane
+            const int sl = tid & 31, grp = tid >> 5;
+            for (int tb = grp; tb < Tp; tb += 2 * RNG) {
+                float acc2[2] = {0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = tb + RNG * u;
+                    if (tt < lim) {
+                        const float4* ep = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd);
+                        float4 e4[4];
+#pragma unroll
+                        for (int n4 = 0; n4 < 4; ++n4) {
+                            const int h0 = sl + 32 * n4;
+                            e4[n4] = h0 < Hd / 4 ? ep[h0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int n4 = 0; n4 < 4; ++n4) {
+                            const int h0 = sl + 32 * n4;
+                            if (h0 < Hd / 4) {
+                                const float4 d4 = reinterpret_cast<const float4*>(dctx)[h0];
+                                acc2[u] += d4.x * e4[n4].x + d4.y * e4[n4].y + d4.z * e4[n4].z + d4.w * e4[n4].w;
+                            }
+                        }
+                        for (int h0 = sl + 128; h0 < Hd / 4; h0 += 32) {       // Hd > 512
+                            const float4 e = ep[h0];
+                            const float4 d4 = reinterpret_cast<const float4*>(dctx)[h0];
+                            acc2[u] += d4.x * e.x + d4.y * e.y + d4.z * e.z + d4.w * e.w;
+                        }
+                    }
                 }
-                if (lane == 0) {
-                    if (loc && t + 1 < U) acc += a.dAext[(size_t)b * Tp + tt];
-                    dal[tt] = acc;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = tb + RNG * u;
+                    float v = sub32_sum(acc2[u]);
+                    if (sl == 0 && tt < Tp) {
+                        if (loc && t + 1 < U) v += a.dAext[(size_t)b * Tp + tt];
+                        dal[tt] = v;
+                    }
                 }
             }
         }
         __syncthreads();
         float dot = 0.f;
-        for (int i = tid; i < Tp; i += 256) dot = fmaf(L.ev[i], dal[i], dot);
-        dot = block_sum<256>(dot, L.red);
-        for (int i = tid; i < Tp; i += 256) dal[i] = L.ev[i] * (dal[i] - dot);   // d energy (0 where masked: alpha = 0)
+        for (int i = tid; i < Tp; i += RNT) dot = fmaf(L.ev[i], dal[i], dot);
+        dot = block_sum<RNT>(dot, L.red);
+        for (int i = tid; i < Tp; i += RNT) dal[i] = L.ev[i] * (dal[i] - dot);   // d energy (0 where masked: alpha = 0)
         __syncthreads();
 
         // energies backward: half-wave per frame; per-lane partials of du, dq (and dWf) over its frames
@@ -428,16 +467,39 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, 
         float du_acc[8], dq_acc[8];    // A <= 256 -> at most 2 float4 per lane
 #pragma unroll
         for (int i = 0; i < 8; ++i) { du_acc[i] = 0.f; dq_acc[i] = 0.f; }
-        for (int tt = grp; tt < Tp; tt += 8) {
+        for (int tb = grp; tb < Tp; tb += 2 * RNG) {
+          float4 kpre[2][2], dkpre[2][2];            // [frame][a4 slot]: keys and dKeys prefetched for both frames
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int tt = tb + RNG * u;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int a4 = sl + 32 * slot;
+                if (tt < Tp && a4 < A / 4) {
+                    kpre[u][slot] = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A)[a4];
+                    dkpre[u][slot] = reinterpret_cast<const float4*>(a.dKeys + ((size_t)b * Tp + tt) * A)[a4];
+                } else {
+                    kpre[u][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dkpre[u][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int tt = tb + RNG * u;
+            if (tt >= Tp) continue;
             const float de = dal[tt];
-            const float4* kp = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A);
             float4* dkp = reinterpret_cast<float4*>(a.dKeys + ((size_t)b * Tp + tt) * A);
             float dfc_l[16];
+            if (loc) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) dfc_l[c] = 0.f;
-            int slot = 0;
-            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot) {
-                const float4 k4 = kp[a4];
+                for (int c = 0; c < 16; ++c) dfc_l[c] = 0.f;
+            }
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int a4 = sl + 32 * slot;
+                if (a4 >= A / 4) continue;
+                const float4 k4 = kpre[u][slot];
                 const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
                 const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
                 float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
@@ -455,76 +517,106 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, 
                 du_acc[slot * 4 + 2] += de * vz; du_acc[slot * 4 + 3] += de * vw;
                 dq_acc[slot * 4 + 0] += dv.x; dq_acc[slot * 4 + 1] += dv.y;
                 dq_acc[slot * 4 + 2] += dv.z; dq_acc[slot * 4 + 3] += dv.w;
-                if (de != 0.f) {
-                    float4 dk = dkp[a4];
+                {
+                    float4 dk = dkpre[u][slot];
                     dk.x += dv.x; dk.y += dv.y; dk.z += dv.z; dk.w += dv.w;
                     dkp[a4] = dk;
                 }
                 if (loc) {
-                    for (int c = 0; c < a.C && c < 16; ++c) {
-                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
-                        dfc_l[c] += dv.x * w4.x + dv.y * w4.y + dv.z * w4.z + dv.w * w4.w;
-                        // dWf[c, a] += fc[t',c] * dv[a]   (row-private accumulation, reduced over rows after the loop)
-                        float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * 8 + grp) * a.C + c) * A) + a4;
-                        const float f = L.fc[tt * a.C + c];
-                        float4 o = *wr;
-                        o.x = fmaf(f, dv.x, o.x); o.y = fmaf(f, dv.y, o.y); o.z = fmaf(f, dv.z, o.z); o.w = fmaf(f, dv.w, o.w);
-                        *wr = o;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if (c < a.C) {
+                            const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                            dfc_l[c] += dv.x * w4.x + dv.y * w4.y + dv.z * w4.z + dv.w * w4.w;
+                            // dWf[c, a] += fc[t',c] * dv[a]   (row-private accumulation, reduced over rows after the loop)
+                            float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * RNG + grp) * a.C + c) * A) + a4;
+                            const float f = L.fc[tt * a.C + c];
+                            float4 o = *wr;
+                            o.x = fmaf(f, dv.x, o.x); o.y = fmaf(f, dv.y, o.y); o.z = fmaf(f, dv.z, o.z); o.w = fmaf(f, dv.w, o.w);
+                            *wr = o;
+                        }
                     }
                 }
             }
             if (loc) {
-                for (int c = 0; c < a.C && c < 16; ++c) {
-                    const float s = sub32_sum(dfc_l[c]);
-                    if (sl == 0) dfc[tt * a.C + c] = s;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (c < a.C) {
+                        const float s2 = sub32_sum(dfc_l[c]);
+                        if (sl == 0) dfc[tt * a.C + c] = s2;
+                    }
                 }
             }
+          }
         }
         // reduce the 8 half-wave partials of du / dq through LDS
         __syncthreads();
-        {
-            int slot = 0;
-            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot)
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int a4 = sl + 32 * slot;
+            if (a4 < A / 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = dq_acc[slot * 4 + e];
+            }
         }
         __syncthreads();
-        for (int i = tid; i < A; i += 256) {
+        for (int i = tid; i < A; i += RNT) {
             float s = 0.f;
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) s += L.part[g8 * A + i];
+            for (int g8 = 0; g8 < RNG; ++g8) s += L.part[g8 * A + i];
             L.qv[i] = s;                                   // qv now holds dq
             a.dQ[((size_t)t * B + b) * A + i] = s;
         }
         __syncthreads();
-        {
-            int slot = 0;
-            for (int a4 = sl; a4 < A / 4; a4 += 32, ++slot)
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int a4 = sl + 32 * slot;
+            if (a4 < A / 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = du_acc[slot * 4 + e];
+            }
         }
         __syncthreads();
-        for (int i = tid; i < A; i += 256) {
+        for (int i = tid; i < A; i += RNT) {
             float s = 0.f;
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) s += L.part[g8 * A + i];
+            for (int g8 = 0; g8 < RNG; ++g8) s += L.part[g8 * A + i];
             a.duRows[(size_t)b * A + i] += s;
         }
         // d state = dq . Ws^T ; total gradient of the states consumed at step t
-        for (int i = tid; i < S; i += 256) {
-            const float4* wr = reinterpret_cast<const float4*>(a.Ws + (size_t)i * A);
-            float acc = 0.f;
-            for (int a4 = 0; a4 < A / 4; ++a4) {
-                const float4 w4 = wr[a4];
-                const float4 d4 = reinterpret_cast<const float4*>(L.qv)[a4];
-                acc += w4.x * d4.x + w4.y * d4.y + w4.z * d4.z + w4.w * d4.w;
+        // half-wave per state row (coalesced 512-B row segments), 8 rows in flight
+        __syncthreads();
+        {
+            const int sl2 = tid & 31, grp2 = tid >> 5;
+            for (int ib = grp2; ib < S; ib += 8 * RNG) {
+                float acc8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + RNG * u;
+                    acc8[u] = 0.f;
+                    if (i < S) {
+                        const float4* wr = reinterpret_cast<const float4*>(a.Ws + (size_t)i * A);
+                        for (int a4 = sl2; a4 < A / 4; a4 += 32) {
+                            const float4 w4 = wr[a4];
+                            const float4 d4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                            acc8[u] += w4.x * d4.x + w4.y * d4.y + w4.z * d4.z + w4.w * d4.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + RNG * u;
+                    const float v = sub32_sum(acc8[u]);
+                    if (sl2 == 0 && i < S) {
+                        const int l = i / D, d = i % D;
+                        a.dH[((size_t)l * B + b) * D + d] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d] + v;
+                    }
+                }
             }
-            const int l = i / D, d = i % D;
-            a.dH[((size_t)l * B + b) * D + d] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d] + acc;
         }
         if (loc) {   // conv1d backward: filter / bias partials per row, and d alpha_{t-1}
             const int pad = (a.Kc - 1) / 2;
-            for (int i = tid; i < a.Kc * a.C; i += 256) {
+            for (int i = tid; i < a.Kc * a.C; i += RNT) {
                 const int k = i / a.C, c = i % a.C;
                 float acc = 0.f;
                 for (int tt = 0; tt < Tp; ++tt) {
@@ -533,12 +625,12 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(DecDev a, int t_att, 
                 }
                 a.dlocwRows[(size_t)b * a.Kc * a.C + i] += acc;
             }
-            for (int c = tid; c < a.C; c += 256) {
+            for (int c = tid; c < a.C; c += RNT) {
                 float acc = 0.f;
                 for (int tt = 0; tt < Tp; ++tt) acc += dfc[tt * a.C + c];
                 a.dlocbRows[(size_t)b * a.C + c] += acc;
             }
-            for (int src = tid; src < Tp; src += 256) {
+            for (int src = tid; src < Tp; src += RNT) {
                 float acc = 0.f;
                 for (int k = 0; k < a.Kc; ++k) {
                     const int tt = src - k + pad;
@@ -589,7 +681,7 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.tmp = o;    o += align256((size_t)NL * B * 2 * D * f);
     w.dlocw = o;  o += align256((size_t)B * (Kc > 0 ? Kc : 1) * (C > 0 ? C : 1) * f);
     w.dlocb = o;  o += align256((size_t)B * (C > 0 ? C : 1) * f);
-    w.dWf = o;    o += align256((size_t)B * 8 * (C > 0 ? C : 1) * A * f);   // one slice per half-wave group
+    w.dWf = o;    o += align256((size_t)B * RNG * (C > 0 ? C : 1) * A * f);   // one slice per half-wave group
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
@@ -653,7 +745,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipS
     void* packF = skinny ? (char*)f->ws + wl_.packF : nullptr;
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     for (int t = 0; t <= U; ++t) {
-        hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), lds, st, d, t);
+        if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);
+        else                       hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
         if (skinny) {
@@ -729,7 +822,8 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     for (int t = U - 1; t >= -1; --t) {
         DecDev ds = d;
         if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
-        hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST>), dim3(B), dim3(256), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        if (loc) hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        else     hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         LAS_LAUNCHED();
         if (t < 0) break;
         for (int l = TOP; l >= 0; --l) {
@@ -777,7 +871,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     if (loc) {
         GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
         GEMM_OK(las_colsum(d.dlocbRows, B, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
-        GEMM_OK(las_colsum(d.dWfRows, B * 8, d.C * A, d.C * A, 1.f, bk->dWf, gws, gws_bytes, st));
+        GEMM_OK(las_colsum(d.dWfRows, B * RNG, d.C * A, d.C * A, 1.f, bk->dWf, gws, gws_bytes, st));
     }
     return 0;
 }
