@@ -89,15 +89,16 @@ __device__ __forceinline__ void tile_sstore(unsigned short* S, const TileRegs<RO
             const float4 v = r.v[i];
             if (ks == 1) {
                 const int row = c >> 3, kq = (c & 7) * 4;
-                u16x4_t pk;
-                pk.x = f2bf(v.x); pk.y = f2bf(v.y); pk.z = f2bf(v.z); pk.w = f2bf(v.w);
-                *reinterpret_cast<u16x4_t*>(&S[row * LDK + kq]) = pk;
+                uint2 pk;
+                pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+                *reinterpret_cast<uint2*>(&S[row * LDK + kq]) = pk;
             } else {
                 const int k = c / RQ, rq = (c % RQ) * 4;
-                S[(rq + 0) * LDK + k] = f2bf(v.x);
-                S[(rq + 1) * LDK + k] = f2bf(v.y);
-                S[(rq + 2) * LDK + k] = f2bf(v.z);
-                S[(rq + 3) * LDK + k] = f2bf(v.w);
+                const unsigned int p01 = f2bf2(v.x, v.y), p23 = f2bf2(v.z, v.w);
+                S[(rq + 0) * LDK + k] = (unsigned short)(p01 & 0xffffu);
+                S[(rq + 1) * LDK + k] = (unsigned short)(p01 >> 16);
+                S[(rq + 2) * LDK + k] = (unsigned short)(p23 & 0xffffu);
+                S[(rq + 3) * LDK + k] = (unsigned short)(p23 >> 16);
             }
         }
     }
@@ -185,6 +186,177 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, branch-free fast path: 16-byte loads legal on both operands, contiguity known at
+// compile time (AKC/BKC: contraction index contiguous in memory), rows clamped instead of predicated
+// (edge tiles compute throw-away rows), k tail zero-filled by a select.  LDS is double buffered: one
+// barrier per k-tile, the next tile's global loads are issued before the MFMAs of the current one.
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int NT, bool KC>
+struct FastRegs {
+    // KC: one float4 (4 consecutive k) per chunk.  !KC: a 4(rows) x 4(k) micro-tile per chunk = 4 float4 along rows.
+    static constexpr int N = KC ? (ROWS * 8 + NT - 1) / NT : 4 * ((ROWS * 2 + NT - 1) / NT);
+    float4 v[N];
+};
+
+template <int ROWS, int NT, bool KC>
+__device__ __forceinline__ void fast_gload(FastRegs<ROWS, NT, KC>& r, const float* __restrict__ X, long long rs, long long ks,
+                                           int row0, int k0, int R, int Kend) {
+    if (KC) {
+        constexpr int NCH = ROWS * 8;
+#pragma unroll
+        for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (NCH % NT != 0 && c >= NCH) { r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const int row = c >> 3, kq = (c & 7) * 4;
+            const int gr = min(row0 + row, R - 1), gk = k0 + kq;
+            const bool on = gk + 3 < Kend;                         // K % 4 == 0 on this path
+            const float4 v = *reinterpret_cast<const float4*>(X + (long long)gr * rs + (on ? gk : 0));
+            r.v[i] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+        constexpr int NCH = ROWS * 2, RQ = ROWS / 4;
+#pragma unroll
+        for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+            const int c = threadIdx.x + i * NT;
+            const bool live = (NCH % NT == 0) || c < NCH;
+            const int kq = (c / RQ) * 4, rq = (c % RQ) * 4;
+            const int gr = min(row0 + rq, R - 4);                  // R % 4 == 0 on this path
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int gk = k0 + kq + kk;
+                const bool on = live && gk < Kend;
+                const float4 v = *reinterpret_cast<const float4*>(X + (long long)(on ? gk : 0) * ks + gr);
+                r.v[i * 4 + kk] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+template <int ROWS, int NT, bool KC>
+__device__ __forceinline__ void fast_sstore(unsigned short* S, const FastRegs<ROWS, NT, KC>& r) {
+    if (KC) {
+        constexpr int NCH = ROWS * 8;
+#pragma unroll
+        for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (NCH % NT != 0 && c >= NCH) continue;
+            const float4 v = r.v[i];
+            const int row = c >> 3, kq = (c & 7) * 4;
+            uint2 pk;
+            pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+            *reinterpret_cast<uint2*>(&S[row * LDK + kq]) = pk;
+        }
+    } else {
+        constexpr int NCH = ROWS * 2, RQ = ROWS / 4;
+#pragma unroll
+        for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (NCH % NT != 0 && c >= NCH) continue;
+            const int kq = (c / RQ) * 4, rq = (c % RQ) * 4;
+            const float4 k0v = r.v[i * 4 + 0], k1v = r.v[i * 4 + 1], k2v = r.v[i * 4 + 2], k3v = r.v[i * 4 + 3];
+            // register micro-transpose: row rq+j gets its 4 consecutive k as one 8-byte LDS store
+            uint2 p0, p1, p2, p3;
+            p0.x = f2bf2(k0v.x, k1v.x); p0.y = f2bf2(k2v.x, k3v.x);
+            p1.x = f2bf2(k0v.y, k1v.y); p1.y = f2bf2(k2v.y, k3v.y);
+            p2.x = f2bf2(k0v.z, k1v.z); p2.y = f2bf2(k2v.z, k3v.z);
+            p3.x = f2bf2(k0v.w, k1v.w); p3.y = f2bf2(k2v.w, k3v.w);
+            *reinterpret_cast<uint2*>(&S[(rq + 0) * LDK + kq]) = p0;
+            *reinterpret_cast<uint2*>(&S[(rq + 1) * LDK + kq]) = p1;
+            *reinterpret_cast<uint2*>(&S[(rq + 2) * LDK + kq]) = p2;
+            *reinterpret_cast<uint2*>(&S[(rq + 3) * LDK + kq]) = p3;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (BM + BN) * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)blockIdx.z * g.strideA;
+        B += (long long)blockIdx.z * g.strideB;
+        C += (long long)blockIdx.z * g.strideC;
+    }
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    FastRegs<BM, NT, AKC> ra;
+    FastRegs<BN, NT, BKC> rb;
+    fast_gload<BM, NT, AKC>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend);
+    fast_gload<BN, NT, BKC>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        unsigned short* As = lds + buf * (BM + BN) * LDK;
+        unsigned short* Bs = As + BM * LDK;
+        fast_sstore<BM, NT, AKC>(As, ra);
+        fast_sstore<BN, NT, BKC>(Bs, rb);
+        __syncthreads();                       // tile visible; the other buffer is free (its readers passed the previous barrier)
+        if (k0 + 32 < kend) {
+            fast_gload<BM, NT, AKC>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend);
+            fast_gload<BN, NT, BKC>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend);
+        }
+        u16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[i] = *reinterpret_cast<const u16x8_t*>(&As[((wm * TM + i) * 16 + (lane & 15)) * LDK + (lane >> 4) * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[j] = *reinterpret_cast<const u16x8_t*>(&Bs[((wn * TN + j) * 16 + (lane & 15)) * LDK + (lane >> 4) * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+        buf ^= 1;
+    }
+    const bool has_bias = g.bias != nullptr, has_beta = g.beta != 0.f, do_tanh = g.act == LAS_ACT_TANH;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+            const float bcol = (has_bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) * 4 + r;
+                if (row < g.M && col < g.N) {
+                    if (g.splitk > 1) {
+                        g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r] + bcol;
+                        float* cp = C + (long long)row * g.ldc + col;
+                        if (has_beta) v += g.beta * (*cp);
+                        *cp = do_tanh ? tanh_fast(v) : v;
+                    }
+                }
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim), blk(WM * WN * 64);
+    const bool akc = g.ksA == 1, bkc = g.ksB == 1;
+    if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, g);
+    else                  hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +514,21 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
 
     if (K == 0 && g.splitk == 1) {
         // empty contraction: C = act(beta*C + bias); run the kernel with no k-tiles
+    }
+    // branch-free fast path: 16-byte loads legal, k (or row) counts multiples of 4, no contraction mask
+    const bool fastA = g.vecA && (g.ksA == 1 ? (K % 4 == 0) : (M % 4 == 0 && M >= 4));
+    const bool fastB = g.vecB && (g.ksB == 1 ? (K % 4 == 0) : (N % 4 == 0 && N >= 4));
+    if (prec == LAS_PREC_BF16 && fastA && fastB && a_mask_period == 0 && K > 0 && (cfg == 1 || cfg == 2)) {
+        if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
+        else          launch_fast<2, 2, 2, 2>(g, zdim, st);
+        LAS_LAUNCHED();
+        if (g.splitk > 1) {
+            int nb = cdiv((long long)M * N, 256);
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, g);
+            LAS_LAUNCHED();
+        }
+        return 0;
     }
     switch (cfg) {
         case 0: {
@@ -515,10 +702,10 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_kernel(const float* __rest
         for (int u = 0; u < UN; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                u16x8_t av;
-                av[0] = f2bf(a0[u][mt].x); av[1] = f2bf(a0[u][mt].y); av[2] = f2bf(a0[u][mt].z); av[3] = f2bf(a0[u][mt].w);
-                av[4] = f2bf(a1[u][mt].x); av[5] = f2bf(a1[u][mt].y); av[6] = f2bf(a1[u][mt].z); av[7] = f2bf(a1[u][mt].w);
-                acc[mt] = mfma_bf16_16x16x32(av, bv[u], acc[mt]);
+                uint4 pk;
+                pk.x = f2bf2(a0[u][mt].x, a0[u][mt].y); pk.y = f2bf2(a0[u][mt].z, a0[u][mt].w);
+                pk.z = f2bf2(a1[u][mt].x, a1[u][mt].y); pk.w = f2bf2(a1[u][mt].z, a1[u][mt].w);
+                acc[mt] = mfma_bf16_16x16x32(__builtin_bit_cast(u16x8_t, pk), bv[u], acc[mt]);
             }
     }
 #pragma unroll

@@ -28,6 +28,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+// two fp32 -> packed bf16x2 (lo in bits 0-15), RNE, one v_cvt_pk_bf16_f32 (gfx950)
+__device__ __forceinline__ unsigned int f2bf2(float lo, float hi) {
+    unsigned int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 // D = A(16x32 bf16) . B(32x16 bf16) + C.  Lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15],
