@@ -31,6 +31,7 @@ struct RnnArgs {
     unsigned long long* xbuf; int* err;     // cluster exchange granules / bounded-spin error flag
     float* sink;                             // scratch rows for the padded part of a ragged batch tile
     int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
+    int ks_packed;                           // wpack holds the K-split BPTT fragment order
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
@@ -240,6 +241,22 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // (a member can be at most one step ahead of the slowest reader).  The buffer is zeroed by a memset node
 // before every launch; spins are bounded and report through err[0].
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) float gfloat;          // explicit global pointers: global_load/store, never flat
+typedef __attribute__((address_space(1))) const float gcfloat;
+#define GF(p) ((gfloat*)(p))
+#define GCF(p) ((gcfloat*)(p))
+// make the compiler wait for (and own) a prefetched value NOW, before the stores that follow are issued:
+// vmcnt retires in order and counts stores, so a later wait would also cover those stores' acknowledgements
+#ifdef LAS_EXP_HOTX
+#define LAS_EXP_X(st) (-(long long)s * (st))   /* experiment: always re-read frame t0 (cache resident) */
+#else
+#define LAS_EXP_X(st) (st)
+#endif
+#ifdef LAS_USE_TOUCH
+#define TOUCH(x) asm volatile("" : "+v"(x))
+#else
+#define TOUCH(x)          /* measured: forcing the x-projection wait before the stores is slower */
+#endif
 #define LAS_SPIN_BUDGET (1 << 22)
 
 __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned tag, unsigned val) {
@@ -305,26 +322,31 @@ struct RnnCfg {
     static constexpr int DP_BYTES = 2 * 16 * LDG * 2;
     static constexpr int RFB = cmin(NFB, RCAP);
     static constexpr int LFB = cmax(0, cmin(NFB - RFB, (150 * 1024 - DP_BYTES) / 4096));
-    static constexpr int FWD_LDS = HS_BYTES + 4 * LF * 1024;
+    static constexpr int FWD_LDS = HS_BYTES + 4 * LF * 1024;      // for RT = 1; RT > 1 requires LF == 0 / LFB == 0
     static constexpr int BWD_LDS = DP_BYTES + 4 * LFB * 1024;
     static constexpr int GPM_F = 16 * UPM / 2;        // granules one member publishes per step, forward
     static constexpr int GPM_B = 16 * G * UPM / 2;    // ... backward
     static constexpr bool OK = (UT % P == 0) && (RF + LF == NFW) && (RFB + LFB == NFB);
 };
 
-template <int CELL, int UT, int P>
-__global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
+template <int CELL, int UT, int P, int RT>
+__global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
     using C = RnnCfg<CELL, UT, P>;
     constexpr int G = C::G, H = C::H, GH = C::GH, KS = C::KS, NFW = C::NFW, LDH = C::LDH, LF = C::LF, RF = C::RF;
     constexpr int UTP = C::UTP, UPM = C::UPM, GPM = C::GPM_F;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* hs = reinterpret_cast<unsigned short*>(smem);               // [2][16][LDH]
-    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::HS_BYTES);               // [4][LF][64]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    // RT row tiles (16 batch rows each) share this workgroup as independent wave groups: 4 waves per row tile,
+    // RT waves per SIMD -> the SIMD always has another chain's instructions to issue while one waits
+    const int rt = threadIdx.x >> 8;
+    unsigned short* hs = reinterpret_cast<unsigned short*>(smem + rt * C::HS_BYTES);   // [2][16][LDH] per row tile
+    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + RT * C::HS_BYTES);          // [4][LF][64] shared by the row tiles
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = a.T, B = a.B;
-    const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;         // cluster, member
-    if (cl >= a.ncl) return;
-    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int cg = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;         // (tile group, direction), member
+    if (cg >= a.ncl) return;
+    const int dir = cg & 1, tile = (cg >> 1) * RT + rt, b0 = tile * 16;
+    if (b0 >= B) return;                         // surplus row-tile group: terminated waves leave the barrier count
+    const int cl = tile * 2 + dir;
     const int vw = pm * 4 + w;                                                   // virtual wave: owns units [vw*16*UTP, ..)
     const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFW * 64;
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;                 // [2 slots][P][GPM]
@@ -344,9 +366,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
     const long long tstep = dir ? -1 : 1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out;
     // rows past the end of a ragged batch tile read/write a scratch row (no exec-mask branches in the loop)
-    float* gptr[4];
-    float* cptr[4];
-    float* optr[4];
+    gfloat* gptr[4];
+    gfloat* cptr[4];
+    gfloat* optr[4];
     long long gst[4], cst_[4], ost[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -354,9 +376,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0;
-        cptr[r] = (valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0;
-        optr[r] = valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0;
+        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
+        cptr[r] = GF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
+        optr[r] = GF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0;
     }
     float cst[UTP][4];
@@ -375,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
             for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][q * H + j * 16];
     int cur = 0;
 #ifdef LAS_PROF
-    const bool prof = a.dbg && blockIdx.x == 0 && tid == 0;
+    const bool prof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     if (prof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
 #define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (prof && s >= 200 && s < 208) a.dbg[8 + (s - 200) * 8 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
                 for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][gst[r] + q * H + j * 16];
+                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][LAS_EXP_X(gst[r]) + q * H + j * 16];
         }
         const unsigned short* hcur = hs + cur * 16 * LDH;
         u16x8_t av[KS];                  // all A fragments of h_{t-1} up front: one LDS round trip, then MFMAs back to back
@@ -418,6 +440,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
         STAMP(2);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
         unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
+        if (s + 1 < T) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int j = 0; j < UTP; ++j) TOUCH(xn[q][j]);
+        }
         float sv_h[UTP][4], sv_g[G][UTP][4];     // results kept in registers; written to HBM after the exchange
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
@@ -474,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (CELL == LAS_CELL_LSTM) {
-                    float* gp = gptr[r] + j * 16;
+                    gfloat* gp = gptr[r] + j * 16;
                     gp[0] = sv_g[0][j][r]; gp[H] = sv_g[G > 1 ? 1 : 0][j][r]; gp[2 * H] = sv_g[G > 2 ? 2 : 0][j][r];
                     gp[3 * H] = sv_g[G > 3 ? 3 : 0][j][r];
                     cptr[r][j * 16] = cst[j][r];
@@ -491,19 +519,22 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a) {
 #endif
 }
 
-template <int CELL, int UT, int P>
-__global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
+template <int CELL, int UT, int P, int RT>
+__global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     using C = RnnCfg<CELL, UT, P>;
     constexpr int G = C::G, H = C::H, GH = C::GH, KSB = C::KSB, NFB = C::NFB, LDG = C::LDG, LFB = C::LFB, RFB = C::RFB;
     constexpr int UTP = C::UTP, UPM = C::UPM, GPM = C::GPM_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* dps = reinterpret_cast<unsigned short*>(smem);              // [2][16][LDG]
-    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::DP_BYTES);               // [4][LFB][64]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int rt = threadIdx.x >> 8;
+    unsigned short* dps = reinterpret_cast<unsigned short*>(smem + rt * C::DP_BYTES);  // [2][16][LDG] per row tile
+    u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + RT * C::DP_BYTES);          // [4][LFB][64]
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = a.T, B = a.B;
-    const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
-    if (cl >= a.ncl) return;
-    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int cg = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
+    if (cg >= a.ncl) return;
+    const int dir = cg & 1, tile = (cg >> 1) * RT + rt, b0 = tile * 16;
+    if (b0 >= B) return;
+    const int cl = tile * 2 + dir;
     const int vw = pm * 4 + w;
     const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFB * 64;
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;
@@ -520,10 +551,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
-    float* gptr[4];
-    const float* cptr[4];
-    const float* optr[4];
-    const float* dptr[4];
+    gfloat* gptr[4];
+    gcfloat* cptr[4];
+    gcfloat* optr[4];
+    gcfloat* dptr[4];
     long long gst[4], cst_[4], ost[4], dst[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -531,10 +562,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0;
-        cptr[r] = (valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0;
-        optr[r] = valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0;
-        dptr[r] = valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0;
+        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
+        cptr[r] = GF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
+        optr[r] = GF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
+        dptr[r] = GCF(valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
     }
     f32x4_t dhr[UTP];
@@ -613,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
         }
         // advance to the next visited frame and refill the operand registers (dz of this step is written
         // to HBM after the exchange; the pointers keep the previous frame in gprev)
-        float* gprev[4];
+        gfloat* gprev[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         if (s + 1 < T) {
@@ -676,6 +707,252 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a) {
     if (errflag && a.err) a.err[0] = 1;
 }
 
+// ====================================================================================================
+// BPTT with a K-split exchange (P > 1).  dh_{t-1} = dG_t . W_hh^T.  Instead of all-gathering dG_t (16 x G*H
+// bf16 -> every member reads (P-1)/P of it every step), each member multiplies ONLY its own gate columns
+// (K slice = G*H/P) against the matching rows of W_hh^T for ALL hidden units, and the fp32 partial sums are
+// reduce-scattered: a wave publishes, for every other member, the accumulator tile that member owns and adds
+// the P-1 tiles it receives for its own tile.  Producer and consumer lanes hold the same (row, unit) position
+// of the MFMA accumulator layout, so a received granule is added straight into a register: half the inbound
+// granules of the all-gather, no LDS decode, exact fp32 partials.
+//   wave w of member pm owns unit tiles (pm, w, j), j < UTP, and computes partial tiles (m, w, j) for all m.
+// ====================================================================================================
+template <int CELL, int UT, int P>
+struct KsCfg {
+    using C = RnnCfg<CELL, UT, P>;
+    static constexpr int G = C::G, H = C::H, UTP = C::UTP, UPM = C::UPM;
+    static constexpr int KP = G * UPM;               // own gate columns = K of the member's product
+    static constexpr int KSP = KP / 32;
+    static constexpr int NFR = P * UTP * KSP;        // B fragments per wave (all kept in registers)
+    static constexpr int LDZ = KP + 8;               // bf16 row pitch of the own-dG tile
+    static constexpr int DZ_BYTES = 2 * 16 * LDZ * 2;
+    static constexpr int GPD = 4 * UTP * 4 * 64;     // granules one member sends to ONE other member per step
+    static constexpr bool OK = C::OK && NFR <= 64 && (KP % 32 == 0);
+};
+
+template <int CELL, int UT, int P>
+__global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
+    using K = KsCfg<CELL, UT, P>;
+    constexpr int G = K::G, H = K::H, GH = G * H, UTP = K::UTP, UPM = K::UPM, KSP = K::KSP, NFR = K::NFR, LDZ = K::LDZ, GPD = K::GPD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* dzs = reinterpret_cast<unsigned short*>(smem);              // [2][16][LDZ] own dG slice (bf16)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int T = a.T, B = a.B;
+    const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
+    if (cl >= a.ncl) return;
+    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int vw = pm * 4 + w;
+    // fragments (dir, vw, m, j, ks), all in registers
+    const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFR * 64;
+    u16x8_t wreg[NFR];
+#pragma unroll
+    for (int r = 0; r < NFR; ++r) wreg[r] = Wp[r * 64 + lane];
+    // inbox of member d: [2 slots][P dst][P src][GPD]
+    unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * P * GPD;
+    int errflag = 0;
+
+    const int t0 = dir ? 0 : T - 1;
+    const long long tstep = dir ? 1 : -1;
+    const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
+    gfloat* gptr[4];
+    gcfloat* cptr[4];
+    gcfloat* optr[4];
+    gcfloat* dptr[4];
+    long long gst[4], cst_[4], ost[4], dst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + g * 4 + r;
+        const bool valid = b < B;
+        const long long row = (long long)b;
+        const int u0 = vw * (16 * UTP) + c;
+        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
+        cptr[r] = GCF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
+        optr[r] = GCF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
+        dptr[r] = GCF(valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0);
+        gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
+    }
+    f32x4_t dhr[UTP];
+    float dcc[UTP][4];
+#pragma unroll
+    for (int j = 0; j < UTP; ++j) {
+        dhr[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dcc[j][r] = 0.f;
+    }
+    constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
+    float n_do[UTP][4], n_g[NG][UTP][4], n_c[UTP][4], n_cn[UTP][4];
+#pragma unroll
+    for (int j = 0; j < UTP; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            n_do[j][r] = dptr[r][j * 16];
+            if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+                for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
+                n_c[j][r] = cptr[r][j * 16];
+                n_cn[j][r] = T > 1 ? cptr[r][cst_[r] + j * 16] : 0.f;
+            } else {
+                n_g[0][j][r] = optr[r][j * 16];
+                n_c[j][r] = 0.f; n_cn[j][r] = 0.f;
+            }
+        }
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        unsigned short* dzc = dzs + cur * 16 * LDZ;
+        float sv_z[G][UTP][4];
+        // ---- gate backward for the own units -> own dG slice in LDS (bf16) and in registers (fp32, for HBM)
+#pragma unroll
+        for (int j = 0; j < UTP; ++j) {
+            const int ucol = (w * UTP + j) * 16 + c;                 // column of this unit inside one gate block of the slice
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dh = n_do[j][r] + dhr[j][r];
+                float dz[G];
+                if (CELL == LAS_CELL_LSTM) {
+                    const float gi = n_g[0][j][r], gj = n_g[NG > 1 ? 1 : 0][j][r], gf = n_g[NG > 2 ? 2 : 0][j][r],
+                                go = n_g[NG > 3 ? 3 : 0][j][r];
+                    const float cprev = (s + 1 < T) ? n_cn[j][r] : 0.f;
+                    const float tc = tanhx<true>(n_c[j][r]);
+                    const float dc = dcc[j][r] + dh * go * (1.f - tc * tc);
+                    dcc[j][r] = dc * gf;
+                    dz[0] = dc * gj * gi * (1.f - gi);
+                    dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
+                    dz[G > 2 ? 2 : 0] = dc * cprev * gf * (1.f - gf);
+                    dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
+                } else {
+                    const float h = n_g[0][j][r];
+                    dz[0] = dh * (1.f - h * h);
+                }
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    dzc[(g * 4 + r) * LDZ + q * UPM + ucol] = f2bf(dz[q]);
+                    sv_z[q][j][r] = dz[q];
+                }
+            }
+        }
+        gfloat* gprev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
+        if (s + 1 < T) {     // operands of the next step fly under this step's MFMAs and exchange
+#pragma unroll
+            for (int j = 0; j < UTP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    n_do[j][r] = dptr[r][j * 16];
+                    if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
+                        n_c[j][r] = n_cn[j][r];
+                        n_cn[j][r] = (s + 2 < T) ? cptr[r][cst_[r] + j * 16] : 0.f;
+                    } else {
+                        n_g[0][j][r] = optr[r][j * 16];
+                    }
+                }
+        }
+        lds_barrier();
+        // ---- partial dh tiles (m, w, j) for every member m:  own dG slice [16 x KP] . W_hh^T rows of those units
+        f32x4_t acc[P][UTP];
+#pragma unroll
+        for (int m = 0; m < P; ++m)
+#pragma unroll
+            for (int j = 0; j < UTP; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dzc[c * LDZ + ks * 32 + g * 8]);
+#pragma unroll
+            for (int m = 0; m < P; ++m)
+#pragma unroll
+                for (int j = 0; j < UTP; ++j) acc[m][j] = mfma_bf16_16x16x32(av, wreg[(m * UTP + j) * KSP + ks], acc[m][j]);
+        }
+        if (s + 1 < T) {
+            // ---- reduce-scatter: send the tiles other members own, add the ones they computed for this wave
+            unsigned long long* xslot = xb + (size_t)(s & 1) * P * P * GPD;
+#pragma unroll
+            for (int mo = 1; mo < P; ++mo) {
+                const int m = (pm + mo) % P;
+                unsigned long long* dstp = xslot + ((size_t)m * P + pm) * GPD + (size_t)(w * UTP) * 4 * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < UTP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers
+                        float v = 0.f;
+#pragma unroll
+                        for (int mm = 0; mm < P; ++mm) v = (mm == m) ? acc[mm][j][r] : v;
+                        granule_store(dstp + (size_t)(j * 4 + r) * 64, (unsigned)(s + 1), __float_as_uint(v));
+                    }
+            }
+            constexpr int NGT = (P - 1) * UTP * 4;
+            unsigned long long xv[NGT];
+            const unsigned long long* inbox = xslot + (size_t)pm * P * GPD + (size_t)(w * UTP) * 4 * 64 + lane;
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int src = (pm + 1 + n / (UTP * 4)) % P;
+                xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 4)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) ok &= (unsigned)(xv[n] >> 32) == (unsigned)(s + 1);
+                if (ok) break;
+                if (--budget <= 0) { errflag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) {
+                    if ((unsigned)(xv[n] >> 32) != (unsigned)(s + 1)) {
+                        const int src = (pm + 1 + n / (UTP * 4)) % P;
+                        xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 4)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UTP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int mm = 0; mm < P; ++mm) v = (mm == pm) ? acc[mm][j][r] : v;
+#pragma unroll
+                    for (int mo = 0; mo < P - 1; ++mo) v += __uint_as_float((unsigned)xv[(mo * UTP + j) * 4 + r]);
+                    dhr[j][r] = v;
+                }
+        }
+        // ---- d(pre-activation) of this step to HBM (never waited on)
+#pragma unroll
+        for (int j = 0; j < UTP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < G; ++q) gprev[r][q * H + j * 16] = sv_z[q][j][r];
+        cur ^= 1;
+    }
+    if (errflag && a.err) a.err[0] = 1;
+}
+
+// fragments for the K-split BPTT: (dir, vw = pm*4+w, m, j, ks):
+//   B[k][n] = W_hh[unit n = m*UPM + (w*UTP + j)*16 + (lane&15)][gate col of k],  k = ks*32 + 8*(lane>>4) + e in the
+//   member's slice: q = k / UPM, gate col = q*H + pm*UPM + (k % UPM)
+__global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const float* W1, int ldw, int H, int G, int P,
+                                                          unsigned short* out) {
+    const int UTP = H / 64 / P, UPM = H / P, KP = G * UPM, KSP = KP / 32, NFR = P * UTP * KSP, NVW = 4 * P;
+    const long long total = 2LL * NVW * NFR * 512;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long rest = idx >> 9;
+        const int fi = (int)(rest % NFR);
+        const int vw = (int)((rest / NFR) % NVW);
+        const int dir = (int)(rest / ((long long)NFR * NVW));
+        const float* W = dir ? W1 : W0;
+        const int ks = fi % KSP, mj = fi / KSP, j = mj % UTP, m = mj / UTP;
+        const int pm = vw / 4, w = vw % 4;
+        const int unit = m * UPM + (w * UTP + j) * 16 + (lane & 15);
+        const int k = ks * 32 + (lane >> 4) * 8 + e;
+        const int q = k / UPM, col = q * H + pm * UPM + (k % UPM);
+        out[idx] = f2bf(W[(long long)unit * ldw + col]);
+    }
+}
+
 // W_hh (fp32 [H, G*H]) -> bf16 MFMA B-fragment order for 4*P "virtual waves" of 16*UTP units each.
 //  fwd: frag (dir,vw,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + vw*16*UTP + j*16 + (lane&15)]
 //  bwd: frag (dir,vw,j,ks):   B[k][n] = W[vw*16*UTP + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
@@ -734,7 +1011,10 @@ static SeqWs seq_ws_layout(int cell, int H, int B) {
     w.sink = o; o += ((size_t)(G * H + 64) * sizeof(float) + 255) & ~(size_t)255;
     w.xbuf = o;
     const size_t ncl = (size_t)((B + 15) / 16) * 2;
-    o += ncl * 2 * (8 * G * H) * sizeof(unsigned long long);           // [ncl][2 slots][P*GPM_B = 8*G*H]
+    {   // [ncl][2 slots][max(all-gather: 8*G*H, K-split reduce-scatter: P*16*H with P <= 8)]
+        const size_t per = (size_t)8 * 16 * H > (size_t)8 * G * H ? (size_t)8 * 16 * H : (size_t)8 * G * H;
+        o += ncl * 2 * per * sizeof(unsigned long long);
+    }
     w.total = o + 256;
     return w;
 }
@@ -749,25 +1029,61 @@ static int set_lds(K kern, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int CELL, int UT, int P>
-static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
+template <int CELL, int UT, int P, int RT>
+static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t st) {
     using C = RnnCfg<CELL, UT, P>;
-    if constexpr (!C::OK) {
-        las_set_error("rnn_seq: cluster width %d cannot keep W_hh resident for H=%d", P, C::H);
+    constexpr int FL = RT * C::HS_BYTES + 4 * C::LF * 1024, BL = RT * C::DP_BYTES + 4 * C::LFB * 1024;
+    if constexpr (!C::OK || FL > 160 * 1024 || BL > 160 * 1024) {
+        las_set_error("rnn_seq: cluster width %d / %d row tiles cannot keep W_hh resident for H=%d", P, RT, C::H);
         return -2;
     } else {
-        dim3 grid(a.ncl_pad * P);
+        RnnArgs a = a0;
+        a.ncl = cdiv(ntiles, RT) * 2;                      // (tile group, direction) pairs
+        a.ncl_pad = (a.ncl + 7) / 8 * 8;                   // members of a cluster share blockIdx % 8 (same XCD: speed only)
+        if ((long long)a.ncl_pad * P > 256) {              // every member must be co-resident (1 workgroup per CU)
+            las_set_error("rnn_seq: %d workgroups exceed the CU count", a.ncl_pad * P);
+            return -2;
+        }
+        dim3 grid(a.ncl_pad * P), blk(256 * RT);
         if (!bwd) {
-            static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT, P>, C::FWD_LDS);
+            static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>, FL);
             if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd) failed: %d", attr); return attr; }
-            hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P>), grid, dim3(256), C::FWD_LDS, st, a);
+            hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>), grid, blk, FL, st, a);
+        } else if (P > 1 && KsCfg<CELL, UT, P>::OK && a.ks_packed) {
+            if constexpr (P > 1 && KsCfg<CELL, UT, P>::OK) {
+                constexpr int KZ = KsCfg<CELL, UT, P>::DZ_BYTES;
+                static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P>, KZ);
+                if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
+                hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P>), grid, dim3(256), KZ, st, a);
+            }
         } else {
-            static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT, P>, C::BWD_LDS);
+            static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT, P, RT>, BL);
             if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd) failed: %d", attr); return attr; }
-            hipLaunchKernelGGL((rnn_seq_bwd_bf16_kernel<CELL, UT, P>), grid, dim3(256), C::BWD_LDS, st, a);
+            hipLaunchKernelGGL((rnn_seq_bwd_bf16_kernel<CELL, UT, P, RT>), grid, blk, BL, st, a);
         }
         return 0;
     }
+}
+
+// row tiles per workgroup: as many waves per SIMD as registers and LDS allow (measured per configuration)
+static int pick_rt(int cell, int H, int P, bool bwd, int ntiles) {
+    // measured on MI355X: extra row-tile waves on the same CU lose (the step is bound by the CU's MFMA +
+    // transcendental issue rate, not by latency) -> one row tile per workgroup, tiles spread over CUs
+    int rt = 1;
+    (void)cell; (void)H; (void)P; (void)bwd;
+    return rt < ntiles ? rt : (ntiles < 1 ? 1 : ntiles);
+}
+
+template <int CELL, int UT, int P>
+static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
+    const int ntiles = cdiv(a.B, 16);
+    int rt = pick_rt(CELL, UT * 64, P, bwd, ntiles);
+    for (; rt >= 1; --rt) {
+        int rc;
+        rc = launch_bf16_rt<CELL, UT, P, 1>(bwd, a, ntiles, st);
+        if (rc != -2) return rc;
+    }
+    return -2;
 }
 
 static int dispatch_bf16(int cell, int P, bool bwd, const RnnArgs& a, hipStream_t st) {
@@ -783,7 +1099,6 @@ static int dispatch_bf16(int cell, int P, bool bwd, const RnnArgs& a, hipStream_
         case 21:   return launch_bf16<LAS_CELL_RNN, 2, 1>(bwd, a, st);
         case 41:   return launch_bf16<LAS_CELL_RNN, 4, 1>(bwd, a, st);
         case 42:   return launch_bf16<LAS_CELL_RNN, 4, 2>(bwd, a, st);
-        case 44:   return launch_bf16<LAS_CELL_RNN, 4, 4>(bwd, a, st);
         case 82:   return launch_bf16<LAS_CELL_RNN, 8, 2>(bwd, a, st);
         case 84:   return launch_bf16<LAS_CELL_RNN, 8, 4>(bwd, a, st);
         default:
@@ -816,17 +1131,19 @@ static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float
     a.err = (int*)(base + L.err);
     a.sink = (float*)(base + L.sink);
     a.xbuf = (unsigned long long*)(base + L.xbuf);
-    a.ncl = cdiv(a.B, 16) * 2;
-    a.ncl_pad = (a.ncl + 7) / 8 * 8;
-    if ((long long)a.ncl_pad * P > 256) P = 1;          // every member must be co-resident (1 workgroup per CU)
-    hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
-                       (unsigned short*)a.wpack);
+    a.ncl = a.ncl_pad = 0;                               // set per launch (depends on the row tiles per workgroup)
+    a.ks_packed = (bwd && P > 1 && !getenv("LAS_NO_KSPLIT")) ? 1 : 0;
+    if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
+                                        (unsigned short*)a.wpack);
+    else hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
+                            (unsigned short*)a.wpack);
     LAS_LAUNCHED();
     LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
     int rc = dispatch_bf16(cell, P, bwd, a, st);
     if (rc == -2 && P != 1) {                            // fall back to the widest supported cluster
         for (int q = 8; q >= 1 && rc == -2; q >>= 1) {
-            if (q == P || (long long)a.ncl_pad * q > 256) continue;
+            if (q == P) continue;
+            a.ks_packed = 0;
             hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G,
                                bwd ? 1 : 0, q, (unsigned short*)a.wpack);
             rc = dispatch_bf16(cell, q, bwd, a, st);
@@ -844,7 +1161,7 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
     a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);
 #endif
@@ -872,7 +1189,7 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
     a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
         if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
     } else {
