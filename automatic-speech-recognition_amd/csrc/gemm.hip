@@ -656,14 +656,17 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
     return M >= 1 && M <= 64 && (K % 8) == 0 && (lda % 4) == 0 && (((uintptr_t)A) & 15) == 0 && N >= 1;
 }
 
+// 8 waves split K; every wave has all of its loads (<= UN k-steps) in flight at once, then MFMAs, then an LDS
+// reduction of the 8 partial tiles.  Latency of one L2 round trip instead of K/32 dependent ones.
 template <int MT>
-__global__ __launch_bounds__(256, 1) void skinny_gemm_kernel(const float* __restrict__ A, int lda, int M, int K,
+__global__ __launch_bounds__(512, 1) void skinny_gemm_kernel(const float* __restrict__ A, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
                                                              float* __restrict__ C, int ldc, const float* __restrict__ bias) {
-    __shared__ float red[4][MT][64][4];
+    constexpr int NW = 8;
+    __shared__ float red[NW][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int ct = blockIdx.x;
-    const int KSW = (KS + 3) / 4;
+    const int KSW = (KS + NW - 1) / NW;
     const int ks0 = w * KSW, ks1 = min(KS, ks0 + KSW);
     const u16x8_t* bp = Bp + (size_t)ct * KS * 64 + lane;
     const float* ap[MT];
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_kernel(const float* __rest
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int UN = 3;                          // k-steps whose loads are all in flight together
+    constexpr int UN = MT <= 3 ? 8 : 6;            // k-steps whose loads are all in flight together
     for (int ks = ks0; ks < ks1; ks += UN) {
         u16x8_t bv[UN];
         float4 a0[UN][MT], a1[UN][MT];
@@ -713,12 +716,14 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w][mt][lane][r] = acc[mt][r];
     __syncthreads();
-    for (int idx = tid; idx < MT * 256; idx += 256) {
+    for (int idx = tid; idx < MT * 256; idx += 512) {
         const int mt = idx >> 8, r16 = (idx >> 4) & 15, c16 = idx & 15;
         const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
         const int row = mt * 16 + r16, col = ct * 16 + c16;
         if (row < M && col < N) {
-            float v = red[0][mt][l2][reg] + red[1][mt][l2][reg] + red[2][mt][l2][reg] + red[3][mt][l2][reg];
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) v += red[ww][mt][l2][reg];
             if (bias) v += bias[col];
             C[(long long)row * ldc + col] = v;
         }
@@ -730,10 +735,10 @@ int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, i
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     const u16x8_t* Bp = reinterpret_cast<const u16x8_t*>(packed);
     switch (MT) {
-        case 1: hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        case 2: hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        case 3: hipLaunchKernelGGL(skinny_gemm_kernel<3>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        default: hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(nct), dim3(256), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        case 1: hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        case 2: hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        case 3: hipLaunchKernelGGL(skinny_gemm_kernel<3>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
+        default: hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
     }
     LAS_LAUNCHED();
     return 0;

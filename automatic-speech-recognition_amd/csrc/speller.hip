@@ -645,14 +645,19 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
     if (t_cell >= 0) cell_bwd_row<CELL, FAST>(a, NL - 1, t_cell, b, a.dHl + (size_t)t_cell * B * D, D);
 }
 
-// demb[v,:] += sum over (t,b) with token v of dXin0[t,b,0:E]
-__global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const float* dXin0, int n, int ld, int E, float* demb) {
-    const int v = blockIdx.x;
+// demb[v,:] += sum over (t,b) with token v of dXin0[t,b,0:E]  -- stage 1: per (vocab row, row chunk) partials
+// (fixed chunking -> deterministic); stage 2 is las_colsum over the chunk axis.
+constexpr int EMB_CHUNKS = 32;
+__global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const float* dXin0, int n, int ld, int E, int V,
+                                                       float* part) {
+    const int v = blockIdx.x, ch = blockIdx.y;
+    const int per = (n + EMB_CHUNKS - 1) / EMB_CHUNKS;
+    const int i0 = ch * per, i1 = min(n, i0 + per);
     for (int e = threadIdx.x; e < E; e += 256) {
         float acc = 0.f;
-        for (int i = 0; i < n; ++i)
+        for (int i = i0; i < i1; ++i)
             if (tok[i] == v) acc += dXin0[(size_t)i * ld + e];
-        demb[(size_t)v * E + e] += acc;
+        part[((size_t)ch * V + v) * E + e] = acc;
     }
 }
 
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -670,6 +675,7 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     const size_t I0D = (size_t)E + Hd + D;
     w.packF = o;  o += align256(las_skinny_pack_bytes((int)I0D, G * D));      // W0 fragments (step product)
     w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
+    w.embp = o;   o += align256((size_t)EMB_CHUNKS * V * E * f);
     w.dHl = o;    o += align256((size_t)U * B * D * f);
     w.dH = o;     o += align256((size_t)NL * B * D * f);
     w.dC = o;     o += align256((size_t)NL * B * D * f);
@@ -685,6 +691,7 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
+    if ((size_t)8 * V * E > big) big = (size_t)8 * V * E;         // las_colsum scratch for the embedding gradient
     o += align256(big * 8 * f);
     w.total = o;
     return w;
@@ -863,8 +870,13 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
                      bk->dWv, V, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
     GEMM_OK(las_colsum(bk->dlogits, UB, V, V, 1.f, bk->dbv, gws, gws_bytes, st));
     GEMM_OK(las_colsum(d.duRows, B, A, A, 1.f, bk->du, gws, gws_bytes, st));
-    hipLaunchKernelGGL(emb_grad_kernel, dim3(V), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D, E, bk->demb);
-    LAS_LAUNCHED();
+    {
+        float* epart = (float*)(base + w.embp);
+        hipLaunchKernelGGL(emb_grad_kernel, dim3(V, EMB_CHUNKS), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D,
+                           E, V, epart);
+        LAS_LAUNCHED();
+        GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
+    }
     // d_enc[b] += alphas[:,b,:]^T . dctx[:,b,:]   (batched over utterances; contraction over the U steps)
     GEMM_OK(las_gemm(prec, 1, 0, Tp, Hd, U, 1.f, d.alphas, B * Tp, Tp, d.dXin0 + E, B * I0D, I0D, 1.f, bk->d_enc, Hd,
                      (long long)Tp * Hd, nullptr, LAS_ACT_NONE, B, 0, 0, nullptr, 0, st));
