@@ -172,3 +172,32 @@ extern "C" int las_clip_adam(float* theta, const float* g, float* m, float* v, l
     LAS_LAUNCHED();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// BasicLSTMCell gate math for ONE step (char RNNLM shallow fusion, reference lang/char_rnn_model.py:57-66,
+// las/beam_search.py:226-236): z = [x,h].kernel + bias comes from las_gemm; here
+//   i,j,f,o = split(z,4); c' = c*sigmoid(f+fb) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float* __restrict__ z, const float* __restrict__ c_prev, int N,
+                                                             int H, float fb, float* __restrict__ c_out, float* __restrict__ h_out) {
+    const long long total = (long long)N * H;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long n = idx / H;
+        const int u = (int)(idx % H);
+        const float* zr = z + n * 4 * H;
+        const float gi = sigmoid_acc(zr[u]), gj = tanh_acc(zr[H + u]), gf = sigmoid_acc(zr[2 * H + u] + fb), go = sigmoid_acc(zr[3 * H + u]);
+        const float c = c_prev[idx] * gf + gi * gj;
+        c_out[idx] = c;
+        h_out[idx] = tanh_acc(c) * go;
+    }
+}
+
+extern "C" int las_lstm_pointwise(const float* z, const float* c_prev, int N, int H, float forget_bias, float* c_out, float* h_out,
+                                  void* stream) {
+    LAS_ARG(z && c_prev && c_out && h_out && N > 0 && H > 0, "las_lstm_pointwise: bad arguments");
+    int nb = cdiv((long long)N * H, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, c_prev, N, H, forget_bias, c_out, h_out);
+    LAS_LAUNCHED();
+    return 0;
+}

@@ -179,6 +179,14 @@ int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
                   void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * R1  one BasicLSTMCell step of the char RNNLM used for shallow fusion (lang/char_rnn_model.py:57-66 with
+ * forget_bias 0, driven from las/beam_search.py:226-236): gate math on z = [x,h].kernel + bias [N,4H]
+ * (the contraction itself is las_gemm): c' = c*sigmoid(f+fb) + sigmoid(i)*tanh(j), h' = tanh(c')*sigmoid(o).
+ */
+int las_lstm_pointwise(const float* z, const float* c_prev, int N, int H, float forget_bias,
+                       float* c_out, float* h_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K10  one pruning step of BeamSearch.decode (las/beam_search.py:119-152, :297-312) for `nutt`
  * utterances at once.  Per utterance: nlive live hypotheses with raw logits [nlive,V] (raw logits
  * are the scores, las/beam_search.py:123-124), running float32 score (0 + np.float32 sums stay

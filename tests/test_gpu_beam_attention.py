@@ -146,3 +146,98 @@ def test_attention_objects_match_oracle(mode):
     assert abs(float(al[3].sum()) - 1.0) < 1e-5 and float((al[3] - 1 / 9).abs().max()) < 1e-6   # all masked -> uniform
     m = att.mask(np.array([2, 3, 1]), 3)
     assert m.tolist() == [[1, 1, 0], [1, 1, 1], [1, 0, 0]]                                      # las/layers.py:182-186
+
+
+def _lm_params(rng, V_lm, E, H, NL):
+    p = {}
+    if E > 0:
+        p["lm/embedding"] = rng.uniform(-0.5, 0.5, (V_lm, E)).astype(np.float32)
+    for l in range(NL):
+        I = (E if E > 0 else V_lm) if l == 0 else H
+        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l] = rng.uniform(-0.3, 0.3, (I + H, 4 * H)).astype(np.float32)
+        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = rng.uniform(-0.1, 0.1, 4 * H).astype(np.float32)
+    p["lm/softmax/softmax_w"] = rng.uniform(-0.5, 0.5, (H, V_lm)).astype(np.float32)
+    p["lm/softmax/softmax_b"] = rng.uniform(-0.1, 0.1, V_lm).astype(np.float32)
+    return p
+
+
+def _oracle_lm(p, E, NL):
+    from oracle import las_oracle as O
+    t = {k: torch.tensor(v) for k, v in p.items()}
+    lm = {"cells": [(t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
+                     t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l]) for l in range(NL)],
+          "softmax_w": t["lm/softmax/softmax_w"], "softmax_b": t["lm/softmax/softmax_b"]}
+    lm["embedding"] = t["lm/embedding"] if E > 0 else torch.eye(t["lm/softmax/softmax_w"].shape[1])
+    return lm
+
+
+@pytest.mark.parametrize("E", [0, 12])
+def test_char_rnnlm_step_matches_oracle(E):
+    """R1: CharRNN inference step (lang/char_rnn_model.py:54-142) vs oracle.lm_step over 3 chained steps."""
+    from las import layers as L, variables as V
+    from lang.char_rnn_model import CharRNN, create_vocab
+    from oracle import las_oracle as O
+    V_lm, H, NL, N = 28, 32, 2, 5
+    assert create_vocab()[2] == 28 and create_vocab()[0]['A'] == 2
+    rng = np.random.RandomState(3)
+    p = _lm_params(rng, V_lm, E, H, NL)
+    L.set_precision("f32")
+    st = V.reset_default_store(device="cuda"); st.load(p)
+    lm = CharRNN(False, 1, 1, V_lm, H, embedding_size=E, num_layers=NL)
+    olm = _oracle_lm(p, E, NL)
+    states = [lm.zero_state(1) for _ in range(N)]
+    ostate = [(torch.zeros(N, H), torch.zeros(N, H)) for _ in range(NL)]
+    for it in range(3):
+        ids = rng.randint(0, V_lm, N)
+        logits, states = lm.step(ids, states)
+        with torch.no_grad():
+            lo, ostate = O.lm_step(torch.tensor(ids), ostate, olm)
+        assert (logits.cpu() - lo).abs().max().item() < 1e-4
+        assert (states[2][1][1].cpu() - ostate[1][1][2]).abs().max().item() < 1e-5
+
+
+def test_beam_search_with_lm_fusion_matches_oracle():
+    """B6: shallow fusion (evident intent of las/beam_search.py:109-116): logits[:,2:] += lm_weight * lm_logits."""
+    from las import layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    from las.beam_search import BeamSearch
+    from lang.char_rnn_model import CharRNN
+    from oracle import las_oracle as O
+    from utils.tokenizer import CharEncoder
+    cell, NL = "lstm", 1
+    args = make_args(enc_units=48, num_enc_layers=2, dec_units=64, num_dec_layers=NL, embedding_size=32, attention_size=32,
+                     beam_size=4, convert_rate=0.3, apply_lm=True, lm_weight=0.5)
+    xs, _ = synthetic_batch(1, 41, 8, 30, seed=4)
+    p0 = O.init_params(args, seed=31, cell=cell)
+    p0["Speller/decode/dense/bias"][2] = 0.3
+    plm = _lm_params(np.random.RandomState(8), 28, 0, 24, 2)
+    L.set_cell(cell); L.set_precision("f32")
+    st = V.reset_default_store(device="cuda"); st.load(p0); st.load(plm)
+    las = LAS(args, Listener, Speller, CharEncoder().token_to_id)
+    lm = CharRNN(False, 1, 1, 28, 24, embedding_size=0, num_layers=2)
+    res = BeamSearch(args, las, CharEncoder().token_to_id, lm).decode(None, xs)
+    po = O.to_torch(p0); olm = _oracle_lm(plm, 0, 2)
+    with torch.no_grad():
+        x = torch.tensor(xs[0]).reshape(1, -1, 39)
+        h, el = O.pblstm_listener(x, xs[1], po, 2, cell)
+        keys = h @ po["Speller/decode/attention/dense/kernel"]
+        emb = po["embedding/embedding_matrix"]
+
+        def step_fn(prev_ids, prev_al, states):
+            N = len(prev_ids)
+            stt = [(torch.cat([s[0][0] for s in states]), torch.cat([s[0][1] for s in states]))]
+            lg, ns, al = O.speller_decode(h.expand(N, -1, -1), el.repeat(N), stt, emb[torch.tensor(prev_ids)],
+                                          torch.tensor(np.stack(prev_al), dtype=torch.float32), po, args, cell, keys.expand(N, -1, -1))
+            return lg.numpy(), [((ns[0][0][i:i + 1], ns[0][1][i:i + 1]),) for i in range(N)], al.numpy()
+
+        def lm_fn(ids, states):
+            stt = [(torch.stack([s[l][0] for s in states]), torch.stack([s[l][1] for s in states])) for l in range(2)]
+            lo, ns = O.lm_step(torch.tensor(ids), stt, olm)
+            return lo.numpy(), [tuple((ns[l][0][i], ns[l][1][i]) for l in range(2)) for i in range(len(ids))]
+        z = torch.zeros(1, args.dec_units)
+        lm0 = tuple((torch.zeros(24), torch.zeros(24)) for _ in range(2))
+        ref = O.beam_search(step_fn, ((z, z),), h.shape[1], int(xs[1][0] * args.convert_rate), 4, 1, 2,
+                            lm_fn=lm_fn, lm_init=lm0, lm_weight=0.5)
+    assert [b.token_ids for b in res] == [b.token_ids for b in ref]
+    for a, b in zip(res, ref):
+        assert float(a.log_prob) == pytest.approx(float(b.log_prob), abs=2e-3)
