@@ -466,6 +466,11 @@ class LAS:
                 L._blstm_params(sc, a.feat_dim * 3 if i == 0 else 2 * H, H, cell)
                 st.get(sc + "/dense/kernel", (2 * H if i == 0 else 4 * H, 2 * H))
                 st.get(sc + "/dense/bias", (2 * H,), init="zeros")
+        elif a.enc_type.lower() == "cnn":
+            # run the (cheap) variable creation path once on a dummy block: every shape follows from args
+            with torch.no_grad():
+                dummy = torch.zeros(1, 8, a.feat_dim, 3, device=st.device)
+                self.listener(dummy, [8], "cnn", is_training=False)
         self.speller._params()
         st.flatten()
 

@@ -182,8 +182,10 @@ def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pa
     tf.concat(rnn_out, -1) of las/layers.py:69,81 is free: both directions share one tensor)."""
     _hip.require_gpu(inputs)
     if is_training is True and dropout_rate:
-        raise NotImplementedError("DropoutWrapper(input_keep_prob<1) (las/layers.py:37-42) is not built yet; "
-                                  "run with --dropout_rate 0 as run.sh:69 does")
+        # DropoutWrapper(input_keep_prob=1-rate): a fresh Bernoulli mask on the cell INPUT at every time step,
+        # scaled by 1/keep (las/layers.py:37-42, SURVEY App. A.5).  The input projection is hoisted over all t, so
+        # the per-step masks are one mask over [B,T,I] (torch RNG: plumbing, the mask is not on the MFMA path).
+        inputs = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
     cell = _CFG["cell"]
     H = int(cell_units)
     I = inputs.shape[-1]
@@ -218,17 +220,78 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     return rnn_out, states, audiolen
 
 
-def conv2d(*a, **k):
-    raise NotImplementedError("CNN listener (reference las/layers.py:97-163) is scheduled as SURVEY 8(f) row F2")
+def _same_pad(n, k=3, s=2):
+    """TF 'SAME': out = ceil(n/s); pad_total = max((out-1)*s + k - n, 0); before = total//2, rest after (App. A.6)."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
 
 
-def bn(*a, **k):
-    raise NotImplementedError("batch norm belongs to the CNN listener (SURVEY 8(f) row F2)")
+def bn(inputs, is_training, scope="batch_normalization"):
+    """tf.layers.batch_normalization over the last axis (reference las/layers.py:114-116; momentum 0.99, eps 1e-3,
+    gamma=1, beta=0 -- SURVEY App. A.12).  Moving statistics live in the store's buffers."""
+    st = V.default_store()
+    C = inputs.shape[-1]
+    gamma = st.get(scope + "/gamma", (C,), init=lambda rng, shp: __import__("numpy").ones(shp))
+    beta = st.get(scope + "/beta", (C,), init="zeros")
+    mean = st.get_buffer(scope + "/moving_mean", (C,), 0.0)
+    var = st.get_buffer(scope + "/moving_variance", (C,), 1.0)
+    if mean.device != inputs.device:
+        mean = st.buffers[scope + "/moving_mean"] = mean.to(inputs.device)
+        var = st.buffers[scope + "/moving_variance"] = var.to(inputs.device)
+    x2 = inputs.reshape(-1, C)
+    y = torch.nn.functional.batch_norm(x2, mean, var, gamma, beta, training=bool(is_training), momentum=0.01, eps=1e-3)
+    return y.view(inputs.shape)
 
 
-def CNNLayer(*a, **k):
-    raise NotImplementedError("CNN listener (reference las/layers.py:118-163) is scheduled as SURVEY 8(f) row F2; "
-                              "use --enc_type pblstm")
+def conv2d(inputs, output_dim, k_h=3, k_w=3, d_h=2, d_w=2, stddev=1, name="conv2d", apply_bn=False, is_training=True):
+    """3x3 stride-2 SAME convolution + bias (+ BN) + ReLU on an NHWC block (reference las/layers.py:97-112).
+    Secondary encoder path: the convolution itself runs through torch/MIOpen, with TF's
+    asymmetric SAME padding applied explicitly."""
+    import numpy as np
+    st = V.default_store()
+    Cin = inputs.shape[-1]
+    w = st.get(name + "/w", (k_h, k_w, Cin, output_dim), init=lambda rng, shp: rng.randn(*shp) * stddev * 0.01)
+    b = st.get(name + "/b", (output_dim,), init=lambda rng, shp: np.full(shp, 0.01))
+    x = inputs.permute(0, 3, 1, 2)                                   # NHWC -> NCHW
+    pt, pb = _same_pad(x.shape[2], k_h, d_h)
+    pl, pr = _same_pad(x.shape[3], k_w, d_w)
+    x = torch.nn.functional.pad(x, (pl, pr, pt, pb))
+    y = torch.nn.functional.conv2d(x, w.permute(3, 2, 0, 1), b, stride=(d_h, d_w))
+    y = y.permute(0, 2, 3, 1)                                        # back to NHWC
+    if apply_bn:
+        y = bn(y, is_training, scope=name + "/batch_normalization")
+    return torch.relu(y)
+
+
+def CNNLayer(inputs, audiolen, num_enc_layers, feat_dim, cell_units, num_channel, dropout_rate, apply_bn=False,
+             is_training=False, scope="Listener"):
+    """CNN listener, reference las/layers.py:118-163: 2 x [conv 3x3 s2 (+BN) + ReLU] -> reshape ->
+    num_enc_layers x [BLSTM -> concat -> dense(enc_units) (-> BN if apply_bn) -> relu(bn(.))]  (the trailing
+    BN+ReLU is unconditional in the reference: SURVEY quirk Q4).  Returns (enc_out, enc_state, audiolen)."""
+    enc_units = int(cell_units)
+    st = V.default_store()
+    audiolen = torch.as_tensor(audiolen).to(torch.float64)
+    conv_out = inputs
+    fd = float(feat_dim)
+    for i in range(2):
+        fd = (fd + fd % 2) / 2                                       # :127-129 (float arithmetic as in the reference)
+        audiolen = (audiolen + audiolen % 2) / 2
+        conv_out = conv2d(conv_out, num_channel, name=scope + "/conv2d_%d" % i, apply_bn=apply_bn, is_training=is_training)
+    B = conv_out.shape[0]
+    enc_out = conv_out.reshape(B, -1, int(fd * num_channel))         # :139-140
+    enc_state = None
+    for i in range(num_enc_layers):
+        sc = scope + "/blstm_%d" % i
+        _, enc_state, out = _blstm_full(enc_out.contiguous(), cell_units, dropout_rate, is_training, scope=sc)
+        enc_out = dense(out, st.get(sc + "/dense/kernel", (2 * cell_units, enc_units)),
+                        st.get(sc + "/dense/bias", (enc_units,), init="zeros"))
+        if apply_bn:
+            enc_out = bn(enc_out, is_training, scope=sc + "/batch_normalization")
+            enc_out = torch.relu(bn(enc_out, is_training, scope=sc + "/batch_normalization_1"))
+        else:
+            enc_out = torch.relu(bn(enc_out, is_training, scope=sc + "/batch_normalization"))
+    return enc_out, enc_state, audiolen
 
 
 # ------------------------------------------------------------------------------------------------

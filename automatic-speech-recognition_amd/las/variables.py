@@ -22,6 +22,7 @@ class VariableStore:
     def __init__(self, device=None, seed=0):
         self.device = torch.device(device) if device is not None else None
         self.vars = {}            # name -> tensor (leaf, requires_grad)
+        self.buffers = {}         # name -> tensor (non-trainable state: batch-norm moving statistics)
         self.order = []           # creation order
         self.rng = np.random.RandomState(seed)
         self.flat = self.flat_grad = self.adam_m = self.adam_v = None
@@ -60,11 +61,21 @@ class VariableStore:
         self.order.append(name)
         return t
 
+    def get_buffer(self, name, shape, fill=0.0):
+        b = self.buffers.get(name)
+        if b is None:
+            b = torch.full(tuple(shape), float(fill), device=self.device)
+            self.buffers[name] = b
+        return b
+
     def load(self, params):
         """Install externally supplied values {name: array} (parity tests, checkpoints)."""
         for name, val in params.items():
             val = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val,
                                   dtype=torch.float32, device=self.device)
+            if "moving_" in name:                      # batch-norm statistics are buffers, not parameters
+                self.buffers[name] = val.clone()
+                continue
             if name in self.vars:
                 with torch.no_grad():
                     self.vars[name].copy_(val)
@@ -118,7 +129,8 @@ class VariableStore:
         return int(sum(v.numel() for v in self.vars.values()))
 
     def state_dict(self):
-        sd = {"params": {n: self.vars[n].detach().cpu() for n in self.order}, "global_step": self.global_step}
+        sd = {"params": {n: self.vars[n].detach().cpu() for n in self.order}, "global_step": self.global_step,
+              "buffers": {n: b.detach().cpu() for n, b in self.buffers.items()}}
         if self.flat is not None:
             sd["adam_m"] = {n: self.adam_m[self.offsets[n]:self.offsets[n] + self.vars[n].numel()].view(self.vars[n].shape).cpu()
                             for n in self.order}
@@ -128,6 +140,8 @@ class VariableStore:
 
     def load_state_dict(self, sd):
         self.load(sd["params"])
+        for n, b in sd.get("buffers", {}).items():
+            self.buffers[n] = b.to(self.device)
         self.global_step = int(sd.get("global_step", 0))
         if "adam_m" in sd:
             self.flatten()

@@ -106,3 +106,44 @@ def test_greedy_inference_matches_oracle():
         assert logits.shape == lo.shape
         assert (logits.cpu() - lo).abs().max().item() < 5e-4
         assert torch.equal(y_hat.cpu(), yo)
+
+
+@pytest.mark.parametrize("apply_bn,cell", [(False, "rnn"), (True, "lstm")])
+def test_cnn_listener_train_step_matches_oracle(apply_bn, cell):
+    """L4: the reference's default encoder (enc_type='cnn', las/layers.py:118-163) end to end."""
+    from las import layers as L
+    from las import variables as V
+    from las.las import LAS, Listener, Speller
+    from oracle import las_oracle as O
+    args = make_args(enc_type="cnn", enc_units=64, num_enc_layers=2, num_enc_channels=8, dec_units=64, num_dec_layers=1,
+                     embedding_size=32, attention_size=32, apply_bn=apply_bn, lr=1e-3)
+    xs, ys = synthetic_batch(4, 45, 8, 30, seed=3)
+    p0 = O.init_params(args, seed=13, cell=cell, enc_type="cnn")
+    po = O.to_torch(p0, requires_grad=True)
+    z = {k: torch.zeros_like(v) for k, v in po.items()}
+    loss_o, logits_o, alphas_o, g_o, newp, _, _ = O.train_step(po, z, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
+                                                                (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell)
+    L.set_cell(cell); L.set_precision("f32")
+    st = V.reset_default_store(device="cuda"); st.load(p0)
+    las = LAS(args, Listener, Speller, {})
+    loss, _, gs, logits, alphas, _, _ = las.train(xs, ys)
+    assert set(st.order) == set(p0), set(st.order) ^ set(p0)
+    assert logits.shape == logits_o.shape and alphas.shape[-1] == 12          # T 45 -> 23 -> 12
+    assert (logits.cpu() - logits_o).abs().max().item() < 1e-3
+    assert abs(float(loss) - float(loss_o)) < 1e-4
+    for n in sorted(p0):
+        go, g = g_o[n], st.vars[n].grad.cpu()
+        scale = max(go.abs().max().item(), 1e-3)
+        assert (g - go).abs().max().item() / scale < 5e-3, n
+    assert float(st.buffers["Listener/blstm_0/batch_normalization/moving_mean"].abs().max()) > 0    # UPDATE_OPS ran
+
+
+def test_dropout_changes_activations_only_in_training():
+    from las import layers as L, variables as V
+    L.set_cell("rnn"); L.set_precision("f32")
+    V.reset_default_store(device="cuda", seed=1)
+    x = torch.randn(2, 6, 10, device="cuda")
+    (f0, _), _ = L.blstm(x, 16, 0.5, False)
+    (f1, _), _ = L.blstm(x, 16, 0.5, False)
+    (f2, _), _ = L.blstm(x, 16, 0.5, True)
+    assert torch.equal(f0, f1) and not torch.allclose(f0, f2)
