@@ -32,6 +32,7 @@ struct DecDev {
     const float *Ws, *u, *emb, *Wv, *bv, *loc_w, *loc_b, *Wf;
     int *tok_in, *tok_out;
     const float* align0;
+    const float* emb_mask;
     float *logits, *alphas, *hs, *cs, *gates, *xin0;
     // backward
     const float* dHl;      // [U,B,D]   dlogits . Wv^T
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
             xrow[E + hd] = cv;
         }
     }
-    for (int i = tid; i < E; i += RNT) xrow[i] = a.emb[(size_t)tok * E + i];
+    for (int i = tid; i < E; i += RNT)
+        xrow[i] = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
     for (int i = tid; i < D; i += RNT) xrow[E + Hd + i] = L.s_state[i];
 }
 
@@ -649,14 +651,14 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
 // (fixed chunking -> deterministic); stage 2 is las_colsum over the chunk axis.
 constexpr int EMB_CHUNKS = 32;
 __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const float* dXin0, int n, int ld, int E, int V,
-                                                       float* part) {
+                                                       const float* mask, float* part) {
     const int v = blockIdx.x, ch = blockIdx.y;
     const int per = (n + EMB_CHUNKS - 1) / EMB_CHUNKS;
     const int i0 = ch * per, i1 = min(n, i0 + per);
     for (int e = threadIdx.x; e < E; e += 256) {
         float acc = 0.f;
         for (int i = i0; i < i1; ++i)
-            if (tok[i] == v) acc += dXin0[(size_t)i * ld + e];
+            if (tok[i] == v) acc += dXin0[(size_t)i * ld + e] * (mask ? mask[(size_t)i * E + e] : 1.f);
         part[((size_t)ch * V + v) * E + e] = acc;
     }
 }
@@ -724,7 +726,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.step_logits = f->step_logits; d.fb = f->forget_bias; d.seed = f->seed;
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
-    d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.logits = f->logits; d.alphas = f->alphas;
+    d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
@@ -873,7 +875,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     {
         float* epart = (float*)(base + w.embp);
         hipLaunchKernelGGL(emb_grad_kernel, dim3(V, EMB_CHUNKS), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D,
-                           E, V, epart);
+                           E, V, d.emb_mask, epart);
         LAS_LAUNCHED();
         GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
     }

@@ -70,7 +70,7 @@ def _ptr_array(tensors):
 
 
 def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
-                   keep_state0=False, align0=None):
+                   keep_state0=False, align0=None, emb_mask=None):
     for k, v in dims.items():
         setattr(fa, k, v)
     fa.step_logits = int(step_logits)
@@ -90,6 +90,7 @@ def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, b
     fa.tokens_out = tokens_out.data_ptr() if tokens_out is not None else None
     fa.logits, fa.alphas = bufs["logits"].data_ptr(), bufs["alphas"].data_ptr()
     fa.align0 = align0.data_ptr() if align0 is not None else None
+    fa.emb_mask = emb_mask.data_ptr() if emb_mask is not None else None
     fa.hs = bufs["hs"].data_ptr()
     fa.cs = bufs["cs"].data_ptr() if bufs["cs"] is not None else None
     fa.gates, fa.xin0 = bufs["gates"].data_ptr(), bufs["xin0"].data_ptr()
@@ -113,7 +114,7 @@ class _SpellerLoop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, Wh, Ws, u, emb, Wv, bv, loc_w, loc_b, Wf, cfg, enc_len_i32, tokens_in, *cell_params):
-        dims, prec, step_logits, seed = cfg
+        dims, prec, step_logits, seed, emb_mask = cfg
         dev = enc.device
         enc = enc.contiguous()
         B, Tp, Hd = enc.shape
@@ -126,21 +127,22 @@ class _SpellerLoop(torch.autograd.Function):
         bufs = _alloc_bufs(dims, dev)
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
-        keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
+        keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
+                              emb_mask=emb_mask)
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], dims["V"], dims["U"], dims["cell"])
         ws = _hip.workspace(dev, nbytes, "speller")
         fa.ws, fa.ws_bytes = ws.data_ptr(), ws.numel()
         with _hip._timed("speller_fwd[U=%d]" % dims["U"]):
             _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
         del keep
-        ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed)
+        ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask)
         ctx.mark_non_differentiable(bufs["alphas"])
         ctx.tokens_out = tokens_out
         return bufs["logits"], bufs["alphas"]
 
     @staticmethod
     def backward(ctx, dlogits, _dalphas):
-        enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed = ctx.saved
+        enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask = ctx.saved
         dev = enc.device
         B, Tp, Hd = enc.shape
         A = Wh.shape[1]
@@ -158,7 +160,8 @@ class _SpellerLoop(torch.autograd.Function):
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], V_, U, dims["cell"])
         ws = _hip.workspace(dev, nbytes, "speller")
         ba = _hip.SpellerBwdArgs()
-        keepf = _fill_fwd_args(ba.f, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed)
+        keepf = _fill_fwd_args(ba.f, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
+                               emb_mask=emb_mask)
         ba.f.ws, ba.f.ws_bytes = ws.data_ptr(), ws.numel()
         ba.dlogits = dlogits.data_ptr()
         ba.d_enc, ba.d_keys = d_enc.data_ptr(), d_keys.data_ptr()
@@ -256,8 +259,6 @@ class Speller:
             raise NotImplementedError("CTC head (las/las.py:75-77,335-349): README 'not yet fully tested', out of scope (SURVEY T5)")
         if a.add_vn:
             raise NotImplementedError("variational noise (las/las.py:164-166) is not built yet")
-        if is_training and a.dropout_rate:
-            raise NotImplementedError("embedding dropout (las/las.py:107-108) is not built yet; use --dropout_rate 0")
         dev = enc_out.device
         B, Tp, _ = enc_out.shape
         U = int(dec_steps)
@@ -285,7 +286,14 @@ class Speller:
                         tokens_in[idx] = -2
             step_logits = bool((tokens_in < 0).any().item()) if not coins[:max(U - 1, 0)].all() else False
         P = self._params()
-        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, 977 + st.global_step)
+        emb_mask = None
+        if is_training and a.dropout_rate:
+            # tf.layers.dropout on the embedded input token of every step (las/las.py:107-108); step 0's SOS
+            # embedding is looked up before the loop (las/las.py:81) and is not dropped
+            keep = 1.0 - float(a.dropout_rate)
+            emb_mask = (torch.rand(U, B, a.embedding_size, device=dev) < keep).to(torch.float32) / keep
+            emb_mask[0] = 1.0
+        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, 977 + st.global_step, emb_mask)
         cp = list(P["cellW"]) + list(P["cellb"])
         logits_tm, alphas_tm = _SpellerLoop.apply(enc_out, P["Wh"], P["Ws"], P["u"], P["emb"], P["Wv"], P["bv"],
                                                   P.get("loc_w"), P.get("loc_b"), P.get("Wf"), cfg, enc_len_i32,

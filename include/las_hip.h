@@ -128,6 +128,8 @@ typedef struct {
     int* tokens_in; int* tokens_out;
     float *logits, *alphas;
     const float* align0;           /* optional [B,Tp]: previous alignment entering step 0 (else zeros) */
+    const float* emb_mask;         /* optional [U,B,E]: inverted-dropout mask on the embedded input token
+                                      (tf.layers.dropout, las/las.py:107-108), already scaled by 1/keep */
     float *hs, *cs, *gates, *xin0;
     void* ws; size_t ws_bytes;
 } las_speller_fwd_args;

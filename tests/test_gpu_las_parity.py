@@ -147,3 +147,21 @@ def test_dropout_changes_activations_only_in_training():
     (f1, _), _ = L.blstm(x, 16, 0.5, False)
     (f2, _), _ = L.blstm(x, 16, 0.5, True)
     assert torch.equal(f0, f1) and not torch.allclose(f0, f2)
+
+
+def test_training_with_dropout_runs_and_is_masked():
+    """dropout_rate > 0 (the reference default 0.5): BLSTM input dropout + embedding dropout are active in training,
+    the step stays finite and two steps with different masks differ."""
+    from las import layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    args = make_args(enc_units=64, num_enc_layers=1, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32,
+                     dropout_rate=0.3, lr=0.0)
+    xs, ys = synthetic_batch(4, 30, 8, 30, seed=2)
+    L.set_cell("lstm"); L.set_precision("f32")
+    V.reset_default_store(device="cuda", seed=5)
+    las = LAS(args, Listener, Speller, {})
+    l1 = float(las.train(xs, ys)[0]); l2 = float(las.train(xs, ys)[0])
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2          # lr = 0: only the masks changed
+    logits, _ = las.inference(xs)
+    logits2, _ = las.inference(xs)
+    assert torch.equal(logits, logits2)                              # no dropout at inference
