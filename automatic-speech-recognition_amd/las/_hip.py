@@ -142,12 +142,56 @@ def workspace(dev, nbytes, tag="default"):
 GEMM_WS_BYTES = 256 << 20
 
 
+# ---- side stream for work that is off the dependency chain (weight gradients during the BPTT sweeps) ----
+_side_stream = None
+_side_used = False
+_on_side = False
+
+
+def side_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+class on_side_stream:
+    """Run the enclosed launches on the side stream, after everything already enqueued on the current stream.
+    Tensors touched inside must be kept alive by the caller (record_stream)."""
+
+    def __enter__(self):
+        global _side_used, _on_side
+        self.ctx = torch.cuda.stream(side_stream())
+        side_stream().wait_stream(torch.cuda.current_stream())
+        self.ctx.__enter__()
+        _side_used = True
+        _on_side = True
+        return self
+
+    def __exit__(self, *exc):
+        global _on_side
+        _on_side = False
+        return self.ctx.__exit__(*exc)
+
+
+def join_side_stream():
+    """Make the current stream wait for all side-stream work (call before the gradients are consumed)."""
+    global _side_used
+    if _side_used:
+        torch.cuda.current_stream().wait_stream(side_stream())
+        _side_used = False
+
+
+def _tag(t):
+    return t + "_side" if _on_side else t
+
+
 def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, batch=1, strideA=0, strideB=0, strideC=0,
          mask_period=0, mask_skip=0, a_off=0, b_off=0, c_off=0):
     """C = act(alpha * op(A).op(B) + beta*C + bias).  A,B,C are fp32 tensors; *_off are element offsets."""
     require_gpu(A, B, C, bias)
-    ws = workspace(C.device, GEMM_WS_BYTES, "gemm")
+    ws = workspace(C.device, GEMM_WS_BYTES, _tag("gemm"))
     rc = lib().las_gemm(prec, int(transA), int(transB), M, N, K, alpha,
                         c_void_p(A.data_ptr() + 4 * a_off), lda, strideA,
                         c_void_p(B.data_ptr() + 4 * b_off), ldb, strideB, beta,
@@ -159,7 +203,7 @@ def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=
 def colsum(X, rows, cols, ldx, out, beta=0.0, x_off=0):
     require_gpu(X, out)
     nb = lib().las_colsum_workspace_bytes(cols)
-    ws = workspace(X.device, nb, "colsum")
+    ws = workspace(X.device, nb, _tag("colsum"))
     check(lib().las_colsum(c_void_p(X.data_ptr() + 4 * x_off), rows, cols, ldx, beta, p(out), p(ws), ws.numel(),
                            stream()), "las_colsum")
 

@@ -523,6 +523,7 @@ class LAS:
         st.flatten()
         st.zero_grad()
         loss.backward()
+        _hip.join_side_stream()                       # weight gradients accumulated on the side stream
         if self.dp is not None:
             self.dp.all_reduce_(st.flat_grad)                                             # one flat bucket (C1)
             loss_val = self.dp.all_reduce_scalar(loss.detach())

@@ -58,6 +58,7 @@ class _Dense(torch.autograd.Function):
         _hip.gemm(prec, x2d, W, y, False, False, M, N, K, K, N, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
         ctx.save_for_backward(x2d, W, y)
         ctx.act, ctx.prec, ctx.has_b = act, prec, b is not None
+        ctx.params = (_PARAMS.get("W"), _PARAMS.get("b"))
         return y
 
     @staticmethod
@@ -71,17 +72,38 @@ class _Dense(torch.autograd.Function):
             _hip.tanh_bwd(y, N, dy, N, dpre, N, M, N)
         else:
             dpre = dy
+        dx = None
+        if ctx.needs_input_grad[0]:                    # on the dependency chain: main stream, first
+            dx = torch.empty_like(x2d)
+            _hip.gemm(ctx.prec, dpre, W, dx, False, True, M, K, N, N, N, K)
+        Wp, bp = ctx.params
+        if _direct_ok(Wp) and (bp is None or _direct_ok(bp)):
+            # off the chain: accumulate straight into the flat gradient bucket on the side stream, overlapping
+            # with the next layer's BPTT sweep (which occupies only a few dozen CUs)
+            with _hip.on_side_stream():
+                for t in (x2d, dpre):
+                    t.record_stream(_hip.side_stream())
+                _hip.gemm(ctx.prec, x2d, dpre, Wp.grad, True, False, K, N, M, K, N, N, beta=1.0)
+                if bp is not None:
+                    _hip.colsum(dpre, M, N, N, bp.grad, beta=1.0)
+            return dx, None, None, None, None
         dW = torch.empty_like(W)
         _hip.gemm(ctx.prec, x2d, dpre, dW, True, False, K, N, M, K, N, N)
         db = None
         if ctx.has_b:
             db = torch.empty(N, device=dy.device, dtype=torch.float32)
             _hip.colsum(dpre, M, N, N, db)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x2d)
-            _hip.gemm(ctx.prec, dpre, W, dx, False, True, M, K, N, N, N, K)
         return dx, dW, db, None, None
+
+
+_PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
+DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
+
+
+def _direct_ok(p):
+    """True when p is a flattened leaf parameter whose .grad is a view of the flat gradient bucket."""
+    return (DIRECT_GRADS and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
+            and V.default_store().flat_grad is not None and p.grad.is_contiguous())
 
 
 def dense(x, W, b=None, tanh=False):
@@ -91,7 +113,9 @@ def dense(x, W, b=None, tanh=False):
     x2d = x.reshape(-1, shp[-1])
     if not x2d.is_contiguous():
         x2d = x2d.contiguous()
+    _PARAMS["W"], _PARAMS["b"] = W, b
     y = _Dense.apply(x2d, W, b, bool(tanh), _prec())
+    _PARAMS.clear()
     return y.view(*shp[:-1], W.shape[1])
 
 
@@ -116,6 +140,7 @@ class _BLSTM(torch.autograd.Function):
                          1.0, wf_off=I * GH, wb_off=I * GH)
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst)
         ctx.cfg = (cell, prec, H, Tp)
+        ctx.params = _PARAMS.get("blstm")
         return out
 
     @staticmethod
@@ -132,6 +157,29 @@ class _BLSTM(torch.autograd.Function):
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I * GH, wb_off=I * GH)
         grads = []
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if dx is not None:                             # on the dependency chain: main stream, first
+            for d, k in enumerate((kfw, kbw)):
+                _hip.gemm(prec, gates, k, dx, False, True, B * T, I, GH, 2 * GH, GH, I, beta=1.0 if d else 0.0, a_off=d * GH)
+        P4 = ctx.params
+        if P4 is not None and all(_direct_ok(p) for p in P4):
+            # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
+            with _hip.on_side_stream():
+                side = _hip.side_stream()
+                for t in (x, gates, out):
+                    t.record_stream(side)
+                part = torch.empty(B, H, GH, device=dev) if T > 1 else None
+                for d in range(2):
+                    kp, bp = P4[2 * d], P4[2 * d + 1]
+                    gk = kp.grad                       # [(I+H), GH] view of the flat bucket
+                    _hip.gemm(prec, x, gates, gk, True, False, I, GH, B * T, I, 2 * GH, GH, beta=1.0, b_off=d * GH)
+                    if T > 1:
+                        a_off = d * H + (0 if d == 0 else 2 * H)
+                        b_off = d * GH + (2 * GH if d == 0 else 0)
+                        _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
+                                  strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
+                        _hip.colsum(part, B, H * GH, H * GH, gk[I:].reshape(-1), beta=1.0)
+                    _hip.colsum(gates, B * T, GH, 2 * GH, bp.grad, beta=1.0, x_off=d * GH)
+            return (dx, None, None, None, None, None, None, None, None)
         part = torch.empty(B, H, GH, device=dev) if T > 1 else None
         for d, k in enumerate((kfw, kbw)):
             dk = torch.empty_like(k)
@@ -151,9 +199,6 @@ class _BLSTM(torch.autograd.Function):
                 dk[I:] = 0
             db = torch.empty(GH, device=dev)
             _hip.colsum(gates, B * T, GH, 2 * GH, db, x_off=d * GH)
-            if dx is not None:
-                _hip.gemm(prec, gates, k, dx, False, True, B * T, I, GH, 2 * GH, GH, I, beta=1.0 if d else 0.0,
-                          a_off=d * GH)
             grads += [dk, db]
         return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None)
 
@@ -190,7 +235,9 @@ def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pa
     H = int(cell_units)
     I = inputs.shape[-1]
     kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
+    _PARAMS["blstm"] = (kfw, bfw, kbw, bbw)
     out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even)
+    _PARAMS.clear()
     T = inputs.shape[1]
     fw, bw = out[..., :H], out[..., H:]
     states = (fw[:, T - 1], bw[:, 0])
