@@ -181,8 +181,19 @@ def main():
                     ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_bf16_kernel")
             else:
                 kname = ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_f32_kernel"
+            # HBM traffic of that kernel from a recorded rocprofv3 --pmc pass of this same command (FETCH_SIZE and
+            # WRITE_SIZE in separate passes; tools/pmc_summary.py); null when no recording matches the configuration
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_final_pmc.json")))
+                if a.cell == "lstm" and a.dtype == "bf16" and B == 48 and T == 1274:
+                    key = [k for k in pmc if k.startswith("rnn_seq_bwd" if bwd else "rnn_seq_fwd")]
+                    if key:
+                        traffic = pmc[key[0]]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "launches_per_step": f["n"] // a.steps,
                     "algorithmic_bytes_per_launch": f["bytes"] // f["n"],
                     "avg_launch_ms": round(f["ms"] / f["n"], 4),
