@@ -32,18 +32,36 @@ def main():
     bs = BeamSearch(args, las, token_to_id, None)
     ckpt = bs.restore_las(None, args.save_dir, args.restore_epoch)
     logging.info("LAS restored: {}".format(ckpt))
-    if not args.synthetic:
-        raise SystemExit("feature files {split}-feats.pkl are produced by the reference's preprocess.py (SURVEY F4); run with --synthetic True")
-    from data import SyntheticBatches
-    (audio, audiolen), (y, tokenlen) = next(SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed + 2, batch_scale=0.1, max_frames=700))
+    if args.synthetic:
+        from data import SyntheticBatches
+        (audio, audiolen), (y, tokenlen) = next(SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed + 2, batch_scale=0.1, max_frames=700))
+        dev_feats = [audio[i, :audiolen[i]] for i in range(len(audio))]
+        dev_tokens = list(y)
+    elif os.path.exists(os.path.join(args.feat_dir, "{}-feats.pkl".format(args.split))):
+        import joblib                                              # decode.py:80-85: the preprocess.py dumps
+        dev_feats = joblib.load(args.feat_dir + "/{}-feats.pkl".format(args.split))
+        dev_tokens = np.load(args.feat_dir + "/{}-{}s.npy".format(args.split, args.unit), allow_pickle=True)
+        tokenlen = np.load(args.feat_dir + "/{}-{}len.npy".format(args.split, args.unit), allow_pickle=True)
+    else:
+        # same utterances from the packed split (create_tfrecord.py writes {split}-1.tfrecord)
+        from tfrecord_data_loader import data_parser, tf_record_iterator
+        path = os.path.join(args.tfrecord_dir or "data/tfrecord_{}_bpe_5k".format(args.feat_type), "{}-1.tfrecord".format(args.split))
+        if not os.path.exists(path):
+            raise Exception("Run preprocess.py first")
+        recs = [data_parser(r) for r in tf_record_iterator(path)]
+        dev_feats = [r[0][0] for r in recs]
+        dev_tokens = [r[1][0] for r in recs]
+        tokenlen = np.asarray([r[1][1] for r in recs])
     order = np.argsort(tokenlen)                                   # decode.py:122-124
     error, N, count = 0, 0, 0
     logging.info("Decoding...")
-    for i in order[: (8 if args.max_steps < 0 else args.max_steps)]:
-        xs = (audio[i:i + 1, :audiolen[i]], audiolen[i:i + 1])
+    limit = args.max_steps if args.max_steps >= 0 else (8 if args.synthetic else len(order))
+    for i in order[:limit]:
+        audio = np.asarray(dev_feats[i], np.float32)
+        xs = (audio[None], np.asarray([audio.shape[0]], np.int32))
         beam_states = bs.decode(None, xs)
         hyp = convert_idx_to_string(beam_states[-1].token_ids[1:], id_to_token, args.unit)
-        ref = convert_idx_to_string(y[i], id_to_token, args.unit)
+        ref = convert_idx_to_string(dev_tokens[i], id_to_token, args.unit)
         dist, n = edit_distance(ref.split(" "), hyp.split(" "))
         error += dist
         N += n

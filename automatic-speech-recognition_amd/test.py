@@ -37,13 +37,23 @@ def main():
     las.build_variables()
     ckpt = checkpoint.restore(args.save_dir, args.restore_epoch)
     logging.info("restored: {}".format(ckpt))
-    if not args.synthetic:
-        raise SystemExit("TFRecord input is SURVEY 8(f) row F1; run with --synthetic True")
-    from data import SyntheticBatches
-    batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed + 1, batch_scale=0.25, max_frames=700)
+    if args.synthetic:
+        from data import SyntheticBatches
+        src = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed + 1, batch_scale=0.25, max_frames=700)
+        batches = (next(src) for _ in range(4 if args.max_steps < 0 else args.max_steps))
+    else:
+        # test.py:47-61: one pass over data/tfrecord_{feat_type}_bpe_5k/dev-1.tfrecord
+        from tfrecord_data_loader import data_parser, get_num_records, tfrecord_iterator
+        eval_filenames = os.path.join(args.tfrecord_dir or "data/tfrecord_{}_bpe_5k".format(args.feat_type), "dev-1.tfrecord")
+        if not os.path.exists(eval_filenames):
+            raise Exception("Run preprocess.py, create_tfrecord.py first")
+        batches, _, _ = tfrecord_iterator(eval_filenames, data_parser, args.feat_dim, is_training=False)
+        logging.info("Total num eval records: {}".format(get_num_records([eval_filenames])))
+        if args.max_steps >= 0:
+            import itertools
+            batches = itertools.islice(batches, args.max_steps)
     output_id, gt_id = [], []
-    for _ in range(4 if args.max_steps < 0 else args.max_steps):
-        xs, ys = next(batches)
+    for xs, ys in batches:
         _, y_hat = las.inference(xs)
         output_id += y_hat.cpu().numpy().tolist()
         gt_id += ys[0].tolist()

@@ -58,14 +58,23 @@ def main():
     if dp is not None:
         dp.broadcast_(st.flat)
 
-    if not args.synthetic:
-        raise SystemExit("TFRecord input (reference tfrecord_data_loader.py) is SURVEY 8(f) row F1; run with --synthetic True")
-    from data import SyntheticBatches
-    batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
+    num_train_batches = 2619                                      # train.py:108
+    if args.synthetic:
+        from data import SyntheticBatches
+        batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
+    else:
+        # train.py:45-55: data/tfrecord_{feat_type}_bpe_5k/train-*.tfrecord; every rank reads its own file subset
+        import glob
+        from tfrecord_data_loader import data_parser, tfrecord_iterator
+        pattern = os.path.join(args.tfrecord_dir or "data/tfrecord_{}_bpe_5k".format(args.feat_type), "train-*.tfrecord")
+        files = sorted(glob.glob(pattern))
+        if not files:
+            raise Exception("Run preprocess.py, create_tfrecord.py first")
+        files = files[rank::world] if len(files) >= world else files
+        batches, _, _ = tfrecord_iterator(files, data_parser, args.feat_dim, seed=args.seed + rank)
 
     if rank == 0:
         logging.info("Total weights: {}".format(st.num_params()))
-    num_train_batches = 2619                                      # train.py:108
     training_steps = num_train_batches * args.epoch if args.max_steps < 0 else args.max_steps
     if rank == 0:
         logging.info("Total num train batches: {}".format(num_train_batches))
