@@ -50,25 +50,57 @@ def sweep_bytes(B, T, H, G, bwd):
     return gates * 2 + (2 * h if G == 4 else h) + h + w
 
 
-def cpu_baseline(cell, seconds_budget=30.0):
-    """Reference-equivalent CPU path (restated; TensorFlow 1.13 is not installable offline)."""
+def usable_cores(cap=16):
+    """Host cores this process may really use: scheduler affinity, cut by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_child(cell):
+    """Runs in a CPU-only child process: one oracle train step on a bounded sample of the bench workload."""
     from helpers import synthetic_batch
     from oracle import las_oracle as O
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     args = bench_args(cell)
-    Bs, T = 4, 1274
-    xs, ys = synthetic_batch(Bs, T, 256, args.vocab_size, seed=0)
-    p0 = O.init_params(args, seed=0, cell=cell)
-    po = O.to_torch(p0, requires_grad=True)
-    z1 = {k: torch.zeros_like(v) for k, v in po.items()}
-    z2 = {k: torch.zeros_like(v) for k, v in po.items()}
-    t0 = time.time()
-    O.train_step(po, z1, z2, 0, (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, hoist=False)
-    dt = time.time() - t0
-    return {"value": Bs / dt, "unit": "utterances/s", "cores": ncores, "kind": "port",
-            "sample": "1 train step of the oracle (reference graph as written, torch-CPU fp32, %s cells) on %d "
-                      "utterances of the same T=1274 workload: %.1f s" % (cell, Bs, dt)}
+    T = 1274
+
+    def one(Bs):
+        xs, ys = synthetic_batch(Bs, T, 256, args.vocab_size, seed=0)
+        po = O.to_torch(O.init_params(args, seed=0, cell=cell), requires_grad=True)
+        z1 = {k: torch.zeros_like(v) for k, v in po.items()}
+        z2 = {k: torch.zeros_like(v) for k, v in po.items()}
+        t0 = time.time()
+        O.train_step(po, z1, z2, 0, (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, hoist=False)
+        return time.time() - t0
+
+    Bs, dt = 1, one(1)
+    if dt < 10.0:                                   # widen the sample while it stays within ~30 s of CPU work
+        Bs, dt = 4, one(4)
+    print(json.dumps({"value": round(Bs / dt, 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
+                      "sample": "1 train step of the oracle (reference graph as written: un-hoisted key projection, "
+                                "torch-CPU fp32, %s cells) on %d utterance(s) of the same T=1274 workload: %.1f s"
+                                % (cell, Bs, dt)}))
+
+
+def cpu_baseline(cell, timeout=240.0):
+    """Reference-equivalent CPU path (restated; TensorFlow 1.13 is not installable offline), timed in a child
+    process that never touches the GPU, with a hard time limit so the bench line always appears."""
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cell", cell],
+                           capture_output=True, text=True, timeout=timeout, env=env)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                          # timeout / parse failure: say so instead of hanging the bench
+        return {"value": None, "unit": "utterances/s", "cores": usable_cores(), "kind": "port",
+                "sample": "oracle train step did not finish within %.0f s (%s)" % (timeout, type(e).__name__)}
 
 
 def main():
@@ -81,7 +113,11 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--frames", type=int, default=1274)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_only:
+        cpu_baseline_child(a.cell)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
