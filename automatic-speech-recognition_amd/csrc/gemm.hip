@@ -653,79 +653,69 @@ int las_skinny_pack(const float* W, int ldw, int K, int N, int transposed, void*
 }
 
 bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
-    return M >= 1 && M <= 64 && (K % 8) == 0 && (lda % 4) == 0 && (((uintptr_t)A) & 15) == 0 && N >= 1;
+    return M >= 1 && M <= 1024 && (K % 8) == 0 && (lda % 4) == 0 && (((uintptr_t)A) & 15) == 0 && N >= 1;
 }
 
-// 8 waves split K; every wave has all of its loads (<= UN k-steps) in flight at once, then MFMAs, then an LDS
-// reduction of the 8 partial tiles.  Latency of one L2 round trip instead of K/32 dependent ones.
-template <int MT>
-__global__ __launch_bounds__(512, 1) void skinny_gemm_kernel(const float* __restrict__ A, int lda, int M, int K,
+// Grid (column tile, 16-row tile): every workgroup reads ONE 16-row slab of A (fp32, or bf16 written by the producer
+// kernel) and one column tile of fragments -- 37+37 KB at K=1152 instead of 221+37 KB for the all-rows form above.
+// 8 waves split K with every load in flight at once, then an LDS reduction of the 8 partial tiles.
+template <bool ABF>
+__global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
                                                              float* __restrict__ C, int ldc, const float* __restrict__ bias) {
     constexpr int NW = 8;
-    __shared__ float red[NW][MT][64][4];
+    __shared__ float red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int ct = blockIdx.x;
+    const int ct = blockIdx.x, mt = blockIdx.y;
     const int KSW = (KS + NW - 1) / NW;
     const int ks0 = w * KSW, ks1 = min(KS, ks0 + KSW);
     const u16x8_t* bp = Bp + (size_t)ct * KS * 64 + lane;
-    const float* ap[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 16 + c;
-        if (row >= M) row = M - 1;                 // padded rows compute garbage that is never stored
-        ap[mt] = A + (long long)row * lda + g * 8;
-    }
-    f32x4_t acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    constexpr int UN = MT <= 3 ? 8 : 6;            // k-steps whose loads are all in flight together
+    int row = mt * 16 + c;
+    if (row >= M) row = M - 1;                     // padded rows compute garbage that is never stored
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;
     for (int ks = ks0; ks < ks1; ks += UN) {
-        u16x8_t bv[UN];
-        float4 a0[UN][MT], a1[UN][MT];
+        u16x8_t bv[UN], av[UN];
+        float4 a0[UN], a1[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int kk = ks + u;
             const bool on = kk < ks1;
             bv[u] = on ? bp[(size_t)kk * 64] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
             const bool ka = on && (kk * 32 + g * 8 + 8 <= K);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (ka) {
-                    a0[u][mt] = *reinterpret_cast<const float4*>(ap[mt] + kk * 32);
-                    a1[u][mt] = *reinterpret_cast<const float4*>(ap[mt] + kk * 32 + 4);
-                } else {
-                    a0[u][mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    a1[u][mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            if (ABF) {
+                const unsigned short* ap = (const unsigned short*)Av + (long long)row * lda + g * 8;
+                av[u] = ka ? *reinterpret_cast<const u16x8_t*>(ap + kk * 32) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            } else {
+                const float* ap = (const float*)Av + (long long)row * lda + g * 8;
+                a0[u] = ka ? *reinterpret_cast<const float4*>(ap + kk * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a1[u] = ka ? *reinterpret_cast<const float4*>(ap + kk * 32 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+        for (int u = 0; u < UN; ++u) {
+            if (!ABF) {
                 uint4 pk;
-                pk.x = f2bf2(a0[u][mt].x, a0[u][mt].y); pk.y = f2bf2(a0[u][mt].z, a0[u][mt].w);
-                pk.z = f2bf2(a1[u][mt].x, a1[u][mt].y); pk.w = f2bf2(a1[u][mt].z, a1[u][mt].w);
-                acc[mt] = mfma_bf16_16x16x32(__builtin_bit_cast(u16x8_t, pk), bv[u], acc[mt]);
+                pk.x = f2bf2(a0[u].x, a0[u].y); pk.y = f2bf2(a0[u].z, a0[u].w);
+                pk.z = f2bf2(a1[u].x, a1[u].y); pk.w = f2bf2(a1[u].z, a1[u].w);
+                av[u] = __builtin_bit_cast(u16x8_t, pk);
             }
+            acc = mfma_bf16_16x16x32(av[u], bv[u], acc);
+        }
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][mt][lane][r] = acc[mt][r];
+    for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
     __syncthreads();
-    for (int idx = tid; idx < MT * 256; idx += 512) {
-        const int mt = idx >> 8, r16 = (idx >> 4) & 15, c16 = idx & 15;
+    if (tid < 256) {
+        const int r16 = tid >> 4, c16 = tid & 15;
         const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
-        const int row = mt * 16 + r16, col = ct * 16 + c16;
-        if (row < M && col < N) {
+        const int orow = mt * 16 + r16, col = ct * 16 + c16;
+        if (orow < M && col < N) {
             float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) v += red[ww][mt][l2][reg];
+            for (int ww = 0; ww < NW; ++ww) v += red[ww][l2][reg];
             if (bias) v += bias[col];
-            C[(long long)row * ldc + col] = v;
+            C[(long long)orow * ldc + col] = v;
         }
     }
 }
@@ -733,13 +723,18 @@ __global__ __launch_bounds__(512, 1) void skinny_gemm_kernel(const float* __rest
 int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
                     hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
-    const u16x8_t* Bp = reinterpret_cast<const u16x8_t*>(packed);
-    switch (MT) {
-        case 1: hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        case 2: hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        case 3: hipLaunchKernelGGL(skinny_gemm_kernel<3>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-        default: hipLaunchKernelGGL(skinny_gemm_kernel<4>, dim3(nct), dim3(512), 0, st, A, lda, M, K, Bp, KS, N, C, ldc, bias); break;
-    }
+    hipLaunchKernelGGL(skinny_rows_kernel<false>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+// A already rounded to bf16 by its producer (lda in elements, multiple of 8; A 16-byte aligned)
+int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
+                         const float* bias, hipStream_t st) {
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    hipLaunchKernelGGL(skinny_rows_kernel<true>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias);
     LAS_LAUNCHED();
     return 0;
 }

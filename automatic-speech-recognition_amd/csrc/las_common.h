@@ -100,4 +100,6 @@ size_t las_skinny_pack_bytes(int K, int N);
 int las_skinny_pack(const float* W, int ldw, int K, int N, int transposed, void* packed, hipStream_t st);
 int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
                     const float* bias, hipStream_t st);
+int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
+                         const float* bias, hipStream_t st);
 bool las_skinny_ok(int M, int K, int N, int lda, const void* A);

@@ -34,6 +34,8 @@ struct DecDev {
     const float* align0;
     const float* emb_mask;
     float *logits, *alphas, *hs, *cs, *gates, *xin0;
+    unsigned short* xbf;   // [B,I0D]  bf16 copy of the current step's cell input row (A operand of the skinny product)
+    unsigned short* dgbf;  // [B,G*D]  bf16 copy of the current step's layer-0 gate gradient
     // backward
     const float* dHl;      // [U,B,D]   dlogits . Wv^T
     float *dH, *dC;        // [NL,B,D]
@@ -309,11 +311,20 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
 #pragma unroll
             for (int hh = 0; hh < RNH; ++hh) cv += L.ctxp[hh * Hd + hd];
             xrow[E + hd] = cv;
+            if (a.xbf) a.xbf[(size_t)b * I0D + E + hd] = f2bf(cv);
         }
     }
-    for (int i = tid; i < E; i += RNT)
-        xrow[i] = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
-    for (int i = tid; i < D; i += RNT) xrow[E + Hd + i] = L.s_state[i];
+    unsigned short* xb = a.xbf ? a.xbf + (size_t)b * I0D : nullptr;
+    for (int i = tid; i < E; i += RNT) {
+        const float v = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+        xrow[i] = v;
+        if (xb) xb[i] = f2bf(v);
+    }
+    for (int i = tid; i < D; i += RNT) {
+        const float v = L.s_state[i];
+        xrow[E + Hd + i] = v;
+        if (xb) xb[E + Hd + i] = f2bf(v);
+    }
 }
 
 // gate nonlinearity of a non-top layer (multi-layer Speller only)
@@ -353,6 +364,7 @@ __device__ __forceinline__ void cell_bwd_row(const DecDev& a, int layer, int t, 
     const float* dHr = a.dH + ((size_t)layer * B + b) * D;
     float* dCr = a.dC + ((size_t)layer * B + b) * D;
     const float* ex = extra + (size_t)b * extra_ld;
+    unsigned short* gb = (layer == 0 && a.dgbf) ? a.dgbf + (size_t)b * GD : nullptr;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         const float dh = dHr[d] + ex[d];
         if (CELL == LAS_CELL_LSTM) {
@@ -362,13 +374,15 @@ __device__ __forceinline__ void cell_bwd_row(const DecDev& a, int layer, int t, 
             const float tc = tanhx<FAST>(c);
             const float dc = dCr[d] + dh * go * (1.f - tc * tc);
             dCr[d] = dc * gf;
-            gp[d] = dc * gj * gi * (1.f - gi);
-            gp[D + d] = dc * gi * (1.f - gj * gj);
-            gp[2 * D + d] = dc * cp * gf * (1.f - gf);
-            gp[3 * D + d] = dh * tc * go * (1.f - go);
+            const float di = dc * gj * gi * (1.f - gi), dj = dc * gi * (1.f - gj * gj);
+            const float df = dc * cp * gf * (1.f - gf), dO = dh * tc * go * (1.f - go);
+            gp[d] = di; gp[D + d] = dj; gp[2 * D + d] = df; gp[3 * D + d] = dO;
+            if (gb) { gb[d] = f2bf(di); gb[D + d] = f2bf(dj); gb[2 * D + d] = f2bf(df); gb[3 * D + d] = f2bf(dO); }
         } else {
             const float h = a.hs[(((size_t)layer * (U + 1) + t + 1) * B + b) * D + d];
-            gp[d] = dh * (1.f - h * h);
+            const float dp = dh * (1.f - h * h);
+            gp[d] = dp;
+            if (gb) gb[d] = f2bf(dp);
         }
     }
 }
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, xbf, dgbf, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -677,6 +691,8 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     const size_t I0D = (size_t)E + Hd + D;
     w.packF = o;  o += align256(las_skinny_pack_bytes((int)I0D, G * D));      // W0 fragments (step product)
     w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
+    w.xbf = o;    o += align256((size_t)B * I0D * 2);
+    w.dgbf = o;   o += align256((size_t)B * G * D * 2);
     w.embp = o;   o += align256((size_t)EMB_CHUNKS * V * E * f);
     w.dHl = o;    o += align256((size_t)U * B * D * f);
     w.dH = o;     o += align256((size_t)NL * B * D * f);
@@ -728,6 +744,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
+    d.xbf = nullptr; d.dgbf = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
     for (int l = 0; l < LAS_MAX_NL; ++l) { d.rec[l] = nullptr; d.recLd[l] = 0; d.recOff[l] = 0; }
@@ -737,7 +754,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
 #define GEMM_OK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
 template <int CELL, bool FAST>
-static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipStream_t st) {
+static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t st) {
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     const int B = d.B, D = d.D, NL = d.NL, U = d.U, E = d.E, Hd = d.Hd, V = d.V;
     const int GD = G * D, I0D = E + Hd + D;
@@ -750,8 +767,9 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipS
     // per-step cell product: with bf16 arithmetic the weights are packed once into MFMA fragments and every
     // step runs the skinny-M kernel (M = batch rows); fp32 mode keeps the generic exact path
     const BwdWs wl_ = bwd_layout(B, d.Tp, Hd, d.A, D, NL, E, V, U, G, d.Kc, d.C);
-    const bool skinny = FAST && f->ws && f->ws_bytes >= wl_.packB && las_skinny_ok(B, I0D, GD, I0D, d.xin0);
+    const bool skinny = FAST && f->ws && f->ws_bytes >= wl_.embp && (I0D % 8) == 0 && las_skinny_ok(B, I0D, GD, I0D, d.xin0);
     void* packF = skinny ? (char*)f->ws + wl_.packF : nullptr;
+    if (skinny) d.xbf = (unsigned short*)((char*)f->ws + wl_.xbf);
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     for (int t = 0; t <= U; ++t) {
         if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);
@@ -759,8 +777,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, const DecDev& d, hipS
         LAS_LAUNCHED();
         if (t == U) break;
         if (skinny) {
-            GEMM_OK(las_skinny_gemm(d.xin0 + (size_t)t * B * I0D, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD,
-                                    f->cellb[0], st));
+            GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD, f->cellb[0], st));
         } else {
             GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, I0D, 1.f, d.xin0 + (size_t)t * B * I0D, I0D, 0, f->cellW[0], GD, 0, 0.f,
                              d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
@@ -813,8 +830,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     const size_t lds = row_lds_bytes(d, true);
     LAS_ARG(lds <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
 
-    const bool skinny = FAST && las_skinny_ok(B, GD, I0D, GD, d.gates);
+    const bool skinny = FAST && (GD % 8) == 0 && las_skinny_ok(B, GD, I0D, GD, d.gates);
     void* packB = base + w.packB;
+    if (skinny) d.dgbf = (unsigned short*)(base + w.dgbf);
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
@@ -838,7 +856,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
         for (int l = TOP; l >= 0; --l) {
             const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
             if (l == 0 && skinny) {
-                GEMM_OK(las_skinny_gemm(dG, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, st));
+                GEMM_OK(las_skinny_gemm_bf16(d.dgbf, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, st));
             } else if (l == 0) {
                 GEMM_OK(las_gemm(prec, 0, 1, B, I0D, GD, 1.f, dG, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0 + (size_t)t * B * I0D,
                                  I0D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
