@@ -91,6 +91,34 @@ template <int NT> __device__ __forceinline__ float block_max(float v, float* red
     return s;
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain vmcnt, so global loads
+// issued earlier (prefetch) stay in flight across it.  Cross-wave data must travel through LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int NT> __device__ __forceinline__ float block_sum_lds(float v, float* red) {
+    v = wave_sum(v);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    lds_barrier();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+template <int NT> __device__ __forceinline__ float block_max_lds(float v, float* red) {
+    v = wave_max(v);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    lds_barrier();
+    float s = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- skinny-M contraction (gemm.hip): C[M<=64, N] = A[M,K] . B + bias with B pre-packed to bf16 MFMA

@@ -38,11 +38,6 @@ struct RnnArgs {
 // every recurrent step on the completion of that step's global stores and of the NEXT step's x-projection
 // prefetch (cdna_hip_programming.md section 5, "Pipelining across barriers").  Cross-wave data here travels
 // through LDS exclusively; global traffic is per-lane private within a sweep.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 // ------------------------------------------------------------------------------------------------
 // fp32 VALU kernels

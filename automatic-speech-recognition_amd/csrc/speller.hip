@@ -36,6 +36,9 @@ struct DecDev {
     float *logits, *alphas, *hs, *cs, *gates, *xin0;
     unsigned short* xbf;   // [B,I0D]  bf16 copy of the current step's cell input row (A operand of the skinny product)
     unsigned short* dgbf;  // [B,G*D]  bf16 copy of the current step's layer-0 gate gradient
+    const unsigned short *Wsbf, *keysbf, *encbf;   // bf16 copies of Ws [S,A], keys [B,Tp,A], enc [B,Tp,Hd] (speed mode)
+    const unsigned short *Wsbf2, *encbf2;          // row-pair interleaved copies: [S/2][A][2], [B][Tp/2][Hd][2]
+    float* dE;             // [U,B,Tp] d energy of every step (keys gradient is contracted after the loop)
     // backward
     const float* dHl;      // [U,B,D]   dlogits . Wv^T
     float *dH, *dC;        // [NL,B,D]
@@ -324,6 +327,483 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
         const float v = L.s_state[i];
         xrow[E + Hd + i] = v;
         if (xb) xb[E + Hd + i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// speed-mode (bf16) row kernels, additive attention.  Same steps as above, but every per-step re-read
+// (Ws, keys, encoder rows) comes from bf16 copies made once per call with 16-byte loads, which halves the
+// bytes each row workgroup pulls through its CU's L2 port -- the bound of these kernels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ float sub16_sum(float v) {  // sum over a 16-lane group
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = f2bf(src[i]);
+}
+
+// src [batch][R][C] fp32 -> dst [batch][ceil(R/2)][C][2] bf16: rows 2r and 2r+1 interleaved per column (zero past R)
+__global__ __launch_bounds__(256) void pair_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int R, int C) {
+    const int R2 = (R + 1) / 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R2 * C) return;
+    const int r2 = (int)(i / C), c = (int)(i % C);
+    const float* sp = src + (size_t)blockIdx.y * R * C;
+    const float lo = sp[(size_t)(2 * r2) * C + c], hi = (2 * r2 + 1 < R) ? sp[(size_t)(2 * r2 + 1) * C + c] : 0.f;
+    reinterpret_cast<unsigned int*>(dst)[(size_t)blockIdx.y * R2 * C + i] = f2bf2(lo, hi);
+}
+
+struct BfLds { float *s_state, *qv, *ev, *hl, *x0, *x1, *red, *scr; int* redi; };
+__device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
+__device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
+    BfLds r; float* p = sm;
+    r.s_state = p; p += up4(a.D * a.NL);
+    r.qv = p;      p += up4(a.A);
+    r.ev = p;      p += up4(a.Tp);
+    r.hl = p;      p += up4(a.D);
+    r.x0 = p;      p += up4(a.Hd);      // bwd: dctx
+    r.x1 = p;      p += up4(a.Tp);      // bwd: d alpha / d energy
+    r.red = p;     p += 32;
+    r.redi = reinterpret_cast<int*>(p); p += 32;
+    r.scr = p;                           // RNW x max(Hd, 2A) partials
+    return r;
+}
+static size_t bf_lds_bytes(const DecDev& a) {
+    auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
+    return (u4((size_t)a.D * a.NL) + u4(a.A) + 2 * u4(a.Tp) + u4(a.D) + u4(a.Hd) + 64 + scr) * sizeof(float) + 64;
+}
+
+template <int CELL, int NJ>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
+    constexpr bool FAST = true;
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const BfLds L = carve_bf(sm, a);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, NL = a.NL, E = a.E, V = a.V, U = a.U;
+    const int S = D * NL, TOP = NL - 1, GD = G * D, I0D = E + Hd + D;
+    int greedy_tok = 1, sample_tok = 1;
+
+    if (t > 0) {  // ---- finish the top layer's cell of step t-1
+        float* gp = a.gates + (((size_t)TOP * U + (t - 1)) * B + b) * GD;
+        float* hnew = a.hs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+        for (int d = tid; d < D; d += RNT) {
+            float h;
+            if (CELL == LAS_CELL_LSTM) {
+                const float* cprev = a.cs + (((size_t)TOP * (U + 1) + (t - 1)) * B + b) * D;
+                float* cnew = a.cs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+                const float gi = sigm<FAST>(gp[d]);
+                const float gj = tanhx<FAST>(gp[D + d]);
+                const float gf = sigm<FAST>(gp[2 * D + d] + a.fb);
+                const float go = sigm<FAST>(gp[3 * D + d]);
+                const float c = cprev[d] * gf + gi * gj;
+                h = tanhx<FAST>(c) * go;
+                gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+                cnew[d] = c;
+            } else {
+                h = tanhx<FAST>(gp[d]);
+            }
+            hnew[d] = h;
+            L.hl[d] = h;
+        }
+        __syncthreads();
+        if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+            float bestv = -INFINITY, bests = -INFINITY;
+            int besti = 0x7fffffff, bestsi = 0x7fffffff;
+            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
+            for (int v = tid; v < V; v += RNT) {
+                float acc = a.bv[v];
+                for (int d = 0; d < D; ++d) acc = fmaf(L.hl[d], a.Wv[(size_t)d * V + v], acc);
+                lrow[v] = acc;
+                if (acc > bestv) { bestv = acc; besti = v; }
+                const float sc = acc + gumbel_noise(a.seed, t, b, v);
+                if (sc > bests) { bests = sc; bestsi = v; }
+            }
+            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
+            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
+            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+        }
+    }
+    if (t >= U) return;
+
+    int tok = a.tok_in[(size_t)t * B + b];
+    if (tok == -1) tok = greedy_tok;
+    else if (tok == -2) tok = sample_tok;
+    if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
+
+    for (int i = tid; i < S; i += RNT) {
+        const int l = i / D, d = i % D;
+        L.s_state[i] = (l == TOP && t > 0) ? L.hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
+    }
+    __syncthreads();
+
+    const int a8 = tid & 15, grp = tid >> 4;       // 16 lanes x 16 bytes = 128 attention columns; 64 groups
+    const int A8 = A >> 3;
+    {   // query projection q = s . Ws : 64 k-groups, up to 8 independent 16-byte loads in flight per thread
+        for (int a0 = a8; a0 < A8; a0 += 16) {
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            const uint4* wp = reinterpret_cast<const uint4*>(a.Wsbf) + a0;
+            for (int k = grp; k < S; k += 8 * 64) {
+                uint4 w8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + 64 * u;
+                    w8[u] = kk < S ? wp[(size_t)kk * A8] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + 64 * u;
+                    const float sk = kk < S ? L.s_state[kk] : 0.f;
+                    float w[8];
+                    unpack8(w8[u], w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(sk, w[e], acc[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {          // the 4 k-groups of this wave
+                acc[e] += __shfl_xor(acc[e], 16, 64);
+                acc[e] += __shfl_xor(acc[e], 32, 64);
+            }
+            if (lane < 16) {
+                float4* o = reinterpret_cast<float4*>(L.scr + wv * A + a0 * 8);
+                o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < A; i += RNT) {
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < RNW; ++w) q += L.scr[w * A + i];
+        L.qv[i] = q;
+    }
+    __syncthreads();
+
+    const int len = a.enc_len[b];
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
+    {   // energies: a 16-lane group per encoder frame, 16-byte key loads, 4 frames in flight
+        float q8[NJ][8], u8[NJ][8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int a0 = a8 + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q8[j][e] = a0 < A8 ? L.qv[a0 * 8 + e] : 0.f;
+                u8[j][e] = a0 < A8 ? a.u[a0 * 8 + e] : 0.f;
+            }
+        }
+        const uint4* kp = reinterpret_cast<const uint4*>(a.keysbf) + (size_t)b * Tp * A8;
+        for (int tb = grp; tb < Tp; tb += 4 * 64) {
+            uint4 k8[4][NJ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = tb + 64 * u;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int a0 = a8 + 16 * j;
+                    k8[u][j] = (tt < len && a0 < A8) ? kp[(size_t)tt * A8 + a0] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = tb + 64 * u;
+                float part = 0.f;
+                if (tt < len) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (a8 + 16 * j < A8) {
+                            float k[8];
+                            unpack8(k8[u][j], k);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) part = fmaf(u8[j][e], tanhx<FAST>(k[e] + q8[j][e]), part);
+                        }
+                    }
+                }
+                part = sub16_sum(part);
+                if (a8 == 0 && tt < Tp) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
+            }
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < Tp; i += RNT) m = fmaxf(m, L.ev[i]);
+    m = block_max<RNT>(m, L.red);
+    float ssum = 0.f;
+    for (int i = tid; i < Tp; i += RNT) { const float e = expf(L.ev[i] - m); L.ev[i] = e; ssum += e; }
+    ssum = block_sum<RNT>(ssum, L.red);
+    const float inv = 1.0f / ssum;
+    float* arow = a.alphas + ((size_t)t * B + b) * Tp;
+    for (int i = tid; i < Tp; i += RNT) { const float al = L.ev[i] * inv; L.ev[i] = al; arow[i] = al; }
+    __syncthreads();
+
+    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
+    unsigned short* xb = a.xbf + (size_t)b * I0D;
+    {   // context = sum_t alpha[t] * enc[b,t,:] : one wave per frame (1 KiB row at Hd = 512), 8 frames in flight
+        const int H8 = Hd >> 3;
+        for (int h0 = lane; h0 < H8; h0 += 64) {
+            const uint4* ep = reinterpret_cast<const uint4*>(a.encbf) + (size_t)b * Tp * H8 + h0;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int tt = wv; tt < lim; tt += 8 * RNW) {
+                uint4 e8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t2 = tt + RNW * u;
+                    e8[u] = t2 < lim ? ep[(size_t)t2 * H8] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t2 = tt + RNW * u;
+                    const float al = t2 < lim ? L.ev[t2] : 0.f;
+                    float x[8];
+                    unpack8(e8[u], x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(al, x[e], acc[e]);
+                }
+            }
+            float4* o = reinterpret_cast<float4*>(L.scr + wv * Hd + h0 * 8);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __syncthreads();
+        for (int hd = tid; hd < Hd; hd += RNT) {
+            float cv = 0.f;
+#pragma unroll
+            for (int w = 0; w < RNW; ++w) cv += L.scr[w * Hd + hd];
+            xrow[E + hd] = cv;
+            xb[E + hd] = f2bf(cv);
+        }
+    }
+    for (int i = tid; i < E; i += RNT) {
+        const float v = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+        xrow[i] = v;
+        xb[i] = f2bf(v);
+    }
+    for (int i = tid; i < D; i += RNT) {
+        const float v = L.s_state[i];
+        xrow[E + Hd + i] = v;
+        xb[E + Hd + i] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefetching row kernels (speed mode, additive attention, single-layer state, S <= 512, A <= 128, Hd <= 512,
+// T' <= 16*NE).  None of the bulk operands of a step (Ws, keys, encoder rows, saved gates) depends on the
+// recurrent state, so every load is issued when the kernel starts and only arithmetic sits on the dependent
+// chain; LDS-only barriers keep the loads in flight (a __syncthreads() would drain vmcnt at every phase).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2bf(unsigned int a, unsigned int b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+
+// The row kernels run one workgroup per utterance and are bound by instruction issue on that one CU, so the
+// contractions use packed-pair dot products: q = s.Ws over k-pairs (Wsbf2 [S/2][A][2]), context over frame pairs
+// (encbf2 [B][T'/2][Hd][2]); the softmax statistics are computed per wave (no block reductions).
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
+    constexpr bool FAST = true;
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const BfLds L = carve_bf(sm, a);
+    unsigned int* sp = reinterpret_cast<unsigned int*>(L.hl);      // packed state pairs  [S/2]
+    unsigned int* ap = reinterpret_cast<unsigned int*>(L.x1);      // packed alpha pairs  [T'/2]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a8 = tid & 15, grp = tid >> 4;           // energies: 16 lanes x 8 columns per frame
+    const int a4 = tid & 31, kg = tid >> 5;            // query:    32 lanes x 4 columns per k-pair
+    const int h4 = tid & 127, fg = tid >> 7;           // context:  128 lanes x 4 columns per frame pair
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V, U = a.U;
+    const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (S + 1) >> 1, Tp2 = (Tp + 1) >> 1;
+
+    // ---- every load of the step whose address does not depend on the recurrence, in consumption order
+    float gr[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f, s0 = 0.f;
+    float* gp = a.gates + (((size_t)0 * U + (t - 1)) * B + b) * GD;
+    if (t > 0 && tid < D) {
+        gr[0] = gp[tid];
+        if (CELL == LAS_CELL_LSTM) {
+            gr[1] = gp[D + tid]; gr[2] = gp[2 * D + tid]; gr[3] = gp[3 * D + tid];
+            cpv = a.cs[(((size_t)0 * (U + 1) + (t - 1)) * B + b) * D + tid];
+        }
+    }
+    if (t == 0 && tid < D) s0 = a.hs[(size_t)b * D + tid];
+    int tok = (t < U) ? a.tok_in[(size_t)t * B + b] : 0;
+    const int len = a.enc_len[b];
+    uint4 w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int kp = kg + 32 * u;
+        w8[u] = (t < U && kp < S2 && a4 < A4) ? reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kp * A4 + a4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float u8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u8[e] = (t < U && a8 < A8) ? a.u[a8 * 8 + e] : 0.f;
+    uint4 k8[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int tt = grp + 64 * u;
+        k8[u] = (t < U && tt < Tp && a8 < A8) ? reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + tt) * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float maskv = 1.f;
+    if (t < U && tid < E && a.emb_mask) maskv = a.emb_mask[((size_t)t * B + b) * E + tid];
+
+    int greedy_tok = 1, sample_tok = 1;
+    {   // ---- finish the cell of step t-1 (or pick up the initial state)
+        float h = s0;
+        if (t > 0 && tid < D) {
+            if (CELL == LAS_CELL_LSTM) {
+                const float gi = sigm<FAST>(gr[0]), gj = tanhx<FAST>(gr[1]);
+                const float gf = sigm<FAST>(gr[2] + a.fb), go = sigm<FAST>(gr[3]);
+                const float c = cpv * gf + gi * gj;
+                h = tanhx<FAST>(c) * go;
+                gp[tid] = gi; gp[D + tid] = gj; gp[2 * D + tid] = gf; gp[3 * D + tid] = go;
+                a.cs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = c;
+            } else {
+                h = tanhx<FAST>(gr[0]);
+            }
+            a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = h;
+        }
+        const float hn = __shfl_xor(h, 1, 64);
+        if (tid < D) {
+            L.s_state[tid] = h;
+            if (!(tid & 1)) sp[tid >> 1] = f2bf2(h, (tid + 1 < D) ? hn : 0.f);
+        }
+        lds_barrier();
+        if (t > 0 && a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+            float bestv = -INFINITY, bests = -INFINITY;
+            int besti = 0x7fffffff, bestsi = 0x7fffffff;
+            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
+            for (int v = tid; v < V; v += RNT) {
+                float acc = a.bv[v];
+                for (int d = 0; d < D; ++d) acc = fmaf(L.s_state[d], a.Wv[(size_t)d * V + v], acc);
+                lrow[v] = acc;
+                if (acc > bestv) { bestv = acc; besti = v; }
+                const float sc = acc + gumbel_noise(a.seed, t, b, v);
+                if (sc > bests) { bests = sc; bestsi = v; }
+            }
+            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
+            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
+            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+        }
+    }
+    if (t >= U) return;
+
+    if (tok < 0) {
+        tok = tok == -1 ? greedy_tok : sample_tok;
+        if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
+    }
+    float embv = 0.f;
+    if (tid < E) embv = a.emb[(size_t)tok * E + tid];       // consumed at the very end
+
+    {   // query projection q = s . Ws : 4 columns x 2 state rows per dot2, 8 prefetched fragments per thread
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kp = kg + 32 * u;
+            const unsigned int s2 = kp < S2 ? sp[kp] : 0u;
+            acc[0] = dot2bf(w8[u].x, s2, acc[0]); acc[1] = dot2bf(w8[u].y, s2, acc[1]);
+            acc[2] = dot2bf(w8[u].z, s2, acc[2]); acc[3] = dot2bf(w8[u].w, s2, acc[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], 32, 64);
+        if (lane < 32 && a4 < A4) reinterpret_cast<float4*>(L.scr + wv * A)[a4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    lds_barrier();
+    // encoder rows for the context: issued now (the Ws registers are free), consumed after the softmax
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
+    uint4 e8[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int tp = fg + 8 * u;
+        e8[u] = (2 * tp < lim && h4 < H4) ? reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b * Tp2 + tp) * H4 + h4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int i = tid; i < A; i += RNT) {
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < RNW; ++w) q += L.scr[w * A + i];
+        L.qv[i] = q;
+    }
+    lds_barrier();
+    {   // energies from the prefetched keys
+        float q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int tt = grp + 64 * u;
+            float part = 0.f;
+            if (tt < len && tt < Tp) {
+                float k[8];
+                unpack8(k8[u], k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part = fmaf(u8[e], tanhx<FAST>(k[e] + q8[e]), part);
+            }
+            part = sub16_sum(part);
+            if (a8 == 0 && tt < Tp) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
+        }
+    }
+    lds_barrier();
+    if (wv < 2) {   // softmax statistics per wave (T' <= 192: three frames per lane); waves 0-1 own the alpha pairs
+        float e0 = lane < Tp ? L.ev[lane] : -INFINITY, e1 = lane + 64 < Tp ? L.ev[lane + 64] : -INFINITY;
+        float e2 = lane + 128 < Tp ? L.ev[lane + 128] : -INFINITY;
+        const float m = wave_max(fmaxf(e0, fmaxf(e1, e2)));
+        const float ssum = wave_sum(expf(e0 - m) + expf(e1 - m) + expf(e2 - m));
+        const float inv = 1.0f / ssum;
+        if (tid < Tp2) {
+            const int i0 = 2 * tid, i1 = 2 * tid + 1;
+            const float al0 = expf(L.ev[i0] - m) * inv, al1 = i1 < Tp ? expf(L.ev[i1] - m) * inv : 0.f;
+            ap[tid] = f2bf2(al0, al1);
+            float* arow = a.alphas + ((size_t)t * B + b) * Tp;
+            arow[i0] = al0;
+            if (i1 < Tp) arow[i1] = al1;
+        }
+    }
+    lds_barrier();
+
+    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
+    unsigned short* xb = a.xbf + (size_t)b * I0D;
+    {   // context = sum_t alpha[t] * enc[b,t,:] : 4 columns x 2 frames per dot2
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int tp = fg + 8 * u;
+            const unsigned int al2 = 2 * tp < lim ? ap[tp] : 0u;
+            acc[0] = dot2bf(e8[u].x, al2, acc[0]); acc[1] = dot2bf(e8[u].y, al2, acc[1]);
+            acc[2] = dot2bf(e8[u].z, al2, acc[2]); acc[3] = dot2bf(e8[u].w, al2, acc[3]);
+        }
+        if (h4 < H4) reinterpret_cast<float4*>(L.scr + fg * Hd)[h4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        lds_barrier();
+        for (int hd = tid; hd < Hd; hd += RNT) {
+            float cv = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) cv += L.scr[w * Hd + hd];
+            xrow[E + hd] = cv;
+            xb[E + hd] = f2bf(cv);
+        }
+    }
+    if (tid < E) {
+        const float v = embv * maskv;
+        xrow[tid] = v;
+        xb[tid] = f2bf(v);
+    }
+    if (tid < D) {
+        const float v = L.s_state[tid];
+        xrow[E + Hd + tid] = v;
+        xb[E + Hd + tid] = f2bf(v);
     }
 }
 
@@ -661,6 +1141,395 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
     if (t_cell >= 0) cell_bwd_row<CELL, FAST>(a, NL - 1, t_cell, b, a.dHl + (size_t)t_cell * B * D, D);
 }
 
+// speed-mode gradient row kernel (additive attention).  Part A: attention backward of step t_att; Part B: top-layer
+// gate backward of step t_cell.  The keys gradient is NOT accumulated here: the step's d energy is stored and
+// dkeys_kernel contracts over the steps after the loop (no per-step read-modify-write of [Tp, A] per row).
+template <int CELL, int NJ>
+__global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_att, int t_cell) {
+    constexpr bool FAST = true;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const BfLds L = carve_bf(sm, a);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, NL = a.NL, E = a.E;
+    const int S = D * NL, I0D = E + Hd + D, A8 = A >> 3, H8 = Hd >> 3;
+    float* dctx = L.x0;
+    float* dal = L.x1;
+
+    if (t_att >= 0) {
+        const int t = t_att;
+        const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D;
+        for (int i = tid; i < Hd; i += RNT) dctx[i] = dxr[E + i];
+        for (int i = tid; i < Tp; i += RNT) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
+        for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
+        __syncthreads();
+        const int len = a.enc_len[b];
+        const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
+        {   // dalpha[t'] = dctx . enc[b,t',:] : one wave per frame, 8 frames in flight
+            for (int tt = wv; tt < Tp; tt += 8 * RNW) {
+                float acc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+                for (int h0 = lane; h0 < H8; h0 += 64) {
+                    const uint4* ep = reinterpret_cast<const uint4*>(a.encbf) + (size_t)b * Tp * H8 + h0;
+                    uint4 e8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t2 = tt + RNW * u;
+                        e8[u] = t2 < lim ? ep[(size_t)t2 * H8] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    const float4 d0 = reinterpret_cast<const float4*>(dctx)[h0 * 2], d1 = reinterpret_cast<const float4*>(dctx)[h0 * 2 + 1];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float x[8];
+                        unpack8(e8[u], x);
+                        acc[u] += d0.x * x[0] + d0.y * x[1] + d0.z * x[2] + d0.w * x[3] + d1.x * x[4] + d1.y * x[5] + d1.z * x[6] + d1.w * x[7];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t2 = tt + RNW * u;
+                    const float v = wave_sum(acc[u]);
+                    if (lane == 0 && t2 < Tp) dal[t2] = t2 < lim ? v : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        float dot = 0.f;
+        for (int i = tid; i < Tp; i += RNT) dot = fmaf(L.ev[i], dal[i], dot);
+        dot = block_sum<RNT>(dot, L.red);
+        float* der = a.dE + ((size_t)t * B + b) * Tp;
+        for (int i = tid; i < Tp; i += RNT) {
+            const float de = L.ev[i] * (dal[i] - dot);   // d energy (0 where masked: alpha = 0)
+            dal[i] = de;
+            der[i] = de;
+        }
+        __syncthreads();
+
+        // energies backward: 16-lane group per frame; per-lane partials of du and dq over its frames
+        const int a8 = tid & 15, grp = tid >> 4;
+        float q8[NJ][8], u8[NJ][8], du_acc[NJ][8], dq_acc[NJ][8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int a0 = a8 + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                q8[j][e] = a0 < A8 ? L.qv[a0 * 8 + e] : 0.f;
+                u8[j][e] = a0 < A8 ? a.u[a0 * 8 + e] : 0.f;
+                du_acc[j][e] = 0.f; dq_acc[j][e] = 0.f;
+            }
+        }
+        {
+            const uint4* kp = reinterpret_cast<const uint4*>(a.keysbf) + (size_t)b * Tp * A8;
+            for (int tb = grp; tb < lim; tb += 4 * 64) {
+                uint4 k8[4][NJ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = tb + 64 * u;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int a0 = a8 + 16 * j;
+                        k8[u][j] = (tt < lim && a0 < A8) ? kp[(size_t)tt * A8 + a0] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = tb + 64 * u;
+                    if (tt >= lim) continue;
+                    const float de = dal[tt];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (a8 + 16 * j < A8) {
+                            float k[8];
+                            unpack8(k8[u][j], k);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = tanhx<FAST>(k[e] + q8[j][e]);
+                                du_acc[j][e] = fmaf(de, v, du_acc[j][e]);
+                                dq_acc[j][e] = fmaf(de * u8[j][e], 1.f - v * v, dq_acc[j][e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // reduce the 64 group partials: 4 groups per wave by shuffles, 16 waves through LDS (dq | du side by side)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int a0 = a8 + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = dq_acc[j][e], w = du_acc[j][e];
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                w += __shfl_xor(w, 16, 64); w += __shfl_xor(w, 32, 64);
+                if (lane < 16 && a0 < A8) {
+                    L.scr[wv * 2 * A + a0 * 8 + e] = v;
+                    L.scr[wv * 2 * A + A + a0 * 8 + e] = w;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * A; i += RNT) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < RNW; ++w) sacc += L.scr[w * 2 * A + i];
+            if (i < A) { L.qv[i] = sacc; a.dQ[((size_t)t * B + b) * A + i] = sacc; }     // qv now holds dq
+            else a.duRows[(size_t)b * A + (i - A)] += sacc;
+        }
+        __syncthreads();
+        {   // d state = dq . Ws^T : 16-lane group per state row (256-byte bf16 row at A = 128), 8 rows in flight
+            float dq8[NJ][8];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dq8[j][e] = (a8 + 16 * j) < A8 ? L.qv[(a8 + 16 * j) * 8 + e] : 0.f;
+            const uint4* wp = reinterpret_cast<const uint4*>(a.Wsbf);
+            for (int ib = grp; ib < S; ib += 8 * 64) {
+                uint4 w8[8][NJ];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + 64 * u;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int a0 = a8 + 16 * j;
+                        w8[u][j] = (i < S && a0 < A8) ? wp[(size_t)i * A8 + a0] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + 64 * u;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float w[8];
+                        unpack8(w8[u][j], w);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc = fmaf(w[e], dq8[j][e], acc);
+                    }
+                    acc = sub16_sum(acc);
+                    if (a8 == 0 && i < S) {
+                        const int l = i / D, d = i % D;
+                        a.dH[((size_t)l * B + b) * D + d] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d] + acc;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t_cell >= 0) cell_bwd_row<CELL, FAST>(a, NL - 1, t_cell, b, a.dHl + (size_t)t_cell * B * D, D);
+}
+
+// prefetching gradient row kernel (same eligibility as dec_step_fwd_pf_kernel).  The recurrent inputs are the
+// dXin0 row of step t_att (context and state gradient) and this row's dC; everything else is issued at once.
+// dalpha = enc . dctx and dstate = Ws . dq contract over pairs that are adjacent in the natural layouts.
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
+    constexpr bool FAST = true;
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const BfLds L = carve_bf(sm, a);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a8 = tid & 15, grp = tid >> 4;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, U = a.U;
+    const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, H8 = Hd >> 3;
+    unsigned int* dcp = reinterpret_cast<unsigned int*>(L.x0);   // packed dctx pairs [Hd/2]
+    unsigned int* dqp = reinterpret_cast<unsigned int*>(L.hl);   // packed dq pairs   [A/2]
+    float* dal = L.x1;
+    float* dhs = L.s_state;                         // gradient of the state consumed at step t_att (attention path)
+    const bool att = t_att >= 0, cel = t_cell >= 0;
+
+    // ---- loads, in consumption order
+    const float* dxr = a.dXin0 + ((size_t)(att ? t_att : 0) * B + b) * I0D;
+    float recv = 0.f, alv = 0.f, qv0 = 0.f, duv = 0.f;
+    float2 dcv = make_float2(0.f, 0.f);
+    if (att) {
+        if (tid < (Hd >> 1)) dcv = reinterpret_cast<const float2*>(dxr + E)[tid];
+        if (tid < D) recv = dxr[E + Hd + tid];
+        if (tid < Tp) alv = a.alphas[((size_t)t_att * B + b) * Tp + tid];
+        if (tid < A) qv0 = a.Q[((size_t)t_att * B + b) * A + tid];
+        else if (tid < 2 * A) duv = a.duRows[(size_t)b * A + (tid - A)];
+    }
+    const int len = a.enc_len[b];
+    uint4 e8[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int t2 = wv + RNW * u;
+        e8[u] = (att && t2 < Tp && lane < H8) ? reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + t2) * H8 + lane] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint4 k8[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int tt = grp + 64 * u;
+        k8[u] = (att && tt < Tp && a8 < A8) ? reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + tt) * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float u8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u8[e] = (att && a8 < A8) ? a.u[a8 * 8 + e] : 0.f;
+    // cell part operands (saved by the forward pass)
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dhl = 0.f, dcr = 0.f;
+    float* gp = a.gates + (((size_t)0 * U + (cel ? t_cell : 0)) * B + b) * GD;
+    if (cel && tid < D) {
+        dhl = a.dHl[((size_t)t_cell * B + b) * D + tid];
+        if (CELL == LAS_CELL_LSTM) {
+            gs[0] = gp[tid]; gs[1] = gp[D + tid]; gs[2] = gp[2 * D + tid]; gs[3] = gp[3 * D + tid];
+            cv = a.cs[(((size_t)0 * (U + 1) + t_cell + 1) * B + b) * D + tid];
+            cpv = a.cs[(((size_t)0 * (U + 1) + t_cell) * B + b) * D + tid];
+            dcr = a.dC[(size_t)b * D + tid];
+        } else {
+            hv = a.hs[(((size_t)0 * (U + 1) + t_cell + 1) * B + b) * D + tid];
+        }
+    }
+
+    if (tid < D) dhs[tid] = 0.f;
+    if (att) {
+        const int t = t_att;
+        const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
+        if (tid < (Hd >> 1)) dcp[tid] = f2bf2(dcv.x, dcv.y);
+        if (tid < Tp) L.ev[tid] = alv;
+        if (tid < A) L.qv[tid] = qv0;
+        lds_barrier();
+        {   // dalpha[t'] = dctx . enc[b,t',:] : one wave per frame, 8 columns (4 pairs) per lane
+            const uint4 d4 = lane < H8 ? reinterpret_cast<const uint4*>(dcp)[lane] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int t2 = wv + RNW * u;
+                float acc = dot2bf(e8[u].x, d4.x, 0.f);
+                acc = dot2bf(e8[u].y, d4.y, acc); acc = dot2bf(e8[u].z, d4.z, acc); acc = dot2bf(e8[u].w, d4.w, acc);
+                acc = wave_sum(acc);
+                if (lane == 0 && t2 < Tp) dal[t2] = t2 < lim ? acc : 0.f;
+            }
+        }
+        // the state-gradient operand: issued now (the encoder registers are free), consumed after the energies
+        uint4 w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = grp + 64 * u;
+            w8[u] = (kk < S && a8 < A8) ? reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kk * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        lds_barrier();
+        float de_own = 0.f;
+        if (wv < 3) {   // T' <= 192: the first three waves own one frame per lane; each sums alpha . dalpha for itself
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = lane + 64 * j;
+                if (i < Tp) dot = fmaf(L.ev[i], dal[i], dot);
+            }
+            dot = wave_sum(dot);
+            if (tid < Tp) {
+                de_own = L.ev[tid] * (dal[tid] - dot);          // d energy (0 where masked: alpha = 0)
+                a.dE[((size_t)t * B + b) * Tp + tid] = de_own;
+            }
+        }
+        lds_barrier();                                           // all three waves have read dal
+        if (tid < Tp) dal[tid] = de_own;
+        lds_barrier();
+        float du_acc[8], dq_acc[8];
+        {   // energies backward from the prefetched keys
+            float q8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f; du_acc[e] = 0.f; dq_acc[e] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tt = grp + 64 * u;
+                if (tt < lim) {
+                    const float de = dal[tt];
+                    float k[8];
+                    unpack8(k8[u], k);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = tanhx<FAST>(k[e] + q8[e]);
+                        du_acc[e] = fmaf(de, v, du_acc[e]);
+                        dq_acc[e] = fmaf(de * u8[e], 1.f - v * v, dq_acc[e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = dq_acc[e], w = du_acc[e];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            w += __shfl_xor(w, 16, 64); w += __shfl_xor(w, 32, 64);
+            if (lane < 16 && a8 < A8) {
+                L.scr[wv * 2 * A + a8 * 8 + e] = v;
+                L.scr[wv * 2 * A + A + a8 * 8 + e] = w;
+            }
+        }
+        lds_barrier();
+        {
+            float sacc = 0.f;
+            if (tid < 2 * A) {
+#pragma unroll
+                for (int w = 0; w < RNW; ++w) sacc += L.scr[w * 2 * A + tid];
+            }
+            const float nb = __shfl_xor(sacc, 1, 64);
+            if (tid < A) {
+                a.dQ[((size_t)t * B + b) * A + tid] = sacc;
+                if (!(tid & 1)) dqp[tid >> 1] = f2bf2(sacc, nb);
+            } else if (tid < 2 * A) {
+                a.duRows[(size_t)b * A + (tid - A)] = duv + sacc;
+            }
+        }
+        lds_barrier();
+        {   // d state = Ws . dq : 16-lane group per state row, 8 columns (4 pairs) per lane, 8 prefetched rows
+            const uint4 q4 = a8 < A8 ? reinterpret_cast<const uint4*>(dqp)[a8] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = grp + 64 * u;
+                float acc = dot2bf(w8[u].x, q4.x, 0.f);
+                acc = dot2bf(w8[u].y, q4.y, acc); acc = dot2bf(w8[u].z, q4.z, acc); acc = dot2bf(w8[u].w, q4.w, acc);
+                acc = sub16_sum(acc);
+                if (a8 == 0 && i < S) dhs[i] = acc;
+            }
+        }
+        lds_barrier();
+    } else {
+        lds_barrier();
+    }
+    if (cel && tid < D) {   // gate backward of step t_cell
+        const float dh = dhs[tid] + recv + dhl;
+        unsigned short* gb = a.dgbf + (size_t)b * GD;
+        if (CELL == LAS_CELL_LSTM) {
+            const float gi = gs[0], gj = gs[1], gf = gs[2], go = gs[3];
+            const float tc = tanhx<FAST>(cv);
+            const float dc = dcr + dh * go * (1.f - tc * tc);
+            a.dC[(size_t)b * D + tid] = dc * gf;
+            const float di = dc * gj * gi * (1.f - gi), dj = dc * gi * (1.f - gj * gj);
+            const float df = dc * cpv * gf * (1.f - gf), dO = dh * tc * go * (1.f - go);
+            gp[tid] = di; gp[D + tid] = dj; gp[2 * D + tid] = df; gp[3 * D + tid] = dO;
+            gb[tid] = f2bf(di); gb[D + tid] = f2bf(dj); gb[2 * D + tid] = f2bf(df); gb[3 * D + tid] = f2bf(dO);
+        } else {
+            const float dp = dh * (1.f - hv * hv);
+            gp[tid] = dp;
+            gb[tid] = f2bf(dp);
+        }
+    }
+}
+
+// dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)
+// workgroup = (utterance, 8 encoder frames); 32 lanes x float4 over the attention dim per frame
+__global__ __launch_bounds__(256) void dkeys_kernel(DecDev a, float* __restrict__ dKeys) {
+    const int b = blockIdx.y, tt = blockIdx.x * 8 + (threadIdx.x >> 5), sl = threadIdx.x & 31;
+    const int B = a.B, Tp = a.Tp, A = a.A, U = a.U;
+    if (tt >= Tp) return;
+    for (int a4 = sl; a4 < A / 4; a4 += 32) {
+        const unsigned short* kr = a.keysbf + ((size_t)b * Tp + tt) * A + a4 * 4;
+        const float k0 = bf2f(kr[0]), k1 = bf2f(kr[1]), k2 = bf2f(kr[2]), k3 = bf2f(kr[3]);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < U; ++t) {
+            const float de = a.dE[((size_t)t * B + b) * Tp + tt];
+            const float4 q4 = reinterpret_cast<const float4*>(a.Q + ((size_t)t * B + b) * A)[a4];
+            const float v0 = tanh_fast(k0 + q4.x), v1 = tanh_fast(k1 + q4.y), v2 = tanh_fast(k2 + q4.z), v3 = tanh_fast(k3 + q4.w);
+            acc.x = fmaf(de, 1.f - v0 * v0, acc.x); acc.y = fmaf(de, 1.f - v1 * v1, acc.y);
+            acc.z = fmaf(de, 1.f - v2 * v2, acc.z); acc.w = fmaf(de, 1.f - v3 * v3, acc.w);
+        }
+        const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+        float4* o = reinterpret_cast<float4*>(dKeys + ((size_t)b * Tp + tt) * A) + a4;
+        float4 cur = *o;
+        cur.x = fmaf(acc.x, u4.x, cur.x); cur.y = fmaf(acc.y, u4.y, cur.y); cur.z = fmaf(acc.z, u4.z, cur.z); cur.w = fmaf(acc.w, u4.w, cur.w);
+        *o = cur;
+    }
+}
+
 // demb[v,:] += sum over (t,b) with token v of dXin0[t,b,0:E]  -- stage 1: per (vocab row, row chunk) partials
 // (fixed chunking -> deterministic); stage 2 is las_colsum over the chunk axis.
 constexpr int EMB_CHUNKS = 32;
@@ -683,7 +1552,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, xbf, dgbf, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -693,6 +1562,12 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
     w.xbf = o;    o += align256((size_t)B * I0D * 2);
     w.dgbf = o;   o += align256((size_t)B * G * D * 2);
+    w.wsbf = o;   o += align256((size_t)D * NL * A * 2);
+    w.wsbf2 = o;  o += align256((size_t)(D * NL + 1) * A * 2);
+    w.keysbf = o; o += align256((size_t)B * Tp * A * 2);
+    w.encbf = o;  o += align256((size_t)B * Tp * Hd * 2);
+    w.encbf2 = o; o += align256((size_t)B * (Tp + 1) * Hd * 2);
+    w.dE = o;     o += align256((size_t)U * B * Tp * f);
     w.embp = o;   o += align256((size_t)EMB_CHUNKS * V * E * f);
     w.dHl = o;    o += align256((size_t)U * B * D * f);
     w.dH = o;     o += align256((size_t)NL * B * D * f);
@@ -744,7 +1619,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
-    d.xbf = nullptr; d.dgbf = nullptr;
+    d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
     for (int l = 0; l < LAS_MAX_NL; ++l) { d.rec[l] = nullptr; d.recLd[l] = 0; d.recOff[l] = 0; }
@@ -752,6 +1627,36 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
 }
 
 #define GEMM_OK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+
+// speed mode, additive attention: the row kernels read bf16 copies of Ws / keys / encoder rows (made once per call)
+static bool bf_rows_ok(const DecDev& d) {
+    const char* off = getenv("LAS_NO_BF_ROWS");       // debugging knob: keep the fp32-operand row kernels
+    return !(off && off[0] == '1') && d.mode == LAS_ATT_ADD && (d.A % 8) == 0 && (d.Hd % 8) == 0 && d.A <= 256;
+}
+// ... and, for the common single-layer geometry, the fully prefetching variants
+static bool pf_rows_ok(const DecDev& d) {
+    const char* off = getenv("LAS_NO_PF_ROWS");
+    return !(off && off[0] == '1') && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 192 && d.E <= 1024 &&
+           (d.E % 2) == 0 && (d.D % 2) == 0;
+}
+static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
+    unsigned short* wsb = (unsigned short*)(base + w.wsbf);
+    unsigned short* kb = (unsigned short*)(base + w.keysbf);
+    unsigned short* eb = (unsigned short*)(base + w.encbf);
+    const size_t nW = (size_t)d.D * d.NL * d.A, nK = (size_t)d.B * d.Tp * d.A, nE = (size_t)d.B * d.Tp * d.Hd;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nW, 1024)), dim3(256), 0, st, d.Ws, wsb, nW);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nK, 2048)), dim3(256), 0, st, d.keys, kb, nK);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nE, 2048)), dim3(256), 0, st, d.enc, eb, nE);
+    // row-pair interleaved copies for the packed dot products of the prefetching forward kernel
+    unsigned short* wsb2 = (unsigned short*)(base + w.wsbf2);
+    unsigned short* eb2 = (unsigned short*)(base + w.encbf2);
+    const int S = d.D * d.NL, S2 = (S + 1) / 2, Tp2 = (d.Tp + 1) / 2;
+    hipLaunchKernelGGL(pair_rows_kernel, dim3(cdiv((size_t)S2 * d.A, 256), 1), dim3(256), 0, st, d.Ws, wsb2, S, d.A);
+    hipLaunchKernelGGL(pair_rows_kernel, dim3(cdiv((size_t)Tp2 * d.Hd, 256), d.B), dim3(256), 0, st, d.enc, eb2, d.Tp, d.Hd);
+    LAS_LAUNCHED();
+    d.Wsbf = wsb; d.keysbf = kb; d.encbf = eb; d.Wsbf2 = wsb2; d.encbf2 = eb2;
+    return 0;
+}
 
 template <int CELL, bool FAST>
 static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t st) {
@@ -770,10 +1675,22 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     const bool skinny = FAST && f->ws && f->ws_bytes >= wl_.embp && (I0D % 8) == 0 && las_skinny_ok(B, I0D, GD, I0D, d.xin0);
     void* packF = skinny ? (char*)f->ws + wl_.packF : nullptr;
     if (skinny) d.xbf = (unsigned short*)((char*)f->ws + wl_.xbf);
+    const bool bfrows = skinny && bf_rows_ok(d);
+    const bool pf = bfrows && pf_rows_ok(d);
+    const size_t lds_bf = bf_lds_bytes(d);
+    if (bfrows) {
+        LAS_ARG(lds_bf <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);
+        GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
+    }
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     for (int t = 0; t <= U; ++t) {
-        if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);
-        else                       hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
+        if (pf && d.Tp <= 128)          hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (bfrows && d.A <= 128)  hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (bfrows)                hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 2>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);
+        else                            hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
         if (skinny) {
@@ -833,6 +1750,14 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     const bool skinny = FAST && (GD % 8) == 0 && las_skinny_ok(B, GD, I0D, GD, d.gates);
     void* packB = base + w.packB;
     if (skinny) d.dgbf = (unsigned short*)(base + w.dgbf);
+    const bool bfrows = skinny && bf_rows_ok(d);
+    const bool pf = bfrows && pf_rows_ok(d);
+    const size_t lds_bf = bf_lds_bytes(d);
+    if (bfrows) {
+        LAS_ARG(lds_bf <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
+        GEMM_OK(make_bf_copies(d, base, w, st));
+        d.dE = (float*)(base + w.dE);
+    }
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
@@ -849,8 +1774,14 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     for (int t = U - 1; t >= -1; --t) {
         DecDev ds = d;
         if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
-        if (loc) hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
-        else     hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        const int ta = (t + 1 < U) ? t + 1 : -1;
+        if (pf && Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        else if (pf && Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        else if (pf)              hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        else if (bfrows && A <= 128) hipLaunchKernelGGL((dec_step_bwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        else if (bfrows) hipLaunchKernelGGL((dec_step_bwd_bf_kernel<CELL, 2>), dim3(B), dim3(RNT), lds_bf, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        else if (loc) hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
+        else          hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         LAS_LAUNCHED();
         if (t < 0) break;
         for (int l = TOP; l >= 0; --l) {
@@ -870,6 +1801,10 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
         }
     }
 
+    if (bfrows) {   // keys gradient: contraction over the steps, every (utterance, frame) independent
+        hipLaunchKernelGGL(dkeys_kernel, dim3(cdiv(Tp, 8), B), dim3(256), 0, st, d, bk->d_keys);
+        LAS_LAUNCHED();
+    }
     // ---- weight gradients: one tall contraction each (K = U*B), deterministic split-K
     const int UB = U * B;
     GEMM_OK(las_gemm(prec, 1, 0, I0D, GD, UB, 1.f, d.xin0, I0D, 0, d.gates, GD, 0, 1.f, bk->dcellW[0], GD, 0, nullptr,

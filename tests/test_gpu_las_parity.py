@@ -21,6 +21,7 @@ CONFIGS = [
     ("lstm", "loc", 1, 64, 96, "f32", True),
     ("lstm", "add", 1, 64, 64, "bf16", False),
     ("rnn", "add", 1, 128, 64, "bf16", False),
+    ("lstm", "add", 2, 64, 64, "bf16", True),
 ]
 
 
