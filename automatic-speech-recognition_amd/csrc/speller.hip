@@ -606,6 +606,12 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
 // recurrent state, so every load is issued when the kernel starts and only arithmetic sits on the dependent
 // chain; LDS-only barriers keep the loads in flight (a __syncthreads() would drain vmcnt at every phase).
 // ------------------------------------------------------------------------------------------------
+#ifdef LAS_ROW_STAMPS   // development aid (tools/micro/bench_rows.hip): phase timestamps of workgroup 0
+__device__ unsigned long long g_stamps[32];
+#define STAMPX(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMPX(i)
+#endif
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
 __device__ __forceinline__ float dot2bf(unsigned int a, unsigned int b, float acc) {
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    STAMPX(0);
     const BfLds L = carve_bf(sm, a);
     unsigned int* sp = reinterpret_cast<unsigned int*>(L.hl);      // packed state pairs  [S/2]
     unsigned int* ap = reinterpret_cast<unsigned int*>(L.x1);      // packed alpha pairs  [T'/2]
@@ -630,50 +637,55 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V, U = a.U;
     const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (S + 1) >> 1, Tp2 = (Tp + 1) >> 1;
 
-    // ---- every load of the step whose address does not depend on the recurrence, in consumption order
-    float gr[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f, s0 = 0.f;
-    float* gp = a.gates + (((size_t)0 * U + (t - 1)) * B + b) * GD;
-    if (t > 0 && tid < D) {
-        gr[0] = gp[tid];
-        if (CELL == LAS_CELL_LSTM) {
-            gr[1] = gp[D + tid]; gr[2] = gp[2 * D + tid]; gr[3] = gp[3 * D + tid];
-            cpv = a.cs[(((size_t)0 * (U + 1) + (t - 1)) * B + b) * D + tid];
-        }
+    // ---- every load of the step whose address does not depend on the recurrence, in consumption order.
+    // All of them are UNCONDITIONAL with clamped addresses: a predicated load becomes an exec-masked branch whose
+    // join makes the compiler drain vmcnt, which serialises the prefetch.  Out-of-range lanes are neutralised where
+    // the value is used (zero multiplier / guarded store), never by a select on the loaded register.
+    const int tm1 = t > 0 ? t - 1 : 0, tc = t < U ? t : U - 1, dd = tid < D ? tid : D - 1;
+    float gr[4], cpv = 0.f;
+    float* gp = a.gates + (((size_t)0 * U + tm1) * B + b) * GD;
+    gr[0] = gp[dd];
+    if (CELL == LAS_CELL_LSTM) {
+        gr[1] = gp[D + dd]; gr[2] = gp[2 * D + dd]; gr[3] = gp[3 * D + dd];
+        cpv = a.cs[(((size_t)0 * (U + 1) + tm1) * B + b) * D + dd];
     }
-    if (t == 0 && tid < D) s0 = a.hs[(size_t)b * D + tid];
-    int tok = (t < U) ? a.tok_in[(size_t)t * B + b] : 0;
+    const float s0 = a.hs[(size_t)b * D + dd];                       // initial state (used at t = 0)
+    int tok = a.tok_in[(size_t)tc * B + b];
     const int len = a.enc_len[b];
+    const int a4c = a4 < A4 ? a4 : A4 - 1, a8c = a8 < A8 ? a8 : A8 - 1, h4c = h4 < H4 ? h4 : H4 - 1;
     uint4 w8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int kp = kg + 32 * u;
-        w8[u] = (t < U && kp < S2 && a4 < A4) ? reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kp * A4 + a4] : make_uint4(0u, 0u, 0u, 0u);
+        const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
+        w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kpc * A4 + a4c];
     }
-    float u8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) u8[e] = (t < U && a8 < A8) ? a.u[a8 * 8 + e] : 0.f;
+    const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
     uint4 k8[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        const int tt = grp + 64 * u;
-        k8[u] = (t < U && tt < Tp && a8 < A8) ? reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + tt) * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+        const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
     }
-    float maskv = 1.f;
-    if (t < U && tid < E && a.emb_mask) maskv = a.emb_mask[((size_t)t * B + b) * E + tid];
-
+    STAMPX(1);
     int greedy_tok = 1, sample_tok = 1;
     {   // ---- finish the cell of step t-1 (or pick up the initial state)
-        float h = s0;
+        // computed by every lane (clamped operands) so that the gate loads stay at the head of the load stream;
+        // only the stores are predicated
+        float h, cnew = 0.f, gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f;
+        if (CELL == LAS_CELL_LSTM) {
+            gi = sigm<FAST>(gr[0]); gj = tanhx<FAST>(gr[1]);
+            gf = sigm<FAST>(gr[2] + a.fb); go = sigm<FAST>(gr[3]);
+            cnew = cpv * gf + gi * gj;
+            h = tanhx<FAST>(cnew) * go;
+        } else {
+            h = tanhx<FAST>(gr[0]);
+        }
+        if (t == 0) h = s0;
+        if (tid >= D) h = 0.f;
         if (t > 0 && tid < D) {
             if (CELL == LAS_CELL_LSTM) {
-                const float gi = sigm<FAST>(gr[0]), gj = tanhx<FAST>(gr[1]);
-                const float gf = sigm<FAST>(gr[2] + a.fb), go = sigm<FAST>(gr[3]);
-                const float c = cpv * gf + gi * gj;
-                h = tanhx<FAST>(c) * go;
                 gp[tid] = gi; gp[D + tid] = gj; gp[2 * D + tid] = gf; gp[3 * D + tid] = go;
-                a.cs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = c;
-            } else {
-                h = tanhx<FAST>(gr[0]);
+                a.cs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = cnew;
             }
             a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = h;
         }
@@ -702,12 +714,15 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     }
     if (t >= U) return;
 
+    STAMPX(2);
     if (tok < 0) {
         tok = tok == -1 ? greedy_tok : sample_tok;
         if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
     }
-    float embv = 0.f;
-    if (tid < E) embv = a.emb[(size_t)tok * E + tid];       // consumed at the very end
+    // consumed at the very end
+    const int ec = tid < E ? tid : E - 1;
+    const float embv = a.emb[(size_t)tok * E + ec];
+    const float maskv = a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + ec] : 1.f;
 
     {   // query projection q = s . Ws : 4 columns x 2 state rows per dot2, 8 prefetched fragments per thread
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -723,13 +738,15 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         if (lane < 32 && a4 < A4) reinterpret_cast<float4*>(L.scr + wv * A)[a4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     lds_barrier();
+    STAMPX(3);
     // encoder rows for the context: issued now (the Ws registers are free), consumed after the softmax
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
     uint4 e8[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
         const int tp = fg + 8 * u;
-        e8[u] = (2 * tp < lim && h4 < H4) ? reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b * Tp2 + tp) * H4 + h4] : make_uint4(0u, 0u, 0u, 0u);
+        const int tpc = tp < Tp2 ? tp : Tp2 - 1;
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b * Tp2 + tpc) * H4 + h4c];
     }
     for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
@@ -738,7 +755,10 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         L.qv[i] = q;
     }
     lds_barrier();
+    STAMPX(4);
     {   // energies from the prefetched keys
+        const float um = a8 < A8 ? 1.f : 0.f;        // lanes past the attention width carry clamped operands
+        const float u8[8] = {u40.x * um, u40.y * um, u40.z * um, u40.w * um, u41.x * um, u41.y * um, u41.z * um, u41.w * um};
         float q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f;
@@ -757,6 +777,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         }
     }
     lds_barrier();
+    STAMPX(5);
     if (wv < 2) {   // softmax statistics per wave (T' <= 192: three frames per lane); waves 0-1 own the alpha pairs
         float e0 = lane < Tp ? L.ev[lane] : -INFINITY, e1 = lane + 64 < Tp ? L.ev[lane + 64] : -INFINITY;
         float e2 = lane + 128 < Tp ? L.ev[lane + 128] : -INFINITY;
@@ -774,6 +795,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     }
     lds_barrier();
 
+    STAMPX(6);
     float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
     unsigned short* xb = a.xbf + (size_t)b * I0D;
     {   // context = sum_t alpha[t] * enc[b,t,:] : 4 columns x 2 frames per dot2
@@ -787,6 +809,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         }
         if (h4 < H4) reinterpret_cast<float4*>(L.scr + fg * Hd)[h4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         lds_barrier();
+    STAMPX(7);
         for (int hd = tid; hd < Hd; hd += RNT) {
             float cv = 0.f;
 #pragma unroll
@@ -805,6 +828,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         xrow[E + Hd + tid] = v;
         xb[E + Hd + tid] = f2bf(v);
     }
+    STAMPX(8);
 }
 
 // gate nonlinearity of a non-top layer (multi-layer Speller only)
@@ -1337,47 +1361,43 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     float* dhs = L.s_state;                         // gradient of the state consumed at step t_att (attention path)
     const bool att = t_att >= 0, cel = t_cell >= 0;
 
-    // ---- loads, in consumption order
-    const float* dxr = a.dXin0 + ((size_t)(att ? t_att : 0) * B + b) * I0D;
-    float recv = 0.f, alv = 0.f, qv0 = 0.f, duv = 0.f;
-    float2 dcv = make_float2(0.f, 0.f);
-    if (att) {
-        if (tid < (Hd >> 1)) dcv = reinterpret_cast<const float2*>(dxr + E)[tid];
-        if (tid < D) recv = dxr[E + Hd + tid];
-        if (tid < Tp) alv = a.alphas[((size_t)t_att * B + b) * Tp + tid];
-        if (tid < A) qv0 = a.Q[((size_t)t_att * B + b) * A + tid];
-        else if (tid < 2 * A) duv = a.duRows[(size_t)b * A + (tid - A)];
-    }
+    // ---- loads, in consumption order; unconditional with clamped addresses (see dec_step_fwd_pf_kernel)
+    const int ta = att ? t_att : 0, tcl = cel ? t_cell : 0;
+    const int dd = tid < D ? tid : D - 1, h2c = tid < (Hd >> 1) ? tid : (Hd >> 1) - 1, tpc = tid < Tp ? tid : Tp - 1;
+    const int a2c = tid < 2 * A ? tid : 2 * A - 1, a8c = a8 < A8 ? a8 : A8 - 1, l8c = lane < H8 ? lane : H8 - 1;
+    const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
+    const float2 dcv = reinterpret_cast<const float2*>(dxr + E)[h2c];
+    const float recv0 = dxr[E + Hd + dd];
+    const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
+    // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
+    const float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     const int len = a.enc_len[b];
     uint4 e8[NE];
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
-        const int t2 = wv + RNW * u;
-        e8[u] = (att && t2 < Tp && lane < H8) ? reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + t2) * H8 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + t2c) * H8 + l8c];
     }
     uint4 k8[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-        const int tt = grp + 64 * u;
-        k8[u] = (att && tt < Tp && a8 < A8) ? reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + tt) * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+        const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
     }
-    float u8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) u8[e] = (att && a8 < A8) ? a.u[a8 * 8 + e] : 0.f;
+    const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
     // cell part operands (saved by the forward pass)
-    float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dhl = 0.f, dcr = 0.f;
-    float* gp = a.gates + (((size_t)0 * U + (cel ? t_cell : 0)) * B + b) * GD;
-    if (cel && tid < D) {
-        dhl = a.dHl[((size_t)t_cell * B + b) * D + tid];
-        if (CELL == LAS_CELL_LSTM) {
-            gs[0] = gp[tid]; gs[1] = gp[D + tid]; gs[2] = gp[2 * D + tid]; gs[3] = gp[3 * D + tid];
-            cv = a.cs[(((size_t)0 * (U + 1) + t_cell + 1) * B + b) * D + tid];
-            cpv = a.cs[(((size_t)0 * (U + 1) + t_cell) * B + b) * D + tid];
-            dcr = a.dC[(size_t)b * D + tid];
-        } else {
-            hv = a.hs[(((size_t)0 * (U + 1) + t_cell + 1) * B + b) * D + tid];
-        }
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dcr = 0.f;
+    float* gp = a.gates + (((size_t)0 * U + tcl) * B + b) * GD;
+    const float dhl = a.dHl[((size_t)tcl * B + b) * D + dd];
+    if (CELL == LAS_CELL_LSTM) {
+        gs[0] = gp[dd]; gs[1] = gp[D + dd]; gs[2] = gp[2 * D + dd]; gs[3] = gp[3 * D + dd];
+        cv = a.cs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+        cpv = a.cs[(((size_t)0 * (U + 1) + tcl) * B + b) * D + dd];
+        dcr = a.dC[(size_t)b * D + dd];
+    } else {
+        hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
     }
+    const float recv = att ? recv0 : 0.f;
 
     if (tid < D) dhs[tid] = 0.f;
     if (att) {
@@ -1385,7 +1405,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
         if (tid < (Hd >> 1)) dcp[tid] = f2bf2(dcv.x, dcv.y);
         if (tid < Tp) L.ev[tid] = alv;
-        if (tid < A) L.qv[tid] = qv0;
+        if (tid < A) L.qv[tid] = qd;
         lds_barrier();
         {   // dalpha[t'] = dctx . enc[b,t',:] : one wave per frame, 8 columns (4 pairs) per lane
             const uint4 d4 = lane < H8 ? reinterpret_cast<const uint4*>(dcp)[lane] : make_uint4(0u, 0u, 0u, 0u);
@@ -1403,7 +1423,8 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int kk = grp + 64 * u;
-            w8[u] = (kk < S && a8 < A8) ? reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kk * A8 + a8] : make_uint4(0u, 0u, 0u, 0u);
+            const int kkc = kk < S ? kk : S - 1;
+            w8[u] = reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kkc * A8 + a8c];
         }
         lds_barrier();
         float de_own = 0.f;
@@ -1425,6 +1446,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         lds_barrier();
         float du_acc[8], dq_acc[8];
         {   // energies backward from the prefetched keys
+            const float u8[8] = {u40.x, u40.y, u40.z, u40.w, u41.x, u41.y, u41.z, u41.w};
             float q8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f; du_acc[e] = 0.f; dq_acc[e] = 0.f; }
@@ -1466,7 +1488,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
                 a.dQ[((size_t)t * B + b) * A + tid] = sacc;
                 if (!(tid & 1)) dqp[tid >> 1] = f2bf2(sacc, nb);
             } else if (tid < 2 * A) {
-                a.duRows[(size_t)b * A + (tid - A)] = duv + sacc;
+                a.duRows[(size_t)b * A + (tid - A)] = qd + sacc;
             }
         }
         lds_barrier();

@@ -59,5 +59,12 @@ int main() {
                             ms * 1e3f / IT, hipGetErrorString(hipGetLastError()));
         }
     }
+#ifdef LAS_ROW_STAMPS
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((dec_step_fwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, d, 7 + i);
+    hipDeviceSynchronize();
+    unsigned long long hs[32];
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+    for (int i = 1; i < 9; ++i) printf("stamp %d: +%.2f us\n", i, (double)(hs[i] - hs[0]) * 0.01);
+#endif
     return 0;
 }
