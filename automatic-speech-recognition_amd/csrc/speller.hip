@@ -1350,6 +1350,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    STAMPX(10);
     const BfLds L = carve_bf(sm, a);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a8 = tid & 15, grp = tid >> 4;
@@ -1399,6 +1400,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     }
     const float recv = att ? recv0 : 0.f;
 
+    STAMPX(11);
     if (tid < D) dhs[tid] = 0.f;
     if (att) {
         const int t = t_att;
@@ -1407,6 +1409,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         if (tid < Tp) L.ev[tid] = alv;
         if (tid < A) L.qv[tid] = qd;
         lds_barrier();
+    STAMPX(12);
         {   // dalpha[t'] = dctx . enc[b,t',:] : one wave per frame, 8 columns (4 pairs) per lane
             const uint4 d4 = lane < H8 ? reinterpret_cast<const uint4*>(dcp)[lane] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -1418,6 +1421,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
                 if (lane == 0 && t2 < Tp) dal[t2] = t2 < lim ? acc : 0.f;
             }
         }
+    STAMPX(13);
         // the state-gradient operand: issued now (the encoder registers are free), consumed after the energies
         uint4 w8[8];
 #pragma unroll
@@ -1427,6 +1431,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
             w8[u] = reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kkc * A8 + a8c];
         }
         lds_barrier();
+    STAMPX(14);
         float de_own = 0.f;
         if (wv < 3) {   // T' <= 192: the first three waves own one frame per lane; each sums alpha . dalpha for itself
             float dot = 0.f;
@@ -1444,6 +1449,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         lds_barrier();                                           // all three waves have read dal
         if (tid < Tp) dal[tid] = de_own;
         lds_barrier();
+    STAMPX(15);
         float du_acc[8], dq_acc[8];
         {   // energies backward from the prefetched keys
             const float u8[8] = {u40.x, u40.y, u40.z, u40.w, u41.x, u41.y, u41.z, u41.w};
@@ -1466,6 +1472,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
                 }
             }
         }
+    STAMPX(16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = dq_acc[e], w = du_acc[e];
@@ -1492,6 +1499,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
             }
         }
         lds_barrier();
+    STAMPX(17);
         {   // d state = Ws . dq : 16-lane group per state row, 8 columns (4 pairs) per lane, 8 prefetched rows
             const uint4 q4 = a8 < A8 ? reinterpret_cast<const uint4*>(dqp)[a8] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -1507,6 +1515,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     } else {
         lds_barrier();
     }
+    STAMPX(18);
     if (cel && tid < D) {   // gate backward of step t_cell
         const float dh = dhs[tid] + recv + dhl;
         unsigned short* gb = a.dgbf + (size_t)b * GD;
@@ -1525,6 +1534,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
             gb[tid] = f2bf(dp);
         }
     }
+    STAMPX(19);
 }
 
 // dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)

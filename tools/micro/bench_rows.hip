@@ -65,6 +65,10 @@ int main() {
     unsigned long long hs[32];
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
     for (int i = 1; i < 9; ++i) printf("stamp %d: +%.2f us\n", i, (double)(hs[i] - hs[0]) * 0.01);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, d, 8 + i, 7 + i);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+    for (int i = 11; i < 20; ++i) printf("bwd stamp %d: +%.2f us\n", i, (double)(hs[i] - hs[10]) * 0.01);
 #endif
     return 0;
 }
