@@ -1759,7 +1759,7 @@ extern "C" int las_speller_fwd(const las_speller_fwd_args* f, void* stream) {
 }
 
 template <int CELL, bool FAST>
-static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_t st) {
+static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, hipStream_t st) {
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     const las_speller_fwd_args* f = &bk->f;
     const int B = d.B, D = d.D, NL = d.NL, U = d.U, E = d.E, Hd = d.Hd, V = d.V, A = d.A, Tp = d.Tp;
@@ -1787,10 +1787,11 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     const size_t lds_bf = bf_lds_bytes(d);
     if (bfrows) {
         LAS_ARG(lds_bf <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
-        GEMM_OK(make_bf_copies(d, base, w, st));
+        if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
     }
-    if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
+    if (skinny && (part & 1)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
+    if (part & 1) {
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
 
@@ -1837,6 +1838,11 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
         hipLaunchKernelGGL(dkeys_kernel, dim3(cdiv(Tp, 8), B), dim3(256), 0, st, d, bk->d_keys);
         LAS_LAUNCHED();
     }
+    // d_enc[b] += alphas[:,b,:]^T . dctx[:,b,:]   (batched over utterances; contraction over the U steps)
+    GEMM_OK(las_gemm(prec, 1, 0, Tp, Hd, U, 1.f, d.alphas, B * Tp, Tp, d.dXin0 + E, B * I0D, I0D, 1.f, bk->d_enc, Hd,
+                     (long long)Tp * Hd, nullptr, LAS_ACT_NONE, B, 0, 0, nullptr, 0, st));
+    }
+    if (!(part & 2)) return 0;
     // ---- weight gradients: one tall contraction each (K = U*B), deterministic split-K
     const int UB = U * B;
     GEMM_OK(las_gemm(prec, 1, 0, I0D, GD, UB, 1.f, d.xin0, I0D, 0, d.gates, GD, 0, 1.f, bk->dcellW[0], GD, 0, nullptr,
@@ -1864,9 +1870,6 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
         LAS_LAUNCHED();
         GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
     }
-    // d_enc[b] += alphas[:,b,:]^T . dctx[:,b,:]   (batched over utterances; contraction over the U steps)
-    GEMM_OK(las_gemm(prec, 1, 0, Tp, Hd, U, 1.f, d.alphas, B * Tp, Tp, d.dXin0 + E, B * I0D, I0D, 1.f, bk->d_enc, Hd,
-                     (long long)Tp * Hd, nullptr, LAS_ACT_NONE, B, 0, 0, nullptr, 0, st));
     if (loc) {
         GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
         GEMM_OK(las_colsum(d.dlocbRows, B, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
@@ -1875,8 +1878,11 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, hipStream_
     return 0;
 }
 
-extern "C" int las_speller_bwd(const las_speller_bwd_args* bk, void* stream) {
+extern "C" int las_speller_bwd(const las_speller_bwd_args* bk, void* stream) { return las_speller_bwd_part(bk, 3, stream); }
+
+extern "C" int las_speller_bwd_part(const las_speller_bwd_args* bk, int part, void* stream) {
     LAS_ARG(bk, "las_speller_bwd: null args");
+    LAS_ARG(part >= 1 && part <= 3, "las_speller_bwd_part: part must be 1 (loop + input gradients), 2 (parameter gradients) or 3");
     DecDev d;
     if (int rc = fill_dev(&bk->f, d)) return rc;
     LAS_ARG(bk->dlogits && bk->d_enc && bk->d_keys && bk->dWs && bk->du && bk->demb && bk->dWv && bk->dbv && bk->dcellW && bk->dcellb,
@@ -1886,6 +1892,6 @@ extern "C" int las_speller_bwd(const las_speller_bwd_args* bk, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool fast = bk->f.prec == LAS_PREC_BF16;
     if (bk->f.cell == LAS_CELL_LSTM)
-        return fast ? speller_bwd_impl<LAS_CELL_LSTM, true>(bk, d, st) : speller_bwd_impl<LAS_CELL_LSTM, false>(bk, d, st);
-    return fast ? speller_bwd_impl<LAS_CELL_RNN, true>(bk, d, st) : speller_bwd_impl<LAS_CELL_RNN, false>(bk, d, st);
+        return fast ? speller_bwd_impl<LAS_CELL_LSTM, true>(bk, d, part, st) : speller_bwd_impl<LAS_CELL_LSTM, false>(bk, d, part, st);
+    return fast ? speller_bwd_impl<LAS_CELL_RNN, true>(bk, d, part, st) : speller_bwd_impl<LAS_CELL_RNN, false>(bk, d, part, st);
 }

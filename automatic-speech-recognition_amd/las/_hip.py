@@ -61,6 +61,7 @@ _SIGS = {
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
+    "las_speller_bwd_part": (c_int, [POINTER(SpellerBwdArgs), c_int, c_void_p]),
     "las_ce_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "las_ce_loss": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -27,6 +27,14 @@ class Listener:
     def __init__(self, args):
         self.args = args
 
+    def output_length(self, audiolen, encoder='cnn'):
+        """Encoder frame counts after the time halvings (pblstm: one per pyramid layer, las/layers.py:94; cnn: the
+        two stride-2 convolutions, las/layers.py:127-129), float64 on the host as the reference computes them."""
+        n = torch.as_tensor(audiolen).to(torch.float64)
+        for _ in range(self.args.num_enc_layers if encoder == 'pblstm' else 2):
+            n = (n + n % 2) / 2
+        return n
+
     def __call__(self, inputs, audiolen, encoder='cnn', is_training=True):
         if encoder == 'pblstm':
             x = inputs.reshape(inputs.shape[0], -1, self.args.feat_dim * 3)            # las/las.py:14
@@ -148,15 +156,24 @@ class _SpellerLoop(torch.autograd.Function):
         A = Wh.shape[1]
         NL, U, V_ = dims["NL"], dims["U"], dims["V"]
         dlogits = dlogits.contiguous()
-        z = lambda t: torch.zeros_like(t)
-        d_enc = torch.zeros(B, Tp, Hd, device=dev)
-        d_keys = torch.zeros(B, Tp, A, device=dev)
-        g = {"Ws": z(P["Ws"]), "u": z(P["u"]), "emb": z(P["emb"]), "Wv": z(P["Wv"]), "bv": z(P["bv"])}
         loc = dims["mode"] == _hip.ATT_LOC
-        if loc:
-            g.update(loc_w=z(P["loc_w"]), loc_b=z(P["loc_b"]), Wf=z(P["Wf"]))
-        dcW = [z(t) for t in P["cellW"]]
-        dcb = [z(t) for t in P["cellb"]]
+        names = ["Ws", "u", "emb", "Wv", "bv"] + (["loc_w", "loc_b", "Wf"] if loc else [])
+        plist = [P[k] for k in names] + list(P["cellW"]) + list(P["cellb"]) + [Wh]
+        # parameter gradients accumulate (+=) straight into the flat gradient bucket when the store is flattened;
+        # they are off the dependency chain, so they run on the side stream while the Listener's BPTT proceeds
+        direct = all(L._direct_ok(p) for p in plist)
+        sizes = [B * Tp * Hd, B * Tp * A] + ([] if direct else [p.numel() for p in plist])
+        zbuf = torch.zeros(sum(sizes), device=dev)                       # ONE fill for every caller-zeroed buffer
+        views, o = [], 0
+        for n in sizes:
+            views.append(zbuf[o:o + n])
+            o += n
+        d_enc, d_keys = views[0].view(B, Tp, Hd), views[1].view(B, Tp, A)
+        gl = [p.grad for p in plist] if direct else [v.view(p.shape) for v, p in zip(views[2:], plist)]
+        g = dict(zip(names, gl))
+        dcW = gl[len(names):len(names) + NL]
+        dcb = gl[len(names) + NL:len(names) + 2 * NL]
+        dWh = gl[-1]
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], V_, U, dims["cell"])
         ws = _hip.workspace(dev, nbytes, "speller")
         ba = _hip.SpellerBwdArgs()
@@ -170,13 +187,24 @@ class _SpellerLoop(torch.autograd.Function):
             ba.dloc_w, ba.dloc_b, ba.dWf = g["loc_w"].data_ptr(), g["loc_b"].data_ptr(), g["Wf"].data_ptr()
         keep = (_ptr_array(dcW), _ptr_array(dcb))
         ba.dcellW, ba.dcellb = keep
+        lib = _hip.lib()
         with _hip._timed("speller_bwd[U=%d]" % dims["U"]):
-            _hip.check(_hip.lib().las_speller_bwd(ctypes.byref(ba), _hip.stream()), "las_speller_bwd")
-        del keep, keepf
-        # key projection backward (K4): dWh = enc^T . d_keys ; d_enc += d_keys . Wh^T
-        dWh = torch.empty_like(Wh)
-        _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A)
+            _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 1, _hip.stream()), "las_speller_bwd_part(1)")
+        # key projection backward (K4), input side: d_enc += d_keys . Wh^T
         _hip.gemm(prec, d_keys, Wh, d_enc, False, True, B * Tp, Hd, A, A, A, Hd, beta=1.0)
+        if direct:
+            with _hip.on_side_stream():
+                side = _hip.side_stream()
+                for t in [enc, keys, dlogits, d_keys, ws, tokens_in, zbuf] + [v for v in bufs.values() if v is not None] + \
+                        ([emb_mask] if emb_mask is not None else []):
+                    t.record_stream(side)
+                _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
+                _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)     # dWh += enc^T . d_keys
+            del keep, keepf
+            return (d_enc, None, None, None, None, None, None, None, None, None, None, None, None, *([None] * (2 * NL)))
+        _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
+        _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)
+        del keep, keepf
         return (d_enc, dWh, g["Ws"], g["u"], g["emb"], g["Wv"], g["bv"], g.get("loc_w"), g.get("loc_b"), g.get("Wf"),
                 None, None, None, *dcW, *dcb)
 
@@ -248,21 +276,16 @@ class Speller:
         return float(min(np.float32(1.0), np.float32(1.0) - np.float32(progress) * np.float32(1.0 - a.min_rate)))
 
     # -- the loop ----------------------------------------------------------------------------------
-    def __call__(self, enc_out, enc_len, dec_steps, teacher=None, is_training=True, coins=None, sampled=None):
-        """reference las/las.py:72-143.  Returns (logits [B,U,V], ctc_logits, alphas [B,U,T']).
-
-        coins / sampled are test hooks: coins[t] True = teacher forcing at step t (one scalar coin
-        per step for the whole batch, las/las.py:101); sampled [B,U] supplies the Categorical draws."""
+    def prepare(self, B, enc_len, dec_steps, dev, teacher=None, is_training=True, coins=None, sampled=None):
+        """Host-side half of the decode loop: token schedule (teacher forcing / scheduled-sampling coins,
+        las/las.py:87-101), encoder lengths on the device, dropout mask.  LAS.train calls this BEFORE it enqueues the
+        Listener so that the small host->device copies and the Python work overlap with the encoder kernels."""
         a = self.args
-        _hip.require_gpu(enc_out)
-        if a.ctc:
-            raise NotImplementedError("CTC head (las/las.py:75-77,335-349): README 'not yet fully tested', out of scope (SURVEY T5)")
-        if a.add_vn:
-            raise NotImplementedError("variational noise (las/las.py:164-166) is not built yet")
-        dev = enc_out.device
-        B, Tp, _ = enc_out.shape
         U = int(dec_steps)
-        enc_len_i32 = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).to(dev).contiguous()   # las/layers.py:193
+        if torch.is_tensor(enc_len) and enc_len.is_cuda and enc_len.dtype == torch.int32:
+            enc_len_i32 = enc_len.contiguous()
+        else:
+            enc_len_i32 = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).to(dev).contiguous()   # las/layers.py:193
         st = V.default_store()
         tokens_in = torch.full((U, B), -1, dtype=torch.int32, device=dev)
         tokens_in[0] = SOS_ID
@@ -285,7 +308,6 @@ class Speller:
                     else:
                         tokens_in[idx] = -2
             step_logits = bool((tokens_in < 0).any().item()) if not coins[:max(U - 1, 0)].all() else False
-        P = self._params()
         emb_mask = None
         if is_training and a.dropout_rate:
             # tf.layers.dropout on the embedded input token of every step (las/las.py:107-108); step 0's SOS
@@ -293,6 +315,30 @@ class Speller:
             keep = 1.0 - float(a.dropout_rate)
             emb_mask = (torch.rand(U, B, a.embedding_size, device=dev) < keep).to(torch.float32) / keep
             emb_mask[0] = 1.0
+        return {"B": B, "U": U, "enc_len_i32": enc_len_i32, "tokens_in": tokens_in, "step_logits": step_logits,
+                "emb_mask": emb_mask}
+
+    def __call__(self, enc_out, enc_len, dec_steps, teacher=None, is_training=True, coins=None, sampled=None, prepared=None):
+        """reference las/las.py:72-143.  Returns (logits [B,U,V], ctc_logits, alphas [B,U,T']).
+
+        coins / sampled are test hooks: coins[t] True = teacher forcing at step t (one scalar coin
+        per step for the whole batch, las/las.py:101); sampled [B,U] supplies the Categorical draws."""
+        a = self.args
+        _hip.require_gpu(enc_out)
+        if a.ctc:
+            raise NotImplementedError("CTC head (las/las.py:75-77,335-349): README 'not yet fully tested', out of scope (SURVEY T5)")
+        if a.add_vn:
+            raise NotImplementedError("variational noise (las/las.py:164-166) is not built yet")
+        dev = enc_out.device
+        B, Tp, _ = enc_out.shape
+        U = int(dec_steps)
+        st = V.default_store()
+        if prepared is None:
+            prepared = self.prepare(B, enc_len, U, dev, teacher, is_training, coins, sampled)
+        assert prepared["B"] == B and prepared["U"] == U
+        enc_len_i32, tokens_in = prepared["enc_len_i32"], prepared["tokens_in"]
+        step_logits, emb_mask = prepared["step_logits"], prepared["emb_mask"]
+        P = self._params()
         cfg = (self._dims(B, Tp, U), L._prec(), step_logits, 977 + st.global_step, emb_mask)
         cp = list(P["cellW"]) + list(P["cellb"])
         logits_tm, alphas_tm = _SpellerLoop.apply(enc_out, P["Wh"], P["Ws"], P["u"], P["emb"], P["Wv"], P["bv"],
@@ -513,8 +559,11 @@ class LAS:
         y = self._to_dev(y, dev, torch.int32)
         dec_steps = int(torch.as_tensor(tokenlen).max())                                  # las/las.py:248
         enc_type = self.args.enc_type.lower()
+        # the Speller's host-side preparation first: its small uploads overlap with the Listener kernels
+        prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
+                                    True, coins, sampled)
         h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)                  # is_training default True
-        logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled)
+        logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
         n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
         n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local

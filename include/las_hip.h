@@ -150,6 +150,11 @@ typedef struct {
     float* const* dcellW; float* const* dcellb;              /* host arrays [NL] of device ptrs */
 } las_speller_bwd_args;
 int las_speller_bwd(const las_speller_bwd_args* a, void* stream);
+/* The same in two launches so that the caller can take the parameter gradients off the dependency chain:
+ *   part 1 = the reverse loop and the input gradients (d_enc, d_keys);
+ *   part 2 = every parameter gradient (reads what part 1 left in `ws`, `gates`, `xin0`, `hs`; may run on another
+ *            stream ordered after part 1);   part 3 = both (= las_speller_bwd). */
+int las_speller_bwd_part(const las_speller_bwd_args* a, int part, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K8  LAS._get_loss (las/las.py:320-333) + label_smoothing (las/utils.py:5-12), forward and
