@@ -285,7 +285,15 @@ class Speller:
         if torch.is_tensor(enc_len) and enc_len.is_cuda and enc_len.dtype == torch.int32:
             enc_len_i32 = enc_len.contiguous()
         else:
-            enc_len_i32 = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).to(dev).contiguous()   # las/layers.py:193
+            # float -> int32 as tf.sequence_mask's cast does (las/layers.py:193); uploaded from a small ring of pinned
+            # staging buffers with a non-blocking copy, so the host is not held until the stream drains
+            host = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).reshape(-1)
+            ring = self.__dict__.setdefault("_pin_ring", {})
+            slot = ring.setdefault(host.numel(), [[torch.empty(host.numel(), dtype=torch.int32).pin_memory() for _ in range(4)], 0])
+            pin = slot[0][slot[1] % 4]
+            slot[1] += 1
+            pin.copy_(host)
+            enc_len_i32 = pin.to(dev, non_blocking=True)
         st = V.default_store()
         tokens_in = torch.full((U, B), -1, dtype=torch.int32, device=dev)
         tokens_in[0] = SOS_ID
