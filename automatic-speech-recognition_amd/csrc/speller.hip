@@ -1373,19 +1373,27 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
     const float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     const int len = a.enc_len[b];
-    uint4 e8[NE];
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
-        e8[u] = reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + t2c) * H8 + l8c];
-    }
-    uint4 k8[3];
+    // encoder rows for dalpha: 16-lane group per frame (3 frames per group), lane a8 covers column chunks a8 + 16 i
+    uint4 e8[3][4];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
+            e8[u][i] = reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + ttc) * H8 + hcc];
+        }
     }
-    const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
+    // keys for the energies gradient: one column pair per lane, one frame per wave and round (sums over frames stay
+    // inside the lane, no cross-lane reduction)
+    const int A2 = A >> 1, c2c = lane < A2 ? lane : A2 - 1;
+    unsigned k2[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
+        k2[u] = reinterpret_cast<const unsigned*>(a.keysbf)[((size_t)b * Tp + t2c) * A2 + c2c];
+    }
+    const float2 u2 = reinterpret_cast<const float2*>(a.u)[c2c];
     // cell part operands (saved by the forward pass)
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dcr = 0.f;
     float* gp = a.gates + (((size_t)0 * U + tcl) * B + b) * GD;
@@ -1410,18 +1418,25 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         if (tid < A) L.qv[tid] = qd;
         lds_barrier();
     STAMPX(12);
-        {   // dalpha[t'] = dctx . enc[b,t',:] : one wave per frame, 8 columns (4 pairs) per lane
-            const uint4 d4 = lane < H8 ? reinterpret_cast<const uint4*>(dcp)[lane] : make_uint4(0u, 0u, 0u, 0u);
+        {   // dalpha[t'] = dctx . enc[b,t',:] : 16-lane group per frame, packed pairs along the columns
+            float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                const int t2 = wv + RNW * u;
-                float acc = dot2bf(e8[u].x, d4.x, 0.f);
-                acc = dot2bf(e8[u].y, d4.y, acc); acc = dot2bf(e8[u].z, d4.z, acc); acc = dot2bf(e8[u].w, d4.w, acc);
-                acc = wave_sum(acc);
-                if (lane == 0 && t2 < Tp) dal[t2] = t2 < lim ? acc : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int hc = a8 + 16 * i;
+                const uint4 d4 = hc < H8 ? reinterpret_cast<const uint4*>(dcp)[hc] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    acc[u] = dot2bf(e8[u][i].x, d4.x, acc[u]); acc[u] = dot2bf(e8[u][i].y, d4.y, acc[u]);
+                    acc[u] = dot2bf(e8[u][i].z, d4.z, acc[u]); acc[u] = dot2bf(e8[u][i].w, d4.w, acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tt = grp + 64 * u;
+                const float v = sub16_sum(acc[u]);
+                if (a8 == 0 && tt < Tp) dal[tt] = tt < lim ? v : 0.f;
             }
         }
-    STAMPX(13);
         // the state-gradient operand: issued now (the encoder registers are free), consumed after the energies
         uint4 w8[8];
 #pragma unroll
@@ -1450,37 +1465,20 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         if (tid < Tp) dal[tid] = de_own;
         lds_barrier();
     STAMPX(15);
-        float du_acc[8], dq_acc[8];
-        {   // energies backward from the prefetched keys
-            const float u8[8] = {u40.x, u40.y, u40.z, u40.w, u41.x, u41.y, u41.z, u41.w};
-            float q8[8];
+        {   // energies backward: sums over this wave's frames stay in the lane (columns 2*lane, 2*lane+1)
+            const float q0 = L.qv[2 * c2c], q1 = L.qv[2 * c2c + 1];
+            float du0 = 0.f, du1 = 0.f, dq0 = 0.f, dq1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f; du_acc[e] = 0.f; dq_acc[e] = 0.f; }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int tt = grp + 64 * u;
-                if (tt < lim) {
-                    const float de = dal[tt];
-                    float k[8];
-                    unpack8(k8[u], k);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = tanhx<FAST>(k[e] + q8[e]);
-                        du_acc[e] = fmaf(de, v, du_acc[e]);
-                        dq_acc[e] = fmaf(de * u8[e], 1.f - v * v, dq_acc[e]);
-                    }
-                }
+            for (int u = 0; u < NE; ++u) {
+                const int t2 = wv + RNW * u;
+                const float de = t2 < lim ? dal[t2] : 0.f;
+                const float v0 = tanhx<FAST>(__uint_as_float(k2[u] << 16) + q0), v1 = tanhx<FAST>(__uint_as_float(k2[u] & 0xffff0000u) + q1);
+                du0 = fmaf(de, v0, du0); du1 = fmaf(de, v1, du1);
+                dq0 = fmaf(de * u2.x, 1.f - v0 * v0, dq0); dq1 = fmaf(de * u2.y, 1.f - v1 * v1, dq1);
             }
-        }
-    STAMPX(16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = dq_acc[e], w = du_acc[e];
-            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            w += __shfl_xor(w, 16, 64); w += __shfl_xor(w, 32, 64);
-            if (lane < 16 && a8 < A8) {
-                L.scr[wv * 2 * A + a8 * 8 + e] = v;
-                L.scr[wv * 2 * A + A + a8 * 8 + e] = w;
+            if (lane < A2) {
+                reinterpret_cast<float2*>(L.scr + wv * 2 * A)[lane] = make_float2(dq0, dq1);
+                reinterpret_cast<float2*>(L.scr + wv * 2 * A + A)[lane] = make_float2(du0, du1);
             }
         }
         lds_barrier();
