@@ -160,10 +160,16 @@ class on_side_stream:
     """Run the enclosed launches on the side stream, after everything already enqueued on the current stream.
     Tensors touched inside must be kept alive by the caller (record_stream)."""
 
+    def __init__(self, after=None):
+        self.after = after          # optional event: order the side work after it instead of after the whole stream
+
     def __enter__(self):
         global _side_used, _on_side
         self.ctx = torch.cuda.stream(side_stream())
-        side_stream().wait_stream(torch.cuda.current_stream())
+        if self.after is not None:
+            side_stream().wait_event(self.after)
+        else:
+            side_stream().wait_stream(torch.cuda.current_stream())
         self.ctx.__enter__()
         _side_used = True
         _on_side = True
@@ -175,9 +181,25 @@ class on_side_stream:
         return self.ctx.__exit__(*exc)
 
 
+_deferred = []
+
+
+def defer_side(fn):
+    """Queue host work that only feeds the side stream (parameter gradients).  It is run by the NEXT backward node
+    after that node has enqueued its own dependency-chain kernels (run_deferred), so the host time it costs does
+    not sit between two chain kernels."""
+    _deferred.append(fn)
+
+
+def run_deferred():
+    while _deferred:
+        _deferred.pop(0)()
+
+
 def join_side_stream():
     """Make the current stream wait for all side-stream work (call before the gradients are consumed)."""
     global _side_used
+    run_deferred()
     if _side_used:
         torch.cuda.current_stream().wait_stream(side_stream())
         _side_used = False

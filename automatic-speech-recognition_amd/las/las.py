@@ -193,14 +193,21 @@ class _SpellerLoop(torch.autograd.Function):
         # key projection backward (K4), input side: d_enc += d_keys . Wh^T
         _hip.gemm(prec, d_keys, Wh, d_enc, False, True, B * Tp, Hd, A, A, A, Hd, beta=1.0)
         if direct:
-            with _hip.on_side_stream():
+            main_done = torch.cuda.Event()
+            main_done.record()
+            held = [enc, keys, dlogits, d_keys, ws, tokens_in, zbuf] + [v for v in bufs.values() if v is not None] + \
+                   ([emb_mask] if emb_mask is not None else [])
+
+            def side_part(ba=ba, keep=(keep, keepf), held=held):
+                # runs after the next backward node has enqueued its chain kernels (_hip.run_deferred)
                 side = _hip.side_stream()
-                for t in [enc, keys, dlogits, d_keys, ws, tokens_in, zbuf] + [v for v in bufs.values() if v is not None] + \
-                        ([emb_mask] if emb_mask is not None else []):
-                    t.record_stream(side)
-                _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
-                _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)     # dWh += enc^T . d_keys
-            del keep, keepf
+                with _hip.on_side_stream(after=main_done):
+                    for t in held:
+                        t.record_stream(side)
+                    _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
+                    _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)  # dWh += enc^T . d_keys
+
+            _hip.defer_side(side_part)
             return (d_enc, None, None, None, None, None, None, None, None, None, None, None, None, *([None] * (2 * NL)))
         _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
         _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)
@@ -567,18 +574,19 @@ class LAS:
         y = self._to_dev(y, dev, torch.int32)
         dec_steps = int(torch.as_tensor(tokenlen).max())                                  # las/las.py:248
         enc_type = self.args.enc_type.lower()
+        # everything that does not depend on the encoder goes first, off the chain between the decode loop and its
+        # gradient: gradient bucket reset, global token count (one small all-reduce under data parallelism)
+        st.flatten()
+        st.zero_grad()
+        n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
+        n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
         # the Speller's host-side preparation first: its small uploads overlap with the Listener kernels
         prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
                                     True, coins, sampled)
         h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)                  # is_training default True
         logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
-        n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
-        n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
         loss = self._get_loss(logits, y, n_total)                                         # sum_local / n_total
-
-        st.flatten()
-        st.zero_grad()
         loss.backward()
         _hip.join_side_stream()                       # weight gradients accumulated on the side stream
         if self.dp is not None:

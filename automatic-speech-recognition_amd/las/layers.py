@@ -77,6 +77,7 @@ class _Dense(torch.autograd.Function):
             dx = torch.empty_like(x2d)
             _hip.gemm(ctx.prec, dpre, W, dx, False, True, M, K, N, N, N, K)
         Wp, bp = ctx.params
+        _hip.run_deferred()          # side-stream work queued by the previous node: its host cost lands here, off the chain
         if _direct_ok(Wp) and (bp is None or _direct_ok(bp)):
             # off the chain: accumulate straight into the flat gradient bucket on the side stream, overlapping
             # with the next layer's BPTT sweep (which occupies only a few dozen CUs)
@@ -161,6 +162,7 @@ class _BLSTM(torch.autograd.Function):
             for d, k in enumerate((kfw, kbw)):
                 _hip.gemm(prec, gates, k, dx, False, True, B * T, I, GH, 2 * GH, GH, I, beta=1.0 if d else 0.0, a_off=d * GH)
         P4 = ctx.params
+        _hip.run_deferred()
         if P4 is not None and all(_direct_ok(p) for p in P4):
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
             with _hip.on_side_stream():
