@@ -492,8 +492,12 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     // tile configuration
     int BM, BN;
     int cfg;
+    // branch-free fast path: 16-byte loads legal, k (or row) counts multiples of 4, no contraction mask
+    const bool fastA = g.vecA && (g.ksA == 1 ? (K % 4 == 0) : (M % 4 == 0 && M >= 4));
+    const bool fastB = g.vecB && (g.ksB == 1 ? (K % 4 == 0) : (N % 4 == 0 && N >= 4));
+    const bool fast_ok = prec == LAS_PREC_BF16 && fastA && fastB && a_mask_period == 0 && K > 0;
     if (prec == LAS_PREC_F32) { cfg = 0; BM = 64; BN = 64; }
-    else if (M <= 48)         { cfg = 3; BM = 48; BN = 64; }
+    else if (M <= 48 && !(fast_ok && K >= 4096)) { cfg = 3; BM = 48; BN = 64; }   // tall contractions: 64-row fast tiles win
     else if (M < 128 || N < 128) { cfg = 2; BM = 64; BN = 64; }
     else                      { cfg = 1; BM = 128; BN = 128; }
     const long long tiles = (long long)cdiv(M, BM) * cdiv(N, BN);
@@ -515,10 +519,7 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     if (K == 0 && g.splitk == 1) {
         // empty contraction: C = act(beta*C + bias); run the kernel with no k-tiles
     }
-    // branch-free fast path: 16-byte loads legal, k (or row) counts multiples of 4, no contraction mask
-    const bool fastA = g.vecA && (g.ksA == 1 ? (K % 4 == 0) : (M % 4 == 0 && M >= 4));
-    const bool fastB = g.vecB && (g.ksB == 1 ? (K % 4 == 0) : (N % 4 == 0 && N >= 4));
-    if (prec == LAS_PREC_BF16 && fastA && fastB && a_mask_period == 0 && K > 0 && (cfg == 1 || cfg == 2)) {
+    if (fast_ok && (cfg == 1 || cfg == 2)) {
         if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
         else          launch_fast<2, 2, 2, 2>(g, zdim, st);
         LAS_LAUNCHED();

@@ -130,37 +130,44 @@ class _BLSTM(torch.autograd.Function):
         GH = G * H
         dev = x.device
         x = x.contiguous()
+        Ik = I
+        if prec == _hip.PREC_BF16 and I % 4 and (I + 3) // 4 * 4 <= I + H:
+            # MFCC-39: pad the operand with zero columns up to a multiple of 4 so the contraction takes the branch-free
+            # MFMA path (16-byte loads).  The extra weight rows it meets are the first rows of W_hh: multiplied by zeros
+            # here, and given an exactly-zero gradient contribution in backward.
+            Ik = (I + 3) // 4 * 4
+            x = torch.nn.functional.pad(x, (0, Ik - I))
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=torch.float32)
         for d, (k, b) in enumerate(((kfw, bfw), (kbw, bbw))):
             # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H])
-            _hip.gemm(prec, x, k, gates, False, False, B * T, GH, I, I, GH, 2 * GH, bias=b, c_off=d * GH)
+            _hip.gemm(prec, x, k, gates, False, False, B * T, GH, Ik, Ik, GH, 2 * GH, bias=b, c_off=d * GH)
         Tp = T + (T % 2) if pad_even else T
         out = torch.zeros(B, Tp, 2 * H, device=dev) if Tp != T else torch.empty(B, T, 2 * H, device=dev)
         cst = torch.empty(B, T, 2, H, device=dev) if cell == "lstm" else None
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          1.0, wf_off=I * GH, wb_off=I * GH)
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst)
-        ctx.cfg = (cell, prec, H, Tp)
+        ctx.cfg = (cell, prec, H, Tp, I)
         ctx.params = _PARAMS.get("blstm")
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, kfw, kbw, gates, out, cst = ctx.saved_tensors
-        cell, prec, H, Tp = ctx.cfg
-        B, T, I = x.shape
+        cell, prec, H, Tp, I0 = ctx.cfg
+        B, T, I = x.shape                              # I = operand width (I0 padded to a multiple of 4 in speed mode)
         G = 4 if cell == "lstm" else 1
         GH = G * H
         dev = x.device
         dout = dout.contiguous()
         # gates: activated gates -> d(pre-activation), in place
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
-                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I * GH, wb_off=I * GH)
+                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH)
         grads = []
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(B, T, I0, device=dev) if ctx.needs_input_grad[0] else None
         if dx is not None:                             # on the dependency chain: main stream, first
             for d, k in enumerate((kfw, kbw)):
-                _hip.gemm(prec, gates, k, dx, False, True, B * T, I, GH, 2 * GH, GH, I, beta=1.0 if d else 0.0, a_off=d * GH)
+                _hip.gemm(prec, gates, k, dx, False, True, B * T, I0, GH, 2 * GH, GH, I0, beta=1.0 if d else 0.0, a_off=d * GH)
         P4 = ctx.params
         _hip.run_deferred()
         if P4 is not None and all(_direct_ok(p) for p in P4):
@@ -179,7 +186,7 @@ class _BLSTM(torch.autograd.Function):
                         b_off = d * GH + (2 * GH if d == 0 else 0)
                         _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
                                   strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
-                        _hip.colsum(part, B, H * GH, H * GH, gk[I:].reshape(-1), beta=1.0)
+                        _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
                     _hip.colsum(gates, B * T, GH, 2 * GH, bp.grad, beta=1.0, x_off=d * GH)
             return (dx, None, None, None, None, None, None, None, None)
         part = torch.empty(B, H, GH, device=dev) if T > 1 else None
@@ -196,9 +203,9 @@ class _BLSTM(torch.autograd.Function):
                           strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
                 whh = torch.empty(H * GH, device=dev)
                 _hip.colsum(part, B, H * GH, H * GH, whh)
-                dk[I:] = whh.view(H, GH)
+                dk[I0:] = whh.view(H, GH)
             else:
-                dk[I:] = 0
+                dk[I0:] = 0
             db = torch.empty(GH, device=dev)
             _hip.colsum(gates, B * T, GH, 2 * GH, db, x_off=d * GH)
             grads += [dk, db]
