@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 CASES = [
     ("rnn", 0, 5, 7, 48), ("lstm", 0, 5, 7, 48), ("rnn", 0, 9, 12, 100), ("lstm", 0, 17, 9, 64),
     ("rnn", 1, 5, 7, 64), ("lstm", 1, 5, 7, 64), ("rnn", 1, 20, 33, 128), ("lstm", 1, 20, 33, 128),
-    ("rnn", 1, 48, 40, 256), ("lstm", 1, 48, 40, 256), ("lstm", 0, 48, 20, 256), ("rnn", 1, 3, 5, 512),
+    ("rnn", 1, 48, 40, 256), ("lstm", 1, 48, 40, 256), ("lstm", 0, 48, 20, 256), ("rnn", 1, 3, 5, 512), ("lstm", 1, 37, 23, 256), ("lstm", 1, 3, 1, 256),
 ]
 
 
