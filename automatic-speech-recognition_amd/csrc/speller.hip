@@ -625,6 +625,7 @@ template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
     extern __shared__ __attribute__((aligned(16))) float sm[];
     STAMPX(0);
     const BfLds L = carve_bf(sm, a);
@@ -660,9 +661,9 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kpc * A4 + a4c];
     }
     const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
-    uint4 k8[3];
+    uint4 k8[NK];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NK; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
     }
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NK; ++u) {
             const int tt = grp + 64 * u;
             float part = 0.f;
             if (tt < len && tt < Tp) {
@@ -778,11 +779,16 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     }
     lds_barrier();
     STAMPX(5);
-    if (wv < 2) {   // softmax statistics per wave (T' <= 192: three frames per lane); waves 0-1 own the alpha pairs
-        float e0 = lane < Tp ? L.ev[lane] : -INFINITY, e1 = lane + 64 < Tp ? L.ev[lane + 64] : -INFINITY;
-        float e2 = lane + 128 < Tp ? L.ev[lane + 128] : -INFINITY;
-        const float m = wave_max(fmaxf(e0, fmaxf(e1, e2)));
-        const float ssum = wave_sum(expf(e0 - m) + expf(e1 - m) + expf(e2 - m));
+    if (wv < 2) {   // softmax statistics per wave (NK frames per lane); waves 0-1 own the alpha pairs (T'/2 <= 128)
+        float ev_[NK];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) { ev_[j] = lane + 64 * j < Tp ? L.ev[lane + 64 * j] : -INFINITY; m = fmaxf(m, ev_[j]); }
+        m = wave_max(m);
+        float ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) ssum += expf(ev_[j] - m);
+        ssum = wave_sum(ssum);
         const float inv = 1.0f / ssum;
         if (tid < Tp2) {
             const int i0 = 2 * tid, i1 = 2 * tid + 1;
@@ -1349,6 +1355,7 @@ template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
     extern __shared__ __attribute__((aligned(16))) float sm[];
     STAMPX(10);
     const BfLds L = carve_bf(sm, a);
@@ -1374,9 +1381,9 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     const float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     const int len = a.enc_len[b];
     // encoder rows for dalpha: 16-lane group per frame (3 frames per group), lane a8 covers column chunks a8 + 16 i
-    uint4 e8[3][4];
+    uint4 e8[NK][4];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NK; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1419,19 +1426,21 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         lds_barrier();
     STAMPX(12);
         {   // dalpha[t'] = dctx . enc[b,t',:] : 16-lane group per frame, packed pairs along the columns
-            float acc[3] = {0.f, 0.f, 0.f};
+            float acc[NK];
+#pragma unroll
+            for (int u = 0; u < NK; ++u) acc[u] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hc = a8 + 16 * i;
                 const uint4 d4 = hc < H8 ? reinterpret_cast<const uint4*>(dcp)[hc] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < NK; ++u) {
                     acc[u] = dot2bf(e8[u][i].x, d4.x, acc[u]); acc[u] = dot2bf(e8[u][i].y, d4.y, acc[u]);
                     acc[u] = dot2bf(e8[u][i].z, d4.z, acc[u]); acc[u] = dot2bf(e8[u][i].w, d4.w, acc[u]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < NK; ++u) {
                 const int tt = grp + 64 * u;
                 const float v = sub16_sum(acc[u]);
                 if (a8 == 0 && tt < Tp) dal[tt] = tt < lim ? v : 0.f;
@@ -1448,10 +1457,10 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         lds_barrier();
     STAMPX(14);
         float de_own = 0.f;
-        if (wv < 3) {   // T' <= 192: the first three waves own one frame per lane; each sums alpha . dalpha for itself
+        if (wv < NK) {   // the first NK waves own one frame per lane; each sums alpha . dalpha for itself
             float dot = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NK; ++j) {
                 const int i = lane + 64 * j;
                 if (i < Tp) dot = fmaf(L.ev[i], dal[i], dot);
             }
@@ -1666,7 +1675,7 @@ static bool bf_rows_ok(const DecDev& d) {
 // ... and, for the common single-layer geometry, the fully prefetching variants
 static bool pf_rows_ok(const DecDev& d) {
     const char* off = getenv("LAS_NO_PF_ROWS");
-    return !(off && off[0] == '1') && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 192 && d.E <= 1024 &&
+    return !(off && off[0] == '1') && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 && d.E <= 1024 &&
            (d.E % 2) == 0 && (d.D % 2) == 0;
 }
 static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
@@ -1716,7 +1725,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     for (int t = 0; t <= U; ++t) {
         if (pf && d.Tp <= 128)          hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
-        else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (bfrows && d.A <= 128)  hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (bfrows)                hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 2>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);
@@ -1808,7 +1818,8 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         const int ta = (t + 1 < U) ? t + 1 : -1;
         if (pf && Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf && Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
-        else if (pf)              hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        else if (pf && Tp <= 192) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        else if (pf)              hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (bfrows && A <= 128) hipLaunchKernelGGL((dec_step_bwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         else if (bfrows) hipLaunchKernelGGL((dec_step_bwd_bf_kernel<CELL, 2>), dim3(B), dim3(RNT), lds_bf, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         else if (loc) hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);

@@ -52,6 +52,9 @@ def _run(no_bf_rows, NL, D, A, Hd2, B, Tp, U, mixed):
     (1, 512, 128, 256, 5, 37, 9, False),      # the bench geometry at small B / T' / U
     (2, 64, 32, 64, 4, 21, 7, True),          # multi-layer state, sampled tokens (in-loop logits)
     (1, 96, 136, 36, 3, 70, 5, False),        # attention width > 128 (two 16-byte chunks per lane), ragged sizes
+    (1, 128, 64, 64, 3, 181, 4, False),       # T' in (160, 192]: 12 frames per wave
+    (1, 128, 64, 64, 2, 214, 3, True),        # T' in (192, 224]: 14 frames per wave, 4 frames per 16-lane group
+    (1, 64, 32, 32, 2, 230, 3, False),        # T' > 224: generic bf16 row kernels
 ])
 def test_bf16_row_kernels_match_fp32_operand_rows(shape):
     NL, D, A, H, B, Tp, U, mixed = shape
