@@ -277,7 +277,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (BM + BN) * LDK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  All column tiles of one row block
+    // go to the same XCD back to back, so the row block of A is fetched into that L2 once instead of once per XCD.
+    // (Only for tall outputs: with fewer than a few row blocks per XCD the plain 2-D order fills the chip better.)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y == 1 && g.M > BM) {
+        const int nx = (g.N + BN - 1) / BN, ny = (g.M + BM - 1) / BM;
+        const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
+        by = xcd + 8 * (li / nx); bx = li % nx;
+        if (by >= ny) return;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const float* A = g.A;
     const float* B = g.B;
     float* C = g.C;
@@ -351,7 +361,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
 template <int WM, int WN, int TM, int TN>
 static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), zdim), blk(WM * WN * 64);
+    const int nx = cdiv(g.N, BN), ny = cdiv(g.M, BM);
+    const bool xcd_order = ny >= 64 && zdim == 1;        // tall output: 1-D grid, row blocks padded to 8, XCD-aware order
+    dim3 grid(xcd_order ? nx * ((ny + 7) / 8 * 8) : nx, xcd_order ? 1 : ny, zdim), blk(WM * WN * 64);
     const bool akc = g.ksA == 1, bkc = g.ksB == 1;
     if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, g);
     else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, g);
