@@ -122,6 +122,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the driver stack may print to fd 1 while the device is initialised (libdrm's "amdgpu.ids" notice): keep stdout
+    # for the ONE JSON line by pointing fd 1 at stderr until the result is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
@@ -221,7 +226,7 @@ def main():
             # WRITE_SIZE in separate passes; tools/pmc_summary.py); null when no recording matches the configuration
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_final_pmc.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_c_pmc.json")))
                 if a.cell == "lstm" and a.dtype == "bf16" and B == 48 and T == 1274:
                     key = [k for k in pmc if k.startswith("rnn_seq_bwd" if bwd else "rnn_seq_fwd")]
                     if key:
@@ -252,7 +257,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cell)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dp is not None:
         dist.barrier()
         dist.destroy_process_group()
