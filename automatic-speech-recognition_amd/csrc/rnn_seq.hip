@@ -30,6 +30,7 @@ struct RnnArgs {
     long long* dbg;   // LAS_PROF builds only: device buffer for s_memtime stamps (env LAS_DBG_PTR)
     unsigned long long* xbuf; int* err;     // cluster exchange granules / bounded-spin error flag
     unsigned long long* xcc;                 // [cluster][member] placement handshake granules (zeroed per launch)
+    float* bpart;                            // BPTT: [cluster][G*H] column sums of d(pre-activation) over the tile's rows and all steps
     int force_agent;                         // env LAS_AGENT_GRANULES=1: never use the same-XCD transport
     float* sink;                             // scratch rows for the padded part of a ragged batch tile
     int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
@@ -776,6 +777,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     gcfloat* optr[4];
     gcfloat* dptr[4];
     long long gst[4], cst_[4], ost[4], dst[4];
+    float vrow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = b0 + g * 4 + r;
@@ -787,7 +789,13 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         optr[r] = GCF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
         dptr[r] = GCF(valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
+        vrow[r] = valid ? 1.f : 0.f;
     }
+    float bsum[G][UTP];                      // bias gradient: column sums of dz over this lane's rows and all steps
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int j = 0; j < UTP; ++j) bsum[q][j] = 0.f;
     f32x4_t dhr[UTP];
     float dcc[UTP][4];
 #pragma unroll
@@ -844,6 +852,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 for (int q = 0; q < G; ++q) {
                     dzc[(g * 4 + r) * LDZ + q * UPM + ucol] = f2bf(dz[q]);
                     sv_z[q][j][r] = dz[q];
+                    bsum[q][j] = fmaf(dz[q], vrow[r], bsum[q][j]);
                 }
             }
         }
@@ -944,7 +953,29 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 for (int q = 0; q < G; ++q) gprev[r][q * H + j * 16] = sv_z[q][j][r];
         cur ^= 1;
     }
+    // bias gradient partials of this (tile, direction): sum the four row groups of the wave, one owner lane per column
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int j = 0; j < UTP; ++j) {
+            float v = bsum[q][j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) a.bpart[(size_t)cl * GH + q * H + vw * (16 * UTP) + j * 16 + c] = v;
+        }
     if (errflag && a.err) a.err[0] = 1;
+}
+
+// db[dir][col] += sum over batch tiles of bpart[(tile*2 + dir)][col]
+__global__ __launch_bounds__(256) void bias_finish_kernel(const float* __restrict__ bpart, int ntiles, int GH, float* db_fw, float* db_bw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * GH) return;
+    const int dir = i / GH, col = i % GH;
+    float* db = dir ? db_bw : db_fw;
+    if (!db) return;
+    float acc = 0.f;
+    for (int t = 0; t < ntiles; ++t) acc += bpart[((size_t)t * 2 + dir) * GH + col];
+    db[col] += acc;
 }
 
 // fragments for the K-split BPTT: (dir, vw = pm*4+w, m, j, ks):
@@ -1018,7 +1049,7 @@ static int pick_cluster(int cell, int H) {
     return P;
 }
 
-struct SeqWs { size_t pack, err, sink, xcc, xbuf, total; };
+struct SeqWs { size_t pack, err, sink, xcc, bpart, xbuf, total; };
 static SeqWs seq_ws_layout(int cell, int H, int B) {
     const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
     SeqWs w;
@@ -1027,8 +1058,9 @@ static SeqWs seq_ws_layout(int cell, int H, int B) {
     w.err = o; o += 256;
     w.sink = o; o += ((size_t)(G * H + 64) * sizeof(float) + 255) & ~(size_t)255;
     w.xcc = o; o += 4096;                 // <= 256 workgroups x 8 bytes (padded)
-    w.xbuf = o;
     const size_t ncl = (size_t)((B + 15) / 16) * 2;
+    w.bpart = o; o += (ncl * G * H * sizeof(float) + 255) & ~(size_t)255;
+    w.xbuf = o;
     {   // [ncl][2 slots][max(all-gather: 8*G*H, K-split reduce-scatter: P*16*H with P <= 8)]
         const size_t per = (size_t)8 * 16 * H > (size_t)8 * G * H ? (size_t)8 * 16 * H : (size_t)8 * G * H;
         o += ncl * 2 * per * sizeof(unsigned long long);
@@ -1139,7 +1171,7 @@ static int check_common(const char* who, int cell, int prec, int B, int T, int H
 
 // bf16 path: pack W_hh, zero the exchange granules, launch the (clustered) persistent sweep
 static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float* w1, int ldw, void* ws, size_t ws_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, float* db_fw = nullptr, float* db_bw = nullptr, int* db_done = nullptr) {
     const int G = cell == LAS_CELL_LSTM ? 4 : 1, H = a.H;
     const SeqWs L = seq_ws_layout(cell, H, a.B);
     LAS_ARG(ws && ws_bytes >= L.total, "las_rnn_seq: workspace too small (%zu < %zu)", ws_bytes, L.total);
@@ -1150,6 +1182,7 @@ static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float
     a.sink = (float*)(base + L.sink);
     a.xbuf = (unsigned long long*)(base + L.xbuf);
     a.xcc = (unsigned long long*)(base + L.xcc);
+    a.bpart = (float*)(base + L.bpart);
     { const char* e = getenv("LAS_AGENT_GRANULES"); a.force_agent = (e && e[0] == '1') ? 1 : 0; }
     a.ncl = a.ncl_pad = 0;                               // set per launch (depends on the row tiles per workgroup)
     a.ks_packed = (bwd && P > 1 && !getenv("LAS_NO_KSPLIT")) ? 1 : 0;
@@ -1160,6 +1193,12 @@ static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float
     LAS_LAUNCHED();
     LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
     int rc = dispatch_bf16(cell, P, bwd, a, st);
+    if (rc == 0 && a.ks_packed && (db_fw || db_bw)) {    // the K-split kernel left per-tile column sums of dz: finish the bias gradient
+        hipLaunchKernelGGL(bias_finish_kernel, dim3(cdiv(2 * G * H, 256)), dim3(256), 0, st, (const float*)a.bpart, cdiv(a.B, 16), G * H,
+                           db_fw, db_bw);
+        LAS_LAUNCHED();
+        if (db_done) *db_done = 1;
+    }
     if (rc == -2 && P != 1) {                            // fall back to the widest supported cluster
         for (int q = 8; q >= 1 && rc == -2; q >>= 1) {
             if (q == P) continue;
@@ -1181,7 +1220,7 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
     a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);
 #endif
@@ -1201,6 +1240,14 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
                                const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
                                const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
                                float forget_bias, void* ws, size_t ws_bytes, void* stream) {
+    return las_rnn_seq_bwd_db(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout,
+                              dout_bstride, forget_bias, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
+                                  const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
+                                  const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
+                                  float forget_bias, float* dbias_fw, float* dbias_bw, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
     hipStream_t st = (hipStream_t)stream;
@@ -1209,9 +1256,11 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
     a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
+    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
-        if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
+        int db_done = 0;
+        if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st, dbias_fw, dbias_bw, &db_done)) return rc;
+        if (db_done) return 0;
     } else {
         LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * sizeof(float), "las_rnn_seq_bwd: workspace too small");
         hipLaunchKernelGGL(transpose_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw,
@@ -1228,5 +1277,11 @@ extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* g
         else                       hipLaunchKernelGGL(rnn_seq_bwd_f32_kernel<LAS_CELL_RNN>, grid, dim3(256), lds, st, a);
     }
     LAS_LAUNCHED();
+    // kernels that do not accumulate the bias gradient themselves: column sums of the finished d(pre-activation)
+    for (int d = 0; d < 2; ++d) {
+        float* db = d ? dbias_bw : dbias_fw;
+        if (!db) continue;
+        if (int rc = las_colsum(gates + (size_t)d * G * H, B * T, G * H, 2 * G * H, 1.f, db, ws, ws_bytes, stream)) return rc;
+    }
     return 0;
 }

@@ -58,6 +58,9 @@ _SIGS = {
     "las_rnn_seq_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
                                 c_float, c_void_p, c_size_t, c_void_p]),
+    "las_rnn_seq_bwd_db": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
+                                   c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
@@ -286,11 +289,12 @@ def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
 
 
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0):
+                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None):
+    """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
-        check(lib().las_rnn_seq_bwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
-                                    c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
-                                    p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(ws), ws.numel(),
-                                    stream()), "las_rnn_seq_bwd")
+        check(lib().las_rnn_seq_bwd_db(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                       c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                       p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(db_fw), p(db_bw),
+                                       p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db")

@@ -161,16 +161,19 @@ class _BLSTM(torch.autograd.Function):
         dev = x.device
         dout = dout.contiguous()
         # gates: activated gates -> d(pre-activation), in place
+        P4 = ctx.params
+        direct = P4 is not None and all(_direct_ok(p) for p in P4)
+        # with direct gradients the sweep itself accumulates the two bias gradients (column sums of dZ held in registers)
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
-                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH)
+                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
+                         db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None)
         grads = []
         dx = torch.empty(B, T, I0, device=dev) if ctx.needs_input_grad[0] else None
         if dx is not None:                             # on the dependency chain: main stream, first
             for d, k in enumerate((kfw, kbw)):
                 _hip.gemm(prec, gates, k, dx, False, True, B * T, I0, GH, 2 * GH, GH, I0, beta=1.0 if d else 0.0, a_off=d * GH)
-        P4 = ctx.params
         _hip.run_deferred()
-        if P4 is not None and all(_direct_ok(p) for p in P4):
+        if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
             with _hip.on_side_stream():
                 side = _hip.side_stream()
@@ -187,7 +190,6 @@ class _BLSTM(torch.autograd.Function):
                         _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
                                   strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
                         _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
-                    _hip.colsum(gates, B * T, GH, 2 * GH, bp.grad, beta=1.0, x_off=d * GH)
             return (dx, None, None, None, None, None, None, None, None)
         part = torch.empty(B, H, GH, device=dev) if T > 1 else None
         for d, k in enumerate((kfw, kbw)):

@@ -92,6 +92,14 @@ int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates,
                     const float* out, int ld_out, long long out_bstride, const float* cstate,
                     const float* dout, int ld_dout, long long dout_bstride,
                     float forget_bias, void* ws, size_t ws_bytes, void* stream);
+/* Same, and additionally accumulates (+=) the bias gradients of the two directions, dbias_fw / dbias_bw [G*H] (either may
+ * be NULL) = column sums of d(pre-activation) over all B*T frames (the bias of the TF cell kernel, las/layers.py:31).  The
+ * cluster BPTT kernel sums them in registers while it sweeps (no extra pass over the 4*B*T*G*H-byte gradient). */
+int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates,
+                       const float* whh_fw, const float* whh_bw, int ldw,
+                       const float* out, int ld_out, long long out_bstride, const float* cstate,
+                       const float* dout, int ld_dout, long long dout_bstride,
+                       float forget_bias, float* dbias_fw, float* dbias_bw, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4-K7  Speller: the whole decode loop of Speller.__call__ (las/las.py:72-143) with

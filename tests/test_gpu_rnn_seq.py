@@ -59,8 +59,16 @@ def test_rnn_seq_fwd_bwd(case):
 
     dout = torch.zeros(B, Tpad, 2 * H, device=dev)
     dout[:, :T] = R.to(dev)
-    _hip.rnn_seq_bwd(c, prec, B, T, H, gates, w0, w1, GH, out, 2 * H, Tpad * 2 * H, cst, dout, 2 * H, Tpad * 2 * H)
+    # the sweep also accumulates (+=) the bias gradients = column sums of dZ per direction
+    db_fw = torch.full((GH,), 0.5, device=dev)
+    db_bw = torch.full((GH,), -0.25, device=dev)
+    _hip.rnn_seq_bwd(c, prec, B, T, H, gates, w0, w1, GH, out, 2 * H, Tpad * 2 * H, cst, dout, 2 * H, Tpad * 2 * H,
+                     db_fw=db_fw, db_bw=db_bw)
     dg = gates.cpu().double()
+    for d, (db, init) in enumerate(((db_fw, 0.5), (db_bw, -0.25))):
+        want = dg[:, :, d].sum((0, 1)) + init
+        errb = (db.cpu().double() - want).abs().max().item()
+        assert errb < 1e-3 * max(1.0, want.abs().max().item()), ("db", case, d, errb)
     refg = xpl.grad
     err = (dg - refg).abs().max().item()
     scale = refg.abs().max().item()
