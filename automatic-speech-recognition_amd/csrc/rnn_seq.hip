@@ -243,18 +243,6 @@ typedef __attribute__((address_space(1))) float gfloat;          // explicit glo
 typedef __attribute__((address_space(1))) const float gcfloat;
 #define GF(p) ((gfloat*)(p))
 #define GCF(p) ((gcfloat*)(p))
-// make the compiler wait for (and own) a prefetched value NOW, before the stores that follow are issued:
-// vmcnt retires in order and counts stores, so a later wait would also cover those stores' acknowledgements
-#ifdef LAS_EXP_HOTX
-#define LAS_EXP_X(st) (-(long long)s * (st))   /* experiment: always re-read frame t0 (cache resident) */
-#else
-#define LAS_EXP_X(st) (st)
-#endif
-#ifdef LAS_USE_TOUCH
-#define TOUCH(x) asm volatile("" : "+v"(x))
-#else
-#define TOUCH(x)          /* measured: forcing the x-projection wait before the stores is slower */
-#endif
 #define LAS_SPIN_BUDGET (1 << 22)
 
 // `local` = every member of this cluster runs on the same XCD (verified at kernel start, cluster_same_xcd): the
@@ -432,7 +420,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 #pragma unroll
                 for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][LAS_EXP_X(gst[r]) + q * H + j * 16];
+                    for (int r = 0; r < 4; ++r) xn[q][j][r] = gptr[r][gst[r] + q * H + j * 16];
         }
         const unsigned short* hcur = hs + cur * 16 * LDH;
         u16x8_t av[KS];                  // all A fragments of h_{t-1} up front: one LDS round trip, then MFMAs back to back
@@ -456,12 +444,6 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
         STAMP(2);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
         unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
-        if (s + 1 < T) {
-#pragma unroll
-            for (int q = 0; q < G; ++q)
-#pragma unroll
-                for (int j = 0; j < UTP; ++j) TOUCH(xn[q][j]);
-        }
         float sv_h[UTP][4], sv_g[G][UTP][4];     // results kept in registers; written to HBM after the exchange
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
