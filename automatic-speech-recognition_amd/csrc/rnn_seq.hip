@@ -882,21 +882,22 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
                 for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers
-                        float v = 0.f;
+                    for (int rp = 0; rp < 2; ++rp) {
+                        // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers.  Two partial
+                        // sums (rows 2rp, 2rp+1) travel as one bf16 pair: half the granules of the reduce-scatter
+                        float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-                        for (int mm = 0; mm < P; ++mm) v = (mm == m) ? acc[mm][j][r] : v;
-                        granule_store(dstp + (size_t)(j * 4 + r) * 64, (unsigned)(s + 1), __float_as_uint(v), local);
+                        for (int mm = 0; mm < P; ++mm) { v0 = (mm == m) ? acc[mm][j][2 * rp] : v0; v1 = (mm == m) ? acc[mm][j][2 * rp + 1] : v1; }
+                        granule_store(dstp + (size_t)(j * 2 + rp) * 64, (unsigned)(s + 1), f2bf2(v0, v1), local);
                     }
             }
-            constexpr int NGT = (P - 1) * UTP * 4;
+            constexpr int NGT = (P - 1) * UTP * 2;
             unsigned long long xv[NGT];
             const unsigned long long* inbox = xslot + (size_t)pm * P * GPD + (size_t)(w * UTP) * 4 * 64 + lane;
 #pragma unroll
             for (int n = 0; n < NGT; ++n) {
-                const int src = (pm + 1 + n / (UTP * 4)) % P;
-                xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 4)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int src = (pm + 1 + n / (UTP * 2)) % P;
+                xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 2)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             int budget = errflag ? 1 : LAS_SPIN_BUDGET;
             for (;;) {
@@ -909,8 +910,8 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
                 for (int n = 0; n < NGT; ++n) {
                     if ((unsigned)(xv[n] >> 32) != (unsigned)(s + 1)) {
-                        const int src = (pm + 1 + n / (UTP * 4)) % P;
-                        xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 4)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int src = (pm + 1 + n / (UTP * 2)) % P;
+                        xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 2)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -922,7 +923,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
                     for (int mm = 0; mm < P; ++mm) v = (mm == pm) ? acc[mm][j][r] : v;
 #pragma unroll
-                    for (int mo = 0; mo < P - 1; ++mo) v += __uint_as_float((unsigned)xv[(mo * UTP + j) * 4 + r]);
+                    for (int mo = 0; mo < P - 1; ++mo) {
+                        const unsigned pk = (unsigned)xv[(mo * UTP + j) * 2 + (r >> 1)];
+                        v += __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                    }
                     dhr[j][r] = v;
                 }
         }
