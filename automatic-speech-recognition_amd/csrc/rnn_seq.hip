@@ -254,6 +254,22 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned ta
     if (local) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16-byte form: two granules {tag, a} {b, tag} written by ONE store and read by ONE load.  Each 8-byte half carries its
+// own tag, so the pair is valid even if the 16 bytes are not delivered atomically (the consumer checks both tags).
+// Buffer intrinsics so that the compiler tracks vmcnt for the loads; aux bit 0 = sc0, bit 4 = sc1.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(unsigned long long* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);        // wave-uniform base, raw addressing
+}
+__device__ __forceinline__ void granule16_store(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, unsigned a, unsigned b,
+                                                bool local) {
+    const u32x4_t v = {tag, a, b, tag};
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 1);          // sc0: stays in the XCD's L2
+    else       __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 17);         // sc0 sc1: write-through
+}
+__device__ __forceinline__ u32x4_t granule16_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);                 // sc1: bypass L1
+}
 __device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err) {
     unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int budget = *err ? 1 : LAS_SPIN_BUDGET;          // sticky: after one timeout never wait again (no hang)
@@ -748,6 +764,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     for (int r = 0; r < NFR; ++r) wreg[r] = Wp[r * 64 + lane];
     // inbox of member d: [2 slots][P dst][P src][GPD]
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * P * GPD;
+    const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(xb);
     int errflag = 0;
     const bool local = a.force_agent ? false : cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag);
 
@@ -874,44 +891,46 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         }
         if (s + 1 < T) {
             // ---- reduce-scatter: send the tiles other members own, add the ones they computed for this wave
-            unsigned long long* xslot = xb + (size_t)(s & 1) * P * P * GPD;
+            // byte offsets into this cluster's exchange buffer (< 2 GB): slot, [dst][src] region, (wave tile, lane) x 16 B
+            const unsigned slot_off = (unsigned)(s & 1) * P * P * GPD * 8u;
+            const unsigned lane_off = ((unsigned)(w * UTP) * 64u + lane) * 16u;
 #pragma unroll
             for (int mo = 1; mo < P; ++mo) {
                 const int m = (pm + mo) % P;
-                unsigned long long* dstp = xslot + ((size_t)m * P + pm) * GPD + (size_t)(w * UTP) * 4 * 64 + lane;
+                const unsigned dst_off = slot_off + (unsigned)(m * P + pm) * GPD * 8u + lane_off;
 #pragma unroll
-                for (int j = 0; j < UTP; ++j)
+                for (int j = 0; j < UTP; ++j) {
+                    // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers.  The four partial
+                    // sums of a lane travel as two bf16 pairs in ONE 16-byte double granule
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int rp = 0; rp < 2; ++rp) {
-                        // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers.  Two partial
-                        // sums (rows 2rp, 2rp+1) travel as one bf16 pair: half the granules of the reduce-scatter
-                        float v0 = 0.f, v1 = 0.f;
+                    for (int mm = 0; mm < P; ++mm)
 #pragma unroll
-                        for (int mm = 0; mm < P; ++mm) { v0 = (mm == m) ? acc[mm][j][2 * rp] : v0; v1 = (mm == m) ? acc[mm][j][2 * rp + 1] : v1; }
-                        granule_store(dstp + (size_t)(j * 2 + rp) * 64, (unsigned)(s + 1), f2bf2(v0, v1), local);
-                    }
+                        for (int r = 0; r < 4; ++r) v[r] = (mm == m) ? acc[mm][j][r] : v[r];
+                    granule16_store(xrs, dst_off + (unsigned)j * 1024u, (unsigned)(s + 1), f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), local);
+                }
             }
-            constexpr int NGT = (P - 1) * UTP * 2;
-            unsigned long long xv[NGT];
-            const unsigned long long* inbox = xslot + (size_t)pm * P * GPD + (size_t)(w * UTP) * 4 * 64 + lane;
+            constexpr int NGT = (P - 1) * UTP;
+            u32x4_t xv[NGT];
+            const unsigned in_off = slot_off + (unsigned)(pm * P) * GPD * 8u + lane_off;
 #pragma unroll
             for (int n = 0; n < NGT; ++n) {
-                const int src = (pm + 1 + n / (UTP * 2)) % P;
-                xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 2)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int src = (pm + 1 + n / UTP) % P;
+                xv[n] = granule16_load(xrs, in_off + (unsigned)src * GPD * 8u + (unsigned)(n % UTP) * 1024u);
             }
             int budget = errflag ? 1 : LAS_SPIN_BUDGET;
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int n = 0; n < NGT; ++n) ok &= (unsigned)(xv[n] >> 32) == (unsigned)(s + 1);
+                for (int n = 0; n < NGT; ++n) ok &= xv[n].x == (unsigned)(s + 1) && xv[n].w == (unsigned)(s + 1);
                 if (ok) break;
                 if (--budget <= 0) { errflag = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int n = 0; n < NGT; ++n) {
-                    if ((unsigned)(xv[n] >> 32) != (unsigned)(s + 1)) {
-                        const int src = (pm + 1 + n / (UTP * 2)) % P;
-                        xv[n] = __hip_atomic_load(inbox + (size_t)src * GPD + (size_t)(n % (UTP * 2)) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (xv[n].x != (unsigned)(s + 1) || xv[n].w != (unsigned)(s + 1)) {
+                        const int src = (pm + 1 + n / UTP) % P;
+                        xv[n] = granule16_load(xrs, in_off + (unsigned)src * GPD * 8u + (unsigned)(n % UTP) * 1024u);
                     }
                 }
             }
@@ -924,7 +943,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     for (int mm = 0; mm < P; ++mm) v = (mm == pm) ? acc[mm][j][r] : v;
 #pragma unroll
                     for (int mo = 0; mo < P - 1; ++mo) {
-                        const unsigned pk = (unsigned)xv[(mo * UTP + j) * 2 + (r >> 1)];
+                        const unsigned pk = (r >> 1) ? xv[mo * UTP + j].z : xv[mo * UTP + j].y;
                         v += __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
                     }
                     dhr[j][r] = v;
