@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
     const int vw = pm * 4 + w;                                                   // virtual wave: owns units [vw*16*UTP, ..)
     const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFW * 64;
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;                 // [2 slots][P][GPM]
+    const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(xb);
     int errflag = 0;
     const bool local = (P > 1 && RT == 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag) : false;
 
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 #endif
         STAMP(2);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
-        unsigned long long* xslot = xb + (size_t)((s & 1) * P) * GPM;
+        const unsigned slot_off = (unsigned)((s & 1) * P) * GPM * 8u;
         float sv_h[UTP][4], sv_g[G][UTP][4];     // results kept in registers; written to HBM after the exchange
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
@@ -484,28 +485,46 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
                 hb[r] = f2bf(h);
                 hnext[(g * 4 + r) * LDH + unit] = hb[r];
             }
-            if (P > 1 && s + 1 < T) {   // publish this wave's slice: 2 granules per lane per tile (rows g*4+{0,1}, g*4+{2,3})
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    granule_store(xslot + (size_t)pm * GPM + ((w * UTP + j) * 2 + k) * 64 + lane, (unsigned)(s + 1),
-                                  (unsigned)hb[2 * k] | ((unsigned)hb[2 * k + 1] << 16), local);
-            }
+            if (P > 1 && s + 1 < T)     // publish this wave's slice: the lane's four rows of the tile as ONE 16-byte double granule
+                granule16_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 16u, (unsigned)(s + 1),
+                                (unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
         }
         STAMP(3);
         if (P > 1 && s + 1 < T) {       // gather the other members' slices of h_t into the LDS tile
-            constexpr int PER = GPM / 256, NGT = (P > 1 ? (P - 1) * PER : 1);
-            unsigned long long xv[NGT];
-            gather_granules<NGT, P, GPM>(xv, xslot, pm, tid, (unsigned)(s + 1), errflag);
+            constexpr int NGT = (P > 1 ? (P - 1) * UTP : 1);              // double granules per thread: UTP per partner
+            u32x4_t xv[NGT];
 #pragma unroll
             for (int n = 0; n < NGT; ++n) {
-                const int m = (pm + 1 + n / PER) % P;
-                const int gi_ = tid + (n % PER) * 256;
-                const unsigned v = (unsigned)xv[n];
-                const int l2 = gi_ & 63, k = (gi_ >> 6) & 1, wj = gi_ >> 7;     // wj = w'*UTP + j'
+                const int m = (pm + 1 + n / UTP) % P;
+                xv[n] = granule16_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 16u);
+            }
+            int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) ok &= xv[n].x == (unsigned)(s + 1) && xv[n].w == (unsigned)(s + 1);
+                if (ok) break;
+                if (--budget <= 0) { errflag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) {
+                    if (xv[n].x != (unsigned)(s + 1) || xv[n].w != (unsigned)(s + 1)) {
+                        const int m = (pm + 1 + n / UTP) % P;
+                        xv[n] = granule16_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 16u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int m = (pm + 1 + n / UTP) % P;
+                const int di = (n % UTP) * 256 + tid;                      // double-granule index = (w'*UTP + j')*64 + lane'
+                const int l2 = di & 63, wj = di >> 6;
                 const int unit = m * UPM + wj * 16 + (l2 & 15);
-                const int row = (l2 >> 4) * 4 + 2 * k;
-                hnext[row * LDH + unit] = (unsigned short)(v & 0xffffu);
-                hnext[(row + 1) * LDH + unit] = (unsigned short)(v >> 16);
+                const int row = (l2 >> 4) * 4;
+                hnext[row * LDH + unit] = (unsigned short)(xv[n].y & 0xffffu);
+                hnext[(row + 1) * LDH + unit] = (unsigned short)(xv[n].y >> 16);
+                hnext[(row + 2) * LDH + unit] = (unsigned short)(xv[n].z & 0xffffu);
+                hnext[(row + 3) * LDH + unit] = (unsigned short)(xv[n].z >> 16);
             }
         }
         lds_barrier();
