@@ -138,9 +138,10 @@ class _BLSTM(torch.autograd.Function):
             Ik = (I + 3) // 4 * 4
             x = torch.nn.functional.pad(x, (0, Ik - I))
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=torch.float32)
-        for d, (k, b) in enumerate(((kfw, bfw), (kbw, bbw))):
-            # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H])
-            _hip.gemm(prec, x, k, gates, False, False, B * T, GH, Ik, Ik, GH, 2 * GH, bias=b, c_off=d * GH)
+        # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H]); both directions in ONE
+        # product over the concatenated weights, so x is read once
+        kcat = torch.cat((kfw[:Ik], kbw[:Ik]), 1)                   # [Ik, 2*GH]
+        _hip.gemm(prec, x, kcat, gates, False, False, B * T, 2 * GH, Ik, Ik, 2 * GH, 2 * GH, bias=torch.cat((bfw, bbw)))
         Tp = T + (T % 2) if pad_even else T
         out = torch.zeros(B, Tp, 2 * H, device=dev) if Tp != T else torch.empty(B, T, 2 * H, device=dev)
         cst = torch.empty(B, T, 2, H, device=dev) if cell == "lstm" else None
@@ -170,8 +171,9 @@ class _BLSTM(torch.autograd.Function):
         grads = []
         dx = torch.empty(B, T, I0, device=dev) if ctx.needs_input_grad[0] else None
         if dx is not None:                             # on the dependency chain: main stream, first
-            for d, k in enumerate((kfw, kbw)):
-                _hip.gemm(prec, gates, k, dx, False, True, B * T, I0, GH, 2 * GH, GH, I0, beta=1.0 if d else 0.0, a_off=d * GH)
+            # dZ [B*T, 2*GH] . [W_ih_fw | W_ih_bw]^T in one product (one pass over dx instead of two)
+            kcat = torch.cat((kfw[:I0], kbw[:I0]), 1)               # [I0, 2*GH]
+            _hip.gemm(prec, gates, kcat, dx, False, True, B * T, I0, 2 * GH, 2 * GH, 2 * GH, I0)
         _hip.run_deferred()
         if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
