@@ -226,7 +226,7 @@ def main():
             # WRITE_SIZE in separate passes; tools/pmc_summary.py); null when no recording matches the configuration
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_e_pmc.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_g_pmc.json")))
                 if a.cell == "lstm" and a.dtype == "bf16" and B == 48 and T == 1274:
                     key = [k for k in pmc if k.startswith("rnn_seq_bwd" if bwd else "rnn_seq_fwd")]
                     if key:
