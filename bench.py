@@ -219,7 +219,7 @@ def main():
             ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9
             if a.dtype == "bf16":
                 kname = "rnn_seq_bwd_ks_kernel<LSTM,4,4>" if (bwd and a.cell == "lstm") else \
-                    ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_bf16_kernel")
+                    ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_hw_kernel")
             else:
                 kname = ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_f32_kernel"
             # HBM traffic of that kernel from a recorded rocprofv3 --pmc pass of this same command (FETCH_SIZE and
