@@ -106,3 +106,24 @@ def test_schedules_match_oracle():
         assert las._scheduled_learning_rate(global_step=gs) == O.scheduled_learning_rate(args.lr, gs)
     for gs in (0, 100000, 250000, 500000, 900000):
         assert las.speller._scheduled_sampling(gs) == O.scheduled_sampling_rate(gs, args.warmup_step, args.max_step, args.min_rate)
+
+
+def test_listener_output_length_matches_the_layers():
+    """LAS.train uploads the encoder lengths before the Listener runs (host preparation); the helper must agree with what
+    pBLSTMLayer / CNNLayer return (reference las/layers.py:94,:127-129)."""
+    import numpy as np
+    import torch
+    from helpers import make_args
+    from las.las import Listener
+    a = make_args(num_enc_layers=3)
+    n = np.array([1274, 1273, 1000, 7, 1])
+    got = Listener(a).output_length(n, "pblstm")
+    want = torch.as_tensor(n).to(torch.float64)
+    for _ in range(3):
+        want = (want + want % 2) / 2
+    assert torch.equal(got, want) and got.dtype == torch.float64
+    got_cnn = Listener(a).output_length(n, "cnn")
+    want = torch.as_tensor(n).to(torch.float64)
+    for _ in range(2):
+        want = (want + want % 2) / 2
+    assert torch.equal(got_cnn, want)
