@@ -35,6 +35,10 @@ struct RnnArgs {
     float* sink;                             // scratch rows for the padded part of a ragged batch tile
     int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
     int ks_packed;                           // wpack holds the K-split BPTT fragment order
+    int spin;                                // bound of every exchange spin (polls); a timeout is reported through `status`
+    int* status;                             // caller-owned sticky device word (may be NULL): LAS_SEQ_STATUS_* on failure
+    int status_code;
+    int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
@@ -243,7 +247,7 @@ typedef __attribute__((address_space(1))) float gfloat;          // explicit glo
 typedef __attribute__((address_space(1))) const float gcfloat;
 #define GF(p) ((gfloat*)(p))
 #define GCF(p) ((gcfloat*)(p))
-#define LAS_SPIN_BUDGET (1 << 22)
+#define LAS_SPIN_BUDGET_DEFAULT (1 << 22)
 
 // `local` = every member of this cluster runs on the same XCD (verified at kernel start, cluster_same_xcd): the
 // granule then only has to reach that XCD's L2, so a workgroup-scope (sc0) store is enough and the consumers' sc1
@@ -270,9 +274,9 @@ __device__ __forceinline__ void granule16_store(__amdgpu_buffer_rsrc_t rs, unsig
 __device__ __forceinline__ u32x4_t granule16_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);                 // sc1: bypass L1
 }
-__device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err) {
+__device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err, int spin) {
     unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int budget = *err ? 1 : LAS_SPIN_BUDGET;          // sticky: after one timeout never wait again (no hang)
+    int budget = *err ? 1 : spin;                     // sticky: after one timeout never wait again (no hang)
     while ((unsigned)(x >> 32) != tag) {
         if (--budget == 0) { *err = 1; break; }
         __builtin_amdgcn_s_sleep(1);
@@ -284,14 +288,14 @@ __device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, un
 // Fetch this thread's N granules (all loads in flight at once), then re-poll only the stale ones.
 template <int N, int P, int GPM>
 __device__ __forceinline__ void gather_granules(unsigned long long (&xv)[N], const unsigned long long* xslot, int pm, int tid,
-                                                unsigned tag, int& errflag) {
+                                                unsigned tag, int& errflag, int spin) {
     constexpr int PER = GPM / 256;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int m = (pm + 1 + n / PER) % P;
         xv[n] = __hip_atomic_load(xslot + (size_t)m * GPM + tid + (n % PER) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+    int budget = errflag ? 1 : spin;
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -311,12 +315,12 @@ __device__ __forceinline__ void gather_granules(unsigned long long (&xv)[N], con
 
 // Placement handshake: every member publishes the XCC_ID it runs on (agent-scope granule, valid under any placement)
 // and reads its partners'; true only if all P agree.  A timeout or a mismatch selects the agent-scope transport.
-__device__ __forceinline__ bool cluster_same_xcd(unsigned long long* slots, int pm, int P, int tid, int* err) {
+__device__ __forceinline__ bool cluster_same_xcd(unsigned long long* slots, int pm, int P, int tid, int* err, int spin) {
     const unsigned tag = 0x58434400u;                                           // "XCD\0"
     const unsigned mine = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;      // HW_REG_XCC_ID[3:0]
     if (tid == 0) __hip_atomic_store(slots + pm, ((unsigned long long)tag << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int same = 1;
-    if (tid < P) same = (granule_wait(slots + tid, tag, err) == mine) && !*err;
+    if (tid < P) same = (granule_wait(slots + tid, tag, err, spin) == mine) && !*err;
     return __syncthreads_and(same) != 0;
 }
 
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;                 // [2 slots][P][GPM]
     const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(xb);
     int errflag = 0;
-    const bool local = (P > 1 && RT == 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag) : false;
+    const bool local = (P > 1 && RT == 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin) : false;
 
     u16x8_t wreg[RF > 0 ? RF : 1];
 #pragma unroll
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
                 const int m = (pm + 1 + n / UTP) % P;
                 xv[n] = granule16_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 16u);
             }
-            int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+            int budget = errflag ? 1 : a.spin;
             for (;;) {
                 bool ok = true;
 #pragma unroll
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
         for (int r = 0; r < 4; ++r) { gptr[r] += gst[r]; optr[r] += ost[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         cur ^= 1;
     }
-    if (errflag && a.err) a.err[0] = 1;
+    if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 #ifdef LAS_PROF
     if (prof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
 #endif
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
     if (b0 >= B) return;
     const int cl = tile * 2 + dir;
     int errflag = 0;
-    const bool local = (P > 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag) : false;
+    const bool local = (P > 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin) : false;
     const int t0 = dir ? T - 1 : 0;
     const long long tstep = dir ? -1 : 1;
 
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 const int m = (pm + 1 + n / UTP) % P;
                 xv[n] = granule16_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 16u);
             }
-            int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+            int budget = errflag ? 1 : a.spin;
             for (;;) {
                 bool ok = true;
 #pragma unroll
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         lds_barrier();
         cur ^= 1;
     }
-    if (errflag && a.err) a.err[0] = 1;
+    if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
 template <int CELL, int UT, int P, int RT>
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
     const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFB * 64;
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * GPM;
     int errflag = 0;
-    const bool local = (P > 1 && RT == 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag) : false;
+    const bool local = (P > 1 && RT == 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin) : false;
 
     u16x8_t wreg[RFB > 0 ? RFB : 1];
 #pragma unroll
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
         if (P > 1) {
             constexpr int PER = GPM / 256, NGT = (P > 1 ? (P - 1) * PER : 1);
             unsigned long long xv[NGT];
-            gather_granules<NGT, P, GPM>(xv, xslot, pm, tid, (unsigned)(s + 1), errflag);
+            gather_granules<NGT, P, GPM>(xv, xslot, pm, tid, (unsigned)(s + 1), errflag, a.spin);
 #pragma unroll
             for (int n = 0; n < NGT; ++n) {
                 const int m = (pm + 1 + n / PER) % P;
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
         for (int j = 0; j < UTP; ++j) dhr[j] = acc[j];
         cur ^= 1;
     }
-    if (errflag && a.err) a.err[0] = 1;
+    if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
 // ====================================================================================================
@@ -1044,7 +1048,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     unsigned long long* xb = a.xbuf + (size_t)cl * 2 * P * P * GPD;
     const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(xb);
     int errflag = 0;
-    const bool local = a.force_agent ? false : cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag);
+    const bool local = a.force_agent ? false : cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin);
 
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
@@ -1196,7 +1200,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 const int src = (pm + 1 + n / UTP) % P;
                 xv[n] = granule16_load(xrs, in_off + (unsigned)src * GPD * 8u + (unsigned)(n % UTP) * 1024u);
             }
-            int budget = errflag ? 1 : LAS_SPIN_BUDGET;
+            int budget = errflag ? 1 : a.spin;
             for (;;) {
                 bool ok = true;
 #pragma unroll
@@ -1246,7 +1250,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             v += __shfl_xor(v, 32, 64);
             if (lane < 16) a.bpart[(size_t)cl * GH + q * H + vw * (16 * UTP) + j * 16 + c] = v;
         }
-    if (errflag && a.err) a.err[0] = 1;
+    if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
 // db[dir][col] += sum over batch tiles of bpart[(tile*2 + dir)][col]
@@ -1320,19 +1324,29 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const fl
 // ------------------------------------------------------------------------------------------------
 static bool mfma_shape_ok(int H) { return H == 64 || H == 128 || H == 256 || H == 512; }
 
-// cluster width: enough members that each keeps its W_hh slice resident (LDS + <=48 register fragments)
-static int pick_cluster(int cell, int H) {
+// cluster width: enough members that each keeps its W_hh slice resident (LDS + <=48 register fragments);
+// LAS_SEQ_P(p) in `flags` overrides it (development / tests)
+static int pick_cluster(int cell, int H, int flags) {
     int P;
     if (cell == LAS_CELL_LSTM) P = H >= 512 ? 8 : (H >= 256 ? 4 : (H >= 128 ? 2 : 1));
     else                       P = H >= 512 ? 2 : 1;
-    if (const char* e = getenv(cell == LAS_CELL_LSTM ? "LAS_LSTM_P" : "LAS_RNN_P")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
-    }
+    const int v = (flags >> 8) & 0xf;
+    if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
     return P;
 }
 
-struct SeqWs { size_t pack, err, sink, xcc, bpart, xbuf, total; };
+// compute units of the current device (init-once attribute cache; partitioned / CU-masked devices report fewer than 256)
+static int device_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return cus;
+}
+
+struct SeqWs { size_t pack, err, sink, xcc, bpart, xbuf, xbuf_per, total; };
 static SeqWs seq_ws_layout(int cell, int H, int B) {
     const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
     SeqWs w;
@@ -1340,14 +1354,13 @@ static SeqWs seq_ws_layout(int cell, int H, int B) {
     size_t o = (2 * G * H * H * sizeof(float) + 255) & ~(size_t)255;   // f32: W^T copy; bf16: packed fragments (half of it)
     w.err = o; o += 256;
     w.sink = o; o += ((size_t)(G * H + 64) * sizeof(float) + 255) & ~(size_t)255;
-    w.xcc = o; o += 4096;                 // <= 256 workgroups x 8 bytes (padded)
     const size_t ncl = (size_t)((B + 15) / 16) * 2;
+    w.xcc = o; o += (ncl * 8 * sizeof(unsigned long long) + 255) & ~(size_t)255;      // [cluster][<= 8 members] handshake granules
     w.bpart = o; o += (ncl * G * H * sizeof(float) + 255) & ~(size_t)255;
     w.xbuf = o;
-    {   // [ncl][2 slots][max(all-gather: 8*G*H, K-split reduce-scatter: P*16*H with P <= 8)]
-        const size_t per = (size_t)8 * 16 * H > (size_t)8 * G * H ? (size_t)8 * 16 * H : (size_t)8 * G * H;
-        o += ncl * 2 * per * sizeof(unsigned long long);
-    }
+    // per cluster: [2 slots][max(all-gather: 8*G*H, K-split reduce-scatter: P*16*H with P <= 8)] granule words
+    w.xbuf_per = 2 * ((size_t)8 * 16 * H > (size_t)8 * G * H ? (size_t)8 * 16 * H : (size_t)8 * G * H);
+    o += ncl * w.xbuf_per * sizeof(unsigned long long);
     w.total = o + 256;
     return w;
 }
@@ -1373,12 +1386,12 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
         RnnArgs a = a0;
         a.ncl = cdiv(ntiles, RT) * 2;                      // (tile group, direction) pairs
         a.ncl_pad = (a.ncl + 7) / 8 * 8;                   // members of a cluster share blockIdx % 8 (same XCD: speed only)
-        if ((long long)a.ncl_pad * P > 256) {              // every member must be co-resident (1 workgroup per CU)
-            las_set_error("rnn_seq: %d workgroups exceed the CU count", a.ncl_pad * P);
+        if ((long long)a.ncl_pad * P > device_cus()) {     // every member must be co-resident (1 workgroup per CU)
+            las_set_error("rnn_seq: %d workgroups exceed the %d compute units of this device", a.ncl_pad * P, device_cus());
             return -2;
         }
         dim3 grid(a.ncl_pad * P), blk(256 * RT);
-        if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !getenv("LAS_NO_HELPER_WAVES")) {
+        if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
             if constexpr (HwCfg<CELL, UT, P>::OK) {
                 constexpr int HL = HwCfg<CELL, UT, P>::LDS;
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P>, HL);
@@ -1459,63 +1472,88 @@ static int check_common(const char* who, int cell, int prec, int B, int T, int H
     return 0;
 }
 
-// bf16 path: pack W_hh, zero the exchange granules, launch the (clustered) persistent sweep
-static int run_bf16(bool bwd, int cell, RnnArgs& a, const float* w0, const float* w1, int ldw, void* ws, size_t ws_bytes,
-                    hipStream_t st, float* db_fw = nullptr, float* db_bw = nullptr, int* db_done = nullptr) {
-    const int G = cell == LAS_CELL_LSTM ? 4 : 1, H = a.H;
-    const SeqWs L = seq_ws_layout(cell, H, a.B);
+// bf16 path: pack W_hh, zero the exchange granules, launch the (clustered) persistent sweep.  Every member of every
+// cluster has to be resident at once (one workgroup per CU), so a batch with more row tiles than the device's CUs can
+// hold is swept in row chunks, one launch after the other on the same stream, each with its own exchange region.
+static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, const float* w1, int ldw, void* ws, size_t ws_bytes,
+                    int flags, hipStream_t st, float* db_fw = nullptr, float* db_bw = nullptr, int* db_done = nullptr) {
+    const int G = cell == LAS_CELL_LSTM ? 4 : 1, H = a_in.H, B = a_in.B, T = a_in.T;
+    const SeqWs L = seq_ws_layout(cell, H, B);
     LAS_ARG(ws && ws_bytes >= L.total, "las_rnn_seq: workspace too small (%zu < %zu)", ws_bytes, L.total);
-    int P = pick_cluster(cell, H);
     char* base = (char*)ws;
-    a.wpack = base + L.pack;
-    a.err = (int*)(base + L.err);
-    a.sink = (float*)(base + L.sink);
-    a.xbuf = (unsigned long long*)(base + L.xbuf);
-    a.xcc = (unsigned long long*)(base + L.xcc);
-    a.bpart = (float*)(base + L.bpart);
-    { const char* e = getenv("LAS_AGENT_GRANULES"); a.force_agent = (e && e[0] == '1') ? 1 : 0; }
-    a.ncl = a.ncl_pad = 0;                               // set per launch (depends on the row tiles per workgroup)
-    a.ks_packed = (bwd && P > 1 && !getenv("LAS_NO_KSPLIT")) ? 1 : 0;
-    if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
-                                        (unsigned short*)a.wpack);
-    else hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
-                            (unsigned short*)a.wpack);
-    LAS_LAUNCHED();
-    LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
-    int rc = dispatch_bf16(cell, P, bwd, a, st);
-    if (rc == 0 && a.ks_packed && (db_fw || db_bw)) {    // the K-split kernel left per-tile column sums of dz: finish the bias gradient
-        hipLaunchKernelGGL(bias_finish_kernel, dim3(cdiv(2 * G * H, 256)), dim3(256), 0, st, (const float*)a.bpart, cdiv(a.B, 16), G * H,
-                           db_fw, db_bw);
+    int P = pick_cluster(cell, H, flags);
+    int rc = -2;
+    for (int attempt = 0; attempt < 5 && rc == -2; ++attempt) {
+        if (attempt > 0) {                               // fall back to the next narrower cluster
+            if (P == 1) break;
+            P >>= 1;
+        }
+        RnnArgs a = a_in;
+        a.wpack = base + L.pack;
+        a.err = (int*)(base + L.err);
+        a.sink = (float*)(base + L.sink);
+        a.force_agent = (flags & LAS_SEQ_AGENT_GRANULES) ? 1 : 0;
+        a.no_helpers = (flags & LAS_SEQ_NO_HELPER_WAVES) ? 1 : 0;
+        a.ks_packed = (bwd && P > 1 && !(flags & LAS_SEQ_NO_KSPLIT)) ? 1 : 0;
+        if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
+                                            (unsigned short*)a.wpack);
+        else hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
+                                (unsigned short*)a.wpack);
         LAS_LAUNCHED();
-        if (db_done) *db_done = 1;
-    }
-    if (rc == -2 && P != 1) {                            // fall back to the widest supported cluster
-        for (int q = 8; q >= 1 && rc == -2; q >>= 1) {
-            if (q == P) continue;
-            a.ks_packed = 0;
-            hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G,
-                               bwd ? 1 : 0, q, (unsigned short*)a.wpack);
-            rc = dispatch_bf16(cell, q, bwd, a, st);
+        LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
+        // row tiles per launch: clusters (tile, direction) are padded to a multiple of 8 workgroups per member
+        const int ntiles = cdiv(B, 16);
+        int max_tiles = (device_cus() / P / 8) * 8 / 2;
+        if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, device_cus()); rc = -2; continue; }
+        const size_t per_cl = L.xbuf_per;                // granule words per cluster
+        rc = 0;
+        for (int tile0 = 0; tile0 < ntiles && rc == 0; tile0 += max_tiles) {
+            const int b0 = tile0 * 16, rows = (B - b0) < max_tiles * 16 ? (B - b0) : max_tiles * 16;
+            RnnArgs c = a;
+            c.B = rows;
+            c.gates = a.gates + (size_t)b0 * T * 2 * G * H;
+            c.out = a.out + (size_t)b0 * a.obs;
+            if (a.cstate) c.cstate = a.cstate + (size_t)b0 * T * 2 * H;
+            if (a.dout) c.dout = a.dout + (size_t)b0 * a.dobs;
+            c.xbuf = (unsigned long long*)(base + L.xbuf) + (size_t)tile0 * 2 * per_cl;
+            c.xcc = (unsigned long long*)(base + L.xcc) + (size_t)tile0 * 2 * 8;
+            c.bpart = (float*)(base + L.bpart) + (size_t)tile0 * 2 * G * H;
+            c.ncl = c.ncl_pad = 0;                           // set per launch
+            rc = dispatch_bf16(cell, P, bwd, c, st);
+        }
+        if (rc == 0 && a.ks_packed && (db_fw || db_bw)) {    // the K-split kernel left per-tile column sums of dz: finish the bias gradient
+            hipLaunchKernelGGL(bias_finish_kernel, dim3(cdiv(2 * G * H, 256)), dim3(256), 0, st, (const float*)(base + L.bpart), ntiles, G * H,
+                               db_fw, db_bw);
+            LAS_LAUNCHED();
+            if (db_done) *db_done = 1;
         }
     }
     return rc;
 }
 
+static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
+    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
+    a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0;
+    const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
+    a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
+    a.status = status; a.status_code = code;
+}
+
 extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, float* out, int ld_out, long long out_bstride,
-                               float* cstate, float forget_bias, void* ws, size_t ws_bytes, void* stream) {
+                               float* cstate, float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RnnArgs a;
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
     a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
+    seq_common_args(a, flags, status, LAS_SEQ_STATUS_FWD_TIMEOUT);
 #ifdef LAS_PROF
-    if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);
+    if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
-        if (int rc = run_bf16(false, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st)) return rc;
+        if (int rc = run_bf16(false, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st)) return rc;
     } else {
         const size_t lds = (size_t)H * F32_BT * sizeof(float);
         dim3 grid(cdiv(B, F32_BT), 2);
@@ -1529,15 +1567,16 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* g
 extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
                                const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
-                               float forget_bias, void* ws, size_t ws_bytes, void* stream) {
+                               float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
     return las_rnn_seq_bwd_db(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout,
-                              dout_bstride, forget_bias, nullptr, nullptr, ws, ws_bytes, stream);
+                              dout_bstride, forget_bias, nullptr, nullptr, flags, status, ws, ws_bytes, stream);
 }
 
 extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
                                   const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
                                   const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
-                                  float forget_bias, float* dbias_fw, float* dbias_bw, void* ws, size_t ws_bytes, void* stream) {
+                                  float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                                  void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
     hipStream_t st = (hipStream_t)stream;
@@ -1546,10 +1585,10 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float
     a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
     a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
     a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
-    a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr; a.ncl = a.ncl_pad = 0; a.ks_packed = 0;
+    seq_common_args(a, flags, status, LAS_SEQ_STATUS_BWD_TIMEOUT);
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
         int db_done = 0;
-        if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, st, dbias_fw, dbias_bw, &db_done)) return rc;
+        if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st, dbias_fw, dbias_bw, &db_done)) return rc;
         if (db_done) return 0;
     } else {
         LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * sizeof(float), "las_rnn_seq_bwd: workspace too small");

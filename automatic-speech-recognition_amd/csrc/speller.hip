@@ -25,7 +25,7 @@ constexpr int RNW = RNT / 64;      // waves
 constexpr int RNH = RNT / 128;     // frame groups of the context reduction
 
 struct DecDev {
-    int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits;
+    int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
     float fb;
     unsigned long long seed;
     const float *enc, *keys; const int* enc_len;
@@ -1653,7 +1653,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     LAS_ARG((((uintptr_t)f->keys | (uintptr_t)f->u | (uintptr_t)f->Ws) & 15) == 0, "speller: keys/u/Ws must be 16-byte aligned");
     d.B = f->B; d.Tp = f->Tp; d.Hd = f->Hd; d.A = f->A; d.D = f->D; d.NL = f->NL; d.E = f->E; d.V = f->V; d.U = f->U;
     d.mode = f->mode; d.Kc = f->mode == LAS_ATT_LOC ? f->Kc : 0; d.C = f->mode == LAS_ATT_LOC ? f->C : 0;
-    d.step_logits = f->step_logits; d.fb = f->forget_bias; d.seed = f->seed;
+    d.step_logits = f->step_logits; d.flags = f->flags; d.fb = f->forget_bias; d.seed = f->seed;
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.logits = f->logits; d.alphas = f->alphas;
@@ -1669,14 +1669,12 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
 
 // speed mode, additive attention: the row kernels read bf16 copies of Ws / keys / encoder rows (made once per call)
 static bool bf_rows_ok(const DecDev& d) {
-    const char* off = getenv("LAS_NO_BF_ROWS");       // debugging knob: keep the fp32-operand row kernels
-    return !(off && off[0] == '1') && d.mode == LAS_ATT_ADD && (d.A % 8) == 0 && (d.Hd % 8) == 0 && d.A <= 256;
+    return !(d.flags & LAS_SPELLER_NO_BF_ROWS) && d.mode == LAS_ATT_ADD && (d.A % 8) == 0 && (d.Hd % 8) == 0 && d.A <= 256;
 }
 // ... and, for the common single-layer geometry, the fully prefetching variants
 static bool pf_rows_ok(const DecDev& d) {
-    const char* off = getenv("LAS_NO_PF_ROWS");
-    return !(off && off[0] == '1') && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 && d.E <= 1024 &&
-           (d.E % 2) == 0 && (d.D % 2) == 0;
+    return !(d.flags & LAS_SPELLER_NO_PF_ROWS) && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 &&
+           d.E <= 1024 && (d.E % 2) == 0 && (d.D % 2) == 0;
 }
 static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
     unsigned short* wsb = (unsigned short*)(base + w.wsbf);

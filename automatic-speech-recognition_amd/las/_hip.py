@@ -23,7 +23,7 @@ _lib = None
 
 class SpellerFwdArgs(Structure):
     _fields_ = [(n, c_int) for n in ("B", "Tp", "Hd", "A", "D", "NL", "E", "V", "U", "cell", "mode", "prec", "Kc", "C",
-                                     "step_logits", "keep_state0")] + [
+                                     "step_logits", "keep_state0", "flags")] + [
         ("forget_bias", c_float), ("seed", ctypes.c_ulonglong),
         ("enc", c_void_p), ("keys", c_void_p), ("enc_len", c_void_p),
         ("Ws", c_void_p), ("u", c_void_p), ("emb", c_void_p), ("Wv", c_void_p), ("bv", c_void_p),
@@ -54,13 +54,13 @@ _SIGS = {
     "las_tanh_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "las_rnn_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "las_rnn_seq_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                c_void_p, c_int, c_longlong, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_int, c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
-                                c_float, c_void_p, c_size_t, c_void_p]),
+                                c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_bwd_db": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
-                                   c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
@@ -274,27 +274,114 @@ class _timed:
         return False
 
 
+# ---- development switches of the sweeps / the Speller (explicit `flags` arguments of the C ABI).  The library itself
+# reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
+# tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
+SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES = 1, 2, 4
+SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS = 1, 2
+SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound",
+              2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
+
+
+def seq_p(p):
+    return (int(p) & 0xf) << 8
+
+
+def seq_spin_log2(n):
+    return (int(n) & 0x1f) << 16
+
+
+def _flags_from_env():
+    e = os.environ.get
+    f = (SEQ_AGENT_GRANULES if e("LAS_AGENT_GRANULES") == "1" else 0) | (SEQ_NO_KSPLIT if e("LAS_NO_KSPLIT") else 0) | \
+        (SEQ_NO_HELPER_WAVES if e("LAS_NO_HELPER_WAVES") else 0)
+    if e("LAS_SEQ_P"):
+        f |= seq_p(e("LAS_SEQ_P"))
+    if e("LAS_SPIN_LOG2"):
+        f |= seq_spin_log2(e("LAS_SPIN_LOG2"))
+    g = (SPELLER_NO_PF_ROWS if e("LAS_NO_PF_ROWS") == "1" else 0) | (SPELLER_NO_BF_ROWS if e("LAS_NO_BF_ROWS") == "1" else 0)
+    return f, g
+
+
+seq_flags, speller_flags = _flags_from_env()
+
+_status = {}
+
+
+def status_word(dev):
+    """The sticky int32 device word the sweeps report exchange timeouts through (one per device)."""
+    key = str(dev)
+    t = _status.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        _status[key] = t
+    return t
+
+
+def check_status(dev=None):
+    """Synchronising check of the sweep status word(s): raises RuntimeError if any sweep reported a timeout.
+    Call it wherever the host already waits for the device (loss read-out, end of a bench loop, checkpoint)."""
+    for key, t in list(_status.items()):
+        if dev is not None and str(dev) != key:
+            continue
+        code = int(t.item())
+        if code:
+            t.zero_()
+            raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s -- the cluster workgroups were not "
+                               "all resident (shared / partitioned GPU?); results of that step are invalid"
+                               % (key, code, SEQ_STATUS.get(code, "unknown")))
+
+
+_probe = {}
+
+
+def poll_status(dev):
+    """Non-blocking companion of check_status for callers that never wait for the device (LAS.train called in a loop
+    without reading the loss): enqueue a copy of the status word to pinned host memory; when an EARLIER probe has
+    completed with a non-zero code, raise.  A timeout is therefore reported at most a couple of steps late."""
+    key = str(dev)
+    if key not in _status:
+        return
+    pr = _probe.get(key)
+    if pr is not None and pr[1].query():
+        code = int(pr[0][0])
+        if code:
+            _status[key].zero_()
+            _probe.pop(key, None)
+            raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s" % (key, code, SEQ_STATUS.get(code, "unknown")))
+        pr = None
+    if pr is None:
+        pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ev = torch.cuda.Event()
+        pin.copy_(_status[key], non_blocking=True)
+        ev.record()
+        _probe[key] = (pin, ev)
+
+
 def rnn_seq_ws(cell, prec, H, B, dev):
     return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H, B), "rnn_seq")
 
 
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                forget_bias=1.0, wf_off=0, wb_off=0):
+                forget_bias=1.0, wf_off=0, wb_off=0, flags=None):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
+    fl = seq_flags if flags is None else flags
     with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                     c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
-                                    p(cstate), forget_bias, p(ws), ws.numel(), stream()), "las_rnn_seq_fwd")
+                                    p(cstate), forget_bias, fl, p(status_word(gates.device)), p(ws), ws.numel(), stream()),
+              "las_rnn_seq_fwd")
 
 
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None):
+                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None):
     """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
+    fl = seq_flags if flags is None else flags
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_bwd_db(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                        c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
                                        p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(db_fw), p(db_bw),
-                                       p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db")
+                                       fl, p(status_word(gates.device)), p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db")

@@ -158,6 +158,7 @@ class BeamSearch(object):
                 break
         if t == dec_step:
             selected.extend(beam_set)
+        _hip.check_status(dev)
         return self._select_best_k(selected, NORM)
 
     def restore_las(self, sess, save_path, restore_epoch):

@@ -16,6 +16,7 @@ from las import _hip
 from las import layers as L
 from las import variables as V
 from las.layers import AdditiveAttention, LocationAwareAttention, pBLSTMLayer, CNNLayer  # noqa: F401
+from las.parallel import sampling_seed
 from las.utils import convert_idx_to_token_tensor
 
 SOS_ID = 1  # tf.ones(...) look-up at reference las/las.py:81
@@ -82,6 +83,7 @@ def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, b
     for k, v in dims.items():
         setattr(fa, k, v)
     fa.step_logits = int(step_logits)
+    fa.flags = int(_hip.speller_flags)
     fa.keep_state0 = int(keep_state0)
     fa.forget_bias = 1.0
     fa.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -232,6 +234,7 @@ class Speller:
                                    kernel_size=self.args.loc_kernel_size, num_channels=self.args.loc_num_channels,
                                    mode=self.args.mode)
         self.last_tokens_out = None
+        self.rank = 0              # data-parallel rank: per-rank sampling noise (set by LAS.train from las.dp)
 
     # -- variables ---------------------------------------------------------------------------------
     def _build_decoder_cell(self):
@@ -292,15 +295,11 @@ class Speller:
         if torch.is_tensor(enc_len) and enc_len.is_cuda and enc_len.dtype == torch.int32:
             enc_len_i32 = enc_len.contiguous()
         else:
-            # float -> int32 as tf.sequence_mask's cast does (las/layers.py:193); uploaded from a small ring of pinned
-            # staging buffers with a non-blocking copy, so the host is not held until the stream drains
+            # float -> int32 as tf.sequence_mask's cast does (las/layers.py:193); uploaded from pinned memory with a
+            # non-blocking copy, so the host is not held until the stream drains (the caching host allocator keeps the
+            # staging block alive until the copy has executed)
             host = torch.as_tensor(enc_len).to(torch.float64).to(torch.int32).reshape(-1)
-            ring = self.__dict__.setdefault("_pin_ring", {})
-            slot = ring.setdefault(host.numel(), [[torch.empty(host.numel(), dtype=torch.int32).pin_memory() for _ in range(4)], 0])
-            pin = slot[0][slot[1] % 4]
-            slot[1] += 1
-            pin.copy_(host)
-            enc_len_i32 = pin.to(dev, non_blocking=True)
+            enc_len_i32 = host.pin_memory().to(dev, non_blocking=True)
         st = V.default_store()
         tokens_in = torch.full((U, B), -1, dtype=torch.int32, device=dev)
         tokens_in[0] = SOS_ID
@@ -354,7 +353,7 @@ class Speller:
         enc_len_i32, tokens_in = prepared["enc_len_i32"], prepared["tokens_in"]
         step_logits, emb_mask = prepared["step_logits"], prepared["emb_mask"]
         P = self._params()
-        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, 977 + st.global_step, emb_mask)
+        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, sampling_seed(st.global_step, self.rank), emb_mask)
         cp = list(P["cellW"]) + list(P["cellb"])
         logits_tm, alphas_tm = _SpellerLoop.apply(enc_out, P["Wh"], P["Ws"], P["u"], P["emb"], P["Wv"], P["bv"],
                                                   P.get("loc_w"), P.get("loc_b"), P.get("Wf"), cfg, enc_len_i32,
@@ -578,6 +577,7 @@ class LAS:
         # gradient: gradient bucket reset, global token count (one small all-reduce under data parallelism)
         st.flatten()
         st.zero_grad()
+        self.speller.rank = self.dp.rank if self.dp is not None else 0
         n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
         n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
         # the Speller's host-side preparation first: its small uploads overlap with the Listener kernels
@@ -598,6 +598,7 @@ class LAS:
         lr = self._scheduled_learning_rate(start=50000, decay_step=100000, decay_rate=0.5, min_rate=0.01,
                                            global_step=st.global_step)
         self._apply_adam(st, lr)
+        _hip.poll_status(dev)                         # a sweep exchange timeout of an earlier step surfaces here
         st.global_step += 1
         sample_rate = self.speller._scheduled_sampling()
         summaries = {"loss": loss_val, "global_step": st.global_step, "lr": lr}
@@ -621,6 +622,10 @@ class LAS:
                    "las_clip_adam")
         self.last_grad_sumsq = sumsq
 
+    def check_status(self):
+        """Synchronising check that no recurrent sweep reported an exchange timeout (raises RuntimeError)."""
+        _hip.check_status(self._device())
+
     def sample_texts(self):
         """The HYP / REF strings the reference builds for its text summaries (las/las.py:286-289)."""
         logits, y = self.last["logits"], self.last["y"]
@@ -642,4 +647,5 @@ class LAS:
             h, enc_state, enc_len = self.listener(audio, audiolen, encoder=self.args.enc_type.lower(), is_training=False)
             logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, is_training=False)
         y_hat = torch.argmax(logits, -1)
+        _hip.check_status(dev)
         return logits, y_hat

@@ -121,15 +121,22 @@ def dense(x, W, b=None, tanh=False):
 
 
 class _BLSTM(torch.autograd.Function):
-    """One bidirectional recurrent layer: K1 input projection + K2 persistent sweep (+ K2b BPTT)."""
+    """One bidirectional recurrent layer: K1 input projection + K2 persistent sweep (+ K2b BPTT).
+
+    x_bw: optional second input block for the backward direction (training with input dropout: the reference wraps
+    fw_cell and bw_cell in separate DropoutWrappers, las/layers.py:37-42, so the two directions see independently
+    masked inputs).  None = both directions read x (one product over the concatenated weights)."""
 
     @staticmethod
-    def forward(ctx, x, kfw, bfw, kbw, bbw, cell, prec, H, pad_even):
+    def forward(ctx, x, kfw, bfw, kbw, bbw, cell, prec, H, pad_even, x_bw=None):
         B, T, I = x.shape
         G = 4 if cell == "lstm" else 1
         GH = G * H
         dev = x.device
         x = x.contiguous()
+        two = x_bw is not None
+        if two:
+            x_bw = x_bw.contiguous()
         Ik = I
         if prec == _hip.PREC_BF16 and I % 4 and (I + 3) // 4 * 4 <= I + H:
             # MFCC-39: pad the operand with zero columns up to a multiple of 4 so the contraction takes the branch-free
@@ -137,30 +144,38 @@ class _BLSTM(torch.autograd.Function):
             # here, and given an exactly-zero gradient contribution in backward.
             Ik = (I + 3) // 4 * 4
             x = torch.nn.functional.pad(x, (0, Ik - I))
+            if two:
+                x_bw = torch.nn.functional.pad(x_bw, (0, Ik - I))
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=torch.float32)
-        # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H]); both directions in ONE
-        # product over the concatenated weights, so x is read once
-        kcat = torch.cat((kfw[:Ik], kbw[:Ik]), 1)                   # [Ik, 2*GH]
-        _hip.gemm(prec, x, kcat, gates, False, False, B * T, 2 * GH, Ik, Ik, 2 * GH, 2 * GH, bias=torch.cat((bfw, bbw)))
+        if not two:
+            # x_t . W_ih + bias for all t at once (W_ih = first I rows of the TF kernel [(I+H), G*H]); both directions in
+            # ONE product over the concatenated weights, so x is read once
+            kcat = torch.cat((kfw[:Ik], kbw[:Ik]), 1)                   # [Ik, 2*GH]
+            _hip.gemm(prec, x, kcat, gates, False, False, B * T, 2 * GH, Ik, Ik, 2 * GH, 2 * GH, bias=torch.cat((bfw, bbw)))
+        else:
+            for d, (xd, k, b) in enumerate(((x, kfw, bfw), (x_bw, kbw, bbw))):
+                _hip.gemm(prec, xd, k, gates, False, False, B * T, GH, Ik, Ik, GH, 2 * GH, bias=b, c_off=d * GH)
         Tp = T + (T % 2) if pad_even else T
         out = torch.zeros(B, Tp, 2 * H, device=dev) if Tp != T else torch.empty(B, T, 2 * H, device=dev)
         cst = torch.empty(B, T, 2, H, device=dev) if cell == "lstm" else None
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          1.0, wf_off=I * GH, wb_off=I * GH)
-        ctx.save_for_backward(x, kfw, kbw, gates, out, cst)
+        ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
         ctx.cfg = (cell, prec, H, Tp, I)
         ctx.params = _PARAMS.get("blstm")
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, kfw, kbw, gates, out, cst = ctx.saved_tensors
+        x, kfw, kbw, gates, out, cst, x_bw = ctx.saved_tensors
         cell, prec, H, Tp, I0 = ctx.cfg
         B, T, I = x.shape                              # I = operand width (I0 padded to a multiple of 4 in speed mode)
         G = 4 if cell == "lstm" else 1
         GH = G * H
         dev = x.device
         dout = dout.contiguous()
+        two = x_bw is not None
+        xs = (x, x_bw if two else x)
         # gates: activated gates -> d(pre-activation), in place
         P4 = ctx.params
         direct = P4 is not None and all(_direct_ok(p) for p in P4)
@@ -168,36 +183,41 @@ class _BLSTM(torch.autograd.Function):
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
                          db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None)
-        grads = []
-        dx = torch.empty(B, T, I0, device=dev) if ctx.needs_input_grad[0] else None
-        if dx is not None:                             # on the dependency chain: main stream, first
+        dx = dx_bw = None
+        if ctx.needs_input_grad[0] and not two:        # on the dependency chain: main stream, first
             # dZ [B*T, 2*GH] . [W_ih_fw | W_ih_bw]^T in one product (one pass over dx instead of two)
+            dx = torch.empty(B, T, I0, device=dev)
             kcat = torch.cat((kfw[:I0], kbw[:I0]), 1)               # [I0, 2*GH]
             _hip.gemm(prec, gates, kcat, dx, False, True, B * T, I0, 2 * GH, 2 * GH, 2 * GH, I0)
+        elif two and (ctx.needs_input_grad[0] or ctx.needs_input_grad[9]):
+            dx, dx_bw = torch.empty(B, T, I0, device=dev), torch.empty(B, T, I0, device=dev)
+            for d, (dxd, k) in enumerate(((dx, kfw), (dx_bw, kbw))):
+                _hip.gemm(prec, gates, k, dxd, False, True, B * T, I0, GH, 2 * GH, GH, I0, a_off=d * GH)
         _hip.run_deferred()
         if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
             with _hip.on_side_stream():
                 side = _hip.side_stream()
-                for t in (x, gates, out):
+                for t in (x, gates, out) + ((x_bw,) if two else ()):
                     t.record_stream(side)
                 part = torch.empty(B, H, GH, device=dev) if T > 1 else None
                 for d in range(2):
                     kp, bp = P4[2 * d], P4[2 * d + 1]
                     gk = kp.grad                       # [(I+H), GH] view of the flat bucket
-                    _hip.gemm(prec, x, gates, gk, True, False, I, GH, B * T, I, 2 * GH, GH, beta=1.0, b_off=d * GH)
+                    _hip.gemm(prec, xs[d], gates, gk, True, False, I, GH, B * T, I, 2 * GH, GH, beta=1.0, b_off=d * GH)
                     if T > 1:
                         a_off = d * H + (0 if d == 0 else 2 * H)
                         b_off = d * GH + (2 * GH if d == 0 else 0)
                         _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
                                   strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
                         _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
-            return (dx, None, None, None, None, None, None, None, None)
+            return (dx, None, None, None, None, None, None, None, None, dx_bw)
+        grads = []
         part = torch.empty(B, H, GH, device=dev) if T > 1 else None
         for d, k in enumerate((kfw, kbw)):
             dk = torch.empty_like(k)
             # dW_ih = x^T . dG_d        (contraction over all B*T frames; split-K inside las_gemm)
-            _hip.gemm(prec, x, gates, dk, True, False, I, GH, B * T, I, 2 * GH, GH, b_off=d * GH)
+            _hip.gemm(prec, xs[d], gates, dk, True, False, I, GH, B * T, I, 2 * GH, GH, b_off=d * GH)
             # dW_hh = sum_b sum_t h_prev^T . dG_d : per-utterance products (fw pairs h[t-1] with dG[t],
             # bw pairs h[t+1] with dG[t]), then a fixed-order sum over utterances
             if T > 1:
@@ -213,7 +233,7 @@ class _BLSTM(torch.autograd.Function):
             db = torch.empty(GH, device=dev)
             _hip.colsum(gates, B * T, GH, 2 * GH, db, x_off=d * GH)
             grads += [dk, db]
-        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None)
+        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, dx_bw)
 
 
 def _blstm_params(scope, I, H, cell):
@@ -239,17 +259,20 @@ def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pa
     """blstm() plus the already-concatenated [B,T(+pad),2H] buffer the kernels wrote (the
     tf.concat(rnn_out, -1) of las/layers.py:69,81 is free: both directions share one tensor)."""
     _hip.require_gpu(inputs)
+    x_bw = None
     if is_training is True and dropout_rate:
-        # DropoutWrapper(input_keep_prob=1-rate): a fresh Bernoulli mask on the cell INPUT at every time step,
-        # scaled by 1/keep (las/layers.py:37-42, SURVEY App. A.5).  The input projection is hoisted over all t, so
-        # the per-step masks are one mask over [B,T,I] (torch RNG: plumbing, the mask is not on the MFMA path).
+        # DropoutWrapper(input_keep_prob=1-rate) around fw_cell AND around bw_cell (las/layers.py:37-47): each direction
+        # draws its own fresh Bernoulli mask on the cell INPUT at every time step, scaled by 1/keep (SURVEY App. A.5).
+        # The input projection is hoisted over all t, so the per-step masks of a direction are one mask over [B,T,I]
+        # (torch RNG: plumbing, the masks are not on the MFMA path).
+        x_bw = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
         inputs = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
     cell = _CFG["cell"]
     H = int(cell_units)
     I = inputs.shape[-1]
     kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
     _PARAMS["blstm"] = (kfw, bfw, kbw, bbw)
-    out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even)
+    out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even, x_bw)
     _PARAMS.clear()
     T = inputs.shape[1]
     fw, bw = out[..., :H], out[..., H:]

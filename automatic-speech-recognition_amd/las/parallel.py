@@ -20,21 +20,29 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+    # The collectives are issued for every world size, 1 included: a one-rank group still goes through the backend
+    # (RCCL on a GPU box), which is how the single-GPU test box exercises communicator set-up and the bucket exchange.
     def all_reduce_(self, flat):
-        if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def all_reduce_scalar(self, x):
         x = x.detach().clone().reshape(1)
-        if self.world > 1:
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
         return x[0]
 
     def broadcast_(self, flat, src=0):
-        if self.world > 1:
-            dist.broadcast(flat, src=src, group=self.group)
+        dist.broadcast(flat, src=src, group=self.group)
         return flat
+
+    def sampling_seed(self, global_step):
+        """Seed of this rank's scheduled-sampling draws at a step: distinct per rank (only the coin is
+        shared), reproducible for a given (step, rank)."""
+        return sampling_seed(global_step, self.rank)
+
+
+def sampling_seed(global_step, rank=0):
+    return (977 + int(global_step)) * 1000003 + 7919 * int(rank)
 
 
 def shard(items, rank, world):

@@ -33,6 +33,7 @@ def main():
         print('=' * 60 + '\n')
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.manual_seed(args.seed * 1000003 + rank)                 # dropout masks: per-rank streams
     dp = None
     if world > 1:
         import torch.distributed as dist
@@ -84,6 +85,7 @@ def main():
         xs, ys = next(batches)
         batch_loss, _, gs, logits, alphas, _, tfrate = las.train(xs, ys)
         batch_loss = float(batch_loss)
+        las.check_status()                                         # the host has just waited for the step anyway
         if rank == 0:
             if args.verbose > 0:
                 logging.info("HYP: {}".format(convert_idx_to_string(torch.argmax(logits[0], -1).cpu().numpy(), id_to_token, args.unit)))

@@ -103,6 +103,33 @@ def cpu_baseline(cell, timeout=240.0):
                 "sample": "oracle train step did not finish within %.0f s (%s)" % (timeout, type(e).__name__)}
 
 
+def self_launch(n, argv):
+    """Run `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child (one rank per GPU over RCCL).
+    Called before anything initialises the GPU in this process (torch.cuda.device_count() does not)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d device(s) are visible\n" % (n, have))
+        return 2
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        return 3
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,10 +145,16 @@ def main():
     if a.cpu_baseline_only:
         cpu_baseline_child(a.cell)
         return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this parent never touches the GPU; it starts N fresh ranks
+        # under torch.distributed.run, relays rank 0's JSON line and exits with the launcher's code
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (a.gpus, world, a.gpus))
     # the driver stack may print to fd 1 while the device is initialised (libdrm's "amdgpu.ids" notice): keep stdout
     # for the ONE JSON line by pointing fd 1 at stderr until the result is printed
     sys.stdout.flush()
@@ -153,6 +186,7 @@ def main():
 
     L.set_cell(a.cell)
     L.set_precision(a.dtype)
+    torch.manual_seed(1000003 + rank)
     V.reset_default_store(device=dev, seed=0)
     args = bench_args(a.cell)
     las = LAS(args, Listener, Speller, {})
@@ -183,6 +217,7 @@ def main():
         loss = las.train(xs, ys)[0]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    las.check_status()                              # a sweep exchange timeout would invalidate the measurement
     if dp is not None:
         dist.barrier()
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -16,7 +16,8 @@
  *     (parity mode), LAS_PREC_BF16 = operands rounded to bf16 (RNE), fp32 MFMA accumulation
  *     (speed mode).  State, activations, gradients and optimiser math are always fp32.
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued asynchronously on it,
- *     no hidden synchronisation, no global mutable state besides an init-once attribute cache.
+ *     no hidden synchronisation, no global mutable state besides an init-once attribute cache; the library
+ *     reads no environment variables (development switches are explicit `flags` arguments).
  *   - return value: 0 ok; <0 invalid argument / unsupported shape (message via las_last_error());
  *     >0 a hipError_t.
  */
@@ -82,16 +83,32 @@ int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, 
  * cstate: lstm only, [B,T,2,H] cell states (saved for bwd).
  * dout  : gradient w.r.t. out, same addressing scheme.
  */
+/* `flags` (development / test switches, 0 in normal use; explicit per call -- the library reads no environment):
+ *   LAS_SEQ_AGENT_GRANULES   cluster members always exchange through agent-scope (write-through) granules,
+ *                            as if they ran on different XCDs
+ *   LAS_SEQ_NO_KSPLIT        BPTT uses the all-gather cluster kernel instead of the K-split reduce-scatter one
+ *   LAS_SEQ_NO_HELPER_WAVES  forward sweep without the helper waves that own the bulk HBM traffic
+ *   LAS_SEQ_P(p)             cluster width override (1, 2, 4, 8 workgroups per (direction, 16-row tile))
+ *   LAS_SEQ_SPIN_LOG2(n)     bound of every exchange spin = 2^n polls (default 2^22)
+ * `status` (may be NULL): caller-owned, caller-zeroed int32 DEVICE word.  The clustered bf16 sweeps exchange h / dh
+ *   between workgroups with bounded spins; if a partner does not publish within the bound (it is not co-resident:
+ *   shared or partitioned device) the launch finishes with undefined results and stores LAS_SEQ_STATUS_* here.
+ *   The word is sticky (never cleared by the library); the caller reads it at its next synchronisation point. */
+enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVES = 4 };
+#define LAS_SEQ_P(p) (((p) & 0xf) << 8)
+#define LAS_SEQ_SPIN_LOG2(n) (((n) & 0x1f) << 16)
+enum { LAS_SEQ_STATUS_OK = 0, LAS_SEQ_STATUS_FWD_TIMEOUT = 1, LAS_SEQ_STATUS_BWD_TIMEOUT = 2 };
+
 size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
 int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
                     float* out, int ld_out, long long out_bstride, float* cstate,
-                    float forget_bias, void* ws, size_t ws_bytes, void* stream);
+                    float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream);
 int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
                     const float* out, int ld_out, long long out_bstride, const float* cstate,
                     const float* dout, int ld_dout, long long dout_bstride,
-                    float forget_bias, void* ws, size_t ws_bytes, void* stream);
+                    float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream);
 /* Same, and additionally accumulates (+=) the bias gradients of the two directions, dbias_fw / dbias_bw [G*H] (either may
  * be NULL) = column sums of d(pre-activation) over all B*T frames (the bias of the TF cell kernel, las/layers.py:31).  The
  * cluster BPTT kernel sums them in registers while it sweeps (no extra pass over the 4*B*T*G*H-byte gradient). */
@@ -99,7 +116,8 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates,
                        const float* whh_fw, const float* whh_bw, int ldw,
                        const float* out, int ld_out, long long out_bstride, const float* cstate,
                        const float* dout, int ld_dout, long long dout_bstride,
-                       float forget_bias, float* dbias_fw, float* dbias_bw, void* ws, size_t ws_bytes, void* stream);
+                       float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4-K7  Speller: the whole decode loop of Speller.__call__ (las/las.py:72-143) with
@@ -126,8 +144,11 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates,
  *   gates [NL,U,B,G*D] activated gates (lstm) / pre-activation scratch (rnn)
  *   xin0 [U,B,E+Hd+D]  first-layer cell input rows  [emb(token) ; context ; h_prev]
  */
+enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetching row kernels (generic bf16 rows) */
+       LAS_SPELLER_NO_BF_ROWS = 2 };  /* speed mode with the fp32-operand row kernels */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
+    int flags;                     /* LAS_SPELLER_* development / test switches, 0 in normal use */
     float forget_bias;
     unsigned long long seed;
     const float *enc, *keys; const int* enc_len;

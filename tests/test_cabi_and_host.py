@@ -49,7 +49,7 @@ def test_argument_validation_happens_before_any_launch(libpath):
     l = _hip.lib()
     rc = l.las_gemm(7, 0, 0, 4, 4, 4, 1.0, None, 4, 0, None, 4, 0, 0.0, None, 4, 0, None, 0, 1, 0, 0, None, 0, None)
     assert rc < 0 and b"bad prec" in l.las_last_error()
-    rc = l.las_rnn_seq_fwd(1, 0, 0, 4, 8, None, None, None, 8, None, 16, 0, None, 1.0, None, 0, None)
+    rc = l.las_rnn_seq_fwd(1, 0, 0, 4, 8, None, None, None, 8, None, 16, 0, None, 1.0, 0, None, None, 0, None)
     assert rc < 0 and b"las_rnn_seq_fwd" in l.las_last_error()
 
 
