@@ -51,6 +51,10 @@ struct DecDev {
     const float* rec[LAS_MAX_NL]; int recLd[LAS_MAX_NL]; int recOff[LAS_MAX_NL];
 };
 
+// contraction operand in the arithmetic of the mode: speed mode rounds to bf16 (RNE) exactly like the MFMA paths do,
+// so that the in-loop vocabulary projection (sampling / greedy steps) equals the after-loop GEMM of the same logits
+template <bool FAST> __device__ __forceinline__ float opnd(float x) { return FAST ? bf2f(f2bf(x)) : x; }
+
 __device__ __forceinline__ float gumbel_noise(unsigned long long seed, int t, int b, int v) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(((long long)t * 1000003 + b) * 65537 + v + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
             float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
             for (int v = tid; v < V; v += RNT) {
                 float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(L.hl[d], a.Wv[(size_t)d * V + v], acc);
+                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.hl[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
                 lrow[v] = acc;
                 if (acc > bestv) { bestv = acc; besti = v; }
                 const float sc = acc + gumbel_noise(a.seed, t, b, v);
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
             float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
             for (int v = tid; v < V; v += RNT) {
                 float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(L.hl[d], a.Wv[(size_t)d * V + v], acc);
+                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.hl[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
                 lrow[v] = acc;
                 if (acc > bestv) { bestv = acc; besti = v; }
                 const float sc = acc + gumbel_noise(a.seed, t, b, v);
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int kk = k + 64 * u;
-                    const float sk = kk < S ? L.s_state[kk] : 0.f;
+                    const float sk = kk < S ? bf2f(f2bf(L.s_state[kk])) : 0.f;   // both operands bf16, as in the pf kernel
                     float w[8];
                     unpack8(w8[u], w);
 #pragma unroll
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int t2 = tt + RNW * u;
-                    const float al = t2 < lim ? L.ev[t2] : 0.f;
+                    const float al = t2 < lim ? bf2f(f2bf(L.ev[t2])) : 0.f;      // both operands bf16, as in the pf kernel
                     float x[8];
                     unpack8(e8[u], x);
 #pragma unroll
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
             float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
             for (int v = tid; v < V; v += RNT) {
                 float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(L.s_state[d], a.Wv[(size_t)d * V + v], acc);
+                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.s_state[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
                 lrow[v] = acc;
                 if (acc > bestv) { bestv = acc; besti = v; }
                 const float sc = acc + gumbel_noise(a.seed, t, b, v);

@@ -43,3 +43,59 @@ def synthetic_batch(B, T, U_max, V, seed=0, feat_dim=13, min_frac=0.5):
         y[b, :n - 1] = rng.randint(3, V, size=n - 1)
         y[b, n - 1] = 2
     return (audio, audiolen), (y, tokenlen)
+
+
+def oracle_mode_for(args, prec):
+    """The oracle arithmetic mode that restates what the HIP path runs for this configuration (oracle.set_precision):
+    speed mode rounds every contraction operand to bf16; with additive attention the Speller row kernels also keep
+    keys / context operands in bf16 ('bf' rows), otherwise only the GEMM operands are rounded ('f32' rows)."""
+    if prec != "bf16":
+        return ("f32", "bf")
+    I0D = args.embedding_size + (2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units) + args.dec_units
+    hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
+    bf_rows = args.mode == "add" and I0D % 8 == 0 and args.attention_size % 8 == 0 and hd % 8 == 0
+    return ("bf16", "bf" if bf_rows else "f32")
+
+
+def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", oracle_dtype=None):
+    """One LAS.train step through the C ABI on cuda and the oracle's train_step in the matching arithmetic mode, on
+    identical weights / inputs.  Returns a dict of both sides' loss, logits, alphas, gradients, updated parameters."""
+    import torch
+    from las import layers as L
+    from las import variables as V
+    from las.las import LAS, Listener, Speller
+    from oracle import las_oracle as O
+    p0 = O.init_params(args, seed=seed, cell=cell, enc_type=enc_type)
+    mode = oracle_mode_for(args, prec)
+    O.set_precision(*mode)
+    try:
+        po = O.to_torch(p0, requires_grad=True)
+        zeros = {k: torch.zeros_like(v) for k, v in po.items()}
+        loss_o, logits_o, alphas_o, g_o, newp, _, _ = O.train_step(
+            po, zeros, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
+            (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, coins=coins,
+            sampled=None if sampled is None else torch.tensor(sampled))
+    finally:
+        O.set_precision("f32")
+    L.set_cell(cell)
+    L.set_precision(prec)
+    st = V.reset_default_store(device="cuda")
+    st.load(p0)
+    las = LAS(args, Listener, Speller, {})
+    loss, _, gs, logits, alphas, summ, rate = las.train(xs, ys, coins=coins, sampled=sampled)
+    torch.cuda.synchronize()
+    las.check_status()
+    grads = {n: st.vars[n].grad.detach().cpu() for n in st.order}
+    params = {n: st.vars[n].detach().cpu() for n in st.order}
+    return dict(loss_o=float(loss_o), loss=float(loss), logits_o=logits_o, logits=logits.cpu(), alphas_o=alphas_o,
+                alphas=alphas.cpu(), g_o=g_o, grads=grads, newp=newp, params=params, names=sorted(p0), gs=gs, las=las,
+                tokens_in=las.speller.last_tokens_in.cpu())
+
+
+def grad_errors(r):
+    """{name: max-abs error / max(|oracle gradient|, 1e-3)} for every parameter."""
+    out = {}
+    for n in r["names"]:
+        go, g = r["g_o"][n], r["grads"][n]
+        out[n] = (g - go).abs().max().item() / max(go.abs().max().item(), 1e-3)
+    return out

@@ -127,3 +127,25 @@ def test_listener_output_length_matches_the_layers():
     for _ in range(2):
         want = (want + want % 2) / 2
     assert torch.equal(got_cnn, want)
+
+
+def test_bench_gpus_n_self_launch_refuses_without_enough_devices():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start N ranks itself (torch.distributed.run children); with
+    fewer than N devices visible it exits non-zero with a message instead of silently running one rank."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "--gpus 2 requested" in r.stderr and '"metric"' not in r.stdout
+    # under a launcher the rank count must agree with --gpus
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_sampling_seed_is_per_rank_and_per_step():
+    from las.parallel import sampling_seed
+    seen = {sampling_seed(s, r) for s in range(50) for r in range(8)}
+    assert len(seen) == 400

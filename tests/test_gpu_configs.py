@@ -1,0 +1,92 @@
+"""BASELINE.json configs at kernel-relevant sizes, every case against the oracle.
+
+  configs[0]  10-utterance pBLSTM-128 (1 pyramid layer), fp32, rnn cell = the reference's own cell: train step +
+              greedy inference (plumbing of the reference-faithful path)
+  configs[3]  subword vocabulary V = 5000 and location-aware attention with the reference defaults K = 201, C = 10
+              (reference las/arguments.py:130-137): CE kernel, vocabulary GEMM, in-loop logits / arg-max / sampling,
+              conv1d over the previous alignment, f32 and bf16
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import grad_errors, make_args, synthetic_batch, train_step_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(r, tol):
+    assert (r["logits"] - r["logits_o"]).abs().max().item() < tol["logits"]
+    assert (r["alphas"] - r["alphas_o"]).abs().max().item() < tol["alphas"]
+    assert abs(r["loss"] - r["loss_o"]) < tol["loss"] * max(1.0, abs(r["loss_o"]))
+    for n, e in grad_errors(r).items():
+        assert e < tol["grad"], (n, e)
+
+
+F32 = dict(logits=5e-4, alphas=1e-4, loss=1e-4, grad=2e-3)
+BF16 = dict(logits=6e-3, alphas=3e-3, loss=2e-3, grad=3e-2)
+
+
+@pytest.mark.parametrize("cell", ["rnn", "lstm"])
+def test_config0_ten_utterances_pblstm128_fp32(cell):
+    args = make_args(enc_units=128, num_enc_layers=1, dec_units=128, num_dec_layers=2, embedding_size=128, attention_size=128,
+                     lr=1e-3, grad_clip=5.0, convert_rate=0.166)
+    xs, ys = synthetic_batch(10, 120, 24, 30, seed=21)
+    r = train_step_pair(args, cell, "f32", xs, ys, seed=5)
+    _check(r, F32)
+    # greedy inference with the UPDATED weights must match the oracle run from the oracle's updated weights
+    from oracle import las_oracle as O
+    with torch.no_grad():
+        lo, yo = O.greedy_inference((torch.tensor(xs[0]), xs[1]), r["newp"], args, cell)
+    logits, y_hat = r["las"].inference(xs)
+    assert logits.shape == lo.shape
+    assert (logits.cpu() - lo).abs().max().item() < 2e-3
+    assert (y_hat.cpu() == yo).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_location_aware_attention_reference_defaults_k201_c10(prec):
+    args = make_args(enc_units=64, num_enc_layers=2, dec_units=128, num_dec_layers=1, embedding_size=64, attention_size=128,
+                     mode="loc", loc_kernel_size=201, loc_num_channels=10, lr=1e-3, grad_clip=5.0)
+    xs, ys = synthetic_batch(3, 530, 24, 30, seed=2)          # T' = 133 frames < kernel width 201: both borders clipped
+    r = train_step_pair(args, "lstm", prec, xs, ys, seed=9)
+    assert r["alphas"].shape[-1] == 133
+    _check(r, F32 if prec == "f32" else BF16)
+    g = r["grads"]["Speller/decode/attention/conv1d/kernel"]
+    assert g.shape == (201, 1, 10) and float(g.abs().max()) > 0
+
+
+@pytest.mark.parametrize("prec,mixed", [("f32", False), ("bf16", False), ("bf16", True)])
+def test_subword_vocabulary_v5000(prec, mixed):
+    V = 5000
+    args = make_args(enc_units=64, num_enc_layers=2, dec_units=128, num_dec_layers=1, embedding_size=64, attention_size=64,
+                     mode="add", vocab_size=V, unit="subword", lr=1e-3, grad_clip=5.0)
+    xs, ys = synthetic_batch(4, 90, 16, V, seed=4)
+    U = int(ys[1].max())
+    coins, sampled = None, None
+    if mixed:                                                  # in-loop logits (D x V product inside the row kernel)
+        rng = np.random.RandomState(1)
+        coins = rng.rand(U) < 0.5
+        sampled = rng.randint(3, V, size=(4, U)).astype(np.int32)
+    r = train_step_pair(args, "lstm", prec, xs, ys, seed=6, coins=coins, sampled=sampled)
+    assert r["logits"].shape[-1] == V
+    _check(r, F32 if prec == "f32" else BF16)
+
+
+def test_greedy_inference_v5000_argmax_on_device():
+    from las import layers as L, variables as V_
+    from las.las import LAS, Listener, Speller
+    from oracle import las_oracle as O
+    V = 5000
+    args = make_args(enc_units=48, num_enc_layers=2, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32,
+                     vocab_size=V, convert_rate=0.2)
+    xs, _ = synthetic_batch(3, 40, 8, V, seed=5)
+    p0 = O.init_params(args, seed=5, cell="lstm")
+    with torch.no_grad():
+        lo, yo = O.greedy_inference((torch.tensor(xs[0]), xs[1]), O.to_torch(p0), args, "lstm")
+    L.set_cell("lstm"); L.set_precision("f32")
+    st = V_.reset_default_store(device="cuda"); st.load(p0)
+    las = LAS(args, Listener, Speller, {})
+    logits, y_hat = las.inference(xs)
+    assert (logits.cpu() - lo).abs().max().item() < 5e-4
+    assert torch.equal(y_hat.cpu(), yo)

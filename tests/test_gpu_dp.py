@@ -59,3 +59,48 @@ def test_two_rank_step_equals_single_rank_full_batch(tmp_path):
     assert abs(got["loss"] - float(loss)) < 1e-5
     # Adam's first step is ~lr*sign(g): compare the UPDATE against lr, not the weights against each other
     assert (got["flat"] - st.flat.cpu()).abs().max().item() < 2e-4
+
+
+_RCCL_SCRIPT = r'''
+import os, sys
+sys.path[:0] = [%(pkg)r, %(root)r, %(tests)r]
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)        # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+from las.parallel import DataParallel
+from test_gpu_dp import _setup
+from helpers import synthetic_batch
+args, las, st = _setup("lstm")
+las.dp = DataParallel()
+las.build_variables()
+ref = st.flat.clone()
+las.dp.broadcast_(st.flat)                                                  # RCCL broadcast of the flat parameter bucket
+assert torch.equal(ref, st.flat)
+g = torch.arange(st.flat.numel(), device=dev, dtype=torch.float32)
+las.dp.all_reduce_(g)                                                       # RCCL all-reduce over one flat fp32 bucket
+assert torch.equal(g, torch.arange(st.flat.numel(), device=dev, dtype=torch.float32))
+xs, ys = synthetic_batch(6, 40, 8, 30, seed=11)
+loss = float(las.train(xs, ys)[0])                                          # a full step with the collectives in it
+torch.cuda.synchronize()
+print("RCCL_OK %%.6f" %% loss)
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_world1_flat_bucket_all_reduce_and_train_step():
+    """RCCL communicator set-up, broadcast and all-reduce of the flat gradient bucket on hardware (one rank: the test box
+    has one GPU), and the data-parallel train step through them == the plain single-process step."""
+    import subprocess
+    script = _RCCL_SCRIPT % dict(pkg=PKG, root=ROOT, tests=os.path.join(ROOT, "tests"), port=str(29900 + os.getpid() % 90))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_OK")]
+    assert line, r.stdout[-2000:]
+    args, las, st = _setup("lstm")
+    xs, ys = synthetic_batch(6, 40, 8, 30, seed=11)
+    loss = float(las.train(xs, ys)[0])
+    assert abs(float(line[0].split()[1]) - loss) < 1e-5

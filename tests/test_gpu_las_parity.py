@@ -2,13 +2,12 @@
 (oracle/las_oracle.py train_step; reference las/las.py:226-304): logits, alignments, loss, every
 parameter gradient and the Adam-updated parameters, on identical seeded inputs and weights.
 
-Tolerances: fp32 mode max-abs <= 1e-4 on logits/alphas at these sizes; bf16 mode is
-checked loosely (operands rounded to 8 mantissa bits)."""
+Tolerances: see TOL below (fp32 mode: SURVEY 8(d); bf16 mode: against the oracle's bf16-operand mode)."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import make_args, synthetic_batch
+from helpers import grad_errors, make_args, synthetic_batch, train_step_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -22,14 +21,19 @@ CONFIGS = [
     ("lstm", "add", 1, 64, 64, "bf16", False),
     ("rnn", "add", 1, 128, 64, "bf16", False),
     ("lstm", "add", 2, 64, 64, "bf16", True),
+    ("lstm", "loc", 1, 64, 64, "bf16", False),
+    ("rnn", "loc", 2, 64, 64, "bf16", True),
 ]
 
 
+# Stated tolerances.  f32 mode: SURVEY 8(d) (<= 1e-4 on logits / alignments at these sizes, 2e-3 relative on gradients).
+# bf16 mode is held against the oracle's bf16-OPERAND mode (oracle.set_precision('bf16'): same rounding points, fp32
+# accumulation), so what remains is accumulation order, fast transcendentals and the few values that land on the other
+# side of a bf16 rounding boundary: <= 4e-3 on logits, 2e-3 on alignments, 2e-2 relative on every gradient.
+TOL = {"f32": dict(logits=5e-4, alphas=1e-4, loss=1e-4, grad=2e-3), "bf16": dict(logits=4e-3, alphas=2e-3, loss=2e-3, grad=2e-2)}
+
+
 def _run_pair(cfg, B=5, T=37, U_max=9):
-    from las import layers as L
-    from las import variables as V
-    from las.las import LAS, Listener, Speller
-    from oracle import las_oracle as O
     cell, mode, NL, H, D, prec, mixed = cfg
     args = make_args(enc_units=H, num_enc_layers=2, dec_units=D, num_dec_layers=NL, embedding_size=32,
                      attention_size=32, mode=mode, loc_kernel_size=11, loc_num_channels=3, lr=1e-3, grad_clip=5.0)
@@ -41,45 +45,21 @@ def _run_pair(cfg, B=5, T=37, U_max=9):
     if mixed:
         coins = rng.rand(U) < 0.5
         sampled = rng.randint(3, args.vocab_size, size=(B, U)).astype(np.int32)
-    p0 = O.init_params(args, seed=11, cell=cell)
-    # --- oracle (fp32 CPU)
-    po = O.to_torch(p0, requires_grad=True)
-    zeros = {k: torch.zeros_like(v) for k, v in po.items()}
-    loss_o, logits_o, alphas_o, g_o, newp, _, _ = O.train_step(
-        po, zeros, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
-        (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, coins=coins,
-        sampled=None if sampled is None else torch.tensor(sampled))
-    # --- HIP path
-    L.set_cell(cell)
-    L.set_precision(prec)
-    st = V.reset_default_store(device="cuda")
-    st.load(p0)
-    las = LAS(args, Listener, Speller, {})
-    loss, _, gs, logits, alphas, summ, rate = las.train(xs, ys, coins=coins, sampled=sampled)
-    torch.cuda.synchronize()
-    grads = {n: st.vars[n].grad.detach().cpu() for n in st.order}
-    params = {n: st.vars[n].detach().cpu() for n in st.order}
-    return dict(loss_o=float(loss_o), loss=float(loss), logits_o=logits_o, logits=logits.cpu(), alphas_o=alphas_o,
-                alphas=alphas.cpu(), g_o=g_o, grads=grads, newp=newp, params=params, names=sorted(p0), gs=gs)
+    return train_step_pair(args, cell, prec, xs, ys, seed=11, coins=coins, sampled=sampled)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS)
 def test_train_step_matches_oracle(cfg):
     r = _run_pair(cfg)
     prec = cfg[5]
-    tol = 1e-4 if prec == "f32" else 6e-2
+    tol = TOL[prec]
     assert r["gs"] == 1
     assert set(r["grads"]) == set(r["names"]), set(r["names"]) ^ set(r["grads"])
-    assert (r["logits"] - r["logits_o"]).abs().max().item() < tol * 5
-    assert (r["alphas"] - r["alphas_o"]).abs().max().item() < tol
-    assert abs(r["loss"] - r["loss_o"]) < tol * max(1.0, abs(r["loss_o"]))
-    worst = 0.0
-    for n in r["names"]:
-        go, g = r["g_o"][n], r["grads"][n]
-        scale = max(go.abs().max().item(), 1e-3)
-        err = (g - go).abs().max().item() / scale
-        worst = max(worst, err)
-        assert err < (2e-3 if prec == "f32" else 0.25), (n, err, scale)
+    assert (r["logits"] - r["logits_o"]).abs().max().item() < tol["logits"]
+    assert (r["alphas"] - r["alphas_o"]).abs().max().item() < tol["alphas"]
+    assert abs(r["loss"] - r["loss_o"]) < tol["loss"] * max(1.0, abs(r["loss_o"]))
+    for n, err in grad_errors(r).items():
+        assert err < tol["grad"], (n, err)
     if prec == "f32":
         for n in r["names"]:
             # Adam's first step moves every weight by ~lr*sign(g): compare the update, not the weight

@@ -83,3 +83,49 @@ def test_rnn_seq_rejects_bad_args():
         _hip.rnn_seq_fwd(0, 0, 0, 4, 8, x, x, x, 8, x, 16, 0, None)     # B = 0
     with pytest.raises(RuntimeError):
         _hip.rnn_seq_fwd(1, 0, 1, 1, 1, x, x, x, 4, x, 2, 0, None)      # lstm without cstate
+
+
+def test_exchange_timeout_is_reported_not_silent():
+    """A cluster member that never sees its partners' granules (forced here by a spin bound of 2 polls) must surface as
+    an error: the sweep stores LAS_SEQ_STATUS_* in the status word and the host raises at its next check."""
+    from las import _hip
+    B, T, H = 48, 512, 256          # 512 exchanges x 24 workgroups: some gather needs more than 2 polls
+    GH = 4 * H
+    gates = torch.randn(B, T, 2, GH, device="cuda")
+    w0 = torch.randn(H, GH, device="cuda") * 0.05
+    out = torch.zeros(B, T, 2 * H, device="cuda")
+    cst = torch.zeros(B, T, 2, H, device="cuda")
+    _hip.check_status()                                   # clean before
+    _hip.rnn_seq_fwd(1, 1, B, T, H, gates, w0, w0, GH, out, 2 * H, T * 2 * H, cst, flags=_hip.seq_spin_log2(1))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="did not publish"):
+        _hip.check_status()
+    _hip.check_status()                                   # the word was cleared by the raise
+    # and the normal bound works on the same shape
+    _hip.rnn_seq_fwd(1, 1, B, T, H, gates, w0, w0, GH, out, 2 * H, T * 2 * H, cst)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    dout = torch.randn(B, T, 2 * H, device="cuda")
+    _hip.rnn_seq_bwd(1, 1, B, T, H, gates, w0, w0, GH, out, 2 * H, T * 2 * H, cst, dout, 2 * H, T * 2 * H, flags=_hip.seq_spin_log2(1))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="status 2"):
+        _hip.check_status()
+
+
+def test_batches_larger_than_the_cu_budget_are_swept_in_row_chunks():
+    """every cluster member must be resident (one workgroup per CU): B = 560 rows x 2 directions x P = 4 needs 280 CUs,
+    so the sweep runs as two launches over row chunks; results must equal the oracle as for a small batch."""
+    from las import _hip
+    B, T, H = 560, 5, 256
+    GH = 4 * H
+    g = torch.Generator().manual_seed(1)
+    xp = torch.randn(B, T, 2, GH, generator=g) * 0.8
+    whh = [(torch.rand(H, GH, generator=g) * 2 - 1) * 0.05 for _ in range(2)]
+    ref = _oracle_sweep(xp, whh, "lstm", double=False)
+    gates = xp.cuda()
+    out = torch.zeros(B, T, 2 * H, device="cuda")
+    cst = torch.zeros(B, T, 2, H, device="cuda")
+    _hip.rnn_seq_fwd(1, 1, B, T, H, gates, whh[0].cuda(), whh[1].cuda(), GH, out, 2 * H, T * 2 * H, cst)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    assert (out.cpu() - ref).abs().max().item() < 4e-2

@@ -1,0 +1,130 @@
+"""On-device scheduled sampling (reference las/las.py:101-105,170-175: tf.distributions.Categorical(logits).sample()).
+
+The row kernels draw Categorical(logits) as arg-max(logits + Gumbel noise) (tokens_in = -2).  Checked here:
+  * the draws follow softmax(logits): chi-square goodness of fit over >= 20k draws,
+  * a fixed (seed, rank) reproduces the draws, another seed / rank changes them,
+  * every row-kernel family resolves tokens in place to valid ids and agrees with the oracle on the step that
+    consumed them (gradients do not flow through the draws).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _speller(prec, D=64, A=32, H=32, NL=1, V=30, flags=0):
+    from las import _hip, layers as L, variables as Vs
+    from las.las import Speller
+    L.set_cell("lstm"); L.set_precision(prec)
+    Vs.reset_default_store(device="cuda", seed=3)
+    _hip.speller_flags = flags
+    args = make_args(enc_units=H, num_enc_layers=2, dec_units=D, num_dec_layers=NL, embedding_size=32, attention_size=A,
+                     mode="add", vocab_size=V, enc_type="pblstm")
+    return Speller(args), args
+
+
+@pytest.mark.parametrize("prec,flags", [("f32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 2)])
+def test_gumbel_draws_follow_softmax_and_are_reproducible(prec, flags):
+    from las import _hip, variables as Vs
+    V, Bn, Tp = 30, 2048, 12
+    sp, args = _speller(prec, V=V, flags=flags)
+    try:
+        rng = np.random.RandomState(0)
+        enc1 = rng.randn(1, Tp, 64).astype(np.float32)
+        enc = torch.tensor(np.repeat(enc1, Bn, 0), device="cuda")         # identical rows -> identical step-0 logits
+        enc_len = np.full(Bn, Tp)
+        y = np.full((Bn, 2), 5)
+        coins = np.array([False, False])                                   # the token entering step 1 is a draw
+        counts = np.zeros(V)
+        st = Vs.default_store()
+        draws = {}
+        for gs in range(10):
+            st.global_step = gs
+            with torch.no_grad():
+                logits, _, _ = sp(enc, enc_len, 2, teacher=y, is_training=True, coins=coins)
+            tok = sp.last_tokens_in[1].cpu().numpy()
+            assert tok.min() >= 0 and tok.max() < V
+            draws[gs] = tok
+            counts += np.bincount(tok, minlength=V)
+            l0 = logits[:, 0].cpu().double()
+            assert (l0 - l0[0]).abs().max().item() < 1e-5                  # identical rows
+        p = torch.softmax(l0[0], -1).numpy()
+        n = counts.sum()
+        assert n == 10 * Bn
+        keep = p * n >= 5                                                  # pool rare classes (chi-square validity)
+        exp = np.append(p[keep] * n, p[~keep].sum() * n)
+        obs = np.append(counts[keep], counts[~keep].sum())
+        if exp[-1] == 0:
+            exp, obs = exp[:-1], obs[:-1]
+        chi2 = ((obs - exp) ** 2 / exp).sum()
+        dof = len(exp) - 1
+        # 99.99 % quantile of chi-square(dof) via Wilson-Hilferty; a wrong sampler (e.g. arg-max, uniform) is off by 100s
+        z = 3.72
+        crit = dof * (1 - 2 / (9 * dof) + z * (2 / (9 * dof)) ** 0.5) ** 3
+        assert chi2 < crit, (chi2, crit, dof)
+        assert counts.argmax() == p.argmax()
+        # determinism: same (step, rank) -> same draws; other step / rank -> different draws
+        st.global_step = 3
+        with torch.no_grad():
+            sp(enc, enc_len, 2, teacher=y, is_training=True, coins=coins)
+        assert (sp.last_tokens_in[1].cpu().numpy() == draws[3]).all()
+        sp.rank = 1
+        with torch.no_grad():
+            sp(enc, enc_len, 2, teacher=y, is_training=True, coins=coins)
+        assert (sp.last_tokens_in[1].cpu().numpy() != draws[3]).mean() > 0.3
+    finally:
+        _hip.speller_flags = 0
+
+
+@pytest.mark.parametrize("prec,NL,flags", [("f32", 1, 0), ("f32", 2, 0), ("bf16", 1, 0), ("bf16", 1, 1), ("bf16", 2, 0)])
+def test_on_device_sampling_step_matches_oracle_given_the_draws(prec, NL, flags):
+    """training with in-kernel logits (step_logits) followed by las_speller_bwd: feed the oracle the tokens the kernel
+    drew and compare logits, alignments and every gradient."""
+    from las import _hip, variables as Vs
+    from oracle import las_oracle as O
+    B, Tp, U, V = 5, 37, 9, 30
+    sp, args = _speller(prec, D=64, A=32, H=32, NL=NL, V=V, flags=flags)
+    try:
+        st = Vs.default_store()
+        rng = np.random.RandomState(2)
+        enc_np = (rng.randn(B, Tp, 64) * 0.5).astype(np.float32)
+        enc = torch.tensor(enc_np, device="cuda", requires_grad=True)
+        enc_len = rng.randint(Tp // 2, Tp + 1, size=B)
+        y = rng.randint(3, V, size=(B, U))
+        coins = rng.rand(U) < 0.5
+        coins[0] = False
+        w = torch.tensor(rng.randn(B, U, V).astype(np.float32))
+        logits, _, alphas = sp(enc, enc_len, U, teacher=y, is_training=True, coins=coins)
+        (logits * w.cuda()).sum().backward()
+        _hip.join_side_stream()
+        torch.cuda.synchronize()
+        tok = sp.last_tokens_in.cpu().numpy()                     # [U, B] resolved in place
+        assert (tok >= 0).all() and (tok < V).all()
+        sampled = np.zeros((B, U), np.int64)
+        sampled[:, :U - 1] = tok[1:].T
+        p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
+        O.set_precision("bf16" if prec == "bf16" else "f32", "bf")
+        try:
+            po = O.to_torch(p0, requires_grad=True)
+            enc_o = torch.tensor(enc_np, requires_grad=True)
+            lo, ao = O.speller_forward(enc_o, enc_len.astype(np.float64), U, po, args, "lstm", teacher=torch.tensor(y),
+                                       is_training=True, coins=coins, sampled=torch.tensor(sampled))
+            (lo * w).sum().backward()
+        finally:
+            O.set_precision("f32")
+        tl, ta, tg = (2e-4, 1e-4, 2e-3) if prec == "f32" else (4e-3, 2e-3, 2e-2)
+        assert (logits.detach().cpu() - lo.detach()).abs().max().item() < tl
+        assert (alphas.detach().cpu() - ao.detach()).abs().max().item() < ta
+        ge = (enc.grad.cpu() - enc_o.grad).abs().max().item() / max(enc_o.grad.abs().max().item(), 1e-3)
+        assert ge < tg, ("enc", ge)
+        for n in st.order:
+            go = po[n].grad
+            if go is None:
+                continue
+            e = (st.vars[n].grad.cpu() - go).abs().max().item() / max(go.abs().max().item(), 1e-3)
+            assert e < tg, (n, e)
+    finally:
+        _hip.speller_flags = 0

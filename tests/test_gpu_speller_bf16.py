@@ -1,10 +1,11 @@
-"""Speed-mode (bf16) Speller row kernels against the fp32-operand row kernels of the same precision mode.
+"""Speed-mode (bf16) Speller row kernels against the ORACLE's Speller (oracle.speller_forward in its bf16-operand
+mode; reference las/las.py:72-160, las/layers.py:199-257): logits, alignments and every gradient, for each row-kernel
+family (fully prefetching `pf`, generic bf16 `bf`, fp32-operand rows) and each frames-per-wave instantiation,
+T' in (128, 160] -- what bench.py times -- included.
 
-Both paths contract in bf16 (MFMA step products); the bf16 row kernels additionally read Ws / keys / encoder
-rows from bf16 copies and contract the keys gradient after the loop.  The two must agree to bf16 rounding of
-those operands (relative 2^-9 per element, averaged down by the contractions)."""
-import os
-
+Tolerance: same rounding points on both sides (bf16 operands, fp32 accumulation), so what is left is accumulation
+order / fast transcendentals / boundary flips of the bf16 rounding: logits 5e-3 (of max|logit|), alignments 2e-3,
+gradients 2e-2 of the largest oracle entry."""
 import numpy as np
 import pytest
 import torch
@@ -14,11 +15,11 @@ from helpers import make_args
 pytestmark = pytest.mark.gpu
 
 
-def _run(no_bf_rows, NL, D, A, Hd2, B, Tp, U, mixed):
-    from las import layers as L
-    from las import variables as V
+def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed):
+    from las import _hip, layers as L, variables as V
     from las.las import Speller
-    os.environ["LAS_NO_BF_ROWS"] = "1" if no_bf_rows else "0"
+    from oracle import las_oracle as O
+    _hip.speller_flags = flags
     try:
         L.set_cell("lstm")
         L.set_precision("bf16")
@@ -27,7 +28,8 @@ def _run(no_bf_rows, NL, D, A, Hd2, B, Tp, U, mixed):
                          attention_size=A, mode="add", vocab_size=30, enc_type="pblstm")
         sp = Speller(args)
         rng = np.random.RandomState(1)
-        enc = torch.tensor(rng.randn(B, Tp, 2 * Hd2).astype(np.float32) * 0.5, device="cuda", requires_grad=True)
+        enc_np = rng.randn(B, Tp, 2 * Hd2).astype(np.float32) * 0.5
+        enc = torch.tensor(enc_np, device="cuda", requires_grad=True)
         enc_len = rng.randint(Tp // 2, Tp + 1, size=B)
         y = rng.randint(3, 30, size=(B, U))
         coins = np.ones(U, bool)
@@ -35,36 +37,55 @@ def _run(no_bf_rows, NL, D, A, Hd2, B, Tp, U, mixed):
         if mixed:
             coins = rng.rand(U) < 0.5
             sampled = rng.randint(3, 30, size=(B, U)).astype(np.int32)
-        w = torch.tensor(rng.randn(B, U, 30).astype(np.float32), device="cuda")
+        w = torch.tensor(rng.randn(B, U, 30).astype(np.float32))
         logits, _, alphas = sp(enc, enc_len, U, teacher=y, is_training=True, coins=coins, sampled=sampled)
-        (logits * w).sum().backward()
+        (logits * w.cuda()).sum().backward()
+        _hip.join_side_stream()
         torch.cuda.synchronize()
         st = V.default_store()
         grads = {n: st.vars[n].grad.detach().cpu().clone() for n in st.order}
         grads["enc"] = enc.grad.detach().cpu().clone()
-        return logits.detach().cpu(), alphas.detach().cpu(), grads
+        # oracle, bf16-operand mode; fp32-operand rows (flag 2) keep query / keys / context in fp32
+        p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
+        O.set_precision("bf16", "f32" if (flags & 2) else "bf")
+        try:
+            po = O.to_torch(p0, requires_grad=True)
+            enc_o = torch.tensor(enc_np, requires_grad=True)
+            lo, ao = O.speller_forward(enc_o, enc_len.astype(np.float64), U, po, args, "lstm", teacher=torch.tensor(y),
+                                       is_training=True, coins=coins, sampled=None if sampled is None else torch.tensor(sampled))
+            (lo * w).sum().backward()
+        finally:
+            O.set_precision("f32")
+        go = {n: po[n].grad for n in po if po[n].grad is not None}
+        go["enc"] = enc_o.grad
+        return logits.detach().cpu(), alphas.detach().cpu(), grads, lo.detach(), ao.detach(), go
     finally:
-        os.environ.pop("LAS_NO_BF_ROWS", None)
+        _hip.speller_flags = 0
 
 
-@pytest.mark.parametrize("shape", [
+SHAPES = [
     # NL, D,  A,   H,  B, Tp, U, mixed sampling
-    (1, 512, 128, 256, 5, 37, 9, False),      # the bench geometry at small B / T' / U
-    (2, 64, 32, 64, 4, 21, 7, True),          # multi-layer state, sampled tokens (in-loop logits)
+    (1, 512, 128, 256, 5, 37, 9, False),      # the bench geometry at small B / T' / U: pf<.,8>
+    (1, 512, 128, 256, 4, 160, 6, False),     # the bench geometry at the bench T' = 160: pf<.,10>
+    (1, 512, 128, 256, 3, 131, 5, True),      # T' in (128, 160], ragged, sampled tokens
+    (2, 64, 32, 64, 4, 21, 7, True),          # multi-layer state (generic bf rows)
     (1, 96, 136, 36, 3, 70, 5, False),        # attention width > 128 (two 16-byte chunks per lane), ragged sizes
-    (1, 128, 64, 64, 3, 181, 4, False),       # T' in (160, 192]: 12 frames per wave
-    (1, 128, 64, 64, 2, 214, 3, True),        # T' in (192, 224]: 14 frames per wave, 4 frames per 16-lane group
+    (1, 128, 64, 64, 3, 181, 4, False),       # T' in (160, 192]: pf<.,12>
+    (1, 128, 64, 64, 2, 214, 3, True),        # T' in (192, 224]: pf<.,14>
     (1, 64, 32, 32, 2, 230, 3, False),        # T' > 224: generic bf16 row kernels
-])
-def test_bf16_row_kernels_match_fp32_operand_rows(shape):
+]
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2])            # default (pf where eligible) / no pf rows / fp32-operand rows
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bf16_row_kernels_match_oracle(shape, flags):
     NL, D, A, H, B, Tp, U, mixed = shape
-    lo, ao, go = _run(True, NL, D, A, H, B, Tp, U, mixed)
-    ln, an, gn = _run(False, NL, D, A, H, B, Tp, U, mixed)
-    assert (an - ao).abs().max().item() < 2e-2
+    ln, an, gn, lo, ao, go = _run(flags, NL, D, A, H, B, Tp, U, mixed)
+    assert (an - ao).abs().max().item() < 2e-3
     assert (an.sum(-1) - 1).abs().max().item() < 1e-4
-    assert (ln - lo).abs().max().item() < 5e-2 * max(1.0, lo.abs().max().item())
-    assert set(go) == set(gn)
+    assert (ln - lo).abs().max().item() < 5e-3 * max(1.0, lo.abs().max().item())
+    assert set(go) <= set(gn)
     for n in sorted(go):
         scale = max(go[n].abs().max().item(), 1e-3)
         err = (gn[n] - go[n]).abs().max().item() / scale
-        assert err < 6e-2, (n, err, scale)
+        assert err < 2e-2, (n, err, scale)

@@ -98,3 +98,42 @@ def test_loss_matches_manual_label_smoothing():
                 soft[y[b, t]] += 0.99
                 tot += float(-(soft * lp[b, t]).sum()); n += 1
     assert abs(float(loss) - tot / n) < 1e-6
+
+
+def test_bf16_operand_mode_of_the_oracle():
+    """oracle.set_precision('bf16'): operands rounded to bf16 (RNE), fp32 accumulation, bf16-operand gradient products,
+    straight-through rounding; 'f32' restores exact arithmetic."""
+    import numpy as np
+    import torch
+    from oracle import las_oracle as O
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(3, 5, 8, generator=g, requires_grad=True)
+    w = torch.randn(8, 4, generator=g, requires_grad=True)
+    r = torch.randn(3, 5, 4, generator=g)
+    O.set_precision("bf16")
+    try:
+        y = O._mm(a, w)
+        (y * r).sum().backward()
+    finally:
+        O.set_precision("f32")
+    bf = lambda t: t.detach().to(torch.bfloat16).to(torch.float32)
+    assert torch.equal(y.detach(), bf(a) @ bf(w))
+    assert torch.allclose(a.grad, bf(r) @ bf(w).t(), atol=1e-6)
+    assert torch.allclose(w.grad, bf(a).reshape(-1, 8).t() @ bf(r).reshape(-1, 4), atol=1e-5)
+    assert torch.equal(O._mm(a, w).detach(), a.detach() @ w.detach())          # back in f32 mode
+    # end to end: the bf16-mode train step stays close to the f32 one (operand rounding only), and differs from it
+    import helpers
+    args = helpers.make_args(enc_units=16, num_enc_layers=1, dec_units=16, num_dec_layers=1, embedding_size=8, attention_size=8)
+    xs, ys = helpers.synthetic_batch(3, 12, 5, 30, seed=1)
+    outs = {}
+    for mode in ("f32", "bf16"):
+        O.set_precision(mode)
+        try:
+            p = O.to_torch(O.init_params(args, seed=2, cell="lstm"), requires_grad=True)
+            z = {k: torch.zeros_like(v) for k, v in p.items()}
+            outs[mode] = O.train_step(p, z, {k: torch.zeros_like(v) for k, v in p.items()}, 0,
+                                      (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, "lstm")
+        finally:
+            O.set_precision("f32")
+    d = (outs["f32"][1] - outs["bf16"][1]).abs().max().item()
+    assert 1e-6 < d < 5e-2
