@@ -53,12 +53,11 @@ class CharRNN(object):
         z = lambda: torch.zeros(self.hidden_size, device=dev)
         return tuple((z(), z()) for _ in range(self.num_layers))
 
-    def step(self, token_ids, states):
-        """token_ids [N] (LM ids), states: list over hypotheses of tuple over layers of (c,h) rows.
-        Returns (logits [N,V_lm], list over hypotheses of new states)."""
+    def step_tensors(self, ids, c_prev, h_prev):
+        """One unrolling for N rows with the state as tensors (device-resident beam search): ids int64 [N] (LM ids),
+        c_prev / h_prev lists over layers of [N,H].  Returns (logits [N,V_lm], c_new list, h_new list)."""
         P = self.params()
         dev = P["softmax_w"].device
-        ids = torch.as_tensor(token_ids, device=dev).long()
         N, H = ids.shape[0], self.hidden_size
         prec = L._prec()
         with torch.no_grad():
@@ -66,22 +65,31 @@ class CharRNN(object):
                 x = P["embedding"].detach()[ids]
             else:
                 x = torch.nn.functional.one_hot(ids, self.vocab_size).to(torch.float32)
-            new = []
+            cs, hs = [], []
             for l, (k, b) in enumerate(P["cells"]):
-                c_prev = torch.stack([s[l][0] for s in states]).contiguous()
-                h_prev = torch.stack([s[l][1] for s in states]).contiguous()
-                xin = torch.cat([x, h_prev], 1).contiguous()
+                xin = torch.cat([x, h_prev[l]], 1).contiguous()
                 I = xin.shape[1]
                 z = torch.empty(N, 4 * H, device=dev)
                 _hip.gemm(prec, xin, k.detach(), z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, bias=b.detach())
                 c_new = torch.empty(N, H, device=dev)
                 h_new = torch.empty(N, H, device=dev)
-                _hip.check(_hip.lib().las_lstm_pointwise(_hip.p(z), _hip.p(c_prev), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
+                _hip.check(_hip.lib().las_lstm_pointwise(_hip.p(z), _hip.p(c_prev[l]), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
                                                          _hip.stream()), "las_lstm_pointwise")
-                new.append((c_new, h_new))
+                cs.append(c_new)
+                hs.append(h_new)
                 x = h_new
             logits = torch.empty(N, self.vocab_size, device=dev)
             _hip.gemm(prec, x, P["softmax_w"].detach(), logits, False, False, N, self.vocab_size, H, H, self.vocab_size,
                       self.vocab_size, bias=P["softmax_b"].detach())
-        out_states = [tuple((new[l][0][i], new[l][1][i]) for l in range(self.num_layers)) for i in range(N)]
+        return logits, cs, hs
+
+    def step(self, token_ids, states):
+        """token_ids [N] (LM ids), states: list over hypotheses of tuple over layers of (c,h) rows.
+        Returns (logits [N,V_lm], list over hypotheses of new states)."""
+        dev = self.params()["softmax_w"].device
+        ids = torch.as_tensor(token_ids, device=dev).long()
+        c_prev = [torch.stack([s[l][0] for s in states]).contiguous() for l in range(self.num_layers)]
+        h_prev = [torch.stack([s[l][1] for s in states]).contiguous() for l in range(self.num_layers)]
+        logits, cs, hs = self.step_tensors(ids, c_prev, h_prev)
+        out_states = [tuple((cs[l][i], hs[l][i]) for l in range(self.num_layers)) for i in range(ids.shape[0])]
         return logits, out_states

@@ -35,6 +35,14 @@ class SpellerFwdArgs(Structure):
         ("ws", c_void_p), ("ws_bytes", c_size_t)]
 
 
+class BeamLoopArgs(Structure):
+    _fields_ = [(n, c_void_p) for n in ("logits", "score", "length", "nlive", "nsel", "done", "dec_step", "step",
+                                        "hist_parent", "hist_token", "hist_slot", "hist_score", "hist_n",
+                                        "sel_t", "sel_j", "src_row", "next_token")] + \
+               [(n, c_int) for n in ("nutt", "beam", "V", "Umax", "selcap", "topn", "start_id", "end_id", "ntens")] + \
+               [("state_in", c_void_p * 16), ("state_out", c_void_p * 16), ("state_width", c_int * 16)]
+
+
 class SpellerBwdArgs(Structure):
     _fields_ = [("f", SpellerFwdArgs), ("dlogits", c_void_p),
                 ("d_enc", c_void_p), ("d_keys", c_void_p), ("dWs", c_void_p), ("du", c_void_p),
@@ -75,6 +83,7 @@ _SIGS = {
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "las_beam_loop_step": (c_int, [POINTER(BeamLoopArgs), c_void_p]),
 }
 
 

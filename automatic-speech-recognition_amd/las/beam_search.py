@@ -5,9 +5,10 @@ What changed underneath: the reference issues 1 encode +
 utterance, re-uploading `np.tile(h)` and re-projecting the keys at every step.  Here the encoder output and
 its key projection are computed once and stay resident; each step is one fused Speller step for all live
 hypotheses (`Speller.decode`, las_speller_fwd with U=1) followed by the K10 pruning kernel
-(`las_beam_step`): expansion, SOS skip, length-normalised ranking and top-`beam` selection on device.
-Only the `beam` winners (parent, token, score) cross to the host, where the reference's bookkeeping
-(EOS retirement, `selected` list, exhaustion path) is kept verbatim.
+(`las_beam_loop_step`): expansion, SOS skip, length-normalised ranking, top-`beam` selection, EOS retirement,
+termination and the gather of the survivors' recurrent state -- all on the device, for several utterances at once.
+The host replays the launches and rebuilds the reference's `BeamState` objects from back-pointer records after the
+last step.
 
 Scores are RAW logits summed in float32 and ranked by sum/len, as the reference does."""
 import ctypes
@@ -79,87 +80,158 @@ class BeamSearch(object):
         audio, audiolen = xs
         if len(audio) != 1:
             raise ValueError('batch size must be 1 while performing beam search.')
-        h, enc_len = self._get_encode(sess, audio, audiolen)
-        dev = h.device
-        Tp, Hd = h.shape[1], h.shape[2]
-        dec_step = int(np.asarray(audiolen).reshape(-1)[0] * self.args.convert_rate)
-        beam = self.beam_size
-        V_ = self.args.vocab_size
-        A = self.args.attention_size
-        P = self.speller._params()
-        keys = torch.empty(1, Tp, A, device=dev)
-        _hip.gemm(L._prec(), h.contiguous(), P["Wh"].detach(), keys, False, False, Tp, A, Hd, Hd, A, A)
-        enc_t = h.expand(beam, Tp, Hd).contiguous()          # resident for the whole search
-        keys_t = keys.expand(beam, Tp, A).contiguous()
-        enc_len_t = torch.as_tensor(enc_len).to(torch.float64).reshape(1).repeat(beam)
+        return self.decode_batch(sess, [xs])[0]
 
-        init_state = self._get_dec_init(sess)
-        init_rows = tuple((s[0][0], s[1][0]) if isinstance(s, tuple) else s[0] for s in init_state)
-        lm_init = self.lm.zero_state(1) if self.args.apply_lm else None
-        beam_set = [BeamState(token_ids=[self.start_id], log_prob=0, att=[torch.zeros(Tp, device=dev)],
-                              dec_state=init_rows, lm_state=lm_init)] * beam
-        selected = []
-        lstm = self.speller.cell == "lstm"
-        NL = self.args.num_dec_layers
-        # device-side pruning buffers
-        d_score = torch.zeros(1, beam, device=dev)
-        d_len = torch.zeros(1, beam, dtype=torch.int32, device=dev)
-        d_nlive = torch.zeros(1, dtype=torch.int32, device=dev)
-        o_parent = torch.zeros(1, beam, dtype=torch.int32, device=dev)
-        o_token = torch.zeros(1, beam, dtype=torch.int32, device=dev)
-        o_score = torch.zeros(1, beam, device=dev)
-        o_n = torch.zeros(1, dtype=torch.int32, device=dev)
-        lg_buf = torch.zeros(1, beam, V_, device=dev)
-        t = 0
-        while t < dec_step and len(selected) < beam:
-            N = len(beam_set)
-            prev_ids = [b.token_ids[-1] for b in beam_set]
-            prev_align = torch.stack([b.att[-1] for b in beam_set])
+    def decode_batch(self, sess, xs_list, sync_every=32):
+        """Beam search for several utterances at once (what decode.py's loop over utterances, decode.py:131-149, becomes on
+        one GPU): xs_list = [(audio [1,T_u,feat_dim,3], audiolen [1]), ...] -> [list of BeamState (ascending), ...].
+
+        Every utterance is ENCODED on its own, at its own length (the reference's encoder has no sequence mask, so its
+        output depends on the padded length -- SURVEY fact 4 -- and decode.py feeds unpadded utterances); the search then
+        runs all utterances x beam hypotheses as ONE batch of rows per step: fused Speller step (las_speller_fwd, U = 1)
+        [+ LM step + shallow fusion] + las_beam_loop_step (pruning, EOS retirement, termination, state gather -- all on
+        the device).  The host replays the launches without waiting and reads the back-pointer records once at the end
+        (plus one `done` poll every `sync_every` steps to stop early)."""
+        import ctypes
+        from las.las import _alloc_bufs, _fill_fwd_args
+        a = self.args
+        dev = self._las._device()
+        n, beam, V_, A, NL, D = len(xs_list), self.beam_size, a.vocab_size, a.attention_size, a.num_dec_layers, a.dec_units
+        sp = self.speller
+        lstm = sp.cell == "lstm"
+        prec = L._prec()
+        P = sp._params()
+        # ---- encoders (one per utterance) and the hoisted key projection
+        encs, enc_lens, dec_steps = [], [], []
+        for audio, audiolen in xs_list:
+            if len(audio) != 1:
+                raise ValueError('every entry of xs_list is one utterance: audio [1,T,feat_dim,3]')
+            h, enc_len = self._get_encode(sess, audio, audiolen)
+            encs.append(h)
+            enc_lens.append(float(torch.as_tensor(enc_len).reshape(-1)[0]))
+            dec_steps.append(int(np.asarray(audiolen).reshape(-1)[0] * a.convert_rate))       # las/beam_search.py:78
+        Tps = [h.shape[1] for h in encs]
+        Tp, Hd = max(Tps), encs[0].shape[2]
+        N = n * beam
+        enc_t = torch.zeros(N, Tp, Hd, device=dev)          # resident for the whole search; frames past T'_u are masked
+        keys_t = torch.zeros(N, Tp, A, device=dev)
+        Wh = P["Wh"].detach()
+        for u, h in enumerate(encs):
+            k = torch.empty(1, Tps[u], A, device=dev)
+            _hip.gemm(prec, h.contiguous(), Wh, k, False, False, Tps[u], A, Hd, Hd, A, A)
+            enc_t[u * beam:(u + 1) * beam, :Tps[u]] = h
+            keys_t[u * beam:(u + 1) * beam, :Tps[u]] = k
+        enc_len_i32 = torch.tensor(np.repeat(np.asarray(enc_lens, np.float64), beam)).to(torch.int32).to(dev)
+        Umax = max(max(dec_steps), 1)
+        # ---- device-resident loop state
+        i32 = dict(dtype=torch.int32, device=dev)
+        selcap = 3 * beam
+        score = torch.zeros(n, beam, device=dev)
+        length = torch.zeros(n, beam, **i32)
+        nlive = torch.full((n,), beam, **i32)
+        nsel = torch.zeros(n, **i32)
+        done = torch.zeros(n, **i32)
+        dstep = torch.tensor(dec_steps, **i32)
+        step = torch.zeros(1, **i32)
+        hist_parent = torch.zeros(Umax, n, beam, **i32)
+        hist_token = torch.zeros(Umax, n, beam, **i32)
+        hist_slot = torch.zeros(Umax, n, beam, **i32)
+        hist_score = torch.zeros(Umax, n, beam, device=dev)
+        hist_n = torch.zeros(Umax, n, **i32)
+        sel_t = torch.zeros(n, selcap, **i32)
+        sel_j = torch.zeros(n, selcap, **i32)
+        src_row = torch.zeros(n, beam, **i32)
+        next_token = torch.full((N,), self.start_id, **i32)
+        alphas_hist = torch.zeros(Umax, N, Tp, device=dev)
+        align_prev = torch.zeros(N, Tp, device=dev)
+        # ---- the fused Speller step for all rows: slot 0 of hs / cs = state entering the step, slot 1 = state leaving it
+        dims = sp._dims(N, Tp, 1)
+        bufs = _alloc_bufs(dims, dev)
+        bufs["hs"].zero_()
+        if lstm:
+            bufs["cs"].zero_()
+        tokens_out = torch.zeros(1, N, **i32)
+        Pd = {k: (v.detach() if torch.is_tensor(v) else [t.detach() for t in v]) for k, v in P.items()}
+        fa = _hip.SpellerFwdArgs()
+        keep = _fill_fwd_args(fa, dims, Pd, enc_t, keys_t, enc_len_i32, next_token, tokens_out, bufs, True, 0, keep_state0=True,
+                              align0=align_prev)
+        lib = _hip.lib()
+        nbytes = lib.las_speller_workspace_bytes(N, Tp, Hd, A, D, NL, a.embedding_size, V_, 1, dims["cell"])
+        ws = _hip.workspace(dev, nbytes, "speller")
+        fa.ws, fa.ws_bytes = ws.data_ptr(), ws.numel()
+        logits = bufs["logits"][0]                                                      # [N, V]
+        # ---- state tensors that follow their hypotheses (gathered by las_beam_loop_step)
+        st_in, st_out = [], []
+        for l in range(NL):
+            st_in.append(bufs["hs"][l, 1]); st_out.append(bufs["hs"][l, 0])
             if lstm:
-                states = tuple((torch.stack([b.dec_state[l][0] for b in beam_set]),
-                                torch.stack([b.dec_state[l][1] for b in beam_set])) for l in range(NL))
-            else:
-                states = tuple(torch.stack([b.dec_state[l] for b in beam_set]) for l in range(NL))
-            logits, new_states, alphas = self._get_decode(sess, enc_t[:N], enc_len_t[:N], prev_ids, prev_align, states,
-                                                          keys=keys_t[:N])
-            lm_states = None
-            if self.args.apply_lm:
-                # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
-                # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-                lm_ids = torch.as_tensor([max(i - 2, 0) for i in prev_ids], device=dev)
-                lm_out, lm_states = self.lm.step(lm_ids, [b.lm_state for b in beam_set])
-                logits = logits.clone()
-                logits[:, 2:] += lm_out * np.float32(self.args.lm_weight)
-            lg_buf[0, :N] = logits
-            d_score[0, :N] = torch.as_tensor([float(b.log_prob) for b in beam_set], device=dev)
-            d_len[0, :N] = torch.as_tensor([len(b.token_ids) - 1 for b in beam_set], dtype=torch.int32, device=dev)
-            d_nlive[0] = N
-            _hip.check(_hip.lib().las_beam_step(_hip.p(lg_buf), _hip.p(d_score), _hip.p(d_len), _hip.p(d_nlive), 1, beam, V_,
-                                                self.TOPN, t, self.start_id, _hip.p(o_parent), _hip.p(o_token),
-                                                _hip.p(o_score), _hip.p(o_n), _hip.stream()), "las_beam_step")
-            n = int(o_n[0])                                   # the only device->host crossing of the step
-            par = o_parent[0, :n].tolist()
-            tok = o_token[0, :n].tolist()
-            sc = o_score[0, :n].cpu().numpy()
-            lg_host = lg_buf[0].cpu().numpy()
-            beam_set_new = []
-            for j in range(n):
-                i, v = par[j], tok[j]
-                st_i = tuple((new_states[l][0][i], new_states[l][1][i]) if lstm else new_states[l][i] for l in range(NL))
-                b = beam_set[i].update(v, lg_host[i, v], alphas[i], st_i, None if lm_states is None else lm_states[i])
-                b.log_prob = np.float32(sc[j])               # the float32 sum computed on device (same arithmetic)
-                if v == self.end_id:
-                    selected.append(b)
-                else:
-                    beam_set_new.append(b)
-            beam_set = beam_set_new
-            t += 1
-            if not beam_set:
-                break
-        if t == dec_step:
-            selected.extend(beam_set)
+                st_in.append(bufs["cs"][l, 1]); st_out.append(bufs["cs"][l, 0])
+        k_align = len(st_in)
+        st_in.append(alphas_hist[0]); st_out.append(align_prev)
+        lm = self.lm if a.apply_lm else None
+        if lm is not None:
+            Hl, NLl = lm.hidden_size, lm.num_layers
+            lm_c = [torch.zeros(N, Hl, device=dev) for _ in range(NLl)]
+            lm_h = [torch.zeros(N, Hl, device=dev) for _ in range(NLl)]
+            k_lm = len(st_in)
+            for l in range(NLl):
+                st_in += [lm_c[l], lm_h[l]]; st_out += [lm_c[l], lm_h[l]]          # inputs are re-pointed every step
+        ba = _hip.BeamLoopArgs()
+        for name, t in (("logits", logits), ("score", score), ("length", length), ("nlive", nlive), ("nsel", nsel), ("done", done),
+                        ("dec_step", dstep), ("step", step), ("hist_parent", hist_parent), ("hist_token", hist_token),
+                        ("hist_slot", hist_slot), ("hist_score", hist_score), ("hist_n", hist_n), ("sel_t", sel_t), ("sel_j", sel_j),
+                        ("src_row", src_row), ("next_token", next_token)):
+            setattr(ba, name, t.data_ptr())
+        ba.nutt, ba.beam, ba.V, ba.Umax, ba.selcap, ba.topn = n, beam, V_, Umax, selcap, self.TOPN
+        ba.start_id, ba.end_id, ba.ntens = self.start_id, self.end_id, len(st_in)
+        for k, (ti, to) in enumerate(zip(st_in, st_out)):
+            ba.state_in[k], ba.state_out[k], ba.state_width[k] = ti.data_ptr(), to.data_ptr(), ti.shape[-1]
+        stream = _hip.stream()
+        lm_w = np.float32(a.lm_weight) if lm is not None else None
+        steps_run = 0
+        with torch.no_grad():
+            for t in range(Umax):
+                fa.alphas = alphas_hist[t].data_ptr()
+                _hip.check(lib.las_speller_fwd(ctypes.byref(fa), stream), "las_speller_fwd")
+                if lm is not None:
+                    # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
+                    # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
+                    lm_ids = (next_token.to(torch.int64) - 2).clamp_min_(0)
+                    lm_out, cs_new, hs_new = lm.step_tensors(lm_ids, lm_c, lm_h)
+                    logits[:, 2:] += lm_out * lm_w
+                    for l in range(NLl):
+                        ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
+                    held = (cs_new, hs_new, lm_out)                                   # alive until the gather has been enqueued
+                ba.state_in[k_align] = alphas_hist[t].data_ptr()
+                _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), stream), "las_beam_loop_step")
+                steps_run = t + 1
+                if (t + 1) % sync_every == 0 and bool(done.all()):                      # the only host wait inside the loop
+                    break
+        del keep
+        # ---- one read-back, then the reference's host-side objects
+        hp, ht, hsl = hist_parent[:steps_run].cpu().numpy(), hist_token[:steps_run].cpu().numpy(), hist_slot[:steps_run].cpu().numpy()
+        hsc = hist_score[:steps_run].cpu().numpy()
+        st_, sj_, ns_ = sel_t.cpu().numpy(), sel_j.cpu().numpy(), nsel.cpu().numpy()
         _hip.check_status(dev)
-        return self._select_best_k(selected, NORM)
+        results = []
+        for u in range(n):
+            selected = []
+            for s_i in range(min(int(ns_[u]), selcap)):
+                t_s, j_s = int(st_[u, s_i]), int(sj_[u, s_i])
+                ids, rows = [], []
+                tt, j = t_s, j_s
+                while True:
+                    ids.append(int(ht[tt, u, j]))
+                    slot = int(hp[tt, u, j])
+                    rows.append((tt, u * beam + slot))
+                    if tt == 0:
+                        break
+                    j = int(hsl[tt - 1, u, slot])
+                    tt -= 1
+                att = [torch.zeros(Tps[u], device=dev)] + [alphas_hist[tt_, r, :Tps[u]] for tt_, r in reversed(rows)]
+                selected.append(BeamState([self.start_id] + ids[::-1], np.float32(hsc[t_s, u, j_s]), att, None, None))
+            results.append(self._select_best_k(selected, NORM))
+        return results
 
     def restore_las(self, sess, save_path, restore_epoch):
         """Restore LAS weights (reference las/beam_search.py:272-281; the TF name remapping of

@@ -48,3 +48,29 @@ def sampling_seed(global_step, rank=0):
 def shard(items, rank, world):
     """Round-robin shard of a (length-sorted) utterance list -- replicas-only decode/eval."""
     return items[rank::world]
+
+
+def init_from_env(device=None):
+    """One process per GPU under torch.distributed.run: initialise RCCL from RANK / WORLD_SIZE / MASTER_* and return a
+    DataParallel, or None for a plain single-process run (the evaluation entry points use it as 'replicas only')."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("LAS_DIST_BACKEND", "nccl")               # "nccl" IS RCCL on ROCm
+    if not dist.is_initialized():
+        if backend == "nccl" and device is not None:
+            dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
+    return DataParallel()
+
+
+def reduce_error_counts(dp, errors, words, device=None):
+    """(errors, reference words) summed over the evaluation replicas -> corpus WER is the same on every rank."""
+    if dp is None:
+        return errors, words
+    t = torch.tensor([float(errors), float(words)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=dp.group)
+    return float(t[0]), float(t[1])

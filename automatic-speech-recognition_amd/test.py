@@ -14,12 +14,17 @@ from las.utils import convert_idx_to_string, edit_distance        # noqa: E402
 from utils.tokenizer import CharEncoder, SubwordEncoder            # noqa: E402
 
 
-def corpus_wer(texts_gt, texts_pred):
+def corpus_counts(texts_gt, texts_pred):
     error, N = 0, 0
     for ref, hyp in zip(texts_gt, texts_pred):
         e, n = edit_distance(ref.split(" "), hyp.split(" "))
         error += e
         N += n
+    return error, N
+
+
+def corpus_wer(texts_gt, texts_pred):
+    error, N = corpus_counts(texts_gt, texts_pred)
     return error / N
 
 
@@ -32,7 +37,14 @@ def main():
     id_to_token = tokenizer.id_to_token
     layers.set_cell(args.cell)
     layers.set_precision(args.dtype)
-    variables.reset_default_store(device=torch.device("cuda", 0), seed=args.seed)
+    # replicas only: ranks take the evaluation batches round-robin; (errors, words) are all-reduced
+    from las import parallel
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dp = parallel.init_from_env(dev)
+    rank, world = (dp.rank, dp.world) if dp is not None else (0, 1)
+    variables.reset_default_store(device=dev, seed=args.seed)
     las = LAS(args, Listener, Speller, id_to_token)
     las.build_variables()
     ckpt = checkpoint.restore(args.save_dir, args.restore_epoch)
@@ -53,18 +65,24 @@ def main():
             import itertools
             batches = itertools.islice(batches, args.max_steps)
     output_id, gt_id = [], []
-    for xs, ys in batches:
+    import itertools
+    for xs, ys in itertools.islice(batches, rank, None, world):
         _, y_hat = las.inference(xs)
         output_id += y_hat.cpu().numpy().tolist()
         gt_id += ys[0].tolist()
     texts_pred = [convert_idx_to_string(o, id_to_token, args.unit) for o in output_id]
     texts_gt = [convert_idx_to_string(g, id_to_token, args.unit) for g in gt_id]
     os.makedirs(args.log_dir, exist_ok=True)
-    with open(os.path.join(args.log_dir, "test_pred.txt"), 'w') as fout:
+    sfx = "" if world == 1 else ".rank%d" % rank
+    with open(os.path.join(args.log_dir, "test_pred.txt" + sfx), 'w') as fout:
         fout.write("\n".join(texts_pred))
-    with open(os.path.join(args.log_dir, "test_gt.txt"), 'w') as fout:
+    with open(os.path.join(args.log_dir, "test_gt.txt" + sfx), 'w') as fout:
         fout.write("\n".join(texts_gt))
-    logging.info("total utterances: {}, WER: {}".format(len(texts_gt), corpus_wer(texts_gt, texts_pred)))
+    error, N = corpus_counts(texts_gt, texts_pred)
+    total = parallel.reduce_error_counts(dp, len(texts_gt), 0, dev)[0]
+    error, N = parallel.reduce_error_counts(dp, error, N, dev)
+    if rank == 0:
+        logging.info("total utterances: {}, WER: {}".format(int(total), error / N))
 
 
 if __name__ == "__main__":

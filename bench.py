@@ -6,14 +6,21 @@ Workload (BASELINE.json configs[1]): LibriSpeech-100 char LAS, 3 x pBLSTM-256 Li
 B=48, T=1274 (tfrecord_data_loader.py:75,83), synthetic MFCC-39 cube and labels per SURVEY.md 8(d).
 
     python bench.py --gpus N --steps K --warmup W
-N>1 is launched by torch.distributed.run (one rank per GPU over RCCL): every rank trains on its own
-48-utterance shard (weak scaling), one flat-bucket all-reduce per step.
+With N > 1 and no WORLD_SIZE in the environment this process starts N fresh ranks itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one rank per GPU over RCCL), relays rank 0's
+JSON line and exits with the launcher's code; under a launcher (the driver's form) it is one of the ranks.
+Every rank trains on its own 48-utterance shard (weak scaling), one flat-bucket all-reduce per step.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch stream around
-the dominant kernel (the recurrent sweep); `cpu_baseline` times the oracle restatement of the reference
-graph AS WRITTEN (un-hoisted key projection, per-step cells) on the host cores for a bounded sample.
+Prints ONE JSON line (rank 0):
+  roofline      dominant kernel family (the recurrent sweep), measured live with HIP events on the launch stream, plus the
+                WHOLE-STEP algorithmic rates against the HBM and MFMA roofs (BASELINE.md section 3 per-utterance figures x utt/s)
+  cpu_baseline  the oracle restatement of the reference graph AS WRITTEN (un-hoisted key projection, per-step cells) on
+                the host cores: 1 warm-up + 3 timed steps on a bounded sample
+  decode        (N = 1) device-resident beam search, beam 16 + 2 x 512 char RNNLM on synthetic T=1274 utterances
+                (BASELINE configs[4]): utterances/s
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +35,10 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# BASELINE.md section 3 (config 2, lstm cells, T=1274 -> T'=160, U=200): algorithmic work of one TRAINED utterance
+STEP_BYTES_PER_UTT = 115e6
+STEP_FLOPS_PER_UTT = 34.3e9
 
 
 def bench_args(cell):
@@ -50,7 +61,7 @@ def sweep_bytes(B, T, H, G, bwd):
     return gates * 2 + (2 * h if G == 4 else h) + h + w
 
 
-def usable_cores(cap=16):
+def usable_cores():
     """Host cores this process may really use: scheduler affinity, cut by the cgroup CPU quota when one is set."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
@@ -59,20 +70,20 @@ def usable_cores(cap=16):
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    return max(1, min(n, cap))
+    return max(1, n)
 
 
-def cpu_baseline_child(cell):
-    """Runs in a CPU-only child process: one oracle train step on a bounded sample of the bench workload."""
+def cpu_baseline_child(cell, budget_s=45.0):
+    """CPU-only child process.  BASELINE.md section 2 protocol: one oracle train step = fwd + bwd + clip + Adam of the
+    reference graph as written; 1 warm-up + 3 timed steps, median; batch as large as fits the time budget; all usable
+    host cores (count stated).  TensorFlow 1.13 itself cannot be run (not installable offline)."""
     from helpers import synthetic_batch
     from oracle import las_oracle as O
-    ncores = usable_cores()
-    torch.set_num_threads(ncores)
     args = bench_args(cell)
     T = 1274
 
     def one(Bs):
-        xs, ys = synthetic_batch(Bs, T, 256, args.vocab_size, seed=0)
+        xs, ys = synthetic_batch(Bs, T, 256, args.vocab_size, seed=0, min_frac=0.834)
         po = O.to_torch(O.init_params(args, seed=0, cell=cell), requires_grad=True)
         z1 = {k: torch.zeros_like(v) for k, v in po.items()}
         z2 = {k: torch.zeros_like(v) for k, v in po.items()}
@@ -80,18 +91,35 @@ def cpu_baseline_child(cell):
         O.train_step(po, z1, z2, 0, (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, hoist=False)
         return time.time() - t0
 
-    Bs, dt = 1, one(1)
-    if dt < 10.0:                                   # widen the sample while it stays within ~30 s of CPU work
-        Bs, dt = 4, one(4)
-    print(json.dumps({"value": round(Bs / dt, 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
-                      "sample": "1 train step of the oracle (reference graph as written: un-hoisted key projection, "
-                                "torch-CPU fp32, %s cells) on %d utterance(s) of the same T=1274 workload: %.1f s"
-                                % (cell, Bs, dt)}))
+    n_all = usable_cores()
+    # torch's intra-op pool does not always scale to every core on these small per-step products: probe two pool sizes
+    # on a small batch and keep the faster one (both stated)
+    probes = {}
+    for n in sorted({n_all, min(n_all, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        one(2)
+        probes[n] = one(2)
+    ncores = min(probes, key=probes.get)
+    torch.set_num_threads(ncores)
+    est = probes[ncores] / 2.0                            # seconds per utterance and step, an upper bound for larger batches
+    Bs = 2
+    for cand in (48, 32, 24, 16, 8, 4):
+        if 4 * cand * est <= budget_s:
+            Bs = cand
+            break
+    one(Bs)                                               # warm-up
+    ts = sorted(one(Bs) for _ in range(3))
+    med = ts[1]
+    print(json.dumps({"value": round(Bs / med, 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
+                      "sample": "reference-equivalent CPU path (restated; TF unavailable offline): oracle train step of the "
+                                "reference graph as written (un-hoisted key projection, torch-CPU fp32, %s cells), B=%d of the "
+                                "same T=1274 workload, 1 warm-up + 3 timed steps, median %.2f s/step; %d of %d usable cores "
+                                "(pool probe: %s)" % (cell, Bs, med, ncores, n_all,
+                                                      ", ".join("%d thr %.2f s" % (k, v) for k, v in sorted(probes.items())))}))
 
 
-def cpu_baseline(cell, timeout=240.0):
-    """Reference-equivalent CPU path (restated; TensorFlow 1.13 is not installable offline), timed in a child
-    process that never touches the GPU, with a hard time limit so the bench line always appears."""
+def cpu_baseline(cell, timeout=300.0):
+    """Timed in a child process that never touches the GPU, with a hard time limit so the bench line always appears."""
     import subprocess
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
@@ -101,6 +129,61 @@ def cpu_baseline(cell, timeout=240.0):
     except Exception as e:                          # timeout / parse failure: say so instead of hanging the bench
         return {"value": None, "unit": "utterances/s", "cores": usable_cores(), "kind": "port",
                 "sample": "oracle train step did not finish within %.0f s (%s)" % (timeout, type(e).__name__)}
+
+
+def recorded_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes recorded under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).
+    Only a recording made from THIS kernel source counts: the file stores the sha of csrc/rnn_seq.hip; else null."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json")))
+        src = os.path.join(ROOT, "automatic-speech-recognition_amd", "csrc", "rnn_seq.hip")
+        if rec.get("rnn_seq_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+            return None
+        for k, v in rec["kernels"].items():
+            if k.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
+    """BASELINE configs[4]: beam search (beam 16) + char RNNLM shallow fusion on synthetic T=1274 utterances, bench
+    architecture, device-resident batched loop (BeamSearch.decode_batch).  Random-init weights: hypotheses do not end
+    early, every utterance runs its full int(T * convert_rate) = 211 steps."""
+    from helpers import synthetic_batch
+    from las import layers as L, variables as V
+    from las.beam_search import BeamSearch
+    from las.las import LAS, Listener, Speller
+    from lang.char_rnn_model import CharRNN
+    from utils.tokenizer import CharEncoder
+    L.set_cell(cell)
+    L.set_precision(dtype)
+    st = V.reset_default_store(device=dev, seed=0)
+    args = bench_args(cell)
+    args.beam_size, args.apply_lm, args.lm_weight, args.convert_rate = beam, True, 0.5, 0.166
+    tok = CharEncoder()
+    las = LAS(args, Listener, Speller, tok.token_to_id)
+    lm = CharRNN(False, 1, 1, 28, 512, embedding_size=0, num_layers=2, store=st)
+    lm.params()
+    las.build_variables()
+    bs = BeamSearch(args, las, tok.token_to_id, lm)
+    utts = []
+    for k in range(nutt):
+        xs, _ = synthetic_batch(1, T, 8, 30, seed=100 + k)
+        utts.append((torch.tensor(xs[0], device=dev), xs[1]))
+    bs.decode_batch(None, utts[:2])                      # warm-up (library init, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = bs.decode_batch(None, utts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = max(len(r[-1].token_ids) - 1 for r in res)
+    return {"value": round(nutt / dt, 2), "unit": "utterances/s", "beam": beam, "lm": "2x512 char RNNLM, lm_weight 0.5",
+            "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 3),
+            "note": "encoders run one utterance at a time (the reference encoder has no length mask: padding would change the "
+                    "result); the search runs all utterances x beam rows per step on the device"}
 
 
 def self_launch(n, argv):
@@ -140,6 +223,7 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--frames", type=int, default=1274)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_only:
@@ -257,25 +341,25 @@ def main():
                     ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_hw_kernel")
             else:
                 kname = ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_f32_kernel"
-            # HBM traffic of that kernel from a recorded rocprofv3 --pmc pass of this same command (FETCH_SIZE and
-            # WRITE_SIZE in separate passes; tools/pmc_summary.py); null when no recording matches the configuration
             traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_g_pmc.json")))
-                if a.cell == "lstm" and a.dtype == "bf16" and B == 48 and T == 1274:
-                    key = [k for k in pmc if k.startswith("rnn_seq_bwd" if bwd else "rnn_seq_fwd")]
-                    if key:
-                        traffic = pmc[key[0]]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+            if a.cell == "lstm" and a.dtype == "bf16" and B == 48 and T == 1274:
+                traffic = recorded_traffic("rnn_seq_bwd" if bwd else "rnn_seq_fwd")
+            # whole-step algorithmic rates: BASELINE.md section 3 per-utterance figures x utterances/s of one GPU
+            per_gpu = value / world
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "launches_per_step": f["n"] // a.steps,
                     "algorithmic_bytes_per_launch": f["bytes"] // f["n"],
                     "avg_launch_ms": round(f["ms"] / f["n"], 4),
                     "us_per_recurrent_step": round(f["ms"] * 1e3 / f["steps"], 3),
-                    "note": "sequential-dependency bound: every launch is T dependent steps (SURVEY 8(d)); "
-                            "includes the W_hh pack + memset launched with it"}
+                    "whole_step": {"hbm_GBps": round(STEP_BYTES_PER_UTT * per_gpu / 1e9, 1),
+                                   "frac_hbm": round(STEP_BYTES_PER_UTT * per_gpu / 1e9 / HBM_PEAK_GBS, 5),
+                                   "mfma_TFLOPps": round(STEP_FLOPS_PER_UTT * per_gpu / 1e12, 2),
+                                   "frac_mfma": round(STEP_FLOPS_PER_UTT * per_gpu / 1e12 / MFMA_PEAK_TFLOPS, 5),
+                                   "per_utterance": "115 MB, 34.3 GFLOP (BASELINE.md section 3; lstm, T=1274, U=200)"},
+                    "note": "sequential-dependency bound: every launch is T dependent steps (SURVEY 8(d)); the launch time "
+                            "includes the W_hh pack + memset enqueued with it; traffic = FETCH_SIZE x2 + WRITE_SIZE of the "
+                            "recorded rocprofv3 --pmc passes when they were made from this kernel source, else null"}
         out = {
             "metric": "utterances/sec (train step) LibriSpeech-360 char-LAS @1/2/4/8 GPU; dev-clean WER",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -290,6 +374,11 @@ def main():
             "loss": round(loss, 4),
             "kernel_ms": {k: [round(v[0], 3), v[1] // a.steps] for k, v in sorted(per.items())},
         }
+        if world == 1 and not a.no_decode:
+            try:
+                out["decode"] = decode_bench(dev, a.cell, a.dtype)
+            except Exception as e:                       # the train metric must still be printed
+                out["decode"] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cell)
         sys.stdout.flush()

@@ -240,6 +240,33 @@ int las_beam_step(const float* logits, const float* score, const int* length, co
                   int nutt, int beam, int V, int topn, int t, int start_id,
                   int* out_parent, int* out_token, float* out_score, int* out_n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * K10b  device-resident BeamSearch.decode loop (las/beam_search.py:94-158) for `nutt` utterances at once: ONE call per
+ * step prunes every utterance exactly as las_beam_step does AND keeps the reference's bookkeeping on the device, so
+ * the host never waits inside the loop:
+ *   - live hypotheses: score / length [nutt,beam] and nlive [nutt] updated in place (compacted, ascending rank);
+ *   - back-pointer records of step t = *step: hist_parent (live slot of step t), hist_token, hist_score [Umax,nutt,beam],
+ *     hist_n [Umax,nutt] picks, hist_slot [Umax,nutt,beam] (live slot k of step t+1 = pick hist_slot[t][u][k]);
+ *   - retired hypotheses (EOS, :148-152; the live ones on step exhaustion, :155-156) appended as (sel_t, sel_j)
+ *     references into the records, nsel [nutt]; selcap >= 3*beam;
+ *   - done[u] set when `t+1 == dec_step[u]`, `nsel >= beam` (:94) or no live hypothesis is left; a done utterance is
+ *     skipped by later calls;
+ *   - src_row [nutt,beam] (global row the new live slot continues) and next_token [nutt*beam] for the next step, and
+ *     the `ntens` recurrent-state tensors gathered accordingly: state_out[k][row] = state_in[k][src_row[row]]
+ *     (state_width[k] floats per row; decoder h/c, previous alignment, LM states);
+ *   - finally *step += 1 (device-resident step counter: the launch sequence is identical every step, hipGraph friendly).
+ * All state is caller-owned and caller-initialised (score 0, length 0, nlive = beam, nsel = done = 0, *step = 0,
+ * next_token = start_id).  The host reads the records once after the last step and rebuilds token ids by back-tracking.
+ */
+typedef struct {
+    const float* logits; float* score; int* length; int* nlive; int* nsel; int* done; const int* dec_step; int* step;
+    int *hist_parent, *hist_token, *hist_slot; float* hist_score; int* hist_n;
+    int *sel_t, *sel_j; int* src_row; int* next_token;
+    int nutt, beam, V, Umax, selcap, topn, start_id, end_id;
+    int ntens; const float* state_in[16]; float* state_out[16]; int state_width[16];
+} las_beam_loop_args;
+int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ What is pinned:
   G2  las/arguments.py    parse_args() defaults
   G3  las/utils.py        edit_distance
   G4  las/utils.py        convert_idx_to_string (char + subword modes)
-  G5  las/beam_search.py  BeamSearch.decode control flow + _select_best_k, with an
+  G5/G6 las/beam_search.py BeamSearch.decode control flow + _select_best_k, with an
                           injected numpy "toy speller" step function (apply_lm=False;
                           the LM branch of the reference is syntactically broken)
 TensorFlow is absent: a stub module satisfies the imports; none of the pinned
@@ -149,6 +149,29 @@ def main():
                    "hyps": [{"token_ids": [int(t) for t in b.token_ids], "log_prob": float(b.log_prob),
                              "n_att": len(b.att)} for b in res]})
     out["G5"] = g5
+
+    # ---- G6: four utterances that share (V, beam, T', D) -- the batched device loop (las_beam_loop_step, nutt = 4)
+    # must reproduce each of them; same reference control flow as G5
+    g6 = []
+    for seed, rate, audiolen in [(21, 0.5, 40), (22, 0.9, 22), (23, 0.3, 50), (24, 1.0, 9)]:
+        V, Tp, D, beam = 30, 12, 12, 8
+        toy = toy_speller(seed, V, Tp, D)
+        o = object.__new__(bs.BeamSearch)
+        o.args = types.SimpleNamespace(convert_rate=rate, apply_lm=False, lm_weight=0.0)
+        o.beam_size = beam
+        o.start_id, o.end_id = 1, 2
+        h = np.zeros((1, Tp, 4), np.float32)
+        o._get_encode = lambda sess, audio, audiolen_, h=h: (h, np.array([Tp]))
+        o._get_dec_init = lambda sess, D=D: (np.zeros((1, D), np.float32), np.zeros((1, D), np.float32))
+
+        def _get_decode6(sess, enc_out, enc_len, prev_ids, prev_align, packed, toy=toy):
+            return toy_step(toy, prev_ids, prev_align, np.asarray(packed, np.float32))
+        o._get_decode = _get_decode6
+        res = o.decode(None, (np.zeros((1, audiolen, 13, 3), np.float32), np.array([audiolen])))
+        g6.append({"seed": seed, "V": V, "Tp": Tp, "D": D, "beam": beam, "convert_rate": rate, "audiolen": audiolen,
+                   "hyps": [{"token_ids": [int(t) for t in b.token_ids], "log_prob": float(b.log_prob),
+                             "n_att": len(b.att)} for b in res]})
+    out["G6"] = g6
 
     with open(os.path.join(HERE, "reference_host_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -66,3 +66,28 @@ def test_two_rank_gradients_equal_single_rank_full_batch():
     assert ret["n"] == n
     assert abs(ret["loss"] - float(loss)) < 1e-6
     assert np.abs(ret["flat"] - flat.numpy()).max() < 1e-6
+
+
+def _eval_worker(rank, world, port, ret):
+    sys.path.insert(0, helpers.PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LAS_DIST_BACKEND="gloo")
+    from las import parallel
+    dp = parallel.init_from_env()
+    assert dp is not None and dp.rank == rank and dp.world == world
+    utts = list(range(11))                                   # length-sorted utterance indices (decode.py:122-124)
+    mine = parallel.shard(utts, rank, world)
+    errors, words = float(sum(mine)), float(10 * len(mine))  # stand-ins for this replica's edit distances / word counts
+    e, n = parallel.reduce_error_counts(dp, errors, words)
+    ret[rank] = (mine, e, n)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_only_evaluation_shards_and_reduces_counts():
+    """SURVEY 8(e) decode / eval: replicas only -- round-robin shard of the utterance list, (errors, words) all-reduced."""
+    port = 29700 + (os.getpid() % 200)
+    ret = mp.Manager().dict()
+    mp.spawn(_eval_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0][0] == [0, 2, 4, 6, 8, 10] and ret[1][0] == [1, 3, 5, 7, 9]
+    assert ret[0][1:] == ret[1][1:] == (55.0, 110.0)

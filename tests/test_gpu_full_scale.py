@@ -6,8 +6,8 @@ K-split BPTT, the fast GEMM path).  Here the SAME architecture runs one full tra
 against the oracle restatement (reference las/las.py:226-304): 3,504 dependent recurrent steps per direction and
 ~190 decoder steps, so error growth through the recurrences is part of what is checked.
 
-Tolerances: f32 mode <= 1e-3 on logits / alignments (SURVEY 8(d) full-T figure), gradients 5e-3 of the largest
-oracle entry; bf16 mode against the oracle's bf16-operand mode: logits 2e-2, alignments 1e-2, loss 2e-3, gradients 3e-2.
+Tolerances: FULL_T_TOL below -- f32 mode <= 1e-3 on logits / alignments (SURVEY 8(d) full-T figure), gradients 5e-3 of
+the largest oracle entry; bf16 mode against the oracle's bf16-operand mode.
 """
 import numpy as np
 import pytest
@@ -25,7 +25,30 @@ def bench_arch(**over):
     return make_args(**kw)
 
 
-@pytest.mark.parametrize("prec,cell", [("f32", "lstm"), ("bf16", "lstm"), ("bf16", "rnn")])
+# (prec, cell) -> tolerances.  The lstm cell is what bench.py times.  The reference's own cell (tanh BasicRNNCell) is
+# chaotic over 1,274 steps at random initialisation: the ORACLE's f32 and bf16 modes already differ by 2.2e-2 (logits),
+# 1.6e-2 (alignments) and 0.43 (the layer-0 backward-direction bias gradient) on this very input (tests/oracle_sensitivity.py,
+# profiles/r2_oracle_sensitivity.txt), i.e. any perturbation -- accumulation order included -- is amplified to the size of
+# the operand rounding.  rnn/bf16 is therefore held to that intrinsic gap, rnn/f32 to the tight bound.
+FULL_T_TOL = {
+    ("f32", "lstm"): dict(logits=1e-3, alphas=1e-3, loss=1e-4, grad=5e-3, agree=0.999),
+    ("f32", "rnn"): dict(logits=1e-3, alphas=1e-3, loss=1e-4, grad=5e-3, agree=0.999),
+    ("bf16", "lstm"): dict(logits=1e-2, alphas=5e-3, loss=1e-3, grad=2e-2, agree=0.99),
+    ("bf16", "rnn"): dict(logits=6e-2, alphas=5e-2, loss=1e-3, grad=0.6, agree=0.97),
+}
+
+
+def _log(name, rec):
+    """append the measured errors to $LAS_PARITY_LOG (kept under profiles/ as the parity record of the round)"""
+    import json
+    import os
+    path = os.environ.get("LAS_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=name, **rec)) + "\n")
+
+
+@pytest.mark.parametrize("prec,cell", sorted(FULL_T_TOL))
 def test_bench_architecture_full_T_train_step(prec, cell):
     args = bench_arch()
     xs, ys = synthetic_batch(4, 1274, 256, 30, seed=7, min_frac=0.834)
@@ -33,22 +56,23 @@ def test_bench_architecture_full_T_train_step(prec, cell):
     assert 150 < U <= 200
     r = train_step_pair(args, cell, prec, xs, ys, seed=3)
     assert r["alphas"].shape[-1] == 160                       # T' in (128, 160]: the <.,10> row-kernel instances
-    tol = dict(logits=1e-3, alphas=1e-3, loss=1e-4, grad=5e-3) if prec == "f32" else \
-        dict(logits=2e-2, alphas=1e-2, loss=2e-3, grad=3e-2)
+    tol = FULL_T_TOL[(prec, cell)]
     errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(),
                 alphas=(r["alphas"] - r["alphas_o"]).abs().max().item(),
                 loss=abs(r["loss"] - r["loss_o"]) / max(1.0, abs(r["loss_o"])))
     ge = grad_errors(r)
     worst = max(ge, key=ge.get)
-    print("full-T %s/%s: logits %.2e alphas %.2e loss %.2e worst grad %s %.2e" % (cell, prec, errs["logits"], errs["alphas"],
-                                                                                  errs["loss"], worst, ge[worst]))
+    # greedy token agreement of the teacher-forced logits (the "token agreement" criterion of SURVEY 8(d) for bf16)
+    agree = (r["logits"].argmax(-1) == r["logits_o"].argmax(-1)).float().mean().item()
+    _log("full_T_train_step", dict(prec=prec, cell=cell, B=4, T=1274, U=U, worst_grad=worst, worst_grad_err=ge[worst],
+                                   token_agreement=agree, **errs))
+    print("full-T %s/%s: logits %.2e alphas %.2e loss %.2e worst grad %s %.2e agree %.4f" % (
+        cell, prec, errs["logits"], errs["alphas"], errs["loss"], worst, ge[worst], agree))
     for k, v in errs.items():
         assert v < tol[k], (k, v)
     for n, e in ge.items():
         assert e < tol["grad"], (n, e)
-    # greedy token agreement of the teacher-forced logits (the "token agreement" criterion of SURVEY 8(d) for bf16)
-    agree = (r["logits"].argmax(-1) == r["logits_o"].argmax(-1)).float().mean().item()
-    assert agree > (0.999 if prec == "f32" else 0.98), agree
+    assert agree > tol["agree"], agree
 
 
 def test_bench_architecture_full_T_with_scheduled_sampling_bf16():
@@ -77,7 +101,9 @@ def test_bench_architecture_full_T_with_scheduled_sampling_bf16():
     # pass 2: same weights, the recovered draws injected on both sides
     r = train_step_pair(args, "lstm", "bf16", xs, ys, seed=3, coins=coins, sampled=sampled)
     assert (r["tokens_in"].numpy() == tok).all()
-    assert (r["logits"] - r["logits_o"]).abs().max().item() < 2e-2
-    assert (r["alphas"] - r["alphas_o"]).abs().max().item() < 1e-2
-    for n, e in grad_errors(r).items():
-        assert e < 3e-2, (n, e)
+    ge = grad_errors(r)
+    errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(), alphas=(r["alphas"] - r["alphas_o"]).abs().max().item())
+    _log("full_T_scheduled_sampling", dict(prec="bf16", cell="lstm", worst_grad_err=max(ge.values()), **errs))
+    assert errs["logits"] < 1e-2 and errs["alphas"] < 5e-3
+    for n, e in ge.items():
+        assert e < 2e-2, (n, e)
