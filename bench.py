@@ -172,7 +172,7 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     utts = []
     for k in range(nutt):
         xs, _ = synthetic_batch(1, T, 8, 30, seed=100 + k)
-        utts.append((torch.tensor(xs[0], device=dev), xs[1]))
+        utts.append(xs)
     bs.decode_batch(None, utts[:2])                      # warm-up (library init, allocator)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

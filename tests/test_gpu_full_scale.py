@@ -33,7 +33,7 @@ def bench_arch(**over):
 FULL_T_TOL = {
     ("f32", "lstm"): dict(logits=1e-3, alphas=1e-3, loss=1e-4, grad=5e-3, agree=0.999),
     ("f32", "rnn"): dict(logits=1e-3, alphas=1e-3, loss=1e-4, grad=5e-3, agree=0.999),
-    ("bf16", "lstm"): dict(logits=1e-2, alphas=5e-3, loss=1e-3, grad=2e-2, agree=0.99),
+    ("bf16", "lstm"): dict(logits=4e-3, alphas=1e-3, loss=1e-3, grad=5e-3, agree=0.99),     # measured r2: 7.3e-4 / 1.8e-5 / 1.0e-3
     ("bf16", "rnn"): dict(logits=6e-2, alphas=5e-2, loss=1e-3, grad=0.6, agree=0.97),
 }
 
@@ -104,6 +104,6 @@ def test_bench_architecture_full_T_with_scheduled_sampling_bf16():
     ge = grad_errors(r)
     errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(), alphas=(r["alphas"] - r["alphas_o"]).abs().max().item())
     _log("full_T_scheduled_sampling", dict(prec="bf16", cell="lstm", worst_grad_err=max(ge.values()), **errs))
-    assert errs["logits"] < 1e-2 and errs["alphas"] < 5e-3
+    assert errs["logits"] < 4e-3 and errs["alphas"] < 1e-3                  # measured r2: 4.6e-4 / 2.1e-5 / 7.6e-4
     for n, e in ge.items():
-        assert e < 2e-2, (n, e)
+        assert e < 5e-3, (n, e)

@@ -29,8 +29,13 @@ CONFIGS = [
 # Stated tolerances.  f32 mode: SURVEY 8(d) (<= 1e-4 on logits / alignments at these sizes, 2e-3 relative on gradients).
 # bf16 mode is held against the oracle's bf16-OPERAND mode (oracle.set_precision('bf16'): same rounding points, fp32
 # accumulation), so what remains is accumulation order, fast transcendentals and the few values that land on the other
-# side of a bf16 rounding boundary: <= 4e-3 on logits, 2e-3 on alignments, 2e-2 relative on every gradient.
-TOL = {"f32": dict(logits=5e-4, alphas=1e-4, loss=1e-4, grad=2e-3), "bf16": dict(logits=4e-3, alphas=2e-3, loss=2e-3, grad=2e-2)}
+# side of a bf16 rounding boundary.  How far ONE such flip moves the outputs depends on the cell: perturbing the inputs of
+# these very configurations by 1e-5 (a handful of flipped bf16 inputs) moves the ORACLE's own logits by 3.8e-4 with lstm
+# cells and by 8.2e-3 with the reference's tanh BasicRNNCell, which has no gates to damp it (tests/oracle_flip_sensitivity.py
+# ; profiles/r2_oracle_sensitivity.txt).  Hence two bf16 rows: lstm <= 4e-3 logits / 2e-3 alignments / 2e-2
+# gradients; rnn 3e-2 / 1.5e-2 / 0.1 (a few flips), with the f32 rows pinning the rnn kernels' arithmetic at 1e-4.
+TOL = {("f32", "lstm"): dict(logits=5e-4, alphas=1e-4, loss=1e-4, grad=2e-3), ("f32", "rnn"): dict(logits=5e-4, alphas=1e-4, loss=1e-4, grad=2e-3),
+       ("bf16", "lstm"): dict(logits=4e-3, alphas=2e-3, loss=2e-3, grad=2e-2), ("bf16", "rnn"): dict(logits=3e-2, alphas=1.5e-2, loss=5e-3, grad=0.1)}
 
 
 def _run_pair(cfg, B=5, T=37, U_max=9):
@@ -52,7 +57,7 @@ def _run_pair(cfg, B=5, T=37, U_max=9):
 def test_train_step_matches_oracle(cfg):
     r = _run_pair(cfg)
     prec = cfg[5]
-    tol = TOL[prec]
+    tol = TOL[(prec, cfg[0])]
     assert r["gs"] == 1
     assert set(r["grads"]) == set(r["names"]), set(r["names"]) ^ set(r["grads"])
     assert (r["logits"] - r["logits_o"]).abs().max().item() < tol["logits"]
