@@ -9,6 +9,7 @@
 // dY.W^T (NT) and X^T.dY (TN), with a fused bias + tanh epilogue, batching (blockIdx.z) and a
 // deterministic split-K (partials to workspace, fixed-order reduce) for the tall-K weight gradients.
 #include "las_common.h"
+#include <type_traits>
 
 struct GemmArgs {
     int M, N, K;
@@ -21,6 +22,7 @@ struct GemmArgs {
     int vecA, vecB;                                // 16-byte vector loads legal
     int splitk, kchunk;                            // split-K: blockIdx.z = split, K range [z*kchunk, ..)
     float* partial;                                // [splitk][M][N] when splitk > 1
+    int in_bf16;                                   // A and B are bf16 in HBM (speed-mode activations / gradients)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) { return act == LAS_ACT_TANH ? tanhf(v) : v; }
@@ -194,27 +196,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 // (edge tiles compute throw-away rows), k tail zero-filled by a select.  LDS is double buffered: one
 // barrier per k-tile, the next tile's global loads are issued before the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int ROWS, int NT, bool KC>
+// TI = float (operands converted to bf16 while they are staged) or unsigned short (operands already bf16 in HBM:
+// speed-mode activations / gradients -- half the bytes, no conversion)
+template <int ROWS, int NT, bool KC, typename TI>
 struct FastRegs {
-    // KC: one float4 (4 consecutive k) per chunk.  !KC: a 4(rows) x 4(k) micro-tile per chunk = 4 float4 along rows.
+    // KC: one 4-element chunk (4 consecutive k).  !KC: a 4(rows) x 4(k) micro-tile per chunk = 4 chunks along rows.
     static constexpr int N = KC ? (ROWS * 8 + NT - 1) / NT : 4 * ((ROWS * 2 + NT - 1) / NT);
-    float4 v[N];
+    typename std::conditional<std::is_same<TI, float>::value, float4, uint2>::type v[N];
 };
 
-template <int ROWS, int NT, bool KC>
-__device__ __forceinline__ void fast_gload(FastRegs<ROWS, NT, KC>& r, const float* __restrict__ X, long long rs, long long ks,
+__device__ __forceinline__ void ld4(float4& d, const float* p, bool on) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    d = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void ld4(uint2& d, const unsigned short* p, bool on) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    d = on ? v : make_uint2(0u, 0u);
+}
+__device__ __forceinline__ void zero4(float4& d) { d = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero4(uint2& d) { d = make_uint2(0u, 0u); }
+
+template <int ROWS, int NT, bool KC, typename TI>
+__device__ __forceinline__ void fast_gload(FastRegs<ROWS, NT, KC, TI>& r, const TI* __restrict__ X, long long rs, long long ks,
                                            int row0, int k0, int R, int Kend) {
     if (KC) {
         constexpr int NCH = ROWS * 8;
 #pragma unroll
         for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
             const int c = threadIdx.x + i * NT;
-            if (NCH % NT != 0 && c >= NCH) { r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (NCH % NT != 0 && c >= NCH) { zero4(r.v[i]); continue; }
             const int row = c >> 3, kq = (c & 7) * 4;
             const int gr = min(row0 + row, R - 1), gk = k0 + kq;
             const bool on = gk + 3 < Kend;                         // K % 4 == 0 on this path
-            const float4 v = *reinterpret_cast<const float4*>(X + (long long)gr * rs + (on ? gk : 0));
-            r.v[i] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ld4(r.v[i], X + (long long)gr * rs + (on ? gk : 0), on);
         }
     } else {
         constexpr int NCH = ROWS * 2, RQ = ROWS / 4;
@@ -228,26 +242,42 @@ __device__ __forceinline__ void fast_gload(FastRegs<ROWS, NT, KC>& r, const floa
             for (int kk = 0; kk < 4; ++kk) {
                 const int gk = k0 + kq + kk;
                 const bool on = live && gk < Kend;
-                const float4 v = *reinterpret_cast<const float4*>(X + (long long)(on ? gk : 0) * ks + gr);
-                r.v[i * 4 + kk] = on ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                ld4(r.v[i * 4 + kk], X + (long long)(on ? gk : 0) * ks + gr, on);
             }
         }
     }
 }
 
-template <int ROWS, int NT, bool KC>
-__device__ __forceinline__ void fast_sstore(unsigned short* S, const FastRegs<ROWS, NT, KC>& r) {
+// 4 consecutive k of one row -> 8 bytes of bf16 in LDS
+__device__ __forceinline__ uint2 pack_k4(const float4& v) { uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w); return pk; }
+__device__ __forceinline__ uint2 pack_k4(const uint2& v) { return v; }
+// register micro-transpose of a 4(rows) x 4(k) tile held as 4 row-chunks (one per k): row j gets its 4 consecutive k
+__device__ __forceinline__ void transpose4(const float4& k0v, const float4& k1v, const float4& k2v, const float4& k3v,
+                                           uint2& p0, uint2& p1, uint2& p2, uint2& p3) {
+    p0.x = f2bf2(k0v.x, k1v.x); p0.y = f2bf2(k2v.x, k3v.x);
+    p1.x = f2bf2(k0v.y, k1v.y); p1.y = f2bf2(k2v.y, k3v.y);
+    p2.x = f2bf2(k0v.z, k1v.z); p2.y = f2bf2(k2v.z, k3v.z);
+    p3.x = f2bf2(k0v.w, k1v.w); p3.y = f2bf2(k2v.w, k3v.w);
+}
+__device__ __forceinline__ void transpose4(const uint2& k0v, const uint2& k1v, const uint2& k2v, const uint2& k3v,
+                                           uint2& p0, uint2& p1, uint2& p2, uint2& p3) {
+    // k?v.x = rows (0,1), k?v.y = rows (2,3) of column k, 16 bits each
+    p0.x = (k0v.x & 0xffffu) | (k1v.x << 16);         p0.y = (k2v.x & 0xffffu) | (k3v.x << 16);
+    p1.x = (k0v.x >> 16) | (k1v.x & 0xffff0000u);     p1.y = (k2v.x >> 16) | (k3v.x & 0xffff0000u);
+    p2.x = (k0v.y & 0xffffu) | (k1v.y << 16);         p2.y = (k2v.y & 0xffffu) | (k3v.y << 16);
+    p3.x = (k0v.y >> 16) | (k1v.y & 0xffff0000u);     p3.y = (k2v.y >> 16) | (k3v.y & 0xffff0000u);
+}
+
+template <int ROWS, int NT, bool KC, typename TI>
+__device__ __forceinline__ void fast_sstore(unsigned short* S, const FastRegs<ROWS, NT, KC, TI>& r) {
     if (KC) {
         constexpr int NCH = ROWS * 8;
 #pragma unroll
         for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
             const int c = threadIdx.x + i * NT;
             if (NCH % NT != 0 && c >= NCH) continue;
-            const float4 v = r.v[i];
             const int row = c >> 3, kq = (c & 7) * 4;
-            uint2 pk;
-            pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
-            *reinterpret_cast<uint2*>(&S[row * LDK + kq]) = pk;
+            *reinterpret_cast<uint2*>(&S[row * LDK + kq]) = pack_k4(r.v[i]);
         }
     } else {
         constexpr int NCH = ROWS * 2, RQ = ROWS / 4;
@@ -256,13 +286,8 @@ __device__ __forceinline__ void fast_sstore(unsigned short* S, const FastRegs<RO
             const int c = threadIdx.x + i * NT;
             if (NCH % NT != 0 && c >= NCH) continue;
             const int kq = (c / RQ) * 4, rq = (c % RQ) * 4;
-            const float4 k0v = r.v[i * 4 + 0], k1v = r.v[i * 4 + 1], k2v = r.v[i * 4 + 2], k3v = r.v[i * 4 + 3];
-            // register micro-transpose: row rq+j gets its 4 consecutive k as one 8-byte LDS store
             uint2 p0, p1, p2, p3;
-            p0.x = f2bf2(k0v.x, k1v.x); p0.y = f2bf2(k2v.x, k3v.x);
-            p1.x = f2bf2(k0v.y, k1v.y); p1.y = f2bf2(k2v.y, k3v.y);
-            p2.x = f2bf2(k0v.z, k1v.z); p2.y = f2bf2(k2v.z, k3v.z);
-            p3.x = f2bf2(k0v.w, k1v.w); p3.y = f2bf2(k2v.w, k3v.w);
+            transpose4(r.v[i * 4 + 0], r.v[i * 4 + 1], r.v[i * 4 + 2], r.v[i * 4 + 3], p0, p1, p2, p3);
             *reinterpret_cast<uint2*>(&S[(rq + 0) * LDK + kq]) = p0;
             *reinterpret_cast<uint2*>(&S[(rq + 1) * LDK + kq]) = p1;
             *reinterpret_cast<uint2*>(&S[(rq + 2) * LDK + kq]) = p2;
@@ -271,7 +296,7 @@ __device__ __forceinline__ void fast_sstore(unsigned short* S, const FastRegs<RO
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC>
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, typename TI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (BM + BN) * LDK];
@@ -288,8 +313,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
         if (by >= ny) return;
     }
     const int m0 = by * BM, n0 = bx * BN;
-    const float* A = g.A;
-    const float* B = g.B;
+    const TI* A = reinterpret_cast<const TI*>(g.A);
+    const TI* B = reinterpret_cast<const TI*>(g.B);
     float* C = g.C;
     int kbeg = 0, kend = g.K;
     if (g.splitk > 1) {
@@ -306,20 +331,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    FastRegs<BM, NT, AKC> ra;
-    FastRegs<BN, NT, BKC> rb;
-    fast_gload<BM, NT, AKC>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend);
-    fast_gload<BN, NT, BKC>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend);
+    FastRegs<BM, NT, AKC, TI> ra;
+    FastRegs<BN, NT, BKC, TI> rb;
+    fast_gload<BM, NT, AKC, TI>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend);
+    fast_gload<BN, NT, BKC, TI>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend);
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         unsigned short* As = lds + buf * (BM + BN) * LDK;
         unsigned short* Bs = As + BM * LDK;
-        fast_sstore<BM, NT, AKC>(As, ra);
-        fast_sstore<BN, NT, BKC>(Bs, rb);
+        fast_sstore<BM, NT, AKC, TI>(As, ra);
+        fast_sstore<BN, NT, BKC, TI>(Bs, rb);
         __syncthreads();                       // tile visible; the other buffer is free (its readers passed the previous barrier)
         if (k0 + 32 < kend) {
-            fast_gload<BM, NT, AKC>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend);
-            fast_gload<BN, NT, BKC>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend);
+            fast_gload<BM, NT, AKC, TI>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend);
+            fast_gload<BN, NT, BKC, TI>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend);
         }
         u16x8_t a[TM], b[TN];
 #pragma unroll
@@ -358,17 +383,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
         }
 }
 
-template <int WM, int WN, int TM, int TN>
-static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, typename TI>
+static void launch_fast_t(const GemmArgs& g, int zdim, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int nx = cdiv(g.N, BN), ny = cdiv(g.M, BM);
     const bool xcd_order = ny >= 64 && zdim == 1;        // tall output: 1-D grid, row blocks padded to 8, XCD-aware order
     dim3 grid(xcd_order ? nx * ((ny + 7) / 8 * 8) : nx, xcd_order ? 1 : ny, zdim), blk(WM * WN * 64);
     const bool akc = g.ksA == 1, bkc = g.ksB == 1;
-    if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, g);
-    else                  hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, g);
+    if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true, TI>), grid, blk, 0, st, g);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false, TI>), grid, blk, 0, st, g);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, true, TI>), grid, blk, 0, st, g);
+    else                  hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, false, TI>), grid, blk, 0, st, g);
+}
+template <int WM, int WN, int TM, int TN>
+static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
+    if (g.in_bf16) launch_fast_t<WM, WN, TM, TN, unsigned short>(g, zdim, st);
+    else           launch_fast_t<WM, WN, TM, TN, float>(g, zdim, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,6 +511,17 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
                         int lda, long long strideA, const float* B, int ldb, long long strideB, float beta,
                         float* C, int ldc, long long strideC, const float* bias, int act, int batch,
                         int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream) {
+    return las_gemm_dt(prec, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, LAS_DT_F32, beta, C, ldc, strideC, bias,
+                       act, batch, a_mask_period, a_mask_skip, ws, ws_bytes, stream);
+}
+
+extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K, float alpha, const void* Av,
+                           int lda, long long strideA, const void* Bv, int ldb, long long strideB, int in_dtype, float beta,
+                           float* C, int ldc, long long strideC, const float* bias, int act, int batch,
+                           int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream) {
+    const float* A = (const float*)Av;
+    const float* B = (const float*)Bv;
+    LAS_ARG(in_dtype == LAS_DT_F32 || (in_dtype == LAS_DT_BF16 && prec == LAS_PREC_BF16), "las_gemm: bf16 operands need LAS_PREC_BF16");
     LAS_ARG(prec == LAS_PREC_F32 || prec == LAS_PREC_BF16, "las_gemm: bad prec %d", prec);
     LAS_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "las_gemm: bad dims M=%d N=%d K=%d batch=%d", M, N, K, batch);
     LAS_ARG(A && B && C, "las_gemm: null operand");
@@ -497,9 +538,11 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     g.rsB = transB ? ldb : 1;  g.ksB = transB ? 1 : ldb;
     g.bias = bias; g.act = act;
     g.mask_period = a_mask_period; g.mask_skip = a_mask_skip;
-    g.vecA = ((lda % 4) == 0) && (((uintptr_t)A & 15) == 0) && ((strideA % 4) == 0);
-    g.vecB = ((ldb % 4) == 0) && (((uintptr_t)B & 15) == 0) && ((strideB % 4) == 0);
+    const uintptr_t amask = in_dtype == LAS_DT_BF16 ? 7 : 15;       // 4-element chunks: 8 bytes of bf16 / 16 bytes of fp32
+    g.vecA = ((lda % 4) == 0) && (((uintptr_t)A & amask) == 0) && ((strideA % 4) == 0);
+    g.vecB = ((ldb % 4) == 0) && (((uintptr_t)B & amask) == 0) && ((strideB % 4) == 0);
     g.splitk = 1; g.kchunk = K; g.partial = nullptr;
+    g.in_bf16 = in_dtype == LAS_DT_BF16;
 
     // tile configuration
     int BM, BN;
@@ -531,6 +574,9 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     if (K == 0 && g.splitk == 1) {
         // empty contraction: C = act(beta*C + bias); run the kernel with no k-tiles
     }
+    LAS_ARG(!g.in_bf16 || (fast_ok && cfg != 3) || (fast_ok && M <= 48),
+            "las_gemm: bf16 operands are served by the branch-free path only (aligned pitches, K / row counts multiples of 4, no mask)");
+    if (g.in_bf16 && cfg == 3) { cfg = 2; BM = 64; BN = 64; }
     if (fast_ok && (cfg == 1 || cfg == 2)) {
         if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
         else          launch_fast<2, 2, 2, 2>(g, zdim, st);
@@ -567,7 +613,15 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
 // ------------------------------------------------------------------------------------------------
 constexpr int CS_SPLITS = 64;
 
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int rows, int cols, int ldx,
+template <typename T> __device__ __forceinline__ float ld_f(const T* p);
+template <> __device__ __forceinline__ float ld_f<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_f<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st_f(T* p, float v);
+template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_f<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int rows, int cols, int ldx,
                                                              float* __restrict__ part, int nsplit) {
     // block: 64 columns x 4 row lanes; blockIdx.y = row split
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -576,7 +630,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float s = 0.f;
     if (c < cols)
-        for (int r = r0 + rl; r < r1; r += 4) s += X[(long long)r * ldx + c];
+        for (int r = r0 + rl; r < r1; r += 4) s += ld_f<T>(X + (long long)r * ldx + c);
     __shared__ float red[4][64];
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
@@ -595,14 +649,19 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 extern "C" size_t las_colsum_workspace_bytes(int cols) { return (size_t)CS_SPLITS * cols * sizeof(float); }
 
-extern "C" int las_colsum(const float* X, int rows, int cols, int ldx, float beta, float* out, void* ws,
-                          size_t ws_bytes, void* stream) {
+extern "C" int las_colsum_dt(const void* X, int dtype, int rows, int cols, int ldx, float beta, float* out, void* ws,
+                             size_t ws_bytes, void* stream) {
     LAS_ARG(X && out && rows >= 0 && cols > 0 && ldx >= cols, "las_colsum: bad arguments");
+    LAS_ARG(dtype == LAS_DT_F32 || dtype == LAS_DT_BF16, "las_colsum: bad dtype %d", dtype);
     LAS_ARG(ws && ws_bytes >= las_colsum_workspace_bytes(cols), "las_colsum: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int nsplit = rows >= CS_SPLITS * 8 ? CS_SPLITS : 1;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), nsplit), dim3(256), 0, st, X, rows, cols, ldx,
-                       (float*)ws, nsplit);
+    if (dtype == LAS_DT_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<unsigned short>, dim3(cdiv(cols, 64), nsplit), dim3(256), 0, st,
+                           (const unsigned short*)X, rows, cols, ldx, (float*)ws, nsplit);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(cdiv(cols, 64), nsplit), dim3(256), 0, st, (const float*)X, rows, cols, ldx,
+                           (float*)ws, nsplit);
     LAS_LAUNCHED();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, cols, nsplit,
                        beta, out);
@@ -610,30 +669,55 @@ extern "C" int las_colsum(const float* X, int rows, int cols, int ldx, float bet
     return 0;
 }
 
+extern "C" int las_colsum(const float* X, int rows, int cols, int ldx, float beta, float* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+    return las_colsum_dt(X, LAS_DT_F32, rows, cols, ldx, beta, out, ws, ws_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // tanh gradient
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ dY,
-                                                       int lddy, float* __restrict__ dX, int lddx, int rows, int cols) {
+template <typename TY, typename TD, typename TX>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const TY* __restrict__ Y, int ldy, const TD* __restrict__ dY,
+                                                       int lddy, TX* __restrict__ dX, int lddx, int rows, int cols) {
     const long long total = (long long)rows * cols;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const long long r = idx / cols;
         const int c = (int)(idx % cols);
-        const float y = Y[r * ldy + c];
-        dX[r * lddx + c] = dY[r * lddy + c] * (1.f - y * y);
+        const float y = ld_f<TY>(Y + r * ldy + c);
+        st_f<TX>(dX + r * lddx + c, ld_f<TD>(dY + r * lddy + c) * (1.f - y * y));
     }
 }
 
-extern "C" int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, int lddx, int rows,
-                            int cols, void* stream) {
+// dX = dY * (1 - Y*Y); each tensor fp32 or bf16 (y_dt / dy_dt / dx_dt)
+extern "C" int las_tanh_bwd_dt(const void* Y, int y_dt, int ldy, const void* dY, int dy_dt, int lddy, void* dX, int dx_dt, int lddx,
+                               int rows, int cols, void* stream) {
     LAS_ARG(Y && dY && dX && rows >= 0 && cols >= 0, "las_tanh_bwd: bad arguments");
     if (rows == 0 || cols == 0) return 0;
     int nb = cdiv((long long)rows * cols, 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Y, ldy, dY, lddy, dX, lddx, rows,
-                       cols);
+    hipStream_t st = (hipStream_t)stream;
+    typedef unsigned short u16;
+#define TB(TY, TD, TX) hipLaunchKernelGGL((tanh_bwd_kernel<TY, TD, TX>), dim3(nb), dim3(256), 0, st, (const TY*)Y, ldy, (const TD*)dY, lddy, (TX*)dX, lddx, rows, cols)
+    const int key = (y_dt == LAS_DT_BF16 ? 4 : 0) | (dy_dt == LAS_DT_BF16 ? 2 : 0) | (dx_dt == LAS_DT_BF16 ? 1 : 0);
+    switch (key) {
+        case 0: TB(float, float, float); break;
+        case 1: TB(float, float, u16); break;
+        case 2: TB(float, u16, float); break;
+        case 3: TB(float, u16, u16); break;
+        case 4: TB(u16, float, float); break;
+        case 5: TB(u16, float, u16); break;
+        case 6: TB(u16, u16, float); break;
+        default: TB(u16, u16, u16); break;
+    }
+#undef TB
     LAS_LAUNCHED();
     return 0;
+}
+
+extern "C" int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, int lddx, int rows,
+                            int cols, void* stream) {
+    return las_tanh_bwd_dt(Y, LAS_DT_F32, ldy, dY, LAS_DT_F32, lddy, dX, LAS_DT_F32, lddx, rows, cols, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

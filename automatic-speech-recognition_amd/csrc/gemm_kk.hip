@@ -1,0 +1,147 @@
+// gemm_kk.hip -- the dependency-chain contractions of the Listener in speed mode (K1 / K3):
+//     C[M,N] = act( A[M,K] . B[N,K]^T + bias )          A, B bf16 with the CONTRACTION index contiguous, C bf16 or fp32
+//
+// Replaces, for the activations that now live in HBM as bf16, the fp32-operand path of gemm.hip whose loader converted
+// fp32 -> bf16 on every tile (2x the algorithmic bytes and a per-CU L1-bandwidth bound).  Every chain
+// product of the pyramidal listener has this shape once the weights are kept as bf16 shadows in both orientations:
+//   x-projection   gates = x . [W_ih_fw | W_ih_bw]     (reference las/layers.py:31,49-53)   B = shadow of W^T  [2GH, I]
+//   dense (+tanh)  y = tanh(out . Wd + b)              (las/layers.py:71-74, :89-93)        B = shadow of Wd^T [2H, 2H|4H]
+//   their input gradients  dX = dY . W^T                                                    B = shadow of W    [K_in, N_out]
+// Structure (cdna_hip_programming.md section 5): 128 x 128 x 64 tile, 4 waves (2 x 2), each wave 64 x 64 = 4 x 4
+// v_mfma_f32_16x16x32_bf16 tiles; both operand tiles go HBM -> LDS with global_load_lds (16 B per lane, no VGPR round
+// trip), double buffered with ONE barrier per k-tile (the next tile's DMA is in flight under the current tile's MFMAs);
+// LDS rows are 128 B, the 16-byte chunks of a row are XOR-swizzled by (row >> 1) & 7 on the SOURCE address and on the
+// fragment read (rule 21), which makes the ds_read_b128 fragment loads conflict free.  The MFMA operands are swapped
+// (D = B_frag . A_frag) so that a lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte (bf16) / 16-byte
+// (fp32) stores, bias as one float4 per tile.
+#include "las_common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gconst_void_t;
+
+struct KKArgs {
+    const unsigned short* A; long long lda;     // [M, K] bf16, row pitch lda elements (multiple of 8)
+    const unsigned short* B; long long ldb;     // [N, K] bf16
+    void* C; long long ldc;                     // [M, N] bf16 or fp32
+    const float* bias;                          // [N] or null
+    int M, N, K, act, out_bf16;
+};
+
+constexpr int KK_BM = 128, KK_BN = 128, KK_BK = 64;
+constexpr int KK_TILE_BYTES = KK_BM * KK_BK * 2;            // 16 KiB per operand tile
+constexpr int KK_LDS = 2 * 2 * KK_TILE_BYTES;               // two buffers x (A, B)
+
+__global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform (LDS-DMA base)
+    const int wm = w >> 1, wn = w & 1;
+    // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): all column tiles of one row block go
+    // to the same XCD back to back, so the 128-row slab of A is fetched into that L2 once
+    const int nx = (g.N + KK_BN - 1) / KK_BN, ny = (g.M + KK_BM - 1) / KK_BM;
+    const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
+    const int by = xcd + 8 * (li / nx), bx = li % nx;
+    if (by >= ny) return;
+    const int m0 = by * KK_BM, n0 = bx * KK_BN;
+
+    // ---- LDS-DMA sources: wave w stages rows [w*32, w*32+32) of both tiles, 8 rows (1 KiB) per instruction; lane l of
+    // piece q covers row w*32 + q*8 + (l >> 3), LDS position l & 7, i.e. global chunk (l & 7) ^ ((row >> 1) & 7)
+    const unsigned short* pa[4];
+    const unsigned short* pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = w * 32 + q * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        const int ra = min(m0 + row, g.M - 1), rb = min(n0 + row, g.N - 1);     // edge tiles: clamped, results never stored
+        pa[q] = g.A + (long long)ra * g.lda + ch * 8;
+        pb[q] = g.B + (long long)rb * g.ldb + ch * 8;
+    }
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* ab = smem + buf * 2 * KK_TILE_BYTES + w * 32 * 128;
+        unsigned char* bb = ab + KK_TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((gconst_void_t*)pa[q], (lds_void_t*)(ab + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gconst_void_t*)pb[q], (lds_void_t*)(bb + q * 1024), 16, 0, 0);
+            pa[q] += KK_BK; pb[q] += KK_BK;
+        }
+    };
+    // ---- fragment reads: row (lane & 15) of a 16-row MFMA tile, k-chunk s*4 + (lane >> 4), swizzled like the source
+    const int sw = (lane & 15) >> 1;
+    const int fo0 = (lane & 15) * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
+    const int fo1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / KK_BK;
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
+        __builtin_amdgcn_s_barrier();                         // ... everybody's has; everybody is done reading tile kt-1
+        if (kt + 1 < nk) stage((kt + 1) & 1);                 // flies under this tile's MFMAs
+        const unsigned char* As = smem + (kt & 1) * 2 * KK_TILE_BYTES + wm * 64 * 128;
+        const unsigned char* Bs = smem + (kt & 1) * 2 * KK_TILE_BYTES + KK_TILE_BYTES + wn * 64 * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fo = s ? fo1 : fo0;
+            u16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u16x8_t*>(As + i * 2048 + fo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u16x8_t*>(Bs + j * 2048 + fo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(b[j], a[i], acc[i][j]);   // swapped: D[n][m]
+        }
+    }
+    // ---- epilogue: lane holds C[m = tile row (lane & 15)][n = 4 consecutive columns (lane >> 4)*4 + r]
+    const bool do_tanh = g.act == LAS_ACT_TANH;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (n >= g.N) continue;                                  // N % 4 == 0
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+            if (do_tanh) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+            if (g.out_bf16) {
+                uint2 pk;
+                pk.x = f2bf2(v0, v1); pk.y = f2bf2(v2, v3);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + (long long)m * g.ldc + n) = pk;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long long)m * g.ldc + n) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                           void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream) {
+    LAS_ARG(A && B && C, "las_gemm_kk: null operand");
+    LAS_ARG(M > 0 && N > 0 && K > 0, "las_gemm_kk: bad dims M=%d N=%d K=%d", M, N, K);
+    LAS_ARG(K % KK_BK == 0, "las_gemm_kk: K=%d must be a multiple of %d (pad the operands with zero columns)", K, KK_BK);
+    LAS_ARG(N % 4 == 0, "las_gemm_kk: N=%d must be a multiple of 4", N);
+    LAS_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0, "las_gemm_kk: row pitches must cover K / N and be multiples of 8");
+    LAS_ARG(c_dtype == LAS_DT_F32 || c_dtype == LAS_DT_BF16, "las_gemm_kk: bad output type %d", c_dtype);
+    LAS_ARG((ldc % 4) == 0, "las_gemm_kk: ldc must be a multiple of 4");
+    LAS_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "las_gemm_kk: operands must be 16-byte aligned");
+    LAS_ARG(act == LAS_ACT_NONE || act == LAS_ACT_TANH, "las_gemm_kk: bad act %d", act);
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KK_LDS);
+    if (attr != 0) { las_set_error("hipFuncSetAttribute(gemm_kk) failed: %d", attr); return attr; }
+    KKArgs g;
+    g.A = (const unsigned short*)A; g.lda = lda; g.B = (const unsigned short*)B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = c_dtype == LAS_DT_BF16;
+    const int nx = cdiv(N, KK_BN), ny = cdiv(M, KK_BM);
+    hipLaunchKernelGGL(gemm_kk_kernel, dim3(nx * ((ny + 7) / 8 * 8)), dim3(256), KK_LDS, (hipStream_t)stream, g);
+    LAS_LAUNCHED();
+    return 0;
+}

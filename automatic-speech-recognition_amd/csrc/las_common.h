@@ -121,6 +121,9 @@ template <int NT> __device__ __forceinline__ float block_max_lds(float v, float*
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+extern "C" int las_colsum_dt(const void* X, int dtype, int rows, int cols, int ldx, float beta, float* out, void* ws,
+                             size_t ws_bytes, void* stream);
+
 // ---- skinny-M contraction (gemm.hip): C[M<=64, N] = A[M,K] . B + bias with B pre-packed to bf16 MFMA
 // fragments.  Used by the Speller's per-step cell products, where M = batch rows and the weights are re-read
 // every step: packing once per call makes every weight load a 1 KiB coalesced wave access.

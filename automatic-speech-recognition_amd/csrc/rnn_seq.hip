@@ -25,6 +25,8 @@ struct RnnArgs {
     float* out; int ld_out; long long obs;
     float* cstate;
     const float* dout; int ld_dout; long long dobs;
+    // the same tensors as seen by the speed-mode (bf16 storage) kernels; exactly one family is used per launch
+    unsigned short *gates16, *out16, *cstate16; const unsigned short* dout16; unsigned short* sink16;
     float fb;
     const void* wpack;
     long long* dbg;   // LAS_PROF builds only: device buffer for s_memtime stamps (env LAS_DBG_PTR)
@@ -243,10 +245,24 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // (a member can be at most one step ahead of the slowest reader).  The buffer is zeroed by a memset node
 // before every launch; spins are bounded and report through err[0].
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-typedef __attribute__((address_space(1))) float gfloat;          // explicit global pointers: global_load/store, never flat
-typedef __attribute__((address_space(1))) const float gcfloat;
-#define GF(p) ((gfloat*)(p))
-#define GCF(p) ((gcfloat*)(p))
+// Activations of the speed mode live in HBM as bf16 (SURVEY 8(d) algorithmic bytes): x-projections / saved gates, cell
+// states, h and their gradients.  BfPtr keeps the kernels' element-wise addressing readable: p[i] reads a bf16 element as
+// float, p[i] = v rounds (RNE) and stores it; explicit global address space (global_load/store_short, never flat).
+typedef __attribute__((address_space(1))) unsigned short gio;
+struct BfRef {
+    gio* p;
+    __device__ __forceinline__ operator float() const { return bf2f(*p); }
+    __device__ __forceinline__ void operator=(float v) const { *p = f2bf(v); }
+};
+struct BfPtr {
+    gio* p;
+    __device__ __forceinline__ BfRef operator[](long long i) const { return BfRef{p + i}; }
+    __device__ __forceinline__ BfPtr operator+(long long o) const { return BfPtr{p + o}; }
+    __device__ __forceinline__ BfPtr& operator+=(long long o) { p += o; return *this; }
+};
+#define GF(p) (BfPtr{(gio*)(p)})
+#define GCF(p) (BfPtr{(gio*)(p)})
+typedef __attribute__((address_space(1))) float gfloat;          // fp32 globals (helper waves' LDS rings stay fp32)
 #define LAS_SPIN_BUDGET_DEFAULT (1 << 22)
 
 // `local` = every member of this cluster runs on the same XCD (verified at kernel start, cluster_same_xcd): the
@@ -391,9 +407,9 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
     const long long tstep = dir ? -1 : 1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out;
     // rows past the end of a ragged batch tile read/write a scratch row (no exec-mask branches in the loop)
-    gfloat* gptr[4];
-    gfloat* cptr[4];
-    gfloat* optr[4];
+    BfPtr gptr[4];
+    BfPtr cptr[4];
+    BfPtr optr[4];
     long long gst[4], cst_[4], ost[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -401,9 +417,9 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
-        cptr[r] = GF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
-        optr[r] = GF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
+        gptr[r] = GF(valid ? a.gates16 + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink16 + u0);
+        cptr[r] = GF((valid && a.cstate16) ? a.cstate16 + ((row * T + t0) * 2 + dir) * H + u0 : a.sink16 + u0);
+        optr[r] = GF(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0;
     }
     float cst[UTP][4];
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (CELL == LAS_CELL_LSTM) {
-                    gfloat* gp = gptr[r] + j * 16;
+                    BfPtr gp = gptr[r] + j * 16;
                     gp[0] = sv_g[0][j][r]; gp[H] = sv_g[G > 1 ? 1 : 0][j][r]; gp[2 * H] = sv_g[G > 2 ? 2 : 0][j][r];
                     gp[3 * H] = sv_g[G > 3 ? 3 : 0][j][r];
                     cptr[r][j * 16] = cst[j][r];
@@ -576,8 +592,8 @@ struct HwCfg {
     static constexpr int LFH = NFW - RFH;                     // the rest: LDS
     static constexpr int XW = G * UPM, XP = XW + 4;           // x row: floats / padded pitch (4*XP = 16 mod 64 banks)
     static constexpr int OW = (CELL == LAS_CELL_LSTM ? (G + 2) : 1) * UPM, OP = OW + 4;   // result row [gates | c | h] or [h]
-    static constexpr int NX = 16 * XW / 4 / 64;               // float4 slots per step of the gate slice (64 lanes each)
-    static constexpr int NC4 = 16 * UPM / 4 / 64;             // float4 slots per step of the c (and h) slice
+    static constexpr int NX = 16 * XW / 8 / 64;               // 8-element (16-byte bf16) slots per step of the gate slice (64 lanes each)
+    static constexpr int NC4 = 16 * UPM / 4 / 64;             // 4-element (8-byte bf16) slots per step of the c (and h) slice
     static constexpr int XR_BYTES = 3 * 16 * XP * 4, OR_BYTES = 2 * 16 * OP * 4;          // x ring: 3 steps, result ring: 2 steps
     static constexpr int LDS = C::HS_BYTES + 4 * LFH * 1024 + XR_BYTES + OR_BYTES;
     static constexpr bool OK = C::OK && (XW % 64 == 0) && (NX % NHW == 0) && (NC4 % NHW == 0) && NC4 >= NHW && LDS <= 160 * 1024;
@@ -609,19 +625,23 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 
     if (w >= 4) {
         // ============================ helper waves: all bulk HBM traffic ============================
+        // HBM side: bf16, 16-byte (8 elements: gate slice) and 8-byte (4 elements: c / h slices) accesses; LDS rings: fp32 in
+        // accumulator order, so the compute waves see exactly what they saw with fp32 storage.
         // Every access is (uniform base of the frame) + (32-bit per-lane element offset).
         typedef float f4v __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(1))) const f4v gcf4;
-        typedef __attribute__((address_space(1))) f4v gf4;
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) const u32x4_t gcu4;
+        typedef __attribute__((address_space(1))) u32x4_t gu4;
+        typedef __attribute__((address_space(1))) u32x2_t gu2;
         const int hw = w - 4;
-        constexpr int GR4 = XW / 4;                    // float4 per row of the gate slice
-        constexpr int UR4 = UPM / 4;                   // float4 per row of the c / h slice
+        constexpr int GR8 = XW / 8;                    // 8-element pieces per row of the gate slice
+        constexpr int UR4 = UPM / 4;                   // 4-element pieces per row of the c / h slice
         auto brow = [&](int row) { const int b = b0 + row; return (unsigned)(b < B ? b : B - 1); };
         unsigned xoff[NXH], coff[NCH], hoff[NCH];
         int xl[NXH], xo[NXH], co[NCH];
 #pragma unroll
         for (int ii = 0; ii < NXH; ++ii) {             // gate slice: x-projection in, activated gates out (same addresses)
-            const int idx = (ii * NHW + hw) * 64 + lane, row = idx / GR4, f = (idx % GR4) * 4;
+            const int idx = (ii * NHW + hw) * 64 + lane, row = idx / GR8, f = (idx % GR8) * 8;
             xoff[ii] = brow(row) * (unsigned)(T * 2 * GH) + dir * GH + (f / UPM) * H + pm * UPM + (f % UPM);
             xl[ii] = row * XP + f;
             xo[ii] = row * OP + f;
@@ -633,58 +653,73 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             hoff[ii] = brow(row) * (unsigned)a.obs + dir * H + pm * UPM + u;
             co[ii] = row * OP + u;
         }
-        auto gframe = [&](int s) { return a.gates + (long long)(t0 + s * tstep) * 2 * GH; };     // uniform frame bases
-        auto cframe = [&](int s) { return a.cstate + (long long)(t0 + s * tstep) * 2 * H; };
-        auto oframe = [&](int s) { return a.out + (long long)(t0 + s * tstep) * a.ld_out; };
-        f4v xq[NXH];                                  // the loads in flight (this wave's share of one step)
+        auto gframe = [&](int s) { return a.gates16 + (long long)(t0 + s * tstep) * 2 * GH; };     // uniform frame bases
+        auto cframe = [&](int s) { return a.cstate16 + (long long)(t0 + s * tstep) * 2 * H; };
+        auto oframe = [&](int s) { return a.out16 + (long long)(t0 + s * tstep) * a.ld_out; };
+        auto to_ring = [&](float* xr, const u32x4_t& v, int off) __attribute__((always_inline)) {   // 8 bf16 -> 2 x float4 in LDS
+            f4v lo = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+            f4v hi = {__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+            *reinterpret_cast<f4v*>(xr + off) = lo;
+            *reinterpret_cast<f4v*>(xr + off + 4) = hi;
+        };
+        u32x4_t xq[NXH];                                // the loads in flight (this wave's share of one step)
         // ring: slot (s % 3) holds step s; steps 0 and 1 are staged here, step 2 is requested before the loop
         {
-            const float* gb = gframe(0);
+            const unsigned short* gb = gframe(0);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcf4*)GCF(gb + xoff[ii]);
+            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) *reinterpret_cast<f4v*>(xring + xl[ii]) = xq[ii];
+            for (int ii = 0; ii < NXH; ++ii) to_ring(xring, xq[ii], xl[ii]);
         }
         if (T > 1) {
-            const float* gb = gframe(1);
+            const unsigned short* gb = gframe(1);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcf4*)GCF(gb + xoff[ii]);
+            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) *reinterpret_cast<f4v*>(xring + 16 * XP + xl[ii]) = xq[ii];
+            for (int ii = 0; ii < NXH; ++ii) to_ring(xring + 16 * XP, xq[ii], xl[ii]);
         }
         if (T > 2) {
-            const float* gb = gframe(2);
+            const unsigned short* gb = gframe(2);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcf4*)GCF(gb + xoff[ii]);
+            for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
         }
         __syncthreads();
-        auto flush = [&](int slot, int s) __attribute__((always_inline)) {      // results of step s: LDS ring -> HBM, 16-byte stores
+        auto pack4 = [&](const float* src) __attribute__((always_inline)) {
+            const f4v v = *reinterpret_cast<const f4v*>(src);
+            u32x2_t r = {f2bf2(v.x, v.y), f2bf2(v.z, v.w)};
+            return r;
+        };
+        auto flush = [&](int slot, int s) __attribute__((always_inline)) {      // results of step s: LDS ring -> HBM (bf16)
             const float* orr = oring + slot * 16 * OP;
-            float* ob = oframe(s);
+            unsigned short* ob = oframe(s);
             if (CELL == LAS_CELL_LSTM) {
-                float* gb = gframe(s);
-                float* cb = cframe(s);
+                unsigned short* gb = gframe(s);
+                unsigned short* cb = cframe(s);
 #pragma unroll
-                for (int ii = 0; ii < NXH; ++ii) *(gf4*)GF(gb + xoff[ii]) = *reinterpret_cast<const f4v*>(orr + xo[ii]);
+                for (int ii = 0; ii < NXH; ++ii) {
+                    const u32x2_t lo = pack4(orr + xo[ii]), hi = pack4(orr + xo[ii] + 4);
+                    const u32x4_t pk = {lo.x, lo.y, hi.x, hi.y};
+                    *(gu4*)(gb + xoff[ii]) = pk;
+                }
 #pragma unroll
                 for (int ii = 0; ii < NCH; ++ii) {
-                    *(gf4*)GF(cb + coff[ii]) = *reinterpret_cast<const f4v*>(orr + co[ii] + G * UPM);
-                    *(gf4*)GF(ob + hoff[ii]) = *reinterpret_cast<const f4v*>(orr + co[ii] + (G + 1) * UPM);
+                    *(gu2*)(cb + coff[ii]) = pack4(orr + co[ii] + G * UPM);
+                    *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii] + (G + 1) * UPM);
                 }
             } else {
 #pragma unroll
-                for (int ii = 0; ii < NCH; ++ii) *(gf4*)GF(ob + hoff[ii]) = *reinterpret_cast<const f4v*>(orr + co[ii]);
+                for (int ii = 0; ii < NCH; ++ii) *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii]);
             }
         };
         for (int s = 0; s < T; ++s) {
             if (s + 2 < T) {        // step s+2 has had a whole step in flight: hand it to the ring, request step s+3
                 float* xr = xring + ((s + 2) % 3) * 16 * XP;
 #pragma unroll
-                for (int ii = 0; ii < NXH; ++ii) *reinterpret_cast<f4v*>(xr + xl[ii]) = xq[ii];
+                for (int ii = 0; ii < NXH; ++ii) to_ring(xr, xq[ii], xl[ii]);
                 if (s + 3 < T) {
-                    const float* gb = gframe(s + 3);
+                    const unsigned short* gb = gframe(s + 3);
 #pragma unroll
-                    for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcf4*)GCF(gb + xoff[ii]);
+                    for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
                 }
             }
             if (s >= 1) flush((s - 1) & 1, s - 1);
@@ -848,10 +883,10 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
-    gfloat* gptr[4];
-    gcfloat* cptr[4];
-    gcfloat* optr[4];
-    gcfloat* dptr[4];
+    BfPtr gptr[4];
+    BfPtr cptr[4];
+    BfPtr optr[4];
+    BfPtr dptr[4];
     long long gst[4], cst_[4], ost[4], dst[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -859,10 +894,10 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
-        cptr[r] = GF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
-        optr[r] = GF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
-        dptr[r] = GCF(valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0);
+        gptr[r] = GF(valid ? a.gates16 + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink16 + u0);
+        cptr[r] = GF((valid && a.cstate16) ? a.cstate16 + ((row * T + t0) * 2 + dir) * H + u0 : a.sink16 + u0);
+        optr[r] = GF(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
+        dptr[r] = GCF(valid ? a.dout16 + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink16 + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
     }
     f32x4_t dhr[UTP];
@@ -941,7 +976,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
         }
         // advance to the next visited frame and refill the operand registers (dz of this step is written
         // to HBM after the exchange; the pointers keep the previous frame in gprev)
-        gfloat* gprev[4];
+        BfPtr gprev[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         if (s + 1 < T) {
@@ -1053,10 +1088,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
-    gfloat* gptr[4];
-    gcfloat* cptr[4];
-    gcfloat* optr[4];
-    gcfloat* dptr[4];
+    BfPtr gptr[4];
+    BfPtr cptr[4];
+    BfPtr optr[4];
+    BfPtr dptr[4];
     long long gst[4], cst_[4], ost[4], dst[4];
     float vrow[4];
 #pragma unroll
@@ -1065,10 +1100,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = GF(valid ? a.gates + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink + u0);
-        cptr[r] = GCF((valid && a.cstate) ? a.cstate + ((row * T + t0) * 2 + dir) * H + u0 : a.sink + u0);
-        optr[r] = GCF(valid ? a.out + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink + u0);
-        dptr[r] = GCF(valid ? a.dout + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink + u0);
+        gptr[r] = GF(valid ? a.gates16 + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink16 + u0);
+        cptr[r] = GCF((valid && a.cstate16) ? a.cstate16 + ((row * T + t0) * 2 + dir) * H + u0 : a.sink16 + u0);
+        optr[r] = GCF(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
+        dptr[r] = GCF(valid ? a.dout16 + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink16 + u0);
         gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
         vrow[r] = valid ? 1.f : 0.f;
     }
@@ -1137,7 +1172,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 }
             }
         }
-        gfloat* gprev[4];
+        BfPtr gprev[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
         if (s + 1 < T) {     // operands of the next step fly under this step's MFMAs and exchange
@@ -1492,6 +1527,7 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         a.wpack = base + L.pack;
         a.err = (int*)(base + L.err);
         a.sink = (float*)(base + L.sink);
+        a.sink16 = (unsigned short*)(base + L.sink);
         a.force_agent = (flags & LAS_SEQ_AGENT_GRANULES) ? 1 : 0;
         a.no_helpers = (flags & LAS_SEQ_NO_HELPER_WAVES) ? 1 : 0;
         a.ks_packed = (bwd && P > 1 && !(flags & LAS_SEQ_NO_KSPLIT)) ? 1 : 0;
@@ -1511,10 +1547,10 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
             const int b0 = tile0 * 16, rows = (B - b0) < max_tiles * 16 ? (B - b0) : max_tiles * 16;
             RnnArgs c = a;
             c.B = rows;
-            c.gates = a.gates + (size_t)b0 * T * 2 * G * H;
-            c.out = a.out + (size_t)b0 * a.obs;
-            if (a.cstate) c.cstate = a.cstate + (size_t)b0 * T * 2 * H;
-            if (a.dout) c.dout = a.dout + (size_t)b0 * a.dobs;
+            c.gates16 = a.gates16 + (size_t)b0 * T * 2 * G * H;
+            c.out16 = a.out16 + (size_t)b0 * a.obs;
+            if (a.cstate16) c.cstate16 = a.cstate16 + (size_t)b0 * T * 2 * H;
+            if (a.dout16) c.dout16 = a.dout16 + (size_t)b0 * a.dobs;
             c.xbuf = (unsigned long long*)(base + L.xbuf) + (size_t)tile0 * 2 * per_cl;
             c.xcc = (unsigned long long*)(base + L.xcc) + (size_t)tile0 * 2 * 8;
             c.bpart = (float*)(base + L.bpart) + (size_t)tile0 * 2 * G * H;
@@ -1539,20 +1575,34 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.status = status; a.status_code = code;
 }
 
-extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
-                               const float* whh_bw, int ldw, float* out, int ld_out, long long out_bstride,
-                               float* cstate, float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int las_rnn_seq_io_dtype(int cell, int prec, int H) {
+    (void)cell;
+    return (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) ? LAS_DT_BF16 : LAS_DT_F32;
+}
+
+static void bind_tensors(RnnArgs& a, void* gates, void* out, void* cstate, const void* dout) {
+    a.gates = (float*)gates; a.out = (float*)out; a.cstate = (float*)cstate; a.dout = (const float*)dout;
+    a.gates16 = (unsigned short*)gates; a.out16 = (unsigned short*)out; a.cstate16 = (unsigned short*)cstate;
+    a.dout16 = (const unsigned short*)dout; a.sink16 = nullptr;
+}
+
+extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                               void* cstate, float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RnnArgs a;
-    a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
-    a.out = out; a.ld_out = ld_out; a.obs = out_bstride; a.cstate = cstate;
-    a.dout = nullptr; a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
+    a.B = B; a.T = T; a.H = H; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
+    a.ld_out = ld_out; a.obs = out_bstride;
+    bind_tensors(a, gates, out, cstate, nullptr);
+    a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
     seq_common_args(a, flags, status, LAS_SEQ_STATUS_FWD_TIMEOUT);
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif
     if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
+        LAS_ARG(ld_out % 4 == 0 && out_bstride % 4 == 0 && (((uintptr_t)gates | (uintptr_t)out | (uintptr_t)cstate) & 15) == 0,
+                "las_rnn_seq_fwd: bf16 tensors must be 16-byte aligned with pitches that are multiples of 4");
         if (int rc = run_bf16(false, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st)) return rc;
     } else {
         const size_t lds = (size_t)H * F32_BT * sizeof(float);
@@ -1564,17 +1614,17 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* g
     return 0;
 }
 
-extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
-                               const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
-                               const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
+extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                               const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
                                float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
     return las_rnn_seq_bwd_db(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout,
                               dout_bstride, forget_bias, nullptr, nullptr, flags, status, ws, ws_bytes, stream);
 }
 
-extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates, const float* whh_fw,
-                                  const float* whh_bw, int ldw, const float* out, int ld_out, long long out_bstride,
-                                  const float* cstate, const float* dout, int ld_dout, long long dout_bstride,
+extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                  const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                                  const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
                                   float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
                                   void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
@@ -1582,11 +1632,13 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float
     hipStream_t st = (hipStream_t)stream;
     const int G = cell == LAS_CELL_LSTM ? 4 : 1;
     RnnArgs a;
-    a.B = B; a.T = T; a.H = H; a.gates = gates; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
-    a.out = const_cast<float*>(out); a.ld_out = ld_out; a.obs = out_bstride; a.cstate = const_cast<float*>(cstate);
-    a.dout = dout; a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
+    a.B = B; a.T = T; a.H = H; a.whh[0] = whh_fw; a.whh[1] = whh_bw; a.ldw = ldw;
+    a.ld_out = ld_out; a.obs = out_bstride;
+    bind_tensors(a, gates, const_cast<void*>(out), const_cast<void*>(cstate), dout);
+    a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
     seq_common_args(a, flags, status, LAS_SEQ_STATUS_BWD_TIMEOUT);
-    if (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) {
+    const bool bf = prec == LAS_PREC_BF16 && mfma_shape_ok(H);
+    if (bf) {
         int db_done = 0;
         if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st, dbias_fw, dbias_bw, &db_done)) return rc;
         if (db_done) return 0;
@@ -1610,7 +1662,8 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float
     for (int d = 0; d < 2; ++d) {
         float* db = d ? dbias_bw : dbias_fw;
         if (!db) continue;
-        if (int rc = las_colsum(gates + (size_t)d * G * H, B * T, G * H, 2 * G * H, 1.f, db, ws, ws_bytes, stream)) return rc;
+        const void* gd = bf ? (const void*)((const unsigned short*)gates + (size_t)d * G * H) : (const void*)((const float*)gates + (size_t)d * G * H);
+        if (int rc = las_colsum_dt(gd, bf ? LAS_DT_BF16 : LAS_DT_F32, B * T, G * H, 2 * G * H, 1.f, db, ws, ws_bytes, stream)) return rc;
     }
     return 0;
 }

@@ -15,6 +15,7 @@ PREC_F32, PREC_BF16 = 0, 1
 CELL_RNN, CELL_LSTM = 0, 1
 ACT_NONE, ACT_TANH = 0, 1
 ATT_ADD, ATT_LOC = 0, 1
+DT_F32, DT_BF16 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblas_hip.so")
@@ -57,10 +58,18 @@ _SIGS = {
     "las_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_longlong,
                          c_void_p, c_int, c_longlong, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
                          c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_gemm_dt": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_longlong,
+                            c_void_p, c_int, c_longlong, c_int, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
+                            c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_gemm_kk": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
+                            c_void_p, c_int, c_void_p]),
     "las_colsum_workspace_bytes": (c_size_t, [c_int]),
     "las_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_tanh_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "las_rnn_seq_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "las_rnn_seq_io_dtype": (c_int, [c_int, c_int, c_int]),
+    "las_colsum_dt": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "las_tanh_bwd_dt": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "las_rnn_seq_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_int, c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_bwd": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
@@ -224,28 +233,50 @@ def _tag(t):
 def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, batch=1, strideA=0, strideB=0, strideC=0,
          mask_period=0, mask_skip=0, a_off=0, b_off=0, c_off=0):
-    """C = act(alpha * op(A).op(B) + beta*C + bias).  A,B,C are fp32 tensors; *_off are element offsets."""
+    """C = act(alpha * op(A).op(B) + beta*C + bias).  A, B both fp32 or both bf16 (speed-mode activations), C fp32;
+    *_off are element offsets."""
     require_gpu(A, B, C, bias)
+    if A.dtype != B.dtype:
+        raise RuntimeError("las_gemm: operands must share one element type (got %s, %s)" % (A.dtype, B.dtype))
     ws = workspace(C.device, GEMM_WS_BYTES, _tag("gemm"))
-    rc = lib().las_gemm(prec, int(transA), int(transB), M, N, K, alpha,
-                        c_void_p(A.data_ptr() + 4 * a_off), lda, strideA,
-                        c_void_p(B.data_ptr() + 4 * b_off), ldb, strideB, beta,
-                        c_void_p(C.data_ptr() + 4 * c_off), ldc, strideC, p(bias), act, batch,
-                        mask_period, mask_skip, p(ws), ws.numel(), stream())
+    es = A.element_size()
+    rc = lib().las_gemm_dt(prec, int(transA), int(transB), M, N, K, alpha,
+                           c_void_p(A.data_ptr() + es * a_off), lda, strideA,
+                           c_void_p(B.data_ptr() + es * b_off), ldb, strideB, DT_BF16 if A.dtype == torch.bfloat16 else DT_F32, beta,
+                           c_void_p(C.data_ptr() + 4 * c_off), ldc, strideC, p(bias), act, batch,
+                           mask_period, mask_skip, p(ws), ws.numel(), stream())
     check(rc, "las_gemm")
 
 
+def gemm_kk(A, B, C, M, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, a_off=0, b_off=0, c_off=0):
+    """C[M,N] = act(A[M,K] . B[N,K]^T + bias): A, B bf16 (contraction contiguous), C bf16 or fp32; *_off element offsets."""
+    require_gpu(A, B, C, bias)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype in (torch.bfloat16, torch.float32)
+    cdt = DT_BF16 if C.dtype == torch.bfloat16 else DT_F32
+    check(lib().las_gemm_kk(M, N, K, c_void_p(A.data_ptr() + 2 * a_off), lda, c_void_p(B.data_ptr() + 2 * b_off), ldb,
+                            c_void_p(C.data_ptr() + C.element_size() * c_off), cdt, ldc, p(bias), act, stream()), "las_gemm_kk")
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    assert t.dtype == torch.float32, t.dtype
+    return DT_F32
+
+
 def colsum(X, rows, cols, ldx, out, beta=0.0, x_off=0):
+    """out[j] = beta*out[j] + sum_r X[r, j]; X fp32 or bf16, out fp32."""
     require_gpu(X, out)
     nb = lib().las_colsum_workspace_bytes(cols)
     ws = workspace(X.device, nb, _tag("colsum"))
-    check(lib().las_colsum(c_void_p(X.data_ptr() + 4 * x_off), rows, cols, ldx, beta, p(out), p(ws), ws.numel(),
-                           stream()), "las_colsum")
+    check(lib().las_colsum_dt(c_void_p(X.data_ptr() + X.element_size() * x_off), _dt(X), rows, cols, ldx, beta, p(out), p(ws),
+                              ws.numel(), stream()), "las_colsum")
 
 
 def tanh_bwd(Y, ldy, dY, lddy, dX, lddx, rows, cols):
+    """dX = dY * (1 - Y*Y); every tensor fp32 or bf16."""
     require_gpu(Y, dY, dX)
-    check(lib().las_tanh_bwd(p(Y), ldy, p(dY), lddy, p(dX), lddx, rows, cols, stream()), "las_tanh_bwd")
+    check(lib().las_tanh_bwd_dt(p(Y), _dt(Y), ldy, p(dY), _dt(dY), lddy, p(dX), _dt(dX), lddx, rows, cols, stream()), "las_tanh_bwd")
 
 
 # ---- optional per-call device timing (bench.py roofline leg): HIP events on the launch stream -----
@@ -371,9 +402,22 @@ def rnn_seq_ws(cell, prec, H, B, dev):
     return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H, B), "rnn_seq")
 
 
+def rnn_seq_io_dtype(cell, prec, H):
+    """torch dtype of gates / out / cstate / dout for this sweep: bf16 when the speed-mode MFMA kernels serve it."""
+    return torch.bfloat16 if lib().las_rnn_seq_io_dtype(cell, prec, H) == DT_BF16 else torch.float32
+
+
+def _check_io(cell, prec, H, *tensors):
+    want = rnn_seq_io_dtype(cell, prec, H)
+    for t in tensors:
+        if t is not None and t.dtype != want:
+            raise RuntimeError("las_rnn_seq: tensors must be %s for (cell=%d, prec=%d, H=%d), got %s" % (want, cell, prec, H, t.dtype))
+
+
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 forget_bias=1.0, wf_off=0, wb_off=0, flags=None):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
+    _check_io(cell, prec, H, gates, out, cstate)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
     with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
@@ -387,6 +431,7 @@ def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
                 dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None):
     """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
+    _check_io(cell, prec, H, gates, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):

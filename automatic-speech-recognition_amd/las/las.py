@@ -620,6 +620,7 @@ class LAS:
         _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n,
                                      _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps, _hip.stream()),
                    "las_clip_adam")
+        st.shadows.clear()                            # bf16 weight shadows are rebuilt from the updated masters
         self.last_grad_sumsq = sumsq
 
     def check_status(self):

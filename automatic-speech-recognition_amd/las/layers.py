@@ -107,15 +107,19 @@ def _direct_ok(p):
             and V.default_store().flat_grad is not None and p.grad.is_contiguous())
 
 
-def dense(x, W, b=None, tanh=False):
-    """x [..., K] -> [..., N]  (tf.layers.dense on a rank-3 input = same weights at every t, App. A.13)"""
+def dense(x, W, b=None, tanh=False, out_f32=True):
+    """x [..., K] -> [..., N]  (tf.layers.dense on a rank-3 input = same weights at every t, App. A.13).
+    bf16 activations (speed-mode listener) go through las_gemm_kk; out_f32=False keeps the result in bf16 too."""
     _hip.require_gpu(x, W)
     shp = x.shape
     x2d = x.reshape(-1, shp[-1])
     if not x2d.is_contiguous():
         x2d = x2d.contiguous()
     _PARAMS["W"], _PARAMS["b"] = W, b
-    y = _Dense.apply(x2d, W, b, bool(tanh), _prec())
+    if x2d.dtype == torch.bfloat16 and W.shape[1] % 4 == 0:
+        y = _Dense16.apply(_as_bf16_operand(x2d), W, b, bool(tanh), bool(out_f32))
+    else:
+        y = _Dense.apply(x2d.float() if x2d.dtype != torch.float32 else x2d, W, b, bool(tanh), _prec())
     _PARAMS.clear()
     return y.view(*shp[:-1], W.shape[1])
 
@@ -236,6 +240,192 @@ class _BLSTM(torch.autograd.Function):
         return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, dx_bw)
 
 
+# ------------------------------------------------------------------------------------------------
+# speed mode with bf16 activation storage (SURVEY 8(d) algorithmic bytes): the Listener's x-projections / saved gates,
+# cell states, h, dense outputs and their gradients live in HBM as bf16; the chain products run through las_gemm_kk
+# (both operands bf16, contraction index contiguous) against bf16 SHADOWS of the fp32 master weights, kept in both
+# orientations and rebuilt after every optimiser step (`_shadow`).  Parameters, their gradients and Adam stay fp32.
+# ------------------------------------------------------------------------------------------------
+def _shadow(tag, params, build):
+    st = V.default_store()
+    key = (tag,) + tuple(int(q.data_ptr()) for q in params)
+    sh = st.shadows.get(key)
+    if sh is None:
+        with torch.no_grad():
+            sh = build()
+        st.shadows[key] = sh
+    return sh
+
+
+def _k64(k):
+    return (k + 63) // 64 * 64
+
+
+def _as_bf16_operand(x):
+    """[..., K] -> bf16 with K padded by zero columns to a multiple of 64 (las_gemm_kk tiles); differentiable."""
+    K = x.shape[-1]
+    if K % 64:
+        x = torch.nn.functional.pad(x, (0, _k64(K) - K))
+    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+
+
+class _Dense16(torch.autograd.Function):
+    """tf.layers.dense (+ tanh) on bf16 activations: y = act(x.W + b), y bf16 or fp32 (`out_f32`)."""
+
+    @staticmethod
+    def forward(ctx, x2d, W, b, act, out_f32):
+        M, K = x2d.shape                               # K = padded width of the operand (>= W.shape[0])
+        Kw, N = W.shape
+        WT = _shadow("denseT", (W,), lambda: _as_bf16_operand(W.detach().t()))           # [N, K64]
+        y = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        _hip.gemm_kk(x2d, WT, y, M, N, K, K, K, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
+        ctx.save_for_backward(x2d, W, y)
+        ctx.act, ctx.has_b = act, b is not None
+        ctx.params = (_PARAMS.get("W"), _PARAMS.get("b"))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W, y = ctx.saved_tensors
+        M, K = x2d.shape
+        Kw, N = W.shape
+        dy = dy.contiguous()
+        if ctx.act:
+            dpre = torch.empty(M, N, device=dy.device, dtype=torch.bfloat16)
+            _hip.tanh_bwd(y, N, dy, N, dpre, N, M, N)
+        else:
+            dpre = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:                    # on the dependency chain: main stream, first
+            Wb = _shadow("dense", (W,), lambda: _as_bf16_operand(torch.nn.functional.pad(W.detach(), (0, 0, 0, K - Kw))))   # [K, N64]
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
+            Nk = Wb.shape[1]
+            if Nk != N:                                # contraction width padded to 64: pad dpre too (rare: N % 64 != 0)
+                dpre_k = torch.nn.functional.pad(dpre, (0, Nk - N))
+            else:
+                dpre_k = dpre
+            _hip.gemm_kk(dpre_k, Wb, dx, M, K, Nk, Nk, Nk, K)
+        Wp, bp = ctx.params
+        _hip.run_deferred()
+        Kg = (Kw + 3) // 4 * 4                         # rows of the weight gradient the TN product writes (zero operand columns beyond Kw)
+        if _direct_ok(Wp) and (bp is None or _direct_ok(bp)) and Kg == Kw:
+            with _hip.on_side_stream():
+                for t in (x2d, dpre):
+                    t.record_stream(_hip.side_stream())
+                _hip.gemm(_hip.PREC_BF16, x2d, dpre, Wp.grad, True, False, Kw, N, M, K, N, N, beta=1.0)
+                if bp is not None:
+                    _hip.colsum(dpre, M, N, N, bp.grad, beta=1.0)
+            return dx, None, None, None, None
+        dW = torch.zeros(Kg, N, device=dy.device)
+        _hip.gemm(_hip.PREC_BF16, x2d, dpre, dW, True, False, Kg, N, M, K, N, N)
+        db = None
+        if ctx.has_b:
+            db = torch.empty(N, device=dy.device, dtype=torch.float32)
+            _hip.colsum(dpre, M, N, N, db)
+        return dx, dW[:Kw], db, None, None
+
+
+class _BLSTM16(torch.autograd.Function):
+    """One bidirectional recurrent layer with bf16 activation storage: K1 x-projection (las_gemm_kk) + K2 sweep + K2b BPTT.
+    x: bf16 [B,T,Ik] (Ik = input width padded to a multiple of 64 with zero columns); I0 = true input width."""
+
+    @staticmethod
+    def forward(ctx, x, kfw, bfw, kbw, bbw, cell, H, pad_even, I0, x_bw=None):
+        B, T, Ik = x.shape
+        G = 4 if cell == "lstm" else 1
+        GH = G * H
+        dev = x.device
+        prec = _hip.PREC_BF16
+        x = x.contiguous()
+        two = x_bw is not None
+        if two:
+            x_bw = x_bw.contiguous()
+        bf = torch.bfloat16
+        gates = torch.empty(B, T, 2, GH, device=dev, dtype=bf)
+        if not two:
+            # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
+            WT = _shadow("ihT", (kfw, kbw), lambda: _as_bf16_operand(torch.cat((kfw.detach()[:I0], kbw.detach()[:I0]), 1).t()))   # [2GH, Ik]
+            bias = _shadow("ihb", (bfw, bbw), lambda: torch.cat((bfw.detach(), bbw.detach())))
+            _hip.gemm_kk(x, WT, gates, B * T, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
+        else:
+            for d, (xd, k, b) in enumerate(((x, kfw, bfw), (x_bw, kbw, bbw))):
+                WTd = _shadow("ihT%d" % d, (k,), lambda k=k: _as_bf16_operand(k.detach()[:I0].t()))                           # [GH, Ik]
+                _hip.gemm_kk(xd, WTd, gates, B * T, GH, Ik, Ik, Ik, 2 * GH, bias=b.detach(), c_off=d * GH)
+        Tp = T + (T % 2) if pad_even else T
+        out = torch.zeros(B, Tp, 2 * H, device=dev, dtype=bf) if Tp != T else torch.empty(B, T, 2 * H, device=dev, dtype=bf)
+        cst = torch.empty(B, T, 2, H, device=dev, dtype=bf) if cell == "lstm" else None
+        _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
+                         1.0, wf_off=I0 * GH, wb_off=I0 * GH)
+        ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
+        ctx.cfg = (cell, H, Tp, I0)
+        ctx.params = _PARAMS.get("blstm")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, kfw, kbw, gates, out, cst, x_bw = ctx.saved_tensors
+        cell, H, Tp, I0 = ctx.cfg
+        B, T, Ik = x.shape
+        G = 4 if cell == "lstm" else 1
+        GH = G * H
+        dev = x.device
+        prec = _hip.PREC_BF16
+        bf = torch.bfloat16
+        dout = dout.contiguous()
+        two = x_bw is not None
+        xs = (x, x_bw if two else x)
+        P4 = ctx.params
+        direct = P4 is not None and all(_direct_ok(p) for p in P4)
+        # gates: activated gates -> d(pre-activation) (bf16), in place; the sweep accumulates the bias gradients in fp32
+        _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
+                         dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
+                         db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None)
+        dx = dx_bw = None
+        if ctx.needs_input_grad[0] and not two:        # on the dependency chain: main stream, first
+            # dX [B*T, Ik] = dZ [B*T, 2GH] . [W_ih_fw | W_ih_bw]^T : B operand = shadow of the concatenated weights [Ik, 2GH]
+            Wb = _shadow("ih", (kfw, kbw), lambda: torch.nn.functional.pad(
+                torch.cat((kfw.detach()[:I0], kbw.detach()[:I0]), 1), (0, 0, 0, Ik - I0)).to(bf).contiguous())
+            dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
+            _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik)
+        elif two and (ctx.needs_input_grad[0] or ctx.needs_input_grad[9]):
+            dx, dx_bw = torch.empty(B, T, Ik, device=dev, dtype=bf), torch.empty(B, T, Ik, device=dev, dtype=bf)
+            for d, (dxd, k) in enumerate(((dx, kfw), (dx_bw, kbw))):
+                Wd = _shadow("ih%d" % d, (k,), lambda k=k: torch.nn.functional.pad(k.detach()[:I0], (0, 0, 0, Ik - I0)).to(bf).contiguous())
+                _hip.gemm_kk(gates, Wd, dxd, B * T, Ik, GH, 2 * GH, GH, Ik, a_off=d * GH)
+        _hip.run_deferred()
+        Ig = (I0 + 3) // 4 * 4          # rows of dW_ih the TN product writes; rows I0..Ig meet zero operand columns (exact zeros)
+        part = torch.empty(B, H, GH, device=dev) if T > 1 else None
+
+        def wgrads(gk_of, d):
+            # dW_ih = x^T . dG_d (contraction over all B*T frames; split-K inside las_gemm); dW_hh = sum_b sum_t h_prev^T . dG_d
+            gk = gk_of(d)
+            _hip.gemm(prec, xs[d], gates, gk, True, False, Ig, GH, B * T, Ik, 2 * GH, GH, beta=1.0, b_off=d * GH)
+            if T > 1:
+                a_off = d * H + (0 if d == 0 else 2 * H)
+                b_off = d * GH + (2 * GH if d == 0 else 0)
+                _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
+                          strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
+                _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
+
+        if direct:
+            # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
+            with _hip.on_side_stream():
+                side = _hip.side_stream()
+                for t in (x, gates, out) + ((x_bw,) if two else ()):
+                    t.record_stream(side)
+                for d in range(2):
+                    wgrads(lambda d: P4[2 * d].grad, d)
+            return (dx, None, None, None, None, None, None, None, None, dx_bw)
+        grads = []
+        for d, k in enumerate((kfw, kbw)):
+            dk = torch.zeros_like(k)
+            wgrads(lambda d, dk=dk: dk, d)
+            db = torch.empty(GH, device=dev)
+            _hip.colsum(gates, B * T, GH, 2 * GH, db, x_off=d * GH)
+            grads += [dk, db]
+        return (dx, grads[0], grads[1], grads[2], grads[3], None, None, None, None, dx_bw)
+
+
 def _blstm_params(scope, I, H, cell):
     st = V.default_store()
     G = 4 if cell == "lstm" else 1
@@ -272,7 +462,15 @@ def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pa
     I = inputs.shape[-1]
     kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
     _PARAMS["blstm"] = (kfw, bfw, kbw, bbw)
-    out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even, x_bw)
+    if _prec() == _hip.PREC_BF16 and _hip.rnn_seq_io_dtype(_cellid(cell), _hip.PREC_BF16, H) == torch.bfloat16:
+        # speed mode: bf16 activation storage (the MFMA sweeps serve this H)
+        out = _BLSTM16.apply(_as_bf16_operand(inputs), kfw, bfw, kbw, bbw, cell, H, pad_even, I,
+                             None if x_bw is None else _as_bf16_operand(x_bw))
+    else:
+        if inputs.dtype != torch.float32:
+            inputs = inputs.float()
+            x_bw = None if x_bw is None else x_bw.float()
+        out = _BLSTM.apply(inputs, kfw, bfw, kbw, bbw, cell, _prec(), H, pad_even, x_bw)
     _PARAMS.clear()
     T = inputs.shape[1]
     fw, bw = out[..., :H], out[..., H:]
@@ -288,7 +486,7 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     sc = scope + "/blstm"
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)
     rnn_out = dense(out, st.get(sc + "/dense/kernel", (2 * H, 2 * H)),
-                    st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True)       # :71-74
+                    st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=num_layers == 0)       # :71-74
     audiolen = torch.as_tensor(audiolen).to(torch.float64)
     states = None
     for l in range(num_layers):
@@ -298,7 +496,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
         # Eq (5): pad T to even, concat frame pairs -- a pure view of the zero-padded buffer (:83-88)
         pairs = out.view(B, Tp // 2, 4 * H)
         rnn_out = dense(pairs, st.get(sc + "/dense/kernel", (4 * H, 2 * H)),
-                        st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True)   # :89-93
+                        st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=l == num_layers - 1)   # :89-93
+        # (the listener's LAST dense output feeds the Speller, whose interface is fp32; everything before it stays bf16)
         audiolen = (audiolen + audiolen % 2) / 2                                          # :94
     return rnn_out, states, audiolen
 

@@ -27,6 +27,7 @@ class VariableStore:
         self.rng = np.random.RandomState(seed)
         self.flat = self.flat_grad = self.adam_m = self.adam_v = None
         self.global_step = 0
+        self.shadows = {}         # bf16 copies of weights for the speed-mode products (las.layers._shadow); cleared when weights change
 
     # ---- creation ----------------------------------------------------------------------------
     def get(self, name, shape=None, init="glorot", fan=None):
@@ -70,6 +71,7 @@ class VariableStore:
 
     def load(self, params):
         """Install externally supplied values {name: array} (parity tests, checkpoints)."""
+        self.shadows.clear()
         for name, val in params.items():
             val = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val,
                                   dtype=torch.float32, device=self.device)
@@ -91,6 +93,7 @@ class VariableStore:
     def flatten(self):
         if self.flat is not None:
             return
+        self.shadows.clear()
         names = list(self.order)
         sizes = [self.vars[n].numel() for n in names]
         offs, o = [], 0

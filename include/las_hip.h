@@ -8,13 +8,14 @@
  * Conventions
  *   - extern "C"; raw DEVICE pointers owned by the caller; the library never allocates or frees
  *     caller tensors.  Scratch is passed in explicitly (ws, ws_bytes), sized by *_workspace_bytes.
- *   - every dimension / leading dimension is an explicit int; tensors are fp32 in HBM, row-major,
+ *   - every dimension / leading dimension is an explicit int; tensors are fp32 in HBM (speed mode: the Listener's
+ *     activations are bf16, see LAS_DT_*), row-major,
  *     batch-major [B,T,C] exactly as the reference lays them out (time_major=False,
  *     las/layers.py:24,53).  Weights keep the TF layout [in,out] with the [x;h] row concat and
  *     gate order i,j,f,o.
  *   - `prec` selects the arithmetic of the contractions:  LAS_PREC_F32 = exact fp32 FMA chains
  *     (parity mode), LAS_PREC_BF16 = operands rounded to bf16 (RNE), fp32 MFMA accumulation
- *     (speed mode).  State, activations, gradients and optimiser math are always fp32.
+ *     (speed mode).  Recurrent state, accumulators, parameters, parameter gradients and optimiser math are always fp32.
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued asynchronously on it,
  *     no hidden synchronisation, no global mutable state besides an init-once attribute cache; the library
  *     reads no environment variables (development switches are explicit `flags` arguments).
@@ -34,6 +35,7 @@ enum { LAS_PREC_F32 = 0, LAS_PREC_BF16 = 1 };
 enum { LAS_CELL_RNN = 0, LAS_CELL_LSTM = 1 };   /* BasicRNNCell (las/layers.py:31) / BasicLSTMCell */
 enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
+enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
 int         las_version(void);
 const char* las_last_error(void);
@@ -58,21 +60,49 @@ int las_gemm(int prec, int transA, int transB, int M, int N, int K,
              const float* bias, int act, int batch,
              int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream);
 
+/* las_gemm with both operands in `in_dtype` (LAS_DT_F32 = las_gemm; LAS_DT_BF16: activations / gradients that already
+ * live in HBM as bf16 -- the weight-gradient contractions X^T . dZ of the speed mode; branch-free path only: aligned
+ * pitches, K resp. row counts multiples of 4, no contraction mask).  C, bias fp32. */
+int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K,
+                float alpha, const void* A, int lda, long long strideA,
+                const void* B, int ldb, long long strideB, int in_dtype,
+                float beta, float* C, int ldc, long long strideC,
+                const float* bias, int act, int batch,
+                int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream);
+
+/* Speed-mode storage type of activations in HBM.  LAS_PREC_BF16 keeps the Listener's activations (x-projections /
+ * saved gates, cell states, h, dense outputs and their gradients) as bf16 -- SURVEY 8(d)'s algorithmic bytes -- while
+ * accumulators, recurrent state inside the sweeps and all parameters / optimiser state stay fp32. */
+/* The dependency-chain products of the Listener in speed mode, both operands bf16 with the contraction index contiguous:
+ *   C[M,N] = act( A[M,K] . B[N,K]^T + bias ),   C bf16 (c_dtype = LAS_DT_BF16) or fp32.
+ * x-projection and dense layers pass the bf16 shadow of W^T as B, their input gradients the shadow of W
+ * (las/layers.py:31,49-53,71-74,89-93 and the matmul gradients of those ops).  K % 64 == 0 (pad with zero columns),
+ * N % 4 == 0, row pitches lda / ldb multiples of 8 elements, 16-byte aligned operands.  LDS-DMA staged, 128x128x64 tiles. */
+int las_gemm_kk(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream);
+
 /* out[j] = beta*out[j] + sum_r X[r*ldx + j],  r < rows, j < cols   (BiasAdd gradient);
  * fixed-order two-stage reduction, ws >= las_colsum_workspace_bytes(cols). */
 size_t las_colsum_workspace_bytes(int cols);
 int las_colsum(const float* X, int rows, int cols, int ldx, float beta, float* out,
                void* ws, size_t ws_bytes, void* stream);
 
+int las_colsum_dt(const void* X, int dtype, int rows, int cols, int ldx, float beta, float* out,
+                  void* ws, size_t ws_bytes, void* stream);            /* X fp32 or bf16 (LAS_DT_*) */
+
 /* dX = dY * (1 - Y*Y)   elementwise over rows x cols (Tanh gradient of dense(.., tanh)). */
 int las_tanh_bwd(const float* Y, int ldy, const float* dY, int lddy, float* dX, int lddx,
                  int rows, int cols, void* stream);
+int las_tanh_bwd_dt(const void* Y, int y_dt, int ldy, const void* dY, int dy_dt, int lddy, void* dX, int dx_dt, int lddx,
+                    int rows, int cols, void* stream);               /* each tensor fp32 or bf16 */
 
 /* ------------------------------------------------------------------------------------------
  * K2/K2b  recurrent sweep of one bidirectional layer
  * (tf.nn.bidirectional_dynamic_rnn without sequence_length, las/layers.py:49-53: every padded
  * frame is run; zero initial state; bw runs t=T-1..0).
  *
+ * Element type of gates / out / cstate / dout: las_rnn_seq_io_dtype(cell, prec, H) -- fp32 in parity mode, bf16 in speed
+ * mode (the recurrent state, accumulators and gate math stay fp32 inside the kernel).
  * gates : [B,T,2,G*H]  (G=1 rnn, 4 lstm; dir 0 = fw, 1 = bw).
  *         fwd in : x_t . W_ih + bias (the K1 product).   fwd out (lstm): activated i,j,f,o.
  *         bwd in : what fwd left.                        bwd out: d(pre-activation) for K1's bwd.
@@ -100,22 +130,26 @@ enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVE
 enum { LAS_SEQ_STATUS_OK = 0, LAS_SEQ_STATUS_FWD_TIMEOUT = 1, LAS_SEQ_STATUS_BWD_TIMEOUT = 2 };
 
 size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
-int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, float* gates,
+/* Element type of gates / out / cstate / dout for (cell, prec, H): LAS_DT_BF16 when the speed-mode MFMA sweeps serve the
+ * shape (prec = LAS_PREC_BF16 and H in {64,128,256,512}), else LAS_DT_F32 (parity mode, or a speed-mode shape that falls
+ * back to the fp32 VALU sweep).  The caller allocates those tensors -- and makes the K1 product write them -- accordingly. */
+int las_rnn_seq_io_dtype(int cell, int prec, int H);
+int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
-                    float* out, int ld_out, long long out_bstride, float* cstate,
+                    void* out, int ld_out, long long out_bstride, void* cstate,
                     float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream);
-int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, float* gates,
+int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
-                    const float* out, int ld_out, long long out_bstride, const float* cstate,
-                    const float* dout, int ld_dout, long long dout_bstride,
+                    const void* out, int ld_out, long long out_bstride, const void* cstate,
+                    const void* dout, int ld_dout, long long dout_bstride,
                     float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream);
-/* Same, and additionally accumulates (+=) the bias gradients of the two directions, dbias_fw / dbias_bw [G*H] (either may
- * be NULL) = column sums of d(pre-activation) over all B*T frames (the bias of the TF cell kernel, las/layers.py:31).  The
- * cluster BPTT kernel sums them in registers while it sweeps (no extra pass over the 4*B*T*G*H-byte gradient). */
-int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, float* gates,
+/* Same, and additionally accumulates (+=) the bias gradients of the two directions, dbias_fw / dbias_bw [G*H] fp32 (either
+ * may be NULL) = column sums of d(pre-activation) over all B*T frames (the bias of the TF cell kernel, las/layers.py:31).
+ * The cluster BPTT kernel sums them in fp32 registers while it sweeps (before the bf16 rounding of the stored gradient). */
+int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates,
                        const float* whh_fw, const float* whh_bw, int ldw,
-                       const float* out, int ld_out, long long out_bstride, const float* cstate,
-                       const float* dout, int ld_dout, long long dout_bstride,
+                       const void* out, int ld_out, long long out_bstride, const void* cstate,
+                       const void* dout, int ld_dout, long long dout_bstride,
                        float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
                        void* ws, size_t ws_bytes, void* stream);
 

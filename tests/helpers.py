@@ -50,11 +50,13 @@ def oracle_mode_for(args, prec):
     speed mode rounds every contraction operand to bf16; with additive attention the Speller row kernels also keep
     keys / context operands in bf16 ('bf' rows), otherwise only the GEMM operands are rounded ('f32' rows)."""
     if prec != "bf16":
-        return ("f32", "bf")
+        return ("f32", "bf", False)
     I0D = args.embedding_size + (2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units) + args.dec_units
     hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
     bf_rows = args.mode == "add" and I0D % 8 == 0 and args.attention_size % 8 == 0 and hd % 8 == 0
-    return ("bf16", "bf" if bf_rows else "f32")
+    # the listener keeps its activations in HBM as bf16 when the MFMA sweeps serve the hidden size
+    store = args.enc_units in (64, 128, 256, 512)
+    return ("bf16", "bf" if bf_rows else "f32", store)
 
 
 def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", oracle_dtype=None):

@@ -90,3 +90,24 @@ def test_colsum_and_tanh_bwd():
     dX = torch.empty_like(Y)
     _hip.tanh_bwd(Y, 130, dY, 130, dX, 130, 77, 130)
     assert torch.allclose(dX.cpu(), (dY * (1 - Y * Y)).cpu(), atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,act,out", [(128, 128, 64, 0, "bf16"), (300, 2048, 512, 0, "bf16"), (1000, 512, 1024, 1, "bf16"),
+                                           (257, 132, 128, 1, "f32"), (61, 512, 2048, 0, "f32"), (4096, 2048, 64, 0, "bf16")])
+def test_gemm_kk_bf16_operands_k_contiguous(M, N, K, act, out):
+    """las_gemm_kk (LDS-DMA staged 128x128x64 MFMA tiles): C = act(A . B^T + bias) with bf16 operands vs a float64 product
+    of the SAME bf16 values (exact operands, so the only error is fp32 accumulation + the output rounding)."""
+    from las import _hip
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K + 8, generator=g) * 0.5).to(torch.bfloat16).cuda()          # padded pitch
+    B = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    C = torch.full((M, N + 4), 7.0, dtype=torch.bfloat16 if out == "bf16" else torch.float32, device="cuda")
+    _hip.gemm_kk(A, B, C, M, N, K, K + 8, K, N + 4, bias=bias, act=act)
+    ref = A[:, :K].double().cpu() @ B.double().cpu().t() + bias.double().cpu()
+    if act:
+        ref = torch.tanh(ref)
+    got = C[:, :N].double().cpu()
+    tol = 2e-5 * K ** 0.5 + (4e-3 * ref.abs().max().item() if out == "bf16" else 0)       # bf16 output: half an ulp of the result
+    assert (got - ref).abs().max().item() < tol + 1e-4
+    assert (C[:, N:].float() == 7.0).all()                                                 # nothing written past N

@@ -1,27 +1,34 @@
-"""Micro-benchmark of las_gemm at the shapes the train step uses."""
+"""Micro-benchmark of the chain contractions at the bench shapes (B=48, T=1274): TF/s of las_gemm_kk (bf16 operands,
+LDS-DMA) next to las_gemm (fp32 operands converted in the loader)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "automatic-speech-recognition_amd"))
 import torch
 from las import _hip
-def run(name, M, N, K, tA, tB, reps=5):
-    A = torch.randn((K, M) if tA else (M, K), device="cuda"); B = torch.randn((N, K) if tB else (K, N), device="cuda")
-    C = torch.empty(M, N, device="cuda")
-    f = lambda: _hip.gemm(1, A, B, C, bool(tA), bool(tB), M, N, K, A.shape[1], B.shape[1], N)
-    f(); torch.cuda.synchronize()
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): f()
+    for _ in range(reps):
+        fn()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    print("%-28s M=%6d N=%5d K=%6d %s%s : %8.3f ms  %7.1f TF" % (name, M, N, K, "T" if tA else "N", "T" if tB else "N", ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+    return e0.elapsed_time(e1) / reps
+
 BT = 48 * 1274
-run("xproj l1 (NN)", BT, 1024, 512, 0, 0)
-run("xproj l0 (NN K=39)", BT, 1024, 39, 0, 0)
-run("dense l0 (NN)", BT, 512, 512, 0, 0)
-run("dense pyr (NN)", BT // 2, 512, 1024, 0, 0)
-run("dx (NT)", BT, 512, 1024, 0, 1)
-run("dW_ih (TN)", 512, 1024, BT, 1, 0)
-run("dW dense (TN)", 1024, 512, BT // 2, 1, 0)
-run("dcellW (TN)", 1152, 2048, 48 * 191, 1, 0)
-run("square 4096", 4096, 4096, 4096, 0, 0)
+for name, M, N, K in [("x-proj L1 (K=512 -> 2GH=2048)", BT, 2048, 512), ("dense L0 (512 -> 512, tanh)", BT, 512, 512),
+                      ("dense L1 pairs (1024 -> 512)", BT // 2, 512, 1024), ("dx of x-proj (2048 -> 512)", BT, 512, 2048),
+                      ("x-proj L0 (K=64 pad -> 2048)", BT, 2048, 64), ("x-proj L3 (T=319)", 48 * 319, 2048, 512)]:
+    A = (torch.randn(M, K, device="cuda") * 0.5)
+    W = (torch.randn(K, N, device="cuda") * 0.05)
+    Ab, WTb = A.to(torch.bfloat16), W.t().contiguous().to(torch.bfloat16)
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    Cf = torch.empty(M, N, device="cuda")
+    t_kk = timeit(lambda: _hip.gemm_kk(Ab, WTb, Cb, M, N, K, K, K, N))
+    t_kkf = timeit(lambda: _hip.gemm_kk(Ab, WTb, Cf, M, N, K, K, K, N))
+    t_old = timeit(lambda: _hip.gemm(_hip.PREC_BF16, A, W, Cf, False, False, M, N, K, K, N, N))
+    fl = 2.0 * M * N * K
+    print("%-34s M=%6d N=%5d K=%5d | kk->bf16 %7.1f us %6.0f TF/s | kk->f32 %7.1f us %6.0f TF/s | fp32-operand %7.1f us %6.0f TF/s" % (
+        name, M, N, K, t_kk * 1e3, fl / t_kk / 1e9, t_kkf * 1e3, fl / t_kkf / 1e9, t_old * 1e3, fl / t_old / 1e9), flush=True)
