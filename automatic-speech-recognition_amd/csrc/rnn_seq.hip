@@ -1049,6 +1049,11 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_bwd_bf16_kernel(RnnArgs a
 // granules of the all-gather, no LDS decode, exact fp32 partials.
 //   wave w of member pm owns unit tiles (pm, w, j), j < UTP, and computes partial tiles (m, w, j) for all m.
 // ====================================================================================================
+// value of the neighbouring lane (lane ^ 1): one v_mov_b32 with DPP quad_perm [1,0,3,2], no LDS crossbar trip
+__device__ __forceinline__ float swap_lane_pair(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
 template <int CELL, int UT, int P>
 struct KsCfg {
     using C = RnnCfg<CELL, UT, P>;
@@ -1088,106 +1093,129 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
     const long long gstep = tstep * 2 * GH, cstep = tstep * 2 * H, ostep = tstep * a.ld_out, dstep = tstep * a.ld_dout;
-    BfPtr gptr[4];
-    BfPtr cptr[4];
-    BfPtr optr[4];
-    BfPtr dptr[4];
-    long long gst[4], cst_[4], ost[4], dst[4];
-    float vrow[4];
+    // ---- element-wise ("pair") layout of the gate backward.  The MFMA accumulator layout gives a lane 4 rows x 1 unit; with
+    // bf16 storage that would mean 2-byte HBM accesses (28 loads + 16 stores per lane and step, partial-line writes).
+    // Instead a lane owns the unit PAIR (c & ~1, c | 1) of 2 rows -- even lanes rows g*4 + {0,1}, odd lanes rows g*4 + {2,3}
+    // -- so every access is one aligned 32-bit word holding two adjacent units: 14 loads + 8 stores per step, and the own-dG
+    // tile is written to LDS as packed pairs.  Only dh (4 values per tile) changes layout: one DPP swap with the
+    // neighbouring lane.  dc (the carried cell gradient) lives in the pair layout throughout.
+    typedef __attribute__((address_space(1))) unsigned int gu32;
+    const int odd = c & 1;
+    gu32* gptr[2];            // row base of the gate block (activated gates in, d(pre-activation) out), at this lane's unit pair
+    const gu32* cptr[2];
+    const gu32* optr[2];
+    const gu32* dptr[2];
+    long long gst[2], cst_[2], ost[2], dst[2];           // per-step advance in 32-bit words (0 for rows past the batch)
+    float vrow[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = b0 + g * 4 + r;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int b = b0 + g * 4 + odd * 2 + rr;
         const bool valid = b < B;
         const long long row = (long long)b;
-        const int u0 = vw * (16 * UTP) + c;
-        gptr[r] = GF(valid ? a.gates16 + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink16 + u0);
-        cptr[r] = GCF((valid && a.cstate16) ? a.cstate16 + ((row * T + t0) * 2 + dir) * H + u0 : a.sink16 + u0);
-        optr[r] = GCF(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
-        dptr[r] = GCF(valid ? a.dout16 + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink16 + u0);
-        gst[r] = valid ? gstep : 0; cst_[r] = valid ? cstep : 0; ost[r] = valid ? ostep : 0; dst[r] = valid ? dstep : 0;
-        vrow[r] = valid ? 1.f : 0.f;
+        const int u0 = vw * (16 * UTP) + (c & ~1);
+        gptr[rr] = (gu32*)(valid ? a.gates16 + ((row * T + t0) * 2 + dir) * GH + u0 : a.sink16 + u0);
+        cptr[rr] = (const gu32*)((valid && a.cstate16) ? a.cstate16 + ((row * T + t0) * 2 + dir) * H + u0 : a.sink16 + u0);
+        optr[rr] = (const gu32*)(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
+        dptr[rr] = (const gu32*)(valid ? a.dout16 + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink16 + u0);
+        gst[rr] = valid ? gstep / 2 : 0; cst_[rr] = valid ? cstep / 2 : 0; ost[rr] = valid ? ostep / 2 : 0; dst[rr] = valid ? dstep / 2 : 0;
+        vrow[rr] = valid ? 1.f : 0.f;
     }
-    float bsum[G][UTP];                      // bias gradient: column sums of dz over this lane's rows and all steps
+    auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
+    auto hi = [](unsigned v) { return __uint_as_float(v & 0xffff0000u); };
+    float bsum[G][UTP][2];                   // bias gradient: column sums of dz over this lane's rows and all steps, per unit of the pair
 #pragma unroll
     for (int q = 0; q < G; ++q)
 #pragma unroll
-        for (int j = 0; j < UTP; ++j) bsum[q][j] = 0.f;
-    f32x4_t dhr[UTP];
-    float dcc[UTP][4];
+        for (int j = 0; j < UTP; ++j) { bsum[q][j][0] = 0.f; bsum[q][j][1] = 0.f; }
+    f32x4_t dhr[UTP];                        // dh_{t-1} of this wave's tiles, accumulator layout (rows g*4+r, unit c)
+    float dcc[UTP][2][2];                    // carried dc, pair layout [row rr][unit k]
 #pragma unroll
     for (int j = 0; j < UTP; ++j) {
         dhr[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dcc[j][r] = 0.f;
+        for (int rr = 0; rr < 2; ++rr) { dcc[j][rr][0] = 0.f; dcc[j][rr][1] = 0.f; }
     }
     constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
-    float n_do[UTP][4], n_g[NG][UTP][4], n_c[UTP][4], n_cn[UTP][4];
+    // operands of one step as packed pairs, ONE register set refilled for step s+1 right after step s consumed it
+    unsigned n_do[UTP][2], n_g[NG][UTP][2], n_c[UTP][2], n_cn[UTP][2];
 #pragma unroll
     for (int j = 0; j < UTP; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            n_do[j][r] = dptr[r][j * 16];
+        for (int rr = 0; rr < 2; ++rr) {
+            n_do[j][rr] = dptr[rr][j * 8];
             if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
-                for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
-                n_c[j][r] = cptr[r][j * 16];
-                n_cn[j][r] = T > 1 ? cptr[r][cst_[r] + j * 16] : 0.f;
+                for (int q = 0; q < NG; ++q) n_g[q][j][rr] = gptr[rr][(q * H + j * 16) / 2];
+                n_c[j][rr] = cptr[rr][j * 8];
+                n_cn[j][rr] = T > 1 ? cptr[rr][cst_[rr] + j * 8] : 0u;
             } else {
-                n_g[0][j][r] = optr[r][j * 16];
-                n_c[j][r] = 0.f; n_cn[j][r] = 0.f;
+                n_g[0][j][rr] = optr[rr][j * 8];
+                n_c[j][rr] = 0u; n_cn[j][rr] = 0u;
             }
         }
     int cur = 0;
     for (int s = 0; s < T; ++s) {
         unsigned short* dzc = dzs + cur * 16 * LDZ;
-        float sv_z[G][UTP][4];
-        // ---- gate backward for the own units -> own dG slice in LDS (bf16) and in registers (fp32, for HBM)
+        unsigned sv_z[G][UTP][2];            // d(pre-activation) of this step as packed pairs (written to HBM after the exchange)
+        // ---- gate backward for the own units -> own dG slice in LDS (bf16 pairs) and in registers
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
-            const int ucol = (w * UTP + j) * 16 + c;                 // column of this unit inside one gate block of the slice
+            // dh of this tile: accumulator layout -> pair layout (swap two values with the neighbouring lane)
+            const float s0 = odd ? dhr[j][0] : dhr[j][2], s1 = odd ? dhr[j][1] : dhr[j][3];
+            const float x0 = swap_lane_pair(s0), x1 = swap_lane_pair(s1);
+            const float o0 = odd ? dhr[j][2] : dhr[j][0], o1 = odd ? dhr[j][3] : dhr[j][1];
+            const float dhp[2][2] = {{odd ? x0 : o0, odd ? o0 : x0}, {odd ? x1 : o1, odd ? o1 : x1}};      // [row rr][unit k]
+            const int ucol = (w * UTP + j) * 16 + (c & ~1);          // column of the pair inside one gate block of the slice
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dh = n_do[j][r] + dhr[j][r];
-                float dz[G];
-                if (CELL == LAS_CELL_LSTM) {
-                    const float gi = n_g[0][j][r], gj = n_g[NG > 1 ? 1 : 0][j][r], gf = n_g[NG > 2 ? 2 : 0][j][r],
-                                go = n_g[NG > 3 ? 3 : 0][j][r];
-                    const float cprev = (s + 1 < T) ? n_cn[j][r] : 0.f;
-                    const float tc = tanhx<true>(n_c[j][r]);
-                    const float dc = dcc[j][r] + dh * go * (1.f - tc * tc);
-                    dcc[j][r] = dc * gf;
-                    dz[0] = dc * gj * gi * (1.f - gi);
-                    dz[G > 1 ? 1 : 0] = dc * gi * (1.f - gj * gj);
-                    dz[G > 2 ? 2 : 0] = dc * cprev * gf * (1.f - gf);
-                    dz[G > 3 ? 3 : 0] = dh * tc * go * (1.f - go);
-                } else {
-                    const float h = n_g[0][j][r];
-                    dz[0] = dh * (1.f - h * h);
+            for (int rr = 0; rr < 2; ++rr) {
+                float dz[G][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float dh = (k ? hi(n_do[j][rr]) : lo(n_do[j][rr])) + dhp[rr][k];
+                    if (CELL == LAS_CELL_LSTM) {
+                        const float gi = k ? hi(n_g[0][j][rr]) : lo(n_g[0][j][rr]);
+                        const float gj = k ? hi(n_g[NG > 1 ? 1 : 0][j][rr]) : lo(n_g[NG > 1 ? 1 : 0][j][rr]);
+                        const float gf = k ? hi(n_g[NG > 2 ? 2 : 0][j][rr]) : lo(n_g[NG > 2 ? 2 : 0][j][rr]);
+                        const float go = k ? hi(n_g[NG > 3 ? 3 : 0][j][rr]) : lo(n_g[NG > 3 ? 3 : 0][j][rr]);
+                        const float cprev = (s + 1 < T) ? (k ? hi(n_cn[j][rr]) : lo(n_cn[j][rr])) : 0.f;
+                        const float tc = tanhx<true>(k ? hi(n_c[j][rr]) : lo(n_c[j][rr]));
+                        const float dc = dcc[j][rr][k] + dh * go * (1.f - tc * tc);
+                        dcc[j][rr][k] = dc * gf;
+                        dz[0][k] = dc * gj * gi * (1.f - gi);
+                        dz[G > 1 ? 1 : 0][k] = dc * gi * (1.f - gj * gj);
+                        dz[G > 2 ? 2 : 0][k] = dc * cprev * gf * (1.f - gf);
+                        dz[G > 3 ? 3 : 0][k] = dh * tc * go * (1.f - go);
+                    } else {
+                        const float h = k ? hi(n_g[0][j][rr]) : lo(n_g[0][j][rr]);
+                        dz[0][k] = dh * (1.f - h * h);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
-                    dzc[(g * 4 + r) * LDZ + q * UPM + ucol] = f2bf(dz[q]);
-                    sv_z[q][j][r] = dz[q];
-                    bsum[q][j] = fmaf(dz[q], vrow[r], bsum[q][j]);
+                    const unsigned pk = f2bf2(dz[q][0], dz[q][1]);
+                    *reinterpret_cast<unsigned*>(&dzc[(g * 4 + odd * 2 + rr) * LDZ + q * UPM + ucol]) = pk;
+                    sv_z[q][j][rr] = pk;
+                    bsum[q][j][0] = fmaf(dz[q][0], vrow[rr], bsum[q][j][0]);
+                    bsum[q][j][1] = fmaf(dz[q][1], vrow[rr], bsum[q][j][1]);
                 }
             }
         }
-        BfPtr gprev[4];
+        gu32* gprev[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { gprev[r] = gptr[r]; gptr[r] += gst[r]; optr[r] += ost[r]; dptr[r] += dst[r]; if (CELL == LAS_CELL_LSTM) cptr[r] += cst_[r]; }
+        for (int rr = 0; rr < 2; ++rr) { gprev[rr] = gptr[rr]; gptr[rr] += gst[rr]; optr[rr] += ost[rr]; dptr[rr] += dst[rr]; if (CELL == LAS_CELL_LSTM) cptr[rr] += cst_[rr]; }
         if (s + 1 < T) {     // operands of the next step fly under this step's MFMAs and exchange
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    n_do[j][r] = dptr[r][j * 16];
+                for (int rr = 0; rr < 2; ++rr) {
+                    n_do[j][rr] = dptr[rr][j * 8];
                     if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
-                        for (int q = 0; q < NG; ++q) n_g[q][j][r] = gptr[r][q * H + j * 16];
-                        n_c[j][r] = n_cn[j][r];
-                        n_cn[j][r] = (s + 2 < T) ? cptr[r][cst_[r] + j * 16] : 0.f;
+                        for (int q = 0; q < NG; ++q) n_g[q][j][rr] = gptr[rr][(q * H + j * 16) / 2];
+                        n_c[j][rr] = n_cn[j][rr];
+                        n_cn[j][rr] = (s + 2 < T) ? cptr[rr][cst_[rr] + j * 8] : 0u;
                     } else {
-                        n_g[0][j][r] = optr[r][j * 16];
+                        n_g[0][j][rr] = optr[rr][j * 8];
                     }
                 }
         }
@@ -1266,24 +1294,25 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     dhr[j][r] = v;
                 }
         }
-        // ---- d(pre-activation) of this step to HBM (never waited on)
+        // ---- d(pre-activation) of this step to HBM as packed bf16 pairs (never waited on)
 #pragma unroll
         for (int j = 0; j < UTP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                for (int q = 0; q < G; ++q) gprev[r][q * H + j * 16] = sv_z[q][j][r];
+                for (int q = 0; q < G; ++q) gprev[rr][(q * H + j * 16) / 2] = sv_z[q][j][rr];
         cur ^= 1;
     }
-    // bias gradient partials of this (tile, direction): sum the four row groups of the wave, one owner lane per column
+    // bias gradient partials of this (tile, direction): sum the rows held by the lane pair and by the four row groups
 #pragma unroll
     for (int q = 0; q < G; ++q)
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
-            float v = bsum[q][j];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lane < 16) a.bpart[(size_t)cl * GH + q * H + vw * (16 * UTP) + j * 16 + c] = v;
+            float v0 = bsum[q][j][0], v1 = bsum[q][j][1];
+            v0 += swap_lane_pair(v0);     v1 += swap_lane_pair(v1);
+            v0 += __shfl_xor(v0, 16, 64); v1 += __shfl_xor(v1, 16, 64);
+            v0 += __shfl_xor(v0, 32, 64); v1 += __shfl_xor(v1, 32, 64);
+            if (lane < 16) a.bpart[(size_t)cl * GH + q * H + vw * (16 * UTP) + j * 16 + c] = odd ? v1 : v0;
         }
     if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
@@ -1629,6 +1658,10 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void*
                                   void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
+    LAS_ARG(prec != LAS_PREC_BF16 || !mfma_shape_ok(H) ||
+            (ld_out % 4 == 0 && out_bstride % 4 == 0 && ld_dout % 4 == 0 && dout_bstride % 4 == 0 &&
+             (((uintptr_t)gates | (uintptr_t)out | (uintptr_t)cstate | (uintptr_t)dout) & 15) == 0),
+            "las_rnn_seq_bwd: bf16 tensors must be 16-byte aligned with pitches that are multiples of 4");
     hipStream_t st = (hipStream_t)stream;
     const int G = cell == LAS_CELL_LSTM ? 4 : 1;
     RnnArgs a;

@@ -266,7 +266,8 @@ def _as_bf16_operand(x):
     K = x.shape[-1]
     if K % 64:
         x = torch.nn.functional.pad(x, (0, _k64(K) - K))
-    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    x = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+    return x.contiguous()                                   # (.to() keeps the strides of a transposed view)
 
 
 class _Dense16(torch.autograd.Function):
@@ -394,10 +395,12 @@ class _BLSTM16(torch.autograd.Function):
                 _hip.gemm_kk(gates, Wd, dxd, B * T, Ik, GH, 2 * GH, GH, Ik, a_off=d * GH)
         _hip.run_deferred()
         Ig = (I0 + 3) // 4 * 4          # rows of dW_ih the TN product writes; rows I0..Ig meet zero operand columns (exact zeros)
-        part = torch.empty(B, H, GH, device=dev) if T > 1 else None
 
         def wgrads(gk_of, d):
             # dW_ih = x^T . dG_d (contraction over all B*T frames; split-K inside las_gemm); dW_hh = sum_b sum_t h_prev^T . dG_d
+            # (`part` is allocated HERE, i.e. on the stream that uses it: a block of the main stream's pool handed to the
+            #  side stream would be recycled by the allocator while the side stream still writes it)
+            part = torch.empty(B, H, GH, device=dev) if T > 1 else None
             gk = gk_of(d)
             _hip.gemm(prec, xs[d], gates, gk, True, False, Ig, GH, B * T, Ik, 2 * GH, GH, beta=1.0, b_off=d * GH)
             if T > 1:

@@ -9,12 +9,13 @@ def run(cell, B=48, T=1274, H=256, prec=1, reps=3):
     G = 4 if cell else 1
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
-    xp = (torch.randn(B, T, 2, G * H, generator=g) * 0.5).to(dev)
+    io = _hip.rnn_seq_io_dtype(cell, prec, H)
+    xp = (torch.randn(B, T, 2, G * H, generator=g) * 0.5).to(dev).to(io)
     w0 = (torch.randn(H, G * H, generator=g) * 0.05).to(dev)
     w1 = (torch.randn(H, G * H, generator=g) * 0.05).to(dev)
-    out = torch.zeros(B, T, 2 * H, device=dev)
-    cst = torch.zeros(B, T, 2, H, device=dev) if cell else None
-    dout = torch.randn(B, T, 2 * H, generator=g).to(dev)
+    out = torch.zeros(B, T, 2 * H, device=dev, dtype=io)
+    cst = torch.zeros(B, T, 2, H, device=dev, dtype=io) if cell else None
+    dout = torch.randn(B, T, 2 * H, generator=g).to(dev).to(io)
     res = {}
     for name in ("fwd", "bwd"):
         ts = []
