@@ -33,6 +33,7 @@ struct DecDev {
     int *tok_in, *tok_out;
     const float* align0;
     const float* emb_mask;
+    const float* emb_noise;   // [U,V,E] variational noise added to the embedding matrix at the look-up of step t (las/las.py:164-166), or null
     float *logits, *alphas, *hs, *cs, *gates, *xin0;
     unsigned short* xbf;   // [B,I0D]  bf16 copy of the current step's cell input row (A operand of the skinny product)
     unsigned short* dgbf;  // [B,G*D]  bf16 copy of the current step's layer-0 gate gradient
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
     }
     unsigned short* xb = a.xbf ? a.xbf + (size_t)b * I0D : nullptr;
     for (int i = tid; i < E; i += RNT) {
-        const float v = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+        const float v = (a.emb[(size_t)tok * E + i] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + i] : 0.f)) *
+                        (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
         xrow[i] = v;
         if (xb) xb[i] = f2bf(v);
     }
@@ -593,7 +595,8 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
         }
     }
     for (int i = tid; i < E; i += RNT) {
-        const float v = a.emb[(size_t)tok * E + i] * (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+        const float v = (a.emb[(size_t)tok * E + i] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + i] : 0.f)) *
+                        (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
         xrow[i] = v;
         xb[i] = f2bf(v);
     }
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     }
     // consumed at the very end
     const int ec = tid < E ? tid : E - 1;
-    const float embv = a.emb[(size_t)tok * E + ec];
+    const float embv = a.emb[(size_t)tok * E + ec] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + ec] : 0.f);
     const float maskv = a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + ec] : 1.f;
 
     {   // query projection q = s . Ws : 4 columns x 2 state rows per dot2, 8 prefetched fragments per thread
@@ -1660,7 +1663,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.step_logits = f->step_logits; d.flags = f->flags; d.fb = f->forget_bias; d.seed = f->seed;
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
-    d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.logits = f->logits; d.alphas = f->alphas;
+    d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;

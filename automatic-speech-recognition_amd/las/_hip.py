@@ -31,7 +31,7 @@ class SpellerFwdArgs(Structure):
         ("loc_w", c_void_p), ("loc_b", c_void_p), ("Wf", c_void_p),
         ("cellW", POINTER(c_void_p)), ("cellb", POINTER(c_void_p)),
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
-        ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p),
+        ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
         ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p),
         ("ws", c_void_p), ("ws_bytes", c_size_t)]
 

@@ -79,7 +79,7 @@ def _ptr_array(tensors):
 
 
 def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
-                   keep_state0=False, align0=None, emb_mask=None):
+                   keep_state0=False, align0=None, emb_mask=None, emb_noise=None):
     for k, v in dims.items():
         setattr(fa, k, v)
     fa.step_logits = int(step_logits)
@@ -101,6 +101,7 @@ def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, b
     fa.logits, fa.alphas = bufs["logits"].data_ptr(), bufs["alphas"].data_ptr()
     fa.align0 = align0.data_ptr() if align0 is not None else None
     fa.emb_mask = emb_mask.data_ptr() if emb_mask is not None else None
+    fa.emb_noise = emb_noise.data_ptr() if emb_noise is not None else None
     fa.hs = bufs["hs"].data_ptr()
     fa.cs = bufs["cs"].data_ptr() if bufs["cs"] is not None else None
     fa.gates, fa.xin0 = bufs["gates"].data_ptr(), bufs["xin0"].data_ptr()
@@ -124,7 +125,7 @@ class _SpellerLoop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, Wh, Ws, u, emb, Wv, bv, loc_w, loc_b, Wf, cfg, enc_len_i32, tokens_in, *cell_params):
-        dims, prec, step_logits, seed, emb_mask = cfg
+        dims, prec, step_logits, seed, emb_mask, emb_noise = cfg
         dev = enc.device
         enc = enc.contiguous()
         B, Tp, Hd = enc.shape
@@ -138,21 +139,21 @@ class _SpellerLoop(torch.autograd.Function):
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
         keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
-                              emb_mask=emb_mask)
+                              emb_mask=emb_mask, emb_noise=emb_noise)
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], dims["V"], dims["U"], dims["cell"])
         ws = _hip.workspace(dev, nbytes, "speller")
         fa.ws, fa.ws_bytes = ws.data_ptr(), ws.numel()
         with _hip._timed("speller_fwd[U=%d]" % dims["U"]):
             _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
         del keep
-        ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask)
+        ctx.saved = (enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask, emb_noise)
         ctx.mark_non_differentiable(bufs["alphas"])
         ctx.tokens_out = tokens_out
         return bufs["logits"], bufs["alphas"]
 
     @staticmethod
     def backward(ctx, dlogits, _dalphas):
-        enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask = ctx.saved
+        enc, keys, Wh, P, bufs, enc_len_i32, tokens_in, tokens_out, dims, prec, step_logits, seed, emb_mask, emb_noise = ctx.saved
         dev = enc.device
         B, Tp, Hd = enc.shape
         A = Wh.shape[1]
@@ -180,7 +181,7 @@ class _SpellerLoop(torch.autograd.Function):
         ws = _hip.workspace(dev, nbytes, "speller")
         ba = _hip.SpellerBwdArgs()
         keepf = _fill_fwd_args(ba.f, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
-                               emb_mask=emb_mask)
+                               emb_mask=emb_mask, emb_noise=emb_noise)
         ba.f.ws, ba.f.ws_bytes = ws.data_ptr(), ws.numel()
         ba.dlogits = dlogits.data_ptr()
         ba.d_enc, ba.d_keys = d_enc.data_ptr(), d_keys.data_ptr()
@@ -198,7 +199,7 @@ class _SpellerLoop(torch.autograd.Function):
             main_done = torch.cuda.Event()
             main_done.record()
             held = [enc, keys, dlogits, d_keys, ws, tokens_in, zbuf] + [v for v in bufs.values() if v is not None] + \
-                   ([emb_mask] if emb_mask is not None else [])
+                   ([emb_mask] if emb_mask is not None else []) + ([emb_noise] if emb_noise is not None else [])
 
             def side_part(ba=ba, keep=(keep, keepf), held=held):
                 # runs after the next backward node has enqueued its chain kernels (_hip.run_deferred)
@@ -329,8 +330,15 @@ class Speller:
             keep = 1.0 - float(a.dropout_rate)
             emb_mask = (torch.rand(U, B, a.embedding_size, device=dev) < keep).to(torch.float32) / keep
             emb_mask[0] = 1.0
+        emb_noise = None
+        if a.add_vn:
+            # variational noise (las/las.py:164-166): `_look_up` adds a fresh N(0, 0.075) draw to the whole embedding matrix
+            # on EVERY call -- training and inference alike (the reference does not test is_training there):
+            # one [V,E] noise matrix per decode step (step 0 = the SOS look-up of las/las.py:81)
+            emb_noise = self.vn_noise if getattr(self, "vn_noise", None) is not None else \
+                torch.randn(U, a.vocab_size, a.embedding_size, device=dev) * 0.075
         return {"B": B, "U": U, "enc_len_i32": enc_len_i32, "tokens_in": tokens_in, "step_logits": step_logits,
-                "emb_mask": emb_mask}
+                "emb_mask": emb_mask, "emb_noise": emb_noise}
 
     def __call__(self, enc_out, enc_len, dec_steps, teacher=None, is_training=True, coins=None, sampled=None, prepared=None):
         """reference las/las.py:72-143.  Returns (logits [B,U,V], ctc_logits, alphas [B,U,T']).
@@ -341,8 +349,6 @@ class Speller:
         _hip.require_gpu(enc_out)
         if a.ctc:
             raise NotImplementedError("CTC head (las/las.py:75-77,335-349): README 'not yet fully tested', out of scope (SURVEY T5)")
-        if a.add_vn:
-            raise NotImplementedError("variational noise (las/las.py:164-166) is not built yet")
         dev = enc_out.device
         B, Tp, _ = enc_out.shape
         U = int(dec_steps)
@@ -353,7 +359,8 @@ class Speller:
         enc_len_i32, tokens_in = prepared["enc_len_i32"], prepared["tokens_in"]
         step_logits, emb_mask = prepared["step_logits"], prepared["emb_mask"]
         P = self._params()
-        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, sampling_seed(st.global_step, self.rank), emb_mask)
+        cfg = (self._dims(B, Tp, U), L._prec(), step_logits, sampling_seed(st.global_step, self.rank), emb_mask,
+               prepared.get("emb_noise"))
         cp = list(P["cellW"]) + list(P["cellb"])
         logits_tm, alphas_tm = _SpellerLoop.apply(enc_out, P["Wh"], P["Ws"], P["u"], P["emb"], P["Wv"], P["bv"],
                                                   P.get("loc_w"), P.get("loc_b"), P.get("Wf"), cfg, enc_len_i32,
@@ -370,8 +377,11 @@ class Speller:
         return _decode_step(self, enc_out, enc_len, dec_state, prev_token, prev_align, keys, token_ids)
 
     def _look_up(self, token):
-        """las/las.py:162-168 (add_vn unsupported)."""
-        return self.embedding_matrix.detach()[torch.as_tensor(token).long()]
+        """las/las.py:162-168 (host-side convenience; the decode loop looks tokens up inside the row kernels)."""
+        m = self.embedding_matrix.detach()
+        if self.args.add_vn:
+            m = m + torch.randn_like(m) * 0.075
+        return m[torch.as_tensor(token).long()]
 
     def _get_hidden_state(self, dec_state):
         """las/las.py:185-189: concat of the layers' states (h only for the lstm variant)."""

@@ -193,6 +193,9 @@ typedef struct {
     const float* align0;           /* optional [B,Tp]: previous alignment entering step 0 (else zeros) */
     const float* emb_mask;         /* optional [U,B,E]: inverted-dropout mask on the embedded input token
                                       (tf.layers.dropout, las/las.py:107-108), already scaled by 1/keep */
+    const float* emb_noise;        /* optional [U,V,E]: variational noise (--add_vn): the reference adds a fresh N(0, 0.075)
+                                      draw to the WHOLE embedding matrix at every look-up (las/las.py:164-166), i.e. one
+                                      [V,E] noise matrix per decode step, shared by the rows that look up the same token */
     float *hs, *cs, *gates, *xin0;
     void* ws; size_t ws_bytes;
 } las_speller_fwd_args;

@@ -134,3 +134,50 @@ def test_on_device_sampling_step_matches_oracle_given_the_draws(prec, NL, flags)
             assert e < tg, (n, e)
     finally:
         _hip.speller_flags = 0
+
+
+@pytest.mark.parametrize("prec,flags", [("f32", 0), ("bf16", 0), ("bf16", 1)])
+def test_variational_noise_on_the_embedding_matrix(prec, flags):
+    """--add_vn (reference las/las.py:164-166): every look-up adds a fresh N(0, 0.075) matrix to the WHOLE embedding matrix.
+    With the noise matrices injected on both sides the Speller must match the oracle; without injection two calls differ."""
+    from las import _hip, variables as Vs
+    from oracle import las_oracle as O
+    B, Tp, U, V = 4, 23, 6, 30
+    sp, args = _speller(prec, D=64, A=32, H=32, NL=1, V=V, flags=flags)
+    args.add_vn = True
+    try:
+        st = Vs.default_store()
+        rng = np.random.RandomState(4)
+        enc_np = (rng.randn(B, Tp, 64) * 0.5).astype(np.float32)
+        enc_len = rng.randint(Tp // 2, Tp + 1, size=B)
+        y = rng.randint(3, V, size=(B, U))
+        y[1] = y[0]                                                  # two rows looking up the same tokens share the noise
+        noise = (rng.randn(U, V, 32) * 0.075).astype(np.float32)
+        sp.vn_noise = torch.tensor(noise, device="cuda")
+        enc = torch.tensor(enc_np, device="cuda", requires_grad=True)
+        w = torch.tensor(rng.randn(B, U, V).astype(np.float32))
+        logits, _, alphas = sp(enc, enc_len, U, teacher=y, is_training=True)
+        (logits * w.cuda()).sum().backward()
+        _hip.join_side_stream()
+        torch.cuda.synchronize()
+        p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
+        O.set_precision("bf16" if prec == "bf16" else "f32", "bf")
+        try:
+            po = O.to_torch(p0, requires_grad=True)
+            lo, ao = O.speller_forward(torch.tensor(enc_np), enc_len.astype(np.float64), U, po, args, "lstm", teacher=torch.tensor(y),
+                                       is_training=True, emb_noise=torch.tensor(noise))
+            (lo * w).sum().backward()
+        finally:
+            O.set_precision("f32")
+        tl, tg = (2e-4, 2e-3) if prec == "f32" else (4e-3, 2e-2)
+        assert (logits.detach().cpu() - lo.detach()).abs().max().item() < tl
+        ge = po["embedding/embedding_matrix"].grad
+        assert (st.vars["embedding/embedding_matrix"].grad.cpu() - ge).abs().max().item() / max(ge.abs().max().item(), 1e-3) < tg
+        # the noise matters, and without an injected matrix it is drawn afresh on every call
+        sp.vn_noise = None
+        with torch.no_grad():
+            l1, _, _ = sp(enc, enc_len, U, teacher=y, is_training=True)
+            l2, _, _ = sp(enc, enc_len, U, teacher=y, is_training=True)
+        assert (l1 - l2).abs().max().item() > 1e-4 and (l1 - logits.detach()).abs().max().item() > 1e-4
+    finally:
+        _hip.speller_flags = 0
