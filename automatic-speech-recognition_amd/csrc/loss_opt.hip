@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     const int b = (int)(row / U), t = (int)(row % U);
     const float* lp = logits + b * sb + t * st;
     const int label = y[(long long)b * ldy + t];
-    const float mask = label != 0 ? 1.f : 0.f;
+    const float mask = (label != 0 || (smooth & 2)) ? 1.f : 0.f;     // bit 1 of `smooth`: every position counts (RNNLM loss)
     float m = -INFINITY, lsum = 0.f;
     for (int k = lane; k < V; k += 64) { const float l = lp[k]; m = fmaxf(m, l); lsum += l; }
     m = wave_max(m);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     for (int k = lane; k < V; k += 64) se += expf(lp[k] - m);
     se = wave_sum(se);
     const float lse = m + logf(se);
-    const float e = smooth ? eps : 0.f;
+    const float e = (smooth & 1) ? eps : 0.f;
     const float ly = (label >= 0 && label < V) ? lp[label] : 0.f;
     const float ce = lse - (1.f - e) * ly - (e / V) * lsum;
     if (lane == 0) { row_ce[row] = ce * mask; row_mask[row] = mask; }
@@ -198,6 +198,43 @@ extern "C" int las_lstm_pointwise(const float* z, const float* c_prev, int N, in
     int nb = cdiv((long long)N * H, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, c_prev, N, H, forget_bias, c_out, h_out);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+
+// gradient of the BasicLSTMCell gate math (R1 training, reference lang/char_rnn_model.py:54-66,177-190):
+//   given z (pre-activations [N,4H], i,j,f,o), c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c' arriving from step t+1):
+//   dz [N,4H] and dc_prev [N,H].   (dc_in may be NULL = zeros.)
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(const float* __restrict__ z, const float* __restrict__ c_prev,
+                                                                 const float* __restrict__ dh, const float* __restrict__ dc_in, int N, int H,
+                                                                 float fb, float* __restrict__ dz, float* __restrict__ dc_prev) {
+    const long long total = (long long)N * H;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long n = idx / H;
+        const int u = (int)(idx % H);
+        const float* zr = z + n * 4 * H;
+        float* dzr = dz + n * 4 * H;
+        const float gi = sigmoid_acc(zr[u]), gj = tanh_acc(zr[H + u]), gf = sigmoid_acc(zr[2 * H + u] + fb), go = sigmoid_acc(zr[3 * H + u]);
+        const float cp = c_prev[idx];
+        const float c = cp * gf + gi * gj;
+        const float tc = tanh_acc(c);
+        const float g = dh[idx];
+        const float dc = (dc_in ? dc_in[idx] : 0.f) + g * go * (1.f - tc * tc);
+        dzr[u] = dc * gj * gi * (1.f - gi);
+        dzr[H + u] = dc * gi * (1.f - gj * gj);
+        dzr[2 * H + u] = dc * cp * gf * (1.f - gf);
+        dzr[3 * H + u] = g * tc * go * (1.f - go);
+        dc_prev[idx] = dc * gf;
+    }
+}
+
+extern "C" int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const float* dh, const float* dc_in, int N, int H,
+                                      float forget_bias, float* dz, float* dc_prev, void* stream) {
+    LAS_ARG(z && c_prev && dh && dz && dc_prev && N > 0 && H > 0, "las_lstm_pointwise_bwd: bad arguments");
+    int nb = cdiv((long long)N * H, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, c_prev, dh, dc_in, N, H, forget_bias, dz, dc_prev);
     LAS_LAUNCHED();
     return 0;
 }

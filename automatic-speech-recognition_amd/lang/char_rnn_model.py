@@ -1,10 +1,17 @@
-"""lang.char_rnn_model -- inference side of the char RNNLM (reference lang/char_rnn_model.py:11-142) used for
-shallow fusion in beam search (reference las/beam_search.py:109-116,226-236; decode.py:27-39).
+"""lang.char_rnn_model -- the char RNNLM (reference lang/char_rnn_model.py) on the MI355X engine.
 
-Only what decoding needs is built: embedding (or one-hot) -> L x BasicLSTMCell(forget_bias=0) ->
-`logits = out . softmax_w + softmax_b`, one unrolling at a time for N hypotheses.  Contractions run through
-las_gemm, gate math through las_lstm_pointwise (liblas_hip.so).  Training the LM (`run_epoch`, reference
-lang/char_rnn_model.py:195-244, train_lm.py) is SURVEY 8(f) row F4."""
+Inference (`step`, `step_tensors`): embedding (or one-hot) -> L x BasicLSTMCell(forget_bias=0) -> `logits = out . softmax_w +
+softmax_b`, one unrolling at a time for N hypotheses -- what shallow fusion in beam search needs (reference
+las/beam_search.py:109-116,226-236; decode.py:27-39).
+Training (`is_training=True`: `train_step`, `run_epoch`; reference lang/char_rnn_model.py:54-193 graph, :195-244 loop):
+truncated BPTT over `num_unrollings` steps with the state carried from batch to batch, mean sparse cross entropy,
+clip_by_global_norm + Adam (TF epsilon-hat form).  Contractions run through las_gemm, gate math through
+las_lstm_pointwise / las_lstm_pointwise_bwd, the loss through las_ce_loss, the update through las_sumsq + las_clip_adam
+(liblas_hip.so); the LM keeps its own VariableStore (flat parameter / gradient / Adam buckets)."""
+import logging
+import math
+import time
+
 import numpy as np
 import torch
 
@@ -24,15 +31,20 @@ class CharRNN(object):
     def __init__(self, is_training, batch_size, num_unrollings, vocab_size, hidden_size, max_grad_norm=5.0,
                  embedding_size=0, num_layers=2, learning_rate=0.0, model='lstm', dropout=0.0, input_dropout=0.0,
                  use_batch=True, scope="lm", store=None):
-        if is_training:
-            raise NotImplementedError("RNNLM training (reference train_lm.py) is SURVEY 8(f) row F4")
         if model != 'lstm':
-            raise NotImplementedError("the shipped LM configuration is model='lstm' (reference decode.py:27-39)")
+            raise NotImplementedError("the shipped LM configuration is model='lstm' (reference decode.py:27-39, train_lm.py default)")
+        self.is_training = bool(is_training)
+        self.batch_size, self.num_unrollings = (batch_size, num_unrollings) if use_batch else (1, 1)     # :17-21
         self.vocab_size, self.hidden_size = vocab_size, hidden_size
         self.embedding_size, self.num_layers = embedding_size, num_layers
         self.input_size = embedding_size if embedding_size > 0 else vocab_size     # char_rnn_model.py:30-35
+        self.max_grad_norm, self.learning_rate = float(max_grad_norm), float(learning_rate)
+        self.dropout = float(dropout)
+        self.input_dropout = float(input_dropout) if embedding_size > 0 else 0.0    # no dropout on the one-hot representation (:33)
         self.scope = scope
         self.store = store or V.default_store()
+        self.global_step = 0
+        self._sum_mean_loss, self._count = 0.0, 0.0                                # the reference's loss monitor (:151-166)
 
     # -- variables (TF names of the reference graph under the given scope) -----------------------------
     def params(self):
@@ -47,6 +59,155 @@ class CharRNN(object):
         p["softmax_w"] = st.get(sc + "/softmax/softmax_w", (H, self.vocab_size))
         p["softmax_b"] = st.get(sc + "/softmax/softmax_b", (self.vocab_size,), init="zeros")
         return p
+
+    # -- training ------------------------------------------------------------------------------------------
+    def train_step(self, inputs, targets, state=None, train=True):
+        """One batch of `num_unrollings` steps (reference graph :110-190): inputs / targets int [B,U].  state: list over layers
+        of (c,h) [B,H] carried from the previous batch (None = zeros).  train=False evaluates only (no update).
+        Returns (mean_loss float tensor, new_state)."""
+        P = self.params()
+        st = self.store
+        dev = P["softmax_w"].device
+        if train:
+            st.flatten()
+            st.zero_grad()
+        prec = L._prec()
+        lib = _hip.lib()
+        ids = torch.as_tensor(np.asarray(inputs), device=dev).long()
+        tgt = torch.as_tensor(np.asarray(targets), device=dev).to(torch.int32).contiguous()
+        B, U = ids.shape
+        H, NL, Vn = self.hidden_size, self.num_layers, self.vocab_size
+        if state is None:
+            state = [(torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)) for _ in range(NL)]
+        with torch.no_grad():
+            if self.embedding_size > 0:
+                x_all = P["embedding"].detach()[ids]                                  # [B,U,E]
+            else:
+                x_all = torch.nn.functional.one_hot(ids, Vn).to(torch.float32)
+            in_mask = None
+            if train and self.input_dropout > 0:
+                keep = 1.0 - self.input_dropout
+                in_mask = (torch.rand_like(x_all) < keep).float() / keep
+                x_all = x_all * in_mask
+            Is = [self.input_size] + [H] * (NL - 1)
+            xin = [torch.empty(U, B, Is[l] + H, device=dev) for l in range(NL)]      # saved [x ; h_prev] rows
+            zs = [torch.empty(U, B, 4 * H, device=dev) for l in range(NL)]           # saved pre-activations
+            cps = [torch.empty(U, B, H, device=dev) for l in range(NL)]              # saved c_{t-1}
+            masks = [None] * NL
+            if train and self.dropout > 0:                                            # DropoutWrapper(output_keep_prob) (:81-85)
+                keep = 1.0 - self.dropout
+                masks = [(torch.rand(U, B, H, device=dev) < keep).float() / keep for _ in range(NL)]
+            top = torch.empty(B, U, H, device=dev)                                    # batch-major, as tf.concat(axis=1) flattens (:127-129)
+            c = [s_[0].contiguous() for s_ in state]
+            h = [s_[1].contiguous() for s_ in state]
+            for t in range(U):
+                x = x_all[:, t]
+                for l, (k, b) in enumerate(P["cells"]):
+                    xi = xin[l][t]
+                    xi[:, :Is[l]] = x
+                    xi[:, Is[l]:] = h[l]
+                    cps[l][t] = c[l]
+                    _hip.gemm(prec, xi, k.detach(), zs[l][t], False, False, B, 4 * H, Is[l] + H, Is[l] + H, 4 * H, 4 * H, bias=b.detach())
+                    c_new, h_new = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+                    _hip.check(lib.las_lstm_pointwise(_hip.p(zs[l][t]), _hip.p(cps[l][t]), B, H, 0.0, _hip.p(c_new), _hip.p(h_new),
+                                                      _hip.stream()), "las_lstm_pointwise")
+                    c[l], h[l] = c_new, h_new
+                    x = h_new if masks[l] is None else h_new * masks[l][t]
+                top[:, t] = x
+            flat = top.view(B * U, H)
+            logits = torch.empty(B, U, Vn, device=dev)
+            _hip.gemm(prec, flat, P["softmax_w"].detach(), logits, False, False, B * U, Vn, H, H, Vn, Vn, bias=P["softmax_b"].detach())
+            # mean sparse cross entropy over all B*U positions (:146-149) + its gradient
+            sums = torch.zeros(2, device=dev)
+            scale = torch.full((1,), 1.0 / (B * U), device=dev)
+            dlog = torch.empty_like(logits) if train else None
+            ws = _hip.workspace(dev, lib.las_ce_loss_workspace_bytes(B, U), "ce")
+            _hip.check(lib.las_ce_loss(_hip.p(logits), U * Vn, Vn, _hip.p(tgt), U, B, U, Vn, 0.0, 2, _hip.p(sums), _hip.p(scale),
+                                       _hip.p(dlog), _hip.p(ws), ws.numel(), _hip.stream()), "las_ce_loss")
+            mean_loss = sums[0] * scale[0]
+            new_state = [(c[l], h[l]) for l in range(NL)]
+            if not train:
+                return mean_loss, new_state
+            # ---- backward
+            g = {n: v.grad for n, v in st.vars.items()}
+            sc = self.scope
+            dl2 = dlog.view(B * U, Vn)
+            _hip.gemm(prec, flat, dl2, g[sc + "/softmax/softmax_w"], True, False, H, Vn, B * U, H, Vn, Vn, beta=1.0)
+            _hip.colsum(dl2, B * U, Vn, Vn, g[sc + "/softmax/softmax_b"], beta=1.0)
+            dtop = torch.empty(B, U, H, device=dev)
+            _hip.gemm(prec, dl2, P["softmax_w"].detach(), dtop.view(B * U, H), False, True, B * U, H, Vn, Vn, Vn, H)
+            dzs = [torch.empty(U, B, 4 * H, device=dev) for l in range(NL)]
+            dh_next = [torch.zeros(B, H, device=dev) for _ in range(NL)]
+            dc_next = [None] * NL
+            dx_all = torch.empty(U, B, self.input_size, device=dev) if self.embedding_size > 0 else None
+            for t in range(U - 1, -1, -1):
+                dabove = dtop[:, t].contiguous()
+                for l in range(NL - 1, -1, -1):
+                    k = P["cells"][l][0].detach()
+                    dh = (dabove if masks[l] is None else dabove * masks[l][t]) + dh_next[l]
+                    dcp = torch.empty(B, H, device=dev)
+                    _hip.check(lib.las_lstm_pointwise_bwd(_hip.p(zs[l][t]), _hip.p(cps[l][t]), _hip.p(dh), _hip.p(dc_next[l]), B, H, 0.0,
+                                                          _hip.p(dzs[l][t]), _hip.p(dcp), _hip.stream()), "las_lstm_pointwise_bwd")
+                    dc_next[l] = dcp
+                    dxi = torch.empty(B, Is[l] + H, device=dev)
+                    _hip.gemm(prec, dzs[l][t], k, dxi, False, True, B, Is[l] + H, 4 * H, 4 * H, 4 * H, Is[l] + H)
+                    dh_next[l] = dxi[:, Is[l]:].contiguous()
+                    dabove = dxi[:, :Is[l]].contiguous()
+                if dx_all is not None:
+                    dx_all[t] = dabove if in_mask is None else dabove * in_mask[:, t]
+            for l in range(NL):
+                base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (sc, l)
+                K = Is[l] + H
+                _hip.gemm(prec, xin[l].view(U * B, K), dzs[l].view(U * B, 4 * H), g[base + "kernel"], True, False, K, 4 * H, U * B, K, 4 * H,
+                          4 * H, beta=1.0)
+                _hip.colsum(dzs[l].view(U * B, 4 * H), U * B, 4 * H, 4 * H, g[base + "bias"], beta=1.0)
+            if dx_all is not None:
+                g[sc + "/embedding"].index_add_(0, ids.t().reshape(-1), dx_all.view(U * B, -1))
+            # ---- clip_by_global_norm + Adam (:177-190)
+            t_ = self.global_step + 1
+            b1, b2, eps = 0.9, 0.999, 1e-8
+            lr_t = self.learning_rate * math.sqrt(1.0 - b2 ** t_) / (1.0 - b1 ** t_)
+            n = st.flat.numel()
+            sumsq = torch.empty(1, device=dev)
+            wss = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
+            _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(wss), wss.numel(), _hip.stream()), "las_sumsq")
+            _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n, _hip.p(sumsq),
+                                         self.max_grad_norm, lr_t, b1, b2, eps, _hip.stream()), "las_clip_adam")
+            st.shadows.clear()
+            self.global_step += 1
+        return mean_loss, new_state
+
+    def run_epoch(self, session, data_size, batch_generator, is_training, verbose=0, freq=10, summary_writer=None, debug=False,
+                  divide_by_n=1):
+        """One full pass over the data (reference lang/char_rnn_model.py:195-244).  Returns (ppl, summary, global_step)."""
+        epoch_size = data_size // (self.batch_size * self.num_unrollings)
+        if data_size % (self.batch_size * self.num_unrollings) != 0:
+            epoch_size += 1
+        if verbose > 0:
+            logging.info('epoch_size: %d', epoch_size)
+            logging.info('data_size: %d', data_size)
+            logging.info('num_unrollings: %d', self.num_unrollings)
+            logging.info('batch_size: %d', self.batch_size)
+        state = None
+        self._sum_mean_loss, self._count = 0.0, 0.0                 # reset_loss_monitor
+        start_time = time.time()
+        ppl, step = float("nan"), -1
+        for step in range(epoch_size // divide_by_n):
+            data = batch_generator.next()                           # [:-1] are the inputs, [1:] the targets
+            inputs = np.array(data[:-1]).transpose()
+            targets = np.array(data[1:]).transpose()
+            mean_loss, state = self.train_step(inputs, targets, state, train=is_training)
+            self._sum_mean_loss += float(mean_loss)
+            self._count += 1
+            average_loss = self._sum_mean_loss / self._count
+            ppl = np.exp(average_loss)
+            if (verbose > 0) and ((step + 1) % freq == 0):
+                logging.info("%.1f%%, step:%d, perplexity: %.3f, speed: %.0f words",
+                             (step + 1) * 1.0 / epoch_size * 100, step, ppl,
+                             (step + 1) * self.batch_size * self.num_unrollings / (time.time() - start_time))
+        logging.info("Perplexity: %.3f, speed: %.0f words per sec",
+                     ppl, (step + 1) * self.batch_size * self.num_unrollings / (time.time() - start_time))
+        return ppl, None, self.global_step
 
     def zero_state(self, n=1):
         dev = self.store.device
@@ -93,3 +254,57 @@ class CharRNN(object):
         logits, cs, hs = self.step_tensors(ids, c_prev, h_prev)
         out_states = [tuple((cs[l][i], hs[l][i]) for l in range(self.num_layers)) for i in range(ids.shape[0])]
         return logits, out_states
+
+
+class BatchGenerator(object):
+    """Generate and hold batches (reference lang/char_rnn_model.py:285-321): `batch_size` cursors spread evenly over the
+    text; next() returns the last batch of the previous call followed by `n_unrollings` new ones."""
+
+    def __init__(self, text, batch_size, n_unrollings, vocab_size, vocab_index_dict, index_vocab_dict):
+        self._text = text
+        self._text_size = len(text)
+        self._batch_size = batch_size
+        self.vocab_size = vocab_size
+        self._n_unrollings = n_unrollings
+        self.vocab_index_dict = vocab_index_dict
+        self.index_vocab_dict = index_vocab_dict
+        segment = self._text_size // batch_size
+        self._cursor = [offset * segment for offset in range(batch_size)]
+        self._last_batch = self._next_batch()
+
+    def _next_batch(self):
+        batch = np.zeros(shape=(self._batch_size), dtype=np.float64)
+        for b in range(self._batch_size):
+            batch[b] = char2id(self._text[self._cursor[b]], self.vocab_index_dict)
+            self._cursor[b] = (self._cursor[b] + 1) % self._text_size
+        return batch
+
+    def next(self):
+        batches = [self._last_batch]
+        for step in range(self._n_unrollings):
+            batches.append(self._next_batch())
+        self._last_batch = batches[-1]
+        return batches
+
+
+def char2id(char, vocab_index_dict):
+    try:
+        return vocab_index_dict[char]
+    except KeyError:
+        logging.info('Unexpected char %s', char)
+        return 0
+
+
+def id2char(index, index_vocab_dict):
+    return index_vocab_dict[index]
+
+
+def id2char_list(lst, index_vocab_dict):
+    return [id2char(i, index_vocab_dict) for i in lst]
+
+
+def batches2string(batches, index_vocab_dict):
+    s = [''] * batches[0].shape[0]
+    for b in batches:
+        s = [''.join(x) for x in zip(s, id2char_list(b, index_vocab_dict))]
+    return s

@@ -90,6 +90,7 @@ _SIGS = {
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
                               c_float, c_float, c_float, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_beam_loop_step": (c_int, [POINTER(BeamLoopArgs), c_void_p]),

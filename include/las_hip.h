@@ -226,7 +226,8 @@ int las_speller_bwd_part(const las_speller_bwd_args* a, int part, void* stream);
  * K8  LAS._get_loss (las/las.py:320-333) + label_smoothing (las/utils.py:5-12), forward and
  * gradient in one pass.  logits element (b,t,v) at logits[b*sb + t*st + v] (so the Speller's
  * time-major [U,B,V] buffer is consumed in place: sb=V, st=B*V); dlogits uses the same strides.
- * y int32 [B,ldy] (first U columns used).
+ * y int32 [B,ldy] (first U columns used).  `smooth`: bit 0 = label smoothing with `epsilon`; bit 1 = no PAD mask, every
+ * position counts (the RNNLM's mean sparse cross entropy, lang/char_rnn_model.py:146-149).
  * sums[0] += sum(ce*mask), sums[1] += sum(mask)   (caller zeroes sums; the division
  * sum/(n+1e-9) is the caller's so that data-parallel ranks can all-reduce both terms first).
  * dlogits = scale_ptr[0] * mask * (softmax - smoothed_onehot)    (scale = 1/(n_total+1e-9), a
@@ -258,6 +259,10 @@ int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
  */
 int las_lstm_pointwise(const float* z, const float* c_prev, int N, int H, float forget_bias,
                        float* c_out, float* h_out, void* stream);
+/* ... and its gradient, for training the RNNLM (lang/char_rnn_model.py:177-190, truncated BPTT over num_unrollings steps):
+ * dz [N,4H] and dc_prev [N,H] from z, c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c', may be NULL). */
+int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const float* dh, const float* dc_in, int N, int H,
+                           float forget_bias, float* dz, float* dc_prev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K10  one pruning step of BeamSearch.decode (las/beam_search.py:119-152, :297-312) for `nutt`

@@ -173,6 +173,27 @@ def main():
                              "n_att": len(b.att)} for b in res]})
     out["G6"] = g6
 
+    # ---- G7: char RNNLM host pieces (lang/char_rnn_model.py BatchGenerator, train_lm.py text_cleaning / create_vocab)
+    import importlib
+    if not hasattr(np, "float"):
+        np.float = float          # numpy-1.17 alias used by the reference's BatchGenerator (requirements.txt pins numpy==1.17.4)
+    crm = importlib.import_module("lang.char_rnn_model")
+    # train_lm.py cannot be imported as a module without side effects on sys.argv only; its helpers are plain functions
+    cwd = os.getcwd()
+    import tempfile
+    os.chdir(tempfile.mkdtemp())
+    os.makedirs("data", exist_ok=True)                       # text_cleaning writes data/libri_cleaned.txt
+    tl = importlib.import_module("train_lm")
+    raw = "Hello, World!\n\nIt's 9 o'clock -- \"time\" to go?  Yes: go_now; (really)\nlast line"
+    cleaned = tl.text_cleaning(raw)
+    v2i, i2v, vs = tl.create_vocab()
+    os.chdir(cwd)
+    text = "THE QUICK BROWN FOX. JUMPS OVER THE LAZY DOG. AND RUNS AWAY"
+    gen = crm.BatchGenerator(text, 4, 3, vs, v2i, i2v)
+    batches = [[[int(x) for x in b] for b in gen.next()] for _ in range(3)]
+    out["G7"] = {"raw": raw, "cleaned": cleaned, "vocab": v2i, "text": text, "batch_size": 4, "n_unrollings": 3, "batches": batches,
+                 "strings": crm.batches2string(gen.next(), i2v)}
+
     with open(os.path.join(HERE, "reference_host_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "reference_host_golden.json"))
