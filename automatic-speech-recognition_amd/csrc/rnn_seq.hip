@@ -748,20 +748,33 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
     int cur = 0;
+#ifdef LAS_PROF
+    const bool hprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    if (hprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
+#define HSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (hprof && s >= 200 && s < 208) a.dbg[8 + (s - 200) * 8 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define HSTAMP(k)
+#endif
     for (int s = 0; s < T; ++s) {
+        HSTAMP(0);
         const float* xr = xring + (s % 3) * 16 * XP;
         float* orr = oring + (s & 1) * 16 * OP;
-        f32x4_t acc[G][UTP];                     // seeded with x.W_ih + b from the ring, then += h.W_hh
+        const unsigned short* hcur = hs + cur * 16 * LDH;
+        u16x8_t av[KS];                          // A fragments of h_{t-1} first: the MFMAs wait on nothing else
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
+        f32x4_t xv[G][UTP];                      // x.W_ih + b from the ring: read under the MFMAs, added after them
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][j][r] = xr[(g * 4 + r) * XP + q * UPM + (w * UTP + j) * 16 + c];
-        const unsigned short* hcur = hs + cur * 16 * LDH;
-        u16x8_t av[KS];
+                for (int r = 0; r < 4; ++r) xv[q][j][r] = xr[(g * 4 + r) * XP + q * UPM + (w * UTP + j) * 16 + c];
+        f32x4_t acc[G][UTP];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < UTP; ++j) acc[q][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -773,6 +786,14 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                     acc[q][j] = mfma_bf16_16x16x32(av[ks], bv, acc[q][j]);
                 }
         }
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < UTP; ++j) acc[q][j] += xv[q][j];
+#ifdef LAS_PROF
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[G - 1][UTP - 1][3]));     // MFMA results landed
+#endif
+        HSTAMP(1);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
         const unsigned slot_off = (unsigned)((s & 1) * P) * GPM * 8u;
 #pragma unroll
@@ -807,6 +828,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 granule16_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 16u, (unsigned)(s + 1),
                                 (unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
         }
+        HSTAMP(2);
         if (P > 1 && s + 1 < T) {       // gather the other members' slices of h_t into the LDS tile
             constexpr int NGT = (P > 1 ? (P - 1) * UTP : 1);
             u32x4_t xv[NGT];
@@ -844,9 +866,14 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 hnext[(row + 3) * LDH + unit] = (unsigned short)(xv[n].z >> 16);
             }
         }
+        HSTAMP(3);
         lds_barrier();
+        HSTAMP(4);
         cur ^= 1;
     }
+#ifdef LAS_PROF
+    if (hprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#endif
     if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
@@ -1154,7 +1181,15 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             }
         }
     int cur = 0;
+#ifdef LAS_PROF
+    const bool kprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    if (kprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
+#define KSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (kprof && s >= 200 && s < 208) a.dbg[8 + (s - 200) * 8 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KSTAMP(k)
+#endif
     for (int s = 0; s < T; ++s) {
+        KSTAMP(0);
         unsigned short* dzc = dzs + cur * 16 * LDZ;
         unsigned sv_z[G][UTP][2];            // d(pre-activation) of this step as packed pairs (written to HBM after the exchange)
         // ---- gate backward for the own units -> own dG slice in LDS (bf16 pairs) and in registers
@@ -1200,6 +1235,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 }
             }
         }
+        KSTAMP(1);
         gu32* gprev[2];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) { gprev[rr] = gptr[rr]; gptr[rr] += gst[rr]; optr[rr] += ost[rr]; dptr[rr] += dst[rr]; if (CELL == LAS_CELL_LSTM) cptr[rr] += cst_[rr]; }
@@ -1219,9 +1255,11 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     }
                 }
         }
+        KSTAMP(2);
         lds_barrier();
+        KSTAMP(3);
         // ---- partial dh tiles (m, w, j) for every member m:  own dG slice [16 x KP] . W_hh^T rows of those units
-        f32x4_t acc[P][UTP];
+        f32x4_t acc[P][UTP];                     // acc[mo]: partial tile of member (pm + mo) % P; acc[0] = own
 #pragma unroll
         for (int m = 0; m < P; ++m)
 #pragma unroll
@@ -1234,6 +1272,10 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
                 for (int j = 0; j < UTP; ++j) acc[m][j] = mfma_bf16_16x16x32(av, wreg[(m * UTP + j) * KSP + ks], acc[m][j]);
         }
+#ifdef LAS_PROF
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[P - 1][UTP - 1][3]));
+#endif
+        KSTAMP(4);
         if (s + 1 < T) {
             // ---- reduce-scatter: send the tiles other members own, add the ones they computed for this wave
             // byte offsets into this cluster's exchange buffer (< 2 GB): slot, [dst][src] region, (wave tile, lane) x 16 B
@@ -1244,17 +1286,11 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 const int m = (pm + mo) % P;
                 const unsigned dst_off = slot_off + (unsigned)(m * P + pm) * GPD * 8u + lane_off;
 #pragma unroll
-                for (int j = 0; j < UTP; ++j) {
-                    // acc[m] with a compile-time m: unrolled select keeps the accumulators in registers.  The four partial
-                    // sums of a lane travel as two bf16 pairs in ONE 16-byte double granule
-                    float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int mm = 0; mm < P; ++mm)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (mm == m) ? acc[mm][j][r] : v[r];
-                    granule16_store(xrs, dst_off + (unsigned)j * 1024u, (unsigned)(s + 1), f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), local);
-                }
+                for (int j = 0; j < UTP; ++j)     // the four partial sums of a lane travel as two bf16 pairs in ONE 16-byte double granule
+                    granule16_store(xrs, dst_off + (unsigned)j * 1024u, (unsigned)(s + 1), f2bf2(acc[mo][j][0], acc[mo][j][1]),
+                                    f2bf2(acc[mo][j][2], acc[mo][j][3]), local);
             }
+            KSTAMP(5);
             constexpr int NGT = (P - 1) * UTP;
             u32x4_t xv[NGT];
             const unsigned in_off = slot_off + (unsigned)(pm * P) * GPD * 8u + lane_off;
@@ -1283,9 +1319,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int mm = 0; mm < P; ++mm) v = (mm == pm) ? acc[mm][j][r] : v;
+                    float v = acc[0][j][r];
 #pragma unroll
                     for (int mo = 0; mo < P - 1; ++mo) {
                         const unsigned pk = (r >> 1) ? xv[mo * UTP + j].z : xv[mo * UTP + j].y;
@@ -1294,6 +1328,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     dhr[j][r] = v;
                 }
         }
+        KSTAMP(6);
         // ---- d(pre-activation) of this step to HBM as packed bf16 pairs (never waited on)
 #pragma unroll
         for (int j = 0; j < UTP; ++j)
@@ -1301,8 +1336,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int q = 0; q < G; ++q) gprev[rr][(q * H + j * 16) / 2] = sv_z[q][j][rr];
+        KSTAMP(7);
         cur ^= 1;
     }
+#ifdef LAS_PROF
+    if (kprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#endif
     // bias gradient partials of this (tile, direction): sum the rows held by the lane pair and by the four row groups
 #pragma unroll
     for (int q = 0; q < G; ++q)
@@ -1343,8 +1382,10 @@ __global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const
         const int vw = (int)((rest / NFR) % NVW);
         const int dir = (int)(rest / ((long long)NFR * NVW));
         const float* W = dir ? W1 : W0;
-        const int ks = fi % KSP, mj = fi / KSP, j = mj % UTP, m = mj / UTP;
         const int pm = vw / 4, w = vw % 4;
+        // fragment slot `mo` of member pm holds the tile of member (pm + mo) % P: the kernel indexes its accumulators by the
+        // RELATIVE member offset, a compile-time constant (slot 0 = own tile), instead of selecting by a run-time member id
+        const int ks = fi % KSP, mj = fi / KSP, j = mj % UTP, m = (pm + mj / UTP) % P;
         const int unit = m * UPM + (w * UTP + j) * 16 + (lane & 15);
         const int k = ks * 32 + (lane >> 4) * 8 + e;
         const int q = k / UPM, col = q * H + pm * UPM + (k % UPM);
@@ -1670,6 +1711,9 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void*
     bind_tensors(a, gates, const_cast<void*>(out), const_cast<void*>(cstate), dout);
     a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
     seq_common_args(a, flags, status, LAS_SEQ_STATUS_BWD_TIMEOUT);
+#ifdef LAS_PROF
+    if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
+#endif
     const bool bf = prec == LAS_PREC_BF16 && mfma_shape_ok(H);
     if (bf) {
         int db_done = 0;
