@@ -48,11 +48,11 @@ def bench_args(cell):
                      scheduled_sampling=True, vocab_size=30)
 
 
-def sweep_bytes(B, T, H, G, bwd):
-    """ALGORITHMIC HBM bytes of one recurrent sweep launch (both directions), fp32 tensors in HBM:
+def sweep_bytes(B, T, H, G, bwd, f=2):
+    """ALGORITHMIC HBM bytes of one recurrent sweep launch (both directions); f = bytes per stored activation (2: speed mode
+    keeps the listener's activations in HBM as bf16 -- SURVEY 8(d)'s figure; 4: parity mode):
     fwd: read x-projection, write activated gates + cell state + h; W_hh fragments once.
     bwd: read activated gates, c_t, c_prev, dout; write d(pre-activation)."""
-    f = 4
     gates = B * T * 2 * G * H * f
     h = B * T * 2 * H * f
     w = 2 * H * G * H * 2
@@ -101,13 +101,17 @@ def cpu_baseline_child(cell, budget_s=45.0):
         probes[n] = one(2)
     ncores = min(probes, key=probes.get)
     torch.set_num_threads(ncores)
-    est = probes[ncores] / 2.0                            # seconds per utterance and step, an upper bound for larger batches
-    Bs = 2
-    for cand in (48, 32, 24, 16, 8, 4):
-        if 4 * cand * est <= budget_s:
-            Bs = cand
+    # batch as large as fits the budget: grow from B=4 while a step scales about linearly (a step at the next size that
+    # takes more than 1.5x the linear prediction -- allocator / cache pathologies seen at B=8 on some hosts -- ends the search)
+    Bs, t_prev = 4, one(4)
+    for cand in (8, 16, 32, 48):
+        if 4.5 * t_prev * cand / Bs > budget_s:
             break
-    one(Bs)                                               # warm-up
+        t_c = one(cand)
+        if t_c > 1.5 * t_prev * cand / Bs:
+            break
+        Bs, t_prev = cand, t_c
+    one(Bs)                                                 # warm-up at the chosen size
     ts = sorted(one(Bs) for _ in range(3))
     med = ts[1]
     print(json.dumps({"value": round(Bs / med, 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
@@ -328,7 +332,7 @@ def main():
             f = fam.setdefault(name, {"ms": 0.0, "n": 0, "bytes": 0, "steps": 0})
             f["ms"] += avg * n
             f["n"] += n
-            f["bytes"] += sweep_bytes(B, Tl, H, G, name.endswith("bwd")) * n
+            f["bytes"] += sweep_bytes(B, Tl, H, G, name.endswith("bwd"), 2 if a.dtype == "bf16" else 4) * n
             f["steps"] += Tl * n
         roof = None
         if fam:
