@@ -14,3 +14,14 @@ void las_set_error(const char* fmt, ...) {
 
 extern "C" int las_version(void) { return 100; }  // 0.1.0
 extern "C" const char* las_last_error(void) { return g_err; }
+
+// compute units of the current device (init-once attribute cache; partitioned / CU-masked devices report fewer than 256)
+int las_device_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return cus;
+}

@@ -7,6 +7,7 @@
 
 // ---- error reporting (thread-local message, negative return codes) ----------------------------
 void las_set_error(const char* fmt, ...);
+int las_device_cus();   // compute units of the current device (cached)
 
 #define LAS_ARG(cond, ...)                                   \
     do { if (!(cond)) { las_set_error(__VA_ARGS__); return -1; } } while (0)
@@ -117,6 +118,24 @@ template <int NT> __device__ __forceinline__ float block_max_lds(float v, float*
 #pragma unroll
     for (int i = 1; i < NT / 64; ++i) s = fmaxf(s, red[i]);
     return s;
+}
+
+// ---- cross-CU exchange granules -----------------------------------------------------------------
+// 16-byte form: two granules {tag, a} {b, tag} written by ONE store and read by ONE load.  Each 8-byte half carries its
+// own tag, so the pair is valid even if the 16 bytes are not delivered atomically (the consumer checks both tags).
+// Buffer intrinsics so that the compiler tracks vmcnt for the loads; aux bit 0 = sc0, bit 4 = sc1.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(unsigned long long* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);        // wave-uniform base, raw addressing
+}
+__device__ __forceinline__ void granule16_store(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, unsigned a, unsigned b,
+                                                bool local) {
+    const u32x4_t v = {tag, a, b, tag};
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 1);          // sc0: stays in the XCD's L2
+    else       __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 17);         // sc0 sc1: write-through
+}
+__device__ __forceinline__ u32x4_t granule16_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);                 // sc1: bypass L1
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

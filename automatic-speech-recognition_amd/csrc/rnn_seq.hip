@@ -274,22 +274,8 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned ta
     if (local) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16-byte form: two granules {tag, a} {b, tag} written by ONE store and read by ONE load.  Each 8-byte half carries its
-// own tag, so the pair is valid even if the 16 bytes are not delivered atomically (the consumer checks both tags).
-// Buffer intrinsics so that the compiler tracks vmcnt for the loads; aux bit 0 = sc0, bit 4 = sc1.
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(unsigned long long* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);        // wave-uniform base, raw addressing
-}
-__device__ __forceinline__ void granule16_store(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, unsigned a, unsigned b,
-                                                bool local) {
-    const u32x4_t v = {tag, a, b, tag};
-    if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 1);          // sc0: stays in the XCD's L2
-    else       __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 17);         // sc0 sc1: write-through
-}
-__device__ __forceinline__ u32x4_t granule16_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);                 // sc1: bypass L1
-}
+// (the 16-byte granule form {tag, a, b, tag} -- granule_rsrc / granule16_store / granule16_load -- lives in las_common.h:
+// the Speller's fused step kernels use the same transport)
 __device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err, int spin) {
     unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int budget = *err ? 1 : spin;                     // sticky: after one timeout never wait again (no hang)
@@ -1440,17 +1426,6 @@ static int pick_cluster(int cell, int H, int flags) {
     return P;
 }
 
-// compute units of the current device (init-once attribute cache; partitioned / CU-masked devices report fewer than 256)
-static int device_cus() {
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-        return n;
-    }();
-    return cus;
-}
-
 struct SeqWs { size_t pack, err, sink, xcc, bpart, xbuf, xbuf_per, total; };
 static SeqWs seq_ws_layout(int cell, int H, int B) {
     const size_t G = cell == LAS_CELL_LSTM ? 4 : 1;
@@ -1491,8 +1466,8 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
         RnnArgs a = a0;
         a.ncl = cdiv(ntiles, RT) * 2;                      // (tile group, direction) pairs
         a.ncl_pad = (a.ncl + 7) / 8 * 8;                   // members of a cluster share blockIdx % 8 (same XCD: speed only)
-        if ((long long)a.ncl_pad * P > device_cus()) {     // every member must be co-resident (1 workgroup per CU)
-            las_set_error("rnn_seq: %d workgroups exceed the %d compute units of this device", a.ncl_pad * P, device_cus());
+        if ((long long)a.ncl_pad * P > las_device_cus()) {     // every member must be co-resident (1 workgroup per CU)
+            las_set_error("rnn_seq: %d workgroups exceed the %d compute units of this device", a.ncl_pad * P, las_device_cus());
             return -2;
         }
         dim3 grid(a.ncl_pad * P), blk(256 * RT);
@@ -1609,8 +1584,8 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
         // row tiles per launch: clusters (tile, direction) are padded to a multiple of 8 workgroups per member
         const int ntiles = cdiv(B, 16);
-        int max_tiles = (device_cus() / P / 8) * 8 / 2;
-        if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, device_cus()); rc = -2; continue; }
+        int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
+        if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, las_device_cus()); rc = -2; continue; }
         const size_t per_cl = L.xbuf_per;                // granule words per cluster
         rc = 0;
         for (int tile0 = 0; tile0 < ntiles && rc == 0; tile0 += max_tiles) {

@@ -24,8 +24,21 @@ constexpr int RNG = RNT / 32;      // 32-lane half-wave groups
 constexpr int RNW = RNT / 64;      // waves
 constexpr int RNH = RNT / 128;     // frame groups of the context reduction
 
+// The per-step cell product when it is fused into the step kernel (dec_step_*_fz_kernel): C[M,N] = A[M,K] . Bp (+ bias),
+// A in bf16 written by the previous step's row workgroups, Bp pre-packed MFMA fragments.  Columns >= gcol0 are
+// published as 16-byte granules {tag, v[col], v[col+1], tag} (gpr granules per row) for the row workgroups of the SAME
+// launch; C (optional) additionally receives all columns as plain fp32 for consumers after the loop.
+struct StepProd {
+    const unsigned short* A; int lda, M, K;
+    const u16x8_t* Bp; int KS, N, nct;
+    const float* bias;
+    float* C; int ldc;
+    unsigned long long* gran; int gcol0, gpr;
+};
+
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
+    StepProd sp;
     float fb;
     unsigned long long seed;
     const float *enc, *keys; const int* enc_len;
@@ -628,17 +641,18 @@ __device__ __forceinline__ float dot2bf(unsigned int a, unsigned int b, float ac
 // The row kernels run one workgroup per utterance and are bound by instruction issue on that one CU, so the
 // contractions use packed-pair dot products: q = s.Ws over k-pairs (Wsbf2 [S/2][A][2]), context over frame pairs
 // (encbf2 [B][T'/2][Hd][2]); the softmax statistics are computed per wave (no block reductions).
-template <int CELL, int NE>
-__global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
+// FUSED: the pre-activation gates of step t-1 are not in a.gates but arrive as granules from the product workgroups of
+// the same launch (dec_step_fwd_fz_kernel); everything that does not depend on them is issued before the poll.
+template <int CELL, int NE, bool FUSED>
+__device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, float* sm) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
-    extern __shared__ __attribute__((aligned(16))) float sm[];
     STAMPX(0);
     const BfLds L = carve_bf(sm, a);
     unsigned int* sp = reinterpret_cast<unsigned int*>(L.hl);      // packed state pairs  [S/2]
     unsigned int* ap = reinterpret_cast<unsigned int*>(L.x1);      // packed alpha pairs  [T'/2]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a8 = tid & 15, grp = tid >> 4;           // energies: 16 lanes x 8 columns per frame
     const int a4 = tid & 31, kg = tid >> 5;            // query:    32 lanes x 4 columns per k-pair
     const int h4 = tid & 127, fg = tid >> 7;           // context:  128 lanes x 4 columns per frame pair
@@ -650,13 +664,13 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     // join makes the compiler drain vmcnt, which serialises the prefetch.  Out-of-range lanes are neutralised where
     // the value is used (zero multiplier / guarded store), never by a select on the loaded register.
     const int tm1 = t > 0 ? t - 1 : 0, tc = t < U ? t : U - 1, dd = tid < D ? tid : D - 1;
-    float gr[4], cpv = 0.f;
+    float gr[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f;
     float* gp = a.gates + (((size_t)0 * U + tm1) * B + b) * GD;
-    gr[0] = gp[dd];
-    if (CELL == LAS_CELL_LSTM) {
-        gr[1] = gp[D + dd]; gr[2] = gp[2 * D + dd]; gr[3] = gp[3 * D + dd];
-        cpv = a.cs[(((size_t)0 * (U + 1) + tm1) * B + b) * D + dd];
+    if (!FUSED) {
+        gr[0] = gp[dd];
+        if (CELL == LAS_CELL_LSTM) { gr[1] = gp[D + dd]; gr[2] = gp[2 * D + dd]; gr[3] = gp[3 * D + dd]; }
     }
+    if (CELL == LAS_CELL_LSTM) cpv = a.cs[(((size_t)0 * (U + 1) + tm1) * B + b) * D + dd];
     const float s0 = a.hs[(size_t)b * D + dd];                       // initial state (used at t = 0)
     int tok = a.tok_in[(size_t)tc * B + b];
     const int len = a.enc_len[b];
@@ -675,6 +689,30 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
     }
     STAMPX(1);
+    if (FUSED && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
+        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.sp.gran);
+        u32x4_t gq[G];
+        unsigned goff[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            goff[i] = (unsigned)(((size_t)b * (GD >> 1) + ((i * D + dd) >> 1)) * 16);
+            gq[i] = granule16_load(rs, goff[i]);
+        }
+        int budget = 1 << 24;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < G; ++i) ok &= gq[i].x == (unsigned)t && gq[i].w == (unsigned)t;
+            if (ok) break;
+            if (--budget == 0) __builtin_trap();          // a product workgroup never ran: fail loudly, never hang
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (gq[i].x != (unsigned)t || gq[i].w != (unsigned)t) gq[i] = granule16_load(rs, goff[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) gr[i] = __uint_as_float((dd & 1) ? gq[i].z : gq[i].y);
+    }
     int greedy_tok = 1, sample_tok = 1;
     {   // ---- finish the cell of step t-1 (or pick up the initial state)
         // computed by every lane (clamped operands) so that the gate loads stay at the head of the load stream;
@@ -842,6 +880,77 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
         xb[E + Hd + tid] = f2bf(v);
     }
     STAMPX(8);
+}
+
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch per decode step (speed mode): workgroups [0, nct) compute the cell product of the PREVIOUS step's input
+// rows (written by the previous launch, so plain loads) and publish the pre-activation gates as granules; workgroups
+// [nct, nct + B) are the row workgroups of THIS step: they issue every state-independent load of the step (Ws, keys,
+// u, later the encoder rows) while the product runs, poll the granules of their row, finish the cell and run the
+// attention.  The dependent chain of a step is then  launch -> product (~3 us) -> one cross-CU hop -> row arithmetic,
+// instead of  launch -> row kernel incl. its load ramp -> launch -> product.  The product workgroups come first in the
+// grid so that they are dispatched first; they wait on nothing, so the row workgroups' poll cannot deadlock as long as
+// nct + B workgroups are co-resident (checked by the host against the CU count).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void step_product(const StepProd& p, const int ct, const unsigned tag, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int MT = (p.M + 15) >> 4, KG = 15 / MT, NWK = MT * KG;       // MT <= 15: wave = (row tile, k group)
+    if (w < NWK) {
+        const int mt = w % MT, kg = w / MT;
+        const int KSW = (p.KS + KG - 1) / KG, ks0 = kg * KSW, ks1 = min(p.KS, ks0 + KSW);
+        const u16x8_t* bp = p.Bp + (size_t)ct * p.KS * 64 + lane;
+        int row = mt * 16 + c;
+        if (row >= p.M) row = p.M - 1;                                  // padded rows: garbage that is never stored
+        const unsigned short* ap = p.A + (long long)row * p.lda;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = ks0; ks < ks1; ks += 8) {
+            u16x8_t bv[8], av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                               // unconditional, clamped: all 16 loads in flight
+                const int kc = min(ks + u, ks1 - 1);
+                bv[u] = bp[(size_t)kc * 64];
+                av[u] = *reinterpret_cast<const u16x8_t*>(ap + min(kc * 32 + g * 8, p.K - 8));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = ks + u;
+                const bool on = kk < ks1 && kk * 32 + g * 8 + 8 <= p.K;
+                const u16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                acc = mfma_bf16_16x16x32(on ? av[u] : z, bv[u], acc);
+            }
+        }
+        *reinterpret_cast<f32x4_t*>(red + ((size_t)w * 64 + lane) * 4) = acc;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = granule_rsrc(p.gran);
+    for (int idx = tid; idx < MT * 256; idx += RNT) {
+        const int mt = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15;
+        const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
+        float v = 0.f;
+        for (int kg = 0; kg < KG; ++kg) v += red[((size_t)(kg * MT + mt) * 64 + l2) * 4 + reg];
+        const int orow = mt * 16 + r16, col = ct * 16 + c16;
+        if (p.bias && col < p.N) v += p.bias[col];
+        const float nb = __shfl_xor(v, 1, 64);
+        if (orow < p.M && col < p.N) {
+            if (p.C) p.C[(long long)orow * p.ldc + col] = v;
+            if (!(c16 & 1) && col >= p.gcol0)
+                granule16_store(rs, (unsigned)(((size_t)orow * p.gpr + ((col - p.gcol0) >> 1)) * 16), tag, __float_as_uint(v),
+                                __float_as_uint(nb), false);
+        }
+    }
+}
+
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_fz_kernel(DecDev a, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < a.sp.nct) { step_product(a.sp, blockIdx.x, (unsigned)t, sm); return; }
+    pf_fwd_row<CELL, NE, true>(a, t, (int)blockIdx.x - a.sp.nct, sm);
 }
 
 // gate nonlinearity of a non-top layer (multi-layer Speller only)
@@ -1358,15 +1467,16 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 // prefetching gradient row kernel (same eligibility as dec_step_fwd_pf_kernel).  The recurrent inputs are the
 // dXin0 row of step t_att (context and state gradient) and this row's dC; everything else is issued at once.
 // dalpha = enc . dctx and dstate = Ws . dq contract over pairs that are adjacent in the natural layouts.
-template <int CELL, int NE>
-__global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
+// FUSED: the dXin0 row of step t_att (context and state gradient) arrives as granules from the product workgroups of the
+// same launch (dec_step_bwd_fz_kernel).
+template <int CELL, int NE, bool FUSED>
+__device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, float* sm) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
-    extern __shared__ __attribute__((aligned(16))) float sm[];
     STAMPX(10);
     const BfLds L = carve_bf(sm, a);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int a8 = tid & 15, grp = tid >> 4;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, U = a.U;
     const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, H8 = Hd >> 3;
@@ -1381,8 +1491,9 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     const int dd = tid < D ? tid : D - 1, h2c = tid < (Hd >> 1) ? tid : (Hd >> 1) - 1, tpc = tid < Tp ? tid : Tp - 1;
     const int a2c = tid < 2 * A ? tid : 2 * A - 1, a8c = a8 < A8 ? a8 : A8 - 1, l8c = lane < H8 ? lane : H8 - 1;
     const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
-    const float2 dcv = reinterpret_cast<const float2*>(dxr + E)[h2c];
-    const float recv0 = dxr[E + Hd + dd];
+    float2 dcv = make_float2(0.f, 0.f);
+    float recv0 = 0.f;
+    if (!FUSED) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
     const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
     // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
     const float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
@@ -1419,6 +1530,23 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         dcr = a.dC[(size_t)b * D + dd];
     } else {
         hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+    }
+    if (FUSED && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
+        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.sp.gran);
+        const unsigned tag = (unsigned)t_att + 1u;
+        const unsigned o0 = (unsigned)(((size_t)b * a.sp.gpr + h2c) * 16), o1 = (unsigned)(((size_t)b * a.sp.gpr + ((Hd + dd) >> 1)) * 16);
+        u32x4_t q0 = granule16_load(rs, o0), q1 = granule16_load(rs, o1);
+        int budget = 1 << 24;
+        for (;;) {
+            const bool ok0 = q0.x == tag && q0.w == tag, ok1 = q1.x == tag && q1.w == tag;
+            if (ok0 && ok1) break;
+            if (--budget == 0) __builtin_trap();          // a product workgroup never ran: fail loudly, never hang
+            __builtin_amdgcn_s_sleep(1);
+            if (!ok0) q0 = granule16_load(rs, o0);
+            if (!ok1) q1 = granule16_load(rs, o1);
+        }
+        dcv = make_float2(__uint_as_float(q0.y), __uint_as_float(q0.z));
+        recv0 = __uint_as_float((dd & 1) ? q1.z : q1.y);
     }
     const float recv = att ? recv0 : 0.f;
 
@@ -1532,7 +1660,9 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
     STAMPX(18);
     if (cel && tid < D) {   // gate backward of step t_cell
         const float dh = dhs[tid] + recv + dhl;
-        unsigned short* gb = a.dgbf + (size_t)b * GD;
+        // FUSED: two parities -- product workgroups of this launch whose columns carry no granules may still be reading
+        // the previous step's gate gradient
+        unsigned short* gb = a.dgbf + (FUSED ? (size_t)(t_cell & 1) * B * GD : 0) + (size_t)b * GD;
         if (CELL == LAS_CELL_LSTM) {
             const float gi = gs[0], gj = gs[1], gf = gs[2], go = gs[3];
             const float tc = tanhx<FAST>(cv);
@@ -1549,6 +1679,22 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
         }
     }
     STAMPX(19);
+}
+
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    pf_bwd_row<CELL, NE, false>(a, t_att, t_cell, blockIdx.x, sm);
+}
+
+// one launch per gradient step: workgroups [0, nct) compute dXin0[t_att] = dG(t_att) . W0^T from the bf16 gate gradient
+// the previous launch left in dgbf (plain fp32 copy for the after-loop contractions + granules for the chain columns),
+// workgroups [nct, nct + B) are this step's row workgroups (see dec_step_fwd_fz_kernel)
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_bwd_fz_kernel(DecDev a, int t_att, int t_cell) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < a.sp.nct) { step_product(a.sp, blockIdx.x, (unsigned)t_att + 1u, sm); return; }
+    pf_bwd_row<CELL, NE, true>(a, t_att, t_cell, (int)blockIdx.x - a.sp.nct, sm);
 }
 
 // dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)
@@ -1598,7 +1744,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, xbf, dgbf, granF, granB, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -1607,7 +1753,9 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.packF = o;  o += align256(las_skinny_pack_bytes((int)I0D, G * D));      // W0 fragments (step product)
     w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
     w.xbf = o;    o += align256((size_t)B * I0D * 2);
-    w.dgbf = o;   o += align256((size_t)B * G * D * 2);
+    w.dgbf = o;   o += align256((size_t)2 * B * G * D * 2);                   // two step parities (fused step kernels)
+    w.granF = o;  o += align256((size_t)B * (G * D / 2) * 16);                // gate granules of the fused forward step
+    w.granB = o;  o += align256((size_t)B * ((Hd + D) / 2) * 16);             // dXin0 chain columns of the fused gradient step
     w.wsbf = o;   o += align256((size_t)D * NL * A * 2);
     w.wsbf2 = o;  o += align256((size_t)(D * NL + 1) * A * 2);
     w.keysbf = o; o += align256((size_t)B * Tp * A * 2);
@@ -1665,6 +1813,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
+    d.sp = StepProd{};
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
@@ -1682,6 +1831,11 @@ static bool bf_rows_ok(const DecDev& d) {
 static bool pf_rows_ok(const DecDev& d) {
     return !(d.flags & LAS_SPELLER_NO_PF_ROWS) && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 &&
            d.E <= 1024 && (d.E % 2) == 0 && (d.D % 2) == 0;
+}
+// ... and one launch per step: the product workgroups and the row workgroups of a step must all be co-resident
+static bool fused_step_ok(const DecDev& d, int nct) {
+    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && pf_rows_ok(d) && cdiv(d.B, 16) <= 15 && nct + d.B <= las_device_cus() &&
+           (d.E % 2) == 0 && ((d.E + d.Hd + d.D) % 8) == 0;
 }
 static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
     unsigned short* wsb = (unsigned short*)(base + w.wsbf);
@@ -1727,8 +1881,25 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
+    const int nctF = cdiv(GD, 16);
+    const bool fused = pf && fused_step_ok(d, nctF);
+    size_t lds_fz = lds_bf < 16384 ? 16384 : lds_bf;         // the product workgroups' 16 partial tiles
+    if (fused) {
+        d.sp.A = d.xbf; d.sp.lda = I0D; d.sp.M = B; d.sp.K = I0D;
+        d.sp.Bp = reinterpret_cast<const u16x8_t*>(packF); d.sp.KS = cdiv(I0D, 32); d.sp.N = GD; d.sp.nct = nctF;
+        d.sp.bias = f->cellb[0]; d.sp.C = nullptr; d.sp.ldc = 0;
+        d.sp.gran = (unsigned long long*)((char*)f->ws + wl_.granF); d.sp.gcol0 = 0; d.sp.gpr = GD / 2;
+        LAS_HIP(hipMemsetAsync(d.sp.gran, 0, (size_t)B * (GD / 2) * 16, st));      // tags of an earlier call must not match
+    }
     for (int t = 0; t <= U; ++t) {
-        if (pf && d.Tp <= 128)          hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        if (fused && t > 0) {
+            const dim3 grid(nctF + B);
+            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 8>), grid, dim3(RNT), lds_fz, st, d, t);
+            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 10>), grid, dim3(RNT), lds_fz, st, d, t);
+            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 12>), grid, dim3(RNT), lds_fz, st, d, t);
+            else                  hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 14>), grid, dim3(RNT), lds_fz, st, d, t);
+        }
+        else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, d, t);
@@ -1738,6 +1909,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         else                            hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
+        if (fused) continue;                               // the next launch carries this step's cell product
         if (skinny) {
             GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD, f->cellb[0], st));
         } else {
@@ -1817,11 +1989,31 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         GEMM_OK(las_gemm(prec, 0, 0, U * B, A, D, 1.f, d.hs + (size_t)l * (U + 1) * B * D, D, 0, d.Ws + (size_t)l * D * A, A, 0,
                          l ? 1.f : 0.f, d.Q, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
 
+    const int nctB = cdiv(I0D, 16);
+    const bool fused = pf && fused_step_ok(d, nctB);
+    const size_t lds_fz = lds_bf < 16384 ? 16384 : lds_bf;
+    if (fused) {
+        d.sp.lda = GD; d.sp.M = B; d.sp.K = GD;
+        d.sp.Bp = reinterpret_cast<const u16x8_t*>(packB); d.sp.KS = cdiv(GD, 32); d.sp.N = I0D; d.sp.nct = nctB;
+        d.sp.bias = nullptr; d.sp.ldc = I0D;
+        d.sp.gran = (unsigned long long*)(base + w.granB); d.sp.gcol0 = E; d.sp.gpr = (Hd + D) / 2;
+        LAS_HIP(hipMemsetAsync(d.sp.gran, 0, (size_t)B * ((Hd + D) / 2) * 16, st));
+    }
     for (int t = U - 1; t >= -1; --t) {
         DecDev ds = d;
         if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
         const int ta = (t + 1 < U) ? t + 1 : -1;
-        if (pf && Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        if (fused && ta >= 0) {
+            // product: dXin0[ta] from the gate gradient of cell ta (parity ta & 1 of dgbf, written by the previous launch)
+            ds.sp.A = d.dgbf + (size_t)(ta & 1) * B * GD;
+            ds.sp.C = d.dXin0 + (size_t)ta * B * I0D;
+            const dim3 grid(nctB + B);
+            if (Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 8>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
+            else if (Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 10>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
+            else if (Tp <= 192) hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 12>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
+            else                hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 14>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
+        }
+        else if (pf && Tp <= 128) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf && Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf && Tp <= 192) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf)              hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
@@ -1831,6 +2023,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         else          hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         LAS_LAUNCHED();
         if (t < 0) break;
+        if (fused) continue;                               // the next launch carries dG(t) . W0^T
         for (int l = TOP; l >= 0; --l) {
             const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
             if (l == 0 && skinny) {

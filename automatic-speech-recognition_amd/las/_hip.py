@@ -319,7 +319,7 @@ class _timed:
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES = 1, 2, 4
-SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS = 1, 2
+SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP = 1, 2, 4
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound",
               2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
 
@@ -340,7 +340,8 @@ def _flags_from_env():
         f |= seq_p(e("LAS_SEQ_P"))
     if e("LAS_SPIN_LOG2"):
         f |= seq_spin_log2(e("LAS_SPIN_LOG2"))
-    g = (SPELLER_NO_PF_ROWS if e("LAS_NO_PF_ROWS") == "1" else 0) | (SPELLER_NO_BF_ROWS if e("LAS_NO_BF_ROWS") == "1" else 0)
+    g = (SPELLER_NO_PF_ROWS if e("LAS_NO_PF_ROWS") == "1" else 0) | (SPELLER_NO_BF_ROWS if e("LAS_NO_BF_ROWS") == "1" else 0) | \
+        (SPELLER_NO_FUSED_STEP if e("LAS_NO_FUSED_STEP") == "1" else 0)
     return f, g
 
 

@@ -26,7 +26,7 @@ def _speller(prec, D=64, A=32, H=32, NL=1, V=30, flags=0):
     return Speller(args), args
 
 
-@pytest.mark.parametrize("prec,flags", [("f32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 2)])
+@pytest.mark.parametrize("prec,flags", [("f32", 0), ("bf16", 0), ("bf16", 1), ("bf16", 2), ("bf16", 4)])
 def test_gumbel_draws_follow_softmax_and_are_reproducible(prec, flags):
     from las import _hip, variables as Vs
     V, Bn, Tp = 30, 2048, 12
@@ -85,7 +85,7 @@ def test_gumbel_draws_follow_softmax_and_are_reproducible(prec, flags):
         _hip.speller_flags = 0
 
 
-@pytest.mark.parametrize("prec,NL,flags", [("f32", 1, 0), ("f32", 2, 0), ("bf16", 1, 0), ("bf16", 1, 1), ("bf16", 2, 0)])
+@pytest.mark.parametrize("prec,NL,flags", [("f32", 1, 0), ("f32", 2, 0), ("bf16", 1, 0), ("bf16", 1, 1), ("bf16", 2, 0), ("bf16", 1, 4)])
 def test_on_device_sampling_step_matches_oracle_given_the_draws(prec, NL, flags):
     """training with in-kernel logits (step_logits) followed by las_speller_bwd: feed the oracle the tokens the kernel
     drew and compare logits, alignments and every gradient."""

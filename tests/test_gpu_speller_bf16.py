@@ -76,7 +76,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2])            # default (pf where eligible) / no pf rows / fp32-operand rows
+@pytest.mark.parametrize("flags", [0, 1, 2, 4])         # default (one launch per step where eligible) / no pf rows / fp32-operand rows / pf rows, two launches per step
 @pytest.mark.parametrize("shape", SHAPES)
 def test_bf16_row_kernels_match_oracle(shape, flags):
     NL, D, A, H, B, Tp, U, mixed = shape
