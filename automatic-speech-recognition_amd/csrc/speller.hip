@@ -24,21 +24,26 @@ constexpr int RNG = RNT / 32;      // 32-lane half-wave groups
 constexpr int RNW = RNT / 64;      // waves
 constexpr int RNH = RNT / 128;     // frame groups of the context reduction
 
-// The per-step cell product when it is fused into the step kernel (dec_step_*_fz_kernel): C[M,N] = A[M,K] . Bp (+ bias),
-// A in bf16 written by the previous step's row workgroups, Bp pre-packed MFMA fragments.  Columns >= gcol0 are
-// published as 16-byte granules {tag, v[col], v[col+1], tag} (gpr granules per row) for the row workgroups of the SAME
-// launch; C (optional) additionally receives all columns as plain fp32 for consumers after the loop.
-struct StepProd {
-    const unsigned short* A; int lda, M, K;
-    const u16x8_t* Bp; int KS, N, nct;
+// The per-step cell product inside the persistent loop kernels (dec_loop_*_kernel): C[M,N] = A[M,K] . Bp (+ bias) once per
+// step.  The grid is 8 groups (workgroup id % 8 = the XCD the hardware dispatches it to) of pn product workgroups followed
+// by R = ceil(M / 8) row workgroups; group x owns the utterances b = 8 r + x.  A arrives from the group's row workgroups as
+// granules of 4 bf16 {tag, k..k+1, k+2..k+3, tag}; Bp is the pre-packed MFMA fragment array, product workgroup j keeps the
+// fragments of its tpw column tiles [j tpw, (j+1) tpw) in registers for the whole loop.  The outputs go back to the rows as
+// granules of 2 fp32 {tag, v[col], v[col+1], tag}; C (optional) additionally receives every column as plain fp32 for
+// consumers after the loop.
+struct LoopProd {
+    const u16x8_t* Bp; int KS, K, N, nct, M, pn, R;
     const float* bias;
-    float* C; int ldc;
-    unsigned long long* gran; int gcol0, gpr;
+    float* C; long long c_step; int ldc;
+    unsigned long long* gA; int gA_row;          // [M][gA_row] granules, gA_row = K / 4
+    unsigned long long* gC; int gC_row;          // [M][gC_row] granules, gC_row = N / 2
+    unsigned long long* xcc;                     // [8 (pn + R)] placement handshake slots (zeroed per launch)
+    int nap;                                     // product workgroups sleep nap x 2048 clocks after a step before they poll again
 };
 
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
-    StepProd sp;
+    LoopProd lp;
     float fb;
     unsigned long long seed;
     const float *enc, *keys; const int* enc_len;
@@ -628,9 +633,13 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
 // ------------------------------------------------------------------------------------------------
 #ifdef LAS_ROW_STAMPS   // development aid (tools/micro/bench_rows.hip): phase timestamps of workgroup 0
 __device__ unsigned long long g_stamps[32];
-#define STAMPX(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMPX(i) do { if (tid == 0 && b == 0) g_stamps[i] = wall_clock64(); } while (0)
+#define STAMPQ(i) g_stamps[i] = wall_clock64()
+#define STAMPL(v) g_stamps[31] = (v)
 #else
 #define STAMPX(i)
+#define STAMPQ(i)
+#define STAMPL(v)
 #endif
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
@@ -641,10 +650,17 @@ __device__ __forceinline__ float dot2bf(unsigned int a, unsigned int b, float ac
 // The row kernels run one workgroup per utterance and are bound by instruction issue on that one CU, so the
 // contractions use packed-pair dot products: q = s.Ws over k-pairs (Wsbf2 [S/2][A][2]), context over frame pairs
 // (encbf2 [B][T'/2][Hd][2]); the softmax statistics are computed per wave (no block reductions).
-// FUSED: the pre-activation gates of step t-1 are not in a.gates but arrive as granules from the product workgroups of
-// the same launch (dec_step_fwd_fz_kernel); everything that does not depend on them is issued before the poll.
-template <int CELL, int NE, bool FUSED>
-__device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, float* sm) {
+// LOOP (dec_loop_fwd_kernel): the function is one iteration of a persistent row workgroup.  The pre-activation gates of
+// step t-1 are not in a.gates but arrive as granules from the product workgroups, the bf16 cell input row leaves as
+// granules, the cell state is carried in a register; everything that does not depend on the gates is issued before the poll.
+// four adjacent lanes (columns col .. col+3, col % 4 == 0 in the first) -> one granule of 4 bf16
+__device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const size_t row_gran, const int col, const float v, const unsigned tag,
+                                          const bool local) {
+    const float v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
+    if (!(col & 3)) granule16_store(rs, (unsigned)((row_gran + (col >> 2)) * 16), tag, f2bf2(v, v1), f2bf2(v2, v3), local);
+}
+template <int CELL, int NE, bool LOOP>
+__device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, const int tid, float* sm, float& ccar, const bool local) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
@@ -652,7 +668,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     const BfLds L = carve_bf(sm, a);
     unsigned int* sp = reinterpret_cast<unsigned int*>(L.hl);      // packed state pairs  [S/2]
     unsigned int* ap = reinterpret_cast<unsigned int*>(L.x1);      // packed alpha pairs  [T'/2]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const int a8 = tid & 15, grp = tid >> 4;           // energies: 16 lanes x 8 columns per frame
     const int a4 = tid & 31, kg = tid >> 5;            // query:    32 lanes x 4 columns per k-pair
     const int h4 = tid & 127, fg = tid >> 7;           // context:  128 lanes x 4 columns per frame pair
@@ -666,11 +682,14 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     const int tm1 = t > 0 ? t - 1 : 0, tc = t < U ? t : U - 1, dd = tid < D ? tid : D - 1;
     float gr[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f;
     float* gp = a.gates + (((size_t)0 * U + tm1) * B + b) * GD;
-    if (!FUSED) {
+    if (!LOOP) {
         gr[0] = gp[dd];
         if (CELL == LAS_CELL_LSTM) { gr[1] = gp[D + dd]; gr[2] = gp[2 * D + dd]; gr[3] = gp[3 * D + dd]; }
     }
-    if (CELL == LAS_CELL_LSTM) cpv = a.cs[(((size_t)0 * (U + 1) + tm1) * B + b) * D + dd];
+    if (CELL == LAS_CELL_LSTM) {
+        if (!LOOP) cpv = a.cs[(((size_t)0 * (U + 1) + tm1) * B + b) * D + dd];
+        else { if (t == 0) ccar = a.cs[(size_t)b * D + dd]; cpv = ccar; }
+    }
     const float s0 = a.hs[(size_t)b * D + dd];                       // initial state (used at t = 0)
     int tok = a.tok_in[(size_t)tc * B + b];
     const int len = a.enc_len[b];
@@ -689,8 +708,8 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
     }
     STAMPX(1);
-    if (FUSED && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
-        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.sp.gran);
+    if (LOOP && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
+        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
         u32x4_t gq[G];
         unsigned goff[G];
 #pragma unroll
@@ -713,6 +732,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 #pragma unroll
         for (int i = 0; i < G; ++i) gr[i] = __uint_as_float((dd & 1) ? gq[i].z : gq[i].y);
     }
+    STAMPX(9);
     int greedy_tok = 1, sample_tok = 1;
     {   // ---- finish the cell of step t-1 (or pick up the initial state)
         // computed by every lane (clamped operands) so that the gate loads stay at the head of the load stream;
@@ -723,6 +743,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             gf = sigm<FAST>(gr[2] + a.fb); go = sigm<FAST>(gr[3]);
             cnew = cpv * gf + gi * gj;
             h = tanhx<FAST>(cnew) * go;
+            if (LOOP && t > 0) ccar = cnew;
         } else {
             h = tanhx<FAST>(gr[0]);
         }
@@ -849,6 +870,8 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     STAMPX(6);
     float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
     unsigned short* xb = a.xbf + (size_t)b * I0D;
+    const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(a.lp.gA);          // LOOP: the row leaves as granules (tag t + 1)
+    const size_t xg0 = (size_t)b * a.lp.gA_row;
     {   // context = sum_t alpha[t] * enc[b,t,:] : 4 columns x 2 frames per dot2
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -861,23 +884,26 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         if (h4 < H4) reinterpret_cast<float4*>(L.scr + fg * Hd)[h4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         lds_barrier();
     STAMPX(7);
-        for (int hd = tid; hd < Hd; hd += RNT) {
+        for (int hd = tid; hd < Hd; hd += RNT) {                        // Hd <= 512: one trip, whole 4-lane groups
             float cv = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) cv += L.scr[w * Hd + hd];
             xrow[E + hd] = cv;
-            xb[E + hd] = f2bf(cv);
+            if (LOOP) put4_bf16(xrs, xg0, E + hd, cv, (unsigned)t + 1u, local);
+            else xb[E + hd] = f2bf(cv);
         }
     }
     if (tid < E) {
         const float v = embv * maskv;
         xrow[tid] = v;
-        xb[tid] = f2bf(v);
+        if (LOOP) put4_bf16(xrs, xg0, tid, v, (unsigned)t + 1u, local);
+        else xb[tid] = f2bf(v);
     }
     if (tid < D) {
         const float v = L.s_state[tid];
         xrow[E + Hd + tid] = v;
-        xb[E + Hd + tid] = f2bf(v);
+        if (LOOP) put4_bf16(xrs, xg0, E + Hd + tid, v, (unsigned)t + 1u, local);
+        else xb[E + Hd + tid] = f2bf(v);
     }
     STAMPX(8);
 }
@@ -885,72 +911,142 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, sm);
+    float ccar = 0.f;
+    pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, threadIdx.x, sm, ccar, false);
 }
 
 // ------------------------------------------------------------------------------------------------
-// One launch per decode step (speed mode): workgroups [0, nct) compute the cell product of the PREVIOUS step's input
-// rows (written by the previous launch, so plain loads) and publish the pre-activation gates as granules; workgroups
-// [nct, nct + B) are the row workgroups of THIS step: they issue every state-independent load of the step (Ws, keys,
-// u, later the encoder rows) while the product runs, poll the granules of their row, finish the cell and run the
-// attention.  The dependent chain of a step is then  launch -> product (~3 us) -> one cross-CU hop -> row arithmetic,
-// instead of  launch -> row kernel incl. its load ramp -> launch -> product.  The product workgroups come first in the
-// grid so that they are dispatched first; they wait on nothing, so the row workgroups' poll cannot deadlock as long as
-// nct + B workgroups are co-resident (checked by the host against the CU count).
+// The whole decode loop in ONE launch (speed mode, single-layer additive-attention geometry).  Eight independent groups,
+// one per XCD: workgroup id = 8 j + x is dispatched to XCD x; j < pn are "product" workgroups that keep their fragments of
+// the cell weights in REGISTERS for all U steps, j >= pn are the row workgroups of the utterances b = 8 (j - pn) + x (the
+// same arithmetic as the per-step row kernel).  Per step the rows publish the bf16 cell input row as granules, the group's
+// products contract it (MFMA tile rows = the group's <= 16 utterances) and publish the pre-activation gates as granules:
+// the data is the flag (tag = step + 1), no fences, no kernel boundaries, no per-step weight re-fetch, and -- because a
+// group lives on one XCD -- every exchange is served by that XCD's L2 (workgroup-scope stores, sc1 loads; the placement is
+// verified by an XCC_ID handshake at kernel start, otherwise agent-scope write-through stores: correct anywhere, slower).
+// Why: with two launches per step the product was bound by per-CU INGEST (every column owner re-reads its 40 KB of weights
+// and all 48 input rows each step, ~5 us), and a chip-wide exchange through memory costs ~1.5 us per hop plus the polling
+// traffic of 200 workgroups.  Progress: products wait only for rows, rows only for products, the host launches the grid only
+// if 8 (pn + R) workgroups fit the device's compute units at once; polls are bounded and trap (never hang).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void step_product(const StepProd& p, const int ct, const unsigned tag, float* red) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int MT = (p.M + 15) >> 4, KG = 15 / MT, NWK = MT * KG;       // MT <= 15: wave = (row tile, k group)
-    if (w < NWK) {
-        const int mt = w % MT, kg = w / MT;
-        const int KSW = (p.KS + KG - 1) / KG, ks0 = kg * KSW, ks1 = min(p.KS, ks0 + KSW);
-        const u16x8_t* bp = p.Bp + (size_t)ct * p.KS * 64 + lane;
-        int row = mt * 16 + c;
-        if (row >= p.M) row = p.M - 1;                                  // padded rows: garbage that is never stored
-        const unsigned short* ap = p.A + (long long)row * p.lda;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = ks0; ks < ks1; ks += 8) {
-            u16x8_t bv[8], av[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {                               // unconditional, clamped: all 16 loads in flight
-                const int kc = min(ks + u, ks1 - 1);
-                bv[u] = bp[(size_t)kc * 64];
-                av[u] = *reinterpret_cast<const u16x8_t*>(ap + min(kc * 32 + g * 8, p.K - 8));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = ks + u;
-                const bool on = kk < ks1 && kk * 32 + g * 8 + 8 <= p.K;
-                const u16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                acc = mfma_bf16_16x16x32(on ? av[u] : z, bv[u], acc);
-            }
+__device__ __forceinline__ bool loop_same_xcd(unsigned long long* slots, const int x, const int members, const int tid) {
+    const unsigned tag = 0x58434400u;                                            // "XCD\0"
+    const unsigned mine = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;       // HW_REG_XCC_ID[3:0]
+    if (tid == 0) __hip_atomic_store(slots + blockIdx.x, ((unsigned long long)tag << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int same = 1;
+    if (tid < members) {
+        const unsigned long long* p = slots + (size_t)tid * 8 + x;
+        unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int budget = 1 << 24;
+        while ((unsigned)(v >> 32) != tag) {
+            if (--budget == 0) __builtin_trap();                                 // a member was never dispatched
+            __builtin_amdgcn_s_sleep(8);
+            v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        *reinterpret_cast<f32x4_t*>(red + ((size_t)w * 64 + lane) * 4) = acc;
+        same = (unsigned)v == mine;
     }
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs = granule_rsrc(p.gran);
-    for (int idx = tid; idx < MT * 256; idx += RNT) {
-        const int mt = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15;
-        const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
-        float v = 0.f;
-        for (int kg = 0; kg < KG; ++kg) v += red[((size_t)(kg * MT + mt) * 64 + l2) * 4 + reg];
-        const int orow = mt * 16 + r16, col = ct * 16 + c16;
-        if (p.bias && col < p.N) v += p.bias[col];
-        const float nb = __shfl_xor(v, 1, 64);
-        if (orow < p.M && col < p.N) {
-            if (p.C) p.C[(long long)orow * p.ldc + col] = v;
-            if (!(c16 & 1) && col >= p.gcol0)
-                granule16_store(rs, (unsigned)(((size_t)orow * p.gpr + ((col - p.gcol0) >> 1)) * 16), tag, __float_as_uint(v),
-                                __float_as_uint(nb), false);
+    return __syncthreads_and(same) != 0;
+}
+
+template <int TPW, int KW>
+__device__ __forceinline__ void loop_product(const LoopProd& p, const int U, const bool reverse, const int x, const int j, const bool local,
+                                             float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int Rx = (p.M - x + 7) >> 3;                                // utterances of this group: b = 8 r + x < M
+    if (Rx <= 0) return;                                              // (a batch of fewer than 8 utterances leaves groups empty)
+    const int ks0 = w * KW;                                           // the 16 waves split K, KW k-steps each (16 * KW >= KS)
+    u16x8_t bf[TPW][KW];
+    unsigned aoff[KW];
+    {
+        const int rr = c < Rx ? c : Rx - 1;                           // padded tile rows: garbage that is never stored
+#pragma unroll
+        for (int u = 0; u < KW; ++u) {
+            const int kk = min(ks0 + u, p.KS - 1);
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) bf[tl][u] = p.Bp[((size_t)min(j * TPW + tl, p.nct - 1) * p.KS + kk) * 64 + lane];
+            const int k = min(kk * 32 + g * 8, p.K - 8);
+            aoff[u] = (unsigned)(((size_t)(rr * 8 + x) * p.gA_row + (k >> 2)) * 16);
         }
+    }
+    const __amdgpu_buffer_rsrc_t ars = granule_rsrc(p.gA), crs = granule_rsrc(p.gC);
+    for (int s = 0; s < U; ++s) {
+        const int step = reverse ? U - 1 - s : s;
+        const unsigned tag = (unsigned)step + 1u;
+        if (tid == 0 && blockIdx.x == 0) { STAMPQ(20); }
+        f32x4_t acc[TPW];
+        {
+            u32x4_t q0[KW], q1[KW];
+#pragma unroll
+            for (int u = 0; u < KW; ++u) { q0[u] = granule16_load(ars, aoff[u]); q1[u] = granule16_load(ars, aoff[u] + 16u); }
+            int budget = 1 << 24;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < KW; ++u) ok &= q0[u].x == tag && q0[u].w == tag && q1[u].x == tag && q1[u].w == tag;
+                if (ok) break;
+                if (--budget == 0) __builtin_trap();
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int u = 0; u < KW; ++u) {
+                    if (q0[u].x != tag || q0[u].w != tag) q0[u] = granule16_load(ars, aoff[u]);
+                    if (q1[u].x != tag || q1[u].w != tag) q1[u] = granule16_load(ars, aoff[u] + 16u);
+                }
+            }
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < KW; ++u) {
+                const int kk = ks0 + u;
+                const bool on = kk < p.KS && kk * 32 + g * 8 + 8 <= p.K;
+                const u32x4_t av = {on ? q0[u].y : 0u, on ? q0[u].z : 0u, on ? q1[u].y : 0u, on ? q1[u].z : 0u};
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) acc[tl] = mfma_bf16_16x16x32(__builtin_bit_cast(u16x8_t, av), bf[tl][u], acc[tl]);
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) *reinterpret_cast<f32x4_t*>(red + ((size_t)(w * TPW + tl) * 64 + lane) * 4) = acc[tl];
+        if (tid == 0 && blockIdx.x == 0) { STAMPQ(21); }
+        __syncthreads();
+        for (int idx = tid; idx < TPW * 256; idx += RNT) {            // whole waves: TPW * 256 is a multiple of 64
+            const int tl = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15;
+            const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < RNW; ++ww) v += red[((size_t)(ww * TPW + tl) * 64 + l2) * 4 + reg];
+            const int ct = j * TPW + tl, col = ct * 16 + c16, orow = r16 * 8 + x;
+            const bool valid = r16 < Rx && ct < p.nct && col < p.N;
+            if (p.bias && valid) v += p.bias[col];
+            const float nb = __shfl_xor(v, 1, 64);
+            if (valid) {
+                if (p.C) p.C[(long long)step * p.c_step + (long long)orow * p.ldc + col] = v;
+                if (!(c16 & 1))
+                    granule16_store(crs, (unsigned)(((size_t)orow * p.gC_row + (col >> 1)) * 16), tag, __float_as_uint(v), __float_as_uint(nb), local);
+            }
+        }
+        if (tid == 0 && blockIdx.x == 0) { STAMPQ(23); }
+        __syncthreads();                                              // the partial tiles are rewritten next step
+        // the rows need >= 6 us for their step: stay off the L2 and the power budget for the first ~4 us of it
+        for (int i = 0; i < p.nap; ++i) __builtin_amdgcn_s_sleep(32);
     }
 }
 
 template <int CELL, int NE>
-__global__ __launch_bounds__(RNT) void dec_step_fwd_fz_kernel(DecDev a, int t) {
+__global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
+    constexpr int TPW = 5, KW = 3;                                    // 26 x 5 column tiles >= 128, 16 waves x 3 k-steps x 32 >= 1280 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    if ((int)blockIdx.x < a.sp.nct) { step_product(a.sp, blockIdx.x, (unsigned)t, sm); return; }
-    pf_fwd_row<CELL, NE, true>(a, t, (int)blockIdx.x - a.sp.nct, sm);
+    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x);
+    if (threadIdx.x == 0 && blockIdx.x == 0) { STAMPL(local); }
+    if (j < a.lp.pn) { loop_product<TPW, KW>(a.lp, a.U, false, x, j, local, sm); return; }
+    const int b = (j - a.lp.pn) * 8 + x;
+    if (b >= a.B) return;
+    float ccar = 0.f;
+    for (int t = 0; t <= a.U; ++t) {
+        int bb = b, tid = threadIdx.x;
+        asm volatile("" : "+s"(bb), "+v"(tid));                       // keep the row's address arithmetic inside the iteration:
+        pf_fwd_row<CELL, NE, true>(a, t, bb, tid, sm, ccar, local);   // hoisted out of the loop it costs ~70 spilled VGPRs
+        lds_barrier();                                                // the next step rewrites the row's LDS state
+    }
 }
 
 // gate nonlinearity of a non-top layer (multi-layer Speller only)
@@ -1467,16 +1563,18 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 // prefetching gradient row kernel (same eligibility as dec_step_fwd_pf_kernel).  The recurrent inputs are the
 // dXin0 row of step t_att (context and state gradient) and this row's dC; everything else is issued at once.
 // dalpha = enc . dctx and dstate = Ws . dq contract over pairs that are adjacent in the natural layouts.
-// FUSED: the dXin0 row of step t_att (context and state gradient) arrives as granules from the product workgroups of the
-// same launch (dec_step_bwd_fz_kernel).
-template <int CELL, int NE, bool FUSED>
-__device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, float* sm) {
+// LOOP (dec_loop_bwd_kernel): one iteration of a persistent row workgroup: the dXin0 row of step t_att (context and state
+// gradient) arrives as granules from the product workgroups, the bf16 gate gradient of step t_cell leaves as granules, dC and
+// the running du column are carried in registers.
+template <int CELL, int NE, bool LOOP>
+__device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, const int tid, float* sm,
+                                           float& dccar, float& ducar, const bool local) {
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
     STAMPX(10);
     const BfLds L = carve_bf(sm, a);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const int a8 = tid & 15, grp = tid >> 4;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, U = a.U;
     const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, H8 = Hd >> 3;
@@ -1493,10 +1591,11 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
     float2 dcv = make_float2(0.f, 0.f);
     float recv0 = 0.f;
-    if (!FUSED) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
+    if (!LOOP) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
     const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
     // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
-    const float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
+    float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
+    if (LOOP && a2c >= A) qd = ducar;                 // (duRows starts at zero; the register copy is the live one)
     const int len = a.enc_len[b];
     // encoder rows for dalpha: 16-lane group per frame (3 frames per group), lane a8 covers column chunks a8 + 16 i
     uint4 e8[NK][4];
@@ -1527,14 +1626,14 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         gs[0] = gp[dd]; gs[1] = gp[D + dd]; gs[2] = gp[2 * D + dd]; gs[3] = gp[3 * D + dd];
         cv = a.cs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
         cpv = a.cs[(((size_t)0 * (U + 1) + tcl) * B + b) * D + dd];
-        dcr = a.dC[(size_t)b * D + dd];
+        dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
     } else {
         hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
     }
-    if (FUSED && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
-        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.sp.gran);
+    if (LOOP && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
+        const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
         const unsigned tag = (unsigned)t_att + 1u;
-        const unsigned o0 = (unsigned)(((size_t)b * a.sp.gpr + h2c) * 16), o1 = (unsigned)(((size_t)b * a.sp.gpr + ((Hd + dd) >> 1)) * 16);
+        const unsigned o0 = (unsigned)(((size_t)b * a.lp.gC_row + h2c) * 16), o1 = (unsigned)(((size_t)b * a.lp.gC_row + ((Hd + dd) >> 1)) * 16);
         u32x4_t q0 = granule16_load(rs, o0), q1 = granule16_load(rs, o1);
         int budget = 1 << 24;
         for (;;) {
@@ -1548,6 +1647,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         dcv = make_float2(__uint_as_float(q0.y), __uint_as_float(q0.z));
         recv0 = __uint_as_float((dd & 1) ? q1.z : q1.y);
     }
+    STAMPX(24);
     const float recv = att ? recv0 : 0.f;
 
     STAMPX(11);
@@ -1638,6 +1738,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 if (!(tid & 1)) dqp[tid >> 1] = f2bf2(sacc, nb);
             } else if (tid < 2 * A) {
                 a.duRows[(size_t)b * A + (tid - A)] = qd + sacc;
+                ducar = qd + sacc;
             }
         }
         lds_barrier();
@@ -1658,24 +1759,32 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         lds_barrier();
     }
     STAMPX(18);
-    if (cel && tid < D) {   // gate backward of step t_cell
+    if (cel && tid < D) {   // gate backward of step t_cell (D % 4 == 0: whole 4-lane groups)
         const float dh = dhs[tid] + recv + dhl;
-        // FUSED: two parities -- product workgroups of this launch whose columns carry no granules may still be reading
-        // the previous step's gate gradient
-        unsigned short* gb = a.dgbf + (FUSED ? (size_t)(t_cell & 1) * B * GD : 0) + (size_t)b * GD;
+        unsigned short* gb = a.dgbf + (size_t)b * GD;
+        const __amdgpu_buffer_rsrc_t grs = granule_rsrc(a.lp.gA);     // LOOP: the bf16 copy leaves as granules (tag t_cell + 1)
+        const size_t gg0 = (size_t)b * a.lp.gA_row;
+        const unsigned gtag = (unsigned)t_cell + 1u;
         if (CELL == LAS_CELL_LSTM) {
             const float gi = gs[0], gj = gs[1], gf = gs[2], go = gs[3];
             const float tc = tanhx<FAST>(cv);
             const float dc = dcr + dh * go * (1.f - tc * tc);
             a.dC[(size_t)b * D + tid] = dc * gf;
+            dccar = dc * gf;
             const float di = dc * gj * gi * (1.f - gi), dj = dc * gi * (1.f - gj * gj);
             const float df = dc * cpv * gf * (1.f - gf), dO = dh * tc * go * (1.f - go);
             gp[tid] = di; gp[D + tid] = dj; gp[2 * D + tid] = df; gp[3 * D + tid] = dO;
-            gb[tid] = f2bf(di); gb[D + tid] = f2bf(dj); gb[2 * D + tid] = f2bf(df); gb[3 * D + tid] = f2bf(dO);
+            if (LOOP) {
+                put4_bf16(grs, gg0, tid, di, gtag, local); put4_bf16(grs, gg0, D + tid, dj, gtag, local);
+                put4_bf16(grs, gg0, 2 * D + tid, df, gtag, local); put4_bf16(grs, gg0, 3 * D + tid, dO, gtag, local);
+            } else {
+                gb[tid] = f2bf(di); gb[D + tid] = f2bf(dj); gb[2 * D + tid] = f2bf(df); gb[3 * D + tid] = f2bf(dO);
+            }
         } else {
             const float dp = dh * (1.f - hv * hv);
             gp[tid] = dp;
-            gb[tid] = f2bf(dp);
+            if (LOOP) put4_bf16(grs, gg0, tid, dp, gtag, local);
+            else gb[tid] = f2bf(dp);
         }
     }
     STAMPX(19);
@@ -1684,17 +1793,30 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
 template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    pf_bwd_row<CELL, NE, false>(a, t_att, t_cell, blockIdx.x, sm);
+    float dccar = 0.f, ducar = 0.f;
+    pf_bwd_row<CELL, NE, false>(a, t_att, t_cell, blockIdx.x, threadIdx.x, sm, dccar, ducar, false);
 }
 
-// one launch per gradient step: workgroups [0, nct) compute dXin0[t_att] = dG(t_att) . W0^T from the bf16 gate gradient
-// the previous launch left in dgbf (plain fp32 copy for the after-loop contractions + granules for the chain columns),
-// workgroups [nct, nct + B) are this step's row workgroups (see dec_step_fwd_fz_kernel)
+// the whole gradient loop in one launch (see dec_loop_fwd_kernel): the product workgroups compute
+// dXin0[t] = dG(t) . W0^T from the gate-gradient granules of step t (plain fp32 copy of every column for the after-loop
+// contractions + granules for the chain columns [E, I0D)), the row workgroups run attention backward of step t + 1 and
+// the gate backward of step t
 template <int CELL, int NE>
-__global__ __launch_bounds__(RNT) void dec_step_bwd_fz_kernel(DecDev a, int t_att, int t_cell) {
+__global__ __launch_bounds__(RNT) void dec_loop_bwd_kernel(DecDev a) {
+    constexpr int TPW = 3, KW = 4;                                    // 26 x 3 column tiles >= 64, 16 waves x 4 k-steps x 32 >= 2048 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    if ((int)blockIdx.x < a.sp.nct) { step_product(a.sp, blockIdx.x, (unsigned)t_att + 1u, sm); return; }
-    pf_bwd_row<CELL, NE, true>(a, t_att, t_cell, (int)blockIdx.x - a.sp.nct, sm);
+    const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x);
+    if (j < a.lp.pn) { loop_product<TPW, KW>(a.lp, a.U, true, x, j, local, sm); return; }
+    const int b = (j - a.lp.pn) * 8 + x;
+    if (b >= a.B) return;
+    float dccar = 0.f, ducar = 0.f;
+    for (int t = a.U - 1; t >= -1; --t) {
+        int bb = b, tid = threadIdx.x;
+        asm volatile("" : "+s"(bb), "+v"(tid));                       // see dec_loop_fwd_kernel
+        pf_bwd_row<CELL, NE, true>(a, (t + 1 < a.U) ? t + 1 : -1, t, bb, tid, sm, dccar, ducar, local);
+        lds_barrier();
+    }
 }
 
 // dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)
@@ -1744,7 +1866,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, granF, granB, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -1753,9 +1875,12 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.packF = o;  o += align256(las_skinny_pack_bytes((int)I0D, G * D));      // W0 fragments (step product)
     w.packB = o;  o += align256(las_skinny_pack_bytes(G * D, (int)I0D));      // W0^T fragments (step gradient)
     w.xbf = o;    o += align256((size_t)B * I0D * 2);
-    w.dgbf = o;   o += align256((size_t)2 * B * G * D * 2);                   // two step parities (fused step kernels)
-    w.granF = o;  o += align256((size_t)B * (G * D / 2) * 16);                // gate granules of the fused forward step
-    w.granB = o;  o += align256((size_t)B * ((Hd + D) / 2) * 16);             // dXin0 chain columns of the fused gradient step
+    w.dgbf = o;   o += align256((size_t)B * G * D * 2);
+    w.granX = o;  o += align256((size_t)B * (I0D / 4 + 1) * 16);              // loop kernels: cell input rows (4 bf16 per granule)
+    w.granF = o;  o += align256((size_t)B * (G * D / 2) * 16);                //               pre-activation gates (2 fp32 per granule)
+    w.granG = o;  o += align256((size_t)B * (G * D / 4) * 16);                //               gate gradients (4 bf16 per granule)
+    w.granB = o;  o += align256((size_t)B * ((Hd + D) / 2) * 16);             //               dXin0 chain columns (2 fp32 per granule)
+    w.xccs = o;   o += align256(256 * 8);                                         //               placement handshake slots
     w.wsbf = o;   o += align256((size_t)D * NL * A * 2);
     w.wsbf2 = o;  o += align256((size_t)(D * NL + 1) * A * 2);
     w.keysbf = o; o += align256((size_t)B * Tp * A * 2);
@@ -1813,7 +1938,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
-    d.sp = StepProd{};
+    d.lp = LoopProd{};
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
@@ -1832,11 +1957,35 @@ static bool pf_rows_ok(const DecDev& d) {
     return !(d.flags & LAS_SPELLER_NO_PF_ROWS) && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 &&
            d.E <= 1024 && (d.E % 2) == 0 && (d.D % 2) == 0;
 }
-// ... and one launch per step: the product workgroups and the row workgroups of a step must all be co-resident
-static bool fused_step_ok(const DecDev& d, int nct) {
-    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && pf_rows_ok(d) && cdiv(d.B, 16) <= 15 && nct + d.B <= las_device_cus() &&
-           (d.E % 2) == 0 && ((d.E + d.Hd + d.D) % 8) == 0;
+// ... and the whole loop in one launch: 8 groups of pn product + R row workgroups, all co-resident (one per compute unit),
+// tpw column tiles per product workgroup and kw k-steps per product wave as instantiated in the kernels
+constexpr int LOOP_TPW_F = 5, LOOP_KW_F = 3, LOOP_TPW_B = 3, LOOP_KW_B = 4;
+static bool loop_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
+    const int R = cdiv(d.B, 8), pn = las_device_cus() / 8 - R;
+    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && pf_rows_ok(d) && (d.E % 4) == 0 && (d.D % 4) == 0 && (d.Hd % 4) == 0 &&
+           ((d.E + d.Hd + d.D) % 8) == 0 && (K % 8) == 0 && R <= 16 && pn >= 1 && pn + R <= 32 && pn * tpw >= cdiv(ncols, 16) &&
+           16 * kw >= cdiv(K, 32);
 }
+static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
+    p.KS = cdiv(K, 32); p.K = K; p.N = ncols; p.nct = cdiv(ncols, 16); p.M = B; p.R = cdiv(B, 8);
+    p.pn = las_device_cus() / 8 - p.R;
+}
+template <class K> static int loop_lds_attr(K kernel) {   // the product workgroups' partial tiles need > 64 KB of dynamic LDS
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+#define LAS_LOOP_LAUNCH1(KERNEL, CELL, NE, grid, lds, st, d)                                               \
+    do {                                                                                                   \
+        static int attr__ = loop_lds_attr(KERNEL<CELL, NE>);                                               \
+        if (attr__ != 0) { las_set_error("hipFuncSetAttribute(speller loop) failed: %d", attr__); return attr__; } \
+        hipLaunchKernelGGL((KERNEL<CELL, NE>), grid, dim3(RNT), lds, st, d);                               \
+    } while (0)
+#define LAS_LOOP_LAUNCH(KERNEL, CELL, Tp, grid, lds, st, d)                                                \
+    do {                                                                                                   \
+        if ((Tp) <= 128)      LAS_LOOP_LAUNCH1(KERNEL, CELL, 8, grid, lds, st, d);                         \
+        else if ((Tp) <= 160) LAS_LOOP_LAUNCH1(KERNEL, CELL, 10, grid, lds, st, d);                        \
+        else if ((Tp) <= 192) LAS_LOOP_LAUNCH1(KERNEL, CELL, 12, grid, lds, st, d);                        \
+        else                  LAS_LOOP_LAUNCH1(KERNEL, CELL, 14, grid, lds, st, d);                        \
+    } while (0)
 static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
     unsigned short* wsb = (unsigned short*)(base + w.wsbf);
     unsigned short* kb = (unsigned short*)(base + w.keysbf);
@@ -1881,25 +2030,23 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
-    const int nctF = cdiv(GD, 16);
-    const bool fused = pf && fused_step_ok(d, nctF);
-    size_t lds_fz = lds_bf < 16384 ? 16384 : lds_bf;         // the product workgroups' 16 partial tiles
-    if (fused) {
-        d.sp.A = d.xbf; d.sp.lda = I0D; d.sp.M = B; d.sp.K = I0D;
-        d.sp.Bp = reinterpret_cast<const u16x8_t*>(packF); d.sp.KS = cdiv(I0D, 32); d.sp.N = GD; d.sp.nct = nctF;
-        d.sp.bias = f->cellb[0]; d.sp.C = nullptr; d.sp.ldc = 0;
-        d.sp.gran = (unsigned long long*)((char*)f->ws + wl_.granF); d.sp.gcol0 = 0; d.sp.gpr = GD / 2;
-        LAS_HIP(hipMemsetAsync(d.sp.gran, 0, (size_t)B * (GD / 2) * 16, st));      // tags of an earlier call must not match
+    const bool loop = pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F);
+    if (loop) {   // the whole loop in one launch
+        const size_t lds_pr = (size_t)RNW * LOOP_TPW_F * 1024;       // the product workgroups' partial tiles (80 KB)
+        const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
+        loop_prod_dims(d.lp, B, GD, I0D);
+        d.lp.Bp = reinterpret_cast<const u16x8_t*>(packF); d.lp.bias = f->cellb[0]; d.lp.C = nullptr; d.lp.c_step = 0; d.lp.ldc = 0;
+        d.lp.gA = (unsigned long long*)((char*)f->ws + wl_.granX); d.lp.gA_row = I0D / 4;
+        d.lp.gC = (unsigned long long*)((char*)f->ws + wl_.granF); d.lp.gC_row = GD / 2;
+        d.lp.xcc = (unsigned long long*)((char*)f->ws + wl_.xccs);
+        LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (I0D / 4) * 16, st));        // tags of an earlier call must not match
+        LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * (GD / 2) * 16, st));
+        LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
+        LAS_LOOP_LAUNCH(dec_loop_fwd_kernel, CELL, d.Tp, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
+        LAS_LAUNCHED();
     }
-    for (int t = 0; t <= U; ++t) {
-        if (fused && t > 0) {
-            const dim3 grid(nctF + B);
-            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 8>), grid, dim3(RNT), lds_fz, st, d, t);
-            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 10>), grid, dim3(RNT), lds_fz, st, d, t);
-            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 12>), grid, dim3(RNT), lds_fz, st, d, t);
-            else                  hipLaunchKernelGGL((dec_step_fwd_fz_kernel<CELL, 14>), grid, dim3(RNT), lds_fz, st, d, t);
-        }
-        else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+    for (int t = 0; t <= U && !loop; ++t) {
+        if (pf && d.Tp <= 128)          hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, d, t);
@@ -1909,7 +2056,6 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         else                            hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
-        if (fused) continue;                               // the next launch carries this step's cell product
         if (skinny) {
             GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD, f->cellb[0], st));
         } else {
@@ -1975,7 +2121,14 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
     }
-    if (skinny && (part & 1)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));   // B[k=gate col][n=input row] = W0[n][k]
+    // the whole loop in one launch: the in-loop product covers the chain columns [E, I0D) only (every product workgroup then
+    // feeds granules to the rows, which is what makes the single-buffered exchange safe); the embedding columns of dXin0 are
+    // one tall contraction after the loop (part 2)
+    const bool loop = pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B);
+    if (skinny && (part & 1)) {   // B[k = gate col][n = input row] = W0[n][k]
+        if (loop) GEMM_OK(las_skinny_pack(f->cellW[0] + (size_t)E * GD, GD, GD, Hd + D, 1, packB, st));
+        else      GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));
+    }
     if (part & 1) {
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;   // rebased per step below
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
@@ -1989,31 +2142,26 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         GEMM_OK(las_gemm(prec, 0, 0, U * B, A, D, 1.f, d.hs + (size_t)l * (U + 1) * B * D, D, 0, d.Ws + (size_t)l * D * A, A, 0,
                          l ? 1.f : 0.f, d.Q, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
 
-    const int nctB = cdiv(I0D, 16);
-    const bool fused = pf && fused_step_ok(d, nctB);
-    const size_t lds_fz = lds_bf < 16384 ? 16384 : lds_bf;
-    if (fused) {
-        d.sp.lda = GD; d.sp.M = B; d.sp.K = GD;
-        d.sp.Bp = reinterpret_cast<const u16x8_t*>(packB); d.sp.KS = cdiv(GD, 32); d.sp.N = I0D; d.sp.nct = nctB;
-        d.sp.bias = nullptr; d.sp.ldc = I0D;
-        d.sp.gran = (unsigned long long*)(base + w.granB); d.sp.gcol0 = E; d.sp.gpr = (Hd + D) / 2;
-        LAS_HIP(hipMemsetAsync(d.sp.gran, 0, (size_t)B * ((Hd + D) / 2) * 16, st));
+    if (loop) {
+        const size_t lds_pr = (size_t)RNW * LOOP_TPW_B * 1024;
+        const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
+        loop_prod_dims(d.lp, B, Hd + D, GD);
+        d.lp.Bp = reinterpret_cast<const u16x8_t*>(packB); d.lp.bias = nullptr;
+        d.lp.C = d.dXin0 + E; d.lp.c_step = (long long)B * I0D; d.lp.ldc = I0D;
+        d.lp.gA = (unsigned long long*)(base + w.granG); d.lp.gA_row = GD / 4;
+        d.lp.gC = (unsigned long long*)(base + w.granB); d.lp.gC_row = (Hd + D) / 2;
+        d.lp.xcc = (unsigned long long*)(base + w.xccs);
+        LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (GD / 4) * 16, st));
+        LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * ((Hd + D) / 2) * 16, st));
+        LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
+        LAS_LOOP_LAUNCH(dec_loop_bwd_kernel, CELL, Tp, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
+        LAS_LAUNCHED();
     }
-    for (int t = U - 1; t >= -1; --t) {
+    for (int t = U - 1; t >= -1 && !loop; --t) {
         DecDev ds = d;
         if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
         const int ta = (t + 1 < U) ? t + 1 : -1;
-        if (fused && ta >= 0) {
-            // product: dXin0[ta] from the gate gradient of cell ta (parity ta & 1 of dgbf, written by the previous launch)
-            ds.sp.A = d.dgbf + (size_t)(ta & 1) * B * GD;
-            ds.sp.C = d.dXin0 + (size_t)ta * B * I0D;
-            const dim3 grid(nctB + B);
-            if (Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 8>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
-            else if (Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 10>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
-            else if (Tp <= 192) hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 12>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
-            else                hipLaunchKernelGGL((dec_step_bwd_fz_kernel<CELL, 14>), grid, dim3(RNT), lds_fz, st, ds, ta, t);
-        }
-        else if (pf && Tp <= 128) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
+        if (pf && Tp <= 128)      hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf && Tp <= 160) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf && Tp <= 192) hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
         else if (pf)              hipLaunchKernelGGL((dec_step_bwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, ds, ta, t);
@@ -2023,7 +2171,6 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         else          hipLaunchKernelGGL((dec_step_bwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, ds, (t + 1 < U) ? t + 1 : -1, t);
         LAS_LAUNCHED();
         if (t < 0) break;
-        if (fused) continue;                               // the next launch carries dG(t) . W0^T
         for (int l = TOP; l >= 0; --l) {
             const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
             if (l == 0 && skinny) {
@@ -2070,6 +2217,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
                      bk->dWv, V, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
     GEMM_OK(las_colsum(bk->dlogits, UB, V, V, 1.f, bk->dbv, gws, gws_bytes, st));
     GEMM_OK(las_colsum(d.duRows, B, A, A, 1.f, bk->du, gws, gws_bytes, st));
+    if (loop)   // dXin0[:, :, 0:E] = dG . W0[0:E, :]^T for all steps at once (the loop kernel left these columns out)
+        GEMM_OK(las_gemm(prec, 0, 1, UB, E, GD, 1.f, d.gates, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0, I0D, 0, nullptr, LAS_ACT_NONE, 1,
+                         0, 0, nullptr, 0, st));
     {
         float* epart = (float*)(base + w.embp);
         hipLaunchKernelGGL(emb_grad_kernel, dim3(V, EMB_CHUNKS), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D,

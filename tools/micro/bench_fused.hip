@@ -1,0 +1,100 @@
+// Standalone timing harness for the Speller step loops, two launches per step vs one (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I automatic-speech-recognition_amd/csrc tools/micro/bench_fused.hip -o /tmp/bench_fused   [-DLAS_ROW_STAMPS]
+#include "gemm.hip"
+#include "common.hip"
+#include "speller.hip"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+template <class T> static T* dalloc(size_t n, float fill = 0.01f) {
+    T* p; hipMalloc(&p, n * sizeof(T));
+    std::vector<T> h(n);
+    for (size_t i = 0; i < n; ++i) {
+        float v = fill * (float)((i * 2654435761u) % 2001) / 1000.f - fill;
+        if (sizeof(T) == 2) { unsigned int u; memcpy(&u, &v, 4); h[i] = (T)(u >> 16); } else h[i] = (T)v;
+    }
+    hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice);
+    return p;
+}
+
+int main(int argc, char** argv) {
+    const int nap = argc > 1 ? atoi(argv[1]) : 0;
+    const int B = 48, Tp = 160, Hd = 512, A = 128, D = 512, NL = 1, E = 128, V = 30, U = 191, G = 4;
+    const int I0D = E + Hd + D, GD = G * D;
+    DecDev d; memset(&d, 0, sizeof(d));
+    d.B = B; d.Tp = Tp; d.Hd = Hd; d.A = A; d.D = D; d.NL = NL; d.E = E; d.V = V; d.U = U; d.mode = LAS_ATT_ADD; d.fb = 1.f;
+    d.enc = dalloc<float>((size_t)B * Tp * Hd); d.keys = dalloc<float>((size_t)B * Tp * A);
+    std::vector<int> hl(B, Tp - 5); int* len; hipMalloc(&len, B * 4); hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice); d.enc_len = len;
+    d.Ws = dalloc<float>((size_t)D * A); d.u = dalloc<float>(A); d.emb = dalloc<float>((size_t)V * E);
+    d.Wv = dalloc<float>((size_t)D * V); d.bv = dalloc<float>(V);
+    std::vector<int> ht((size_t)U * B, 3); int* tok; hipMalloc(&tok, U * B * 4); hipMemcpy(tok, ht.data(), U * B * 4, hipMemcpyHostToDevice); d.tok_in = tok;
+    d.logits = dalloc<float>((size_t)U * B * V); d.alphas = dalloc<float>((size_t)U * B * Tp);
+    d.hs = dalloc<float>((size_t)(U + 1) * B * D); d.cs = dalloc<float>((size_t)(U + 1) * B * D);
+    d.gates = dalloc<float>((size_t)U * B * GD); d.xin0 = dalloc<float>((size_t)U * B * I0D);
+    d.xbf = dalloc<unsigned short>((size_t)B * I0D); d.dgbf = dalloc<unsigned short>((size_t)B * GD);
+    d.Wsbf = dalloc<unsigned short>((size_t)D * A); d.keysbf = dalloc<unsigned short>((size_t)B * Tp * A);
+    d.encbf = dalloc<unsigned short>((size_t)B * Tp * Hd);
+    d.Wsbf2 = dalloc<unsigned short>((size_t)D * A); d.encbf2 = dalloc<unsigned short>((size_t)B * Tp * Hd);
+    d.dE = dalloc<float>((size_t)U * B * Tp); d.dHl = dalloc<float>((size_t)U * B * D); d.dH = dalloc<float>((size_t)B * D);
+    d.dC = dalloc<float>((size_t)B * D); d.dXin0 = dalloc<float>((size_t)U * B * I0D); d.Q = dalloc<float>((size_t)U * B * A);
+    d.dQ = dalloc<float>((size_t)U * B * A); d.duRows = dalloc<float>((size_t)B * A);
+    d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;
+    const size_t lds = bf_lds_bytes(d), lds_lp = 16 * 5 * 1024;
+    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    void *packF, *packB; hipMalloc(&packF, las_skinny_pack_bytes(I0D, GD)); hipMalloc(&packB, las_skinny_pack_bytes(GD, I0D));
+    float* W0 = dalloc<float>((size_t)I0D * GD); float* b0 = dalloc<float>(GD);
+    unsigned long long *gX, *gF, *gG, *gB, *xcc; hipMalloc(&xcc, 256 * 8);
+    hipMalloc(&gX, (size_t)B * (I0D / 4) * 16); hipMalloc(&gF, (size_t)B * (GD / 2) * 16);
+    hipMalloc(&gG, (size_t)B * (GD / 4) * 16); hipMalloc(&gB, (size_t)B * ((Hd + D) / 2) * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int which = 0; which < 4; ++which) {
+        for (int rep = 0; rep < 3; ++rep) {
+            DecDev f = d;
+            if (which == 0 || which == 1) las_skinny_pack(W0, GD, I0D, GD, 0, packF, 0);
+            if (which == 2) las_skinny_pack(W0, GD, GD, I0D, 1, packB, 0);
+            if (which == 3) las_skinny_pack(W0 + (size_t)E * GD, GD, GD, Hd + D, 1, packB, 0);
+            if (which == 1) {
+                loop_prod_dims(f.lp, B, GD, I0D);
+                f.lp.Bp = (const u16x8_t*)packF; f.lp.bias = b0; f.lp.C = nullptr; f.lp.gA = gX; f.lp.gA_row = I0D / 4;
+                f.lp.gC = gF; f.lp.gC_row = GD / 2; f.lp.xcc = xcc; f.lp.nap = nap; hipMemsetAsync(xcc, 0, 256 * 8, 0);
+                hipMemsetAsync(gX, 0, (size_t)B * (I0D / 4) * 16, 0); hipMemsetAsync(gF, 0, (size_t)B * (GD / 2) * 16, 0);
+            }
+            if (which == 3) {
+                loop_prod_dims(f.lp, B, Hd + D, GD);
+                f.lp.Bp = (const u16x8_t*)packB; f.lp.bias = nullptr; f.lp.C = d.dXin0 + E; f.lp.c_step = (long long)B * I0D; f.lp.ldc = I0D;
+                f.lp.gA = gG; f.lp.gA_row = GD / 4; f.lp.gC = gB; f.lp.gC_row = (Hd + D) / 2; f.lp.xcc = xcc; f.lp.nap = nap; hipMemsetAsync(xcc, 0, 256 * 8, 0);
+                hipMemsetAsync(gG, 0, (size_t)B * (GD / 4) * 16, 0); hipMemsetAsync(gB, 0, (size_t)B * ((Hd + D) / 2) * 16, 0);
+            }
+            hipEventRecord(e0, 0);
+            if (which == 0) for (int t = 0; t <= U; ++t) {
+                hipLaunchKernelGGL((dec_step_fwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, f, t);
+                if (t < U) las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + (size_t)t * B * GD, GD, b0, 0);
+            }
+            if (which == 1) hipLaunchKernelGGL((dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            if (which == 2) for (int t = U - 1; t >= -1; --t) {
+                hipLaunchKernelGGL((dec_step_bwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, f, t + 1 < U ? t + 1 : -1, t);
+                if (t >= 0) las_skinny_gemm_bf16(d.dgbf, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, 0);
+            }
+            if (which == 3) hipLaunchKernelGGL((dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("%s : %.2f us/step  (%s, %d workgroups)\n", which == 0 ? "fwd two launches per step" : which == 1 ? "fwd one launch per loop " : which == 2 ? "bwd two launches per step" : "bwd one launch per loop ",
+                            ms * 1e3f / (U + 1), hipGetErrorString(hipGetLastError()), (which & 1) ? 8 * (f.lp.pn + f.lp.R) : B);
+#ifdef LAS_ROW_STAMPS
+            if (rep == 2 && (which == 1 || which == 3)) {   // last iteration of the loop: product (ct 0) and row 0 phases on one clock
+                unsigned long long hs[32];
+                hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
+                const int ids[2][12] = {{0, 1, 9, 2, 3, 4, 5, 6, 7, 8, 21, 23}, {10, 24, 11, 12, 14, 15, 17, 18, 19, 20, 21, 23}};
+                printf("  same-XCD groups: %d\n", (int)hs[31]);
+                const unsigned long long z = hs[ids[which == 3][0]];
+                for (int i = 0; i < 12; ++i) printf("  stamp %2d: %+7.2f us\n", ids[which == 3][i], ((double)hs[ids[which == 3][i]] - (double)z) * 0.01);
+            }
+#endif
+        }
+    }
+    return 0;
+}
