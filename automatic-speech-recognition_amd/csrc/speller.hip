@@ -1007,6 +1007,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
         for (int tl = 0; tl < TPW; ++tl) *reinterpret_cast<f32x4_t*>(red + ((size_t)(w * TPW + tl) * 64 + lane) * 4) = acc[tl];
         if (tid == 0 && blockIdx.x == 0) { STAMPQ(21); }
         __syncthreads();
+        if (tid == 0 && blockIdx.x == 0) { STAMPQ(22); }
         for (int idx = tid; idx < TPW * 256; idx += RNT) {            // whole waves: TPW * 256 is a multiple of 64
             const int tl = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15;
             const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;

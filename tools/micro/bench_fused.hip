@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
             if (rep == 2 && (which == 1 || which == 3)) {   // last iteration of the loop: product (ct 0) and row 0 phases on one clock
                 unsigned long long hs[32];
                 hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
-                const int ids[2][12] = {{0, 1, 9, 2, 3, 4, 5, 6, 7, 8, 21, 23}, {10, 24, 11, 12, 14, 15, 17, 18, 19, 20, 21, 23}};
+                const int ids[2][12] = {{0, 1, 9, 2, 3, 4, 5, 6, 8, 21, 22, 23}, {10, 24, 11, 12, 14, 15, 17, 19, 20, 21, 22, 23}};
                 printf("  same-XCD groups: %d\n", (int)hs[31]);
                 const unsigned long long z = hs[ids[which == 3][0]];
                 for (int i = 0; i < 12; ++i) printf("  stamp %2d: %+7.2f us\n", ids[which == 3][i], ((double)hs[ids[which == 3][i]] - (double)z) * 0.01);
