@@ -18,7 +18,7 @@ print("step window: %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
 
 
 def fam(n):
-    for k in ("rnn_seq_fwd", "rnn_seq_bwd", "dec_step_fwd", "dec_step_bwd", "skinny_rows", "gemm_bf16_fast", "gemm_bf16_kernel",
+    for k in ("rnn_seq_fwd", "rnn_seq_bwd", "dec_loop_fwd", "dec_loop_bwd", "gemm_kk", "dec_step_fwd", "dec_step_bwd", "skinny_rows", "gemm_bf16_fast", "gemm_bf16_kernel",
               "gemm_f32", "splitk", "colsum", "pack_whh", "ce_rows", "clip_adam", "sumsq", "dkeys", "emb_grad", "to_bf16", "pair_rows",
               "tanh_bwd", "skinny_pack"):
         if k in n:
