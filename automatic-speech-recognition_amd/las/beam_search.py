@@ -11,7 +11,10 @@ The host replays the launches and rebuilds the reference's `BeamState` objects f
 last step.
 
 Scores are RAW logits summed in float32 and ranked by sum/len, as the reference does."""
+import collections.abc
 import ctypes
+
+import os
 
 import numpy as np
 import torch
@@ -37,6 +40,26 @@ class BeamState(object):
         return BeamState(self.token_ids + [token_id], self.log_prob + log_prob, self.att + [att], dec_state, lm_state)
 
 
+class _AttRows(collections.abc.Sequence):
+    """`BeamState.att` of a hypothesis returned by decode_batch: item i is the alignment that produced token i (item 0 = zeros,
+    las/beam_search.py:88), all items views of ONE [len, T'] tensor gathered from the device-side history in a single
+    indexing operation -- building a Python list of 200 slices per hypothesis was a third of the decode time."""
+
+    def __init__(self, rows):
+        self._rows = rows
+
+    def __len__(self):
+        return self._rows.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return list(self._rows[i].unbind(0))
+        return self._rows[i]
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+
 class BeamSearch(object):
     """reference las/beam_search.py:32-312."""
 
@@ -55,6 +78,7 @@ class BeamSearch(object):
         if args.apply_lm:
             self.lm = language_model
         self._las = las
+        self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
 
     # -- model calls (the reference's sess.run wrappers, las/beam_search.py:203-246) -------------------
     def _get_encode(self, sess, audio, audiolen):
@@ -102,14 +126,31 @@ class BeamSearch(object):
         prec = L._prec()
         P = sp._params()
         # ---- encoders (one per utterance) and the hoisted key projection
-        encs, enc_lens, dec_steps = [], [], []
-        for audio, audiolen in xs_list:
+        import time
+        tm = {}
+        def mark(name):                                  # wall-clock marks (with a device sync) only when asked for
+            if os.environ.get("LAS_DECODE_TIMING") == "1":
+                torch.cuda.synchronize(dev)
+                tm[name] = time.perf_counter()
+        mark("start")
+        encs, enc_lens, dec_steps = [None] * n, [None] * n, []
+        groups = {}
+        for u, (audio, audiolen) in enumerate(xs_list):
             if len(audio) != 1:
                 raise ValueError('every entry of xs_list is one utterance: audio [1,T,feat_dim,3]')
+            al = np.asarray(audiolen).reshape(-1)
+            groups.setdefault((tuple(np.shape(audio)[1:]), float(al[0])), []).append(u)
+            dec_steps.append(int(al[0] * a.convert_rate))                                       # las/beam_search.py:78
+        for us in groups.values():
+            # utterances of the SAME shape and length share one encoder launch: every row of the encoder is computed
+            # independently of the other rows, so this is exactly the one-at-a-time result (unlike padding, see above)
+            audio = np.concatenate([np.asarray(xs_list[u][0]) for u in us], 0)
+            audiolen = np.concatenate([np.asarray(xs_list[u][1]).reshape(-1)[:1] for u in us], 0)
             h, enc_len = self._get_encode(sess, audio, audiolen)
-            encs.append(h)
-            enc_lens.append(float(torch.as_tensor(enc_len).reshape(-1)[0]))
-            dec_steps.append(int(np.asarray(audiolen).reshape(-1)[0] * a.convert_rate))       # las/beam_search.py:78
+            el = torch.as_tensor(enc_len).reshape(-1)
+            for i, u in enumerate(us):
+                encs[u] = h[i:i + 1]
+                enc_lens[u] = float(el[i])
         Tps = [h.shape[1] for h in encs]
         Tp, Hd = max(Tps), encs[0].shape[2]
         N = n * beam
@@ -142,7 +183,7 @@ class BeamSearch(object):
         sel_j = torch.zeros(n, selcap, **i32)
         src_row = torch.zeros(n, beam, **i32)
         next_token = torch.full((N,), self.start_id, **i32)
-        alphas_hist = torch.zeros(Umax, N, Tp, device=dev)
+        alphas_hist = torch.zeros(Umax + 1, N, Tp, device=dev)      # [Umax] stays zero: item 0 of every hypothesis' att
         align_prev = torch.zeros(N, Tp, device=dev)
         # ---- the fused Speller step for all rows: slot 0 of hs / cs = state entering the step, slot 1 = state leaving it
         dims = sp._dims(N, Tp, 1)
@@ -186,51 +227,100 @@ class BeamSearch(object):
         ba.start_id, ba.end_id, ba.ntens = self.start_id, self.end_id, len(st_in)
         for k, (ti, to) in enumerate(zip(st_in, st_out)):
             ba.state_in[k], ba.state_out[k], ba.state_width[k] = ti.data_ptr(), to.data_ptr(), ti.shape[-1]
-        stream = _hip.stream()
         lm_w = np.float32(a.lm_weight) if lm is not None else None
+        mark("encoded")
+        # the step's alignments land in a fixed buffer and are filed under the DEVICE step counter, so that one step is the
+        # same sequence of launches with the same arguments every time: it is captured into a HIP graph after the first
+        # (eager) step and replayed -- the loop is bound by the host's launch rate otherwise (~25 launches per step)
+        alphas_cur = torch.zeros(N, Tp, device=dev)
+        step64 = torch.zeros(1, dtype=torch.int64, device=dev)
+        fa.alphas = alphas_cur.data_ptr()
+        ba.state_in[k_align] = alphas_cur.data_ptr()
+        held = []
+
+        def one_step():
+            stream = _hip.stream()
+            _hip.check(lib.las_speller_fwd(ctypes.byref(fa), stream), "las_speller_fwd")
+            if lm is not None:
+                # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
+                # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
+                lm_ids = (next_token.to(torch.int64) - 2).clamp_min_(0)
+                lm_out, cs_new, hs_new = lm.step_tensors(lm_ids, lm_c, lm_h)
+                logits[:, 2:] += lm_out * lm_w
+                for l in range(NLl):
+                    ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
+                held[:] = [cs_new, hs_new, lm_out]                                # alive until the gather has been enqueued
+            alphas_hist.index_copy_(0, step64, alphas_cur.unsqueeze(0))
+            _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), stream), "las_beam_loop_step")
+            step64.copy_(step)
+
         steps_run = 0
+        graph = None
+        use_graph = self.use_graph and Umax > 2
         with torch.no_grad():
             for t in range(Umax):
-                fa.alphas = alphas_hist[t].data_ptr()
-                _hip.check(lib.las_speller_fwd(ctypes.byref(fa), stream), "las_speller_fwd")
-                if lm is not None:
-                    # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
-                    # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-                    lm_ids = (next_token.to(torch.int64) - 2).clamp_min_(0)
-                    lm_out, cs_new, hs_new = lm.step_tensors(lm_ids, lm_c, lm_h)
-                    logits[:, 2:] += lm_out * lm_w
-                    for l in range(NLl):
-                        ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
-                    held = (cs_new, hs_new, lm_out)                                   # alive until the gather has been enqueued
-                ba.state_in[k_align] = alphas_hist[t].data_ptr()
-                _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), stream), "las_beam_loop_step")
+                if graph is not None:
+                    graph.replay()
+                elif use_graph and t == 1:
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            one_step()
+                        graph = g                      # (capturing does not execute: the captured step runs as the replay)
+                        graph.replay()
+                    except Exception as e:             # capture refused (e.g. an op that allocates host memory): stay eager
+                        use_graph = False
+                        torch.cuda.synchronize(dev)
+                        if self.args.verbose > 0:
+                            print("decode_batch: graph capture failed, running eagerly: %s" % e)
+                        one_step()
+                else:
+                    one_step()
                 steps_run = t + 1
                 if (t + 1) % sync_every == 0 and bool(done.all()):                      # the only host wait inside the loop
                     break
         del keep
+        mark("searched")
         # ---- one read-back, then the reference's host-side objects
-        hp, ht, hsl = hist_parent[:steps_run].cpu().numpy(), hist_token[:steps_run].cpu().numpy(), hist_slot[:steps_run].cpu().numpy()
+        hp, ht, hsl = hist_parent[:steps_run].cpu().tolist(), hist_token[:steps_run].cpu().tolist(), hist_slot[:steps_run].cpu().tolist()
         hsc = hist_score[:steps_run].cpu().numpy()
-        st_, sj_, ns_ = sel_t.cpu().numpy(), sel_j.cpu().numpy(), nsel.cpu().numpy()
+        st_, sj_, ns_ = sel_t.cpu().tolist(), sel_j.cpu().tolist(), nsel.cpu().tolist()
         _hip.check_status(dev)
-        results = []
+        walks = []                                           # (utterance, ids, score, [time indices], [row indices]) per selected hypothesis
         for u in range(n):
-            selected = []
+            hp_u = [row[u] for row in hp]
+            ht_u = [row[u] for row in ht]
+            hsl_u = [row[u] for row in hsl]
             for s_i in range(min(int(ns_[u]), selcap)):
-                t_s, j_s = int(st_[u, s_i]), int(sj_[u, s_i])
-                ids, rows = [], []
+                t_s, j_s = st_[u][s_i], sj_[u][s_i]
+                ids, tts, rows = [], [], []
                 tt, j = t_s, j_s
-                while True:
-                    ids.append(int(ht[tt, u, j]))
-                    slot = int(hp[tt, u, j])
-                    rows.append((tt, u * beam + slot))
+                while True:                                  # walk the back pointers (plain Python ints: this loop is hot)
+                    ids.append(ht_u[tt][j])
+                    slot = hp_u[tt][j]
+                    tts.append(tt)
+                    rows.append(u * beam + slot)
                     if tt == 0:
                         break
-                    j = int(hsl[tt - 1, u, slot])
+                    j = hsl_u[tt - 1][slot]
                     tt -= 1
-                att = [torch.zeros(Tps[u], device=dev)] + [alphas_hist[tt_, r, :Tps[u]] for tt_, r in reversed(rows)]
-                selected.append(BeamState([self.start_id] + ids[::-1], np.float32(hsc[t_s, u, j_s]), att, None, None))
-            results.append(self._select_best_k(selected, NORM))
+                walks.append((u, [self.start_id] + ids[::-1], np.float32(hsc[t_s, u, j_s]), [Umax] + tts[::-1], [0] + rows[::-1]))
+        # every hypothesis' alignments in ONE gather ([Umax] is the all-zero slab: item 0)
+        if walks:
+            ti = torch.tensor([t_ for w_ in walks for t_ in w_[3]], dtype=torch.int64).to(dev)
+            ri = torch.tensor([r_ for w_ in walks for r_ in w_[4]], dtype=torch.int64).to(dev)
+            g_att = alphas_hist[ti, ri]
+        results, off = [[] for _ in range(n)], 0
+        for u, ids, sc, tts, rows in walks:
+            results[u].append(BeamState(ids, sc, _AttRows(g_att[off:off + len(tts), :Tps[u]]), None, None))
+            off += len(tts)
+        results = [self._select_best_k(sel, NORM) for sel in results]
+        mark("done")
+        if tm:
+            ks = list(tm)
+            self.last_timing = {ks[i + 1]: round(tm[ks[i + 1]] - tm[ks[i]], 4) for i in range(len(ks) - 1)}
+            self.last_timing["steps"] = steps_run
+            print("decode_batch timing (s):", self.last_timing)
         return results
 
     def restore_las(self, sess, save_path, restore_epoch):

@@ -186,8 +186,9 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     steps = max(len(r[-1].token_ids) - 1 for r in res)
     return {"value": round(nutt / dt, 2), "unit": "utterances/s", "beam": beam, "lm": "2x512 char RNNLM, lm_weight 0.5",
             "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 3),
-            "note": "encoders run one utterance at a time (the reference encoder has no length mask: padding would change the "
-                    "result); the search runs all utterances x beam rows per step on the device"}
+            "note": "utterances of equal length share one encoder launch (rows are independent; the reference encoder has no length "
+                    "mask, so utterances are never padded to a common length); the search runs all utterances x beam rows per "
+                    "step on the device, one captured step replayed as a HIP graph"}
 
 
 def self_launch(n, argv):
