@@ -1992,6 +1992,11 @@ static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st)
     unsigned short* kb = (unsigned short*)(base + w.keysbf);
     unsigned short* eb = (unsigned short*)(base + w.encbf);
     const size_t nW = (size_t)d.D * d.NL * d.A, nK = (size_t)d.B * d.Tp * d.A, nE = (size_t)d.B * d.Tp * d.Hd;
+    if (d.flags & LAS_SPELLER_REUSE_PREP) {   // the caller vouches that an earlier call left the copies of the SAME tensors here
+        d.Wsbf = wsb; d.keysbf = kb; d.encbf = eb;
+        d.Wsbf2 = (unsigned short*)(base + w.wsbf2); d.encbf2 = (unsigned short*)(base + w.encbf2);
+        return 0;
+    }
     hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nW, 1024)), dim3(256), 0, st, d.Ws, wsb, nW);
     hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nK, 2048)), dim3(256), 0, st, d.keys, kb, nK);
     hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nE, 2048)), dim3(256), 0, st, d.enc, eb, nE);
@@ -2030,7 +2035,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         LAS_ARG(lds_bf <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
-    if (skinny) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
+    if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     const bool loop = pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F);
     if (loop) {   // the whole loop in one launch
         const size_t lds_pr = (size_t)RNW * LOOP_TPW_F * 1024;       // the product workgroups' partial tiles (80 KB)

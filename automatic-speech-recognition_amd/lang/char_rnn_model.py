@@ -244,6 +244,56 @@ class CharRNN(object):
                       self.vocab_size, bias=P["softmax_b"].detach())
         return logits, cs, hs
 
+    def fusion_plan(self, lm_weight):
+        """Constants of a beam search with shallow fusion (made once per search): the first layer's input rows for the
+        one-hot case (W_x[id], rounded like a bf16 GEMM operand in speed mode) and the output projection pre-scaled by
+        lm_weight, so that the step can ADD lm_weight * lm_logits into the acoustic logits with the GEMM's own beta."""
+        P = self.params()
+        k0 = P["cells"][0][0].detach()
+        plan = {"w": float(lm_weight)}
+        if self.embedding_size == 0:
+            wx = k0[:self.vocab_size]
+            plan["wx"] = (wx.to(torch.bfloat16).to(torch.float32) if L._prec() == _hip.PREC_BF16 else wx).contiguous()
+        plan["sw"] = (P["softmax_w"].detach() * plan["w"]).contiguous()
+        plan["sb"] = (P["softmax_b"].detach() * plan["w"]).contiguous()
+        return plan
+
+    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0):
+        """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM ids), the result is
+        ACCUMULATED into logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input
+        and recurrent halves of every cell product are separate GEMMs against row blocks of the TF kernel.
+        Returns (c_new list, h_new list)."""
+        P = self.params()
+        dev = logits.device
+        N, H, Vn = ids.shape[0], self.hidden_size, self.vocab_size
+        prec = L._prec()
+        lib = _hip.lib()
+        cs, hs = [], []
+        x = None
+        with torch.no_grad():
+            for l, (k, b) in enumerate(P["cells"]):
+                k, b = k.detach(), b.detach()
+                I = k.shape[0] - H
+                z = torch.empty(N, 4 * H, device=dev)
+                # recurrent half (+ bias), then the input half on top
+                _hip.gemm(prec, h_prev[l], k, z, False, False, N, 4 * H, H, H, 4 * H, 4 * H, bias=b, b_off=I * 4 * H)
+                if l == 0 and "wx" in plan:
+                    z += plan["wx"].index_select(0, ids)
+                else:
+                    if l == 0:
+                        x = P["embedding"].detach().index_select(0, ids)
+                    _hip.gemm(prec, x, k, z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, beta=1.0)
+                c_new = torch.empty(N, H, device=dev)
+                h_new = torch.empty(N, H, device=dev)
+                _hip.check(lib.las_lstm_pointwise(_hip.p(z), _hip.p(c_prev[l]), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
+                                                  _hip.stream()), "las_lstm_pointwise")
+                cs.append(c_new)
+                hs.append(h_new)
+                x = h_new
+            V_all = logits.shape[1]
+            _hip.gemm(prec, x, plan["sw"], logits, False, False, N, Vn, H, H, Vn, V_all, beta=1.0, bias=plan["sb"], c_off=col0)
+        return cs, hs
+
     def step(self, token_ids, states):
         """token_ids [N] (LM ids), states: list over hypotheses of tuple over layers of (c,h) rows.
         Returns (logits [N,V_lm], list over hypotheses of new states)."""

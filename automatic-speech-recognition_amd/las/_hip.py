@@ -319,7 +319,7 @@ class _timed:
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES = 1, 2, 4
-SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP = 1, 2, 4
+SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP = 1, 2, 4, 8
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound",
               2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
 

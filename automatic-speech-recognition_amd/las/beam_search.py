@@ -238,21 +238,31 @@ class BeamSearch(object):
         ba.state_in[k_align] = alphas_cur.data_ptr()
         held = []
 
-        def one_step():
-            stream = _hip.stream()
-            _hip.check(lib.las_speller_fwd(ctypes.byref(fa), stream), "las_speller_fwd")
-            if lm is not None:
-                # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
-                # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-                lm_ids = (next_token.to(torch.int64) - 2).clamp_min_(0)
-                lm_out, cs_new, hs_new = lm.step_tensors(lm_ids, lm_c, lm_h)
-                logits[:, 2:] += lm_out * lm_w
-                for l in range(NLl):
-                    ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
-                held[:] = [cs_new, hs_new, lm_out]                                # alive until the gather has been enqueued
+        def speller_part():
+            _hip.check(lib.las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+            fa.flags |= _hip.SPELLER_REUSE_PREP      # enc / keys / weights are fixed for the search: their bf16 copies are made once
+
+        lm_plan = lm.fusion_plan(lm_w) if lm is not None else None
+
+        def lm_part():
+            # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
+            # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
+            lm_ids = (next_token - 2).clamp_min_(0)
+            cs_new, hs_new = lm.step_fused(lm_plan, lm_ids, lm_c, lm_h, logits, 2)
+            for l in range(NLl):
+                ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
+            held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued
+
+        def beam_part():
             alphas_hist.index_copy_(0, step64, alphas_cur.unsqueeze(0))
-            _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), stream), "las_beam_loop_step")
+            _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")
             step64.copy_(step)
+
+        def one_step():
+            speller_part()
+            if lm is not None:
+                lm_part()
+            beam_part()
 
         steps_run = 0
         graph = None
@@ -316,6 +326,22 @@ class BeamSearch(object):
             off += len(tts)
         results = [self._select_best_k(sel, NORM) for sel in results]
         mark("done")
+        if tm and os.environ.get("LAS_DECODE_PARTS") == "1":        # development aid: device time of the three parts of a step
+            step.zero_(); step64.zero_()
+            for name, fn in (("speller", speller_part), ("lm", lm_part if lm is not None else None), ("beam", beam_part)):
+                if fn is None:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.no_grad():
+                    fn(); e0.record()
+                    for _ in range(50):
+                        fn()
+                        if name == "beam":
+                            step.zero_(); step64.zero_()
+                    e1.record()
+                torch.cuda.synchronize(dev)
+                tm_ = e0.elapsed_time(e1) / 50 * 1e3
+                print("decode step part %-8s %.1f us" % (name, tm_))
         if tm:
             ks = list(tm)
             self.last_timing = {ks[i + 1]: round(tm[ks[i + 1]] - tm[ks[i]], 4) for i in range(len(ks) - 1)}

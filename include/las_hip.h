@@ -180,8 +180,11 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates,
  */
 enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetching row kernels (generic bf16 rows) */
        LAS_SPELLER_NO_BF_ROWS = 2,    /* speed mode with the fp32-operand row kernels */
-       LAS_SPELLER_NO_FUSED_STEP = 4 }; /* speed mode with two launches per step (row kernel, then the cell product)
-                                           instead of the one-launch step kernels (product + rows, granule hand-off) */
+       LAS_SPELLER_NO_FUSED_STEP = 4,   /* speed mode with two launches per step (row kernel, then the cell product)
+                                           instead of the whole loop in one launch (product + row workgroups, granule hand-off) */
+       LAS_SPELLER_REUSE_PREP = 8 };    /* las_speller_fwd only: the workspace still holds the bf16 copies of enc / keys / Ws and the
+                                           packed cell weights that an earlier call made from the SAME tensors -- skip rebuilding
+                                           them (beam search calls the step U = 1 at a time against a fixed encoder output) */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
     int flags;                     /* LAS_SPELLER_* development / test switches, 0 in normal use */
