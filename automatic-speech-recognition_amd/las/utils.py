@@ -39,7 +39,6 @@ def edit_distance(s1, s2):
     reference las/utils.py:54-67 (float64 DP table, denominator = reference length).  The DP runs one
     numpy row at a time instead of the reference's O(n*m) Python loop."""
     n, m = len(s1), len(s2)
-    a = np.asarray([hash(x) for x in s1], dtype=np.int64) if n else np.zeros(0, np.int64)
     prev = np.arange(n + 1, dtype=np.float64)              # column j = 0
     for j in range(1, m + 1):
         cur = np.empty(n + 1, dtype=np.float64)
@@ -52,7 +51,6 @@ def edit_distance(s1, s2):
             run = min(cand[i - 1], run + 1.0)
             cur[i] = run
         prev = cur
-    del a
     return float(prev[-1]), n
 
 

@@ -114,7 +114,25 @@ def cpu_baseline_child(cell, budget_s=45.0):
     one(Bs)                                                 # warm-up at the chosen size
     ts = sorted(one(Bs) for _ in range(3))
     med = ts[1]
-    print(json.dumps({"value": round(Bs / med, 4), "unit": "utterances/s", "cores": ncores, "kind": "port",
+    # decode leg (BASELINE configs[4]): the oracle's beam search, beam 16 + 2x512 char RNNLM, ONE synthetic T=1274 utterance
+    dec = None
+    try:
+        from helpers import lm_params, oracle_lm, oracle_decode
+        dargs = bench_args(cell)
+        dargs.beam_size, dargs.apply_lm, dargs.lm_weight, dargs.convert_rate = 16, True, 0.5, 0.166
+        p0 = O.init_params(dargs, seed=0, cell=cell)
+        p0["Speller/decode/dense/bias"][2] = -1e4           # no hypothesis ends early: all int(T * convert_rate) = 211 steps, like the GPU leg
+        olm = (oracle_lm(lm_params(np.random.RandomState(8), 28, 0, 512, 2), 0, 2), 512, 2)
+        xs1, _ = synthetic_batch(1, T, 8, 30, seed=100)
+        t0 = time.time()
+        res = oracle_decode(xs1, p0, dargs, cell, 16, lm=olm, lm_weight=0.5)
+        dt = time.time() - t0
+        dec = {"value": round(1.0 / dt, 4), "unit": "utterances/s", "cores": ncores,
+               "sample": "oracle beam search (las/beam_search.py:61-158 restated, torch-CPU fp32), 1 utterance, %d steps, %.1f s"
+                         % (max(len(r.token_ids) - 1 for r in res), dt)}
+    except Exception as e:                                  # the train baseline must not depend on this leg
+        dec = {"value": None, "sample": "oracle decode failed: %s" % e}
+    print(json.dumps({"value": round(Bs / med, 4), "unit": "utterances/s", "cores": ncores, "kind": "port", "decode": dec,
                       "sample": "reference-equivalent CPU path (restated; TF unavailable offline): oracle train step of the "
                                 "reference graph as written (un-hoisted key projection, torch-CPU fp32, %s cells), B=%d of the "
                                 "same T=1274 workload, 1 warm-up + 3 timed steps, median %.2f s/step; %d of %d usable cores "
@@ -386,6 +404,9 @@ def main():
                 out["decode"] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cell)
+            cpu_dec = out["cpu_baseline"].pop("decode", None)          # the CPU decode leg rides along in the same child
+            if cpu_dec is not None and isinstance(out.get("decode"), dict):
+                out["decode"]["cpu_baseline"] = cpu_dec
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -101,3 +101,68 @@ def grad_errors(r):
         go, g = r["g_o"][n], r["grads"][n]
         out[n] = (g - go).abs().max().item() / max(go.abs().max().item(), 1e-3)
     return out
+
+
+# ---- char RNNLM / beam search through the oracle (shared by the beam tests and bench.py's CPU decode leg) ----
+def lm_params(rng, V_lm, E, H, NL):
+    p = {}
+    if E > 0:
+        p["lm/embedding"] = rng.uniform(-0.5, 0.5, (V_lm, E)).astype(np.float32)
+    for l in range(NL):
+        I = (E if E > 0 else V_lm) if l == 0 else H
+        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l] = rng.uniform(-0.3, 0.3, (I + H, 4 * H)).astype(np.float32)
+        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = rng.uniform(-0.1, 0.1, 4 * H).astype(np.float32)
+    p["lm/softmax/softmax_w"] = rng.uniform(-0.5, 0.5, (H, V_lm)).astype(np.float32)
+    p["lm/softmax/softmax_b"] = rng.uniform(-0.1, 0.1, V_lm).astype(np.float32)
+    return p
+
+
+def oracle_lm(p, E, NL):
+    import torch
+    from oracle import las_oracle as O
+    t = {k: torch.tensor(v) for k, v in p.items()}
+    lm = {"cells": [(t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
+                     t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l]) for l in range(NL)],
+          "softmax_w": t["lm/softmax/softmax_w"], "softmax_b": t["lm/softmax/softmax_b"]}
+    lm["embedding"] = t["lm/embedding"] if E > 0 else torch.eye(t["lm/softmax/softmax_w"].shape[1])
+    return lm
+
+
+def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0):
+    """BeamSearch.decode of ONE utterance through the oracle (CPU): xs = (audio [1,T,39,1|3], audiolen [1]); lm = (oracle_lm(...), H, NL)."""
+    import torch
+    from oracle import las_oracle as O
+    NL = args.num_dec_layers
+    po = O.to_torch(p0)
+    with torch.no_grad():
+        x = torch.tensor(xs[0]).reshape(1, -1, 39)
+        h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)
+        keys = h @ po["Speller/decode/attention/dense/kernel"]
+        emb = po["embedding/embedding_matrix"]
+
+        def step_fn(prev_ids, prev_al, states):
+            N = len(prev_ids)
+            stt = []
+            for l in range(NL):
+                if cell == "lstm":
+                    stt.append((torch.cat([s[l][0] for s in states]), torch.cat([s[l][1] for s in states])))
+                else:
+                    stt.append(torch.cat([s[l] for s in states]))
+            lg, ns, al = O.speller_decode(h.expand(N, -1, -1), el.repeat(N), stt, emb[torch.tensor(prev_ids)],
+                                          torch.tensor(np.stack(prev_al), dtype=torch.float32), po, args, cell, keys.expand(N, -1, -1))
+            outs = [tuple((ns[l][0][i:i + 1], ns[l][1][i:i + 1]) if cell == "lstm" else ns[l][i:i + 1] for l in range(NL))
+                    for i in range(N)]
+            return lg.numpy(), outs, al.numpy()
+        lm_fn, lm0 = None, None
+        if lm is not None:
+            olm, Hl, NLl = lm
+
+            def lm_fn(ids, states):
+                stt = [(torch.stack([s[l][0] for s in states]), torch.stack([s[l][1] for s in states])) for l in range(NLl)]
+                lo, ns = O.lm_step(torch.tensor(ids), stt, olm)
+                return lo.numpy(), [tuple((ns[l][0][i], ns[l][1][i]) for l in range(NLl)) for i in range(len(ids))]
+            lm0 = tuple((torch.zeros(Hl), torch.zeros(Hl)) for _ in range(NLl))
+        z = torch.zeros(1, args.dec_units)
+        init = tuple((z, z) if cell == "lstm" else z for _ in range(NL))
+        return O.beam_search(step_fn, init, h.shape[1], int(xs[1][0] * args.convert_rate), beam, 1, 2,
+                             lm_fn=lm_fn, lm_init=lm0, lm_weight=lm_weight)

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import helpers
-from helpers import make_args, synthetic_batch
+from helpers import make_args, synthetic_batch, lm_params, oracle_lm, oracle_decode
 
 pytestmark = pytest.mark.gpu
 
@@ -148,29 +148,6 @@ def test_attention_objects_match_oracle(mode):
     assert m.tolist() == [[1, 1, 0], [1, 1, 1], [1, 0, 0]]                                      # las/layers.py:182-186
 
 
-def _lm_params(rng, V_lm, E, H, NL):
-    p = {}
-    if E > 0:
-        p["lm/embedding"] = rng.uniform(-0.5, 0.5, (V_lm, E)).astype(np.float32)
-    for l in range(NL):
-        I = (E if E > 0 else V_lm) if l == 0 else H
-        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l] = rng.uniform(-0.3, 0.3, (I + H, 4 * H)).astype(np.float32)
-        p["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l] = rng.uniform(-0.1, 0.1, 4 * H).astype(np.float32)
-    p["lm/softmax/softmax_w"] = rng.uniform(-0.5, 0.5, (H, V_lm)).astype(np.float32)
-    p["lm/softmax/softmax_b"] = rng.uniform(-0.1, 0.1, V_lm).astype(np.float32)
-    return p
-
-
-def _oracle_lm(p, E, NL):
-    from oracle import las_oracle as O
-    t = {k: torch.tensor(v) for k, v in p.items()}
-    lm = {"cells": [(t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l],
-                     t["lm/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/bias" % l]) for l in range(NL)],
-          "softmax_w": t["lm/softmax/softmax_w"], "softmax_b": t["lm/softmax/softmax_b"]}
-    lm["embedding"] = t["lm/embedding"] if E > 0 else torch.eye(t["lm/softmax/softmax_w"].shape[1])
-    return lm
-
-
 @pytest.mark.parametrize("E", [0, 12])
 def test_char_rnnlm_step_matches_oracle(E):
     """R1: CharRNN inference step (lang/char_rnn_model.py:54-142) vs oracle.lm_step over 3 chained steps."""
@@ -180,11 +157,11 @@ def test_char_rnnlm_step_matches_oracle(E):
     V_lm, H, NL, N = 28, 32, 2, 5
     assert create_vocab()[2] == 28 and create_vocab()[0]['A'] == 2
     rng = np.random.RandomState(3)
-    p = _lm_params(rng, V_lm, E, H, NL)
+    p = lm_params(rng, V_lm, E, H, NL)
     L.set_precision("f32")
     st = V.reset_default_store(device="cuda"); st.load(p)
     lm = CharRNN(False, 1, 1, V_lm, H, embedding_size=E, num_layers=NL)
-    olm = _oracle_lm(p, E, NL)
+    olm = oracle_lm(p, E, NL)
     states = [lm.zero_state(1) for _ in range(N)]
     ostate = [(torch.zeros(N, H), torch.zeros(N, H)) for _ in range(NL)]
     for it in range(3):
@@ -210,13 +187,13 @@ def test_beam_search_with_lm_fusion_matches_oracle():
     xs, _ = synthetic_batch(1, 41, 8, 30, seed=4)
     p0 = O.init_params(args, seed=31, cell=cell)
     p0["Speller/decode/dense/bias"][2] = 0.3
-    plm = _lm_params(np.random.RandomState(8), 28, 0, 24, 2)
+    plm = lm_params(np.random.RandomState(8), 28, 0, 24, 2)
     L.set_cell(cell); L.set_precision("f32")
     st = V.reset_default_store(device="cuda"); st.load(p0); st.load(plm)
     las = LAS(args, Listener, Speller, CharEncoder().token_to_id)
     lm = CharRNN(False, 1, 1, 28, 24, embedding_size=0, num_layers=2)
     res = BeamSearch(args, las, CharEncoder().token_to_id, lm).decode(None, xs)
-    po = O.to_torch(p0); olm = _oracle_lm(plm, 0, 2)
+    po = O.to_torch(p0); olm = oracle_lm(plm, 0, 2)
     with torch.no_grad():
         x = torch.tensor(xs[0]).reshape(1, -1, 39)
         h, el = O.pblstm_listener(x, xs[1], po, 2, cell)

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import helpers
-from helpers import make_args, synthetic_batch
+from helpers import make_args, synthetic_batch, lm_params, oracle_lm, oracle_decode
 
 pytestmark = pytest.mark.gpu
 
@@ -120,44 +120,6 @@ def test_device_loop_four_utterances_in_one_launch_reproduce_the_goldens(golden)
         _assert_matches(g, c)
 
 
-def _oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0):
-    from oracle import las_oracle as O
-    NL = args.num_dec_layers
-    po = O.to_torch(p0)
-    with torch.no_grad():
-        x = torch.tensor(xs[0]).reshape(1, -1, 39)
-        h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)
-        keys = h @ po["Speller/decode/attention/dense/kernel"]
-        emb = po["embedding/embedding_matrix"]
-
-        def step_fn(prev_ids, prev_al, states):
-            N = len(prev_ids)
-            stt = []
-            for l in range(NL):
-                if cell == "lstm":
-                    stt.append((torch.cat([s[l][0] for s in states]), torch.cat([s[l][1] for s in states])))
-                else:
-                    stt.append(torch.cat([s[l] for s in states]))
-            lg, ns, al = O.speller_decode(h.expand(N, -1, -1), el.repeat(N), stt, emb[torch.tensor(prev_ids)],
-                                          torch.tensor(np.stack(prev_al), dtype=torch.float32), po, args, cell, keys.expand(N, -1, -1))
-            outs = [tuple((ns[l][0][i:i + 1], ns[l][1][i:i + 1]) if cell == "lstm" else ns[l][i:i + 1] for l in range(NL))
-                    for i in range(N)]
-            return lg.numpy(), outs, al.numpy()
-        lm_fn, lm0 = None, None
-        if lm is not None:
-            olm, Hl, NLl = lm
-
-            def lm_fn(ids, states):
-                stt = [(torch.stack([s[l][0] for s in states]), torch.stack([s[l][1] for s in states])) for l in range(NLl)]
-                lo, ns = O.lm_step(torch.tensor(ids), stt, olm)
-                return lo.numpy(), [tuple((ns[l][0][i], ns[l][1][i]) for l in range(NLl)) for i in range(len(ids))]
-            lm0 = tuple((torch.zeros(Hl), torch.zeros(Hl)) for _ in range(NLl))
-        z = torch.zeros(1, args.dec_units)
-        init = tuple((z, z) if cell == "lstm" else z for _ in range(NL))
-        return O.beam_search(step_fn, init, h.shape[1], int(xs[1][0] * args.convert_rate), beam, 1, 2,
-                             lm_fn=lm_fn, lm_init=lm0, lm_weight=lm_weight)
-
-
 @pytest.mark.parametrize("cell,mode", [("lstm", "add"), ("rnn", "loc")])
 def test_decode_batch_equals_one_at_a_time_and_the_oracle(cell, mode):
     from las import layers as L, variables as V
@@ -183,7 +145,7 @@ def test_decode_batch_equals_one_at_a_time_and_the_oracle(cell, mode):
         one = bs.decode(None, xs)
         assert [b.token_ids for b in one] == [b.token_ids for b in res]
         assert [float(b.log_prob) for b in one] == [float(b.log_prob) for b in res]
-        ref = _oracle_decode(xs, p0, args, cell, 4)
+        ref = oracle_decode(xs, p0, args, cell, 4)
         assert [b.token_ids for b in res] == [b.token_ids for b in ref]
         for a, b in zip(res, ref):
             assert float(a.log_prob) == pytest.approx(float(b.log_prob), abs=2e-3)
@@ -199,7 +161,7 @@ def test_beam16_with_2x512_char_rnnlm_matches_oracle():
     from lang.char_rnn_model import CharRNN
     from oracle import las_oracle as O
     from utils.tokenizer import CharEncoder
-    from test_gpu_beam_attention import _lm_params, _oracle_lm
+    from helpers import lm_params as _lm_params, oracle_lm as _oracle_lm
     cell = "lstm"
     args = make_args(enc_units=64, num_enc_layers=2, dec_units=128, num_dec_layers=1, embedding_size=64, attention_size=64,
                      beam_size=16, convert_rate=0.3, apply_lm=True, lm_weight=0.5)
@@ -217,7 +179,7 @@ def test_beam16_with_2x512_char_rnnlm_matches_oracle():
     batch = bs.decode_batch(None, utts)
     olm = (_oracle_lm(plm, 0, 2), 512, 2)
     for xs, res in zip(utts, batch):
-        ref = _oracle_decode(xs, p0, args, cell, 16, lm=olm, lm_weight=0.5)
+        ref = oracle_decode(xs, p0, args, cell, 16, lm=olm, lm_weight=0.5)
         assert len(res) == len(ref) and len(res) > 0
         assert [b.token_ids for b in res] == [b.token_ids for b in ref]
         for a, b in zip(res, ref):
