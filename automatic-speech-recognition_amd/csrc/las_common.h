@@ -138,6 +138,17 @@ __device__ __forceinline__ u32x4_t granule16_load(__amdgpu_buffer_rsrc_t rs, uns
     return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);                 // sc1: bypass L1
 }
 
+// 8-byte form {tag, a}: one aligned 64-bit access, delivered atomically
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void granule8_store(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, unsigned a, bool local) {
+    const u32x2_t v = {tag, a};
+    if (local) __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte_off, 0, 1);
+    else       __builtin_amdgcn_raw_buffer_store_b64(v, rs, byte_off, 0, 17);
+}
+__device__ __forceinline__ u32x2_t granule8_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16);
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 extern "C" int las_colsum_dt(const void* X, int dtype, int rows, int cols, int ldx, float beta, float* out, void* ws,

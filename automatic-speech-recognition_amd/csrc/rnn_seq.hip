@@ -41,6 +41,7 @@ struct RnnArgs {
     int* status;                             // caller-owned sticky device word (may be NULL): LAS_SEQ_STATUS_* on failure
     int status_code;
     int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
+    int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
@@ -615,7 +616,6 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         // accumulator order, so the compute waves see exactly what they saw with fp32 storage.
         // Every access is (uniform base of the frame) + (32-bit per-lane element offset).
         typedef float f4v __attribute__((ext_vector_type(4)));
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(1))) const u32x4_t gcu4;
         typedef __attribute__((address_space(1))) u32x4_t gu4;
         typedef __attribute__((address_space(1))) u32x2_t gu2;
@@ -1067,7 +1067,7 @@ __device__ __forceinline__ float swap_lane_pair(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-template <int CELL, int UT, int P>
+template <int CELL, int UT, int P, int RB = 16>
 struct KsCfg {
     using C = RnnCfg<CELL, UT, P>;
     static constexpr int G = C::G, H = C::H, UTP = C::UTP, UPM = C::UPM;
@@ -1075,23 +1075,31 @@ struct KsCfg {
     static constexpr int KSP = KP / 32;
     static constexpr int NFR = P * UTP * KSP;        // B fragments per wave (all kept in registers)
     static constexpr int LDZ = KP + 8;               // bf16 row pitch of the own-dG tile
-    static constexpr int DZ_BYTES = 2 * 16 * LDZ * 2;
+    static constexpr int DZ_BYTES = 2 * RB * LDZ * 2;
     static constexpr int GPD = 4 * UTP * 4 * 64;     // granules one member sends to ONE other member per step
     static constexpr bool OK = C::OK && NFR <= 64 && (KP % 32 == 0);
 };
 
-template <int CELL, int UT, int P>
+// RB = batch rows per tile.  RB = 8: the step is bound by per-lane work (gate backward, operand loads, granules), all of which
+// scale with the rows a CU owns, while the MFMAs do not care -- so an 8-row tile feeds the MFMA an A operand whose rows 8..15
+// repeat rows 0..7.  Lanes 32..63 then hold the same accumulators as lanes 0..31 and every lane keeps HALF of them (selected
+// by hsel = lane >> 5): one row x one unit pair per lane instead of two rows, half the loads / stores / transcendentals /
+// granule bytes per step, twice as many CUs per batch.
+template <int CELL, int UT, int P, int RB>
 __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
-    using K = KsCfg<CELL, UT, P>;
+    static_assert(RB == 16 || RB == 8, "row tile");
+    using K = KsCfg<CELL, UT, P, RB>;
+    constexpr int NR = RB == 16 ? 2 : 1;              // rows of the pair layout a lane owns
     constexpr int G = K::G, H = K::H, GH = G * H, UTP = K::UTP, UPM = K::UPM, KSP = K::KSP, NFR = K::NFR, LDZ = K::LDZ, GPD = K::GPD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* dzs = reinterpret_cast<unsigned short*>(smem);              // [2][16][LDZ] own dG slice (bf16)
+    unsigned short* dzs = reinterpret_cast<unsigned short*>(smem);              // [2][RB][LDZ] own dG slice (bf16)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = a.T, B = a.B;
     const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
     if (cl >= a.ncl) return;
-    const int dir = cl & 1, b0 = (cl >> 1) * 16;
+    const int dir = cl & 1, b0 = (cl >> 1) * RB;
     const int vw = pm * 4 + w;
+    const int gl = RB == 16 ? g : (g & 1), hsel = RB == 16 ? 0 : (g >> 1);
     // fragments (dir, vw, m, j, ks), all in registers
     const u16x8_t* __restrict__ Wp = reinterpret_cast<const u16x8_t*>(a.wpack) + ((size_t)dir * 4 * P + vw) * NFR * 64;
     u16x8_t wreg[NFR];
@@ -1121,8 +1129,8 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     long long gst[2], cst_[2], ost[2], dst[2];           // per-step advance in 32-bit words (0 for rows past the batch)
     float vrow[2];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int b = b0 + g * 4 + odd * 2 + rr;
+    for (int rr = 0; rr < NR; ++rr) {
+        const int b = b0 + gl * 4 + odd * 2 + (RB == 16 ? rr : hsel);
         const bool valid = b < B;
         const long long row = (long long)b;
         const int u0 = vw * (16 * UTP) + (c & ~1);
@@ -1140,7 +1148,8 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     for (int q = 0; q < G; ++q)
 #pragma unroll
         for (int j = 0; j < UTP; ++j) { bsum[q][j][0] = 0.f; bsum[q][j][1] = 0.f; }
-    f32x4_t dhr[UTP];                        // dh_{t-1} of this wave's tiles, accumulator layout (rows g*4+r, unit c)
+    f32x4_t dhr[UTP];                        // dh_{t-1} of this wave's tiles, accumulator layout (rows g*4+r, unit c);
+                                             // RB = 8: only [0], [1] are kept = rows gl*4 + hsel and gl*4 + 2 + hsel
     float dcc[UTP][2][2];                    // carried dc, pair layout [row rr][unit k]
 #pragma unroll
     for (int j = 0; j < UTP; ++j) {
@@ -1154,7 +1163,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
     for (int j = 0; j < UTP; ++j)
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < NR; ++rr) {
             n_do[j][rr] = dptr[rr][j * 8];
             if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
@@ -1176,19 +1185,26 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #endif
     for (int s = 0; s < T; ++s) {
         KSTAMP(0);
-        unsigned short* dzc = dzs + cur * 16 * LDZ;
+        unsigned short* dzc = dzs + cur * RB * LDZ;
         unsigned sv_z[G][UTP][2];            // d(pre-activation) of this step as packed pairs (written to HBM after the exchange)
         // ---- gate backward for the own units -> own dG slice in LDS (bf16 pairs) and in registers
 #pragma unroll
         for (int j = 0; j < UTP; ++j) {
             // dh of this tile: accumulator layout -> pair layout (swap two values with the neighbouring lane)
-            const float s0 = odd ? dhr[j][0] : dhr[j][2], s1 = odd ? dhr[j][1] : dhr[j][3];
-            const float x0 = swap_lane_pair(s0), x1 = swap_lane_pair(s1);
-            const float o0 = odd ? dhr[j][2] : dhr[j][0], o1 = odd ? dhr[j][3] : dhr[j][1];
-            const float dhp[2][2] = {{odd ? x0 : o0, odd ? o0 : x0}, {odd ? x1 : o1, odd ? o1 : x1}};      // [row rr][unit k]
+            float dhp[2][2];                                          // [row rr][unit k]
+            if (RB == 16) {
+                const float s0 = odd ? dhr[j][0] : dhr[j][2], s1 = odd ? dhr[j][1] : dhr[j][3];
+                const float x0 = swap_lane_pair(s0), x1 = swap_lane_pair(s1);
+                const float o0 = odd ? dhr[j][2] : dhr[j][0], o1 = odd ? dhr[j][3] : dhr[j][1];
+                dhp[0][0] = odd ? x0 : o0; dhp[0][1] = odd ? o0 : x0; dhp[1][0] = odd ? x1 : o1; dhp[1][1] = odd ? o1 : x1;
+            } else {      // the lane's row is r = odd*2 + hsel: own value dhr[odd], the neighbour wants dhr[!odd]
+                const float own = odd ? dhr[j][1] : dhr[j][0];
+                const float x = swap_lane_pair(odd ? dhr[j][0] : dhr[j][1]);
+                dhp[0][0] = odd ? x : own; dhp[0][1] = odd ? own : x; dhp[1][0] = 0.f; dhp[1][1] = 0.f;
+            }
             const int ucol = (w * UTP + j) * 16 + (c & ~1);          // column of the pair inside one gate block of the slice
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < NR; ++rr) {
                 float dz[G][2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -1214,7 +1230,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const unsigned pk = f2bf2(dz[q][0], dz[q][1]);
-                    *reinterpret_cast<unsigned*>(&dzc[(g * 4 + odd * 2 + rr) * LDZ + q * UPM + ucol]) = pk;
+                    *reinterpret_cast<unsigned*>(&dzc[(gl * 4 + odd * 2 + (RB == 16 ? rr : hsel)) * LDZ + q * UPM + ucol]) = pk;
                     sv_z[q][j][rr] = pk;
                     bsum[q][j][0] = fmaf(dz[q][0], vrow[rr], bsum[q][j][0]);
                     bsum[q][j][1] = fmaf(dz[q][1], vrow[rr], bsum[q][j][1]);
@@ -1224,18 +1240,21 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         KSTAMP(1);
         gu32* gprev[2];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) { gprev[rr] = gptr[rr]; gptr[rr] += gst[rr]; optr[rr] += ost[rr]; dptr[rr] += dst[rr]; if (CELL == LAS_CELL_LSTM) cptr[rr] += cst_[rr]; }
+        for (int rr = 0; rr < NR; ++rr) { gprev[rr] = gptr[rr]; gptr[rr] += gst[rr]; optr[rr] += ost[rr]; dptr[rr] += dst[rr]; if (CELL == LAS_CELL_LSTM) cptr[rr] += cst_[rr]; }
         if (s + 1 < T) {     // operands of the next step fly under this step's MFMAs and exchange
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
+                for (int rr = 0; rr < NR; ++rr) {
                     n_do[j][rr] = dptr[rr][j * 8];
                     if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
                         for (int q = 0; q < NG; ++q) n_g[q][j][rr] = gptr[rr][(q * H + j * 16) / 2];
                         n_c[j][rr] = n_cn[j][rr];
-                        n_cn[j][rr] = (s + 2 < T) ? cptr[rr][cst_[rr] + j * 8] : 0u;
+                        asm volatile("" : "+v"(n_c[j][rr]));        // the copy happens HERE: the old register of n_cn is free for the load below
+                        // unconditional (a conditional load makes the compiler drain vmcnt at the join, which puts the HBM latency of
+                        // this whole prefetch on the dependent chain); past the last frame the address is clamped and the value unused
+                        n_cn[j][rr] = cptr[rr][((s + 2 < T) ? cst_[rr] : 0) + j * 8];
                     } else {
                         n_g[0][j][rr] = optr[rr][j * 8];
                     }
@@ -1252,7 +1271,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             for (int j = 0; j < UTP; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
-            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dzc[c * LDZ + ks * 32 + g * 8]);
+            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dzc[(c & (RB - 1)) * LDZ + ks * 32 + g * 8]);
 #pragma unroll
             for (int m = 0; m < P; ++m)
 #pragma unroll
@@ -1266,6 +1285,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             // ---- reduce-scatter: send the tiles other members own, add the ones they computed for this wave
             // byte offsets into this cluster's exchange buffer (< 2 GB): slot, [dst][src] region, (wave tile, lane) x 16 B
             const unsigned slot_off = (unsigned)(s & 1) * P * P * GPD * 8u;
+            if constexpr (RB == 16) {
             const unsigned lane_off = ((unsigned)(w * UTP) * 64u + lane) * 16u;
 #pragma unroll
             for (int mo = 1; mo < P; ++mo) {
@@ -1313,13 +1333,63 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     }
                     dhr[j][r] = v;
                 }
+            } else {
+            // RB = 8: a lane keeps rows r = hsel and r = 2 + hsel of its (gl, unit c) position -- exactly the two values the
+            // same lane of the owning member needs -- so the two partial sums travel as ONE bf16 pair in an 8-byte granule.
+            const unsigned lane_off = ((unsigned)(w * UTP) * 64u + lane) * 8u;
+#pragma unroll
+            for (int mo = 1; mo < P; ++mo) {
+                const int m = (pm + mo) % P;
+                const unsigned dst_off = slot_off + (unsigned)(m * P + pm) * GPD * 8u + lane_off;
+#pragma unroll
+                for (int j = 0; j < UTP; ++j)
+                    granule8_store(xrs, dst_off + (unsigned)j * 512u, (unsigned)(s + 1),
+                                   f2bf2(hsel ? acc[mo][j][1] : acc[mo][j][0], hsel ? acc[mo][j][3] : acc[mo][j][2]), local);
+            }
+            KSTAMP(5);
+            constexpr int NGT = (P - 1) * UTP;
+            u32x2_t xv[NGT];
+            const unsigned in_off = slot_off + (unsigned)(pm * P) * GPD * 8u + lane_off;
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int src = (pm + 1 + n / UTP) % P;
+                xv[n] = granule8_load(xrs, in_off + (unsigned)src * GPD * 8u + (unsigned)(n % UTP) * 512u);
+            }
+            int budget = errflag ? 1 : a.spin;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) ok &= xv[n].x == (unsigned)(s + 1);
+                if (ok) break;
+                if (--budget <= 0) { errflag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) {
+                    if (xv[n].x != (unsigned)(s + 1)) {
+                        const int src = (pm + 1 + n / UTP) % P;
+                        xv[n] = granule8_load(xrs, in_off + (unsigned)src * GPD * 8u + (unsigned)(n % UTP) * 512u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UTP; ++j) {
+                float v0 = hsel ? acc[0][j][1] : acc[0][j][0], v1 = hsel ? acc[0][j][3] : acc[0][j][2];
+#pragma unroll
+                for (int mo = 0; mo < P - 1; ++mo) {
+                    const unsigned pk = xv[mo * UTP + j].y;
+                    v0 += __uint_as_float(pk << 16);
+                    v1 += __uint_as_float(pk & 0xffff0000u);
+                }
+                dhr[j][0] = v0; dhr[j][1] = v1;
+            }
+            }
         }
         KSTAMP(6);
         // ---- d(pre-activation) of this step to HBM as packed bf16 pairs (never waited on)
 #pragma unroll
         for (int j = 0; j < UTP; ++j)
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
                 for (int q = 0; q < G; ++q) gprev[rr][(q * H + j * 16) / 2] = sv_z[q][j][rr];
         KSTAMP(7);
@@ -1434,7 +1504,7 @@ static SeqWs seq_ws_layout(int cell, int H, int B) {
     size_t o = (2 * G * H * H * sizeof(float) + 255) & ~(size_t)255;   // f32: W^T copy; bf16: packed fragments (half of it)
     w.err = o; o += 256;
     w.sink = o; o += ((size_t)(G * H + 64) * sizeof(float) + 255) & ~(size_t)255;
-    const size_t ncl = (size_t)((B + 15) / 16) * 2;
+    const size_t ncl = (size_t)((B + 7) / 8) * 2;             // 8-row tiles: the finest tiling any kernel uses
     w.xcc = o; o += (ncl * 8 * sizeof(unsigned long long) + 255) & ~(size_t)255;      // [cluster][<= 8 members] handshake granules
     w.bpart = o; o += (ncl * G * H * sizeof(float) + 255) & ~(size_t)255;
     w.xbuf = o;
@@ -1455,6 +1525,13 @@ static int set_lds(K kern, int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// which kernels can sweep 8-row tiles (lane-compacted duplicate MFMA rows)
+template <int CELL, int UT, int P>
+static constexpr bool rb8_ok(bool bwd) {
+    if constexpr (P > 1) return bwd ? KsCfg<CELL, UT, P, 8>::OK : false;
+    else return false;
+}
+
 template <int CELL, int UT, int P, int RT>
 static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t st) {
     using C = RnnCfg<CELL, UT, P>;
@@ -1464,6 +1541,7 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
         return -2;
     } else {
         RnnArgs a = a0;
+        if (a.rb == 8 && !rb8_ok<CELL, UT, P>(bwd)) { las_set_error("rnn_seq: no 8-row kernel for this configuration"); return -1; }
         a.ncl = cdiv(ntiles, RT) * 2;                      // (tile group, direction) pairs
         a.ncl_pad = (a.ncl + 7) / 8 * 8;                   // members of a cluster share blockIdx % 8 (same XCD: speed only)
         if ((long long)a.ncl_pad * P > las_device_cus()) {     // every member must be co-resident (1 workgroup per CU)
@@ -1484,10 +1562,17 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>), grid, blk, FL, st, a);
         } else if (P > 1 && KsCfg<CELL, UT, P>::OK && a.ks_packed) {
             if constexpr (P > 1 && KsCfg<CELL, UT, P>::OK) {
-                constexpr int KZ = KsCfg<CELL, UT, P>::DZ_BYTES;
-                static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P>, KZ);
-                if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
-                hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P>), grid, dim3(256), KZ, st, a);
+                if (a.rb == 8) {
+                    constexpr int KZ = KsCfg<CELL, UT, P, 8>::DZ_BYTES;
+                    static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8>, KZ);
+                    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
+                    hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 8>), grid, dim3(256), KZ, st, a);
+                } else {
+                    constexpr int KZ = KsCfg<CELL, UT, P, 16>::DZ_BYTES;
+                    static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 16>, KZ);
+                    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
+                    hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 16>), grid, dim3(256), KZ, st, a);
+                }
             }
         } else {
             static int attr = set_lds(rnn_seq_bwd_bf16_kernel<CELL, UT, P, RT>, BL);
@@ -1508,8 +1593,9 @@ static int pick_rt(int cell, int H, int P, bool bwd, int ntiles) {
 }
 
 template <int CELL, int UT, int P>
-static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
-    const int ntiles = cdiv(a.B, 16);
+static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st, bool query) {
+    if (query) return rb8_ok<CELL, UT, P>(bwd) ? 1 : 0;
+    const int ntiles = cdiv(a.B, a.rb);
     int rt = pick_rt(CELL, UT * 64, P, bwd, ntiles);
     for (; rt >= 1; --rt) {
         int rc;
@@ -1519,22 +1605,24 @@ static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st) {
     return -2;
 }
 
-static int dispatch_bf16(int cell, int P, bool bwd, const RnnArgs& a, hipStream_t st) {
+// query = true: 1 if this configuration has an 8-row-tile kernel for the direction, else 0 (nothing is launched)
+static int dispatch_bf16(int cell, int P, bool bwd, const RnnArgs& a, hipStream_t st, bool query = false) {
     const int key = (cell == LAS_CELL_LSTM ? 1000 : 0) + (a.H / 64) * 10 + P;
     switch (key) {
-        case 1011: return launch_bf16<LAS_CELL_LSTM, 1, 1>(bwd, a, st);
-        case 1021: return launch_bf16<LAS_CELL_LSTM, 2, 1>(bwd, a, st);
-        case 1022: return launch_bf16<LAS_CELL_LSTM, 2, 2>(bwd, a, st);
-        case 1042: return launch_bf16<LAS_CELL_LSTM, 4, 2>(bwd, a, st);
-        case 1044: return launch_bf16<LAS_CELL_LSTM, 4, 4>(bwd, a, st);
-        case 1088: return launch_bf16<LAS_CELL_LSTM, 8, 8>(bwd, a, st);
-        case 11:   return launch_bf16<LAS_CELL_RNN, 1, 1>(bwd, a, st);
-        case 21:   return launch_bf16<LAS_CELL_RNN, 2, 1>(bwd, a, st);
-        case 41:   return launch_bf16<LAS_CELL_RNN, 4, 1>(bwd, a, st);
-        case 42:   return launch_bf16<LAS_CELL_RNN, 4, 2>(bwd, a, st);
-        case 82:   return launch_bf16<LAS_CELL_RNN, 8, 2>(bwd, a, st);
-        case 84:   return launch_bf16<LAS_CELL_RNN, 8, 4>(bwd, a, st);
+        case 1011: return launch_bf16<LAS_CELL_LSTM, 1, 1>(bwd, a, st, query);
+        case 1021: return launch_bf16<LAS_CELL_LSTM, 2, 1>(bwd, a, st, query);
+        case 1022: return launch_bf16<LAS_CELL_LSTM, 2, 2>(bwd, a, st, query);
+        case 1042: return launch_bf16<LAS_CELL_LSTM, 4, 2>(bwd, a, st, query);
+        case 1044: return launch_bf16<LAS_CELL_LSTM, 4, 4>(bwd, a, st, query);
+        case 1088: return launch_bf16<LAS_CELL_LSTM, 8, 8>(bwd, a, st, query);
+        case 11:   return launch_bf16<LAS_CELL_RNN, 1, 1>(bwd, a, st, query);
+        case 21:   return launch_bf16<LAS_CELL_RNN, 2, 1>(bwd, a, st, query);
+        case 41:   return launch_bf16<LAS_CELL_RNN, 4, 1>(bwd, a, st, query);
+        case 42:   return launch_bf16<LAS_CELL_RNN, 4, 2>(bwd, a, st, query);
+        case 82:   return launch_bf16<LAS_CELL_RNN, 8, 2>(bwd, a, st, query);
+        case 84:   return launch_bf16<LAS_CELL_RNN, 8, 4>(bwd, a, st, query);
         default:
+            if (query) return 0;
             las_set_error("rnn_seq: no bf16 kernel for cell=%d H=%d P=%d", cell, a.H, P);
             return -2;
     }
@@ -1583,13 +1671,18 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         LAS_LAUNCHED();
         LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
         // row tiles per launch: clusters (tile, direction) are padded to a multiple of 8 workgroups per member
-        const int ntiles = cdiv(B, 16);
         int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
         if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, las_device_cus()); rc = -2; continue; }
+        // 8-row tiles (twice the CUs, half the per-lane work of a dependent step) while the whole batch still fits one launch
+        const bool k8 = (bwd ? a.ks_packed != 0 : !a.no_helpers) && !(flags & LAS_SEQ_ROWS16) && cdiv(B, 8) <= max_tiles &&
+                        dispatch_bf16(cell, P, bwd, a, st, true) == 1;
+        const int RBk = k8 ? 8 : 16;
+        a.rb = RBk;
+        const int ntiles = cdiv(B, RBk);
         const size_t per_cl = L.xbuf_per;                // granule words per cluster
         rc = 0;
         for (int tile0 = 0; tile0 < ntiles && rc == 0; tile0 += max_tiles) {
-            const int b0 = tile0 * 16, rows = (B - b0) < max_tiles * 16 ? (B - b0) : max_tiles * 16;
+            const int b0 = tile0 * RBk, rows = (B - b0) < max_tiles * RBk ? (B - b0) : max_tiles * RBk;
             RnnArgs c = a;
             c.B = rows;
             c.gates16 = a.gates16 + (size_t)b0 * T * 2 * G * H;
@@ -1614,7 +1707,7 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
 
 static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
-    a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0;
+    a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;
