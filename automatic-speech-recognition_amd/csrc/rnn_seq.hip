@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 // step take longer than the compute chain, and the barrier then waits for it.)
 // Rows past the end of a ragged batch tile alias the last valid row (identical loads, identical stores).
 // ------------------------------------------------------------------------------------------------
-template <int CELL, int UT, int P>
+template <int CELL, int UT, int P, int RB = 16>
 struct HwCfg {
     using C = RnnCfg<CELL, UT, P>;
     static constexpr int G = C::G, UPM = C::UPM, NFW = C::NFW;
@@ -579,30 +579,36 @@ struct HwCfg {
     static constexpr int LFH = NFW - RFH;                     // the rest: LDS
     static constexpr int XW = G * UPM, XP = XW + 4;           // x row: floats / padded pitch (4*XP = 16 mod 64 banks)
     static constexpr int OW = (CELL == LAS_CELL_LSTM ? (G + 2) : 1) * UPM, OP = OW + 4;   // result row [gates | c | h] or [h]
-    static constexpr int NX = 16 * XW / 8 / 64;               // 8-element (16-byte bf16) slots per step of the gate slice (64 lanes each)
-    static constexpr int NC4 = 16 * UPM / 4 / 64;             // 4-element (8-byte bf16) slots per step of the c (and h) slice
-    static constexpr int XR_BYTES = 3 * 16 * XP * 4, OR_BYTES = 2 * 16 * OP * 4;          // x ring: 3 steps, result ring: 2 steps
+    static constexpr int NX = RB * XW / 8 / 64;               // 8-element (16-byte bf16) slots per step of the gate slice (64 lanes each)
+    static constexpr int CE = RB == 16 ? 4 : 2;               // elements per access of the c / h slices (8- or 4-byte bf16)
+    static constexpr int NC4 = RB * UPM / CE / 64;            // CE-element slots per step of the c (and h) slice
+    static constexpr int XR_BYTES = 3 * RB * XP * 4, OR_BYTES = 2 * RB * OP * 4;          // x ring: 3 steps, result ring: 2 steps
     static constexpr int LDS = C::HS_BYTES + 4 * LFH * 1024 + XR_BYTES + OR_BYTES;
-    static constexpr bool OK = C::OK && (XW % 64 == 0) && (NX % NHW == 0) && (NC4 % NHW == 0) && NC4 >= NHW && LDS <= 160 * 1024;
+    static constexpr bool OK = C::OK && (XW % 64 == 0) && (NX % NHW == 0) && (NC4 % NHW == 0) && NC4 >= NHW && LDS <= 160 * 1024 &&
+                               (RB == 16 || P > 1);
 };
 
-template <int CELL, int UT, int P>
+// RB = 8: see rnn_seq_bwd_ks_kernel -- the A operand repeats rows 0..7 in rows 8..15, every lane keeps the two accumulator rows
+// r = 2*hsel + {0,1} of its (gl, unit) position: half the transcendentals, ring traffic and granule bytes per CU and step.
+template <int CELL, int UT, int P, int RB>
 __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
+    static_assert(RB == 16 || RB == 8, "row tile");
     using C = RnnCfg<CELL, UT, P>;
-    using HC = HwCfg<CELL, UT, P>;
+    using HC = HwCfg<CELL, UT, P, RB>;
     constexpr int G = C::G, H = C::H, GH = C::GH, KS = C::KS, LDH = C::LDH, UTP = C::UTP, UPM = C::UPM, GPM = C::GPM_F;
-    constexpr int RF = HC::RFH, LF = HC::LFH, XP = HC::XP, OP = HC::OP, XW = HC::XW, NHW = HC::NHW;
+    constexpr int RF = HC::RFH, LF = HC::LFH, XP = HC::XP, OP = HC::OP, XW = HC::XW, NHW = HC::NHW, CE = HC::CE;
     constexpr int NXH = HC::NX / NHW, NCH = HC::NC4 / NHW;
+    constexpr int NV = RB == 16 ? 4 : 2;                      // accumulator rows a lane works on
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* hs = reinterpret_cast<unsigned short*>(smem);                                   // [2][16][LDH]
     u16x8_t* wl = reinterpret_cast<u16x8_t*>(smem + C::HS_BYTES);                                   // [4][LF][64]
     float* xring = reinterpret_cast<float*>(smem + C::HS_BYTES + 4 * LF * 1024);                    // [3][16][XP]
-    float* oring = xring + 3 * 16 * XP;                                                             // [2][16][OP]
+    float* oring = xring + 3 * RB * XP;                                                             // [2][RB][OP]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int T = a.T, B = a.B;
     const int cg = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
     if (cg >= a.ncl) return;
-    const int dir = cg & 1, tile = cg >> 1, b0 = tile * 16;
+    const int dir = cg & 1, tile = cg >> 1, b0 = tile * RB;
     if (b0 >= B) return;
     const int cl = tile * 2 + dir;
     int errflag = 0;
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         typedef __attribute__((address_space(1))) u32x2_t gu2;
         const int hw = w - 4;
         constexpr int GR8 = XW / 8;                    // 8-element pieces per row of the gate slice
-        constexpr int UR4 = UPM / 4;                   // 4-element pieces per row of the c / h slice
+        constexpr int UR4 = UPM / CE;                  // CE-element pieces per row of the c / h slice
         auto brow = [&](int row) { const int b = b0 + row; return (unsigned)(b < B ? b : B - 1); };
         unsigned xoff[NXH], coff[NCH], hoff[NCH];
         int xl[NXH], xo[NXH], co[NCH];
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         }
 #pragma unroll
         for (int ii = 0; ii < NCH; ++ii) {
-            const int idx = (ii * NHW + hw) * 64 + lane, row = idx / UR4, u = (idx % UR4) * 4;
+            const int idx = (ii * NHW + hw) * 64 + lane, row = idx / UR4, u = (idx % UR4) * CE;
             coff[ii] = brow(row) * (unsigned)(T * 2 * H) + dir * H + pm * UPM + u;
             hoff[ii] = brow(row) * (unsigned)a.obs + dir * H + pm * UPM + u;
             co[ii] = row * OP + u;
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #pragma unroll
             for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
 #pragma unroll
-            for (int ii = 0; ii < NXH; ++ii) to_ring(xring + 16 * XP, xq[ii], xl[ii]);
+            for (int ii = 0; ii < NXH; ++ii) to_ring(xring + RB * XP, xq[ii], xl[ii]);
         }
         if (T > 2) {
             const unsigned short* gb = gframe(2);
@@ -675,8 +681,13 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             u32x2_t r = {f2bf2(v.x, v.y), f2bf2(v.z, v.w)};
             return r;
         };
+        typedef __attribute__((address_space(1))) unsigned int gu1;
+        auto pack2 = [&](const float* src) __attribute__((always_inline)) {
+            const float2 v = *reinterpret_cast<const float2*>(src);
+            return f2bf2(v.x, v.y);
+        };
         auto flush = [&](int slot, int s) __attribute__((always_inline)) {      // results of step s: LDS ring -> HBM (bf16)
-            const float* orr = oring + slot * 16 * OP;
+            const float* orr = oring + slot * RB * OP;
             unsigned short* ob = oframe(s);
             if (CELL == LAS_CELL_LSTM) {
                 unsigned short* gb = gframe(s);
@@ -689,17 +700,25 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 }
 #pragma unroll
                 for (int ii = 0; ii < NCH; ++ii) {
-                    *(gu2*)(cb + coff[ii]) = pack4(orr + co[ii] + G * UPM);
-                    *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii] + (G + 1) * UPM);
+                    if (CE == 4) {
+                        *(gu2*)(cb + coff[ii]) = pack4(orr + co[ii] + G * UPM);
+                        *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii] + (G + 1) * UPM);
+                    } else {
+                        *(gu1*)(cb + coff[ii]) = pack2(orr + co[ii] + G * UPM);
+                        *(gu1*)(ob + hoff[ii]) = pack2(orr + co[ii] + (G + 1) * UPM);
+                    }
                 }
             } else {
 #pragma unroll
-                for (int ii = 0; ii < NCH; ++ii) *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii]);
+                for (int ii = 0; ii < NCH; ++ii) {
+                    if (CE == 4) *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii]);
+                    else         *(gu1*)(ob + hoff[ii]) = pack2(orr + co[ii]);
+                }
             }
         };
         for (int s = 0; s < T; ++s) {
             if (s + 2 < T) {        // step s+2 has had a whole step in flight: hand it to the ring, request step s+3
-                float* xr = xring + ((s + 2) % 3) * 16 * XP;
+                float* xr = xring + ((s + 2) % 3) * RB * XP;
 #pragma unroll
                 for (int ii = 0; ii < NXH; ++ii) to_ring(xr, xq[ii], xl[ii]);
                 if (s + 3 < T) {
@@ -728,11 +747,13 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
     for (int i = tid; i < 16 * LDH; i += 256) hs[i] = 0;
     __syncthreads();
 
-    float cst[UTP][4];
+    const int gl = RB == 16 ? g : (g & 1), hsel = RB == 16 ? 0 : (g >> 1);
+    const int row0 = RB == 16 ? g * 4 : gl * 4 + hsel * 2;     // the lane's rows are row0 + k, k < NV
+    float cst[UTP][NV];
 #pragma unroll
     for (int j = 0; j < UTP; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cst[j][r] = 0.f;
+        for (int r = 0; r < NV; ++r) cst[j][r] = 0.f;
     int cur = 0;
 #ifdef LAS_PROF
     const bool hprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
@@ -743,19 +764,19 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #endif
     for (int s = 0; s < T; ++s) {
         HSTAMP(0);
-        const float* xr = xring + (s % 3) * 16 * XP;
-        float* orr = oring + (s & 1) * 16 * OP;
+        const float* xr = xring + (s % 3) * RB * XP;
+        float* orr = oring + (s & 1) * RB * OP;
         const unsigned short* hcur = hs + cur * 16 * LDH;
         u16x8_t av[KS];                          // A fragments of h_{t-1} first: the MFMAs wait on nothing else
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[c * LDH + ks * 32 + g * 8]);
-        f32x4_t xv[G][UTP];                      // x.W_ih + b from the ring: read under the MFMAs, added after them
+        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[(c & (RB - 1)) * LDH + ks * 32 + g * 8]);
+        float xv[G][UTP][NV];                    // x.W_ih + b from the ring: read under the MFMAs, added after them
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xv[q][j][r] = xr[(g * 4 + r) * XP + q * UPM + (w * UTP + j) * 16 + c];
+                for (int r = 0; r < NV; ++r) xv[q][j][r] = xr[(row0 + r) * XP + q * UPM + (w * UTP + j) * 16 + c];
         f32x4_t acc[G][UTP];
 #pragma unroll
         for (int q = 0; q < G; ++q)
@@ -772,12 +793,16 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                     acc[q][j] = mfma_bf16_16x16x32(av[ks], bv, acc[q][j]);
                 }
         }
+        float pre[G][UTP][NV];                   // pre-activations of the lane's rows (RB = 8: its half of the duplicated tile)
 #pragma unroll
         for (int q = 0; q < G; ++q)
 #pragma unroll
-            for (int j = 0; j < UTP; ++j) acc[q][j] += xv[q][j];
+            for (int j = 0; j < UTP; ++j)
+#pragma unroll
+                for (int r = 0; r < NV; ++r)
+                    pre[q][j][r] = (RB == 16 ? acc[q][j][r] : (hsel ? acc[q][j][2 + (r & 1)] : acc[q][j][r & 1])) + xv[q][j][r];
 #ifdef LAS_PROF
-        asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[G - 1][UTP - 1][3]));     // MFMA results landed
+        asm volatile("s_nop 0" :: "v"(pre[0][0][0]), "v"(pre[G - 1][UTP - 1][NV - 1]));     // MFMA results landed
 #endif
         HSTAMP(1);
         unsigned short* hnext = hs + (cur ^ 1) * 16 * LDH;
@@ -786,16 +811,16 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         for (int j = 0; j < UTP; ++j) {
             const int ul = (w * UTP + j) * 16 + c;                   // unit inside this member's slice
             const int unit = pm * UPM + ul;
-            unsigned short hb[4];
+            unsigned short hb[NV];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < NV; ++r) {
                 float h;
-                float* orow = orr + (g * 4 + r) * OP;
+                float* orow = orr + (row0 + r) * OP;
                 if (CELL == LAS_CELL_LSTM) {
-                    const float gi = sigm<true>(acc[0][j][r]);
-                    const float gj = tanhx<true>(acc[G > 1 ? 1 : 0][j][r]);
-                    const float gf = sigm<true>(acc[G > 2 ? 2 : 0][j][r] + a.fb);
-                    const float go = sigm<true>(acc[G > 3 ? 3 : 0][j][r]);
+                    const float gi = sigm<true>(pre[0][j][r]);
+                    const float gj = tanhx<true>(pre[G > 1 ? 1 : 0][j][r]);
+                    const float gf = sigm<true>(pre[G > 2 ? 2 : 0][j][r] + a.fb);
+                    const float go = sigm<true>(pre[G > 3 ? 3 : 0][j][r]);
                     const float cc = cst[j][r] * gf + gi * gj;
                     cst[j][r] = cc;
                     h = tanhx<true>(cc) * go;
@@ -804,19 +829,25 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                     orow[G * UPM + ul] = cc;
                     orow[(G + 1) * UPM + ul] = h;
                 } else {
-                    h = tanhx<true>(acc[0][j][r]);
+                    h = tanhx<true>(pre[0][j][r]);
                     orow[ul] = h;
                 }
                 hb[r] = f2bf(h);
-                hnext[(g * 4 + r) * LDH + unit] = hb[r];
+                hnext[(row0 + r) * LDH + unit] = hb[r];
             }
-            if (P > 1 && s + 1 < T)     // publish this wave's slice: the lane's four rows of the tile as ONE 16-byte double granule
-                granule16_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 16u, (unsigned)(s + 1),
-                                (unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16), local);
+            if (P > 1 && s + 1 < T) {   // publish this wave's slice: the lane's rows of the tile as ONE granule
+                if constexpr (RB == 16)
+                    granule16_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 16u, (unsigned)(s + 1),
+                                    (unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[NV > 2 ? 2 : 0] | ((unsigned)hb[NV > 2 ? 3 : 0] << 16), local);
+                else
+                    granule8_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 8u, (unsigned)(s + 1),
+                                   (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
+            }
         }
         HSTAMP(2);
         if (P > 1 && s + 1 < T) {       // gather the other members' slices of h_t into the LDS tile
             constexpr int NGT = (P > 1 ? (P - 1) * UTP : 1);
+            if constexpr (RB == 16) {
             u32x4_t xv[NGT];
 #pragma unroll
             for (int n = 0; n < NGT; ++n) {
@@ -850,6 +881,40 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 hnext[(row + 1) * LDH + unit] = (unsigned short)(xv[n].y >> 16);
                 hnext[(row + 2) * LDH + unit] = (unsigned short)(xv[n].z & 0xffffu);
                 hnext[(row + 3) * LDH + unit] = (unsigned short)(xv[n].z >> 16);
+            }
+            } else {
+            u32x2_t xv[NGT];
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int m = (pm + 1 + n / UTP) % P;
+                xv[n] = granule8_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 8u);
+            }
+            int budget = errflag ? 1 : a.spin;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) ok &= xv[n].x == (unsigned)(s + 1);
+                if (ok) break;
+                if (--budget <= 0) { errflag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int n = 0; n < NGT; ++n) {
+                    if (xv[n].x != (unsigned)(s + 1)) {
+                        const int m = (pm + 1 + n / UTP) % P;
+                        xv[n] = granule8_load(xrs, slot_off + (unsigned)m * GPM * 8u + ((unsigned)(n % UTP) * 256u + tid) * 8u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NGT; ++n) {
+                const int m = (pm + 1 + n / UTP) % P;
+                const int di = (n % UTP) * 256 + tid;
+                const int l2 = di & 63, wj = di >> 6, g2 = l2 >> 4;
+                const int unit = m * UPM + wj * 16 + (l2 & 15);
+                const int row = (g2 & 1) * 4 + (g2 >> 1) * 2;
+                hnext[row * LDH + unit] = (unsigned short)(xv[n].y & 0xffffu);
+                hnext[(row + 1) * LDH + unit] = (unsigned short)(xv[n].y >> 16);
+            }
             }
         }
         HSTAMP(3);
@@ -1269,13 +1334,16 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         for (int m = 0; m < P; ++m)
 #pragma unroll
             for (int j = 0; j < UTP; ++j) acc[m][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        u16x8_t av[KSP];                         // all A fragments requested up front: the MFMAs then wait on LDS once, not per pair
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&dzc[(c & (RB - 1)) * LDZ + ks * 32 + g * 8]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
-            const u16x8_t av = *reinterpret_cast<const u16x8_t*>(&dzc[(c & (RB - 1)) * LDZ + ks * 32 + g * 8]);
 #pragma unroll
             for (int m = 0; m < P; ++m)
 #pragma unroll
-                for (int j = 0; j < UTP; ++j) acc[m][j] = mfma_bf16_16x16x32(av, wreg[(m * UTP + j) * KSP + ks], acc[m][j]);
+                for (int j = 0; j < UTP; ++j) acc[m][j] = mfma_bf16_16x16x32(av[ks], wreg[(m * UTP + j) * KSP + ks], acc[m][j]);
         }
 #ifdef LAS_PROF
         asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[P - 1][UTP - 1][3]));
@@ -1528,7 +1596,7 @@ static int set_lds(K kern, int bytes) {
 // which kernels can sweep 8-row tiles (lane-compacted duplicate MFMA rows)
 template <int CELL, int UT, int P>
 static constexpr bool rb8_ok(bool bwd) {
-    if constexpr (P > 1) return bwd ? KsCfg<CELL, UT, P, 8>::OK : false;
+    if constexpr (P > 1) return bwd ? KsCfg<CELL, UT, P, 8>::OK : HwCfg<CELL, UT, P, 8>::OK;
     else return false;
 }
 
@@ -1549,12 +1617,19 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             return -2;
         }
         dim3 grid(a.ncl_pad * P), blk(256 * RT);
-        if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
+        if (!bwd && RT == 1 && a.rb == 8) {
+            if constexpr (HwCfg<CELL, UT, P, 8>::OK) {
+                constexpr int HL = HwCfg<CELL, UT, P, 8>::LDS;
+                static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>, HL);
+                if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
+                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>), grid, dim3(512), HL, st, a);
+            }
+        } else if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
             if constexpr (HwCfg<CELL, UT, P>::OK) {
                 constexpr int HL = HwCfg<CELL, UT, P>::LDS;
-                static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P>, HL);
+                static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
-                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P>), grid, dim3(512), HL, st, a);
+                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>), grid, dim3(512), HL, st, a);
             }
         } else if (!bwd) {
             static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>, FL);
