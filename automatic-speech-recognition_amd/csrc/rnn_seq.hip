@@ -17,6 +17,9 @@
 #include "las_common.h"
 #include <stdlib.h>
 
+#ifndef LAS_ABL
+#define LAS_ABL 0      // development: bit mask of parts of the forward sweep to leave out (timing experiments, tools/abl_rnn.py)
+#endif
 struct RnnArgs {
     int B, T, H;
     float* gates;
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             }
         };
         for (int s = 0; s < T; ++s) {
+            if (LAS_ABL & 16) { lds_barrier(); continue; }
             if (s + 2 < T) {        // step s+2 has had a whole step in flight: hand it to the ring, request step s+3
                 float* xr = xring + ((s + 2) % 3) * RB * XP;
 #pragma unroll
@@ -769,7 +773,8 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         const unsigned short* hcur = hs + cur * 16 * LDH;
         u16x8_t av[KS];                          // A fragments of h_{t-1} first: the MFMAs wait on nothing else
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[(c & (RB - 1)) * LDH + ks * 32 + g * 8]);
+        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[(c & (RB - 1)) * LDH + ((LAS_ABL & 2) ? 0 : ks) * 32 + g * 8]);
+        __builtin_amdgcn_sched_barrier(0);       // all of them in flight before anything else (the compiler otherwise fetches them in pairs)
         float xv[G][UTP][NV];                    // x.W_ih + b from the ring: read under the MFMAs, added after them
 #pragma unroll
         for (int q = 0; q < G; ++q)
@@ -777,6 +782,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
                 for (int r = 0; r < NV; ++r) xv[q][j][r] = xr[(row0 + r) * XP + q * UPM + (w * UTP + j) * 16 + c];
+        __builtin_amdgcn_sched_barrier(0);
         f32x4_t acc[G][UTP];
 #pragma unroll
         for (int q = 0; q < G; ++q)
@@ -790,8 +796,9 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 for (int j = 0; j < UTP; ++j) {
                     const int fi = (q * UTP + j) * KS + ks;
                     const u16x8_t bv = fi < RF ? wreg[fi < RF ? fi : 0] : wl[(w * LF + (fi - RF)) * 64 + lane];
-                    acc[q][j] = mfma_bf16_16x16x32(av[ks], bv, acc[q][j]);
+                    if (!(LAS_ABL & 1) || ks == 0) acc[q][j] = mfma_bf16_16x16x32(av[ks], bv, acc[q][j]);
                 }
+            __builtin_amdgcn_sched_barrier(0);   // k-step-major issue order: G*UTP independent accumulators between dependent MFMAs
         }
         float pre[G][UTP][NV];                   // pre-activations of the lane's rows (RB = 8: its half of the duplicated tile)
 #pragma unroll
@@ -799,8 +806,12 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
-                for (int r = 0; r < NV; ++r)
-                    pre[q][j][r] = (RB == 16 ? acc[q][j][r] : (hsel ? acc[q][j][2 + (r & 1)] : acc[q][j][r & 1])) + xv[q][j][r];
+                for (int r = 0; r < NV; ++r) {
+                    float v;
+                    if (RB == 16) v = acc[q][j][r];
+                    else { const float lo = (r & 1) ? acc[q][j][1] : acc[q][j][0], hi = (r & 1) ? acc[q][j][3] : acc[q][j][2]; v = hsel ? hi : lo; }
+                    pre[q][j][r] = v + xv[q][j][r];
+                }
 #ifdef LAS_PROF
         asm volatile("s_nop 0" :: "v"(pre[0][0][0]), "v"(pre[G - 1][UTP - 1][NV - 1]));     // MFMA results landed
 #endif
@@ -812,28 +823,25 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             const int ul = (w * UTP + j) * 16 + c;                   // unit inside this member's slice
             const int unit = pm * UPM + ul;
             unsigned short hb[NV];
+            float res[NV][6];                    // gates, c, h of the lane's rows: h is published FIRST, the ring writes follow
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 float h;
-                float* orow = orr + (row0 + r) * OP;
                 if (CELL == LAS_CELL_LSTM) {
-                    const float gi = sigm<true>(pre[0][j][r]);
-                    const float gj = tanhx<true>(pre[G > 1 ? 1 : 0][j][r]);
-                    const float gf = sigm<true>(pre[G > 2 ? 2 : 0][j][r] + a.fb);
-                    const float go = sigm<true>(pre[G > 3 ? 3 : 0][j][r]);
+                    constexpr bool TR = !(LAS_ABL & 4);
+                    const float gi = TR ? sigm<true>(pre[0][j][r]) : pre[0][j][r] * 0.5f;
+                    const float gj = TR ? tanhx<true>(pre[G > 1 ? 1 : 0][j][r]) : pre[G > 1 ? 1 : 0][j][r] * 0.25f;
+                    const float gf = TR ? sigm<true>(pre[G > 2 ? 2 : 0][j][r] + a.fb) : pre[G > 2 ? 2 : 0][j][r] * 0.125f;
+                    const float go = TR ? sigm<true>(pre[G > 3 ? 3 : 0][j][r]) : pre[G > 3 ? 3 : 0][j][r] * 0.75f;
                     const float cc = cst[j][r] * gf + gi * gj;
                     cst[j][r] = cc;
-                    h = tanhx<true>(cc) * go;
-                    orow[ul] = gi; orow[(G > 1 ? 1 : 0) * UPM + ul] = gj; orow[(G > 2 ? 2 : 0) * UPM + ul] = gf;
-                    orow[(G > 3 ? 3 : 0) * UPM + ul] = go;
-                    orow[G * UPM + ul] = cc;
-                    orow[(G + 1) * UPM + ul] = h;
+                    h = (TR ? tanhx<true>(cc) : cc * 0.3f) * go;
+                    res[r][0] = gi; res[r][1] = gj; res[r][2] = gf; res[r][3] = go; res[r][4] = cc;
                 } else {
                     h = tanhx<true>(pre[0][j][r]);
-                    orow[ul] = h;
                 }
+                res[r][5] = h;
                 hb[r] = f2bf(h);
-                hnext[(row0 + r) * LDH + unit] = hb[r];
             }
             if (P > 1 && s + 1 < T) {   // publish this wave's slice: the lane's rows of the tile as ONE granule
                 if constexpr (RB == 16)
@@ -842,6 +850,21 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 else
                     granule8_store(xrs, slot_off + (unsigned)pm * GPM * 8u + ((unsigned)(w * UTP + j) * 64u + lane) * 8u, (unsigned)(s + 1),
                                    (unsigned)hb[0] | ((unsigned)hb[1] << 16), local);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                float* orow = orr + (row0 + r) * OP;
+                hnext[(row0 + r) * LDH + unit] = hb[r];
+                if (CELL == LAS_CELL_LSTM) {
+                    if (LAS_ABL & 8) { orow[ul] = res[r][5]; continue; }
+                    orow[ul] = res[r][0]; orow[(G > 1 ? 1 : 0) * UPM + ul] = res[r][1]; orow[(G > 2 ? 2 : 0) * UPM + ul] = res[r][2];
+                    orow[(G > 3 ? 3 : 0) * UPM + ul] = res[r][3];
+                    orow[G * UPM + ul] = res[r][4];
+                    orow[(G + 1) * UPM + ul] = res[r][5];
+                } else {
+                    orow[ul] = res[r][5];
+                }
             }
         }
         HSTAMP(2);
@@ -1338,12 +1361,14 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&dzc[(c & (RB - 1)) * LDZ + ks * 32 + g * 8]);
         __builtin_amdgcn_sched_barrier(0);
+        // (measured: contracting the partners' tiles first and the own tile under the sends / the poll is slower, 1.31-1.36 vs 1.29 us)
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
 #pragma unroll
             for (int m = 0; m < P; ++m)
 #pragma unroll
                 for (int j = 0; j < UTP; ++j) acc[m][j] = mfma_bf16_16x16x32(av[ks], wreg[(m * UTP + j) * KSP + ks], acc[m][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef LAS_PROF
         asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[P - 1][UTP - 1][3]));
@@ -1363,6 +1388,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 for (int j = 0; j < UTP; ++j)     // the four partial sums of a lane travel as two bf16 pairs in ONE 16-byte double granule
                     granule16_store(xrs, dst_off + (unsigned)j * 1024u, (unsigned)(s + 1), f2bf2(acc[mo][j][0], acc[mo][j][1]),
                                     f2bf2(acc[mo][j][2], acc[mo][j][3]), local);
+                __builtin_amdgcn_sched_barrier(0);
             }
             KSTAMP(5);
             constexpr int NGT = (P - 1) * UTP;
@@ -1413,6 +1439,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                 for (int j = 0; j < UTP; ++j)
                     granule8_store(xrs, dst_off + (unsigned)j * 512u, (unsigned)(s + 1),
                                    f2bf2(hsel ? acc[mo][j][1] : acc[mo][j][0], hsel ? acc[mo][j][3] : acc[mo][j][2]), local);
+                __builtin_amdgcn_sched_barrier(0);
             }
             KSTAMP(5);
             constexpr int NGT = (P - 1) * UTP;
