@@ -659,6 +659,9 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
     const float v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
     if (!(col & 3)) granule16_store(rs, (unsigned)((row_gran + (col >> 2)) * 16), tag, f2bf2(v, v1), f2bf2(v2, v3), local);
 }
+#ifndef LAS_ABL_SP
+#define LAS_ABL_SP 0   // development: bit mask of parts of the forward row to leave out (timing experiments only; make abl_sp ABL=<mask>)
+#endif
 template <int CELL, int NE, bool LOOP>
 __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, const int tid, float* sm, float& ccar, const bool local) {
     constexpr bool FAST = true;
@@ -698,14 +701,14 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
-        w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kpc * A4 + a4c];
+        w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : (size_t)kpc * A4 + a4c];
     }
     const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
     uint4 k8[NK];
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c];
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
     }
     STAMPX(1);
     if (LOOP && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
@@ -813,7 +816,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     for (int u = 0; u < NE; ++u) {
         const int tp = fg + 8 * u;
         const int tpc = tp < Tp2 ? tp : Tp2 - 1;
-        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b * Tp2 + tpc) * H4 + h4c];
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp2 + tpc) * H4 + h4c];
     }
     for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
@@ -837,7 +840,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
                 float k[8];
                 unpack8(k8[u], k);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) part = fmaf(u8[e], tanhx<FAST>(k[e] + q8[e]), part);
+                for (int e = 0; e < 8; ++e) part = fmaf(u8[e], (LAS_ABL_SP & 2) ? (k[e] + q8[e]) * 0.1f : tanhx<FAST>(k[e] + q8[e]), part);
             }
             part = sub16_sum(part);
             if (a8 == 0 && tt < Tp) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207

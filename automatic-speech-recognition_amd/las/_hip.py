@@ -18,7 +18,7 @@ ATT_ADD, ATT_LOC = 0, 1
 DT_F32, DT_BF16 = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "liblas_hip.so")
+LIB_PATH = os.environ.get("LAS_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "liblas_hip.so")   # (override: development builds)
 _lib = None
 
 

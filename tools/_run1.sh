@@ -1,4 +1,3 @@
 cd /root/repo
-python -m pytest tests/test_gpu_rnn_seq.py -x -q 2>&1 | tail -2
-python tools/bench_rnn.py 2>&1 | tail -2
-python tools/prof_rnn.py 2>&1 | grep -A15 "lstm fwd"
+python tools/bench_speller.py 2>&1 | grep speller
+for m in 1 2 3; do echo abl $m; LAS_LIB_PATH=/root/repo/automatic-speech-recognition_amd/lib/liblas_hip_ablsp$m.so python tools/bench_speller.py 2>&1 | grep speller_fwd; done
