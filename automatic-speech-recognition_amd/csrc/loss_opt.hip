@@ -238,3 +238,47 @@ extern "C" int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const
     LAS_LAUNCHED();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// bf16 weight shadows of the speed mode (las.layers._shadow): after every optimiser step ALL of them are rebuilt from the fp32
+// masters by ONE launch.  A shadow is D = pad(op([S0 | S1])): up to two fp32 sources concatenated along the columns, optionally
+// transposed, zero-padded to dst_rows x dst_cols, stored as bf16 (or fp32).  grid = (max tiles over the shadows, shadows).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_shadows_kernel(const las_shadow_desc* __restrict__ descs) {
+    const las_shadow_desc d = descs[blockIdx.y];
+    const int tiles_c = (d.dst_cols + 31) / 32, tiles_r = (d.dst_rows + 31) / 32;
+    if ((int)blockIdx.x >= tiles_c * tiles_r) return;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, four rows each
+    __shared__ float tile[32][33];
+    const int cols = d.cols0 + d.cols1;
+    auto src = [&](int r, int c) -> float {
+        if (r >= d.rows || c >= cols) return 0.f;
+        return c < d.cols0 ? d.src0[(long long)r * d.ld0 + c] : d.src1[(long long)r * d.ld1 + (c - d.cols0)];
+    };
+    // destination element (i, j) = L(j, i) when transposed, else L(i, j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = ty * 4 + k;
+        // read coalesced along the SOURCE columns
+        tile[y][tx] = d.transpose ? src(tc * 32 + y, tr * 32 + tx) : src(tr * 32 + y, tc * 32 + tx);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int y = ty * 4 + k;
+        const int i = tr * 32 + y, j = tc * 32 + tx;
+        if (i >= d.dst_rows || j >= d.dst_cols) continue;
+        const float v = d.transpose ? tile[tx][y] : tile[y][tx];
+        if (d.dst_bf16) reinterpret_cast<unsigned short*>(d.dst)[(long long)i * d.dst_ld + j] = f2bf(v);
+        else            reinterpret_cast<float*>(d.dst)[(long long)i * d.dst_ld + j] = v;
+    }
+}
+
+extern "C" int las_build_shadows(const las_shadow_desc* descs_dev, int n, int max_tiles, void* stream) {
+    LAS_ARG(descs_dev && n > 0 && max_tiles > 0, "las_build_shadows: bad arguments");
+    hipLaunchKernelGGL(build_shadows_kernel, dim3(max_tiles, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    LAS_LAUNCHED();
+    return 0;
+}

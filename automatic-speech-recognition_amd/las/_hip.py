@@ -52,6 +52,13 @@ class SpellerBwdArgs(Structure):
                 ("dcellW", POINTER(c_void_p)), ("dcellb", POINTER(c_void_p))]
 
 
+class ShadowDesc(ctypes.Structure):
+    """include/las_hip.h las_shadow_desc"""
+    _fields_ = [("src0", c_void_p), ("src1", c_void_p), ("ld0", c_int), ("ld1", c_int), ("rows", c_int), ("cols0", c_int),
+                ("cols1", c_int), ("transpose", c_int), ("dst", c_void_p), ("dst_rows", c_int), ("dst_cols", c_int),
+                ("dst_ld", c_int), ("dst_bf16", c_int)]
+
+
 _SIGS = {
     "las_version": (c_int, []),
     "las_last_error": (c_char_p, []),
@@ -89,6 +96,7 @@ _SIGS = {
     "las_sumsq": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
                               c_float, c_float, c_float, c_void_p]),
+    "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -152,14 +160,23 @@ def stream():
 _ws_cache = {}
 
 
+_ws_epoch = {}
+
+
 def workspace(dev, nbytes, tag="default"):
-    """Grow-only scratch buffer per (device, tag)."""
+    """Grow-only scratch buffer per (device, tag).  Every request bumps the tag's epoch: a caller that wants to find what its
+    previous call left in the buffer (the Speller's backward reusing the forward's operand copies) compares epochs."""
     key = (str(dev), tag)
+    _ws_epoch[key] = _ws_epoch.get(key, 0) + 1
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
         _ws_cache[key] = buf
     return buf
+
+
+def workspace_epoch(dev, tag):
+    return _ws_epoch.get((str(dev), tag), 0)
 
 
 GEMM_WS_BYTES = 256 << 20

@@ -142,6 +142,7 @@ class _SpellerLoop(torch.autograd.Function):
                               emb_mask=emb_mask, emb_noise=emb_noise)
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], dims["V"], dims["U"], dims["cell"])
         ws = _hip.workspace(dev, nbytes, "speller")
+        ctx.ws_epoch = _hip.workspace_epoch(dev, "speller")
         fa.ws, fa.ws_bytes = ws.data_ptr(), ws.numel()
         with _hip._timed("speller_fwd[U=%d]" % dims["U"]):
             _hip.check(_hip.lib().las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
@@ -178,10 +179,14 @@ class _SpellerLoop(torch.autograd.Function):
         dcb = gl[len(names) + NL:len(names) + 2 * NL]
         dWh = gl[-1]
         nbytes = _hip.lib().las_speller_workspace_bytes(B, Tp, Hd, A, dims["D"], NL, dims["E"], V_, U, dims["cell"])
+        # nobody asked for the Speller's workspace since this node's forward: its bf16 copies of enc / keys / Ws are still there
+        reuse = _hip.workspace_epoch(dev, "speller") == ctx.ws_epoch
         ws = _hip.workspace(dev, nbytes, "speller")
         ba = _hip.SpellerBwdArgs()
         keepf = _fill_fwd_args(ba.f, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,
                                emb_mask=emb_mask, emb_noise=emb_noise)
+        if reuse:
+            ba.f.flags |= _hip.SPELLER_REUSE_PREP
         ba.f.ws, ba.f.ws_bytes = ws.data_ptr(), ws.numel()
         ba.dlogits = dlogits.data_ptr()
         ba.d_enc, ba.d_keys = d_enc.data_ptr(), d_keys.data_ptr()

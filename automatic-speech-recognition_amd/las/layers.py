@@ -246,14 +246,48 @@ class _BLSTM(torch.autograd.Function):
 # (both operands bf16, contraction index contiguous) against bf16 SHADOWS of the fp32 master weights, kept in both
 # orientations and rebuilt after every optimiser step (`_shadow`).  Parameters, their gradients and Adam stay fp32.
 # ------------------------------------------------------------------------------------------------
-def _shadow(tag, params, build):
+def _shadow(tag, srcs, rows, transpose, dst_rows, dst_cols, bf16=True):
+    """Operand copy of one or two fp32 parameters for the speed-mode products: D = zero-pad(op([S0[:rows] | S1[:rows]])) with
+    op = transpose or identity, [dst_rows, dst_cols], bf16 (or fp32).  Valid until the parameters change (Adam / load / flatten
+    clear `store.shadows`).  The first build runs through torch and registers the recipe; afterwards ALL registered shadows are
+    rebuilt together by one las_build_shadows launch at the first request after an optimiser step."""
+    import ctypes
     st = V.default_store()
-    key = (tag,) + tuple(int(q.data_ptr()) for q in params)
+    key = (tag, int(rows), bool(transpose), int(dst_rows), int(dst_cols), bool(bf16)) + tuple(int(q.data_ptr()) for q in srcs)
     sh = st.shadows.get(key)
-    if sh is None:
-        with torch.no_grad():
-            sh = build()
-        st.shadows[key] = sh
+    if sh is not None:
+        return sh
+    if key in st.shadow_recipes:
+        recs = list(st.shadow_recipes.values())
+        if st.shadow_table is None or st.shadow_table[1] != len(recs):
+            arr = (_hip.ShadowDesc * len(recs))(*[r[1] for r in recs])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            mt = max(((r[1].dst_rows + 31) // 32) * ((r[1].dst_cols + 31) // 32) for r in recs)
+            st.shadow_table = (host.to(recs[0][0].device), len(recs), mt)
+        tab, n, mt = st.shadow_table
+        _hip.check(_hip.lib().las_build_shadows(tab.data_ptr(), n, mt, _hip.stream()), "las_build_shadows")
+        for k, r in st.shadow_recipes.items():
+            st.shadows[k] = r[0]
+        return st.shadows[key]
+    with torch.no_grad():
+        mats = [(q.detach().reshape(1, -1) if q.dim() == 1 else q.detach())[:rows] for q in srcs]
+        Lm = torch.cat(mats, 1) if len(mats) > 1 else mats[0]
+        D = Lm.t() if transpose else Lm
+        sh = torch.zeros(dst_rows, dst_cols, device=D.device, dtype=torch.bfloat16 if bf16 else torch.float32)
+        sh[:D.shape[0], :D.shape[1]] = D
+    d = _hip.ShadowDesc()
+    d.src0 = mats[0].data_ptr(); d.ld0 = mats[0].stride(0) if mats[0].shape[0] > 1 else mats[0].shape[1]
+    d.cols0 = mats[0].shape[1]; d.rows = mats[0].shape[0]
+    if len(mats) > 1:
+        assert mats[1].shape[0] == mats[0].shape[0]
+        d.src1 = mats[1].data_ptr(); d.ld1 = mats[1].stride(0) if mats[1].shape[0] > 1 else mats[1].shape[1]; d.cols1 = mats[1].shape[1]
+    else:
+        d.src1 = None; d.ld1 = 0; d.cols1 = 0
+    d.transpose = int(bool(transpose)); d.dst = sh.data_ptr(); d.dst_rows, d.dst_cols, d.dst_ld = dst_rows, dst_cols, dst_cols
+    d.dst_bf16 = int(bool(bf16))
+    st.shadow_recipes[key] = (sh, d, srcs)          # (srcs kept alive: the descriptor holds their addresses)
+    st.shadow_table = None
+    st.shadows[key] = sh
     return sh
 
 
@@ -277,7 +311,7 @@ class _Dense16(torch.autograd.Function):
     def forward(ctx, x2d, W, b, act, out_f32):
         M, K = x2d.shape                               # K = padded width of the operand (>= W.shape[0])
         Kw, N = W.shape
-        WT = _shadow("denseT", (W,), lambda: _as_bf16_operand(W.detach().t()))           # [N, K64]
+        WT = _shadow("denseT", (W,), Kw, True, N, _k64(Kw))                              # W^T: [N, K64]
         y = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
         _hip.gemm_kk(x2d, WT, y, M, N, K, K, K, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
         ctx.save_for_backward(x2d, W, y)
@@ -298,7 +332,7 @@ class _Dense16(torch.autograd.Function):
             dpre = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
         dx = None
         if ctx.needs_input_grad[0]:                    # on the dependency chain: main stream, first
-            Wb = _shadow("dense", (W,), lambda: _as_bf16_operand(torch.nn.functional.pad(W.detach(), (0, 0, 0, K - Kw))))   # [K, N64]
+            Wb = _shadow("dense", (W,), Kw, False, K, _k64(N))                           # W, rows padded to K: [K, N64]
             dx = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
             Nk = Wb.shape[1]
             if Nk != N:                                # contraction width padded to 64: pad dpre too (rare: N % 64 != 0)
@@ -345,12 +379,12 @@ class _BLSTM16(torch.autograd.Function):
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=bf)
         if not two:
             # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
-            WT = _shadow("ihT", (kfw, kbw), lambda: _as_bf16_operand(torch.cat((kfw.detach()[:I0], kbw.detach()[:I0]), 1).t()))   # [2GH, Ik]
-            bias = _shadow("ihb", (bfw, bbw), lambda: torch.cat((bfw.detach(), bbw.detach())))
+            WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
+            bias = _shadow("ihb", (bfw, bbw), 1, False, 1, 2 * GH, bf16=False).view(-1)
             _hip.gemm_kk(x, WT, gates, B * T, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
         else:
             for d, (xd, k, b) in enumerate(((x, kfw, bfw), (x_bw, kbw, bbw))):
-                WTd = _shadow("ihT%d" % d, (k,), lambda k=k: _as_bf16_operand(k.detach()[:I0].t()))                           # [GH, Ik]
+                WTd = _shadow("ihT%d" % d, (k,), I0, True, GH, _k64(I0))                    # [GH, Ik]
                 _hip.gemm_kk(xd, WTd, gates, B * T, GH, Ik, Ik, Ik, 2 * GH, bias=b.detach(), c_off=d * GH)
         Tp = T + (T % 2) if pad_even else T
         out = torch.zeros(B, Tp, 2 * H, device=dev, dtype=bf) if Tp != T else torch.empty(B, T, 2 * H, device=dev, dtype=bf)
@@ -384,14 +418,13 @@ class _BLSTM16(torch.autograd.Function):
         dx = dx_bw = None
         if ctx.needs_input_grad[0] and not two:        # on the dependency chain: main stream, first
             # dX [B*T, Ik] = dZ [B*T, 2GH] . [W_ih_fw | W_ih_bw]^T : B operand = shadow of the concatenated weights [Ik, 2GH]
-            Wb = _shadow("ih", (kfw, kbw), lambda: torch.nn.functional.pad(
-                torch.cat((kfw.detach()[:I0], kbw.detach()[:I0]), 1), (0, 0, 0, Ik - I0)).to(bf).contiguous())
+            Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
             _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik)
         elif two and (ctx.needs_input_grad[0] or ctx.needs_input_grad[9]):
             dx, dx_bw = torch.empty(B, T, Ik, device=dev, dtype=bf), torch.empty(B, T, Ik, device=dev, dtype=bf)
             for d, (dxd, k) in enumerate(((dx, kfw), (dx_bw, kbw))):
-                Wd = _shadow("ih%d" % d, (k,), lambda k=k: torch.nn.functional.pad(k.detach()[:I0], (0, 0, 0, Ik - I0)).to(bf).contiguous())
+                Wd = _shadow("ih%d" % d, (k,), I0, False, Ik, GH)
                 _hip.gemm_kk(gates, Wd, dxd, B * T, Ik, GH, 2 * GH, GH, Ik, a_off=d * GH)
         _hip.run_deferred()
         Ig = (I0 + 3) // 4 * 4          # rows of dW_ih the TN product writes; rows I0..Ig meet zero operand columns (exact zeros)

@@ -28,6 +28,8 @@ class VariableStore:
         self.flat = self.flat_grad = self.adam_m = self.adam_v = None
         self.global_step = 0
         self.shadows = {}         # bf16 copies of weights for the speed-mode products (las.layers._shadow); cleared when weights change
+        self.shadow_recipes = {}  # key -> (tensor, ShadowDesc): how to rebuild every shadow in ONE launch (cleared when storage moves)
+        self.shadow_table = None
 
     # ---- creation ----------------------------------------------------------------------------
     def get(self, name, shape=None, init="glorot", fan=None):
@@ -72,6 +74,8 @@ class VariableStore:
     def load(self, params):
         """Install externally supplied values {name: array} (parity tests, checkpoints)."""
         self.shadows.clear()
+        self.shadow_recipes.clear()
+        self.shadow_table = None
         for name, val in params.items():
             val = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val,
                                   dtype=torch.float32, device=self.device)
@@ -94,6 +98,8 @@ class VariableStore:
         if self.flat is not None:
             return
         self.shadows.clear()
+        self.shadow_recipes.clear()
+        self.shadow_table = None
         names = list(self.order)
         sizes = [self.vars[n].numel() for n in names]
         offs, o = [], 0

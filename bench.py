@@ -157,14 +157,17 @@ def recorded_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes recorded under profiles/ (FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).
     Only a recording made from THIS kernel source counts: the file stores the sha of csrc/rnn_seq.hip; else null."""
+    import glob
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json")))
         src = os.path.join(ROOT, "automatic-speech-recognition_amd", "csrc", "rnn_seq.hip")
-        if rec.get("rnn_seq_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
-            return None
-        for k, v in rec["kernels"].items():
-            if k.startswith(kernel_prefix):
-                return v["hbm_bytes_per_launch"]
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+            rec = json.load(open(path))
+            if rec.get("rnn_seq_sha16") != sha:
+                continue
+            for k, v in rec["kernels"].items():
+                if k.startswith(kernel_prefix):
+                    return v["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None

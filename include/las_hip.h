@@ -184,7 +184,7 @@ enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetchin
        LAS_SPELLER_NO_BF_ROWS = 2,    /* speed mode with the fp32-operand row kernels */
        LAS_SPELLER_NO_FUSED_STEP = 4,   /* speed mode with two launches per step (row kernel, then the cell product)
                                            instead of the whole loop in one launch (product + row workgroups, granule hand-off) */
-       LAS_SPELLER_REUSE_PREP = 8 };    /* las_speller_fwd only: the workspace still holds the bf16 copies of enc / keys / Ws and the
+       LAS_SPELLER_REUSE_PREP = 8 };    /* (las_speller_bwd: operand copies only) the workspace still holds the bf16 copies of enc / keys / Ws and the
                                            packed cell weights that an earlier call made from the SAME tensors -- skip rebuilding
                                            them (beam search calls the step U = 1 at a time against a fixed encoder output) */
 typedef struct {
@@ -253,6 +253,18 @@ int las_ce_loss(const float* logits, long long sb, long long st, const int* y, i
  * g *= clip/max(sqrt(sumsq[0]),clip) when clip>0;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller;  theta -= lr_t * m / (sqrt(v) + eps)   (TF "epsilon-hat" placement).
  */
+/* bf16 (or fp32) weight shadows of the speed mode, rebuilt after every optimiser step by ONE launch over a device-resident
+ * descriptor table: D = zero-pad(op([src0 | src1])), op = transpose or identity; src1 may be NULL (cols1 = 0).
+ * max_tiles >= max over the descriptors of ceil(dst_rows/32) * ceil(dst_cols/32).  (No reference counterpart: the
+ * reference's fp32 graph has no operand copies; this replaces ~50 small copy / cat / cast kernels per step.) */
+typedef struct las_shadow_desc {
+    const float* src0; const float* src1;
+    int ld0, ld1, rows, cols0, cols1, transpose;
+    void* dst;
+    int dst_rows, dst_cols, dst_ld, dst_bf16;
+} las_shadow_desc;
+int las_build_shadows(const las_shadow_desc* descs_dev, int n, int max_tiles, void* stream);
+
 size_t las_sumsq_workspace_bytes(long long n);
 int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream);
 int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,

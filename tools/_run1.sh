@@ -1,3 +1,3 @@
 cd /root/repo
-python tools/bench_speller.py 2>&1 | grep speller
-for m in 1 2 3; do echo abl $m; LAS_LIB_PATH=/root/repo/automatic-speech-recognition_amd/lib/liblas_hip_ablsp$m.so python tools/bench_speller.py 2>&1 | grep speller_fwd; done
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode 2>&1 | tail -1 | cut -c1-330
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5
