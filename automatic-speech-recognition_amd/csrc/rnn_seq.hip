@@ -1522,8 +1522,15 @@ __global__ __launch_bounds__(256) void bias_finish_kernel(const float* __restric
 // fragments for the K-split BPTT: (dir, vw = pm*4+w, m, j, ks):
 //   B[k][n] = W_hh[unit n = m*UPM + (w*UTP + j)*16 + (lane&15)][gate col of k],  k = ks*32 + 8*(lane>>4) + e in the
 //   member's slice: q = k / UPM, gate col = q*H + pm*UPM + (k % UPM)
+// the pack kernels also clear the launch's exchange state (error flag, scratch rows, placement handshake, bias partials, granule
+// tags): one launch instead of a pack + a memset node in front of every sweep
+__device__ __forceinline__ void zero_region(uint4* z, long long n16) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 __global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const float* W1, int ldw, int H, int G, int P,
-                                                          unsigned short* out) {
+                                                          unsigned short* out, uint4* zero, long long zero16) {
+    zero_region(zero, zero16);
     const int UTP = H / 64 / P, UPM = H / P, KP = G * UPM, KSP = KP / 32, NFR = P * UTP * KSP, NVW = 4 * P;
     const long long total = 2LL * NVW * NFR * 512;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -1548,7 +1555,8 @@ __global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const
 //  fwd: frag (dir,vw,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + vw*16*UTP + j*16 + (lane&15)]
 //  bwd: frag (dir,vw,j,ks):   B[k][n] = W[vw*16*UTP + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
 __global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const float* W1, int ldw, int H, int G,
-                                                       int bwd, int P, unsigned short* out) {
+                                                       int bwd, int P, unsigned short* out, uint4* zero, long long zero16) {
+    zero_region(zero, zero16);
     const int UTP = H / 64 / P, GH = G * H, NVW = 4 * P;
     const int KS = bwd ? GH / 32 : H / 32;
     const int NF = bwd ? UTP * KS : G * UTP * KS;
@@ -1766,12 +1774,14 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         a.force_agent = (flags & LAS_SEQ_AGENT_GRANULES) ? 1 : 0;
         a.no_helpers = (flags & LAS_SEQ_NO_HELPER_WAVES) ? 1 : 0;
         a.ks_packed = (bwd && P > 1 && !(flags & LAS_SEQ_NO_KSPLIT)) ? 1 : 0;
+        // (err, sink, and for clusters the handshake / bias partials / granule tags: multiples of 256 bytes by construction)
+        uint4* zr = (uint4*)(base + L.err);
+        const long long z16 = (long long)(((P > 1 ? L.total : L.xbuf) - L.err) / 16);
         if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
-                                            (unsigned short*)a.wpack);
+                                            (unsigned short*)a.wpack, zr, z16);
         else hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
-                                (unsigned short*)a.wpack);
+                                (unsigned short*)a.wpack, zr, z16);
         LAS_LAUNCHED();
-        LAS_HIP(hipMemsetAsync(base + L.err, 0, (P > 1 ? L.total : L.xbuf) - L.err, st));   // err, sink, (granules)
         // row tiles per launch: clusters (tile, direction) are padded to a multiple of 8 workgroups per member
         int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
         if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, las_device_cus()); rc = -2; continue; }
