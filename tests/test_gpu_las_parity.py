@@ -151,3 +151,37 @@ def test_training_with_dropout_runs_and_is_masked():
     logits, _ = las.inference(xs)
     logits2, _ = las.inference(xs)
     assert torch.equal(logits, logits2)                              # no dropout at inference
+
+
+def test_weight_shadows_are_rebuilt_by_one_launch_and_match_the_torch_build():
+    """las.layers._shadow: the first request builds a bf16 operand copy with torch and registers its recipe; after the
+    parameters change (store.shadows cleared, as Adam does) ONE las_build_shadows launch rebuilds every registered copy.
+    Both must give the same bits for every recipe shape the Listener uses (transposed / concatenated / padded / fp32 bias)."""
+    from las import _hip, layers as L, variables as V
+    st = V.reset_default_store(device="cuda", seed=0)
+    kfw = st.get("a/kfw", (39 + 64, 256)); kbw = st.get("a/kbw", (39 + 64, 256))
+    bfw = st.get("a/bfw", (256,), init="uniform1"); bbw = st.get("a/bbw", (256,), init="uniform1")
+    W = st.get("a/dense", (200, 96))
+    st.flatten()
+
+    def all_shadows():
+        return [L._shadow("ihT", (kfw, kbw), 39, True, 512, 64), L._shadow("ihb", (bfw, bbw), 1, False, 1, 512, bf16=False),
+                L._shadow("ih", (kfw, kbw), 39, False, 64, 512), L._shadow("ihT0", (kfw,), 39, True, 256, 64),
+                L._shadow("denseT", (W,), 200, True, 96, 256), L._shadow("dense", (W,), 200, False, 256, 128)]
+
+    first = [t.clone() for t in all_shadows()]                       # torch builds
+    assert len(st.shadow_recipes) == 6
+    with torch.no_grad():
+        want = torch.cat((kfw[:39], kbw[:39]), 1).t().to(torch.bfloat16)
+    assert torch.equal(first[0][:, :39], want) and first[0][:, 39:].abs().max().item() == 0
+    with torch.no_grad():
+        st.flat.mul_(-1.5).add_(0.01)                                # "optimiser step"
+    st.shadows.clear()
+    second = all_shadows()                                           # one fused launch
+    st.shadows.clear(); st.shadow_recipes.clear(); st.shadow_table = None
+    third = all_shadows()                                            # torch builds of the NEW values
+    torch.cuda.synchronize()
+    for a, b, c in zip(first, second, third):
+        assert a.shape == b.shape == c.shape and b.dtype == c.dtype
+        assert torch.equal(b, c)
+        assert not torch.equal(a, b)

@@ -138,3 +138,33 @@ def test_batches_larger_than_the_cu_budget_are_swept_in_row_chunks():
     torch.cuda.synchronize()
     _hip.check_status()
     assert (out.float().cpu() - ref).abs().max().item() < 4e-2
+
+
+@pytest.mark.parametrize("case", [("lstm", 1, 48, 40, 256), ("lstm", 1, 37, 23, 256), ("lstm", 1, 5, 9, 256), ("lstm", 1, 20, 33, 128)])
+def test_rows16_flag_gives_the_same_sweep(case):
+    """The clustered sweeps default to 8-row batch tiles (duplicated MFMA rows, half the per-lane work of a dependent step);
+    LAS_SEQ_ROWS16 selects the 16-row tiling.  Both are checked against the oracle by test_rnn_seq_fwd_bwd (default) and here
+    (flag); the two tilings must also agree with EACH OTHER to rounding noise of the bf16 exchange."""
+    from las import _hip
+    cell, prec, B, T, H = case
+    GH = 4 * H
+    g = torch.Generator().manual_seed(7)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).to(torch.bfloat16)
+    whh = [((torch.rand(H, GH, generator=g) * 2 - 1) * 0.06).cuda() for _ in range(2)]
+    R = torch.randn(B, T, 2 * H, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for flags in (0, _hip.SEQ_ROWS16):
+        gates = xp.cuda().clone()
+        out = torch.zeros(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+        cst = torch.zeros(B, T, 2, H, device="cuda", dtype=torch.bfloat16)
+        _hip.rnn_seq_fwd(1, 1, B, T, H, gates, whh[0], whh[1], GH, out, 2 * H, T * 2 * H, cst, flags=flags)
+        db = [torch.zeros(GH, device="cuda") for _ in range(2)]
+        _hip.rnn_seq_bwd(1, 1, B, T, H, gates, whh[0], whh[1], GH, out, 2 * H, T * 2 * H, cst, R, 2 * H, T * 2 * H,
+                         db_fw=db[0], db_bw=db[1], flags=flags)
+        torch.cuda.synchronize()
+        _hip.check_status()
+        res.append((out.float().cpu(), cst.float().cpu(), gates.float().cpu(), db[0].cpu(), db[1].cpu()))
+    names = ("h", "c", "dZ", "db_fw", "db_bw")
+    for n, a, b in zip(names, res[0], res[1]):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2e-2 * scale, (n, case, (a - b).abs().max().item(), scale)

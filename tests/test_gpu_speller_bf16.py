@@ -89,3 +89,35 @@ def test_bf16_row_kernels_match_oracle(shape, flags):
         scale = max(go[n].abs().max().item(), 1e-3)
         err = (gn[n] - go[n]).abs().max().item() / scale
         assert err < 2e-2, (n, err, scale)
+
+
+def test_backward_reuses_the_forward_operand_copies_only_when_nobody_else_used_the_workspace():
+    """_SpellerLoop.backward passes LAS_SPELLER_REUSE_PREP when no other Speller call asked for the workspace since its own
+    forward (the bf16 copies of enc / keys / Ws are still there).  An interleaved call on OTHER inputs must switch the reuse
+    off: the gradients of the first call have to be the same either way."""
+    from las import _hip, layers as L, variables as V
+    from las.las import Speller
+    L.set_cell("lstm"); L.set_precision("bf16")
+    grads = []
+    for interleave in (False, True):
+        V.reset_default_store(device="cuda", seed=3)
+        args = make_args(enc_units=64, num_enc_layers=2, dec_units=128, num_dec_layers=1, embedding_size=64, attention_size=64,
+                         mode="add", vocab_size=30, enc_type="pblstm")
+        sp = Speller(args)
+        rng = np.random.RandomState(5)
+        enc = torch.tensor(rng.randn(6, 40, 128).astype(np.float32) * 0.5, device="cuda", requires_grad=True)
+        enc2 = torch.tensor(rng.randn(6, 40, 128).astype(np.float32) * 0.5, device="cuda")
+        enc_len = rng.randint(20, 41, size=6)
+        y = rng.randint(3, 30, size=(6, 9))
+        w = torch.tensor(rng.randn(6, 9, 30).astype(np.float32)).cuda()
+        logits, _, _ = sp(enc, enc_len, 9, teacher=y, is_training=True)
+        if interleave:
+            with torch.no_grad():
+                sp(enc2, enc_len, 9, teacher=y, is_training=True)        # overwrites the workspace's operand copies
+        (logits * w).sum().backward()
+        _hip.join_side_stream()
+        torch.cuda.synchronize()
+        st = V.default_store()
+        grads.append([enc.grad.cpu().clone()] + [st.vars[n].grad.detach().cpu().clone() for n in st.order])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
