@@ -1019,7 +1019,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             for (int ww = 0; ww < RNW; ++ww) v += red[((size_t)(ww * TPW + tl) * 64 + l2) * 4 + reg];
             const int ct = j * TPW + tl, col = ct * 16 + c16, orow = r16 * 8 + x;
             const bool valid = r16 < Rx && ct < p.nct && col < p.N;
-            if (p.bias && valid) v += p.bias[col];
+            if (!(LAS_ABL_SP & 4) && p.bias && valid) v += p.bias[col];
             const float nb = __shfl_xor(v, 1, 64);
             if (valid) {
                 if (p.C) p.C[(long long)step * p.c_step + (long long)orow * p.ldc + col] = v;

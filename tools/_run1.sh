@@ -1,2 +1,5 @@
 cd /root/repo
-python -m pytest tests/test_gpu_rnn_seq.py tests/test_gpu_speller_bf16.py tests/test_gpu_las_parity.py -x -q -k "rows16 or shadows or reuses" 2>&1 | tail -15
+for i in 1 2; do
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-decode 2>&1 | tail -1 | cut -c100-200
+LAS_NO_TAIL2=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-decode 2>&1 | tail -1 | cut -c100-200
+done
