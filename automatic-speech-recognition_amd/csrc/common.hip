@@ -25,3 +25,22 @@ int las_device_cus() {
     }();
     return cus;
 }
+
+// Stream-ordered wait on a device word (bounded): everything enqueued behind it on `stream` starts only once *word == value
+// or max_us microseconds have passed.  A scheduling aid, never a correctness dependency: the host uses it to keep the
+// weight-gradient GEMMs of the side stream off the machine until the next recurrent sweep (LAS_SEQ_ANNOUNCE) is resident.
+__global__ __launch_bounds__(64) void wait_word_kernel(const int* word, int value, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();                      // 100 MHz
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
+        if (wall_clock64() - t0 > max_ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+extern "C" int las_wait_word(const int* word, int value, int max_us, void* stream) {
+    LAS_ARG(word && max_us >= 0, "las_wait_word: bad arguments");
+    hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, value, (long long)max_us * 100);
+    LAS_LAUNCHED();
+    return 0;
+}

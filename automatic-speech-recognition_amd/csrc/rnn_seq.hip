@@ -44,6 +44,7 @@ struct RnnArgs {
     int* status;                             // caller-owned sticky device word (may be NULL): LAS_SEQ_STATUS_* on failure
     int status_code;
     int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
+    int announce;                            // LAS_SEQ_ANNOUNCE(n): cluster 0 stores n into status[1] once its members are resident
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
 };
 
@@ -1198,6 +1199,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     const __amdgpu_buffer_rsrc_t xrs = granule_rsrc(xb);
     int errflag = 0;
     const bool local = a.force_agent ? false : cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin);
+    // "this sweep is on the machine": lets the host hold back work of other streams until then (las_wait_word)
+    if (a.announce && a.status && cl == 0 && pm == 0 && tid == 0)
+        __hip_atomic_store(a.status + 1, a.announce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const int t0 = dir ? 0 : T - 1;
     const long long tstep = dir ? 1 : -1;
@@ -1823,6 +1827,7 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;
+    a.announce = (flags >> 21) & 0x3ff;
 }
 
 extern "C" int las_rnn_seq_io_dtype(int cell, int prec, int H) {

@@ -97,6 +97,7 @@ _SIGS = {
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
                               c_float, c_float, c_float, c_void_p]),
     "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -372,9 +373,22 @@ def status_word(dev):
     key = str(dev)
     t = _status.get(key)
     if t is None:
-        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        t = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] sticky error code, [1] launch announcements (LAS_SEQ_ANNOUNCE)
         _status[key] = t
     return t
+
+
+_announce = [0]
+
+
+def next_announce():
+    """The value the NEXT BPTT sweep will store into status_word[1] when it is resident (1..1023, cyclic)."""
+    return _announce[0] % 1023 + 1
+
+
+def hold_until_next_sweep(dev, max_us=1500):
+    """Enqueue (on the current = side stream) a bounded wait for the next BPTT sweep's announcement."""
+    check(lib().las_wait_word(c_void_p(status_word(dev).data_ptr() + 4), next_announce(), max_us, stream()), "las_wait_word")
 
 
 def check_status(dev=None):
@@ -383,7 +397,7 @@ def check_status(dev=None):
     for key, t in list(_status.items()):
         if dev is not None and str(dev) != key:
             continue
-        code = int(t.item())
+        code = int(t[0].item())
         if code:
             t.zero_()
             raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s -- the cluster workgroups were not "
@@ -410,7 +424,7 @@ def poll_status(dev):
             raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s" % (key, code, SEQ_STATUS.get(code, "unknown")))
         pr = None
     if pr is None:
-        pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+        pin = torch.zeros(2, dtype=torch.int32).pin_memory()
         ev = torch.cuda.Event()
         pin.copy_(_status[key], non_blocking=True)
         ev.record()
@@ -453,6 +467,8 @@ def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
     _check_io(cell, prec, H, gates, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
+    fl |= next_announce() << 21                    # LAS_SEQ_ANNOUNCE: status_word[1] = this number once the sweep is resident
+    _announce[0] += 1
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_bwd_db(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                        c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,

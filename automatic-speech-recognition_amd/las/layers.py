@@ -98,6 +98,8 @@ class _Dense(torch.autograd.Function):
 
 
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
+import os
+HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
 
 
@@ -394,6 +396,7 @@ class _BLSTM16(torch.autograd.Function):
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
         ctx.cfg = (cell, H, Tp, I0)
         ctx.params = _PARAMS.get("blstm")
+        ctx.hold_side = bool(_PARAMS.get("hold_side")) and HOLD_SIDE
         return out
 
     @staticmethod
@@ -449,6 +452,11 @@ class _BLSTM16(torch.autograd.Function):
                 side = _hip.side_stream()
                 for t in (x, gates, out) + ((x_bw,) if two else ()):
                     t.record_stream(side)
+                if ctx.hold_side and ctx.needs_input_grad[0]:
+                    # keep the side stream (these GEMMs and whatever is queued behind them) off the machine until the NEXT
+                    # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
+                    # front of it; bounded wait, scheduling only
+                    _hip.hold_until_next_sweep(dev)
                 for d in range(2):
                     wgrads(lambda d: P4[2 * d].grad, d)
             return (dx, None, None, None, None, None, None, None, None, dx_bw)
@@ -497,7 +505,9 @@ def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pa
     H = int(cell_units)
     I = inputs.shape[-1]
     kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
+    after_blstm = _PARAMS.pop("after_blstm", False)
     _PARAMS["blstm"] = (kfw, bfw, kbw, bbw)
+    _PARAMS["hold_side"] = after_blstm
     if _prec() == _hip.PREC_BF16 and _hip.rnn_seq_io_dtype(_cellid(cell), _hip.PREC_BF16, H) == torch.bfloat16:
         # speed mode: bf16 activation storage (the MFMA sweeps serve this H)
         out = _BLSTM16.apply(_as_bf16_operand(inputs), kfw, bfw, kbw, bbw, cell, H, pad_even, I,
@@ -527,6 +537,7 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     states = None
     for l in range(num_layers):
         sc = scope + "/pyramid_blstm_%d" % l
+        _PARAMS["after_blstm"] = True     # in backward another BPTT sweep (of the layer below) follows this layer's
         _, states, out = _blstm_full(rnn_out, H, dropout_rate, is_training, scope=sc, pad_even=True)
         B, Tp, _ = out.shape
         # Eq (5): pad T to even, concat frame pairs -- a pure view of the zero-padded buffer (:83-88)

@@ -129,6 +129,9 @@ int las_tanh_bwd_dt(const void* Y, int y_dt, int ldy, const void* dY, int dy_dt,
 enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVES = 4, LAS_SEQ_ROWS16 = 8 };
 #define LAS_SEQ_P(p) (((p) & 0xf) << 8)
 #define LAS_SEQ_SPIN_LOG2(n) (((n) & 0x1f) << 16)
+/* LAS_SEQ_ANNOUNCE(n), n in 1..1023 (las_rnn_seq_bwd*, clustered kernels): `status` then points to TWO ints and the launch
+ * stores n into status[1] as soon as its first cluster is resident on the device -- see las_wait_word. */
+#define LAS_SEQ_ANNOUNCE(n) (((n) & 0x3ff) << 21)
 enum { LAS_SEQ_STATUS_OK = 0, LAS_SEQ_STATUS_FWD_TIMEOUT = 1, LAS_SEQ_STATUS_BWD_TIMEOUT = 2 };
 
 size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
@@ -253,6 +256,12 @@ int las_ce_loss(const float* logits, long long sb, long long st, const int* y, i
  * g *= clip/max(sqrt(sumsq[0]),clip) when clip>0;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the
  * caller;  theta -= lr_t * m / (sqrt(v) + eps)   (TF "epsilon-hat" placement).
  */
+/* Stream-ordered, BOUNDED wait on a device word: work enqueued behind it on `stream` starts once *word == value or after
+ * max_us microseconds.  A scheduling aid (never a correctness dependency): the weight-gradient GEMMs of a side stream are
+ * held back until the next recurrent sweep has announced itself (LAS_SEQ_ANNOUNCE), so that they neither delay its start nor
+ * compete with the chain GEMMs in front of it.  No reference counterpart (the reference has one stream). */
+int las_wait_word(const int* word, int value, int max_us, void* stream);
+
 /* bf16 (or fp32) weight shadows of the speed mode, rebuilt after every optimiser step by ONE launch over a device-resident
  * descriptor table: D = zero-pad(op([src0 | src1])), op = transpose or identity; src1 may be NULL (cols1 = 0).
  * max_tiles >= max over the descriptors of ceil(dst_rows/32) * ceil(dst_cols/32).  (No reference counterpart: the
