@@ -4,6 +4,7 @@
 # rocprofv3 databases go to /tmp (they exceed gpurun's 64 MiB merge limit); only the summaries are kept.  Counter passes are
 # separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); python3 bench.py directly after `--`.
 set -u
+# (build both libraries first: make -C automatic-speech-recognition_amd/csrc all prof -- the phase stamps need liblas_hip_prof.so of the SAME source)
 P=${1:-r2}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
