@@ -45,6 +45,7 @@ struct RnnArgs {
     int status_code;
     int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
     int announce;                            // LAS_SEQ_ANNOUNCE(n): cluster 0 stores n into status[1] once its members are resident
+    int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
 };
 
@@ -574,6 +575,52 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 // step take longer than the compute chain, and the barrier then waits for it.)
 // Rows past the end of a ragged batch tile alias the last valid row (identical loads, identical stores).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// L2 warmers.  Ablations (make abl ABL=32|64|128) showed that the bulk HBM traffic of a sweep costs the dependent chain
+// 0.15 us per step NOT by its instruction count but by its MISSES: a load that goes to HBM (or walks the page table) sits in
+// the CU's memory pipeline in front of the latency-critical granule traffic.  One extra workgroup per cluster -- on the same
+// XCD, hence the same L2 -- follows the cluster's progress (the step tags in its exchange slots) and touches the operands of
+// the next steps, so that the cluster's own loads are L2 hits.  Warmers are never waited for: a missing or late warmer only
+// means cold loads; they leave when the cluster has published its last step or after a bounded number of polls.
+//   seg[i]: base of row 0 / step 0 of operand i for this cluster, row stride rs[i] (elements), step stride ss[i] (elements,
+//   signed), nb[i] bytes per row and step (multiple of 16).
+// ------------------------------------------------------------------------------------------------
+struct WarmSeg { const unsigned short* base; long long rs, ss; int nb; };
+template <int NSEG, int LEAD, int AHEAD>      // keep steps [p + LEAD, p + AHEAD] warm (LEAD = how far ahead the cluster itself fetches, + 1)
+__device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, int T, const unsigned long long* tagp0, const unsigned long long* tagp1,
+                                          int spin, unsigned short* sink) {
+    typedef __attribute__((address_space(1))) const u32x4_t gcu4;
+    unsigned acc = 0;
+    int done = -1;                               // last step already touched
+    int idle = 0;
+    for (;;) {
+        const unsigned t0 = (unsigned)(__hip_atomic_load(tagp0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const unsigned t1 = (unsigned)(__hip_atomic_load(tagp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int p = (int)(t0 > t1 ? t0 : t1) - 1;                  // step whose result was published last (-1: none yet)
+        int from = done + 1, to = p + AHEAD;
+        if (from < p + LEAD) from = p + LEAD;
+        if (to > T - 1) to = T - 1;
+        if (from <= to) {
+            idle = 0;
+#pragma unroll
+            for (int i = 0; i < NSEG; ++i) {
+                const int per_row = seg[i].nb / 16, per_step = per_row * rows;
+                const int total = per_step * (to - from + 1);
+                for (int e = threadIdx.x; e < total; e += blockDim.x) {
+                    const int st = from + e / per_step, r = (e % per_step) / per_row, q = e % per_row;
+                    const u32x4_t v = *(gcu4*)(seg[i].base + (long long)r * seg[i].rs + (long long)st * seg[i].ss + q * 8);
+                    acc ^= v.x ^ v.w;
+                }
+            }
+            done = to;
+        }
+        if (p >= T - 2 || done >= T - 1) break;                      // the last step that is ever published is T - 2
+        if (++idle > spin) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (acc == 0x9e3779b9u && sink) sink[threadIdx.x] = (unsigned short)acc;   // keeps the loads alive
+}
+
 template <int CELL, int UT, int P, int RB = 16>
 struct HwCfg {
     using C = RnnCfg<CELL, UT, P>;
@@ -615,10 +662,19 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
     const int dir = cg & 1, tile = cg >> 1, b0 = tile * RB;
     if (b0 >= B) return;
     const int cl = tile * 2 + dir;
-    int errflag = 0;
-    const bool local = (P > 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin) : false;
     const int t0 = dir ? T - 1 : 0;
     const long long tstep = dir ? -1 : 1;
+    if (pm >= P) {               // L2 warmer of cluster cl: the x-projection rows of the next steps (all members' columns)
+        if (P == 1) return;
+        const int rows = (B - b0) < RB ? (B - b0) : RB;
+        // (touching the lines the results go to -- c, h -- as well was measured: 1.17 vs 1.15 us per step, left out)
+        const unsigned long long* xbw = a.xbuf + (size_t)cl * 2 * P * GPM;
+        const WarmSeg seg[1] = {{a.gates16 + ((long long)b0 * T + t0) * 2 * GH + dir * GH, (long long)T * 2 * GH, tstep * 2 * GH, GH * 2}};
+        l2_warmer<1, 4, 12>(seg, rows, T, xbw, xbw + (size_t)P * GPM, a.spin, a.sink16);
+        return;
+    }
+    int errflag = 0;
+    const bool local = (P > 1 && !a.force_agent) ? cluster_same_xcd(a.xcc + (size_t)cl * P, pm, P, tid, &errflag, a.spin) : false;
 
     if (w >= 4) {
         // ============================ helper waves: all bulk HBM traffic ============================
@@ -649,9 +705,9 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             hoff[ii] = brow(row) * (unsigned)a.obs + dir * H + pm * UPM + u;
             co[ii] = row * OP + u;
         }
-        auto gframe = [&](int s) { return a.gates16 + (long long)(t0 + s * tstep) * 2 * GH; };     // uniform frame bases
-        auto cframe = [&](int s) { return a.cstate16 + (long long)(t0 + s * tstep) * 2 * H; };
-        auto oframe = [&](int s) { return a.out16 + (long long)(t0 + s * tstep) * a.ld_out; };
+        auto gframe = [&](int s) { if (LAS_ABL & 128) s &= 1; if (LAS_ABL & 256) s &= 15; if (LAS_ABL & 1024) s = (s & 15) * 64; return a.gates16 + (long long)(t0 + s * tstep) * 2 * GH; };     // uniform frame bases
+        auto cframe = [&](int s) { if (LAS_ABL & 128) s &= 1; if (LAS_ABL & 256) s &= 15; if (LAS_ABL & 1024) s = (s & 15) * 64; return a.cstate16 + (long long)(t0 + s * tstep) * 2 * H; };
+        auto oframe = [&](int s) { if (LAS_ABL & 128) s &= 1; if (LAS_ABL & 256) s &= 15; if (LAS_ABL & 1024) s = (s & 15) * 64; return a.out16 + (long long)(t0 + s * tstep) * a.ld_out; };
         auto to_ring = [&](float* xr, const u32x4_t& v, int off) __attribute__((always_inline)) {   // 8 bf16 -> 2 x float4 in LDS
             f4v lo = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
             f4v hi = {__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
@@ -726,13 +782,13 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 float* xr = xring + ((s + 2) % 3) * RB * XP;
 #pragma unroll
                 for (int ii = 0; ii < NXH; ++ii) to_ring(xr, xq[ii], xl[ii]);
-                if (s + 3 < T) {
+                if (s + 3 < T && !(LAS_ABL & 32)) {
                     const unsigned short* gb = gframe(s + 3);
 #pragma unroll
                     for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
                 }
             }
-            if (s >= 1) flush((s - 1) & 1, s - 1);
+            if (s >= 1 && !(LAS_ABL & 64)) flush((s - 1) & 1, s - 1);
             lds_barrier();
         }
         flush((T - 1) & 1, T - 1);
@@ -1187,6 +1243,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     const int cl = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
     if (cl >= a.ncl) return;
     const int dir = cl & 1, b0 = (cl >> 1) * RB;
+    if (b0 >= B) return;
+    // (an L2 warmer workgroup like the forward sweep's was measured here too -- saved gates, cell states, dout of the next steps:
+    //  1.27 vs 1.27 us per step; with EVERY access L2-resident (make abl ABL=512) the step is 1.20)
     const int vw = pm * 4 + w;
     const int gl = RB == 16 ? g : (g & 1), hsel = RB == 16 ? 0 : (g >> 1);
     // fragments (dir, vw, m, j, ks), all in registers
@@ -1231,6 +1290,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         optr[rr] = (const gu32*)(valid ? a.out16 + row * a.obs + (long long)t0 * a.ld_out + dir * H + u0 : a.sink16 + u0);
         dptr[rr] = (const gu32*)(valid ? a.dout16 + row * a.dobs + (long long)t0 * a.ld_dout + dir * H + u0 : a.sink16 + u0);
         gst[rr] = valid ? gstep / 2 : 0; cst_[rr] = valid ? cstep / 2 : 0; ost[rr] = valid ? ostep / 2 : 0; dst[rr] = valid ? dstep / 2 : 0;
+        if (LAS_ABL & 512) { gst[rr] = 0; cst_[rr] = 0; ost[rr] = 0; dst[rr] = 0; }      // timing experiment: every step hits the same (L2-resident) frame
         vrow[rr] = valid ? 1.f : 0.f;
     }
     auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
@@ -1656,19 +1716,23 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             return -2;
         }
         dim3 grid(a.ncl_pad * P), blk(256 * RT);
+        // one more workgroup per cluster (same XCD) that keeps the operands of the next steps in that XCD's L2
+        const bool warm = P > 1 && a.warm && (long long)a.ncl_pad * (P + 1) <= las_device_cus();
+        const dim3 gridw(a.ncl_pad * (P + (warm ? 1 : 0)));
+        a.warm = warm ? 1 : 0;
         if (!bwd && RT == 1 && a.rb == 8) {
             if constexpr (HwCfg<CELL, UT, P, 8>::OK) {
                 constexpr int HL = HwCfg<CELL, UT, P, 8>::LDS;
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
-                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>), grid, dim3(512), HL, st, a);
+                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>), gridw, dim3(512), HL, st, a);
             }
         } else if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
             if constexpr (HwCfg<CELL, UT, P>::OK) {
                 constexpr int HL = HwCfg<CELL, UT, P>::LDS;
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
-                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>), grid, dim3(512), HL, st, a);
+                hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>), gridw, dim3(512), HL, st, a);
             }
         } else if (!bwd) {
             static int attr = set_lds(rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>, FL);
@@ -1824,6 +1888,7 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
 static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
     a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
+    a.warm = (flags & LAS_SEQ_NO_WARMERS) ? 0 : 1;
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;

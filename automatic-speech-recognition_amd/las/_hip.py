@@ -336,7 +336,7 @@ class _timed:
 # ---- development switches of the sweeps / the Speller (explicit `flags` arguments of the C ABI).  The library itself
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
-SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16 = 1, 2, 4, 8
+SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS = 1, 2, 4, 8, 16
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP = 1, 2, 4, 8
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound",
               2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
@@ -353,7 +353,8 @@ def seq_spin_log2(n):
 def _flags_from_env():
     e = os.environ.get
     f = (SEQ_AGENT_GRANULES if e("LAS_AGENT_GRANULES") == "1" else 0) | (SEQ_NO_KSPLIT if e("LAS_NO_KSPLIT") else 0) | \
-        (SEQ_NO_HELPER_WAVES if e("LAS_NO_HELPER_WAVES") else 0) | (SEQ_ROWS16 if e("LAS_ROWS16") else 0)
+        (SEQ_NO_HELPER_WAVES if e("LAS_NO_HELPER_WAVES") else 0) | (SEQ_ROWS16 if e("LAS_ROWS16") else 0) | \
+        (SEQ_NO_WARMERS if e("LAS_NO_WARMERS") else 0)
     if e("LAS_SEQ_P"):
         f |= seq_p(e("LAS_SEQ_P"))
     if e("LAS_SPIN_LOG2"):
