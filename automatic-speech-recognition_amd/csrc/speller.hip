@@ -752,7 +752,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         }
         if (t == 0) h = s0;
         if (tid >= D) h = 0.f;
-        if (t > 0 && tid < D) {
+        if (t > 0 && tid < D && !(LAS_ABL_SP & 8)) {
             if (CELL == LAS_CELL_LSTM) {
                 gp[tid] = gi; gp[D + tid] = gj; gp[2 * D + tid] = gf; gp[3 * D + tid] = go;
                 a.cs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = cnew;
@@ -864,8 +864,10 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             const float al0 = expf(L.ev[i0] - m) * inv, al1 = i1 < Tp ? expf(L.ev[i1] - m) * inv : 0.f;
             ap[tid] = f2bf2(al0, al1);
             float* arow = a.alphas + ((size_t)t * B + b) * Tp;
+            if (!(LAS_ABL_SP & 8)) {
             arow[i0] = al0;
             if (i1 < Tp) arow[i1] = al1;
+            }
         }
     }
     lds_barrier();
@@ -891,20 +893,20 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             float cv = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) cv += L.scr[w * Hd + hd];
-            xrow[E + hd] = cv;
+            if (!(LAS_ABL_SP & 8)) xrow[E + hd] = cv;
             if (LOOP) put4_bf16(xrs, xg0, E + hd, cv, (unsigned)t + 1u, local);
             else xb[E + hd] = f2bf(cv);
         }
     }
     if (tid < E) {
         const float v = embv * maskv;
-        xrow[tid] = v;
+        if (!(LAS_ABL_SP & 8)) xrow[tid] = v;
         if (LOOP) put4_bf16(xrs, xg0, tid, v, (unsigned)t + 1u, local);
         else xb[tid] = f2bf(v);
     }
     if (tid < D) {
         const float v = L.s_state[tid];
-        xrow[E + Hd + tid] = v;
+        if (!(LAS_ABL_SP & 8)) xrow[E + Hd + tid] = v;
         if (LOOP) put4_bf16(xrs, xg0, E + Hd + tid, v, (unsigned)t + 1u, local);
         else xb[E + Hd + tid] = f2bf(v);
     }
