@@ -340,7 +340,7 @@ struct RnnCfg {
     static constexpr int UPM = H / P;             // hidden units owned by one member
     static constexpr int KS = H / 32;             // k-steps of the forward product (K = H)
     static constexpr int NFW = G * UTP * KS;      // B fragments per wave, forward
-    static constexpr int LDH = H + 8;             // bf16 row pitch of the h tile
+    static constexpr int LDH = H + 16;            // bf16 row pitch of the h tile: 8 dwords mod 64 banks -> the ds_read_b128 A-fragment reads of a lane group (8 or 16 rows x 2 k-chunks) hit 64 distinct banks (H + 8 was 2-way conflicted with 8-row tiles)
     static constexpr int HS_BYTES = 2 * 16 * LDH * 2;
     // W_hh slice placement: VGPR/AGPRs first (one wave per SIMD owns 512 registers per lane; an MFMA B operand
     // that already sits in a register costs no LDS cycle and no latency), LDS for the remainder.
@@ -1219,7 +1219,7 @@ struct KsCfg {
     static constexpr int KP = G * UPM;               // own gate columns = K of the member's product
     static constexpr int KSP = KP / 32;
     static constexpr int NFR = P * UTP * KSP;        // B fragments per wave (all kept in registers)
-    static constexpr int LDZ = KP + 8;               // bf16 row pitch of the own-dG tile
+    static constexpr int LDZ = KP + 16;              // bf16 row pitch of the own-dG tile (8 dwords mod 64 banks, see RnnCfg::LDH)
     static constexpr int DZ_BYTES = 2 * RB * LDZ * 2;
     static constexpr int GPD = 4 * UTP * 4 * 64;     // granules one member sends to ONE other member per step
     static constexpr bool OK = C::OK && NFR <= 64 && (KP % 32 == 0);
