@@ -810,6 +810,9 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 
     const int gl = RB == 16 ? g : (g & 1), hsel = RB == 16 ? 0 : (g >> 1);
     const int row0 = RB == 16 ? g * 4 : gl * 4 + hsel * 2;     // the lane's rows are row0 + k, k < NV
+    // LDS position of batch row r in the h tile.  RB = 8: rows r and r + 4 are written by the same 32-lane group (ds_write_b16),
+    // and with the pitch the A-fragment reads want (8 dwords mod 16) four positions apart is the same bank -> interleave them
+    auto hpos = [](int r) { return RB == 16 ? r : (((r & 3) << 1) | (r >> 2)); };
     float cst[UTP][NV];
 #pragma unroll
     for (int j = 0; j < UTP; ++j)
@@ -830,7 +833,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         const unsigned short* hcur = hs + cur * 16 * LDH;
         u16x8_t av[KS];                          // A fragments of h_{t-1} first: the MFMAs wait on nothing else
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[(c & (RB - 1)) * LDH + ((LAS_ABL & 2) ? 0 : ks) * 32 + g * 8]);
+        for (int ks = 0; ks < KS; ++ks) av[ks] = *reinterpret_cast<const u16x8_t*>(&hcur[hpos(c & (RB - 1)) * LDH + ((LAS_ABL & 2) ? 0 : ks) * 32 + g * 8]);
         __builtin_amdgcn_sched_barrier(0);       // all of them in flight before anything else (the compiler otherwise fetches them in pairs)
         float xv[G][UTP][NV];                    // x.W_ih + b from the ring: read under the MFMAs, added after them
 #pragma unroll
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 float* orow = orr + (row0 + r) * OP;
-                hnext[(row0 + r) * LDH + unit] = hb[r];
+                hnext[hpos(row0 + r) * LDH + unit] = hb[r];
                 if (CELL == LAS_CELL_LSTM) {
                     if (LAS_ABL & 8) { orow[ul] = res[r][5]; continue; }
                     orow[ul] = res[r][0]; orow[(G > 1 ? 1 : 0) * UPM + ul] = res[r][1]; orow[(G > 2 ? 2 : 0) * UPM + ul] = res[r][2];
@@ -992,8 +995,8 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 const int l2 = di & 63, wj = di >> 6, g2 = l2 >> 4;
                 const int unit = m * UPM + wj * 16 + (l2 & 15);
                 const int row = (g2 & 1) * 4 + (g2 >> 1) * 2;
-                hnext[row * LDH + unit] = (unsigned short)(xv[n].y & 0xffffu);
-                hnext[(row + 1) * LDH + unit] = (unsigned short)(xv[n].y >> 16);
+                hnext[hpos(row) * LDH + unit] = (unsigned short)(xv[n].y & 0xffffu);
+                hnext[hpos(row + 1) * LDH + unit] = (unsigned short)(xv[n].y >> 16);
             }
             }
         }
