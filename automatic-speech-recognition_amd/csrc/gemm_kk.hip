@@ -24,6 +24,7 @@ struct KKArgs {
     const unsigned short* B; long long ldb;     // [N, K] bf16
     void* C; long long ldc;                     // [M, N] bf16 or fp32
     const float* bias;                          // [N] or null
+    const unsigned short* ymul; long long ldy;  // optional [M, N] bf16: C *= 1 - y^2 (the tanh gradient of the layer that produced A's consumer)
     int M, N, K, act, out_bf16;
 };
 
@@ -113,6 +114,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
             if (m >= g.M) continue;
             float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
             if (do_tanh) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
+            if (g.ymul) {          // fused Tanh gradient: dX = dY * (1 - Y*Y), Y at the same [m, n]
+                const uint2 yy = *reinterpret_cast<const uint2*>(g.ymul + (long long)m * g.ldy + n);
+                const float y0 = __uint_as_float(yy.x << 16), y1 = __uint_as_float(yy.x & 0xffff0000u);
+                const float y2 = __uint_as_float(yy.y << 16), y3 = __uint_as_float(yy.y & 0xffff0000u);
+                v0 *= 1.f - y0 * y0; v1 *= 1.f - y1 * y1; v2 *= 1.f - y2 * y2; v3 *= 1.f - y3 * y3;
+            }
             if (g.out_bf16) {
                 uint2 pk;
                 pk.x = f2bf2(v0, v1); pk.y = f2bf2(v2, v3);
@@ -124,8 +131,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
     }
 }
 
+extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                                    void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream);
+
 extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                            void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream) {
+    return las_gemm_kk_tanhgrad(M, N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, nullptr, 0, stream);
+}
+
+extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                                    void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream) {
+    LAS_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 7) == 0), "las_gemm_kk: y must be 8-byte aligned with a pitch that is a multiple of 4 and >= N");
     LAS_ARG(A && B && C, "las_gemm_kk: null operand");
     LAS_ARG(M > 0 && N > 0 && K > 0, "las_gemm_kk: bad dims M=%d N=%d K=%d", M, N, K);
     LAS_ARG(K % KK_BK == 0, "las_gemm_kk: K=%d must be a multiple of %d (pad the operands with zero columns)", K, KK_BK);
@@ -140,6 +156,7 @@ extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, co
     KKArgs g;
     g.A = (const unsigned short*)A; g.lda = lda; g.B = (const unsigned short*)B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = c_dtype == LAS_DT_BF16;
+    g.ymul = (const unsigned short*)y; g.ldy = ldy;
     const int nx = cdiv(N, KK_BN), ny = cdiv(M, KK_BM);
     hipLaunchKernelGGL(gemm_kk_kernel, dim3(nx * ((ny + 7) / 8 * 8)), dim3(256), KK_LDS, (hipStream_t)stream, g);
     LAS_LAUNCHED();

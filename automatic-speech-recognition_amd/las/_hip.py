@@ -70,6 +70,8 @@ _SIGS = {
                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "las_gemm_kk": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
                             c_void_p, c_int, c_void_p]),
+    "las_gemm_kk_tanhgrad": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
+                            c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
     "las_colsum_workspace_bytes": (c_size_t, [c_int]),
     "las_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_tanh_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -267,11 +269,17 @@ def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=
     check(rc, "las_gemm")
 
 
-def gemm_kk(A, B, C, M, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, a_off=0, b_off=0, c_off=0):
+def gemm_kk(A, B, C, M, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, a_off=0, b_off=0, c_off=0, tanh_y=None, ldy=0):
     """C[M,N] = act(A[M,K] . B[N,K]^T + bias): A, B bf16 (contraction contiguous), C bf16 or fp32; *_off element offsets."""
     require_gpu(A, B, C, bias)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype in (torch.bfloat16, torch.float32)
     cdt = DT_BF16 if C.dtype == torch.bfloat16 else DT_F32
+    if tanh_y is not None:           # fused Tanh gradient: C *= 1 - tanh_y^2 (bf16 [M, N], pitch ldy)
+        assert tanh_y.dtype == torch.bfloat16
+        check(lib().las_gemm_kk_tanhgrad(M, N, K, c_void_p(A.data_ptr() + 2 * a_off), lda, c_void_p(B.data_ptr() + 2 * b_off), ldb,
+                                         c_void_p(C.data_ptr() + C.element_size() * c_off), cdt, ldc, p(bias), act, p(tanh_y), ldy,
+                                         stream()), "las_gemm_kk_tanhgrad")
+        return
     check(lib().las_gemm_kk(M, N, K, c_void_p(A.data_ptr() + 2 * a_off), lda, c_void_p(B.data_ptr() + 2 * b_off), ldb,
                             c_void_p(C.data_ptr() + C.element_size() * c_off), cdt, ldc, p(bias), act, stream()), "las_gemm_kk")
 

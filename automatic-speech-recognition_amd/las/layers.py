@@ -97,8 +97,12 @@ class _Dense(torch.autograd.Function):
         return dx, dW, db, None, None
 
 
+_TANH_OUT = {}        # data_ptr -> bf16 output of a dense+tanh layer (speed mode): a recurrent layer that reads exactly this tensor
+                      # fuses the Tanh gradient into its dX product (las_gemm_kk_tanhgrad) and hands dPre, not dY, to the dense node
+_DPRE = set()         # data_ptr of gradients that already ARE d(pre-activation) of the dense layer they flow into
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
+FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
 
@@ -120,6 +124,8 @@ def dense(x, W, b=None, tanh=False, out_f32=True):
     _PARAMS["W"], _PARAMS["b"] = W, b
     if x2d.dtype == torch.bfloat16 and W.shape[1] % 4 == 0:
         y = _Dense16.apply(_as_bf16_operand(x2d), W, b, bool(tanh), bool(out_f32))
+        if tanh and not out_f32 and y.requires_grad:
+            _TANH_OUT[y.data_ptr()] = y
     else:
         y = _Dense.apply(x2d.float() if x2d.dtype != torch.float32 else x2d, W, b, bool(tanh), _prec())
     _PARAMS.clear()
@@ -327,7 +333,10 @@ class _Dense16(torch.autograd.Function):
         M, K = x2d.shape
         Kw, N = W.shape
         dy = dy.contiguous()
-        if ctx.act:
+        if ctx.act and dy.dtype == torch.bfloat16 and dy.data_ptr() in _DPRE:
+            _DPRE.discard(dy.data_ptr())               # the consumer's dX product already applied 1 - y^2
+            dpre = dy
+        elif ctx.act:
             dpre = torch.empty(M, N, device=dy.device, dtype=torch.bfloat16)
             _hip.tanh_bwd(y, N, dy, N, dpre, N, M, N)
         else:
@@ -397,6 +406,8 @@ class _BLSTM16(torch.autograd.Function):
         ctx.cfg = (cell, H, Tp, I0)
         ctx.params = _PARAMS.get("blstm")
         ctx.hold_side = bool(_PARAMS.get("hold_side")) and HOLD_SIDE
+        # the input IS the (unpadded) tanh output of the dense layer below: its gradient can leave this node as dPre
+        ctx.x_is_tanh = FUSE_TANH_GRAD and not two and I0 == Ik and _TANH_OUT.pop(x.data_ptr(), None) is not None
         return out
 
     @staticmethod
@@ -423,7 +434,11 @@ class _BLSTM16(torch.autograd.Function):
             # dX [B*T, Ik] = dZ [B*T, 2GH] . [W_ih_fw | W_ih_bw]^T : B operand = shadow of the concatenated weights [Ik, 2GH]
             Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
-            _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik)
+            if ctx.x_is_tanh:
+                _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik, tanh_y=x, ldy=Ik)
+                _DPRE.add(dx.data_ptr())
+            else:
+                _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik)
         elif two and (ctx.needs_input_grad[0] or ctx.needs_input_grad[9]):
             dx, dx_bw = torch.empty(B, T, Ik, device=dev, dtype=bf), torch.empty(B, T, Ik, device=dev, dtype=bf)
             for d, (dxd, k) in enumerate(((dx, kfw), (dx_bw, kbw))):
@@ -530,6 +545,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     H = int(cell_units)
     st = V.default_store()
     sc = scope + "/blstm"
+    _TANH_OUT.clear()
+    _DPRE.clear()
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)
     rnn_out = dense(out, st.get(sc + "/dense/kernel", (2 * H, 2 * H)),
                     st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=num_layers == 0)       # :71-74

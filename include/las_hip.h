@@ -80,6 +80,11 @@ int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K,
  * N % 4 == 0, row pitches lda / ldb multiples of 8 elements, 16-byte aligned operands.  LDS-DMA staged, 128x128x64 tiles. */
 int las_gemm_kk(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                 void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream);
+/* ... with the Tanh gradient of the producer of the result's consumer fused into the epilogue: C[m,n] *= 1 - y[m,n]^2
+ * (y bf16, pitch ldy; NULL = las_gemm_kk).  Used for dX of a recurrent layer whose input IS the tanh output of the dense
+ * layer below (las/layers.py:71-74 feeding :80): the separate las_tanh_bwd pass over dX disappears. */
+int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                         void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream);
 
 /* out[j] = beta*out[j] + sum_r X[r*ldx + j],  r < rows, j < cols   (BiasAdd gradient);
  * fixed-order two-stage reduction, ws >= las_colsum_workspace_bytes(cols). */
