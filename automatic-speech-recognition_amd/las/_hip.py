@@ -323,11 +323,34 @@ def prof_end():
     return out
 
 
+ROCTX = bool(os.environ.get("LAS_ROCTX"))      # roctx ranges (torch.cuda.nvtx maps to roctx on ROCm) around the phases of a step
+                                               # and the K2 / K5-K7 launches: rocprofv3 --marker-trace shows them on the timeline
+
+
+class roctx_range:
+    """with roctx_range("listener fwd"): ...   -- a no-op unless LAS_ROCTX=1."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if ROCTX:
+            torch.cuda.nvtx.range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if ROCTX:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 class _timed:
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
+        if ROCTX:
+            torch.cuda.nvtx.range_push(self.name)
         if _PROF is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
@@ -338,6 +361,8 @@ class _timed:
         if _PROF is not None:
             self.e1.record()
             _PROF.setdefault(self.name, []).append((self.e0, self.e1))
+        if ROCTX:
+            torch.cuda.nvtx.range_pop()
         return False
 
 

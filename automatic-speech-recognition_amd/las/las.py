@@ -598,12 +598,16 @@ class LAS:
         # the Speller's host-side preparation first: its small uploads overlap with the Listener kernels
         prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
                                     True, coins, sampled)
-        h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)                  # is_training default True
-        logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
+        with _hip.roctx_range("listener fwd"):
+            h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)              # is_training default True
+        with _hip.roctx_range("speller fwd"):
+            logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
-        loss = self._get_loss(logits, y, n_total)                                         # sum_local / n_total
-        loss.backward()
-        _hip.join_side_stream()                       # weight gradients accumulated on the side stream
+        with _hip.roctx_range("loss"):
+            loss = self._get_loss(logits, y, n_total)                                     # sum_local / n_total
+        with _hip.roctx_range("backward"):
+            loss.backward()
+            _hip.join_side_stream()                   # weight gradients accumulated on the side stream
         if self.dp is not None:
             self.dp.all_reduce_(st.flat_grad)                                             # one flat bucket (C1)
             loss_val = self.dp.all_reduce_scalar(loss.detach())
@@ -612,7 +616,8 @@ class LAS:
 
         lr = self._scheduled_learning_rate(start=50000, decay_step=100000, decay_rate=0.5, min_rate=0.01,
                                            global_step=st.global_step)
-        self._apply_adam(st, lr)
+        with _hip.roctx_range("clip + adam"):
+            self._apply_adam(st, lr)
         _hip.poll_status(dev)                         # a sweep exchange timeout of an earlier step surfaces here
         st.global_step += 1
         sample_rate = self.speller._scheduled_sampling()
