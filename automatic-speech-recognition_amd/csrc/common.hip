@@ -44,3 +44,15 @@ extern "C" int las_wait_word(const int* word, int value, int max_us, void* strea
     LAS_LAUNCHED();
     return 0;
 }
+
+// stream-ordered store of a device word (the completion flag behind a chunk of work that another, already running, kernel waits for)
+__global__ __launch_bounds__(64) void set_word_kernel(int* word, int value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+extern "C" int las_set_word(int* word, int value, void* stream) {
+    LAS_ARG(word, "las_set_word: null pointer");
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, value);
+    LAS_LAUNCHED();
+    return 0;
+}

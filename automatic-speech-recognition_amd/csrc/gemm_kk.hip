@@ -26,7 +26,16 @@ struct KKArgs {
     const float* bias;                          // [N] or null
     const unsigned short* ymul; long long ldy;  // optional [M, N] bf16: C *= 1 - y^2 (the tanh gradient of the layer that produced A's consumer)
     int M, N, K, act, out_bf16;
+    // optional frame selection ("row map"): logical row m of A and C is frame t of utterance b in a [B, T, *] tensor, with
+    // b = m / fn, r = m % fn, t = r < nlo ? lo0 + r : hi0 + (r - nlo), fn = nlo + nhi (0 = identity).  Lets the x-projection of a
+    // recurrent layer be computed in time chunks, both ends of the sequence first (las_gemm_kk_frames).
+    int fT, lo0, nlo, hi0, fn;
 };
+__device__ __forceinline__ long long kk_row(const KKArgs& g, int m) {
+    if (g.fn == 0) return m;
+    const int b = m / g.fn, r = m - b * g.fn;
+    return (long long)b * g.fT + (r < g.nlo ? g.lo0 + r : g.hi0 + (r - g.nlo));
+}
 
 constexpr int KK_BM = 128, KK_BN = 128, KK_BK = 64;
 constexpr int KK_TILE_BYTES = KK_BM * KK_BK * 2;            // 16 KiB per operand tile
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
         const int row = w * 32 + q * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((row >> 1) & 7);
         const int ra = min(m0 + row, g.M - 1), rb = min(n0 + row, g.N - 1);     // edge tiles: clamped, results never stored
-        pa[q] = g.A + (long long)ra * g.lda + ch * 8;
+        pa[q] = g.A + kk_row(g, ra) * g.lda + ch * 8;
         pb[q] = g.B + (long long)rb * g.ldb + ch * 8;
     }
     auto stage = [&](int buf) __attribute__((always_inline)) {
@@ -110,12 +119,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
         if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + n);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-            if (m >= g.M) continue;
+            const int ml = m0 + wm * 64 + i * 16 + (lane & 15);
+            if (ml >= g.M) continue;
+            const long long m = kk_row(g, ml);
             float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
             if (do_tanh) { v0 = tanh_fast(v0); v1 = tanh_fast(v1); v2 = tanh_fast(v2); v3 = tanh_fast(v3); }
             if (g.ymul) {          // fused Tanh gradient: dX = dY * (1 - Y*Y), Y at the same [m, n]
-                const uint2 yy = *reinterpret_cast<const uint2*>(g.ymul + (long long)m * g.ldy + n);
+                const uint2 yy = *reinterpret_cast<const uint2*>(g.ymul + m * g.ldy + n);
                 const float y0 = __uint_as_float(yy.x << 16), y1 = __uint_as_float(yy.x & 0xffff0000u);
                 const float y2 = __uint_as_float(yy.y << 16), y3 = __uint_as_float(yy.y & 0xffff0000u);
                 v0 *= 1.f - y0 * y0; v1 *= 1.f - y1 * y1; v2 *= 1.f - y2 * y2; v3 *= 1.f - y3 * y3;
@@ -123,9 +133,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
             if (g.out_bf16) {
                 uint2 pk;
                 pk.x = f2bf2(v0, v1); pk.y = f2bf2(v2, v3);
-                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + (long long)m * g.ldc + n) = pk;
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(g.C) + m * g.ldc + n) = pk;
             } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long long)m * g.ldc + n) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + m * g.ldc + n) = make_float4(v0, v1, v2, v3);
             }
         }
     }
@@ -139,8 +149,24 @@ extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, co
     return las_gemm_kk_tanhgrad(M, N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, nullptr, 0, stream);
 }
 
+static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
+                        const float* bias, int act, const void* y, long long ldy, int fT, int lo0, int nlo, int hi0, int nhi, void* stream);
+
 extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                                     void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream) {
+    return gemm_kk_impl(M, N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, y, ldy, 0, 0, 0, 0, 0, stream);
+}
+
+// A, C are [nb, T, *] tensors; only the frames [lo0, lo0 + nlo) and [hi0, hi0 + nhi) of every utterance are computed
+extern "C" int las_gemm_kk_frames(int nb, int T, int lo0, int nlo, int hi0, int nhi, int N, int K, const void* A, long long lda,
+                                  const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream) {
+    LAS_ARG(nb > 0 && T > 0 && nlo >= 0 && nhi >= 0 && nlo + nhi > 0 && lo0 >= 0 && lo0 + nlo <= T && hi0 >= 0 && hi0 + nhi <= T,
+            "las_gemm_kk_frames: bad frame ranges");
+    return gemm_kk_impl(nb * (nlo + nhi), N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, nullptr, 0, T, lo0, nlo, hi0, nhi, stream);
+}
+
+static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
+                        const float* bias, int act, const void* y, long long ldy, int fT, int lo0, int nlo, int hi0, int nhi, void* stream) {
     LAS_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 7) == 0), "las_gemm_kk: y must be 8-byte aligned with a pitch that is a multiple of 4 and >= N");
     LAS_ARG(A && B && C, "las_gemm_kk: null operand");
     LAS_ARG(M > 0 && N > 0 && K > 0, "las_gemm_kk: bad dims M=%d N=%d K=%d", M, N, K);
@@ -157,6 +183,7 @@ extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long lon
     g.A = (const unsigned short*)A; g.lda = lda; g.B = (const unsigned short*)B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = c_dtype == LAS_DT_BF16;
     g.ymul = (const unsigned short*)y; g.ldy = ldy;
+    g.fT = fT; g.lo0 = lo0; g.nlo = nlo; g.hi0 = hi0; g.fn = fT ? nlo + nhi : 0;
     const int nx = cdiv(N, KK_BN), ny = cdiv(M, KK_BM);
     hipLaunchKernelGGL(gemm_kk_kernel, dim3(nx * ((ny + 7) / 8 * 8)), dim3(256), KK_LDS, (hipStream_t)stream, g);
     LAS_LAUNCHED();

@@ -45,6 +45,8 @@ struct RnnArgs {
     int status_code;
     int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
     int announce;                            // LAS_SEQ_ANNOUNCE(n): cluster 0 stores n into status[1] once its members are resident
+    const int* xflag; int xsc;               // forward: the x-projection arrives in time chunks of xsc steps from both ends of the sequence,
+                                             // *xflag = number of chunks complete (another stream's kernels write it); NULL: all there
     int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
 };
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 struct WarmSeg { const unsigned short* base; long long rs, ss; int nb; };
 template <int NSEG, int LEAD, int AHEAD>      // keep steps [p + LEAD, p + AHEAD] warm (LEAD = how far ahead the cluster itself fetches, + 1)
 __device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, int T, const unsigned long long* tagp0, const unsigned long long* tagp1,
-                                          int spin, unsigned short* sink) {
+                                          int spin, unsigned short* sink, const int* xflag = nullptr, int xsc = 0) {
     typedef __attribute__((address_space(1))) const u32x4_t gcu4;
     unsigned acc = 0;
     int done = -1;                               // last step already touched
@@ -600,6 +602,12 @@ __device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, 
         int from = done + 1, to = p + AHEAD;
         if (from < p + LEAD) from = p + LEAD;
         if (to > T - 1) to = T - 1;
+        if (xflag) {       // chunked x-projection: a line must never be touched before the chunk that writes it is complete (a stale
+                           // copy in this XCD's L2 would be what the cluster reads later)
+            const int have = __hip_atomic_load(xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            const int th = (T + 1) / 2;
+            if (have * xsc < th && to > have * xsc - 1) to = have * xsc - 1;      // (second half: every chunk is complete by then)
+        }
         if (from <= to) {
             idle = 0;
 #pragma unroll
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         // (touching the lines the results go to -- c, h -- as well was measured: 1.17 vs 1.15 us per step, left out)
         const unsigned long long* xbw = a.xbuf + (size_t)cl * 2 * P * GPM;
         const WarmSeg seg[1] = {{a.gates16 + ((long long)b0 * T + t0) * 2 * GH + dir * GH, (long long)T * 2 * GH, tstep * 2 * GH, GH * 2}};
-        l2_warmer<1, 4, 12>(seg, rows, T, xbw, xbw + (size_t)P * GPM, a.spin, a.sink16);
+        l2_warmer<1, 4, 12>(seg, rows, T, xbw, xbw + (size_t)P * GPM, a.spin, a.sink16, a.xflag, a.xsc);
         return;
     }
     int errflag = 0;
@@ -714,9 +722,24 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             *reinterpret_cast<f4v*>(xr + off) = lo;
             *reinterpret_cast<f4v*>(xr + off + 4) = hi;
         };
+        int have = 0;                                   // chunks of the x-projection known to be complete (a.xflag)
+        auto wait_chunk = [&](int st) __attribute__((always_inline)) {
+            if (!a.xflag) return;
+            const int mm = st < T - 1 - st ? st : T - 1 - st;
+            const int need = mm / a.xsc + 1;
+            if (need <= have) return;
+            int budget = a.spin;
+            for (;;) {
+                have = __hip_atomic_load(a.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (have >= need) break;
+                if (--budget <= 0) { if (a.status) a.status[0] = a.status_code; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        };
         u32x4_t xq[NXH];                                // the loads in flight (this wave's share of one step)
         // ring: slot (s % 3) holds step s; steps 0 and 1 are staged here, step 2 is requested before the loop
         {
+            wait_chunk(0);
             const unsigned short* gb = gframe(0);
 #pragma unroll
             for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
@@ -724,6 +747,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             for (int ii = 0; ii < NXH; ++ii) to_ring(xring, xq[ii], xl[ii]);
         }
         if (T > 1) {
+            wait_chunk(1);
             const unsigned short* gb = gframe(1);
 #pragma unroll
             for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
@@ -731,6 +755,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             for (int ii = 0; ii < NXH; ++ii) to_ring(xring + RB * XP, xq[ii], xl[ii]);
         }
         if (T > 2) {
+            wait_chunk(2);
             const unsigned short* gb = gframe(2);
 #pragma unroll
             for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
@@ -783,6 +808,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
 #pragma unroll
                 for (int ii = 0; ii < NXH; ++ii) to_ring(xr, xq[ii], xl[ii]);
                 if (s + 3 < T && !(LAS_ABL & 32)) {
+                    wait_chunk(s + 3);
                     const unsigned short* gb = gframe(s + 3);
 #pragma unroll
                     for (int ii = 0; ii < NXH; ++ii) xq[ii] = *(gcu4*)(gb + xoff[ii]);
@@ -1775,7 +1801,11 @@ static int pick_rt(int cell, int H, int P, bool bwd, int ntiles) {
 
 template <int CELL, int UT, int P>
 static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st, bool query) {
-    if (query) return rb8_ok<CELL, UT, P>(bwd) ? 1 : 0;
+    if (query) {       // bit 0: an 8-row-tile kernel exists for the direction; bit 1: the forward helper-wave kernel exists for 16-row tiles
+        int r = rb8_ok<CELL, UT, P>(bwd) ? 1 : 0;
+        if constexpr (P > 1) r |= (!bwd && HwCfg<CELL, UT, P, 16>::OK) ? 2 : 0;
+        return r;
+    }
     const int ntiles = cdiv(a.B, a.rb);
     int rt = pick_rt(CELL, UT * 64, P, bwd, ntiles);
     for (; rt >= 1; --rt) {
@@ -1858,7 +1888,7 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         if (max_tiles < 1) { las_set_error("rnn_seq: cluster width %d does not fit %d compute units", P, las_device_cus()); rc = -2; continue; }
         // 8-row tiles (twice the CUs, half the per-lane work of a dependent step) while the whole batch still fits one launch
         const bool k8 = (bwd ? a.ks_packed != 0 : !a.no_helpers) && !(flags & LAS_SEQ_ROWS16) && cdiv(B, 8) <= max_tiles &&
-                        dispatch_bf16(cell, P, bwd, a, st, true) == 1;
+                        (dispatch_bf16(cell, P, bwd, a, st, true) & 1);
         const int RBk = k8 ? 8 : 16;
         a.rb = RBk;
         const int ntiles = cdiv(B, RBk);
@@ -1892,10 +1922,26 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
     a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
     a.warm = (flags & LAS_SEQ_NO_WARMERS) ? 0 : 1;
+    a.xflag = nullptr; a.xsc = 0;
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;
     a.announce = (flags >> 21) & 0x3ff;
+}
+
+// 1 if las_rnn_seq_fwd would serve (cell, prec, B, H, flags) with ONE launch of the helper-wave kernel -- the only kernel that
+// understands x-projection chunks (las_rnn_seq_fwd_chunked)
+extern "C" int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int flags) {
+    if (prec != LAS_PREC_BF16 || !mfma_shape_ok(H) || B <= 0 || (flags & LAS_SEQ_NO_HELPER_WAVES)) return 0;
+    const int P = pick_cluster(cell, H, flags);
+    if (P <= 1) return 0;
+    RnnArgs a; a.H = H; a.B = B;
+    const int q = dispatch_bf16(cell, P, false, a, nullptr, true);
+    const int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
+    if (max_tiles < 1) return 0;
+    const bool k8 = !(flags & LAS_SEQ_ROWS16) && cdiv(B, 8) <= max_tiles && (q & 1);
+    if (k8) return 1;
+    return ((q & 2) && cdiv(B, 16) <= max_tiles) ? 1 : 0;
 }
 
 extern "C" int las_rnn_seq_io_dtype(int cell, int prec, int H) {
@@ -1912,6 +1958,14 @@ static void bind_tensors(RnnArgs& a, void* gates, void* out, void* cstate, const
 extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
                                void* cstate, float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream) {
+    return las_rnn_seq_fwd_chunked(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, forget_bias, flags,
+                                   status, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                       const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                                       void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
+                                       void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RnnArgs a;
@@ -1920,6 +1974,9 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* ga
     bind_tensors(a, gates, out, cstate, nullptr);
     a.ld_dout = 0; a.dobs = 0; a.fb = forget_bias; a.wpack = ws;
     seq_common_args(a, flags, status, LAS_SEQ_STATUS_FWD_TIMEOUT);
+    LAS_ARG(!chunk_flag || (chunk_steps > 0 && las_rnn_seq_fwd_chunks_ok(cell, prec, B, H, flags)),
+            "las_rnn_seq_fwd_chunked: this configuration is not served by the kernel that waits for x-projection chunks");
+    a.xflag = chunk_flag; a.xsc = chunk_steps;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif

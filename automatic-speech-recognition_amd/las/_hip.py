@@ -100,6 +100,12 @@ _SIGS = {
                               c_float, c_float, c_float, c_void_p]),
     "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "las_set_word": (c_int, [c_void_p, c_int, c_void_p]),
+    "las_gemm_kk_frames": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong,
+                                   c_void_p, c_int, c_longlong, c_void_p, c_int, c_void_p]),
+    "las_rnn_seq_fwd_chunks_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "las_rnn_seq_fwd_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                        c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -481,12 +487,36 @@ def _check_io(cell, prec, H, *tensors):
             raise RuntimeError("las_rnn_seq: tensors must be %s for (cell=%d, prec=%d, H=%d), got %s" % (want, cell, prec, H, t.dtype))
 
 
+def gemm_kk_frames(A, B, C, nb, T, lo0, nlo, hi0, nhi, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE):
+    """las_gemm_kk on the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of the [nb, T, *] tensors A (bf16) and C."""
+    require_gpu(A, B, C, bias)
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype in (torch.bfloat16, torch.float32)
+    cdt = DT_BF16 if C.dtype == torch.bfloat16 else DT_F32
+    check(lib().las_gemm_kk_frames(nb, T, lo0, nlo, hi0, nhi, N, K, p(A), lda, p(B), ldb, p(C), cdt, ldc, p(bias), act, stream()),
+          "las_gemm_kk_frames")
+
+
+def set_word(word, value):
+    check(lib().las_set_word(p(word), int(value), stream()), "las_set_word")
+
+
+def rnn_seq_fwd_chunks_ok(cell, prec, B, H, flags=None):
+    return bool(lib().las_rnn_seq_fwd_chunks_ok(cell, prec, B, H, seq_flags if flags is None else flags))
+
+
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                forget_bias=1.0, wf_off=0, wb_off=0, flags=None):
+                forget_bias=1.0, wf_off=0, wb_off=0, flags=None, chunk_flag=None, chunk_steps=0):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
     _check_io(cell, prec, H, gates, out, cstate)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
+    if chunk_flag is not None:
+        with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
+            check(lib().las_rnn_seq_fwd_chunked(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                                c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                                p(cstate), forget_bias, fl, p(status_word(gates.device)), p(chunk_flag), chunk_steps,
+                                                p(ws), ws.numel(), stream()), "las_rnn_seq_fwd_chunked")
+        return
     with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_fwd(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                     c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,

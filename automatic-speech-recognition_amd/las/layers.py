@@ -102,6 +102,7 @@ _TANH_OUT = {}        # data_ptr -> bf16 output of a dense+tanh layer (speed mod
 _DPRE = set()         # data_ptr of gradients that already ARE d(pre-activation) of the dense layer they flow into
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
+XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
@@ -299,6 +300,20 @@ def _shadow(tag, srcs, rows, transpose, dst_rows, dst_cols, bf16=True):
     return sh
 
 
+_CHUNK_FLAGS = {}
+
+
+def _chunk_flag(dev):
+    """A zeroed device word for the completion count of one layer's x-projection chunks (a small ring: a word is reused only
+    after several later sweeps have been enqueued behind the one that reads it)."""
+    ring = _CHUNK_FLAGS.setdefault(str(dev), [torch.zeros(16, dtype=torch.int32, device=dev), 0])
+    i = ring[1] % 16
+    ring[1] += 1
+    w = ring[0][i:i + 1]
+    w.zero_()
+    return w
+
+
 def _k64(k):
     return (k + 63) // 64 * 64
 
@@ -392,7 +407,31 @@ class _BLSTM16(torch.autograd.Function):
             # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
             bias = _shadow("ihb", (bfw, bbw), 1, False, 1, 2 * GH, bf16=False).view(-1)
-            _hip.gemm_kk(x, WT, gates, B * T, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
+            chunk_flag, cs = None, XPROJ_CHUNK_STEPS
+            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H):
+                # The sweep consumes the x-projection in time order (forward direction from t = 0, backward from t = T - 1), so only
+                # the first chunk of frames -- both ends of the sequence -- has to exist when it starts: chunk 0 on this stream,
+                # the others on the side stream WHILE the sweep runs (it holds a fifth of the CUs); the sweep's helper waves wait
+                # for a chunk's completion flag before they read its frames.
+                th = (T + 1) // 2
+                nch = (th + cs - 1) // cs
+                chunk_flag = _chunk_flag(dev)
+
+                def chunk(k):
+                    lo0, lo1 = k * cs, min((k + 1) * cs, th)
+                    hi0, hi1 = max(T - lo1, lo1), T - lo0
+                    _hip.gemm_kk_frames(x, WT, gates, B, T, lo0, lo1 - lo0, hi0, hi1 - hi0, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
+                    _hip.set_word(chunk_flag, k + 1)
+
+                chunk(0)
+                with _hip.on_side_stream():
+                    side = _hip.side_stream()
+                    for t in (x, gates, chunk_flag):
+                        t.record_stream(side)
+                    for k in range(1, nch):
+                        chunk(k)
+            else:
+                _hip.gemm_kk(x, WT, gates, B * T, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
         else:
             for d, (xd, k, b) in enumerate(((x, kfw, bfw), (x_bw, kbw, bbw))):
                 WTd = _shadow("ihT%d" % d, (k,), I0, True, GH, _k64(I0))                    # [GH, Ik]
@@ -401,7 +440,9 @@ class _BLSTM16(torch.autograd.Function):
         out = torch.zeros(B, Tp, 2 * H, device=dev, dtype=bf) if Tp != T else torch.empty(B, T, 2 * H, device=dev, dtype=bf)
         cst = torch.empty(B, T, 2, H, device=dev, dtype=bf) if cell == "lstm" else None
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
-                         1.0, wf_off=I0 * GH, wb_off=I0 * GH)
+                         1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs)
+        if not two and chunk_flag is not None:
+            _hip.join_side_stream()          # (the chunks are long finished; this orders later users of `gates` after them)
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
         ctx.cfg = (cell, H, Tp, I0)
         ctx.params = _PARAMS.get("blstm")

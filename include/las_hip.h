@@ -150,6 +150,24 @@ int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
                     void* out, int ld_out, long long out_bstride, void* cstate,
                     float forget_bias, int flags, int* status, void* ws, size_t ws_bytes, void* stream);
+/* las_rnn_seq_fwd for an x-projection that is still being computed: `gates` is filled in time chunks of `chunk_steps` sweep steps,
+ * chunk k = frames [k*cs, (k+1)*cs) and [T-(k+1)*cs, T-k*cs) of every utterance (both ends of the sequence first: the forward
+ * direction consumes t = 0, 1, .., the backward direction t = T-1, T-2, ..), e.g. by las_gemm_kk_frames launches on ANOTHER
+ * stream, each followed by las_set_word(chunk_flag, k+1).  The sweep reads a frame only after *chunk_flag has reached its chunk
+ * (bounded wait -> LAS_SEQ_STATUS_FWD_TIMEOUT).  Chunk 0 must be complete (and *chunk_flag >= 1) before this call is
+ * enqueued work reaches the device, or at least be enqueued where it cannot be blocked by the sweep.  Only the helper-wave kernel
+ * supports this: ask las_rnn_seq_fwd_chunks_ok first.  chunk_flag = NULL: las_rnn_seq_fwd. */
+int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int flags);
+int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                            const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                            void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
+                            void* ws, size_t ws_bytes, void* stream);
+/* C = act(A . B^T + bias) like las_gemm_kk, restricted to the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of
+ * [nb, T, *] tensors A and C (row pitches lda / ldc per frame); las_set_word: stream-ordered store of a device word. */
+int las_gemm_kk_frames(int nb, int T, int lo0, int nlo, int hi0, int nhi, int N, int K, const void* A, long long lda,
+                       const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream);
+int las_set_word(int* word, int value, void* stream);
+
 int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates,
                     const float* whh_fw, const float* whh_bw, int ldw,
                     const void* out, int ld_out, long long out_bstride, const void* cstate,
