@@ -111,3 +111,26 @@ def test_gemm_kk_bf16_operands_k_contiguous(M, N, K, act, out):
     tol = 2e-5 * K ** 0.5 + (4e-3 * ref.abs().max().item() if out == "bf16" else 0)       # bf16 output: half an ulp of the result
     assert (got - ref).abs().max().item() < tol + 1e-4
     assert (C[:, N:].float() == 7.0).all()                                                 # nothing written past N
+
+
+@pytest.mark.parametrize("case", [(3, 37, 0, 5, 30, 7, 128, 64), (2, 64, 16, 16, 32, 16, 256, 128), (4, 21, 0, 11, 11, 10, 64, 64),
+                                  (2, 50, 10, 8, 40, 0, 192, 64)])
+def test_gemm_kk_frames_touches_exactly_the_selected_frames(case):
+    """las_gemm_kk_frames: C[b, t, :] = A[b, t, :] . B^T + bias for t in [lo0, lo0+nlo) u [hi0, hi0+nhi) only (the time chunks
+    of a layer's x-projection); every other frame of C keeps its old contents."""
+    from las import _hip
+    nb, T, lo0, nlo, hi0, nhi, N, K = case
+    g = torch.Generator().manual_seed(sum(case))
+    A = (torch.randn(nb, T, K, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    Bm = (torch.randn(N, K, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    C = torch.full((nb, T, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    _hip.gemm_kk_frames(A, Bm, C, nb, T, lo0, nlo, hi0, nhi, N, K, K, K, N, bias=bias)
+    torch.cuda.synchronize()
+    ref = (A.float() @ Bm.float().t() + bias).to(torch.bfloat16).float()
+    sel = torch.zeros(T, dtype=torch.bool)
+    sel[lo0:lo0 + nlo] = True
+    sel[hi0:hi0 + nhi] = True
+    got = C.float().cpu()
+    assert (got[:, sel] - ref.cpu()[:, sel]).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert (got[:, ~sel] == 7.0).all()

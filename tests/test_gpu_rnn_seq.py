@@ -168,3 +168,57 @@ def test_rows16_flag_gives_the_same_sweep(case):
     for n, a, b in zip(names, res[0], res[1]):
         scale = max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() <= 2e-2 * scale, (n, case, (a - b).abs().max().item(), scale)
+
+
+def test_chunked_x_projection_is_waited_for():
+    """las_rnn_seq_fwd_chunked: the forward sweep may be launched while its x-projection is still being written in time chunks
+    (both ends of the sequence first) by kernels of ANOTHER stream; it must read a frame only after the chunk's flag.  Here the
+    chunks are copied in late and slowly (sleep kernels between them) from a second stream; the result has to equal the sweep
+    over the complete x-projection bit for bit.  A flag that never arrives must surface as a status error, not as a hang."""
+    from las import _hip
+    B, T, H, cs = 24, 300, 256, 32
+    GH = 4 * H
+    assert _hip.rnn_seq_fwd_chunks_ok(1, 1, B, H)
+    g = torch.Generator().manual_seed(11)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).cuda().to(torch.bfloat16)
+    w = [((torch.rand(H, GH, generator=g) * 2 - 1) * 0.06).cuda() for _ in range(2)]
+
+    def sweep(gates, **kw):
+        out = torch.zeros(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+        cst = torch.zeros(B, T, 2, H, device="cuda", dtype=torch.bfloat16)
+        _hip.rnn_seq_fwd(1, 1, B, T, H, gates, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst, **kw)
+        return out, cst
+
+    ref_out, ref_c = sweep(xp.clone())
+    torch.cuda.synchronize()
+    th = (T + 1) // 2
+    nch = (th + cs - 1) // cs
+    gates = torch.full_like(xp, float("nan"))                   # frames of incomplete chunks are poison
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+
+    def put(k):
+        lo0, lo1 = k * cs, min((k + 1) * cs, th)
+        hi0, hi1 = max(T - lo1, lo1), T - lo0
+        gates[:, lo0:lo1] = xp[:, lo0:lo1]
+        gates[:, hi0:hi1] = xp[:, hi0:hi1]
+        _hip.set_word(flag, k + 1)
+
+    put(0)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(1, nch):
+            torch.cuda._sleep(400000)                           # ~0.17 ms: the sweep reaches the chunk boundary first and has to wait
+            put(k)
+    out, cst = sweep(gates, chunk_flag=flag, chunk_steps=cs)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    assert torch.equal(out, ref_out) and torch.equal(cst, ref_c)
+    # the flag never moves past chunk 0: bounded wait, then the status word says so
+    gates = xp.clone()
+    flag.fill_(1)
+    sweep(gates, chunk_flag=flag, chunk_steps=cs, flags=_hip.seq_spin_log2(6))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        _hip.check_status()
