@@ -728,7 +728,8 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             const int mm = st < T - 1 - st ? st : T - 1 - st;
             const int need = mm / a.xsc + 1;
             if (need <= have) return;
-            int budget = a.spin;
+            int budget = a.spin < (1 << 16) ? a.spin : (1 << 16);     // ~0.1 s: a chunk is a sub-millisecond GEMM; if kernels of different
+                                                                       // streams cannot overlap (a profiler that serialises them) fail fast
             for (;;) {
                 have = __hip_atomic_load(a.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (have >= need) break;

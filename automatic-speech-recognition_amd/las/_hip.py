@@ -377,7 +377,9 @@ class _timed:
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS = 1, 2, 4, 8, 16
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP = 1, 2, 4, 8
-SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound",
+SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
+                 "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
+                 "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_XPROJ_CHUNK=0)",
               2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
 
 
@@ -424,6 +426,34 @@ _announce = [0]
 def next_announce():
     """The value the NEXT BPTT sweep will store into status_word[1] when it is resident (1..1023, cyclic)."""
     return _announce[0] % 1023 + 1
+
+
+_overlap = {}
+
+
+def streams_overlap(dev):
+    """True if kernels of two streams really run concurrently on this device (probed once): a bounded waiter on the current stream,
+    then the store it waits for on the side stream.  Under a tool that serialises kernels (rocprofv3 --pmc) the waiter runs into
+    its bound; the cross-stream hand-overs (x-projection chunks, held side stream) are then switched off."""
+    key = str(dev)
+    if key not in _overlap:
+        flag = torch.zeros(2, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(side_stream()):                    # (the side stream's first launch creates its hardware queue)
+            check(lib().las_set_word(p(flag[1:]), 1, stream()), "las_set_word")
+        best = 1e9
+        for _ in range(2):
+            flag[0:1].zero_()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().las_wait_word(p(flag), 1, 4000, stream()), "las_wait_word")
+            e1.record()
+            with torch.cuda.stream(side_stream()):
+                check(lib().las_set_word(p(flag), 1, stream()), "las_set_word")
+            torch.cuda.synchronize(dev)
+            best = min(best, e0.elapsed_time(e1))
+        _overlap[key] = best < 2.0
+    return _overlap[key]
 
 
 def hold_until_next_sweep(dev, max_us=1500):

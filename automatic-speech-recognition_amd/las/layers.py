@@ -408,7 +408,7 @@ class _BLSTM16(torch.autograd.Function):
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
             bias = _shadow("ihb", (bfw, bbw), 1, False, 1, 2 * GH, bf16=False).view(-1)
             chunk_flag, cs = None, XPROJ_CHUNK_STEPS
-            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H):
+            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H) and _hip.streams_overlap(dev):
                 # The sweep consumes the x-projection in time order (forward direction from t = 0, backward from t = T - 1), so only
                 # the first chunk of frames -- both ends of the sequence -- has to exist when it starts: chunk 0 on this stream,
                 # the others on the side stream WHILE the sweep runs (it holds a fifth of the CUs); the sweep's helper waves wait
@@ -508,7 +508,7 @@ class _BLSTM16(torch.autograd.Function):
                 side = _hip.side_stream()
                 for t in (x, gates, out) + ((x_bw,) if two else ()):
                     t.record_stream(side)
-                if ctx.hold_side and ctx.needs_input_grad[0]:
+                if ctx.hold_side and ctx.needs_input_grad[0] and _hip.streams_overlap(dev):
                     # keep the side stream (these GEMMs and whatever is queued behind them) off the machine until the NEXT
                     # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
                     # front of it; bounded wait, scheduling only
