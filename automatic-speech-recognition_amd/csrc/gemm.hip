@@ -620,6 +620,37 @@ template <typename T> __device__ __forceinline__ void st_f(T* p, float v);
 template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_f<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
 
+// bf16 input with 16-byte alignment: a thread owns 8 adjacent columns (one 16-byte load per row), a block 512 columns x 4 row lanes.
+// direct (nsplit == 1): out = beta * out + sum, no second pass.
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const unsigned short* __restrict__ X, int rows, int cols, int ldx,
+                                                            float* __restrict__ part, int nsplit, float beta, float* __restrict__ out) {
+    const int c8 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
+    const int rl = threadIdx.x >> 6;
+    const int per = (rows + nsplit - 1) / nsplit;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c8 < cols)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(X + (long long)r * ldx + c8);
+            s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+            s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+            s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+            s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+        }
+    __shared__ float red[4][64][9];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][threadIdx.x & 63][e] = s[e];
+    __syncthreads();
+    if (rl == 0 && c8 < cols) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = red[0][threadIdx.x][e] + red[1][threadIdx.x][e] + red[2][threadIdx.x][e] + red[3][threadIdx.x][e];
+            if (nsplit == 1) out[c8 + e] = (beta != 0.f ? beta * out[c8 + e] : 0.f) + v;
+            else part[(long long)blockIdx.y * cols + c8 + e] = v;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, int rows, int cols, int ldx,
                                                              float* __restrict__ part, int nsplit) {
@@ -636,6 +667,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     __syncthreads();
     if (rl == 0 && c < cols)
         part[(long long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// rows < 512 (the per-utterance dW_hh partials: rows = batch): one pass, out = beta * out + column sum
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_direct_kernel(const T* __restrict__ X, int rows, int cols, int ldx, float beta, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += ld_f<T>(X + (long long)r * ldx + c);
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int cols, int nsplit, float beta,
@@ -656,6 +697,21 @@ extern "C" int las_colsum_dt(const void* X, int dtype, int rows, int cols, int l
     LAS_ARG(ws && ws_bytes >= las_colsum_workspace_bytes(cols), "las_colsum: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int nsplit = rows >= CS_SPLITS * 8 ? CS_SPLITS : 1;
+    if (nsplit == 1) {                 // few rows: one launch
+        if (dtype == LAS_DT_BF16) hipLaunchKernelGGL(colsum_direct_kernel<unsigned short>, dim3(cdiv(cols, 256)), dim3(256), 0, st,
+                                                      (const unsigned short*)X, rows, cols, ldx, beta, out);
+        else hipLaunchKernelGGL(colsum_direct_kernel<float>, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)X, rows, cols, ldx, beta, out);
+        LAS_LAUNCHED();
+        return 0;
+    }
+    if (dtype == LAS_DT_BF16 && cols % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)X & 15) == 0) {
+        hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(cdiv(cols, 512), nsplit), dim3(256), 0, st, (const unsigned short*)X, rows, cols, ldx,
+                           (float*)ws, nsplit, beta, out);
+        LAS_LAUNCHED();
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const float*)ws, cols, nsplit, beta, out);
+        LAS_LAUNCHED();
+        return 0;
+    }
     if (dtype == LAS_DT_BF16)
         hipLaunchKernelGGL(colsum_partial_kernel<unsigned short>, dim3(cdiv(cols, 64), nsplit), dim3(256), 0, st,
                            (const unsigned short*)X, rows, cols, ldx, (float*)ws, nsplit);

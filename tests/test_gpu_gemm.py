@@ -134,3 +134,16 @@ def test_gemm_kk_frames_touches_exactly_the_selected_frames(case):
     got = C.float().cpu()
     assert (got[:, sel] - ref.cpu()[:, sel]).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
     assert (got[:, ~sel] == 7.0).all()
+
+
+@pytest.mark.parametrize("rows,cols,dt", [(48, 4096, "f32"), (48, 1000, "bf16"), (7000, 512, "bf16"), (7000, 520, "bf16"), (600, 64, "bf16")])
+def test_colsum_paths(rows, cols, dt):
+    """las_colsum_dt: few rows -> one direct pass; bf16 with 16-byte rows -> 8 columns per thread; else the generic two-stage kernel."""
+    from las import _hip
+    g = torch.Generator().manual_seed(rows + cols)
+    X = torch.randn(rows, cols, generator=g)
+    Xd = X.cuda().to(torch.bfloat16) if dt == "bf16" else X.cuda()
+    out = torch.full((cols,), 0.5, device="cuda")
+    _hip.colsum(Xd, rows, cols, cols, out, beta=2.0)
+    want = Xd.float().cpu().double().sum(0) + 1.0
+    assert (out.cpu().double() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
