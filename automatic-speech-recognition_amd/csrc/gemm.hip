@@ -23,6 +23,7 @@ struct GemmArgs {
     int splitk, kchunk;                            // split-K: blockIdx.z = split, K range [z*kchunk, ..)
     float* partial;                                // [splitk][M][N] when splitk > 1
     int in_bf16;                                   // A and B are bf16 in HBM (speed-mode activations / gradients)
+    int zgroup;                                    // > 0: 1-D grid, all tiles of one k-chunk / batch entry on one XCD (count of entries)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) { return act == LAS_ACT_TANH ? tanhf(v) : v; }
@@ -305,8 +306,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  All column tiles of one row block
     // go to the same XCD back to back, so the row block of A is fetched into that L2 once instead of once per XCD.
     // (Only for tall outputs: with fewer than a few row blocks per XCD the plain 2-D order fills the chip better.)
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (gridDim.y == 1 && g.M > BM) {
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.zgroup) {
+        // split-K / batched contractions with few output tiles (the weight gradients): 1-D grid, ALL tiles of one k-chunk (or
+        // batch entry) on ONE XCD and next to each other in dispatch order, so that the chunk's operand rows are fetched into that
+        // XCD's L2 once and shared by its tiles instead of every tile pulling them from HBM (the 3-D order spread them over 8 L2s)
+        const int nx = (g.N + BN - 1) / BN, ny = (g.M + BM - 1) / BM, nt = nx * ny;
+        const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
+        bz = xcd + 8 * (li / nt);
+        if (bz >= g.zgroup) return;
+        const int t = li % nt;
+        by = t / nx; bx = t % nx;
+    } else if (gridDim.y == 1 && g.M > BM) {
         const int nx = (g.N + BN - 1) / BN, ny = (g.M + BM - 1) / BM;
         const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
         by = xcd + 8 * (li / nx); bx = li % nx;
@@ -318,12 +329,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
     float* C = g.C;
     int kbeg = 0, kend = g.K;
     if (g.splitk > 1) {
-        kbeg = blockIdx.z * g.kchunk;
+        kbeg = bz * g.kchunk;
         kend = min(g.K, kbeg + g.kchunk);
     } else {
-        A += (long long)blockIdx.z * g.strideA;
-        B += (long long)blockIdx.z * g.strideB;
-        C += (long long)blockIdx.z * g.strideC;
+        A += (long long)bz * g.strideA;
+        B += (long long)bz * g.strideB;
+        C += (long long)bz * g.strideC;
     }
     f32x4_t acc[TM][TN];
 #pragma unroll
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
                 const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) * 4 + r;
                 if (row < g.M && col < g.N) {
                     if (g.splitk > 1) {
-                        g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                        g.partial[((long long)bz * g.M + row) * g.N + col] = acc[i][j][r];
                     } else {
                         float v = g.alpha * acc[i][j][r] + bcol;
                         float* cp = C + (long long)row * g.ldc + col;
@@ -383,17 +394,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
         }
 }
 
+static bool g_zgroup_on = true;
+extern "C" void las_dev_gemm_zgroup(int on) { g_zgroup_on = on != 0; }     // development switch (A/B measurements)
+
 template <int WM, int WN, int TM, int TN, typename TI>
 static void launch_fast_t(const GemmArgs& g, int zdim, hipStream_t st) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const int nx = cdiv(g.N, BN), ny = cdiv(g.M, BM);
     const bool xcd_order = ny >= 64 && zdim == 1;        // tall output: 1-D grid, row blocks padded to 8, XCD-aware order
     dim3 grid(xcd_order ? nx * ((ny + 7) / 8 * 8) : nx, xcd_order ? 1 : ny, zdim), blk(WM * WN * 64);
+    GemmArgs gz = g;
+    gz.zgroup = 0;
+    if (zdim > 1 && nx * ny <= 64 && g_zgroup_on) {      // few tiles per k-chunk / batch entry: group them per XCD (see the kernel)
+        gz.zgroup = zdim;
+        grid = dim3(nx * ny * ((zdim + 7) / 8 * 8), 1, 1);
+    }
+    const GemmArgs& g_ = gz;
     const bool akc = g.ksA == 1, bkc = g.ksB == 1;
-    if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true, TI>), grid, blk, 0, st, g);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false, TI>), grid, blk, 0, st, g);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, true, TI>), grid, blk, 0, st, g);
-    else                  hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, false, TI>), grid, blk, 0, st, g);
+    if (akc && bkc)       hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, true, TI>), grid, blk, 0, st, g_);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, true, false, TI>), grid, blk, 0, st, g_);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, true, TI>), grid, blk, 0, st, g_);
+    else                  hipLaunchKernelGGL((gemm_bf16_fast_kernel<WM, WN, TM, TN, false, false, TI>), grid, blk, 0, st, g_);
 }
 template <int WM, int WN, int TM, int TN>
 static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
