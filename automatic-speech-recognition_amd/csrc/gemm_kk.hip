@@ -159,10 +159,11 @@ extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long lon
 
 // A, C are [nb, T, *] tensors; only the frames [lo0, lo0 + nlo) and [hi0, hi0 + nhi) of every utterance are computed
 extern "C" int las_gemm_kk_frames(int nb, int T, int lo0, int nlo, int hi0, int nhi, int N, int K, const void* A, long long lda,
-                                  const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream) {
+                                  const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act,
+                                  const void* y, long long ldy, void* stream) {
     LAS_ARG(nb > 0 && T > 0 && nlo >= 0 && nhi >= 0 && nlo + nhi > 0 && lo0 >= 0 && lo0 + nlo <= T && hi0 >= 0 && hi0 + nhi <= T,
             "las_gemm_kk_frames: bad frame ranges");
-    return gemm_kk_impl(nb * (nlo + nhi), N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, nullptr, 0, T, lo0, nlo, hi0, nhi, stream);
+    return gemm_kk_impl(nb * (nlo + nhi), N, K, A, lda, B, ldb, C, c_dtype, ldc, bias, act, y, ldy, T, lo0, nlo, hi0, nhi, stream);
 }
 
 static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,

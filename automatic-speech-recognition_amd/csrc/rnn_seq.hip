@@ -47,6 +47,8 @@ struct RnnArgs {
     int announce;                            // LAS_SEQ_ANNOUNCE(n): cluster 0 stores n into status[1] once its members are resident
     const int* xflag; int xsc;               // forward: the x-projection arrives in time chunks of xsc steps from both ends of the sequence,
                                              // *xflag = number of chunks complete (another stream's kernels write it); NULL: all there
+    const int* dflag; int dcp, dTq, dshift;  // BPTT: dout arrives in chunks of 2^dcp producer rows (dTq per utterance; row = frame >> dshift) from
+                                             // both ends of the sequence; *dflag = chunks complete
     int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
 };
@@ -1260,7 +1262,8 @@ struct KsCfg {
 // repeat rows 0..7.  Lanes 32..63 then hold the same accumulators as lanes 0..31 and every lane keeps HALF of them (selected
 // by hsel = lane >> 5): one row x one unit pair per lane instead of two rows, half the loads / stores / transcendentals /
 // granule bytes per step, twice as many CUs per batch.
-template <int CELL, int UT, int P, int RB>
+// CH: dout arrives in chunks (a.dflag): a separate instantiation -- the kernel sits at the register limit and the plain one must not change
+template <int CELL, int UT, int P, int RB, bool CH = false>
 __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     static_assert(RB == 16 || RB == 8, "row tile");
     using K = KsCfg<CELL, UT, P, RB>;
@@ -1340,6 +1343,23 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         for (int rr = 0; rr < 2; ++rr) { dcc[j][rr][0] = 0.f; dcc[j][rr][1] = 0.f; }
     }
     constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
+    // chunked dout (las_rnn_seq_bwd_db_chunked): the frame of step st may be read once the chunk of its producer row is complete
+    int dhave = 0;
+    auto wait_dout = [&](int st) __attribute__((always_inline)) {
+        if constexpr (!CH) return;
+        const int f = dir ? st : T - 1 - st, pr = f >> a.dshift;
+        const int mm = pr < a.dTq - 1 - pr ? pr : a.dTq - 1 - pr;
+        const int need = (mm >> a.dcp) + 1;
+        if (need <= dhave) return;
+        int budget = a.spin < (1 << 16) ? a.spin : (1 << 16);
+        for (;;) {
+            dhave = __hip_atomic_load(a.dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (dhave >= need) break;
+            if (--budget <= 0) { errflag = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    };
+    wait_dout(0);
     // operands of one step as packed pairs, ONE register set refilled for step s+1 right after step s consumed it
     unsigned n_do[UTP][2], n_g[NG][UTP][2], n_c[UTP][2], n_cn[UTP][2];
 #pragma unroll
@@ -1424,6 +1444,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) { gprev[rr] = gptr[rr]; gptr[rr] += gst[rr]; optr[rr] += ost[rr]; dptr[rr] += dst[rr]; if (CELL == LAS_CELL_LSTM) cptr[rr] += cst_[rr]; }
         if (s + 1 < T) {     // operands of the next step fly under this step's MFMAs and exchange
+            wait_dout(s + 1);
 #pragma unroll
             for (int j = 0; j < UTP; ++j)
 #pragma unroll
@@ -1432,8 +1453,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
                     if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
                         for (int q = 0; q < NG; ++q) n_g[q][j][rr] = gptr[rr][(q * H + j * 16) / 2];
+                        if constexpr (CH) n_c[j][rr] = cptr[rr][j * 8];      // (this variant re-loads c_t -- an L1 / L2 hit -- instead of rotating
+                                                                            //  registers: the pinned rotation below survives only in the plain loop shape)
+                        else {
                         n_c[j][rr] = n_cn[j][rr];
                         asm volatile("" : "+v"(n_c[j][rr]));        // the copy happens HERE: the old register of n_cn is free for the load below
+                        }
                         // unconditional (a conditional load makes the compiler drain vmcnt at the join, which puts the HBM latency of
                         // this whole prefetch on the dependent chain); past the last frame the address is clamped and the value unused
                         n_cn[j][rr] = cptr[rr][((s + 2 < T) ? cst_[rr] : 0) + j * 8];
@@ -1770,7 +1795,12 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>), grid, blk, FL, st, a);
         } else if (P > 1 && KsCfg<CELL, UT, P>::OK && a.ks_packed) {
             if constexpr (P > 1 && KsCfg<CELL, UT, P>::OK) {
-                if (a.rb == 8) {
+                if (a.rb == 8 && a.dflag) {
+                    constexpr int KZ = KsCfg<CELL, UT, P, 8>::DZ_BYTES;
+                    static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>, KZ);
+                    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
+                    hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>), grid, dim3(256), KZ, st, a);
+                } else if (a.rb == 8) {
                     constexpr int KZ = KsCfg<CELL, UT, P, 8>::DZ_BYTES;
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8>, KZ);
                     if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
@@ -1805,7 +1835,7 @@ static int launch_bf16(bool bwd, const RnnArgs& a, hipStream_t st, bool query) {
     if (query) {       // bit 0: an 8-row-tile kernel exists for the direction; bit 1: the forward helper-wave kernel exists for 16-row tiles
         int r = rb8_ok<CELL, UT, P>(bwd) ? 1 : 0;
         if constexpr (P > 1) r |= (!bwd && HwCfg<CELL, UT, P, 16>::OK) ? 2 : 0;
-        return r;
+        return r;                                                   // (bwd: bit 0 also means the chunk-aware K-split variant exists)
     }
     const int ntiles = cdiv(a.B, a.rb);
     int rt = pick_rt(CELL, UT * 64, P, bwd, ntiles);
@@ -1923,7 +1953,7 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
     a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
     a.warm = (flags & LAS_SEQ_NO_WARMERS) ? 0 : 1;
-    a.xflag = nullptr; a.xsc = 0;
+    a.xflag = nullptr; a.xsc = 0; a.dflag = nullptr; a.dcp = 0; a.dTq = 0; a.dshift = 0;
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;
@@ -1995,6 +2025,16 @@ extern "C" int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, 
     return 0;
 }
 
+extern "C" int las_rnn_seq_bwd_chunks_ok(int cell, int prec, int B, int H, int flags) {
+    if (prec != LAS_PREC_BF16 || !mfma_shape_ok(H) || B <= 0 || (flags & (LAS_SEQ_NO_KSPLIT | LAS_SEQ_ROWS16))) return 0;
+    const int P = pick_cluster(cell, H, flags);
+    if (P <= 1) return 0;
+    RnnArgs a; a.H = H; a.B = B;
+    const int q = dispatch_bf16(cell, P, true, a, nullptr, true);
+    const int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
+    return (max_tiles >= 1 && (q & 1) && cdiv(B, 8) <= max_tiles) ? 1 : 0;      // served by ONE launch of the 8-row K-split kernel
+}
+
 extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
                                const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
@@ -2008,6 +2048,15 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void*
                                   const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
                                   float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
                                   void* ws, size_t ws_bytes, void* stream) {
+    return las_rnn_seq_bwd_db_chunked(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout,
+                                      dout_bstride, forget_bias, dbias_fw, dbias_bw, flags, status, nullptr, 0, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                          const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                                          const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                                          float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                                          const int* chunk_flag, int chunk_rows, int n_rows, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
     LAS_ARG(prec != LAS_PREC_BF16 || !mfma_shape_ok(H) ||
@@ -2022,6 +2071,11 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void*
     bind_tensors(a, gates, const_cast<void*>(out), const_cast<void*>(cstate), dout);
     a.ld_dout = ld_dout; a.dobs = dout_bstride; a.fb = forget_bias; a.wpack = ws;
     seq_common_args(a, flags, status, LAS_SEQ_STATUS_BWD_TIMEOUT);
+    LAS_ARG(!chunk_flag || (chunk_rows > 0 && (chunk_rows & (chunk_rows - 1)) == 0 && (n_rows == T || n_rows == (T + 1) / 2) &&
+                            las_rnn_seq_bwd_chunks_ok(cell, prec, B, H, flags)),
+            "las_rnn_seq_bwd_db_chunked: bad chunk geometry, or a configuration the chunk-aware kernel does not serve");
+    a.dflag = chunk_flag; a.dTq = n_rows; a.dshift = (chunk_flag && n_rows != T) ? 1 : 0;
+    for (int c = chunk_rows; c > 1; c >>= 1) ++a.dcp;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif

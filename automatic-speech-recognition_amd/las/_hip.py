@@ -102,7 +102,11 @@ _SIGS = {
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_set_word": (c_int, [c_void_p, c_int, c_void_p]),
     "las_gemm_kk_frames": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong,
-                                   c_void_p, c_int, c_longlong, c_void_p, c_int, c_void_p]),
+                                   c_void_p, c_int, c_longlong, c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
+    "las_rnn_seq_bwd_chunks_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "las_rnn_seq_bwd_db_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
+                                           c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_fwd_chunks_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "las_rnn_seq_fwd_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                         c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -229,6 +233,47 @@ class on_side_stream:
         return self.ctx.__exit__(*exc)
 
 
+_chain_stream = None
+_chain_used = False
+
+
+def chain_stream():
+    """Second auxiliary stream: chunks of dependency-chain GEMMs that run WHILE the sweep that consumes them runs (the side
+    stream cannot carry them: its weight-gradient GEMMs are held back / long)."""
+    global _chain_stream
+    if _chain_stream is None:
+        _chain_stream = torch.cuda.Stream()
+    return _chain_stream
+
+
+class on_chain_stream:
+    """Run the enclosed launches on the chain stream, after `after` (an event) or everything already enqueued on the current stream."""
+
+    def __init__(self, after=None):
+        self.after = after
+
+    def __enter__(self):
+        global _chain_used
+        if self.after is not None:
+            chain_stream().wait_event(self.after)
+        else:
+            chain_stream().wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(chain_stream())
+        self.ctx.__enter__()
+        _chain_used = True
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_chain_stream():
+    global _chain_used
+    if _chain_used:
+        torch.cuda.current_stream().wait_stream(chain_stream())
+        _chain_used = False
+
+
 _deferred = []
 
 
@@ -248,6 +293,7 @@ def join_side_stream():
     """Make the current stream wait for all side-stream work (call before the gradients are consumed)."""
     global _side_used
     run_deferred()
+    join_chain_stream()
     if _side_used:
         torch.cuda.current_stream().wait_stream(side_stream())
         _side_used = False
@@ -342,9 +388,16 @@ class roctx_range:
     def __enter__(self):
         if ROCTX:
             torch.cuda.nvtx.range_push(self.name)
+        if _PROF is not None:                      # prof_begin(): the phase's span on the launch stream, by HIP events
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
         return self
 
     def __exit__(self, *exc):
+        if _PROF is not None and hasattr(self, "e0"):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROF.setdefault("phase:" + self.name, []).append((self.e0, e1))
         if ROCTX:
             torch.cuda.nvtx.range_pop()
         return False
@@ -517,13 +570,14 @@ def _check_io(cell, prec, H, *tensors):
             raise RuntimeError("las_rnn_seq: tensors must be %s for (cell=%d, prec=%d, H=%d), got %s" % (want, cell, prec, H, t.dtype))
 
 
-def gemm_kk_frames(A, B, C, nb, T, lo0, nlo, hi0, nhi, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE):
-    """las_gemm_kk on the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of the [nb, T, *] tensors A (bf16) and C."""
-    require_gpu(A, B, C, bias)
+def gemm_kk_frames(A, B, C, nb, T, lo0, nlo, hi0, nhi, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, tanh_y=None, ldy=0):
+    """las_gemm_kk on the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of the [nb, T, *] tensors A (bf16) and C
+    (tanh_y: as in gemm_kk)."""
+    require_gpu(A, B, C, bias, tanh_y)
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype in (torch.bfloat16, torch.float32)
     cdt = DT_BF16 if C.dtype == torch.bfloat16 else DT_F32
-    check(lib().las_gemm_kk_frames(nb, T, lo0, nlo, hi0, nhi, N, K, p(A), lda, p(B), ldb, p(C), cdt, ldc, p(bias), act, stream()),
-          "las_gemm_kk_frames")
+    check(lib().las_gemm_kk_frames(nb, T, lo0, nlo, hi0, nhi, N, K, p(A), lda, p(B), ldb, p(C), cdt, ldc, p(bias), act,
+                                   p(tanh_y), ldy, stream()), "las_gemm_kk_frames")
 
 
 def set_word(word, value):
@@ -554,15 +608,29 @@ def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
               "las_rnn_seq_fwd")
 
 
+def rnn_seq_bwd_chunks_ok(cell, prec, B, H, flags=None):
+    return bool(lib().las_rnn_seq_bwd_chunks_ok(cell, prec, B, H, seq_flags if flags is None else flags))
+
+
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None):
-    """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself."""
+                dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None,
+                chunk_flag=None, chunk_rows=0, n_rows=0):
+    """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself.
+    chunk_flag / chunk_rows / n_rows: dout is still being produced in chunks (las_rnn_seq_bwd_db_chunked)."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
     _check_io(cell, prec, H, gates, out, cstate, dout)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
     fl |= next_announce() << 21                    # LAS_SEQ_ANNOUNCE: status_word[1] = this number once the sweep is resident
     _announce[0] += 1
+    if chunk_flag is not None:
+        with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
+            check(lib().las_rnn_seq_bwd_db_chunked(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                                   c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                                   p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(db_fw), p(db_bw),
+                                                   fl, p(status_word(gates.device)), p(chunk_flag), chunk_rows, n_rows,
+                                                   p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db_chunked")
+        return
     with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
         check(lib().las_rnn_seq_bwd_db(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
                                        c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,

@@ -100,9 +100,15 @@ class _Dense(torch.autograd.Function):
 _TANH_OUT = {}        # data_ptr -> bf16 output of a dense+tanh layer (speed mode): a recurrent layer that reads exactly this tensor
                       # fuses the Tanh gradient into its dX product (las_gemm_kk_tanhgrad) and hands dPre, not dY, to the dense node
 _DPRE = set()         # data_ptr of gradients that already ARE d(pre-activation) of the dense layer they flow into
+_DCHUNK = {}          # data_ptr of a dPre whose producer (a recurrent layer's dX product) has only run its first time chunk:
+                      # (chunk rows, rows per utterance, chunks, fn(k), holder) -- the dense node below runs fn(k) interleaved with its
+                      # own chunks and puts the event behind the last one into `holder`
+_DOUT_CHUNKS = {}     # data_ptr of a dense layer's dX that is still being produced in chunks on the chain stream: (flag, chunk rows, rows)
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
 XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
+DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "0"))         # backward hand-over in chunks of this many rows (a power of two); 0 = off:
+                                                                     # measured a wash on one GPU (DESIGN "Wavefront hand-over"), kept for other shapes
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
@@ -357,6 +363,12 @@ class _Dense16(torch.autograd.Function):
         else:
             dpre = dy if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16)
         dx = None
+        ch = _DCHUNK.pop(dy.data_ptr(), None) if dpre is dy else None
+        chain_done = None
+        if ch is not None and not (ctx.needs_input_grad[0] and _k64(N) == N):
+            for k in range(1, ch[2]):                  # no hand-over here: finish the producer's product first (this stream)
+                ch[3](k)
+            ch = None
         if ctx.needs_input_grad[0]:                    # on the dependency chain: main stream, first
             Wb = _shadow("dense", (W,), Kw, False, K, _k64(N))                           # W, rows padded to K: [K, N64]
             dx = torch.empty(M, K, device=dy.device, dtype=torch.bfloat16)
@@ -365,18 +377,67 @@ class _Dense16(torch.autograd.Function):
                 dpre_k = torch.nn.functional.pad(dpre, (0, Nk - N))
             else:
                 dpre_k = dpre
-            _hip.gemm_kk(dpre_k, Wb, dx, M, K, Nk, Nk, Nk, K)
+            if ch is not None:
+                # Wavefront hand-over to the BPTT sweep below (the mirror of the chunked x-projection): dPre arrives in time
+                # chunks from both ends of the sequence, this product follows chunk by chunk -- chunk 0 here, the others on the
+                # chain stream while the sweep already runs -- and publishes its progress in `flag`.
+                c, Tq, nch, produce, holder = ch
+                nb, th = M // Tq, (Tq + 1) // 2
+                flag = _chunk_flag(dy.device)
+
+                def mine(k):
+                    lo0, lo1 = k * c, min((k + 1) * c, th)
+                    hi0, hi1 = max(Tq - lo1, lo1), Tq - lo0
+                    _hip.gemm_kk_frames(dpre, Wb, dx, nb, Tq, lo0, lo1 - lo0, hi0, hi1 - hi0, K, N, N, N, K)
+                    _hip.set_word(flag, k + 1)
+
+                mine(0)
+                first = torch.cuda.Event()
+                first.record()
+                chain_done = []
+
+                def rest():
+                    # enqueued by the consumer AFTER it has launched its sweep (the host must not spend the 3 launches per chunk
+                    # in front of that launch); at the latest by the next run_deferred()
+                    if chain_done:
+                        return
+                    with _hip.on_chain_stream(after=first):
+                        for t in (dpre, dx, flag):
+                            t.record_stream(_hip.chain_stream())
+                        for k in range(1, nch):
+                            produce(k)
+                            mine(k)
+                        chain_done.append(torch.cuda.Event())
+                        chain_done[0].record()
+                    holder.append(chain_done[0])
+
+                _DOUT_CHUNKS[dx.data_ptr()] = (flag, c, Tq, rest)
+            else:
+                _hip.gemm_kk(dpre_k, Wb, dx, M, K, Nk, Nk, Nk, K)
         Wp, bp = ctx.params
-        _hip.run_deferred()
+        if chain_done is None:
+            _hip.run_deferred()                        # (else: the consumer sweep's node runs them, after its launch)
         Kg = (Kw + 3) // 4 * 4                         # rows of the weight gradient the TN product writes (zero operand columns beyond Kw)
         if _direct_ok(Wp) and (bp is None or _direct_ok(bp)) and Kg == Kw:
-            with _hip.on_side_stream():
-                for t in (x2d, dpre):
-                    t.record_stream(_hip.side_stream())
-                _hip.gemm(_hip.PREC_BF16, x2d, dpre, Wp.grad, True, False, Kw, N, M, K, N, N, beta=1.0)
-                if bp is not None:
-                    _hip.colsum(dpre, M, N, N, bp.grad, beta=1.0)
+            def wgrad(after=None):
+                with _hip.on_side_stream(after=after):
+                    for t in (x2d, dpre):
+                        t.record_stream(_hip.side_stream())
+                    _hip.gemm(_hip.PREC_BF16, x2d, dpre, Wp.grad, True, False, Kw, N, M, K, N, N, beta=1.0)
+                    if bp is not None:
+                        _hip.colsum(dpre, M, N, N, bp.grad, beta=1.0)
+
+            if chain_done is None:
+                wgrad()
+            else:
+                def later():
+                    rest()
+                    wgrad(chain_done[0])           # all of dPre
+                _hip.defer_side(later)
             return dx, None, None, None, None
+        if chain_done is not None:
+            rest()
+            torch.cuda.current_stream().wait_event(chain_done[0])
         dW = torch.zeros(Kg, N, device=dy.device)
         _hip.gemm(_hip.PREC_BF16, x2d, dpre, dW, True, False, Kg, N, M, K, N, N)
         db = None
@@ -466,16 +527,47 @@ class _BLSTM16(torch.autograd.Function):
         xs = (x, x_bw if two else x)
         P4 = ctx.params
         direct = P4 is not None and all(_direct_ok(p) for p in P4)
+        produced = None
+        dc = _DOUT_CHUNKS.pop(dout.data_ptr(), None)       # dout still arrives in chunks (the dense node above, chain stream)
+        if dc is not None and not (dc[2] in (T, (T + 1) // 2) and _hip.rnn_seq_bwd_chunks_ok(_cellid(cell), prec, B, H)):
+            dc[3]()
+            _hip.join_chain_stream()
+            dc = None
         # gates: activated gates -> d(pre-activation) (bf16), in place; the sweep accumulates the bias gradients in fp32
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
-                         db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None)
+                         db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None,
+                         chunk_flag=None if dc is None else dc[0], chunk_rows=0 if dc is None else dc[1],
+                         n_rows=0 if dc is None else dc[2])
+        if dc is not None:
+            dc[3]()                          # the other chunks: chain stream, enqueued behind the sweep's launch
+            _hip.join_chain_stream()         # (they are finished when the sweep is; this orders later readers of dout)
         dx = dx_bw = None
         if ctx.needs_input_grad[0] and not two:        # on the dependency chain: main stream, first
             # dX [B*T, Ik] = dZ [B*T, 2GH] . [W_ih_fw | W_ih_bw]^T : B operand = shadow of the concatenated weights [Ik, 2GH]
             Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
-            if ctx.x_is_tanh:
+            c = DOUT_CHUNK_ROWS
+            if ctx.x_is_tanh and c and T >= 4 * c and direct and _hip.streams_overlap(dev):
+                # first time chunk only; the dense node below (the consumer of this dPre) interleaves the others with its own
+                th = (T + 1) // 2
+
+                def produce(k):
+                    if k == 1:
+                        for t in (gates, x, dx):
+                            t.record_stream(_hip.chain_stream())
+                    lo0, lo1 = k * c, min((k + 1) * c, th)
+                    hi0, hi1 = max(T - lo1, lo1), T - lo0
+                    _hip.gemm_kk_frames(gates, Wb, dx, B, T, lo0, lo1 - lo0, hi0, hi1 - hi0, Ik, 2 * GH, 2 * GH, 2 * GH, Ik,
+                                        tanh_y=x, ldy=Ik)
+
+                produce(0)
+                chain_done = []
+                _DCHUNK[dx.data_ptr()] = (c, T, (th + c - 1) // c, produce, chain_done)
+                _DPRE.add(dx.data_ptr())
+                produced = torch.cuda.Event()
+                produced.record()
+            elif ctx.x_is_tanh:
                 _hip.gemm_kk(gates, Wb, dx, B * T, Ik, 2 * GH, 2 * GH, 2 * GH, Ik, tanh_y=x, ldy=Ik)
                 _DPRE.add(dx.data_ptr())
             else:
@@ -504,17 +596,30 @@ class _BLSTM16(torch.autograd.Function):
 
         if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
-            with _hip.on_side_stream():
-                side = _hip.side_stream()
-                for t in (x, gates, out) + ((x_bw,) if two else ()):
-                    t.record_stream(side)
-                if ctx.hold_side and ctx.needs_input_grad[0] and _hip.streams_overlap(dev):
-                    # keep the side stream (these GEMMs and whatever is queued behind them) off the machine until the NEXT
-                    # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
-                    # front of it; bounded wait, scheduling only
-                    _hip.hold_until_next_sweep(dev)
-                for d in range(2):
-                    wgrads(lambda d: P4[2 * d].grad, d)
+            hold = ctx.hold_side and ctx.needs_input_grad[0] and _hip.streams_overlap(dev)
+
+            def side_work(after=None):
+                with _hip.on_side_stream(after=after):
+                    side = _hip.side_stream()
+                    for t in (x, gates, out) + ((x_bw,) if two else ()):
+                        t.record_stream(side)
+                    if after is not None:
+                        # hand-over in chunks: these GEMMs would compete with the chain-stream chunks the next sweep is
+                        # waiting for -- they start when the last chunk is done
+                        if chain_done:
+                            side.wait_event(chain_done[0])
+                    elif hold:
+                        # keep the side stream (these GEMMs and whatever is queued behind them) off the machine until the NEXT
+                        # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
+                        # front of it; bounded wait, scheduling only
+                        _hip.hold_until_next_sweep(dev)
+                    for d in range(2):
+                        wgrads(lambda d: P4[2 * d].grad, d)
+
+            if produced is not None:
+                _hip.defer_side(lambda: side_work(produced))      # run by the next sweep's node, after its launch
+            else:
+                side_work()
             return (dx, None, None, None, None, None, None, None, None, dx_bw)
         grads = []
         for d, k in enumerate((kfw, kbw)):
@@ -588,6 +693,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     sc = scope + "/blstm"
     _TANH_OUT.clear()
     _DPRE.clear()
+    _DCHUNK.clear()
+    _DOUT_CHUNKS.clear()
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)
     rnn_out = dense(out, st.get(sc + "/dense/kernel", (2 * H, 2 * H)),
                     st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=num_layers == 0)       # :71-74

@@ -342,6 +342,9 @@ def main():
         G = 4 if a.cell == "lstm" else 1
         H = args.enc_units
         per = {k: (sum(v) / len(v), len(v)) for k, v in prof.items()}
+        if os.environ.get("LAS_PHASES"):            # spans of the step's phases and sweeps on the launch stream (no profiler needed)
+            for k in sorted(per):
+                print("  %-34s %8.3f ms  x%d" % (k, per[k][0], per[k][1] // a.steps), file=sys.stderr)
         # dominant kernel = the recurrent-sweep kernel family (fwd or bwd) with the largest total time in the timed
         # region.  achieved = algorithmic bytes of ALL its launches / their total duration (HIP events on the launch
         # stream), avg_launch_ms = mean over the same launches -> directly comparable with rocprofv3's per-kernel average.

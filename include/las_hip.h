@@ -165,7 +165,8 @@ int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates
 /* C = act(A . B^T + bias) like las_gemm_kk, restricted to the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of
  * [nb, T, *] tensors A and C (row pitches lda / ldc per frame); las_set_word: stream-ordered store of a device word. */
 int las_gemm_kk_frames(int nb, int T, int lo0, int nlo, int hi0, int nhi, int N, int K, const void* A, long long lda,
-                       const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act, void* stream);
+                       const void* B, long long ldb, void* C, int c_dtype, long long ldc, const float* bias, int act,
+                       const void* y_tanh, long long ldy, void* stream);       /* y_tanh as in las_gemm_kk_tanhgrad (may be NULL) */
 int las_set_word(int* word, int value, void* stream);
 
 int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates,
@@ -182,6 +183,18 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates,
                        const void* dout, int ld_dout, long long dout_bstride,
                        float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
                        void* ws, size_t ws_bytes, void* stream);
+/* las_rnn_seq_bwd_db for an upstream gradient `dout` that is still being computed: dout [B, Tp, 2H] is the input gradient of the
+ * dense layer above, whose rows are pyramid frame pairs (n_rows = ceil(T/2)) or single frames (n_rows = T); it is filled in chunks
+ * of `chunk_rows` (a power of two) of those rows from both ends of the sequence (chunk k = rows [k*c, (k+1)*c) and
+ * [n_rows-(k+1)*c, n_rows-k*c) of every utterance), e.g. by las_gemm_kk_frames launches on another stream each followed by
+ * las_set_word(chunk_flag, k+1).  The sweep reads a frame of dout only after *chunk_flag has reached the chunk of its row
+ * (bounded wait -> LAS_SEQ_STATUS_BWD_TIMEOUT).  Only the 8-row K-split cluster kernel supports it (las_rnn_seq_bwd_chunks_ok). */
+int las_rnn_seq_bwd_chunks_ok(int cell, int prec, int B, int H, int flags);
+int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                               const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                               float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                               const int* chunk_flag, int chunk_rows, int n_rows, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K4-K7  Speller: the whole decode loop of Speller.__call__ (las/las.py:72-143) with

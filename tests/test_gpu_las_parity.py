@@ -185,3 +185,43 @@ def test_weight_shadows_are_rebuilt_by_one_launch_and_match_the_torch_build():
         assert a.shape == b.shape == c.shape and b.dtype == c.dtype
         assert torch.equal(b, c)
         assert not torch.equal(a, b)
+
+
+def test_backward_hand_over_in_chunks_gives_the_same_gradients():
+    """Speed-mode Listener backward: between two BPTT sweeps the dX products (recurrent layer's dX with the fused Tanh gradient,
+    then the dense layer's dX) run in time chunks from both ends of the sequence, the lower sweep starting after the first chunk
+    (las.layers DOUT_CHUNK_ROWS, las_rnn_seq_bwd_db_chunked).  The parameter gradients must equal those of the whole-GEMM
+    schedule: the chain values bit for bit (same tiles per row), the weight gradients up to split-K summation order."""
+    from las import _hip, layers as L, variables as V
+    B, T, F, H, layers = 8, 1100, 39, 256, 2
+    if not (_hip.rnn_seq_bwd_chunks_ok(1, 1, B, H) and _hip.streams_overlap(torch.device("cuda", 0))):
+        pytest.skip("chunk-aware BPTT kernel / stream overlap not available in this configuration")
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, T, F, generator=g).cuda()
+    dy = None
+    got = {}
+    L.set_cell("lstm"); L.set_precision("bf16")
+    old = L.DOUT_CHUNK_ROWS
+    try:
+        for rows in (0, 64):
+            L.DOUT_CHUNK_ROWS = rows
+            st = V.reset_default_store(device="cuda", seed=3)
+            for _ in range(2):                        # first pass creates the variables; the second runs on the flattened store
+                y, _, _ = L.pBLSTMLayer(x, [T] * B, layers, H, 0.0, True)
+                if st.flat_grad is None:
+                    st.flatten()
+                    continue
+                if dy is None:
+                    dy = torch.randn(y.shape, generator=g).cuda() * 0.1
+                st.flat_grad.zero_()
+                y.backward(dy)
+                _hip.join_side_stream()
+            torch.cuda.synchronize()
+            _hip.check_status()
+            got[rows] = st.flat_grad.clone()
+    finally:
+        L.DOUT_CHUNK_ROWS = old
+        L.set_cell("rnn"); L.set_precision("f32")
+    a, b = got[0], got[64]
+    assert torch.isfinite(a).all() and a.abs().max().item() > 0
+    assert (a - b).abs().max().item() <= 1e-3 * max(1.0, a.abs().max().item())

@@ -222,3 +222,68 @@ def test_chunked_x_projection_is_waited_for():
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError):
         _hip.check_status()
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_chunked_upstream_gradient_is_waited_for(pairs):
+    """las_rnn_seq_bwd_db_chunked: the BPTT sweep may start while its upstream gradient `dout` is still being written in chunks of
+    producer rows (frames, or frame PAIRS under a pyramid dense layer) from both ends of the sequence by another stream.  Late,
+    slow chunks (poison in the frames not yet delivered) must give the same dZ / bias gradients as the sweep over the complete
+    dout, bit for bit; a flag that never arrives surfaces as a status error."""
+    from las import _hip
+    B, T, H, c = 24, 301 if pairs else 300, 256, 32
+    GH = 4 * H
+    assert _hip.rnn_seq_bwd_chunks_ok(1, 1, B, H)
+    Tp = T + (T % 2)
+    Tq = Tp // 2 if pairs else T
+    g = torch.Generator().manual_seed(12)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).cuda().to(torch.bfloat16)
+    w = [((torch.rand(H, GH, generator=g) * 2 - 1) * 0.06).cuda() for _ in range(2)]
+    out = torch.zeros(B, Tp, 2 * H, device="cuda", dtype=torch.bfloat16)
+    cst = torch.zeros(B, T, 2, H, device="cuda", dtype=torch.bfloat16)
+    act = xp.clone()
+    _hip.rnn_seq_fwd(1, 1, B, T, H, act, w[0], w[1], GH, out, 2 * H, Tp * 2 * H, cst)
+    dfull = (torch.randn(B, Tp, 2 * H, generator=g) * 0.1).cuda().to(torch.bfloat16)
+
+    def bptt(dout, **kw):
+        gz = act.clone()
+        db = [torch.zeros(GH, device="cuda") for _ in range(2)]
+        _hip.rnn_seq_bwd(1, 1, B, T, H, gz, w[0], w[1], GH, out, 2 * H, Tp * 2 * H, cst, dout, 2 * H, Tp * 2 * H,
+                         db_fw=db[0], db_bw=db[1], **kw)
+        return gz, db
+
+    ref_z, ref_db = bptt(dfull)
+    torch.cuda.synchronize()
+    rows = dfull.view(B, Tq, -1)
+    dout = torch.full_like(dfull, float("nan"))
+    drows = dout.view(B, Tq, -1)
+    th = (Tq + 1) // 2
+    nch = (th + c - 1) // c
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+
+    def put(k):
+        lo0, lo1 = k * c, min((k + 1) * c, th)
+        hi0, hi1 = max(Tq - lo1, lo1), Tq - lo0
+        drows[:, lo0:lo1] = rows[:, lo0:lo1]
+        drows[:, hi0:hi1] = rows[:, hi0:hi1]
+        _hip.set_word(flag, k + 1)
+
+    put(0)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(1, nch):
+            torch.cuda._sleep(400000)
+            put(k)
+    gz, db = bptt(dout, chunk_flag=flag, chunk_rows=c, n_rows=Tq)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    assert torch.equal(gz, ref_z)
+    for a, b in zip(db, ref_db):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+    flag.fill_(1)
+    bptt(dfull, chunk_flag=flag, chunk_rows=c, n_rows=Tq, flags=_hip.seq_spin_log2(6))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        _hip.check_status()
