@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round measurement evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_evidence.sh r2        -> gpurun_out/<prefix>_{bench.json,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,bucket_sweep.txt}
+#   tools/collect_evidence.sh r2        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,bucket_sweep.txt}
 # rocprofv3 databases go to /tmp (they exceed gpurun's 64 MiB merge limit); only the summaries are kept.  Counter passes are
 # separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); python3 bench.py directly after `--`.
 set -u
@@ -9,7 +9,7 @@ P=${1:-r2}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python3 bench.py --steps 10 --warmup 3 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
+LAS_PHASES=1 python3 bench.py --steps 10 --warmup 3 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_phases.txt     # stderr: spans of the phases / sweeps (HIP events)
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$P -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode > gpurun_out/${P}_kt.log 2>&1
 python3 tools/kernel_stats.py /tmp/kt_$P 3 gpurun_out/${P}_kernel_stats.csv > /dev/null
 # counter passes serialise kernels: the x-projection chunks (another stream's kernels the running sweep waits for) must be off there
