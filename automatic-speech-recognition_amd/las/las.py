@@ -591,15 +591,19 @@ class LAS:
         # everything that does not depend on the encoder goes first, off the chain between the decode loop and its
         # gradient: gradient bucket reset, global token count (one small all-reduce under data parallelism)
         st.flatten()
-        st.zero_grad()
         self.speller.rank = self.dp.rank if self.dp is not None else 0
-        n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
-        n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
-        # the Speller's host-side preparation first: its small uploads overlap with the Listener kernels
-        prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
-                                    True, coins, sampled)
+        # ... and on the auxiliary ("chain") stream: a dozen tiny kernels (0.1 ms back to back) that only the Speller and the
+        # backward pass need run next to the first Listener sweep instead of in front of it
+        with _hip.on_chain_stream():
+            st.zero_grad()
+            n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
+            n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
+            # the Speller's host-side preparation: token schedule, encoder lengths, masks
+            prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
+                                        True, coins, sampled)
         with _hip.roctx_range("listener fwd"):
             h, enc_state, enc_len = self.listener(audio, audiolen, enc_type)              # is_training default True
+        _hip.join_chain_stream()
         with _hip.roctx_range("speller fwd"):
             logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
