@@ -37,11 +37,21 @@ __device__ __forceinline__ long long kk_row(const KKArgs& g, int m) {
     return (long long)b * g.fT + (r < g.nlo ? g.lo0 + r : g.hi0 + (r - g.nlo));
 }
 
-constexpr int KK_BM = 128, KK_BN = 128, KK_BK = 64;
-constexpr int KK_TILE_BYTES = KK_BM * KK_BK * 2;            // 16 KiB per operand tile
-constexpr int KK_LDS = 2 * 2 * KK_TILE_BYTES;               // two buffers x (A, B)
+constexpr int KK_BK = 64;
+// Two tilings: 128 x 128 (4 waves as 2 x 2, wave tile 64 x 64, 2 workgroups per CU) and 256 x 256 (8 waves as 4 x 2, wave tile
+// 64 x 128, one workgroup per CU).  With every CU streaming operand tiles the chip delivers ~13 bytes per clock and CU into LDS
+// (MI355X_MICROARCH.md, "prologue HBM burst"; measured here: 2.0 GB of tile fills in 232 us = 8.6 TB/s for the x-projection),
+// so the tall products are bound by tile fills, not by MFMA (27 % busy): the large tile moves half the bytes per flop.
+template <int WM, int TN> struct KKCfg {
+    static constexpr int NW = WM * 2, BM = WM * 64, BN = 2 * TN * 16;
+    static constexpr int TILE_A = BM * KK_BK * 2, TILE_B = BN * KK_BK * 2, STAGE = TILE_A + TILE_B, LDS = 2 * STAGE;
+    static_assert(BM / NW == 32 && BN / NW == 32, "every wave stages 32 rows of each operand tile");
+};
 
-__global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
+template <int WM, int TN>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kk_kernel(KKArgs g) {
+    using Cfg = KKCfg<WM, TN>;
+    constexpr int KK_BM = Cfg::BM, KK_BN = Cfg::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);            // provably wave-uniform (LDS-DMA base)
@@ -67,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
         pb[q] = g.B + (long long)rb * g.ldb + ch * 8;
     }
     auto stage = [&](int buf) __attribute__((always_inline)) {
-        unsigned char* ab = smem + buf * 2 * KK_TILE_BYTES + w * 32 * 128;
-        unsigned char* bb = ab + KK_TILE_BYTES;
+        unsigned char* ab = smem + buf * Cfg::STAGE + w * 32 * 128;
+        unsigned char* bb = smem + buf * Cfg::STAGE + Cfg::TILE_A + w * 32 * 128;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             __builtin_amdgcn_global_load_lds((gconst_void_t*)pa[q], (lds_void_t*)(ab + q * 1024), 16, 0, 0);
@@ -81,39 +91,55 @@ __global__ __launch_bounds__(256, 2) void gemm_kk_kernel(KKArgs g) {
     const int fo0 = (lane & 15) * 128 + (((0 + (lane >> 4)) ^ sw) << 4);
     const int fo1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ sw) << 4);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][TN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / KK_BK;
     stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                         // ... everybody's has; everybody is done reading tile kt-1
-        if (kt + 1 < nk) stage((kt + 1) & 1);                 // flies under this tile's MFMAs
-        const unsigned char* As = smem + (kt & 1) * 2 * KK_TILE_BYTES + wm * 64 * 128;
-        const unsigned char* Bs = smem + (kt & 1) * 2 * KK_TILE_BYTES + KK_TILE_BYTES + wn * 64 * 128;
+#ifndef KK_ABL
+#define KK_ABL 0                                              // timing experiments: 1 = no MFMAs, 2 = no tile fills after the first two
+#endif
+        if (kt + 1 < nk && !((KK_ABL & 2) && kt >= 1)) stage((kt + 1) & 1);   // flies under this tile's MFMAs
+        if (KK_ABL & 1) continue;
+        const unsigned char* As = smem + (kt & 1) * Cfg::STAGE + wm * 64 * 128;
+        const unsigned char* Bs = smem + (kt & 1) * Cfg::STAGE + Cfg::TILE_A + wn * (TN * 16) * 128;
+        // second k-half's 4 + TN fragment reads are issued behind the first MFMAs of the first half and land under the rest of them
+        // (left to itself the scheduler puts every read directly in front of its MFMAs, behind an lgkmcnt(0))
+        u16x8_t a[2][4], b[2][TN];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fo = s ? fo1 : fo0;
-            u16x8_t a[4], b[4];
+        for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const u16x8_t*>(As + i * 2048 + fo0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u16x8_t*>(As + i * 2048 + fo);
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const u16x8_t*>(Bs + j * 2048 + fo0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u16x8_t*>(Bs + j * 2048 + fo);
+        for (int j = 0; j < TN; ++j) acc[0][j] = mfma_bf16_16x16x32(b[0][j], a[0][0], acc[0][j]);       // swapped operands: D[n][m]
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) a[1][i] = *reinterpret_cast<const u16x8_t*>(As + i * 2048 + fo1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(b[j], a[i], acc[i][j]);   // swapped: D[n][m]
-        }
+        for (int j = 0; j < TN; ++j) b[1][j] = *reinterpret_cast<const u16x8_t*>(Bs + j * 2048 + fo1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(b[0][j], a[0][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16_16x16x32(b[1][j], a[1][i], acc[i][j]);
     }
     // ---- epilogue: lane holds C[m = tile row (lane & 15)][n = 4 consecutive columns (lane >> 4)*4 + r]
     const bool do_tanh = g.act == LAS_ACT_TANH;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 16) + j * 16 + (lane >> 4) * 4;
         if (n >= g.N) continue;                                  // N % 4 == 0
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + n);
@@ -151,6 +177,8 @@ extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, co
 
 static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
                         const float* bias, int act, const void* y, long long ldy, int fT, int lo0, int nlo, int hi0, int nhi, void* stream);
+static bool g_kk_big = true;
+extern "C" void las_dev_gemm_kk_big(int on) { g_kk_big = on != 0; }        // development switch (A/B measurements)
 
 extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                                     void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream) {
@@ -178,15 +206,24 @@ static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const
     LAS_ARG((ldc % 4) == 0, "las_gemm_kk: ldc must be a multiple of 4");
     LAS_ARG((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "las_gemm_kk: operands must be 16-byte aligned");
     LAS_ARG(act == LAS_ACT_NONE || act == LAS_ACT_TANH, "las_gemm_kk: bad act %d", act);
-    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KK_LDS);
+    static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kk_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, KKCfg<2, 4>::LDS) |
+                      (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kk_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, KKCfg<4, 8>::LDS);
     if (attr != 0) { las_set_error("hipFuncSetAttribute(gemm_kk) failed: %d", attr); return attr; }
     KKArgs g;
     g.A = (const unsigned short*)A; g.lda = lda; g.B = (const unsigned short*)B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = c_dtype == LAS_DT_BF16;
     g.ymul = (const unsigned short*)y; g.ldy = ldy;
     g.fT = fT; g.lo0 = lo0; g.nlo = nlo; g.hi0 = hi0; g.fn = fT ? nlo + nhi : 0;
-    const int nx = cdiv(N, KK_BN), ny = cdiv(M, KK_BM);
-    hipLaunchKernelGGL(gemm_kk_kernel, dim3(nx * ((ny + 7) / 8 * 8)), dim3(256), KK_LDS, (hipStream_t)stream, g);
+    // the large tile where it still fills the chip (>= 3/4 of a round of 256 workgroups) and N has no ragged 256-column edge
+    constexpr int lds_big = KKCfg<4, 8>::LDS, lds_small = KKCfg<2, 4>::LDS;
+    const bool big = g_kk_big && N % 256 == 0 && (long long)cdiv(M, 256) * (N / 256) >= 192;
+    if (big) {
+        const int nx = N / 256, ny = cdiv(M, 256);
+        hipLaunchKernelGGL((gemm_kk_kernel<4, 8>), dim3(nx * ((ny + 7) / 8 * 8)), dim3(512), lds_big, (hipStream_t)stream, g);
+    } else {
+        const int nx = cdiv(N, 128), ny = cdiv(M, 128);
+        hipLaunchKernelGGL((gemm_kk_kernel<2, 4>), dim3(nx * ((ny + 7) / 8 * 8)), dim3(256), lds_small, (hipStream_t)stream, g);
+    }
     LAS_LAUNCHED();
     return 0;
 }

@@ -93,9 +93,11 @@ def test_colsum_and_tanh_bwd():
 
 
 @pytest.mark.parametrize("M,N,K,act,out", [(128, 128, 64, 0, "bf16"), (300, 2048, 512, 0, "bf16"), (1000, 512, 1024, 1, "bf16"),
-                                           (257, 132, 128, 1, "f32"), (61, 512, 2048, 0, "f32"), (4096, 2048, 64, 0, "bf16")])
+                                           (257, 132, 128, 1, "f32"), (61, 512, 2048, 0, "f32"), (4096, 2048, 64, 0, "bf16"),
+                                           # 256 x 256 tiles (>= 192 of them, N % 256 == 0): ragged last row block, odd k-tile count
+                                           (6200, 2048, 192, 0, "bf16"), (24500, 512, 256, 1, "bf16"), (12300, 1024, 128, 0, "f32")])
 def test_gemm_kk_bf16_operands_k_contiguous(M, N, K, act, out):
-    """las_gemm_kk (LDS-DMA staged 128x128x64 MFMA tiles): C = act(A . B^T + bias) with bf16 operands vs a float64 product
+    """las_gemm_kk (LDS-DMA staged 128x128x64 or 256x256x64 MFMA tiles): C = act(A . B^T + bias) with bf16 operands vs a float64 product
     of the SAME bf16 values (exact operands, so the only error is fp32 accumulation + the output rounding)."""
     from las import _hip
     g = torch.Generator().manual_seed(M + N + K)
@@ -114,7 +116,7 @@ def test_gemm_kk_bf16_operands_k_contiguous(M, N, K, act, out):
 
 
 @pytest.mark.parametrize("case", [(3, 37, 0, 5, 30, 7, 128, 64), (2, 64, 16, 16, 32, 16, 256, 128), (4, 21, 0, 11, 11, 10, 64, 64),
-                                  (2, 50, 10, 8, 40, 0, 192, 64)])
+                                  (2, 50, 10, 8, 40, 0, 192, 64), (48, 300, 0, 70, 230, 70, 2048, 128)])     # last: 256 x 256 tiles
 def test_gemm_kk_frames_touches_exactly_the_selected_frames(case):
     """las_gemm_kk_frames: C[b, t, :] = A[b, t, :] . B^T + bias for t in [lo0, lo0+nlo) u [hi0, hi0+nhi) only (the time chunks
     of a layer's x-projection); every other frame of C keeps its old contents."""

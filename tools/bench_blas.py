@@ -71,6 +71,11 @@ hf = h.view(R, 2 * H)[:-1, :H]
 df = dz[1:, :GH]
 t_lib = timeit(lambda: torch.mm(hf.t(), df))
 rows.append(("dW_hh as ONE TN product K=%d" % (R - 1), t_mine, t_lib, flops(H, GH, R - 1)))
+for big in (0, 1):
+    _hip.lib().las_dev_gemm_kk_big(big)
+    t1 = timeit(lambda: _hip.gemm_kk(x, w_ihT, gates, R, 2 * GH, Ik, Ik, Ik, 2 * GH))
+    t2 = timeit(lambda: _hip.gemm_kk(dz, w_ih, dx, R, Ik, 2 * GH, 2 * GH, 2 * GH, Ik))
+    print("las_gemm_kk %s tiles: x-projection %.1f us, dX %.1f us" % ("256 x 256" if big else "128 x 128", t1, t2))
 print("%-44s %10s %10s %12s %12s" % ("product", "ours us", "library us", "ours TF/s", "library TF/s"))
 for name, a, b, f in rows:
     print("%-44s %10.1f %10.1f %12.0f %12.0f" % (name, a, b, f / a / 1e6, f / b / 1e6))
