@@ -394,6 +394,132 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_fast_kernel(GemmArgs g)
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN contraction with bf16 operands that are BOTH k-strided (the weight gradients  dW = X^T . dZ : contraction over frames,
+// rows of X and dZ are frames).  The generic fast kernel above turns the [k][m] tiles into [m][k] LDS rows with a 4 x 4
+// register transpose and four 8-byte LDS stores per lane -- rows 4 apart are 80 dwords apart, 16 mod 32, so every one of those
+// stores is 16-way bank conflicted, and the ablation builds (GEMM_ABL) showed the stores bound the kernel: 190 us for dW_ih of
+// a T = 1274 layer, 189 without the global loads, 77 without loads and stores.  Here the tiles stay [k][m] in LDS (16-byte
+// loads, 16-byte conflict-free stores, no VALU work) and the transposition happens in the LDS READ: ds_read_b64_tr_b16 hands
+// lane i of a 16-lane group column i of a [4 k][16 m] block (tools/micro/probe_tr.hip), two of them are one MFMA fragment.
+// 128 x 128 x 32 tiles, 4 waves (2 x 2), rows of 256 + 32 bytes: the four k-rows of a block land in four different bank octets.
+// ------------------------------------------------------------------------------------------------
+constexpr int TR_PITCH = 288;                                        // bytes per LDS k-row (128 elements + 16 pad)
+constexpr int TR_TILE = 32 * TR_PITCH;                               // one operand tile
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_v4s lds_v4s_t;
+
+__device__ __forceinline__ u16x8_t tr_frag(const unsigned char* tile, int col0, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const unsigned char* p = tile + (g * 8 + (l15 >> 2)) * TR_PITCH + (col0 + (l15 & 3) * 4) * 2;
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(__attribute__((address_space(3))) unsigned char*)p);
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(__attribute__((address_space(3))) unsigned char*)(p + 4 * TR_PITCH));
+    u16x8_t f;
+    f[0] = (unsigned short)lo[0]; f[1] = (unsigned short)lo[1]; f[2] = (unsigned short)lo[2]; f[3] = (unsigned short)lo[3];
+    f[4] = (unsigned short)hi[0]; f[5] = (unsigned short)hi[1]; f[6] = (unsigned short)hi[2]; f[7] = (unsigned short)hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.zgroup) {                                                  // all tiles of one k-chunk / batch entry on one XCD (see the fast kernel)
+        const int nx = g.N / BN, ny = g.M / BM, nt = nx * ny;
+        const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
+        bz = xcd + 8 * (li / nt);
+        if (bz >= g.zgroup) return;
+        const int t = li % nt;
+        by = t / nx; bx = t % nx;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(g.A);
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(g.B);
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = bz * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)bz * g.strideA;
+        B += (long long)bz * g.strideB;
+        C += (long long)bz * g.strideC;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // staging: piece p = tid + 256 u (u = 0, 1) is 16 bytes = 8 columns of k-row p >> 4
+    const int pk = tid >> 4, pc = (tid & 15) * 8;
+    const unsigned short* pa = A + (long long)(kbeg + pk) * g.ksA + m0 + pc;
+    const unsigned short* pb = B + (long long)(kbeg + pk) * g.ksB + n0 + pc;
+    const long long sa16 = 16 * g.ksA, sb16 = 16 * g.ksB, sa32 = 32 * g.ksA, sb32 = 32 * g.ksB;
+    const int so = pk * TR_PITCH + pc * 2;
+    u32x4_t ra[2], rb[2];
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool on = k0 + pk + 16 * u < kend;                 // rows past the contraction range read as zero
+            // (default cache policy: non-temporal loads lose the L2 sharing between the tiles of a k-chunk -- 124 -> 155 us)
+            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? pa + u * sa16 : A);
+            const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(on ? pb + u * sb16 : B);
+            ra[u] = on ? va : zero;
+            rb[u] = on ? vb : zero;
+        }
+        pa += sa32; pb += sb32;
+    };
+    gload(kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        unsigned char* As = lds + buf * 2 * TR_TILE;
+        unsigned char* Bs = As + TR_TILE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<u32x4_t*>(As + so + u * 16 * TR_PITCH) = ra[u];
+            *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = rb[u];
+        }
+        __syncthreads();                       // tile visible; the other buffer is free (its readers passed the previous barrier)
+        if (k0 + 32 < kend) gload(k0 + 32);
+        u16x8_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = tr_frag(Bs, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+        buf ^= 1;
+    }
+    const bool has_bias = g.bias != nullptr, has_beta = g.beta != 0.f, do_tanh = g.act == LAS_ACT_TANH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + (wn * 4 + j) * 16 + (lane & 15);
+            const float bcol = has_bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * 4 + i) * 16 + (lane >> 4) * 4 + r;
+                if (g.splitk > 1) {
+                    g.partial[((long long)bz * g.M + row) * g.N + col] = acc[i][j][r];
+                } else {
+                    float v = g.alpha * acc[i][j][r] + bcol;
+                    float* cp = C + (long long)row * g.ldc + col;
+                    if (has_beta) v += g.beta * (*cp);
+                    *cp = do_tanh ? tanh_fast(v) : v;
+                }
+            }
+        }
+}
+
+static bool g_tn_tr_on = true;
+extern "C" void las_dev_gemm_tn_tr(int on) { g_tn_tr_on = on != 0; }       // development switch (A/B measurements)
 static bool g_zgroup_on = true;
 extern "C" void las_dev_gemm_zgroup(int on) { g_zgroup_on = on != 0; }     // development switch (A/B measurements)
 
@@ -598,8 +724,23 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
     LAS_ARG(!g.in_bf16 || (fast_ok && cfg != 3) || (fast_ok && M <= 48),
             "las_gemm: bf16 operands are served by the branch-free path only (aligned pitches, K / row counts multiples of 4, no mask)");
     if (g.in_bf16 && cfg == 3) { cfg = 2; BM = 64; BN = 64; }
+    // weight-gradient form (both operands k-strided bf16, whole 128 x 128 tiles, 16-byte aligned rows): LDS-transposing kernel
+    const bool tn_tr = g_tn_tr_on && fast_ok && cfg == 1 && g.in_bf16 && g.ksA != 1 && g.ksB != 1 && M % 128 == 0 && N % 128 == 0 &&
+                       lda % 8 == 0 && ldb % 8 == 0 && strideA % 8 == 0 && strideB % 8 == 0 &&
+                       (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
     if (fast_ok && (cfg == 1 || cfg == 2)) {
-        if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
+        if (tn_tr) {
+            const int nx = N / 128, ny = M / 128;
+            GemmArgs gz = g;
+            gz.zgroup = 0;
+            dim3 grid(nx, ny, zdim);
+            if (zdim > 1 && nx * ny <= 64 && g_zgroup_on) {
+                gz.zgroup = zdim;
+                grid = dim3(nx * ny * ((zdim + 7) / 8 * 8), 1, 1);
+            }
+            hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), 0, st, gz);
+        }
+        else if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
         else          launch_fast<2, 2, 2, 2>(g, zdim, st);
         LAS_LAUNCHED();
         if (g.splitk > 1) {

@@ -1244,6 +1244,11 @@ __device__ __forceinline__ float swap_lane_pair(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
+#ifndef LAS_KS_SHARE_CU
+#define LAS_KS_SHARE_CU 0        // 1: request only the LDS the kernel uses (timing experiments: lets other kernels share the sweep's CUs)
+#endif
+constexpr int ks_lds(int used) { return LAS_KS_SHARE_CU ? used : (used > 144 * 1024 ? used : 144 * 1024); }   // leaves 16 KB: nothing with an MFMA tile fits
+
 template <int CELL, int UT, int P, int RB = 16>
 struct KsCfg {
     using C = RnnCfg<CELL, UT, P>;
@@ -1795,18 +1800,21 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             hipLaunchKernelGGL((rnn_seq_fwd_bf16_kernel<CELL, UT, P, RT>), grid, blk, FL, st, a);
         } else if (P > 1 && KsCfg<CELL, UT, P>::OK && a.ks_packed) {
             if constexpr (P > 1 && KsCfg<CELL, UT, P>::OK) {
+                // The K-split kernel keeps its weights in registers and needs 9-17 KB of LDS and half of the register file: other
+                // kernels' workgroups (the side stream's weight-gradient GEMMs) WOULD be scheduled onto the same CU and share its
+                // SIMDs, LDS and L1 with the dependent chain.  Asking for (nearly) the whole LDS keeps the CU to the sweep.
                 if (a.rb == 8 && a.dflag) {
-                    constexpr int KZ = KsCfg<CELL, UT, P, 8>::DZ_BYTES;
+                    constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 8>::DZ_BYTES);
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>, KZ);
                     if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
                     hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>), grid, dim3(256), KZ, st, a);
                 } else if (a.rb == 8) {
-                    constexpr int KZ = KsCfg<CELL, UT, P, 8>::DZ_BYTES;
+                    constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 8>::DZ_BYTES);
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8>, KZ);
                     if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
                     hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 8>), grid, dim3(256), KZ, st, a);
                 } else {
-                    constexpr int KZ = KsCfg<CELL, UT, P, 16>::DZ_BYTES;
+                    constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 16>::DZ_BYTES);
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 16>, KZ);
                     if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
                     hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 16>), grid, dim3(256), KZ, st, a);

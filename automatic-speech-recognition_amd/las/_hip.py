@@ -142,8 +142,10 @@ def lib():
         if missing and not os.environ.get("LAS_ALLOW_PARTIAL"):
             raise RuntimeError("liblas_hip.so does not export: %s" % ", ".join(missing))
         # development switches (A/B measurements): LAS_DEV_KK_BIG=0 -> 128 x 128 tiles only in las_gemm_kk;
-        # LAS_DEV_ZGROUP=0 -> 3-D grid order for split-K / batched las_gemm
-        for env, sym in (("LAS_DEV_KK_BIG", "las_dev_gemm_kk_big"), ("LAS_DEV_ZGROUP", "las_dev_gemm_zgroup")):
+        # LAS_DEV_ZGROUP=0 -> 3-D grid order for split-K / batched las_gemm; LAS_DEV_TN_TR=0 -> weight gradients through the
+        # register-transposing kernel instead of the LDS-transposing one
+        for env, sym in (("LAS_DEV_KK_BIG", "las_dev_gemm_kk_big"), ("LAS_DEV_ZGROUP", "las_dev_gemm_zgroup"),
+                         ("LAS_DEV_TN_TR", "las_dev_gemm_tn_tr")):
             if os.environ.get(env) is not None and hasattr(l, sym):
                 getattr(l, sym)(int(os.environ[env]))
         _lib = l
