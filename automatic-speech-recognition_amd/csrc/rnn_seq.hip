@@ -631,6 +631,11 @@ __device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, 
     if (acc == 0x9e3779b9u && sink) sink[threadIdx.x] = (unsigned short)acc;   // keeps the loads alive
 }
 
+#ifndef LAS_KS_SHARE_CU
+#define LAS_KS_SHARE_CU 0        // 1: request only the LDS the kernel uses (timing experiments: lets other kernels share the sweep's CUs)
+#endif
+constexpr int ks_lds(int used) { return LAS_KS_SHARE_CU ? used : (used > 144 * 1024 ? used : 144 * 1024); }   // leaves 16 KB: nothing with an MFMA tile fits
+
 template <int CELL, int UT, int P, int RB = 16>
 struct HwCfg {
     using C = RnnCfg<CELL, UT, P>;
@@ -1244,11 +1249,6 @@ __device__ __forceinline__ float swap_lane_pair(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-#ifndef LAS_KS_SHARE_CU
-#define LAS_KS_SHARE_CU 0        // 1: request only the LDS the kernel uses (timing experiments: lets other kernels share the sweep's CUs)
-#endif
-constexpr int ks_lds(int used) { return LAS_KS_SHARE_CU ? used : (used > 144 * 1024 ? used : 144 * 1024); }   // leaves 16 KB: nothing with an MFMA tile fits
-
 template <int CELL, int UT, int P, int RB = 16>
 struct KsCfg {
     using C = RnnCfg<CELL, UT, P>;
@@ -1782,14 +1782,15 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
         a.warm = warm ? 1 : 0;
         if (!bwd && RT == 1 && a.rb == 8) {
             if constexpr (HwCfg<CELL, UT, P, 8>::OK) {
-                constexpr int HL = HwCfg<CELL, UT, P, 8>::LDS;
+                constexpr int HL = ks_lds(HwCfg<CELL, UT, P, 8>::LDS);    // (the CU to itself, as for the K-split BPTT kernel: 67 KB used,
+                                                                          //  198 registers x 8 waves -- a 64 KB / 110-register GEMM workgroup fits next to it)
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
                 hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>), gridw, dim3(512), HL, st, a);
             }
         } else if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
             if constexpr (HwCfg<CELL, UT, P>::OK) {
-                constexpr int HL = HwCfg<CELL, UT, P>::LDS;
+                constexpr int HL = ks_lds(HwCfg<CELL, UT, P>::LDS);
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
                 hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 16>), gridw, dim3(512), HL, st, a);
