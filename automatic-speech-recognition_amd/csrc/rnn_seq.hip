@@ -634,7 +634,7 @@ __device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, 
 #ifndef LAS_KS_SHARE_CU
 #define LAS_KS_SHARE_CU 0        // 1: request only the LDS the kernel uses (timing experiments: lets other kernels share the sweep's CUs)
 #endif
-constexpr int ks_lds(int used) { return LAS_KS_SHARE_CU ? used : (used > 144 * 1024 ? used : 144 * 1024); }   // leaves 16 KB: nothing with an MFMA tile fits
+constexpr int ks_lds(int used) { return LAS_KS_SHARE_CU ? used : 159 * 1024; }   // all but 1 KB (the kernels have 256 B of static LDS): nothing that uses LDS fits next to the sweep
 
 template <int CELL, int UT, int P, int RB = 16>
 struct HwCfg {
@@ -1803,7 +1803,7 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
             if constexpr (P > 1 && KsCfg<CELL, UT, P>::OK) {
                 // The K-split kernel keeps its weights in registers and needs 9-17 KB of LDS and half of the register file: other
                 // kernels' workgroups (the side stream's weight-gradient GEMMs) WOULD be scheduled onto the same CU and share its
-                // SIMDs, LDS and L1 with the dependent chain.  Asking for (nearly) the whole LDS keeps the CU to the sweep.
+                // SIMDs, LDS and L1 with the dependent chain.  Asking for (nearly) the whole LDS keeps the CU to the sweep (ks_lds).
                 if (a.rb == 8 && a.dflag) {
                     constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 8>::DZ_BYTES);
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>, KZ);
