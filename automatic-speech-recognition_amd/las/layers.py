@@ -107,8 +107,7 @@ _DOUT_CHUNKS = {}     # data_ptr of a dense layer's dX that is still being produ
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
 XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
-DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "0"))         # backward hand-over in chunks of this many rows (a power of two); 0 = off:
-                                                                     # measured a wash on one GPU (DESIGN "Wavefront hand-over"), kept for other shapes
+DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
