@@ -420,14 +420,18 @@ __device__ __forceinline__ u16x8_t tr_frag(const unsigned char* tile, int col0, 
     return f;
 }
 
+// BM = 128: waves 2 x 2, wave tile 64 x 64.  BM = 64 (a first-layer dW_ih: 40 input features): waves 1 x 4, wave tile 64 x 32; the A
+// tile's columns beyond M (a multiple of 8) are neither read nor stored.
+template <int BM>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
-    constexpr int BM = 128, BN = 128;
+    constexpr int BN = 128, WN = BM == 128 ? 2 : 4, TNF = BM == 128 ? 4 : 2;
+    constexpr int APR = BM / 8, APASS = APR / 8, AROWS = 256 / APR;      // A staging: 16-byte pieces per k-row, passes, k-rows per pass
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (g.zgroup) {                                                  // all tiles of one k-chunk / batch entry on one XCD (see the fast kernel)
-        const int nx = g.N / BN, ny = g.M / BM, nt = nx * ny;
+        const int nx = g.N / BN, ny = (g.M + BM - 1) / BM, nt = nx * ny;
         const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
         bz = xcd + 8 * (li / nt);
         if (bz >= g.zgroup) return;
@@ -447,28 +451,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
         B += (long long)bz * g.strideB;
         C += (long long)bz * g.strideC;
     }
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][TNF];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // staging: piece p = tid + 256 u (u = 0, 1) is 16 bytes = 8 columns of k-row p >> 4
+    // staging: a piece is 16 bytes = 8 columns of one k-row; B: piece tid + 256 u (u = 0, 1) of k-row (tid >> 4) + 16 u;
+    // A: the same at BM = 128, one piece of k-row tid >> 3 at BM = 64
     const int pk = tid >> 4, pc = (tid & 15) * 8;
-    const unsigned short* pa = A + (long long)(kbeg + pk) * g.ksA + m0 + pc;
+    const int ak = tid / APR, ac = (tid % APR) * 8;
+    const unsigned short* pa = A + (long long)(kbeg + ak) * g.ksA + m0 + ac;
     const unsigned short* pb = B + (long long)(kbeg + pk) * g.ksB + n0 + pc;
-    const long long sa16 = 16 * g.ksA, sb16 = 16 * g.ksB, sa32 = 32 * g.ksA, sb32 = 32 * g.ksB;
-    const int so = pk * TR_PITCH + pc * 2;
-    u32x4_t ra[2], rb[2];
+    const long long saR = (long long)AROWS * g.ksA, sb16 = 16 * g.ksB, sa32 = 32 * g.ksA, sb32 = 32 * g.ksB;
+    const int so = pk * TR_PITCH + pc * 2, soa = ak * TR_PITCH + ac * 2;
+    u32x4_t ra[APASS], rb[2];
     const u32x4_t zero = {0u, 0u, 0u, 0u};
     auto gload = [&](int k0) __attribute__((always_inline)) {
+        // (default cache policy: non-temporal loads lose the L2 sharing between the tiles of a k-chunk -- 124 -> 155 us)
+#pragma unroll
+        for (int u = 0; u < APASS; ++u) {
+            const bool on = k0 + ak + AROWS * u < kend && (BM == 128 || ac < g.M);     // rows past the contraction range (and, at BM = 64,
+                                                                                       // columns past M: a multiple of 8) read as zero
+            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? pa + u * saR : A);
+            ra[u] = on ? va : zero;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bool on = k0 + pk + 16 * u < kend;                 // rows past the contraction range read as zero
-            // (default cache policy: non-temporal loads lose the L2 sharing between the tiles of a k-chunk -- 124 -> 155 us)
-            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? pa + u * sa16 : A);
+            const bool on = k0 + pk + 16 * u < kend;
             const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(on ? pb + u * sb16 : B);
-            ra[u] = on ? va : zero;
             rb[u] = on ? vb : zero;
         }
         pa += sa32; pb += sb32;
@@ -479,33 +490,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
         unsigned char* As = lds + buf * 2 * TR_TILE;
         unsigned char* Bs = As + TR_TILE;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<u32x4_t*>(As + so + u * 16 * TR_PITCH) = ra[u];
-            *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = rb[u];
-        }
+        for (int u = 0; u < APASS; ++u) *reinterpret_cast<u32x4_t*>(As + soa + u * AROWS * TR_PITCH) = ra[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = rb[u];
         __syncthreads();                       // tile visible; the other buffer is free (its readers passed the previous barrier)
         if (k0 + 32 < kend) gload(k0 + 32);
-        u16x8_t a[4], b[4];
+        u16x8_t a[4], b[TNF];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 64 + i * 16, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = tr_frag(Bs, wn * 64 + j * 16, lane);
+        for (int j = 0; j < TNF; ++j) b[j] = tr_frag(Bs, wn * (TNF * 16) + j * 16, lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < TNF; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
         buf ^= 1;
     }
     const bool has_bias = g.bias != nullptr, has_beta = g.beta != 0.f, do_tanh = g.act == LAS_ACT_TANH;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + (wn * 4 + j) * 16 + (lane & 15);
+        for (int j = 0; j < TNF; ++j) {
+            const int col = n0 + (wn * TNF + j) * 16 + (lane & 15);
             const float bcol = has_bias ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + (wm * 4 + i) * 16 + (lane >> 4) * 4 + r;
+                if (BM == 64 && row >= g.M) continue;
                 if (g.splitk > 1) {
                     g.partial[((long long)bz * g.M + row) * g.N + col] = acc[i][j][r];
                 } else {
@@ -725,11 +736,23 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
             "las_gemm: bf16 operands are served by the branch-free path only (aligned pitches, K / row counts multiples of 4, no mask)");
     if (g.in_bf16 && cfg == 3) { cfg = 2; BM = 64; BN = 64; }
     // weight-gradient form (both operands k-strided bf16, whole 128 x 128 tiles, 16-byte aligned rows): LDS-transposing kernel
-    const bool tn_tr = g_tn_tr_on && fast_ok && cfg == 1 && g.in_bf16 && g.ksA != 1 && g.ksB != 1 && M % 128 == 0 && N % 128 == 0 &&
-                       lda % 8 == 0 && ldb % 8 == 0 && strideA % 8 == 0 && strideB % 8 == 0 &&
-                       (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+    const bool tn_al = g_tn_tr_on && fast_ok && g.in_bf16 && g.ksA != 1 && g.ksB != 1 && N % 128 == 0 &&
+                       lda % 8 == 0 && ldb % 8 == 0 && strideA % 8 == 0 && strideB % 8 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+    const bool tn_tr = tn_al && cfg == 1 && M % 128 == 0;
+    const bool tn_tr64 = tn_al && cfg == 2 && M <= 64 && M % 8 == 0 && batch == 1;     // (a first layer's dW_ih; one row block)
     if (fast_ok && (cfg == 1 || cfg == 2)) {
-        if (tn_tr) {
+        if (tn_tr64) {
+            const int nx = N / 128;
+            GemmArgs gz = g;
+            gz.zgroup = 0;
+            dim3 grid(nx, 1, zdim);
+            if (zdim > 1 && nx <= 64 && g_zgroup_on) {
+                gz.zgroup = zdim;
+                grid = dim3(nx * ((zdim + 7) / 8 * 8), 1, 1);
+            }
+            hipLaunchKernelGGL(gemm_tn_tr_kernel<64>, grid, dim3(256), 0, st, gz);
+        }
+        else if (tn_tr) {
             const int nx = N / 128, ny = M / 128;
             GemmArgs gz = g;
             gz.zgroup = 0;
@@ -738,7 +761,7 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
                 gz.zgroup = zdim;
                 grid = dim3(nx * ny * ((zdim + 7) / 8 * 8), 1, 1);
             }
-            hipLaunchKernelGGL(gemm_tn_tr_kernel, grid, dim3(256), 0, st, gz);
+            hipLaunchKernelGGL(gemm_tn_tr_kernel<128>, grid, dim3(256), 0, st, gz);
         }
         else if (cfg == 1) launch_fast<2, 2, 4, 4>(g, zdim, st);
         else          launch_fast<2, 2, 2, 2>(g, zdim, st);

@@ -151,10 +151,11 @@ def test_colsum_paths(rows, cols, dt):
     assert (out.cpu().double() - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K,batch", [(256, 384, 5000, 1), (512, 1024, 20011, 1), (128, 128, 31, 1), (256, 256, 300, 5)])
+@pytest.mark.parametrize("M,N,K,batch", [(256, 384, 5000, 1), (512, 1024, 20011, 1), (128, 128, 31, 1), (256, 256, 300, 5),
+                                         (40, 256, 9001, 1), (64, 1024, 4100, 1)])      # last two: the 64-row variant (first-layer dW_ih)
 def test_weight_gradient_form_bf16_tn(M, N, K, batch):
     """las_gemm with bf16 operands that are both k-strided (dW = X^T . dZ): served by gemm_tn_tr_kernel ([k][m] LDS tiles read
-    with ds_read_b64_tr_b16) when M, N are multiples of 128 -- split-K, a contraction length that is no multiple of 32, element
+    with ds_read_b64_tr_b16) when M, N are multiples of 128 (or M <= 64, a multiple of 8) -- split-K, a contraction length that is no multiple of 32, element
     offsets into wider tensors, batched with strides, beta = 1 accumulation; against float64 on the same bf16 values, and against
     the register-transposing kernel it replaced (las_dev_gemm_tn_tr(0))."""
     from las import _hip
