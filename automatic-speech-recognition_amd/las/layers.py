@@ -506,7 +506,8 @@ class _BLSTM16(torch.autograd.Function):
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
         ctx.cfg = (cell, H, Tp, I0)
         ctx.params = _PARAMS.get("blstm")
-        ctx.hold_side = bool(_PARAMS.get("hold_side")) and HOLD_SIDE
+        ctx.in_pyramid = bool(_PARAMS.get("hold_side"))      # built by pBLSTMLayer on top of (recurrent layer -> dense + tanh)
+        ctx.hold_side = ctx.in_pyramid and HOLD_SIDE
         # the input IS the (unpadded) tanh output of the dense layer below: its gradient can leave this node as dPre
         ctx.x_is_tanh = FUSE_TANH_GRAD and not two and I0 == Ik and _TANH_OUT.pop(x.data_ptr(), None) is not None
         return out
@@ -547,8 +548,10 @@ class _BLSTM16(torch.autograd.Function):
             Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
             c = DOUT_CHUNK_ROWS
-            if ctx.x_is_tanh and c and T >= 4 * c and direct and _hip.streams_overlap(dev):
-                # first time chunk only; the dense node below (the consumer of this dPre) interleaves the others with its own
+            if ctx.x_is_tanh and ctx.in_pyramid and c and T >= 4 * c and direct and _hip.streams_overlap(dev):
+                # first time chunk only; the dense node below (the consumer of this dPre) interleaves the others with its own.
+                # (Only inside pBLSTMLayer's stack, where that dense node's input gradient goes to the recurrent layer below and
+                #  nowhere else: a consumer that does not know about the chunks would read an unfinished tensor.)
                 th = (T + 1) // 2
 
                 def produce(k):
