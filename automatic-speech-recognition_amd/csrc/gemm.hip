@@ -530,9 +530,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
 }
 
 static bool g_tn_tr_on = true;
+#ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_tn_tr(int on) { g_tn_tr_on = on != 0; }       // development switch (A/B measurements)
+#endif
 static bool g_zgroup_on = true;
+#ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_zgroup(int on) { g_zgroup_on = on != 0; }     // development switch (A/B measurements)
+#endif
 
 template <int WM, int WN, int TM, int TN, typename TI>
 static void launch_fast_t(const GemmArgs& g, int zdim, hipStream_t st) {

@@ -178,7 +178,9 @@ extern "C" int las_gemm_kk(int M, int N, int K, const void* A, long long lda, co
 static int gemm_kk_impl(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C, int c_dtype, long long ldc,
                         const float* bias, int act, const void* y, long long ldy, int fT, int lo0, int nlo, int hi0, int nhi, void* stream);
 static bool g_kk_big = true;
+#ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_kk_big(int on) { g_kk_big = on != 0; }        // development switch (A/B measurements)
+#endif
 
 extern "C" int las_gemm_kk_tanhgrad(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                                     void* C, int c_dtype, long long ldc, const float* bias, int act, const void* y, long long ldy, void* stream) {

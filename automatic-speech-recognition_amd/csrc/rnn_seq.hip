@@ -740,7 +740,11 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             for (;;) {
                 have = __hip_atomic_load(a.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (have >= need) break;
-                if (--budget <= 0) { if (a.status) a.status[0] = a.status_code; break; }
+                if (--budget <= 0) {                   // the step is invalid from here on: report once, never wait again
+                    if (a.status) a.status[0] = a.status_code;
+                    have = 0x7fffffff;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(16);
             }
         };
@@ -1360,7 +1364,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         for (;;) {
             dhave = __hip_atomic_load(a.dflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             if (dhave >= need) break;
-            if (--budget <= 0) { errflag = 1; break; }
+            if (--budget <= 0) { errflag = 1; dhave = 0x7fffffff; break; }      // sticky: later waits return at once
             __builtin_amdgcn_s_sleep(16);
         }
     };

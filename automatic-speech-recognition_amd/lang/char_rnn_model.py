@@ -172,41 +172,44 @@ class CharRNN(object):
             wss = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
             _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(wss), wss.numel(), _hip.stream()), "las_sumsq")
             _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n, _hip.p(sumsq),
-                                         self.max_grad_norm, lr_t, b1, b2, eps, _hip.stream()), "las_clip_adam")
+                                         self.max_grad_norm, lr_t, b1, b2, eps, None, None, _hip.stream()), "las_clip_adam")
             st.shadows.clear()
             self.global_step += 1
         return mean_loss, new_state
 
     def run_epoch(self, session, data_size, batch_generator, is_training, verbose=0, freq=10, summary_writer=None, debug=False,
                   divide_by_n=1):
-        """One full pass over the data (reference lang/char_rnn_model.py:195-244).  Returns (ppl, summary, global_step)."""
-        epoch_size = data_size // (self.batch_size * self.num_unrollings)
-        if data_size % (self.batch_size * self.num_unrollings) != 0:
-            epoch_size += 1
+        """One pass over `data_size` characters (the reference's epoch driver, lang/char_rnn_model.py:195-244: same signature and
+        return value).  Returns (perplexity of the mean batch loss, None, global_step).  The per-batch losses stay on the device and
+        are read back once per progress report / once at the end, so the loop never waits for a step."""
+        per_batch = self.batch_size * self.num_unrollings
+        n_batches = -(-data_size // per_batch) // divide_by_n
         if verbose > 0:
-            logging.info('epoch_size: %d', epoch_size)
+            logging.info('epoch_size: %d', -(-data_size // per_batch))
             logging.info('data_size: %d', data_size)
             logging.info('num_unrollings: %d', self.num_unrollings)
             logging.info('batch_size: %d', self.batch_size)
-        state = None
-        self._sum_mean_loss, self._count = 0.0, 0.0                 # reset_loss_monitor
-        start_time = time.time()
-        ppl, step = float("nan"), -1
-        for step in range(epoch_size // divide_by_n):
-            data = batch_generator.next()                           # [:-1] are the inputs, [1:] the targets
-            inputs = np.array(data[:-1]).transpose()
-            targets = np.array(data[1:]).transpose()
-            mean_loss, state = self.train_step(inputs, targets, state, train=is_training)
-            self._sum_mean_loss += float(mean_loss)
-            self._count += 1
-            average_loss = self._sum_mean_loss / self._count
-            ppl = np.exp(average_loss)
-            if (verbose > 0) and ((step + 1) % freq == 0):
-                logging.info("%.1f%%, step:%d, perplexity: %.3f, speed: %.0f words",
-                             (step + 1) * 1.0 / epoch_size * 100, step, ppl,
-                             (step + 1) * self.batch_size * self.num_unrollings / (time.time() - start_time))
-        logging.info("Perplexity: %.3f, speed: %.0f words per sec",
-                     ppl, (step + 1) * self.batch_size * self.num_unrollings / (time.time() - start_time))
+        t0 = time.time()
+        losses, state = [], None
+        self._sum_mean_loss, self._count = 0.0, 0.0
+
+        def perplexity():
+            self._sum_mean_loss = float(torch.stack(losses).sum()) if losses else 0.0
+            self._count = float(len(losses))
+            return float(np.exp(self._sum_mean_loss / self._count)) if losses else float("nan")
+
+        def rate():
+            return len(losses) * per_batch / max(time.time() - t0, 1e-9)
+
+        for k in range(n_batches):
+            ids = batch_generator.next_ids()                            # [U + 1, B]: row u + 1 is the target of row u
+            loss, state = self.train_step(ids[:-1].T, ids[1:].T, state, train=is_training)
+            losses.append(loss.detach())
+            if verbose > 0 and (k + 1) % freq == 0:
+                logging.info("%.1f%%, step:%d, perplexity: %.3f, speed: %.0f words", 100.0 * (k + 1) / max(n_batches * divide_by_n, 1), k,
+                             perplexity(), rate())
+        ppl = perplexity()
+        logging.info("Perplexity: %.3f, speed: %.0f words per sec", ppl, rate())
         return ppl, None, self.global_step
 
     def zero_state(self, n=1):
@@ -307,54 +310,58 @@ class CharRNN(object):
 
 
 class BatchGenerator(object):
-    """Generate and hold batches (reference lang/char_rnn_model.py:285-321): `batch_size` cursors spread evenly over the
-    text; next() returns the last batch of the previous call followed by `n_unrollings` new ones."""
+    """The reference's batch iterator (lang/char_rnn_model.py:285-321; behaviour pinned by golden G7): `batch_size` read cursors
+    start evenly spaced over the text and advance together, wrapping at the end; `next()` returns `n_unrollings + 1` id vectors
+    -- the last vector of the previous call followed by `n_unrollings` new ones -- each a float64 array of `batch_size` ids.
+
+    Here the text is encoded ONCE into an id array and a call is one fancy-indexing gather of a [n_unrollings, batch_size] block
+    (the reference encodes one character at a time); `next_ids()` is the same block as one int64 array for the trainer."""
 
     def __init__(self, text, batch_size, n_unrollings, vocab_size, vocab_index_dict, index_vocab_dict):
-        self._text = text
-        self._text_size = len(text)
-        self._batch_size = batch_size
         self.vocab_size = vocab_size
-        self._n_unrollings = n_unrollings
-        self.vocab_index_dict = vocab_index_dict
-        self.index_vocab_dict = index_vocab_dict
-        segment = self._text_size // batch_size
-        self._cursor = [offset * segment for offset in range(batch_size)]
-        self._last_batch = self._next_batch()
+        self.vocab_index_dict, self.index_vocab_dict = vocab_index_dict, index_vocab_dict
+        self._ids = encode_text(text, vocab_index_dict)
+        self._n, self._rows = len(text), int(n_unrollings)
+        self._pos = (len(text) // batch_size) * np.arange(batch_size, dtype=np.int64)      # cursor of every stream
+        self._tail = self._take(1)[0]
 
-    def _next_batch(self):
-        batch = np.zeros(shape=(self._batch_size), dtype=np.float64)
-        for b in range(self._batch_size):
-            batch[b] = char2id(self._text[self._cursor[b]], self.vocab_index_dict)
-            self._cursor[b] = (self._cursor[b] + 1) % self._text_size
-        return batch
+    def _take(self, rows):
+        idx = (self._pos[None, :] + np.arange(rows, dtype=np.int64)[:, None]) % self._n
+        self._pos = (self._pos + rows) % self._n
+        return self._ids[idx]
+
+    def next_ids(self):
+        block = np.concatenate([self._tail[None, :], self._take(self._rows)], 0)
+        self._tail = block[-1]
+        return block
 
     def next(self):
-        batches = [self._last_batch]
-        for step in range(self._n_unrollings):
-            batches.append(self._next_batch())
-        self._last_batch = batches[-1]
-        return batches
+        return list(self.next_ids().astype(np.float64))
+
+
+def encode_text(text, vocab_index_dict):
+    """ids of a string as an int64 array; characters outside the vocabulary are logged and mapped to id 0 (the reference's
+    `char2id`, lang/char_rnn_model.py:367-372)."""
+    table = np.zeros(max(0x110000 if any(ord(c) > 0xFFFF for c in vocab_index_dict) else 0x10000, 1), np.int64)
+    known = np.zeros(table.shape[0], bool)
+    for c, i in vocab_index_dict.items():
+        table[ord(c)], known[ord(c)] = i, True
+    cps = np.frombuffer(text.encode("utf-32-le"), dtype=np.uint32).astype(np.int64)
+    cps = np.minimum(cps, table.shape[0] - 1)            # (beyond the table: certainly not in the vocabulary)
+    for cp in np.unique(cps[~known[cps]]):
+        logging.info('Unexpected char %s', chr(int(cp)))
+    return table[cps]
 
 
 def char2id(char, vocab_index_dict):
-    try:
-        return vocab_index_dict[char]
-    except KeyError:
-        logging.info('Unexpected char %s', char)
-        return 0
+    return int(encode_text(char, vocab_index_dict)[0])
 
 
 def id2char(index, index_vocab_dict):
     return index_vocab_dict[index]
 
 
-def id2char_list(lst, index_vocab_dict):
-    return [id2char(i, index_vocab_dict) for i in lst]
-
-
 def batches2string(batches, index_vocab_dict):
-    s = [''] * batches[0].shape[0]
-    for b in batches:
-        s = [''.join(x) for x in zip(s, id2char_list(b, index_vocab_dict))]
-    return s
+    """the `batch_size` strings spelled by a list of id vectors (debug print of the reference's trainer)"""
+    block = np.stack([np.asarray(b) for b in batches], 1).astype(np.int64)                 # [batch_size, len]
+    return [''.join(index_vocab_dict[int(i)] for i in row) for row in block]

@@ -97,7 +97,7 @@ _SIGS = {
     "las_sumsq_workspace_bytes": (c_size_t, [c_longlong]),
     "las_sumsq": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
-                              c_float, c_float, c_float, c_void_p]),
+                              c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_set_word": (c_int, [c_void_p, c_int, c_void_p]),
@@ -141,7 +141,7 @@ def lib():
             fn.argtypes = args
         if missing and not os.environ.get("LAS_ALLOW_PARTIAL"):
             raise RuntimeError("liblas_hip.so does not export: %s" % ", ".join(missing))
-        # development switches (A/B measurements): LAS_DEV_KK_BIG=0 -> 128 x 128 tiles only in las_gemm_kk;
+        # development switches (A/B measurements, `make prof` builds only -- the shipping library does not export them): LAS_DEV_KK_BIG=0 -> 128 x 128 tiles only in las_gemm_kk;
         # LAS_DEV_ZGROUP=0 -> 3-D grid order for split-K / batched las_gemm; LAS_DEV_TN_TR=0 -> weight gradients through the
         # register-transposing kernel instead of the LDS-transposing one
         for env, sym in (("LAS_DEV_KK_BIG", "las_dev_gemm_kk_big"), ("LAS_DEV_ZGROUP", "las_dev_gemm_zgroup"),
@@ -307,7 +307,9 @@ def join_side_stream():
 
 
 def _tag(t):
-    return t + "_side" if _on_side else t
+    """scratch is per STREAM (split-K partials, column-sum partials): launches of two streams may overlap"""
+    sid = torch.cuda.current_stream().stream_id
+    return t if sid == 0 else "%s_s%d" % (t, sid)
 
 
 def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=None, ldb=None, ldc=None,
@@ -492,27 +494,32 @@ _overlap = {}
 
 
 def streams_overlap(dev):
-    """True if kernels of two streams really run concurrently on this device (probed once): a bounded waiter on the current stream,
-    then the store it waits for on the side stream.  Under a tool that serialises kernels (rocprofv3 --pmc) the waiter runs into
-    its bound; the cross-stream hand-overs (x-projection chunks, held side stream) are then switched off."""
+    """True if kernels of the launch stream and of BOTH auxiliary streams (side: x-projection chunks, held weight gradients;
+    chain: the backward hand-over's chunks) really run concurrently on this device (probed once per stream): a bounded waiter on
+    the current stream, then the store it waits for on the other stream.  Under a tool that serialises kernels (rocprofv3
+    --pmc), or when two streams share one hardware queue, the waiter runs into its bound; the cross-stream hand-overs are then
+    switched off."""
     key = str(dev)
     if key not in _overlap:
-        flag = torch.zeros(2, dtype=torch.int32, device=dev)
-        with torch.cuda.stream(side_stream()):                    # (the side stream's first launch creates its hardware queue)
-            check(lib().las_set_word(p(flag[1:]), 1, stream()), "las_set_word")
-        best = 1e9
-        for _ in range(2):
-            flag[0:1].zero_()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            check(lib().las_wait_word(p(flag), 1, 4000, stream()), "las_wait_word")
-            e1.record()
-            with torch.cuda.stream(side_stream()):
-                check(lib().las_set_word(p(flag), 1, stream()), "las_set_word")
-            torch.cuda.synchronize(dev)
-            best = min(best, e0.elapsed_time(e1))
-        _overlap[key] = best < 2.0
+        ok = True
+        for other in (side_stream(), chain_stream()):
+            flag = torch.zeros(2, dtype=torch.int32, device=dev)
+            with torch.cuda.stream(other):                            # (a stream's first launch creates its hardware queue)
+                check(lib().las_set_word(p(flag[1:]), 1, stream()), "las_set_word")
+            best = 1e9
+            for _ in range(2):
+                flag[0:1].zero_()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib().las_wait_word(p(flag), 1, 4000, stream()), "las_wait_word")
+                e1.record()
+                with torch.cuda.stream(other):
+                    check(lib().las_set_word(p(flag), 1, stream()), "las_set_word")
+                torch.cuda.synchronize(dev)
+                best = min(best, e0.elapsed_time(e1))
+            ok = ok and best < 2.0
+        _overlap[key] = ok
     return _overlap[key]
 
 
@@ -530,6 +537,7 @@ def check_status(dev=None):
         code = int(t[0].item())
         if code:
             t.zero_()
+            _probe.pop(key, None)                  # (a probe of the same word may still be in flight: it reports nothing new)
             raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s -- the cluster workgroups were not "
                                "all resident (shared / partitioned GPU?); results of that step are invalid"
                                % (key, code, SEQ_STATUS.get(code, "unknown")))

@@ -612,8 +612,12 @@ class LAS:
         with _hip.roctx_range("backward"):
             loss.backward()
             _hip.join_side_stream()                   # weight gradients accumulated on the side stream
+            L.check_handovers_consumed()
         if self.dp is not None:
-            self.dp.all_reduce_(st.flat_grad)                                             # one flat bucket (C1)
+            # one flat bucket (C1); its last slot carries this rank's sweep status, so that a time-out on ANY rank makes EVERY
+            # rank skip the update (las_clip_adam's guard) and the replicas stay identical
+            st.guard.copy_(_hip.status_word(dev)[0:1].ne(0))
+            self.dp.all_reduce_(st.grad_bucket)
             loss_val = self.dp.all_reduce_scalar(loss.detach())
         else:
             loss_val = loss.detach()
@@ -642,7 +646,8 @@ class LAS:
             ws = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
             _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(ws), ws.numel(), _hip.stream()), "las_sumsq")
         _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n,
-                                     _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps, _hip.stream()),
+                                     _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps,
+                                     _hip.p(_hip.status_word(dev)), _hip.p(st.guard), _hip.stream()),
                    "las_clip_adam")
         st.shadows.clear()                            # bf16 weight shadows are rebuilt from the updated masters
         self.last_grad_sumsq = sumsq

@@ -100,6 +100,9 @@ class _Dense(torch.autograd.Function):
 _TANH_OUT = {}        # data_ptr -> bf16 output of a dense+tanh layer (speed mode): a recurrent layer that reads exactly this tensor
                       # fuses the Tanh gradient into its dX product (las_gemm_kk_tanhgrad) and hands dPre, not dY, to the dense node
 _DPRE = set()         # data_ptr of gradients that already ARE d(pre-activation) of the dense layer they flow into
+_EXPECT_DPRE = set()  # data_ptr of dense+tanh outputs whose consumer promised to hand back dPre (checked in _Dense16.backward: a
+                      # gradient that arrives there by any other route -- accumulation from a second consumer, a hook, retain_grad --
+                      # would get 1 - y^2 applied twice without this check)
 _DCHUNK = {}          # data_ptr of a dPre whose producer (a recurrent layer's dX product) has only run its first time chunk:
                       # (chunk rows, rows per utterance, chunks, fn(k), holder) -- the dense node below runs fn(k) interleaved with its
                       # own chunks and puts the event behind the last one into `holder`
@@ -118,6 +121,17 @@ def _direct_ok(p):
     """True when p is a flattened leaf parameter whose .grad is a view of the flat gradient bucket."""
     return (DIRECT_GRADS and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
             and V.default_store().flat_grad is not None and p.grad.is_contiguous())
+
+
+def check_handovers_consumed():
+    """Called when a backward pass is complete (LAS.train): every chunked hand-over registered by a producer must have been
+    taken by its consumer -- a left-over entry means some node read a tensor whose later chunks were never computed."""
+    left = [n for n, r in (("_DCHUNK", _DCHUNK), ("_DOUT_CHUNKS", _DOUT_CHUNKS)) if r]
+    if left:
+        _DCHUNK.clear()
+        _DOUT_CHUNKS.clear()
+        raise RuntimeError("las.layers: chunked gradient hand-over left unconsumed (%s): the autograd graph between two recurrent "
+                           "layers is not the pBLSTMLayer stack -- set LAS_DOUT_CHUNK=0 for such graphs" % ", ".join(left))
 
 
 def dense(x, W, b=None, tanh=False, out_f32=True):
@@ -354,7 +368,12 @@ class _Dense16(torch.autograd.Function):
         M, K = x2d.shape
         Kw, N = W.shape
         dy = dy.contiguous()
-        if ctx.act and dy.dtype == torch.bfloat16 and dy.data_ptr() in _DPRE:
+        if ctx.act and y.data_ptr() in _EXPECT_DPRE:
+            _EXPECT_DPRE.discard(y.data_ptr())
+            if not (dy.dtype == torch.bfloat16 and dy.data_ptr() in _DPRE):
+                raise RuntimeError("las.layers: the recurrent layer that consumed this dense+tanh output fused the Tanh gradient into "
+                                   "its dX product, but the gradient arriving here is not that tensor (a second consumer, a tensor "
+                                   "hook or retain_grad on the activation?) -- set LAS_NO_FUSE_TANH_GRAD=1 for such graphs")
             _DPRE.discard(dy.data_ptr())               # the consumer's dX product already applied 1 - y^2
             dpre = dy
         elif ctx.act:
@@ -511,6 +530,8 @@ class _BLSTM16(torch.autograd.Function):
         ctx.hold_side = ctx.in_pyramid and HOLD_SIDE
         # the input IS the (unpadded) tanh output of the dense layer below: its gradient can leave this node as dPre
         ctx.x_is_tanh = FUSE_TANH_GRAD and not two and I0 == Ik and _TANH_OUT.pop(x.data_ptr(), None) is not None
+        if ctx.x_is_tanh:
+            _EXPECT_DPRE.add(x.data_ptr())
         return out
 
     @staticmethod
@@ -707,6 +728,7 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     sc = scope + "/blstm"
     _TANH_OUT.clear()
     _DPRE.clear()
+    _EXPECT_DPRE.clear()
     _DCHUNK.clear()
     _DOUT_CHUNKS.clear()
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)

@@ -25,7 +25,7 @@ class VariableStore:
         self.buffers = {}         # name -> tensor (non-trainable state: batch-norm moving statistics)
         self.order = []           # creation order
         self.rng = np.random.RandomState(seed)
-        self.flat = self.flat_grad = self.adam_m = self.adam_v = None
+        self.flat = self.flat_grad = self.adam_m = self.adam_v = self.grad_bucket = self.guard = None
         self.global_step = 0
         self.shadows = {}         # bf16 copies of weights for the speed-mode products (las.layers._shadow); cleared when weights change
         self.shadow_recipes = {}  # key -> (tensor, ShadowDesc): how to rebuild every shadow in ONE launch (cleared when storage moves)
@@ -109,7 +109,11 @@ class VariableStore:
         total = max(o, 4)
         dev = self.vars[names[0]].device if names else self.device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros_like(self.flat)
+        # the gradient bucket carries ONE extra slot behind the gradients (4 floats, keeps 16-byte granularity): the data-parallel
+        # exchange all-reduces `grad_bucket`, so a rank whose sweep timed out tells every rank to skip the update (guard != 0)
+        self.grad_bucket = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        self.flat_grad = self.grad_bucket[:total]
+        self.guard = self.grad_bucket[total:total + 1]
         self.adam_m = torch.zeros_like(self.flat)
         self.adam_v = torch.zeros_like(self.flat)
         self.offsets = dict(zip(names, offs))
@@ -124,7 +128,7 @@ class VariableStore:
 
     def zero_grad(self):
         if self.flat_grad is not None:
-            self.flat_grad.zero_()
+            self.grad_bucket.zero_()
             for n in self.order:                     # autograd may have replaced .grad
                 off, v = self.offsets[n], self.vars[n]
                 g = self.flat_grad[off:off + v.numel()].view(v.shape)

@@ -96,140 +96,148 @@ def save_vocab(vocab_index_dict, vocab_file, encoding):
         json.dump(vocab_index_dict, f, indent=2, sort_keys=True)
 
 
-def _save(store, prefix, step, keep=None):
-    import glob
-    import torch
-    path = "%s-%d" % (prefix, step)
-    torch.save(store.state_dict(), path)
-    if keep:
-        old = sorted(glob.glob(prefix + "-*"), key=lambda q: int(q.rsplit("-", 1)[1]))
-        for q in old[:-keep]:
-            os.remove(q)
-    return path
+class Corpus:
+    """The cleaned text cut into its train / validation / test parts (fractions --train_frac / --valid_frac, the rest is the test
+    part) with one batch iterator per part."""
+
+    def __init__(self, text, train_frac, valid_frac, vocab):
+        from lang.char_rnn_model import BatchGenerator
+        self.vocab = vocab
+        n = len(text)
+        cut = [0, int(train_frac * n), int(train_frac * n) + int(valid_frac * n), n]
+        self.parts = {name: text[cut[k]:cut[k + 1]] for k, name in enumerate(("train", "valid", "test"))}
+        self._make = lambda part, B, U: BatchGenerator(self.parts[part], B, U, vocab[2], vocab[0], vocab[1])
+
+    def size(self, part):
+        return len(self.parts[part])
+
+    def batches(self, part, batch_size, unroll):
+        return self._make(part, batch_size, unroll)
+
+
+class RunDir:
+    """What a run leaves under --output_dir (the artefacts decode.py and a later --init_dir run read): vocab.json, result.json
+    and the rotating `lang/save_model/model-<step>` / best `lang/best_model/model-<step>` checkpoints."""
+
+    def __init__(self, root, resume, keep):
+        self.root, self.keep = root, keep
+        self.latest_prefix = os.path.join(root, 'lang/save_model/model')
+        self.best_prefix = os.path.join(root, 'lang/best_model/model')
+        self.record = {}
+        if resume:
+            with open(self.path('result.json')) as f:
+                self.record = json.load(f)
+        else:
+            if os.path.exists(root):
+                shutil.rmtree(root)
+            for prefix in (self.latest_prefix, self.best_prefix):
+                os.makedirs(os.path.dirname(prefix))
+
+    def path(self, name):
+        return os.path.join(self.root, name)
+
+    def checkpoint(self, store, step, best=False):
+        import glob
+        import torch
+        prefix = self.best_prefix if best else self.latest_prefix
+        target = "%s-%d" % (prefix, step)
+        torch.save(store.state_dict(), target)
+        if not best and self.keep:
+            by_step = sorted(glob.glob(prefix + "-*"), key=lambda q: int(q.rsplit("-", 1)[1]))
+            for stale in by_step[:-self.keep]:
+                os.remove(stale)
+        return target
+
+    def write(self, **fields):
+        self.record.update(fields)
+        with open(self.path('result.json'), 'w') as f:
+            json.dump(self.record, f, indent=2, sort_keys=True)
+
+
+HYPER = ('batch_size', 'num_unrollings', 'hidden_size', 'max_grad_norm', 'embedding_size', 'num_layers', 'learning_rate', 'model',
+         'dropout', 'input_dropout')
 
 
 def main(argv=None):
     import torch
-    from lang.char_rnn_model import BatchGenerator, CharRNN, batches2string
+    from lang.char_rnn_model import CharRNN, batches2string
     from las import layers, variables
     args = build_parser().parse_args(argv)
-    args.save_model = os.path.join(args.output_dir, 'lang/save_model/model')
-    args.save_best_model = os.path.join(args.output_dir, 'lang/best_model/model')
-    args.vocab_file = ''
-    if args.init_dir:
-        args.output_dir = args.init_dir
+    resume = bool(args.init_dir)
+    run = RunDir(args.init_dir or args.output_dir, resume, args.max_to_keep)
+    log_file = run.path('experiment_log.txt') if args.log_to_file else 'stdout'
+    logging.basicConfig(format='%(asctime)s %(levelname)s:%(message)s', level=logging.INFO, datefmt='%I:%M:%S',
+                        **({'stream': sys.stdout} if log_file == 'stdout' else {'filename': log_file}))
+    print('=' * 60 + '\nAll final and intermediate outputs will be stored in %s/\nAll information will be logged to %s\n'
+          % (run.root, log_file) + '=' * 60 + '\n')
+    # ---- hyper-parameters, best-so-far and vocabulary: from the command line, or from the run that is being continued
+    if resume:
+        hyper = dict(run.record['params'])
+        init_model, best_model, best_ppl = run.record['latest_model'], run.record['best_model'], run.record['best_valid_ppl']
+        encoding = run.record.get('encoding', 'utf-8')
+        vocab = load_vocab(run.path('vocab.json'), encoding)
     else:
-        if os.path.exists(args.output_dir):
-            shutil.rmtree(args.output_dir)
-        for paths in [args.save_model, args.save_best_model]:
-            os.makedirs(os.path.dirname(paths))
-    args.log_file = os.path.join(args.output_dir, 'experiment_log.txt') if args.log_to_file else 'stdout'
-    kw = dict(format='%(asctime)s %(levelname)s:%(message)s', level=logging.INFO, datefmt='%I:%M:%S')
-    logging.basicConfig(**(dict(stream=sys.stdout) if args.log_file == 'stdout' else dict(filename=args.log_file)), **kw)
-    print('=' * 60)
-    print('All final and intermediate outputs will be stored in %s/' % args.output_dir)
-    print('All information will be logged to %s' % args.log_file)
-    print('=' * 60 + '\n')
-    if args.init_dir:
-        with open(os.path.join(args.init_dir, 'result.json'), 'r') as f:
-            result = json.load(f)
-        params = result['params']
-        args.init_model = result['latest_model']
-        best_model = result['best_model']
-        best_valid_ppl = result['best_valid_ppl']
-        args.encoding = result.get('encoding', 'utf-8')
-        args.vocab_file = os.path.join(args.init_dir, 'vocab.json')
-    else:
-        params = {'batch_size': args.batch_size, 'num_unrollings': args.num_unrollings, 'hidden_size': args.hidden_size,
-                  'max_grad_norm': args.max_grad_norm, 'embedding_size': args.embedding_size, 'num_layers': args.num_layers,
-                  'learning_rate': args.learning_rate, 'model': args.model, 'dropout': args.dropout,
-                  'input_dropout': args.input_dropout}
-        best_model = ''
-        best_valid_ppl = args.best_valid_ppl
-    logging.info('Parameters are:\n%s\n', json.dumps(params, sort_keys=True, indent=4))
+        hyper = {k: getattr(args, k) for k in HYPER}
+        init_model, best_model, best_ppl, encoding = args.init_model, args.best_model, args.best_valid_ppl, args.encoding
+        vocab = create_vocab()
+        save_vocab(vocab[0], run.path('vocab.json'), encoding)
+        logging.info('Vocabulary is saved in %s', run.path('vocab.json'))
+    hyper['vocab_size'] = vocab[2]
+    logging.info('Parameters are:\n%s\n', json.dumps(hyper, sort_keys=True, indent=4))
     logging.info('Reading data from: %s', args.data_file)
-    with codecs.open(args.data_file, 'r', encoding=args.encoding) as f:
-        text_origin = f.read()
-    text = text_cleaning(text_origin, save_path=os.path.join(args.output_dir, "libri_cleaned.txt"))
+    with codecs.open(args.data_file, 'r', encoding=encoding) as f:
+        text = text_cleaning(f.read(), save_path=run.path("libri_cleaned.txt"))
     if args.test:
         text = text[:1000]
     logging.info('Number of characters: %s', len(text))
-    logging.info('Creating train, valid, test split')
-    train_size = int(args.train_frac * len(text))
-    valid_size = int(args.valid_frac * len(text))
-    test_size = len(text) - train_size - valid_size
-    train_text = text[:train_size]
-    valid_text = text[train_size:train_size + valid_size]
-    test_text = text[train_size + valid_size:]
-    if args.vocab_file:
-        vocab_index_dict, index_vocab_dict, vocab_size = load_vocab(args.vocab_file, args.encoding)
-    else:
-        logging.info('Creating vocabulary')
-        vocab_index_dict, index_vocab_dict, vocab_size = create_vocab()
-        vocab_file = os.path.join(args.output_dir, 'vocab.json')
-        save_vocab(vocab_index_dict, vocab_file, args.encoding)
-        logging.info('Vocabulary is saved in %s', vocab_file)
-        args.vocab_file = vocab_file
-    params['vocab_size'] = vocab_size
-    logging.info('Vocab size: %d', vocab_size)
-    batch_size, num_unrollings = params['batch_size'], params['num_unrollings']
-    train_batches = BatchGenerator(train_text, batch_size, num_unrollings, vocab_size, vocab_index_dict, index_vocab_dict)
-    valid_batches = BatchGenerator(valid_text, batch_size, num_unrollings, vocab_size, vocab_index_dict, index_vocab_dict)
-    test_batches = BatchGenerator(test_text, 1, 1, vocab_size, vocab_index_dict, index_vocab_dict)
+    corpus = Corpus(text, args.train_frac, args.valid_frac, vocab)
+    logging.info('Vocab size: %d', vocab[2])
+    B, U = hyper['batch_size'], hyper['num_unrollings']
+    feeds = {"train": corpus.batches("train", B, U), "valid": corpus.batches("valid", B, U), "test": corpus.batches("test", 1, 1)}
     if args.debug:
-        logging.info(batches2string(train_batches.next(), index_vocab_dict))
-    logging.info('Creating graph')
+        logging.info(batches2string(feeds["train"].next(), vocab[1]))
+    # ---- three views of ONE parameter store (reference train_lm.py:239-249: training / validation / batch-1 evaluation graphs)
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     layers.set_precision(args.dtype)
     store = variables.VariableStore(device=dev, seed=args.seed)
-    train_model = CharRNN(is_training=True, use_batch=True, store=store, **params)
-    valid_model = CharRNN(is_training=False, use_batch=True, store=store, **params)
-    test_model = CharRNN(is_training=False, use_batch=False, store=store, **params)
-    train_model.params()
+    models = {"train": CharRNN(is_training=True, use_batch=True, store=store, **hyper),
+              "valid": CharRNN(is_training=False, use_batch=True, store=store, **hyper),
+              "test": CharRNN(is_training=False, use_batch=False, store=store, **hyper)}
+    trainer = models["train"]
+    trainer.params()
     logging.info('Model size (number of parameters): %s\n', store.num_params())
-    logging.info('Start training\n')
-    result = {'params': params, 'vocab_file': args.vocab_file, 'encoding': args.encoding}
-    saved_path = ''
-    try:
-        if args.init_model:
-            sd = torch.load(args.init_model, map_location="cpu", weights_only=False)
-            store.load_state_dict(sd)
-            train_model.global_step = int(sd.get("global_step", 0))
-        for i in range(args.num_epochs):
-            for j in range(args.n_save):
-                logging.info('=' * 19 + ' Epoch %d: %d/%d' + '=' * 19 + '\n', i + 1, j + 1, args.n_save)
-                logging.info('Training on training set')
-                ppl, _, global_step = train_model.run_epoch(None, train_size, train_batches, is_training=True, verbose=args.verbose,
-                                                            freq=args.progress_freq, divide_by_n=args.n_save)
-                store.global_step = train_model.global_step
-                saved_path = _save(store, args.save_model, train_model.global_step, keep=args.max_to_keep)
-                logging.info('Latest model saved in %s\n', saved_path)
-                logging.info('Evaluate on validation set')
-                valid_ppl, _, _ = valid_model.run_epoch(None, valid_size, valid_batches, is_training=False, verbose=args.verbose,
-                                                        freq=args.progress_freq)
-                if (not best_model) or (valid_ppl < best_valid_ppl):
-                    best_model = _save(store, args.save_best_model, train_model.global_step)
-                    best_valid_ppl = valid_ppl
-                logging.info('Best model is saved in %s', best_model)
-                logging.info('Best validation ppl is %f\n', best_valid_ppl)
-                result['latest_model'] = saved_path
-                result['best_model'] = best_model
-                result['best_valid_ppl'] = float(best_valid_ppl)
-                with open(os.path.join(args.output_dir, 'result.json'), 'w') as f:
-                    json.dump(result, f, indent=2, sort_keys=True)
-        logging.info('Latest model is saved in %s', saved_path)
+    if init_model:
+        sd = torch.load(init_model, map_location="cpu", weights_only=False)
+        store.load_state_dict(sd)
+        trainer.global_step = int(sd.get("global_step", 0))
+
+    def sweep(part, train=False, **kw):
+        return models[part].run_epoch(None, corpus.size(part), feeds[part], is_training=train, verbose=args.verbose,
+                                      freq=args.progress_freq, **kw)[0]
+
+    run.write(params=hyper, vocab_file=run.path('vocab.json'), encoding=encoding)
+    latest = ''
+    # every epoch is cut into --n_save slices; after each slice: checkpoint, validate, keep the best
+    for done in range(args.num_epochs * args.n_save):
+        logging.info('=' * 19 + ' Epoch %d: %d/%d' + '=' * 19 + '\n', done // args.n_save + 1, done % args.n_save + 1, args.n_save)
+        logging.info('Training on training set')
+        sweep("train", train=True, divide_by_n=args.n_save)
+        store.global_step = trainer.global_step
+        latest = run.checkpoint(store, trainer.global_step)
+        logging.info('Latest model saved in %s\n', latest)
+        logging.info('Evaluate on validation set')
+        valid_ppl = sweep("valid")
+        if not best_model or valid_ppl < best_ppl:
+            best_model, best_ppl = run.checkpoint(store, trainer.global_step, best=True), valid_ppl
         logging.info('Best model is saved in %s', best_model)
-        logging.info('Best validation ppl is %f\n', best_valid_ppl)
-        logging.info('Evaluate the best model on test set')
-        if best_model:
-            store.load_state_dict(torch.load(best_model, map_location="cpu", weights_only=False))
-        test_ppl, _, _ = test_model.run_epoch(None, test_size, test_batches, is_training=False, verbose=args.verbose,
-                                              freq=args.progress_freq)
-        result['test_ppl'] = float(test_ppl)
-    finally:
-        with open(os.path.join(args.output_dir, 'result.json'), 'w') as f:
-            json.dump(result, f, indent=2, sort_keys=True)
+        logging.info('Best validation ppl is %f\n', best_ppl)
+        run.write(latest_model=latest, best_model=best_model, best_valid_ppl=float(best_ppl))
+    logging.info('Latest model is saved in %s', latest)
+    logging.info('Evaluate the best model on test set')
+    if best_model:
+        store.load_state_dict(torch.load(best_model, map_location="cpu", weights_only=False))
+    run.write(test_ppl=float(sweep("test")))
 
 
 if __name__ == '__main__':

@@ -366,8 +366,9 @@ def main():
             bwd = dom.endswith("bwd")
             ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9
             if a.dtype == "bf16":
-                kname = "rnn_seq_bwd_ks_kernel<LSTM,4,4>" if (bwd and a.cell == "lstm") else \
-                    ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_hw_kernel")
+                # template arguments <CELL, UT, P, RB[, CH]>: LSTM = 1, 4 unit tiles per wave, clusters of P = 4 CUs, 8-row batch tiles
+                kname = "rnn_seq_bwd_ks_kernel<1,4,4,8,CH>" if (bwd and a.cell == "lstm") else \
+                    ("rnn_seq_bwd_bf16_kernel" if bwd else "rnn_seq_fwd_hw_kernel<1,4,4,8>")
             else:
                 kname = ("rnn_seq_bwd" if bwd else "rnn_seq_fwd") + "_f32_kernel"
             traffic = None

@@ -128,8 +128,18 @@ def oracle_lm(p, E, NL):
     return lm
 
 
-def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0):
-    """BeamSearch.decode of ONE utterance through the oracle (CPU): xs = (audio [1,T,39,1|3], audiolen [1]); lm = (oracle_lm(...), H, NL)."""
+def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0, prec="f32"):
+    """BeamSearch.decode of ONE utterance through the oracle (CPU): xs = (audio [1,T,39,1|3], audiolen [1]); lm = (oracle_lm(...), H, NL).
+    prec="bf16": the oracle's speed-mode arithmetic (oracle_mode_for) for the whole search."""
+    from oracle import las_oracle as O
+    O.set_precision(*oracle_mode_for(args, prec))
+    try:
+        return _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight)
+    finally:
+        O.set_precision("f32")
+
+
+def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight):
     import torch
     from oracle import las_oracle as O
     NL = args.num_dec_layers
@@ -137,7 +147,7 @@ def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0):
     with torch.no_grad():
         x = torch.tensor(xs[0]).reshape(1, -1, 39)
         h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)
-        keys = h @ po["Speller/decode/attention/dense/kernel"]
+        keys = O.project_keys(h, po)                  # (f32 mode: h @ Wh)
         emb = po["embedding/embedding_matrix"]
 
         def step_fn(prev_ids, prev_al, states):

@@ -121,6 +121,56 @@ def test_exchange_timeout_is_reported_not_silent():
         _hip.check_status()
 
 
+def test_a_reported_timeout_keeps_the_optimiser_from_using_the_step():
+    """a sweep time-out must not reach the parameters.  las_clip_adam checks the status word (and the all-reduced
+    guard slot of the gradient bucket) ON THE DEVICE and leaves theta / m / v untouched -- no host synchronisation involved;
+    LAS.train wires both in, and the next check_status() still raises."""
+    from helpers import make_args, synthetic_batch
+    from las import _hip, layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    n = 1000
+    th = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda")
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    th0 = th.clone()
+    sumsq = (g * g).sum().reshape(1)
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    guard = torch.zeros(1, device="cuda")
+
+    def adam():
+        _hip.check(_hip.lib().las_clip_adam(_hip.p(th), _hip.p(g), _hip.p(m), _hip.p(v), n, _hip.p(sumsq), 5.0, 1e-3, 0.9, 0.999, 1e-8,
+                                            _hip.p(status), _hip.p(guard), _hip.stream()), "las_clip_adam")
+        torch.cuda.synchronize()
+
+    status[0] = 2
+    adam()
+    assert torch.equal(th, th0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+    status[0] = 0; guard[0] = 1.0                                   # another rank's time-out (summed guard slot)
+    adam()
+    assert torch.equal(th, th0) and float(m.abs().max()) == 0
+    guard[0] = 0.0
+    adam()
+    assert not torch.equal(th, th0) and float(m.abs().max()) > 0
+    # end to end: a step whose status word is set leaves the store untouched; the step after the raise trains again
+    args = make_args(enc_units=64, num_enc_layers=1, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32, lr=1e-3)
+    L.set_cell("lstm"); L.set_precision("bf16")
+    st = V.reset_default_store(device="cuda", seed=4)
+    las = LAS(args, Listener, Speller, {})
+    xs, ys = synthetic_batch(4, 40, 8, 30, seed=3)
+    las.build_variables()
+    _hip.check_status()
+    before = st.flat.clone()
+    _hip.status_word(st.flat.device)[0] = 1                         # as a timed-out forward sweep would leave it
+    las.train(xs, ys)
+    torch.cuda.synchronize()
+    assert torch.equal(st.flat, before) and float(st.adam_m.abs().max()) == 0
+    with pytest.raises(RuntimeError, match="status 1"):
+        las.check_status()
+    las.train(xs, ys)
+    torch.cuda.synchronize()
+    las.check_status()
+    assert not torch.equal(st.flat, before)
+
+
 def test_batches_larger_than_the_cu_budget_are_swept_in_row_chunks():
     """every cluster member must be resident (one workgroup per CU): B = 560 rows x 2 directions x P = 4 needs 280 CUs,
     so the sweep runs as two launches over row chunks; results must equal the oracle as for a small batch."""

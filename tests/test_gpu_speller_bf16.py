@@ -73,6 +73,15 @@ SHAPES = [
     (1, 128, 64, 64, 3, 181, 4, False),       # T' in (160, 192]: pf<.,12>
     (1, 128, 64, 64, 2, 214, 3, True),        # T' in (192, 224]: pf<.,14>
     (1, 64, 32, 32, 2, 230, 3, False),        # T' > 224: generic bf16 row kernels
+    # the geometry bench.py times (D = 512, A = 128, Hd = 512, T' = 160) with MORE THAN ONE utterance per XCD group of the
+    # one-launch loop kernels: utterance b = 8 r + x is tile row r of group x, so B = 9 / 17 / 48 exercise Rx = 2 / 3 / 6 row
+    # workgroups per group (ragged: some groups one row short), the `r16 < Rx` masking and the (j - pn) * 8 + x indexing
+    (1, 512, 128, 256, 9, 160, 6, False),
+    (1, 512, 128, 256, 17, 160, 6, True),
+    (1, 512, 128, 256, 48, 160, 6, False),
+    (1, 512, 128, 256, 48, 160, 5, True),
+    # the B = 96 / T = 638 bucket (T' = 80): R = 12 row workgroups per group
+    (1, 512, 128, 256, 96, 80, 5, False),
 ]
 
 

@@ -1,0 +1,118 @@
+"""Parity and determinism AT THE GEOMETRY bench.py TIMES (VERDICT r2 "next round" item 1): B = 48 utterances of T = 1274
+frames on the bench architecture, speed mode.  At this size the oracle needs minutes per step, so the checks are the
+size-independent properties the path offers:
+
+  * row independence: the reference model has no cross-utterance arithmetic in its forward pass (las/las.py:93-117 run every
+    utterance through the same weights; the only batch-wide quantity is the loss normaliser, las/las.py:329-331), so the rows
+    of the B = 48 step must equal the same utterances run as twelve B = 4 steps -- which ARE oracle-checked
+    (test_gpu_full_scale.py) -- and the B = 48 gradient must equal the token-weighted sum of the twelve;
+  * bitwise run-to-run determinism of three optimiser steps (SURVEY section 5 "race detection": the step depends on five
+    cross-stream hand-overs guarded by spin-waits; DESIGN section 4 claims "no atomics, bit-reproducible");
+  * the same three steps with every cross-stream hand-over switched off (whole x-projections, whole GEMMs between the BPTT
+    sweeps, no held side stream, one-stream tail) within the split-K tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_args, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+B, T = 48, 1274
+
+
+def bench_arch(**over):
+    kw = dict(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128,
+              mode="add", lr=1e-3, grad_clip=5.0, label_smoothing=True, vocab_size=30)
+    kw.update(over)
+    return make_args(**kw)
+
+
+def _fresh(args, p0):
+    from las import layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    L.set_cell("lstm")
+    L.set_precision("bf16")
+    st = V.reset_default_store(device="cuda")
+    st.load(p0)
+    return LAS(args, Listener, Speller, {}), st
+
+
+def _sub(xs, ys, lo, hi):
+    return (xs[0][lo:hi], xs[1][lo:hi]), (ys[0][lo:hi], ys[1][lo:hi])
+
+
+def test_b48_rows_equal_twelve_b4_batches():
+    from oracle import las_oracle as O
+    args = bench_arch()
+    xs, ys = synthetic_batch(B, T, 256, 30, seed=7, min_frac=0.834)
+    p0 = O.init_params(args, seed=3, cell="lstm")
+    las, st = _fresh(args, p0)
+    _, _, _, logits, alphas, _, _ = las.train(xs, ys)
+    torch.cuda.synchronize()
+    las.check_status()
+    logits, alphas, g48 = logits.cpu(), alphas.cpu(), st.flat_grad.cpu().clone()
+    assert alphas.shape[-1] == 160
+    n_tot = int((ys[0][:, :int(ys[1].max())] != 0).sum())
+    gsum = torch.zeros_like(g48)
+    worst_l = worst_a = 0.0
+    for k in range(B // 4):
+        xk, yk = _sub(xs, ys, 4 * k, 4 * k + 4)
+        las_k, st_k = _fresh(args, p0)
+        _, _, _, lk, ak, _, _ = las_k.train(xk, yk)
+        torch.cuda.synchronize()
+        las_k.check_status()
+        Uk = int(yk[1].max())
+        n_k = int((yk[0][:, :Uk] != 0).sum())
+        gsum += st_k.flat_grad.cpu() * (n_k / n_tot)
+        # every decode step an utterance owns (t < its token count) must not depend on who else is in the batch
+        for i in range(4):
+            n_i = int(yk[1][i])
+            worst_l = max(worst_l, (lk[i, :n_i].cpu() - logits[4 * k + i, :n_i]).abs().max().item())
+            worst_a = max(worst_a, (ak[i, :n_i].cpu() - alphas[4 * k + i, :n_i]).abs().max().item())
+    gerr = (g48 - gsum).abs().max().item() / g48.abs().max().item()
+    print("B=48 vs 12 x B=4: logits %.2e alphas %.2e flat_grad %.2e (of max |g| %.3e)" % (worst_l, worst_a, gerr, g48.abs().max().item()))
+    assert worst_l <= 1e-5 and worst_a <= 1e-5, (worst_l, worst_a)
+    assert gerr <= 2e-3, gerr
+
+
+def _three_steps(args, p0, xs, ys):
+    las, st = _fresh(args, p0)
+    out = []
+    for _ in range(3):
+        loss = las.train(xs, ys)[0]
+        if not out:
+            torch.cuda.synchronize()
+            g0 = st.flat_grad.clone()
+        out.append(loss)
+    torch.cuda.synchronize()
+    las.check_status()
+    return st.flat.clone(), g0, [float(v) for v in out]
+
+
+def test_three_b48_steps_are_bit_reproducible_and_independent_of_the_hand_overs():
+    from las import layers as L
+    from oracle import las_oracle as O
+    args = bench_arch(scheduled_sampling=True)       # what bench.py runs (rate 1.0 at step 0: teacher forcing, sampler path armed)
+    xs, ys = synthetic_batch(B, T, 256, 30, seed=0, min_frac=0.834)
+    p0 = O.init_params(args, seed=0, cell="lstm")
+    f1, g1, l1 = _three_steps(args, p0, xs, ys)
+    f2, g2, l2 = _three_steps(args, p0, xs, ys)
+    assert l1 == l2, (l1, l2)
+    assert torch.equal(g1, g2), "first-step gradient differs between two identical runs: max %.3e" % (g1 - g2).abs().max().item()
+    assert torch.equal(f1, f2), "parameters after 3 steps differ between two identical runs: max %.3e" % (f1 - f2).abs().max().item()
+    saved = (L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS)
+    try:
+        L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = 0, 0, False, False
+        f3, g3, l3 = _three_steps(args, p0, xs, ys)
+    finally:
+        L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = saved
+    gerr = (g1 - g3).abs().max().item() / g1.abs().max().item()
+    print("hand-overs on vs off: first-step gradient %.2e of max |g| (bitwise equal: %s), losses %s vs %s"
+          % (gerr, torch.equal(g1, g3), l1, l3))
+    assert gerr <= 2e-3, gerr
+    assert abs(l1[0] - l3[0]) <= 1e-5 * max(1.0, abs(l1[0]))
+    # after three Adam steps (lr 1e-3, sign-like updates of near-zero gradients) parameters may differ by a few lr at most
+    assert (f1 - f3).abs().max().item() <= 6.5e-3
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(l1, l3)), (l1, l3)
