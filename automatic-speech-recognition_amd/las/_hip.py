@@ -52,6 +52,19 @@ class SpellerBwdArgs(Structure):
                 ("dcellW", POINTER(c_void_p)), ("dcellb", POINTER(c_void_p))]
 
 
+class InputConfig(Structure):
+    """include/las_hip.h las_input_config"""
+    _fields_ = [("feat_dim", c_int), ("is_training", c_int), ("n_bounds", c_int), ("bounds", c_int * 16), ("batch_limit", c_int * 17),
+                ("max_tokenlen", c_int), ("shuffle_buffer", c_int), ("cycle_length", c_int), ("seed", ctypes.c_ulonglong),
+                ("rank", c_int), ("world", c_int), ("slots", c_int)]
+
+
+class InputBatch(Structure):
+    """include/las_hip.h las_input_batch"""
+    _fields_ = [(n, c_int) for n in ("slot", "B", "T", "bucket", "global_B", "max_tokenlen")] + \
+               [("feat", c_void_p), ("token", c_void_p), ("featlen", c_void_p), ("tokenlen", c_void_p)]
+
+
 class ShadowDesc(ctypes.Structure):
     """include/las_hip.h las_shadow_desc"""
     _fields_ = [("src0", c_void_p), ("src1", c_void_p), ("ld0", c_int), ("ld1", c_int), ("rows", c_int), ("cols0", c_int),
@@ -115,6 +128,13 @@ _SIGS = {
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_beam_loop_step": (c_int, [POINTER(BeamLoopArgs), c_void_p]),
+    "las_crc32c": (ctypes.c_uint, [c_char_p, c_size_t]),
+    "las_input_open": (c_void_p, [POINTER(c_char_p), c_int, POINTER(InputConfig)]),
+    "las_input_next": (c_int, [c_void_p, POINTER(InputBatch)]),
+    "las_input_upload": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "las_input_release": (c_int, [c_void_p, c_int]),
+    "las_input_records": (c_longlong, [c_void_p]),
+    "las_input_close": (None, [c_void_p]),
 }
 
 

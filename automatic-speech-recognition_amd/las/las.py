@@ -321,13 +321,16 @@ class Speller:
             if U > 1:
                 tokens_in[1:] = y[:, :U - 1].t()
                 if not coins[:U - 1].all():
-                    idx = torch.as_tensor(np.nonzero(~coins[:U - 1])[0] + 1, device=dev)
+                    # (pinned + non-blocking: a pageable upload would wait for the stream, i.e. for the whole previous step)
+                    idx = torch.as_tensor(np.nonzero(~coins[:U - 1])[0] + 1).pin_memory().to(dev, non_blocking=True)
                     if sampled is not None:
                         sm = torch.as_tensor(sampled).to(dev).to(torch.int32)
                         tokens_in[idx] = sm[:, :U - 1].t()[idx - 1]
                     else:
                         tokens_in[idx] = -2
-            step_logits = bool((tokens_in < 0).any().item()) if not coins[:max(U - 1, 0)].all() else False
+            # in-loop logits / draws are needed exactly when some step samples ON THE DEVICE (token -2): known on the host,
+            # no read-back (a `.item()` here would make every scheduled-sampling step wait for the whole previous step)
+            step_logits = bool(U > 1 and not coins[:U - 1].all() and sampled is None)
         emb_mask = None
         if is_training and a.dropout_rate:
             # tf.layers.dropout on the embedded input token of every step (las/las.py:107-108); step 0's SOS

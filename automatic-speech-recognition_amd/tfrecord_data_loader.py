@@ -39,6 +39,12 @@ def _crc_table():
 
 
 def crc32c(data):
+    if len(data) > 4096:                              # payloads (150 KB of floats): the library's table-driven loop when it is there
+        try:
+            from las import _hip
+            return int(_hip.lib().las_crc32c(bytes(data), len(data)))
+        except Exception:
+            pass
     tab = _crc_table()
     c = 0xFFFFFFFF
     for b in bytes(data):
@@ -236,20 +242,50 @@ EVAL_BOUNDARIES = [639, 1062, 1275, 1377, 1449, 1506, 1563, 3600]       # :80
 BUCKET_BATCH_LIMIT = [96, 48, 48, 48, 48, 48, 48, 48, 48]               # :83
 
 
+class _Rng:
+    """The pipeline's shuffle stream: splitmix64, restated bit for bit in csrc/input.hip (`Rng`) so that the native reader
+    and this iterator produce the same batch order from the same seed.  (The reference's order comes from TensorFlow's own
+    generators and is not reproducible outside it.)"""
+    M = (1 << 64) - 1
+
+    def __init__(self, seed):
+        self.s = int(seed) & self.M
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & self.M
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.M
+        return z ^ (z >> 31)
+
+    def randint(self, n):
+        return self.next() % n
+
+    def shuffle(self, v):
+        for i in range(len(v), 1, -1):                                    # Fisher-Yates from the top
+            j = self.randint(i)
+            v[i - 1], v[j] = v[j], v[i - 1]
+
+
 class _BucketedIterator:
     """list_files(shuffle) -> interleave(16) -> parse -> bucket_by_sequence_length(pad_to_bucket_boundary)
-    [-> shuffle(64) -> repeat()]."""
+    [-> shuffle(64) -> repeat()].
 
-    def __init__(self, files, record_parser, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16):
+    rank / world (data parallel, lock step): every rank walks the SAME record stream; a bucket emits when it holds
+    world x batch-limit utterances and this rank keeps rows rank, rank + world, ... of that global batch (a leftover smaller
+    than the world is dropped on every rank) -- all ranks train on the same bucket shape at every step."""
+
+    def __init__(self, files, record_parser, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1):
         self.files = list(files)
         self.parser = record_parser
         self.feat_dim = feat_dim
         self.is_training = is_training
         self.bounds = TRAIN_BOUNDARIES if is_training else EVAL_BOUNDARIES
         self.max_tokenlen = 219 if is_training else 227                   # :76,:81
-        self.rng = np.random.RandomState(seed)
+        self.rng = _Rng(seed)
         self.shuffle_buffer = shuffle_buffer if is_training else 0
         self.cycle_length = cycle_length
+        self.rank, self.world = int(rank), max(int(world), 1)
         self.initializer = None                                           # API parity with make_initializable_iterator
         self._gen = self._batches()
 
@@ -274,6 +310,7 @@ class _BucketedIterator:
 
     def _emit(self, k, items):
         T = self.bounds[k] - 1 if k < len(self.bounds) else max(x[0][1] for x in items)
+        items = items[self.rank::self.world]
         B = len(items)
         feat = np.zeros((B, T, self.feat_dim, 3), np.float32)
         featlen = np.zeros(B, np.int32)
@@ -298,11 +335,11 @@ class _BucketedIterator:
             if ys[1] > self.max_tokenlen:
                 raise ValueError("token sequence of %d exceeds the padded length %d" % (ys[1], self.max_tokenlen))
             buckets[k].append((xs, ys))
-            if len(buckets[k]) == BUCKET_BATCH_LIMIT[k]:
+            if len(buckets[k]) == BUCKET_BATCH_LIMIT[k] * self.world:
                 yield self._emit(k, buckets[k])
                 buckets[k] = []
         for k, items in enumerate(buckets):                               # leftovers at end of data
-            if items:
+            if len(items) >= self.world:
                 yield self._emit(k, items)
 
     def _batches(self):
@@ -331,13 +368,99 @@ class _BucketedIterator:
         return self
 
 
-def tfrecord_iterator(filenames, record_parser, feat_dim=13, is_training=True, seed=0):
+class NativeReader:
+    """The same pipeline through liblas_hip.so's reader (csrc/input.hip: one C++ producer thread, mmap'ed files, pinned batch
+    ring): same constructor arguments, same batch order as `_BucketedIterator`.  `get_next()` returns numpy COPIES (API parity);
+    the train loop uses `next_slot()` / `upload()` (las.input_pipeline.DeviceFeeder) and never copies on the host."""
+
+    def __init__(self, files, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1, slots=4):
+        import ctypes
+        from las import _hip
+        self._hip, self._ct = _hip, ctypes
+        self.files = list(files)
+        self.feat_dim, self.is_training = int(feat_dim), bool(is_training)
+        bounds = TRAIN_BOUNDARIES if is_training else EVAL_BOUNDARIES
+        self.max_tokenlen = 219 if is_training else 227
+        cfg = _hip.InputConfig()
+        cfg.feat_dim, cfg.is_training, cfg.n_bounds = self.feat_dim, int(self.is_training), len(bounds)
+        for i, b in enumerate(bounds):
+            cfg.bounds[i] = b
+        for i, b in enumerate(BUCKET_BATCH_LIMIT):
+            cfg.batch_limit[i] = b
+        cfg.max_tokenlen = self.max_tokenlen
+        cfg.shuffle_buffer = shuffle_buffer if is_training else 0
+        cfg.cycle_length, cfg.seed, cfg.rank, cfg.world, cfg.slots = cycle_length, int(seed) & ((1 << 64) - 1), int(rank), max(int(world), 1), slots
+        arr = (ctypes.c_char_p * len(self.files))(*[f.encode() for f in self.files])
+        self._h = _hip.lib().las_input_open(arr, len(self.files), ctypes.byref(cfg))
+        if not self._h:
+            raise IOError("las_input_open: %s" % _hip.lib().las_last_error().decode())
+        self.initializer = None
+
+    def next_slot(self):
+        """-> las_input_batch (pointers into a pinned slot; release it with `release(slot)`), or None at the end of an evaluation pass"""
+        b = self._hip.InputBatch()
+        rc = self._hip.lib().las_input_next(self._h, self._ct.byref(b))
+        if rc == 1:
+            return None
+        if rc != 0:
+            raise IOError(self._hip.lib().las_last_error().decode())
+        return b
+
+    def arrays(self, b):
+        """numpy views of a slot (valid until it is released)"""
+        ct = self._ct
+        F = self.feat_dim
+        feat = np.ctypeslib.as_array(ct.cast(b.feat, ct.POINTER(ct.c_float)), shape=(b.B, b.T, F, 3))
+        tok = np.ctypeslib.as_array(ct.cast(b.token, ct.POINTER(ct.c_int)), shape=(b.B, b.max_tokenlen))
+        fl = np.ctypeslib.as_array(ct.cast(b.featlen, ct.POINTER(ct.c_int)), shape=(b.B,))
+        tl = np.ctypeslib.as_array(ct.cast(b.tokenlen, ct.POINTER(ct.c_int)), shape=(b.B,))
+        return (feat, fl), (tok, tl)
+
+    def upload(self, b, d_feat, d_token, stream):
+        self._hip.check(self._hip.lib().las_input_upload(self._h, b.slot, d_feat, d_token, stream), "las_input_upload")
+
+    def release(self, b):
+        self._hip.check(self._hip.lib().las_input_release(self._h, b.slot), "las_input_release")
+
+    def get_next(self):
+        b = self.next_slot()
+        if b is None:
+            raise StopIteration
+        (feat, fl), (tok, tl) = self.arrays(b)
+        out = (feat.copy(), fl.astype(np.int32)), (tok.astype(np.int32), tl.astype(np.int32))
+        self.release(b)
+        return out
+
+    __next__ = get_next
+
+    def __iter__(self):
+        return self
+
+    def records(self):
+        return int(self._hip.lib().las_input_records(self._h))
+
+    def close(self):
+        if self._h:
+            self._hip.lib().las_input_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tfrecord_iterator(filenames, record_parser, feat_dim=13, is_training=True, seed=0, rank=0, world=1, native=False):
     """reference tfrecord_data_loader.py:54-109.  `filenames`: a glob pattern or a list of paths.
-    Returns (iterator, output_types, output_shapes)."""
+    Returns (iterator, output_types, output_shapes).  native=True: the C++ reader of liblas_hip.so (same batches)."""
     files = sorted(glob.glob(filenames)) if isinstance(filenames, str) else list(filenames)
     if not files:
         raise IOError("no TFRecord files match %r" % (filenames,))
-    it = _BucketedIterator(files, record_parser, feat_dim, is_training, seed=seed)
+    if native:
+        it = NativeReader(files, feat_dim, is_training, seed=seed, rank=rank, world=world)
+    else:
+        it = _BucketedIterator(files, record_parser, feat_dim, is_training, seed=seed, rank=rank, world=world)
     max_tok = it.max_tokenlen
     types = ((np.float32, np.int32), (np.int32, np.int32))
     shapes = (([None, None, feat_dim, 3], [None]), ([None, max_tok], [None]))

@@ -4,7 +4,13 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...   # data parallel
 
 Replaces the `sess.run` step loop of train.py:114-133: every iteration is one eager `las.train(xs, ys)` on
-this rank's batch; with WORLD_SIZE>1 the gradient bucket is all-reduced over RCCL (las/parallel.py)."""
+this rank's batch; with WORLD_SIZE>1 the gradient bucket is all-reduced over RCCL (las/parallel.py).
+
+The loop never waits for the device: batches arrive through `las.input_pipeline.DeviceFeeder` (background reader thread --
+the C++ TFRecord reader of liblas_hip.so or the synthetic source -- pinned staging, host->device copies on a copy stream,
+`--prefetch` batches ahead), and the per-step log line is printed from an asynchronous copy of the loss one or two steps later
+(`LaggedLog`).  Data parallel runs are LOCK STEP: every rank draws the same bucket at every step and keeps its rows of that
+bucket's global batch (tfrecord_data_loader: rank / world), so no rank waits for another rank's longer utterances."""
 import json
 import logging
 import os
@@ -60,19 +66,22 @@ def main():
         dp.broadcast_(st.flat)
 
     num_train_batches = 2619                                      # train.py:108
+    from las.input_pipeline import LaggedLog, feeder_for
     if args.synthetic:
         from data import SyntheticBatches
-        batches = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
+        source = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
     else:
-        # train.py:45-55: data/tfrecord_{feat_type}_bpe_5k/train-*.tfrecord; every rank reads its own file subset
+        # train.py:45-55: data/tfrecord_{feat_type}_bpe_5k/train-*.tfrecord.  Every rank walks the same record stream (same
+        # seed) and keeps its rows of every global batch: one bucket shape per step on all ranks
         import glob
         from tfrecord_data_loader import data_parser, tfrecord_iterator
         pattern = os.path.join(args.tfrecord_dir or "data/tfrecord_{}_bpe_5k".format(args.feat_type), "train-*.tfrecord")
         files = sorted(glob.glob(pattern))
         if not files:
             raise Exception("Run preprocess.py, create_tfrecord.py first")
-        files = files[rank::world] if len(files) >= world else files
-        batches, _, _ = tfrecord_iterator(files, data_parser, args.feat_dim, seed=args.seed + rank)
+        source, _, _ = tfrecord_iterator(files, data_parser, args.feat_dim, seed=args.seed, rank=rank, world=world,
+                                         native=os.environ.get("LAS_PY_READER") != "1")
+    batches = feeder_for(source, dev, args.feat_dim, is_training=True, depth=max(2, int(os.environ.get("LAS_PREFETCH", "3"))))
 
     if rank == 0:
         logging.info("Total weights: {}".format(st.num_params()))
@@ -81,23 +90,40 @@ def main():
         logging.info("Total num train batches: {}".format(num_train_batches))
         logging.info("Training...")
     loss_ = []
+
+    def report(info, value):                                       # runs when the step's loss has reached the host (lagged)
+        gs, tfrate = info
+        loss_.append(value)
+        if rank == 0:
+            logging.info("Step: {}, Loss: {:.3f}, tf rate: {:.3f}".format(gs, value, tfrate))
+
+    log = LaggedLog(report)
+    import time
+    t_loop, n_utt = time.perf_counter(), 0
     for step in range(training_steps):
         xs, ys = next(batches)
         batch_loss, _, gs, logits, alphas, _, tfrate = las.train(xs, ys)
-        batch_loss = float(batch_loss)
-        las.check_status()                                         # the host has just waited for the step anyway
-        if rank == 0:
-            if args.verbose > 0:
-                logging.info("HYP: {}".format(convert_idx_to_string(torch.argmax(logits[0], -1).cpu().numpy(), id_to_token, args.unit)))
-                logging.info("REF: {}\n".format(convert_idx_to_string(ys[0][0], id_to_token, args.unit)))
-            logging.info("Step: {}, Loss: {:.3f}, tf rate: {:.3f}".format(gs, batch_loss, tfrate))
-        loss_.append(batch_loss)
+        n_utt += int(xs[0].shape[0])
+        log.push((gs, tfrate), batch_loss)
+        if rank == 0 and args.verbose > 0:                         # (the text summaries synchronise: debugging aid, as in the reference)
+            logging.info("HYP: {}".format(convert_idx_to_string(torch.argmax(logits[0], -1).cpu().numpy(), id_to_token, args.unit)))
+            logging.info("REF: {}\n".format(convert_idx_to_string(ys[0][0].cpu().numpy(), id_to_token, args.unit)))
         if gs and gs % num_train_batches == 0:
+            log.drain(True)
+            las.check_status()
             e_ = gs // num_train_batches
             if rank == 0:
                 logging.info('=' * 19 + ' Epoch %d, Step %d, Ave loss %f' + '=' * 19 + '\n', e_, gs, np.mean(loss_))
                 checkpoint.save(args.save_dir, e_)
             loss_ = []
+    log.drain(True)
+    torch.cuda.synchronize()
+    las.check_status()                                             # (LAS.train polls the status word without waiting in between)
+    if rank == 0:
+        dt = time.perf_counter() - t_loop
+        logging.info("train loop: {} steps, {} utterances in {:.2f} s = {:.1f} utterances/s on this rank (input pipeline and "
+                     "host->device copies included)".format(training_steps, n_utt, dt, n_utt / max(dt, 1e-9)))
+    batches.close()
     if rank == 0 and args.max_steps >= 0:
         checkpoint.save(args.save_dir, max(1, st.global_step // num_train_batches))
 

@@ -378,6 +378,48 @@ typedef struct {
 } las_beam_loop_args;
 int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * F1  input side of the step loop: TFRecord reader + bucket_by_sequence_length + pinned batch ring + H2D upload
+ * (reference tfrecord_data_loader.py:54-109: list_files / parallel_interleave(cycle_length 16) / map(data_parser) /
+ * bucket_by_sequence_length(pad_to_bucket_boundary) / shuffle(64) / repeat / prefetch -- TensorFlow's C++ input threads in the
+ * reference, one producer thread per reader here; train.py:45-55,114-117 is the consumer).  Host code; the only device
+ * interaction is the asynchronous copy of las_input_upload.  Batch order is a pure function of (files, seed) and equals the
+ * Python restatement in tfrecord_data_loader.py (same splitmix64 stream).  rank / world: lock-step data parallelism -- a bucket
+ * emits when it holds world x batch_limit utterances and this rank keeps rows rank, rank + world, ... of that global batch, so
+ * every rank runs the same bucket shape at every step.
+ */
+typedef struct las_input_config {
+    int feat_dim;                 /* MFCC coefficients per channel (13): a frame is feat_dim x 3 floats */
+    int is_training;              /* 1: shuffle + repeat forever; 0: one pass, then las_input_next returns 1 */
+    int n_bounds;                 /* number of bucket boundaries (<= 16) */
+    int bounds[16];               /* tfrecord_data_loader.py:75,80 */
+    int batch_limit[17];          /* tfrecord_data_loader.py:83, per rank */
+    int max_tokenlen;             /* token rows are padded to this (219 train / 227 eval, :76,:81) */
+    int shuffle_buffer;           /* batches (64 train, 0 eval) */
+    int cycle_length;             /* files read round robin (16) */
+    unsigned long long seed;
+    int rank, world;
+    int slots;                    /* pinned batches in flight (>= 2) */
+} las_input_config;
+
+typedef struct las_input_batch {
+    int slot, B, T, bucket, global_B, max_tokenlen;
+    const float* feat;            /* [B, T, feat_dim, 3] zero padded, pinned host memory (valid until the slot is released) */
+    const int* token;             /* [B, max_tokenlen] zero padded */
+    const int* featlen;           /* [B] */
+    const int* tokenlen;          /* [B] */
+} las_input_batch;
+
+unsigned int las_crc32c(const void* data, size_t n);              /* CRC-32C (Castagnoli) of a host buffer: the TFRecord framing's checksum */
+void* las_input_open(const char* const* files, int nfiles, const las_input_config* cfg);   /* NULL on error (las_last_error) */
+int las_input_next(void* reader, las_input_batch* out);          /* blocks; 0 = a batch, 1 = end of data, < 0 = error */
+/* asynchronous copy of the slot's features / tokens to caller-owned device buffers on `stream`; the reader does not refill the
+ * slot before that copy has executed.  Follow with las_input_release. */
+int las_input_upload(void* reader, int slot, float* d_feat, int* d_token, void* stream);
+int las_input_release(void* reader, int slot);
+long long las_input_records(void* reader);                       /* records parsed so far */
+void las_input_close(void* reader);
+
 #ifdef __cplusplus
 }
 #endif
