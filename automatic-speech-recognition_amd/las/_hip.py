@@ -301,6 +301,18 @@ def join_chain_stream():
         _chain_used = False
 
 
+_comm_stream = None
+
+
+def comm_stream():
+    """Stream the data-parallel exchange of the bucket's early part is issued from (orders it behind main / side / chain work
+    without making any of those streams wait for the collective)."""
+    global _comm_stream
+    if _comm_stream is None:
+        _comm_stream = torch.cuda.Stream()
+    return _comm_stream
+
+
 _deferred = []
 
 

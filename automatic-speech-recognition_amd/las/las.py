@@ -612,15 +612,40 @@ class LAS:
 
         with _hip.roctx_range("loss"):
             loss = self._get_loss(logits, y, n_total)                                     # sum_local / n_total
+        early = []
+        if self.dp is not None:
+            def before_tail(P4, st=st, dev=dev):
+                # Called by the bottom recurrent layer's backward right before it enqueues the end-of-step tail (its own weight
+                # gradients).  Those parameters were created first, so they -- and the guard slot in front of them -- are the
+                # head of the bucket; everything behind is final once the work enqueued so far (main, side, chain streams) has
+                # run.  That part is all-reduced NOW on the communication stream, under the last sweep's tail.
+                mine = {n for n in st.order if any(st.vars[n] is q for q in P4)}
+                n_head = 4 + (max(st.offsets[n] + st.vars[n].numel() for n in mine) + 3) // 4 * 4
+                if any(st.offsets[n] + 4 < n_head for n in st.order if n not in mine) or n_head >= st.grad_bucket.numel():
+                    return                                   # (unexpected layout: fall back to one exchange at the end)
+                comm = _hip.comm_stream()
+                for s_ in (torch.cuda.current_stream(), _hip.side_stream(), _hip.chain_stream()):
+                    comm.wait_stream(s_)
+                with torch.cuda.stream(comm):
+                    early.append((n_head, self.dp.all_reduce_(st.grad_bucket[n_head:], async_op=True)))
+            L.BEFORE_TAIL_HOOK[0] = before_tail
         with _hip.roctx_range("backward"):
-            loss.backward()
+            try:
+                loss.backward()
+            finally:
+                L.BEFORE_TAIL_HOOK[0] = None
             _hip.join_side_stream()                   # weight gradients accumulated on the side stream
             L.check_handovers_consumed()
         if self.dp is not None:
-            # one flat bucket (C1); its last slot carries this rank's sweep status, so that a time-out on ANY rank makes EVERY
+            # one flat bucket (C1); its first slot carries this rank's sweep status, so that a time-out on ANY rank makes EVERY
             # rank skip the update (las_clip_adam's guard) and the replicas stay identical
             st.guard.copy_(_hip.status_word(dev)[0:1].ne(0))
-            self.dp.all_reduce_(st.grad_bucket)
+            if early:
+                n_head, work = early[0]
+                self.dp.all_reduce_(st.grad_bucket[:n_head])          # guard + the bottom layer's gradients (the tail's output)
+                work.wait()                                           # the launch stream waits for the early part
+            else:
+                self.dp.all_reduce_(st.grad_bucket)
             loss_val = self.dp.all_reduce_scalar(loss.detach())
         else:
             loss_val = loss.detach()

@@ -114,6 +114,7 @@ DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward 
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 TAIL_TWO_STREAMS = not os.environ.get("LAS_NO_TAIL_TWO_STREAMS")   # bottom layer's weight gradients: one direction per auxiliary stream
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
+BEFORE_TAIL_HOOK = [None]   # callable(bottom layer's parameters) run right before the end-of-step tail is enqueued (data parallel)
 DIRECT_GRADS = True   # weight gradients accumulate into the flat bucket on a side stream (needs a flattened store)
 
 
@@ -643,6 +644,10 @@ class _BLSTM16(torch.autograd.Function):
             if produced is not None:
                 _hip.defer_side(lambda: side_work(produced))      # run by the next sweep's node, after its launch
             elif TAIL_TWO_STREAMS and not ctx.needs_input_grad[0] and not two:
+                if BEFORE_TAIL_HOOK[0] is not None:
+                    # data parallel: every gradient but this layer's is final once the work queued so far has run -- the
+                    # all-reduce of that part of the bucket starts now, under the tail (las.las.LAS.train)
+                    BEFORE_TAIL_HOOK[0](P4)
                 # bottom layer = the end-of-step tail, nothing left to hide behind: the two directions' weight gradients on two
                 # streams (with the LDS-transposing kernel a single one of these products no longer fills the chip: 15.07 -> 14.99 ms)
                 with _hip.on_side_stream():

@@ -22,9 +22,11 @@ class DataParallel:
 
     # The collectives are issued for every world size, 1 included: a one-rank group still goes through the backend
     # (RCCL on a GPU box), which is how the single-GPU test box exercises communicator set-up and the bucket exchange.
-    def all_reduce_(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        return flat
+    def all_reduce_(self, flat, async_op=False):
+        """in-place sum over the ranks; async_op=True returns the work handle (the backend's own stream runs it; `wait()` orders
+        the current stream behind it)"""
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return work if async_op else flat
 
     def all_reduce_scalar(self, x):
         x = x.detach().clone().reshape(1)

@@ -109,11 +109,12 @@ class VariableStore:
         total = max(o, 4)
         dev = self.vars[names[0]].device if names else self.device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        # the gradient bucket carries ONE extra slot behind the gradients (4 floats, keeps 16-byte granularity): the data-parallel
-        # exchange all-reduces `grad_bucket`, so a rank whose sweep timed out tells every rank to skip the update (guard != 0)
+        # the gradient bucket carries ONE extra slot IN FRONT of the gradients (4 floats, keeps 16-byte granularity): the
+        # data-parallel exchange all-reduces `grad_bucket`, so a rank whose sweep timed out tells every rank to skip the update
+        # (guard != 0).  It sits next to the bottom layer's gradients -- the part of the bucket that is exchanged LAST.
         self.grad_bucket = torch.zeros(total + 4, dtype=torch.float32, device=dev)
-        self.flat_grad = self.grad_bucket[:total]
-        self.guard = self.grad_bucket[total:total + 1]
+        self.guard = self.grad_bucket[0:1]
+        self.flat_grad = self.grad_bucket[4:]
         self.adam_m = torch.zeros_like(self.flat)
         self.adam_v = torch.zeros_like(self.flat)
         self.offsets = dict(zip(names, offs))

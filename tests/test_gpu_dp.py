@@ -13,18 +13,18 @@ from helpers import make_args, synthetic_batch, PKG, ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cell):
+def _setup(cell, prec="f32"):
     from las import layers as L, variables as V
     from las.las import LAS, Listener, Speller
     from oracle import las_oracle as O
     args = make_args(enc_units=64, num_enc_layers=1, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32, lr=1e-3)
     p0 = O.init_params(args, seed=7, cell=cell)
-    L.set_cell(cell); L.set_precision("f32")
+    L.set_cell(cell); L.set_precision(prec)
     st = V.reset_default_store(device="cuda:0"); st.load(p0)
     return args, LAS(args, Listener, Speller, {}), st
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, prec="f32"):
     for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -33,32 +33,52 @@ def _worker(rank, world, port, out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from las.parallel import DataParallel
-    args, las, st = _setup("lstm")
+    args, las, st = _setup("lstm", prec)
     las.dp = DataParallel()
-    xs, ys = synthetic_batch(6, 40, 8, 30, seed=11)
-    sl = slice(rank * 3, rank * 3 + 3)
     las.build_variables()
     las.dp.broadcast_(st.flat)
-    loss = las.train((xs[0][sl], xs[1][sl]), (ys[0][sl], ys[1][sl]))[0]
+    calls = []
+    if prec == "bf16":                                   # the early exchange must really have been taken (speed-mode pBLSTM stack)
+        real = las.dp.all_reduce_
+        las.dp.all_reduce_ = lambda t, async_op=False: (calls.append((t.numel(), async_op)), real(t, async_op=async_op))[1]
+    losses = []
+    for k in range(3):                                   # three optimiser steps, a different (lock-step) global batch each
+        xs, ys = synthetic_batch(6, 40 + 8 * k, 8, 30, seed=11 + k)
+        sl = slice(rank, None, world)                    # the reader's sharding rule: rows rank, rank + world, ...
+        losses.append(float(las.train((xs[0][sl], xs[1][sl]), (ys[0][sl], ys[1][sl]))[0]))
     torch.cuda.synchronize()
-    if rank == 0:
-        torch.save({"flat": st.flat.cpu(), "loss": float(loss)}, out_path)
+    las.check_status()
+    if prec == "bf16":
+        assert len(calls) == 6 and [c[1] for c in calls] == [True, False] * 3, calls
+        assert calls[0][0] + calls[1][0] == st.grad_bucket.numel() and calls[0][0] > calls[1][0]
+    torch.save({"flat": st.flat.cpu(), "m": st.adam_m.cpu(), "v": st.adam_v.cpu(), "loss": losses}, out_path + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_rank_full_batch(tmp_path):
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_two_rank_steps_equal_single_rank_full_batch(tmp_path, prec):
+    """three steps: token count + gradient bucket all-reduced (the bucket in two parts: everything but the bottom layer under the
+    end-of-step tail, then guard + bottom layer), replicated clip + Adam -- parameters AND Adam moments equal single-process
+    training on the concatenated batches, and the two replicas stay bit-identical"""
     import torch.multiprocessing as mp
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 300, out), nprocs=2, join=True)
-    got = torch.load(out)
-    args, las, st = _setup("lstm")
-    xs, ys = synthetic_batch(6, 40, 8, 30, seed=11)
-    loss = las.train(xs, ys)[0]
+    mp.spawn(_worker, args=(2, 29600 + os.getpid() % 300, out, prec), nprocs=2, join=True)
+    got, got1 = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in ("flat", "m", "v"):
+        assert torch.equal(got[k], got1[k]), k
+    args, las, st = _setup("lstm", prec)
+    losses = []
+    for k in range(3):
+        xs, ys = synthetic_batch(6, 40 + 8 * k, 8, 30, seed=11 + k)
+        losses.append(float(las.train(xs, ys)[0]))
     torch.cuda.synchronize()
-    assert abs(got["loss"] - float(loss)) < 1e-5
-    # Adam's first step is ~lr*sign(g): compare the UPDATE against lr, not the weights against each other
-    assert (got["flat"] - st.flat.cpu()).abs().max().item() < 2e-4
+    tol = 1.0 if prec == "f32" else 20.0                 # bf16: near-zero gradients whose Adam steps are sign-like, then 2 more steps
+    assert max(abs(a - b) for a, b in zip(got["loss"], losses)) < 2e-4 * tol
+    # Adam's first steps are ~lr*sign(g): compare the UPDATE against lr, not the weights against each other
+    assert (got["flat"] - st.flat.cpu()).abs().max().item() < 6e-4 * (1 if prec == "f32" else 10)
+    assert (got["m"] - st.adam_m.cpu()).abs().max().item() < 1e-5 * tol * max(1.0, st.adam_m.abs().max().item())
+    assert (got["v"] - st.adam_v.cpu()).abs().max().item() < 1e-6 * tol * max(1.0, st.adam_v.abs().max().item())
 
 
 _RCCL_SCRIPT = r'''
