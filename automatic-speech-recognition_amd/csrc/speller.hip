@@ -39,7 +39,16 @@ struct LoopProd {
     unsigned long long* gC; int gC_row;          // [M][gC_row] granules, gC_row = N / 2
     unsigned long long* xcc;                     // [8 (pn + R)] placement handshake slots (zeroed per launch)
     int nap;                                     // product workgroups sleep nap x 2048 clocks after a step before they poll again
+    int budget;                                  // polls before a wave gives up (2^21 ~ seconds; LAS_SPELLER_SPIN_LOG2 for tests)
+    int* status;                                 // optional device word: LAS_SPELLER_STATUS_TIMEOUT when a partner workgroup was not seen within the poll bound
 };
+// A poll that runs out of budget (a partner workgroup that was never dispatched: the grid needs every workgroup co-resident)
+// reports through the status word and ENDS its wave (s_endpgm: like the trap it replaces it is a no-return path, so the
+// register allocation of the loops -- which sit at their 128-VGPR budget -- is unchanged; terminated waves drop out of the
+// workgroup's barriers).  The waves that are left run their remaining steps on whatever data they have, partners that wait for
+// the ended waves' granules end the same way: the launch drains in bounded time and the host raises at its next status check.
+#define LOOP_POLL_TIMEOUT(lp)                                                                                   \
+    do { if ((lp).status) (lp).status[0] = LAS_SPELLER_STATUS_TIMEOUT; __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_endpgm(); } while (0)
 
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
@@ -720,13 +729,13 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             goff[i] = (unsigned)(((size_t)b * (GD >> 1) + ((i * D + dd) >> 1)) * 16);
             gq[i] = granule16_load(rs, goff[i]);
         }
-        int budget = 1 << 24;
+        int budget = a.lp.budget;
         for (;;) {
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < G; ++i) ok &= gq[i].x == (unsigned)t && gq[i].w == (unsigned)t;
             if (ok) break;
-            if (--budget == 0) __builtin_trap();          // a product workgroup never ran: fail loudly, never hang
+            if (--budget == 0) LOOP_POLL_TIMEOUT(a.lp);    // a product workgroup never ran: report, never hang
             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int i = 0; i < G; ++i)
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
 // traffic of 200 workgroups.  Progress: products wait only for rows, rows only for products, the host launches the grid only
 // if 8 (pn + R) workgroups fit the device's compute units at once; polls are bounded and trap (never hang).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool loop_same_xcd(unsigned long long* slots, const int x, const int members, const int tid) {
+__device__ __forceinline__ bool loop_same_xcd(unsigned long long* slots, const int x, const int members, const int tid, int* status) {
     const unsigned tag = 0x58434400u;                                            // "XCD\0"
     const unsigned mine = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;       // HW_REG_XCC_ID[3:0]
     if (tid == 0) __hip_atomic_store(slots + blockIdx.x, ((unsigned long long)tag << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -942,13 +951,13 @@ __device__ __forceinline__ bool loop_same_xcd(unsigned long long* slots, const i
     if (tid < members) {
         const unsigned long long* p = slots + (size_t)tid * 8 + x;
         unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int budget = 1 << 24;
+        int budget = 1 << 20;
         while ((unsigned)(v >> 32) != tag) {
-            if (--budget == 0) __builtin_trap();                                 // a member was never dispatched
+            if (--budget == 0) { if (status) status[0] = LAS_SPELLER_STATUS_TIMEOUT; break; }    // a member was never dispatched
             __builtin_amdgcn_s_sleep(8);
             v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        same = (unsigned)v == mine;
+        same = (unsigned)(v >> 32) == tag && (unsigned)v == mine;
     }
     return __syncthreads_and(same) != 0;
 }
@@ -983,13 +992,13 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             u32x4_t q0[KW], q1[KW];
 #pragma unroll
             for (int u = 0; u < KW; ++u) { q0[u] = granule16_load(ars, aoff[u]); q1[u] = granule16_load(ars, aoff[u] + 16u); }
-            int budget = 1 << 24;
-            for (;;) {
+            int budget = a.lp.budget;
+                for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int u = 0; u < KW; ++u) ok &= q0[u].x == tag && q0[u].w == tag && q1[u].x == tag && q1[u].w == tag;
                 if (ok) break;
-                if (--budget == 0) __builtin_trap();
+                if (--budget == 0) LOOP_POLL_TIMEOUT(p);
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < KW; ++u) {
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
     constexpr int TPW = 5, KW = 3;                                    // 26 x 5 column tiles >= 128, 16 waves x 3 k-steps x 32 >= 1280 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x);
+    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x, a.lp.status);
     if (threadIdx.x == 0 && blockIdx.x == 0) { STAMPL(local); }
     if (j < a.lp.pn) { loop_product<TPW, KW>(a.lp, a.U, false, x, j, local, sm); return; }
     const int b = (j - a.lp.pn) * 8 + x;
@@ -1641,11 +1650,11 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         const unsigned tag = (unsigned)t_att + 1u;
         const unsigned o0 = (unsigned)(((size_t)b * a.lp.gC_row + h2c) * 16), o1 = (unsigned)(((size_t)b * a.lp.gC_row + ((Hd + dd) >> 1)) * 16);
         u32x4_t q0 = granule16_load(rs, o0), q1 = granule16_load(rs, o1);
-        int budget = 1 << 24;
+        int budget = a.lp.budget;
         for (;;) {
             const bool ok0 = q0.x == tag && q0.w == tag, ok1 = q1.x == tag && q1.w == tag;
             if (ok0 && ok1) break;
-            if (--budget == 0) __builtin_trap();          // a product workgroup never ran: fail loudly, never hang
+            if (--budget == 0) LOOP_POLL_TIMEOUT(a.lp);    // a product workgroup never ran: report, never hang
             __builtin_amdgcn_s_sleep(1);
             if (!ok0) q0 = granule16_load(rs, o0);
             if (!ok1) q1 = granule16_load(rs, o1);
@@ -1812,7 +1821,7 @@ __global__ __launch_bounds__(RNT) void dec_loop_bwd_kernel(DecDev a) {
     constexpr int TPW = 3, KW = 4;                                    // 26 x 3 column tiles >= 64, 16 waves x 4 k-steps x 32 >= 2048 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x);
+    const bool local = loop_same_xcd(a.lp.xcc, x, a.lp.pn + a.lp.R, threadIdx.x, a.lp.status);
     if (j < a.lp.pn) { loop_product<TPW, KW>(a.lp, a.U, true, x, j, local, sm); return; }
     const int b = (j - a.lp.pn) * 8 + x;
     if (b >= a.B) return;
@@ -1945,6 +1954,8 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
     d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
     d.lp = LoopProd{};
+    d.lp.status = f->status;
+    d.lp.budget = 1 << (((f->flags >> 8) & 31) ? ((f->flags >> 8) & 31) : 21);
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
     d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;

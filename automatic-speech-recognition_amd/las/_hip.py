@@ -33,7 +33,7 @@ class SpellerFwdArgs(Structure):
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
         ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
         ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p),
-        ("ws", c_void_p), ("ws_bytes", c_size_t)]
+        ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p)]
 
 
 class BeamLoopArgs(Structure):
@@ -474,11 +474,17 @@ SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PRE
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
                  "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_XPROJ_CHUNK=0)",
-              2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound"}
+              2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound",
+              3: "Speller loop kernel: a partner workgroup was not seen within the poll bound (the one-launch decode loop needs one "
+                 "workgroup per compute unit co-resident; on a shared / partitioned device set LAS_NO_FUSED_STEP=1)"}
 
 
 def seq_p(p):
     return (int(p) & 0xf) << 8
+
+
+def speller_spin_log2(n):
+    return (int(n) & 0x1f) << 8
 
 
 def seq_spin_log2(n):

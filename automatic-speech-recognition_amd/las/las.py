@@ -106,6 +106,7 @@ def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, b
     fa.cs = bufs["cs"].data_ptr() if bufs["cs"] is not None else None
     fa.gates, fa.xin0 = bufs["gates"].data_ptr(), bufs["xin0"].data_ptr()
     fa.ws, fa.ws_bytes = None, 0
+    fa.status = _hip.status_word(enc.device).data_ptr()      # a loop-kernel poll time-out is reported here (never a trap / hang)
     return keep
 
 

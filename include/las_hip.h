@@ -221,6 +221,7 @@ int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* ga
  *   gates [NL,U,B,G*D] activated gates (lstm) / pre-activation scratch (rnn)
  *   xin0 [U,B,E+Hd+D]  first-layer cell input rows  [emb(token) ; context ; h_prev]
  */
+enum { LAS_SPELLER_STATUS_TIMEOUT = 3 };   /* (LAS_SEQ_STATUS_* are 1 and 2) */
 enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetching row kernels (generic bf16 rows) */
        LAS_SPELLER_NO_BF_ROWS = 2,    /* speed mode with the fp32-operand row kernels */
        LAS_SPELLER_NO_FUSED_STEP = 4,   /* speed mode with two launches per step (row kernel, then the cell product)
@@ -228,6 +229,7 @@ enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetchin
        LAS_SPELLER_REUSE_PREP = 8 };    /* (las_speller_bwd: operand copies only) the workspace still holds the bf16 copies of enc / keys / Ws and the
                                            packed cell weights that an earlier call made from the SAME tensors -- skip rebuilding
                                            them (beam search calls the step U = 1 at a time against a fixed encoder output) */
+#define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
     int flags;                     /* LAS_SPELLER_* development / test switches, 0 in normal use */
@@ -246,6 +248,11 @@ typedef struct {
                                       [V,E] noise matrix per decode step, shared by the rows that look up the same token */
     float *hs, *cs, *gates, *xin0;
     void* ws; size_t ws_bytes;
+    int* status;                   /* optional device int (the sweeps' status word): the one-launch loop kernels need all their
+                                      workgroups co-resident (one per compute unit); a workgroup that does not see a partner
+                                      within the poll bound stores LAS_SPELLER_STATUS_TIMEOUT here and the launch DRAINS
+                                      (every workgroup finishes its steps without waiting) instead of hanging or trapping --
+                                      results of that call are invalid, the host checks the word at its next synchronisation */
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
 int las_speller_fwd(const las_speller_fwd_args* a, void* stream);

@@ -130,3 +130,48 @@ def test_backward_reuses_the_forward_operand_copies_only_when_nobody_else_used_t
         grads.append([enc.grad.cpu().clone()] + [st.vars[n].grad.detach().cpu().clone() for n in st.order])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_loop_kernel_poll_timeout_is_reported_and_the_launch_drains():
+    """the one-launch loop kernels used to __builtin_trap() (abort the context) when a partner workgroup was not
+    seen within the poll bound.  Now the wave stores LAS_SPELLER_STATUS_TIMEOUT in the status word and ends, the launch drains in
+    bounded time, and the host raises at its next status check -- forced here with a poll budget of 2 (LAS_SPELLER_SPIN_LOG2(1)),
+    in a child process so that a regression can only cost the child."""
+    import subprocess, sys, os
+    from helpers import PKG, ROOT
+    script = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, torch
+from helpers import make_args
+from las import _hip, layers as L, variables as V
+from las.las import Speller
+L.set_cell("lstm"); L.set_precision("bf16")
+V.reset_default_store(device="cuda", seed=3)
+args = make_args(enc_units=256, num_enc_layers=2, dec_units=512, num_dec_layers=1, embedding_size=64, attention_size=128, mode="add", vocab_size=30)
+sp = Speller(args)
+rng = np.random.RandomState(1)
+enc = torch.tensor(rng.randn(48, 160, 512).astype(np.float32) * 0.5, device="cuda", requires_grad=True)
+y = rng.randint(3, 30, size=(48, 12))
+_hip.speller_flags = _hip.speller_spin_log2(1)
+logits, _, _ = sp(enc, np.full(48, 160), 12, teacher=y, is_training=True)
+logits.sum().backward()
+_hip.join_side_stream()
+torch.cuda.synchronize()
+try:
+    _hip.check_status()
+    print("NO_ERROR")
+except RuntimeError as e:
+    print("RAISED", "status 3" in str(e))
+_hip.speller_flags = 0
+V.default_store().zero_grad()
+logits, _, _ = sp(enc, np.full(48, 160), 12, teacher=y, is_training=True)      # and the normal budget works right after
+logits.sum().backward()
+_hip.join_side_stream()
+torch.cuda.synchronize()
+_hip.check_status()
+print("CLEAN", bool(torch.isfinite(logits).all()))
+''' % (PKG, ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RAISED True" in r.stdout and "CLEAN True" in r.stdout, r.stdout[-2000:]
