@@ -992,7 +992,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             u32x4_t q0[KW], q1[KW];
 #pragma unroll
             for (int u = 0; u < KW; ++u) { q0[u] = granule16_load(ars, aoff[u]); q1[u] = granule16_load(ars, aoff[u] + 16u); }
-            int budget = a.lp.budget;
+            int budget = p.budget;
                 for (;;) {
                 bool ok = true;
 #pragma unroll
