@@ -993,7 +993,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
 #pragma unroll
             for (int u = 0; u < KW; ++u) { q0[u] = granule16_load(ars, aoff[u]); q1[u] = granule16_load(ars, aoff[u] + 16u); }
             int budget = p.budget;
-                for (;;) {
+            for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int u = 0; u < KW; ++u) ok &= q0[u].x == tag && q0[u].w == tag && q1[u].x == tag && q1[u].w == tag;

@@ -206,7 +206,7 @@ _ws_epoch = {}
 def workspace(dev, nbytes, tag="default"):
     """Grow-only scratch buffer per (device, tag).  Every request bumps the tag's epoch: a caller that wants to find what its
     previous call left in the buffer (the Speller's backward reusing the forward's operand copies) compares epochs."""
-    key = (str(dev), tag)
+    key = (_devkey(dev), tag)
     _ws_epoch[key] = _ws_epoch.get(key, 0) + 1
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -216,7 +216,7 @@ def workspace(dev, nbytes, tag="default"):
 
 
 def workspace_epoch(dev, tag):
-    return _ws_epoch.get((str(dev), tag), 0)
+    return _ws_epoch.get((_devkey(dev), tag), 0)
 
 
 GEMM_WS_BYTES = 256 << 20
@@ -510,9 +510,18 @@ seq_flags, speller_flags = _flags_from_env()
 _status = {}
 
 
+def _devkey(dev):
+    """'cuda:<index>' for any spelling of a device ('cuda', torch.device('cuda'), a tensor's device): ONE status word /
+    probe / overlap record per physical device"""
+    d = torch.device(dev) if not isinstance(dev, torch.device) else dev
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 def status_word(dev):
     """The sticky int32 device word the sweeps report exchange timeouts through (one per device)."""
-    key = str(dev)
+    key = _devkey(dev)
     t = _status.get(key)
     if t is None:
         t = torch.zeros(2, dtype=torch.int32, device=dev)      # [0] sticky error code, [1] launch announcements (LAS_SEQ_ANNOUNCE)
@@ -537,7 +546,7 @@ def streams_overlap(dev):
     the current stream, then the store it waits for on the other stream.  Under a tool that serialises kernels (rocprofv3
     --pmc), or when two streams share one hardware queue, the waiter runs into its bound; the cross-stream hand-overs are then
     switched off."""
-    key = str(dev)
+    key = _devkey(dev)
     if key not in _overlap:
         ok = True
         for other in (side_stream(), chain_stream()):
@@ -570,7 +579,7 @@ def check_status(dev=None):
     """Synchronising check of the sweep status word(s): raises RuntimeError if any sweep reported a timeout.
     Call it wherever the host already waits for the device (loss read-out, end of a bench loop, checkpoint)."""
     for key, t in list(_status.items()):
-        if dev is not None and str(dev) != key:
+        if dev is not None and _devkey(dev) != key:
             continue
         code = int(t[0].item())
         if code:
@@ -588,7 +597,7 @@ def poll_status(dev):
     """Non-blocking companion of check_status for callers that never wait for the device (LAS.train called in a loop
     without reading the loss): enqueue a copy of the status word to pinned host memory; when an EARLIER probe has
     completed with a non-zero code, raise.  A timeout is therefore reported at most a couple of steps late."""
-    key = str(dev)
+    key = _devkey(dev)
     if key not in _status:
         return
     pr = _probe.get(key)

@@ -41,11 +41,18 @@ STEP_BYTES_PER_UTT = 115e6
 STEP_FLOPS_PER_UTT = 34.3e9
 
 
-def bench_args(cell):
+def bench_args(cell, config=1):
+    """config 1 (default): BASELINE configs[1] -- char units, additive attention (the headline).
+    config 3: BASELINE configs[3] -- subword vocabulary (V = 5000, train_subword.py) + location-aware attention at the reference
+    defaults K = 201, C = 10 (las/arguments.py:130-137), same listener / speller sizes: the per-step row kernels with the conv1d over
+    the previous alignment (the one-launch loop serves additive attention only)."""
     from helpers import make_args
-    return make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128,
-                     attention_size=128, mode="add", lr=1e-3, grad_clip=5.0, label_smoothing=True,
-                     scheduled_sampling=True, vocab_size=30)
+    kw = dict(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128,
+              attention_size=128, mode="add", lr=1e-3, grad_clip=5.0, label_smoothing=True,
+              scheduled_sampling=True, vocab_size=30)
+    if config == 3:
+        kw.update(mode="loc", loc_kernel_size=201, loc_num_channels=10, vocab_size=5000, unit="subword")
+    return make_args(**kw)
 
 
 def sweep_bytes(B, T, H, G, bwd, f=2):
@@ -310,6 +317,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--frames", type=int, default=1274)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3], help="BASELINE.json configs[] index (1 = headline, 3 = subword + location-aware)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
@@ -361,7 +369,7 @@ def main():
     L.set_precision(a.dtype)
     torch.manual_seed(1000003 + rank)
     V.reset_default_store(device=dev, seed=0)
-    args = bench_args(a.cell)
+    args = bench_args(a.cell, a.config)
     las = LAS(args, Listener, Speller, {})
     las.dp = dp
     las.build_variables()
@@ -458,15 +466,22 @@ def main():
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype if a.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "LibriSpeech-100 char LAS (BASELINE configs[1]): 3xpBLSTM-256 listener + 1x%s-512 "
-                                   "speller, additive attention, MFCC-39, bucket B=%d T=%d, U=%d, V=30; full train "
-                                   "step fwd+bwd+clip+Adam" % (a.cell.upper(), B, T, U),
+            "config": {"workload": ("LibriSpeech-100 char LAS (BASELINE configs[1]): 3xpBLSTM-256 listener + 1x%s-512 "
+                                    "speller, additive attention, MFCC-39, bucket B=%d T=%d, U=%d, V=30; full train "
+                                    "step fwd+bwd+clip+Adam" % (a.cell.upper(), B, T, U)) if a.config == 1 else
+                                   ("LibriSpeech-360 subword LAS (BASELINE configs[3], one rank of it): 3xpBLSTM-256 listener + "
+                                    "1x%s-512 speller, location-aware attention K=201 C=10, V=5000, MFCC-39, bucket B=%d T=%d, "
+                                    "U=%d; full train step fwd+bwd+clip+Adam" % (a.cell.upper(), B, T, U)),
                        "cell": a.cell, "per_gpu_batch": B, "global_batch": B * world, "frames": T, "dec_steps": U,
                        "parallelism": "dp%d" % world, "params": st.num_params()},
             "roofline": roof,
             "loss": round(loss, 4),
             "kernel_ms": {k: [round(v[0], 3), v[1] // a.steps] for k, v in sorted(per.items())},
         }
+        out["scale_measured"] = world > 1           # (no multi-GPU node was available to rounds 1-3: until a line with n_gpus > 1 exists, the
+                                                    #  data-parallel path is covered by gloo / RCCL-world-1 tests only)
+        if a.config != 1:
+            a.no_train_loop = a.no_decode = a.no_cpu_baseline = True       # side legs belong to the headline configuration
         if world == 1 and not a.no_train_loop:
             try:
                 out["train_loop"] = train_loop_bench(las, dev, a, value)

@@ -33,6 +33,11 @@ def _worker(rank, world, port, out_path, prec="f32"):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from las.parallel import DataParallel
+    from las import _hip
+    # two PROCESSES share the one GPU of the test box: the one-launch Speller loop needs all of its 256 workgroups co-resident
+    # (one per compute unit), which two concurrent launches cannot both have -- per-step kernels here (one process per GPU, the
+    # real deployment, never shares)
+    _hip.speller_flags = _hip.SPELLER_NO_FUSED_STEP
     args, las, st = _setup("lstm", prec)
     las.dp = DataParallel()
     las.build_variables()

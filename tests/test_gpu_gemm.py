@@ -157,21 +157,25 @@ def test_weight_gradient_form_bf16_tn(M, N, K, batch):
     """las_gemm with bf16 operands that are both k-strided (dW = X^T . dZ): served by gemm_tn_tr_kernel ([k][m] LDS tiles read
     with ds_read_b64_tr_b16) when M, N are multiples of 128 (or M <= 64, a multiple of 8) -- split-K, a contraction length that is no multiple of 32, element
     offsets into wider tensors, batched with strides, beta = 1 accumulation; against float64 on the same bf16 values, and against
-    the register-transposing kernel it replaced (las_dev_gemm_tn_tr(0))."""
+    the register-transposing kernel it replaced when the library was built with the development switches (`make prof`:
+    las_dev_gemm_tn_tr(0); the shipping library does not export them)."""
     from las import _hip
     g = torch.Generator().manual_seed(M + N + K + batch)
     X = (torch.randn(batch, K, M + 64, generator=g) * 0.5).cuda().to(torch.bfloat16)           # operands are column slices of wider tensors
     Z = (torch.randn(batch, K, 2 * N, generator=g) * 0.5).cuda().to(torch.bfloat16)
     C0 = torch.randn(batch, M, N, generator=g).cuda()
     res = []
-    for on in (1, 0):
-        _hip.lib().las_dev_gemm_tn_tr(on)
+    dev_switch = getattr(_hip.lib(), "las_dev_gemm_tn_tr", None) if hasattr(_hip.lib(), "las_dev_gemm_tn_tr") else None
+    for on in (1, 0) if dev_switch is not None else (1,):
+        if dev_switch is not None:
+            dev_switch(on)
         C = C0.clone()
         _hip.gemm(_hip.PREC_BF16, X, Z, C, True, False, M, N, K, M + 64, 2 * N, N, beta=1.0, batch=batch,
                   strideA=K * (M + 64), strideB=K * 2 * N, strideC=M * N, a_off=64, b_off=N)
         res.append(C.double().cpu())
-    _hip.lib().las_dev_gemm_tn_tr(1)
+    if dev_switch is not None:
+        dev_switch(1)
     ref = C0.double().cpu() + X[:, :, 64:].double().cpu().transpose(1, 2) @ Z[:, :, N:].double().cpu()
     tol = 3e-6 * K ** 0.5 * max(1.0, ref.abs().max().item())                                  # fp32 accumulation of exact bf16 products
     assert (res[0] - ref).abs().max().item() < tol
-    assert (res[0] - res[1]).abs().max().item() < tol
+    assert len(res) == 1 or (res[0] - res[1]).abs().max().item() < tol

@@ -77,6 +77,10 @@ def initial_weights(args, seed=5):
     return {n: st.vars[n].detach().cpu().numpy().copy() for n in st.order}
 
 
+def window_means(losses, w=25):
+    return [float(np.mean(losses[i:i + w])) for i in range(0, len(losses) - w + 1, w)]
+
+
 def run_mode(prec, corpus, p0, args, steps, B, order_seed=0):
     from las import layers as L, variables as V
     from las.las import LAS, Listener, Speller
@@ -120,7 +124,8 @@ def main():
     ap.add_argument("--fpc", type=int, default=8)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--noise", type=float, default=0.3)
-    ap.add_argument("--modes", default="f32,bf16")
+    ap.add_argument("--modes", default="f32,bf16,f32p", help="f32p = the CONTROL: parity mode from initial weights perturbed by 1e-6 "
+                    "(relative): how far two correct runs drift apart by themselves")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     corpus = LearnableCorpus(a.utts, a.frames, a.fpc, seed=1, noise=a.noise)
@@ -128,14 +133,20 @@ def main():
     p0 = initial_weights(args)
     out = {"config": vars(a), "modes": {}}
     for prec in a.modes.split(","):
-        out["modes"][prec] = run_mode(prec, corpus, p0, args, a.steps, a.batch)
+        if prec == "f32p":
+            rng = np.random.RandomState(99)
+            pp = {n: (v * (1.0 + 1e-6 * rng.randn(*v.shape))).astype(np.float32) for n, v in p0.items()}
+            out["modes"][prec] = run_mode("f32", corpus, pp, args, a.steps, a.batch)
+        else:
+            out["modes"][prec] = run_mode(prec, corpus, p0, args, a.steps, a.batch)
         r = out["modes"][prec]
-        print("%s: loss %s -> %.4f, WER %.4f, exact %.3f, e.g. %s" % (prec, ["%.3f" % v for v in r["loss"][::25]], r["loss"][-1], r["wer"],
-                                                                   r["exact"], r["examples"][:2]), file=sys.stderr)
+        r["window_mean_25"] = window_means(r["loss"])
+        print("%s: mean loss per 25 steps %s -> %.4f, WER %.4f, exact %.3f, e.g. %s" % (
+            prec, ["%.3f" % v for v in r["window_mean_25"]], r["loss"][-1], r["wer"], r["exact"], r["examples"][:2]), file=sys.stderr)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(out, f)
-    print(json.dumps({k: {"loss_every_25": [round(v, 4) for v in r["loss"][::25]], "final_loss": round(r["loss"][-1], 4), "wer": r["wer"],
+    print(json.dumps({k: {"window_mean_25": [round(v, 4) for v in r["window_mean_25"]], "final_loss": round(r["loss"][-1], 4), "wer": r["wer"],
                           "exact": r["exact"]} for k, r in out["modes"].items()}))
 
 
