@@ -74,6 +74,7 @@ struct DecDev {
     float *Q, *dQ;         // [U,B,A]
     float* duRows;         // [B,A]
     float* dAext;          // [B,Tp]   grad wrt alpha_t arriving from step t+1's location conv
+    float* dVbuf;          // [B,Tp,A] location-aware attention: the step's d(pre-tanh) rows (dWf is contracted from them)
     float* dKeys;          // [B,Tp,A]
     float *dlocwRows, *dlocbRows, *dWfRows;   // [B,Kc*C], [B,C], [B,C*A]
     const float* rec[LAS_MAX_NL]; int recLd[LAS_MAX_NL]; int recOff[LAS_MAX_NL];
@@ -119,6 +120,7 @@ __device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane hal
 // LDS carve shared by the forward and backward row kernels
 struct RowLds {
     float *s_state, *qv, *part, *ev, *hl, *aprev, *fc, *red, *x0, *x1, *x2, *ctxp;
+    float *locw, *wfl;        // location-aware attention: the conv filter [Kc, C] and Wf [C, A], staged once per kernel
     int* redi;
 };
 __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
@@ -132,6 +134,9 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
     r.hl = p;      p += a.D;
     r.aprev = p;   p += a.Tp;
     r.fc = p;      p += (a.mode == LAS_ATT_LOC ? a.Tp * a.C : 0);
+    if (a.mode == LAS_ATT_LOC) p += (4 - ((p - sm) & 3)) & 3;              // float4 reads of wfl
+    r.locw = p;    p += (a.mode == LAS_ATT_LOC ? (a.Kc * a.C + 3) / 4 * 4 : 0);
+    r.wfl = p;     p += (a.mode == LAS_ATT_LOC ? a.C * a.A : 0);
     r.red = p;     p += 32;
     r.redi = reinterpret_cast<int*>(p); p += 32;
     r.ctxp = p; p += RNH * a.Hd;
@@ -145,9 +150,26 @@ __device__ __forceinline__ RowLds carve(float* sm, const DecDev& a, bool bwd) {
 }
 static size_t row_lds_bytes(const DecDev& a, bool bwd) {
     size_t n = (size_t)a.D * a.NL + a.A + RNG * a.A + a.Tp + a.D + a.Tp + 64 + RNH * a.Hd;
-    if (a.mode == LAS_ATT_LOC) n += (size_t)a.Tp * a.C;
+    if (a.mode == LAS_ATT_LOC) n += (size_t)a.Tp * a.C + 4 + (a.Kc * a.C + 3) / 4 * 4 + (size_t)a.C * a.A;
     if (bwd) n += a.Hd + a.Tp + (a.mode == LAS_ATT_LOC ? (size_t)a.Tp * a.C : 0);
     return n * sizeof(float) + 64;
+}
+
+// location-aware attention: the filter and Wf are read Tp x C x Kc (resp. Tp x A x C) times per step -- from LDS, not through the L1
+__device__ __forceinline__ void stage_loc_weights(const RowLds& L, const DecDev& a, int tid) {
+    for (int i = tid; i < a.Kc * a.C; i += RNT) L.locw[i] = a.loc_w[i];
+    for (int i = tid; i < a.C * a.A; i += RNT) L.wfl[i] = a.Wf[i];
+}
+// f[t', c] = bias[c] + sum_k prev_align[t' + k - pad] * w[k, c]   (conv1d, SAME, cross-correlation: las/layers.py:295-296)
+__device__ __forceinline__ void loc_conv_fwd(const RowLds& L, const DecDev& a, int tid) {
+    const int Tp = a.Tp, C = a.C, pad = (a.Kc - 1) / 2;
+    for (int i = tid; i < Tp * C; i += RNT) {
+        const int tt = i / C, c = i - tt * C;
+        const int k0 = pad - tt > 0 ? pad - tt : 0, k1 = a.Kc < Tp + pad - tt ? a.Kc : Tp + pad - tt;     // taps that meet a frame
+        float acc = a.loc_b[c];
+        for (int k = k0; k < k1; ++k) acc = fmaf(L.aprev[tt + k - pad], L.locw[k * C + c], acc);
+        L.fc[i] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,9 +236,11 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
         const int l = i / D, d = i % D;
         L.s_state[i] = (l == TOP && t > 0) ? L.hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
     }
-    if (LOC)
+    if (LOC) {
         for (int i = tid; i < Tp; i += RNT)
             L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+        stage_loc_weights(L, a, tid);
+    }
     __syncthreads();
 
     {   // query projection q = s . Ws : RNG k-groups x 32 float4 lanes over A, 8 independent 16-byte loads in flight per thread
@@ -244,18 +268,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
             reinterpret_cast<float4*>(L.part + kg * A)[a0] = acc;
         }
     }
-    if (LOC) {  // f = conv1d(prev_align) (SAME, cross-correlation, bias): las/layers.py:295-296
-        const int pad = (a.Kc - 1) / 2;
-        for (int i = tid; i < Tp * a.C; i += RNT) {
-            const int tt = i / a.C, c = i % a.C;
-            float acc = a.loc_b[c];
-            for (int k = 0; k < a.Kc; ++k) {
-                const int src = tt + k - pad;
-                if (src >= 0 && src < Tp) acc = fmaf(L.aprev[src], a.loc_w[k * a.C + c], acc);
-            }
-            L.fc[i] = acc;
-        }
-    }
+    if (LOC) loc_conv_fwd(L, a, tid);   // f = conv1d(prev_align)
     __syncthreads();
     for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
                     if (loc && tt < Tp) {
                         for (int c = 0; c < a.C; ++c) {
                             const float f = L.fc[tt * a.C + c];
-                            const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                            const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
                             p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
                         }
                     }
@@ -1148,22 +1161,13 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
         for (int i = tid; i < Hd; i += RNT) dctx[i] = dxr[E + i];
         for (int i = tid; i < Tp; i += RNT) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
         for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
-        if (loc) for (int i = tid; i < Tp; i += RNT)
-            L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
-        __syncthreads();
         if (loc) {
-            const int pad = (a.Kc - 1) / 2;
-            for (int i = tid; i < Tp * a.C; i += RNT) {
-                const int tt = i / a.C, c = i % a.C;
-                float acc = a.loc_b[c];
-                for (int k = 0; k < a.Kc; ++k) {
-                    const int src = tt + k - pad;
-                    if (src >= 0 && src < Tp) acc = fmaf(L.aprev[src], a.loc_w[k * a.C + c], acc);
-                }
-                L.fc[i] = acc;
-                dfc[i] = 0.f;
-            }
+            for (int i = tid; i < Tp; i += RNT)
+                L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+            stage_loc_weights(L, a, tid);
         }
+        __syncthreads();
+        if (loc) loc_conv_fwd(L, a, tid);          // recompute f = conv1d(prev_align) (dfc is written for every frame below)
         const int len = a.enc_len[b];
         const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
         {   // dalpha[t'] = dctx . enc[b,t',:]   (+ what step t+1's location conv sent back)
@@ -1243,14 +1247,11 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
             if (tt >= Tp) continue;
             const float de = dal[tt];
             float4* dkp = reinterpret_cast<float4*>(a.dKeys + ((size_t)b * Tp + tt) * A);
-            float dfc_l[16];
-            if (loc) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) dfc_l[c] = 0.f;
-            }
+            float4 dvs[2];
 #pragma unroll
             for (int slot = 0; slot < 2; ++slot) {
                 const int a4 = sl + 32 * slot;
+                dvs[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a4 >= A / 4) continue;
                 const float4 k4 = kpre[u][slot];
                 const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
@@ -1259,7 +1260,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
                 if (loc) {
                     for (int c = 0; c < a.C; ++c) {
                         const float f = L.fc[tt * a.C + c];
-                        const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
+                        const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
                         p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
                     }
                 }
@@ -1275,32 +1276,47 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
                     dk.x += dv.x; dk.y += dv.y; dk.z += dv.z; dk.w += dv.w;
                     dkp[a4] = dk;
                 }
-                if (loc) {
+                dvs[slot] = dv;
+                // the filter-projection gradient dWf[c, a] = sum_t' f[t', c] dv[t', a] is contracted AFTER this loop from the
+                // step's dv rows (a per-frame read-modify-write of the row-private [C, A] partials was a 50-deep dependent
+                // chain of global accesses per lane and step: 285 us per decode step at the reference's K = 201, C = 10)
+                if (loc) reinterpret_cast<float4*>(a.dVbuf + ((size_t)b * Tp + tt) * A)[a4] = dv;
+            }
+            if (loc) {   // d f[t', c] = sum_a dv[a] Wf[c, a]: one half-wave reduction per channel, nothing carried in registers
+                for (int c = 0; c < a.C; ++c) {
+                    float s1 = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        if (c < a.C) {
-                            const float4 w4 = reinterpret_cast<const float4*>(a.Wf + (size_t)c * A)[a4];
-                            dfc_l[c] += dv.x * w4.x + dv.y * w4.y + dv.z * w4.z + dv.w * w4.w;
-                            // dWf[c, a] += fc[t',c] * dv[a]   (row-private accumulation, reduced over rows after the loop)
-                            float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * RNG + grp) * a.C + c) * A) + a4;
-                            const float f = L.fc[tt * a.C + c];
-                            float4 o = *wr;
-                            o.x = fmaf(f, dv.x, o.x); o.y = fmaf(f, dv.y, o.y); o.z = fmaf(f, dv.z, o.z); o.w = fmaf(f, dv.w, o.w);
-                            *wr = o;
+                    for (int slot = 0; slot < 2; ++slot) {
+                        const int a4 = sl + 32 * slot;
+                        if (a4 < A / 4) {
+                            const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                            s1 += dvs[slot].x * w4.x + dvs[slot].y * w4.y + dvs[slot].z * w4.z + dvs[slot].w * w4.w;
                         }
                     }
-                }
-            }
-            if (loc) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c < a.C) {
-                        const float s2 = sub32_sum(dfc_l[c]);
-                        if (sl == 0) dfc[tt * a.C + c] = s2;
-                    }
+                    s1 = sub32_sum(s1);
+                    if (sl == 0) dfc[tt * a.C + c] = s1;
                 }
             }
           }
+        }
+        if (loc) {   // dWf partials: half-wave group g owns channel g % C and the frames t' = g / C (mod groups-per-channel)
+            __syncthreads();                                           // dVbuf rows of this workgroup are complete (and visible)
+            const int gpc = RNG / a.C;                                 // groups per channel (C <= 16 -> >= 2)
+            const int c = grp % a.C, part = grp / a.C;
+            if (part < gpc) {
+                for (int a4 = sl; a4 < A / 4; a4 += 32) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int tt = part; tt < Tp; tt += gpc) {
+                        const float f = L.fc[tt * a.C + c];
+                        const float4 dv = reinterpret_cast<const float4*>(a.dVbuf + ((size_t)b * Tp + tt) * A)[a4];
+                        acc.x = fmaf(f, dv.x, acc.x); acc.y = fmaf(f, dv.y, acc.y); acc.z = fmaf(f, dv.z, acc.z); acc.w = fmaf(f, dv.w, acc.w);
+                    }
+                    float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * RNG + grp) * a.C + c) * A) + a4;
+                    float4 o = *wr;
+                    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+                    *wr = o;
+                }
+            }
         }
         // reduce the 8 half-wave partials of du / dq through LDS
         __syncthreads();
@@ -1368,28 +1384,41 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
             }
         }
         if (loc) {   // conv1d backward: filter / bias partials per row, and d alpha_{t-1}
-            const int pad = (a.Kc - 1) / 2;
-            for (int i = tid; i < a.Kc * a.C; i += RNT) {
-                const int k = i / a.C, c = i % a.C;
+            const int pad = (a.Kc - 1) / 2, C = a.C;
+            for (int i = tid; i < a.Kc * C; i += RNT) {
+                const int k = i / C, c = i - k * C;
+                const int t0 = pad - k > 0 ? pad - k : 0, t1 = Tp < Tp + pad - k ? Tp : Tp + pad - k;
                 float acc = 0.f;
-                for (int tt = 0; tt < Tp; ++tt) {
-                    const int src = tt + k - pad;
-                    if (src >= 0 && src < Tp) acc = fmaf(dfc[tt * a.C + c], L.aprev[src], acc);
+                for (int tt = t0; tt < t1; ++tt) acc = fmaf(dfc[tt * C + c], L.aprev[tt + k - pad], acc);
+                a.dlocwRows[(size_t)b * a.Kc * C + i] += acc;
+            }
+            for (int c = tid; c < C; c += RNT) {
+                float acc = 0.f;
+                for (int tt = 0; tt < Tp; ++tt) acc += dfc[tt * C + c];
+                a.dlocbRows[(size_t)b * C + c] += acc;
+            }
+            // d alpha_{t-1}[src] = sum_k sum_c dfc[src - k + pad, c] w[k, c]: the taps of a source frame are split over NKC
+            // thread groups (160 threads x 2010 serial taps before), partial sums meet in LDS (the du / dq scratch is free now)
+            const int NKC = RNT / Tp > 0 ? (RNT / Tp < 8 ? RNT / Tp : 8) : 1;
+            __syncthreads();
+            for (int i = tid; i < NKC * Tp; i += RNT) {
+                const int kc = i / Tp, src = i - kc * Tp;
+                const int kper = (a.Kc + NKC - 1) / NKC;
+                int k0 = kc * kper, k1 = k0 + kper < a.Kc ? k0 + kper : a.Kc;
+                if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
+                if (k1 > src + pad + 1) k1 = src + pad + 1;
+                float acc = 0.f;
+                for (int k = k0; k < k1; ++k) {
+                    const float* dr = dfc + (src - k + pad) * C;
+                    const float* wr = L.locw + k * C;
+                    for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
                 }
-                a.dlocwRows[(size_t)b * a.Kc * a.C + i] += acc;
+                L.part[i] = acc;
             }
-            for (int c = tid; c < a.C; c += RNT) {
-                float acc = 0.f;
-                for (int tt = 0; tt < Tp; ++tt) acc += dfc[tt * a.C + c];
-                a.dlocbRows[(size_t)b * a.C + c] += acc;
-            }
+            __syncthreads();
             for (int src = tid; src < Tp; src += RNT) {
                 float acc = 0.f;
-                for (int k = 0; k < a.Kc; ++k) {
-                    const int tt = src - k + pad;
-                    if (tt >= 0 && tt < Tp)
-                        for (int c = 0; c < a.C; ++c) acc = fmaf(dfc[tt * a.C + c], a.loc_w[k * a.C + c], acc);
-                }
+                for (int kc = 0; kc < NKC; ++kc) acc += L.part[kc * Tp + src];
                 a.dAext[(size_t)b * Tp + src] = acc;
             }
         }
@@ -1881,7 +1910,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, gemm, total;
+    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, dV, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -1915,6 +1944,7 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.dlocw = o;  o += align256((size_t)B * (Kc > 0 ? Kc : 1) * (C > 0 ? C : 1) * f);
     w.dlocb = o;  o += align256((size_t)B * (C > 0 ? C : 1) * f);
     w.dWf = o;    o += align256((size_t)B * RNG * (C > 0 ? C : 1) * A * f);   // one slice per half-wave group
+    w.dV = o;     o += align256(C > 0 ? (size_t)B * Tp * A * f : 0);
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
@@ -1958,7 +1988,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.lp.budget = 1 << (((f->flags >> 8) & 31) ? ((f->flags >> 8) & 31) : 21);
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
-    d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr;
+    d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr; d.dVbuf = nullptr;
     for (int l = 0; l < LAS_MAX_NL; ++l) { d.rec[l] = nullptr; d.recLd[l] = 0; d.recOff[l] = 0; }
     return 0;
 }
@@ -2033,7 +2063,13 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     const int B = d.B, D = d.D, NL = d.NL, U = d.U, E = d.E, Hd = d.Hd, V = d.V;
     const int GD = G * D, I0D = E + Hd + D;
     const size_t lds = row_lds_bytes(d, false);
-    LAS_ARG(lds <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds);
+    LAS_ARG(lds <= 150 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds);
+    if (lds > 64 * 1024) {   // location-aware attention with the reference's K = 201, C = 10: the staged filter + Wf push the carve past 64 KB
+        static int attr__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_fwd_kernel<CELL, FAST, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        LAS_ARG(attr__ == 0, "hipFuncSetAttribute(dec_step_fwd_kernel) failed: %d", attr__);
+        LAS_ARG(d.mode == LAS_ATT_LOC, "speller: row state does not fit LDS (%zu bytes)", lds);
+    }
     for (int l = 0; l < NL && !f->keep_state0; ++l) {
         LAS_HIP(hipMemsetAsync(d.hs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
         if (CELL == LAS_CELL_LSTM) LAS_HIP(hipMemsetAsync(d.cs + (size_t)l * (U + 1) * B * D, 0, (size_t)B * D * sizeof(float), st));
@@ -2126,11 +2162,18 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     d.Q = (float*)(base + w.Q); d.dQ = (float*)(base + w.dQ); d.duRows = (float*)(base + w.duRows);
     d.dAext = (float*)(base + w.dAext); d.dKeys = bk->d_keys;
     d.dlocwRows = (float*)(base + w.dlocw); d.dlocbRows = (float*)(base + w.dlocb); d.dWfRows = (float*)(base + w.dWf);
+    d.dVbuf = (float*)(base + w.dV);
     float* tmp = (float*)(base + w.tmp);          // [NL][B][2D] input/recurrent grads of layers >= 1
     void* gws = base + w.gemm;
     const size_t gws_bytes = f->ws_bytes - w.gemm;
     const size_t lds = row_lds_bytes(d, true);
-    LAS_ARG(lds <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
+    LAS_ARG(lds <= 150 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
+    if (lds > 64 * 1024) {
+        static int attr__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_bwd_kernel<CELL, FAST, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        LAS_ARG(attr__ == 0, "hipFuncSetAttribute(dec_step_bwd_kernel) failed: %d", attr__);
+        LAS_ARG(d.mode == LAS_ATT_LOC, "speller bwd: row state does not fit LDS (%zu bytes)", lds);
+    }
 
     const bool skinny = FAST && (GD % 8) == 0 && las_skinny_ok(B, GD, I0D, GD, d.gates);
     void* packB = base + w.packB;

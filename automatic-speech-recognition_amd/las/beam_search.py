@@ -79,6 +79,8 @@ class BeamSearch(object):
             self.lm = language_model
         self._las = las
         self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
+        self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
+        self.last_timing = None
 
     # -- model calls (the reference's sess.run wrappers, las/beam_search.py:203-246) -------------------
     def _get_encode(self, sess, audio, audiolen):
@@ -129,7 +131,7 @@ class BeamSearch(object):
         import time
         tm = {}
         def mark(name):                                  # wall-clock marks (with a device sync) only when asked for
-            if os.environ.get("LAS_DECODE_TIMING") == "1":
+            if self.measure:
                 torch.cuda.synchronize(dev)
                 tm[name] = time.perf_counter()
         mark("start")
@@ -326,7 +328,8 @@ class BeamSearch(object):
             off += len(tts)
         results = [self._select_best_k(sel, NORM) for sel in results]
         mark("done")
-        if tm and os.environ.get("LAS_DECODE_PARTS") == "1":        # development aid: device time of the three parts of a step
+        parts = {}
+        if tm:        # device time of the three parts of a decode step (HIP events, 50 eager repetitions each, after the search)
             step.zero_(); step64.zero_()
             for name, fn in (("speller", speller_part), ("lm", lm_part if lm is not None else None), ("beam", beam_part)):
                 if fn is None:
@@ -340,13 +343,12 @@ class BeamSearch(object):
                             step.zero_(); step64.zero_()
                     e1.record()
                 torch.cuda.synchronize(dev)
-                tm_ = e0.elapsed_time(e1) / 50 * 1e3
-                print("decode step part %-8s %.1f us" % (name, tm_))
-        if tm:
+                parts[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
             ks = list(tm)
             self.last_timing = {ks[i + 1]: round(tm[ks[i + 1]] - tm[ks[i]], 4) for i in range(len(ks) - 1)}
-            self.last_timing["steps"] = steps_run
-            print("decode_batch timing (s):", self.last_timing)
+            self.last_timing.update(steps=steps_run, rows=N, frames=Tp, graph=graph is not None, parts_us=parts)
+            if self.args.verbose > 0:
+                print("decode_batch timing (s):", self.last_timing)
         return results
 
     def restore_las(self, sess, save_path, restore_epoch):

@@ -212,8 +212,36 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = max(len(r[-1].token_ids) - 1 for r in res)
+    # a second, instrumented pass (device syncs between the phases, then the three parts of a step timed alone with HIP events):
+    # where the time of a decode step goes, and the dominant part against the HBM roof
+    bs.measure = True
+    bs.decode_batch(None, utts)
+    tm = bs.last_timing or {}
+    bs.measure = False
+    parts = tm.get("parts_us", {})
+    N, Tp = nutt * beam, tm.get("frames", 160)
+    D, A, Hd, E = args.dec_units, args.attention_size, 2 * args.enc_units, args.embedding_size
+    f = 2 if dtype == "bf16" else 4
+    # algorithmic HBM bytes of one decode step = every DISTINCT operand once (all rows of an utterance share its keys / encoder
+    # rows, all rows share the weights; re-reads are L2 hits by construction): Speller = Ws + per-utterance keys and encoder rows
+    # + the cell weights + the rows' state in and out; LM = its two cell kernels (fp32 masters, converted in the loader) + state
+    sp_bytes = D * A * f + nutt * Tp * (A + Hd) * f + (E + Hd + D) * 4 * D * f + N * (2 * 2 * D * 4 + Tp * 4 * 2)
+    lm_bytes = ((28 + 512) * 2048 + (512 + 512) * 2048) * 4 + N * 2 * 2 * 2 * 512 * 4
+    roof = None
+    if parts:
+        dom = max(parts, key=parts.get)
+        byts = {"speller": sp_bytes, "lm": lm_bytes}.get(dom, 0)
+        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> + skinny_rows_kernel (256 rows: per-step kernels)",
+                                                          "lm": "gemm_bf16_fast_kernel x5 + lstm_pointwise_kernel x2",
+                                                          "beam": "beam_loop_kernel + beam_gather_kernel + beam_advance_kernel"}[dom],
+                "us_per_decode_step": parts[dom], "algorithmic_bytes_per_step": int(byts),
+                "achieved": round(byts / (parts[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(byts / (parts[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "latency-bound: one decode step is a chain of ~25 dependent small kernels over %d rows" % N}
     return {"value": round(nutt / dt, 2), "unit": "utterances/s", "beam": beam, "lm": "2x512 char RNNLM, lm_weight 0.5",
             "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 3),
+            "us_per_decode_step": round((tm.get("searched", 0.0)) / max(tm.get("steps", 1), 1) * 1e6, 1) if tm else None,
+            "phases_s": {k: tm[k] for k in ("encoded", "searched", "done") if k in tm}, "step_parts_us": parts, "roofline": roof,
             "note": "utterances of equal length share one encoder launch (rows are independent; the reference encoder has no length "
                     "mask, so utterances are never padded to a common length); the search runs all utterances x beam rows per "
                     "step on the device, one captured step replayed as a HIP graph"}
@@ -321,6 +349,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
+    ap.add_argument("--decode-only", action="store_true", help="only the decode leg (BASELINE configs[4]); prints its JSON object")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_only:
@@ -365,6 +394,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         dp = DataParallel()
 
+    if a.decode_only:
+        out = decode_bench(dev, a.cell, a.dtype)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"decode": out}), flush=True)
+        return
     L.set_cell(a.cell)
     L.set_precision(a.dtype)
     torch.manual_seed(1000003 + rank)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collect the per-round measurement evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_evidence.sh r2        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,bucket_sweep.txt}
+#   tools/collect_evidence.sh r3        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,bucket_sweep.txt,
+#                                          decode_{bench.json,kernel_stats.csv,pmc.csv,pmc.json},speller_phase_stamps.txt}
+# (build first: make -C automatic-speech-recognition_amd/csrc all prof; hipcc ... -DLAS_ROW_STAMPS tools/micro/bench_fused.hip -o tools/micro/bin/bench_fused_stamps)
 # rocprofv3 databases go to /tmp (they exceed gpurun's 64 MiB merge limit); only the summaries are kept.  Counter passes are
 # separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); python3 bench.py directly after `--`.
 set -u
@@ -25,5 +27,18 @@ unset LAS_XPROJ_CHUNK LAS_DOUT_CHUNK
 cp gpurun_out/${P}_pmc.json profiles/${P}_pmc.json 2>/dev/null
 LAS_PHASES=1 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_phases.txt     # stderr: spans of the phases / sweeps (HIP events)
 python3 tools/prof_rnn.py > gpurun_out/${P}_phase_stamps.txt 2>&1
+# ---- decode leg (BASELINE configs[4]: beam 16 + 2x512 char RNNLM, 16 utterances x 16 beams = 256 rows per step): its own kernel
+# trace, counter passes (HBM bytes, MFMA busy, waits) and bench object with the per-part timing / roofline
+rocprofv3 --kernel-trace --stats -d /tmp/kt_dec_$P -o b -- python3 bench.py --decode-only > gpurun_out/${P}_decode_kt.log 2>&1
+python3 tools/rocpd_summary.py "$(ls /tmp/kt_dec_$P/*/*_results.db /tmp/kt_dec_$P/*_results.db 2>/dev/null | head -1)" gpurun_out/${P}_decode_kernel_stats.csv > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_dec_${P}_$c -o p -- python3 bench.py --decode-only > /tmp/pmc_dec_${P}_$c.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+  -d /tmp/pmc_dec_${P}_SQ -o p -- python3 bench.py --decode-only > /tmp/pmc_dec_${P}_SQ.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${P}_decode /tmp/pmc_dec_${P}_FETCH_SIZE /tmp/pmc_dec_${P}_WRITE_SIZE /tmp/pmc_dec_${P}_SQ > gpurun_out/${P}_decode_pmc_summary.log 2>&1
+python3 bench.py --decode-only > gpurun_out/${P}_decode_bench.json 2> /dev/null
+# ---- Speller loop kernels: phase stamps of one decode step (row workgroup 0 and product workgroup 0 on one clock)
+[ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps > gpurun_out/${P}_speller_phase_stamps.txt 2>&1
 python3 tools/bucket_sweep.py > gpurun_out/${P}_bucket_sweep.txt 2>&1
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300

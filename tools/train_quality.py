@@ -105,8 +105,9 @@ def run_mode(prec, corpus, p0, args, steps, B, order_seed=0):
     for lo in range(0, n, B):
         idx = np.arange(lo, min(lo + B, n))
         xs, _ = corpus.batch(idx)
-        # utterances are padded to one common length; greedy decoding runs int(convert_rate * max audiolen) steps (las/las.py:310-312)
-        _, y_hat = las.inference((xs[0], np.full(len(idx), corpus.audio.shape[1], np.int32)))
+        # greedy decoding runs int(convert_rate * max audiolen) steps (las/las.py:310-312): 8 frames per character -> 1.33 steps per
+        # character of the longest utterance, enough for its <EOS>; the attention mask follows the true lengths, as in training
+        _, y_hat = las.inference(xs)
         hyp += [convert_idx_to_string(r, corpus.tok.id_to_token, "char") for r in y_hat.cpu().numpy().tolist()]
     # corpus WER as test.py:127-136 computes it: summed word-level edit distance / summed reference words
     pairs = [edit_distance(t.split(" "), h.split(" ")) for t, h in zip(corpus.texts, hyp)]
