@@ -1306,9 +1306,22 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
             if (part < gpc) {
                 for (int a4 = sl; a4 < A / 4; a4 += 32) {
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int tt = part; tt < Tp; tt += gpc) {
+                    const float4* dvp = reinterpret_cast<const float4*>(a.dVbuf + (size_t)b * Tp * A) + a4;
+                    int tt = part;
+                    for (; tt + 7 * gpc < Tp; tt += 8 * gpc) {                  // 8 independent 16-byte loads in flight
+                        float4 dv8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) dv8[u] = dvp[(size_t)(tt + u * gpc) * (A / 4)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float f = L.fc[(tt + u * gpc) * a.C + c];
+                            acc.x = fmaf(f, dv8[u].x, acc.x); acc.y = fmaf(f, dv8[u].y, acc.y);
+                            acc.z = fmaf(f, dv8[u].z, acc.z); acc.w = fmaf(f, dv8[u].w, acc.w);
+                        }
+                    }
+                    for (; tt < Tp; tt += gpc) {
                         const float f = L.fc[tt * a.C + c];
-                        const float4 dv = reinterpret_cast<const float4*>(a.dVbuf + ((size_t)b * Tp + tt) * A)[a4];
+                        const float4 dv = dvp[(size_t)tt * (A / 4)];
                         acc.x = fmaf(f, dv.x, acc.x); acc.y = fmaf(f, dv.y, acc.y); acc.z = fmaf(f, dv.z, acc.z); acc.w = fmaf(f, dv.w, acc.w);
                     }
                     float4* wr = reinterpret_cast<float4*>(a.dWfRows + (((size_t)b * RNG + grp) * a.C + c) * A) + a4;
