@@ -681,6 +681,19 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
     const float v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
     if (!(col & 3)) granule16_store(rs, (unsigned)((row_gran + (col >> 2)) * 16), tag, f2bf2(v, v1), f2bf2(v2, v3), local);
 }
+// Where the row kernels issue the bulk loads that are consumed two phases later (measured with tools/micro/bench_fused.hip,
+// B = 48, T' = 160, profiles/r3_speller_phase_stamps.txt):
+//   LAS_E8_LATE (forward, the context's encoder rows, 164 KB per row and step): inside the energies phase instead of in front of the
+//       q reduction -- the q-reduction phase shrinks 1.32 -> 0.56 us, the energies phase grows 2.28 -> 3.12 us: 12.48 vs 12.51 us
+//       per step, no gain (a wave that waits to issue vector memory is not covered by the other waves' transcendentals) -> off;
+//   LAS_W8_LATE (backward, the Ws rows of the state gradient, 128 KB): one load per frame inside the energies-gradient loop instead
+//       of all at once in front of a barrier: 10.75 -> 10.50 us per step -> on.
+#ifndef LAS_E8_LATE
+#define LAS_E8_LATE 0
+#endif
+#ifndef LAS_W8_LATE
+#define LAS_W8_LATE 1
+#endif
 #ifndef LAS_ABL_SP
 #define LAS_ABL_SP 0   // development: bit mask of parts of the forward row to leave out (timing experiments only; make abl_sp ABL=<mask>)
 #endif
@@ -831,14 +844,21 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     }
     lds_barrier();
     STAMPX(3);
-    // encoder rows for the context: issued now (the Ws registers are free), consumed after the softmax
+    // encoder rows for the context (the Ws registers are free now), consumed after the softmax.  164 KB per row and step: at the
+    // L1's 64 B / clock that is 1.07 us of vector-memory issue.  Issued here -- by all 16 waves at once, in front of the q
+    // reduction that only waves 0-1 execute -- those two waves sat in the issue queue for ~1 us while the other 14 waited at the
+    // barrier (phase stamps: 1.32 us for a 16-term sum).  LAS_E8_LATE: the loads are issued in NK portions between the frames of
+    // the energies phase instead, where the other waves of a SIMD have transcendental work to cover a wave that waits to issue.
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
     uint4 e8[NE];
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
+    auto e8_load = [&](const int u) __attribute__((always_inline)) {
         const int tp = fg + 8 * u;
         const int tpc = tp < Tp2 ? tp : Tp2 - 1;
         e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp2 + tpc) * H4 + h4c];
+    };
+    if (!LAS_E8_LATE) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) e8_load(u);
     }
     for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
@@ -856,6 +876,11 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         for (int e = 0; e < 8; ++e) q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f;
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
+            if (LAS_E8_LATE) {
+#pragma unroll
+                for (int v = u * NE / NK; v < (u + 1) * NE / NK; ++v) e8_load(v);
+                __builtin_amdgcn_sched_barrier(0);       // keep the portion in front of THIS frame's arithmetic
+            }
             const int tt = grp + 64 * u;
             float part = 0.f;
             if (tt < len && tt < Tp) {
@@ -1738,13 +1763,18 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 if (a8 == 0 && tt < Tp) dal[tt] = tt < lim ? v : 0.f;
             }
         }
-        // the state-gradient operand: issued now (the encoder registers are free), consumed after the energies
+        // the state-gradient operand (the encoder registers are free), consumed after the energies: 128 KB per row and step.
+        // LAS_W8_LATE: issued one load per frame inside the energies-gradient loop (transcendental work of the other waves covers
+        // a wave that waits to issue) instead of all at once in front of a barrier -- see pf_fwd_row
         uint4 w8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        auto w8_load = [&](const int u) __attribute__((always_inline)) {
             const int kk = grp + 64 * u;
             const int kkc = kk < S ? kk : S - 1;
             w8[u] = reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kkc * A8 + a8c];
+        };
+        if (!LAS_W8_LATE) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8_load(u);
         }
         lds_barrier();
     STAMPX(14);
@@ -1771,6 +1801,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             float du0 = 0.f, du1 = 0.f, dq0 = 0.f, dq1 = 0.f;
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
+                if (LAS_W8_LATE && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
                 const int t2 = wv + RNW * u;
                 const float de = t2 < lim ? dal[t2] : 0.f;
                 const float v0 = tanhx<FAST>(__uint_as_float(k2[u] << 16) + q0), v1 = tanhx<FAST>(__uint_as_float(k2[u] & 0xffff0000u) + q1);

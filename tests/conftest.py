@@ -12,6 +12,14 @@ for p in (PKG, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is thousands of tiny matmuls ([8, 256] x [256, 1024] per recurrent step): on the GPU box (256 logical CPUs)
+    # torch picks 128 intra-op threads and every one of those calls pays a 128-way fork / join -- 29 ms per call, 254 s for ONE
+    # oracle step of the T = 1274 cases against 3.7 s with 16 threads (measured with tools/prof_oracle.py).  Eight is plenty.
+    try:
+        import torch
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -7,7 +7,11 @@ V=5000
 args = make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128,
                  mode="loc", loc_kernel_size=201, loc_num_channels=10, vocab_size=V, unit="subword", lr=1e-3, grad_clip=5.0, label_smoothing=True)
 prec=sys.argv[1]; nthr=int(sys.argv[2])
-torch.set_num_threads(nthr)
+if nthr > 0:
+    torch.set_num_threads(nthr)
+if len(sys.argv) > 3:
+    x = torch.zeros(4, device='cuda'); torch.cuda.synchronize()
+print('threads', torch.get_num_threads(), 'affinity', len(os.sched_getaffinity(0)), 'cuda_init', len(sys.argv) > 3)
 xs, ys = synthetic_batch(8, 1274, 24, V, seed=12, min_frac=0.9)
 ys = (ys[0][:, :12], np.minimum(ys[1], 12)); ys[0][np.arange(8), ys[1]-1]=2
 U=12
