@@ -2053,7 +2053,9 @@ static bool pf_rows_ok(const DecDev& d) {
 constexpr int LOOP_TPW_F = 5, LOOP_KW_F = 3, LOOP_TPW_B = 3, LOOP_KW_B = 4;
 static bool loop_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
     const int R = cdiv(d.B, 8), pn = las_device_cus() / 8 - R;
-    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && pf_rows_ok(d) && (d.E % 4) == 0 && (d.D % 4) == 0 && (d.Hd % 4) == 0 &&
+    // (U >= 4: a launch of the persistent grid costs ~100 us before its first step -- 256 workgroups, placement handshake -- which
+    //  30 us saved per step only repays from the fourth step on; beam search calls the step with U = 1: 141 vs 43 us, r3 decode trace)
+    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && d.U >= 4 && pf_rows_ok(d) && (d.E % 4) == 0 && (d.D % 4) == 0 && (d.Hd % 4) == 0 &&
            ((d.E + d.Hd + d.D) % 8) == 0 && (K % 8) == 0 && R <= 16 && pn >= 1 && pn + R <= 32 && pn * tpw >= cdiv(ncols, 16) &&
            16 * kw >= cdiv(K, 32);
 }

@@ -132,10 +132,11 @@ def cpu_baseline_child(cell, budget_s=45.0):
         olm = (oracle_lm(lm_params(np.random.RandomState(8), 28, 0, 512, 2), 0, 2), 512, 2)
         xs1, _ = synthetic_batch(1, T, 8, 30, seed=100)
         t0 = time.time()
-        res = oracle_decode(xs1, p0, dargs, cell, 16, lm=olm, lm_weight=0.5)
+        res = oracle_decode(xs1, p0, dargs, cell, 16, lm=olm, lm_weight=0.5, hoist=False)       # as written: keys re-projected per step
         dt = time.time() - t0
         dec = {"value": round(1.0 / dt, 4), "unit": "utterances/s", "cores": ncores,
-               "sample": "oracle beam search (las/beam_search.py:61-158 restated, torch-CPU fp32), 1 utterance, %d steps, %.1f s"
+               "sample": "oracle beam search (las/beam_search.py:61-158 restated as written: key projection recomputed at every step for "
+                         "every hypothesis row, torch-CPU fp32), 1 utterance, %d steps, %.1f s"
                          % (max(len(r.token_ids) - 1 for r in res), dt)}
     except Exception as e:                                  # the train baseline must not depend on this leg
         dec = {"value": None, "sample": "oracle decode failed: %s" % e}
@@ -300,6 +301,14 @@ def train_loop_bench(las, dev, a, value, steps=20, warmup=4):
             feed.close()
             out[name] = {"value": round(n_utt / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
                          "vs_resident_batch": round(n_utt / dt / value, 4), "losses_logged": len(seen)}
+        rd = tdl.tfrecord_iterator(files, tdl.data_parser, 13, seed=0, native=True)[0]
+        t0, n_rd = time.perf_counter(), 0
+        for _ in range(60):                                     # the reader alone: parse + bucket + assemble into pinned slots
+            bslot = rd.next_slot()
+            n_rd += bslot.B
+            rd.release(bslot)
+        out["reader_alone"] = {"value": round(n_rd / (time.perf_counter() - t0), 0), "note": "csrc/input.hip producer thread, no device copy"}
+        rd.close()
         out["unit"] = "utterances/s"
         out["note"] = ("the loop of train.py on the headline's bucket: reader thread + pinned staging + host->device copy on a copy "
                        "stream included, loss logged without synchronising; tfrecord = the C++ reader of liblas_hip.so on files "
@@ -307,6 +316,31 @@ def train_loop_bench(las, dev, a, value, steps=20, warmup=4):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+def parity_mode_bench(dev, a, xs, ys, steps=5, warmup=2):
+    """The same step in the PARITY mode (--dtype f32: fp32 storage and arithmetic everywhere, the mode the f32 rows of the parity
+    table are measured in): reported beside the speed-mode headline so that the price of exactness is on record."""
+    from las import layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    L.set_precision("f32")
+    try:
+        V.reset_default_store(device=dev, seed=0)
+        las = LAS(bench_args(a.cell, a.config), Listener, Speller, {})
+        las.build_variables()
+        for _ in range(warmup):
+            las.train(xs, ys)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            las.train(xs, ys)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        las.check_status()
+        return {"dtype": "f32", "ms_per_step": round(dt / steps * 1e3, 3), "value": round(xs[0].shape[0] * steps / dt, 1),
+                "unit": "utterances/s", "steps": steps}
+    finally:
+        L.set_precision(a.dtype)
 
 
 def self_launch(n, argv):
@@ -517,6 +551,15 @@ def main():
                                                     #  data-parallel path is covered by gloo / RCCL-world-1 tests only)
         if a.config != 1:
             a.no_train_loop = a.no_decode = a.no_cpu_baseline = True       # side legs belong to the headline configuration
+        if world == 1 and a.dtype == "bf16" and a.config == 1 and not a.no_train_loop:
+            try:
+                out["parity_mode"] = parity_mode_bench(dev, a, xs, ys)
+            except Exception as e:
+                out["parity_mode"] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            L.set_precision(a.dtype)
+            V.reset_default_store(device=dev, seed=0)           # (the legs below build their own models)
+            las = LAS(args, Listener, Speller, {})
+            las.build_variables()
         if world == 1 and not a.no_train_loop:
             try:
                 out["train_loop"] = train_loop_bench(las, dev, a, value)

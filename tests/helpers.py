@@ -128,18 +128,20 @@ def oracle_lm(p, E, NL):
     return lm
 
 
-def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0, prec="f32"):
+def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0, prec="f32", hoist=True):
     """BeamSearch.decode of ONE utterance through the oracle (CPU): xs = (audio [1,T,39,1|3], audiolen [1]); lm = (oracle_lm(...), H, NL).
-    prec="bf16": the oracle's speed-mode arithmetic (oracle_mode_for) for the whole search."""
+    prec="bf16": the oracle's speed-mode arithmetic (oracle_mode_for) for the whole search.  hoist=False: the key projection
+    dense(hidden) is recomputed inside every decode step for every hypothesis row, as the reference does (las/beam_search.py:216 feeds
+    np.tile(h) to a graph whose attention layer projects it again, las/layers.py:250) -- same values, the reference's cost."""
     from oracle import las_oracle as O
     O.set_precision(*oracle_mode_for(args, prec))
     try:
-        return _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight)
+        return _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist)
     finally:
         O.set_precision("f32")
 
 
-def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight):
+def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist=True):
     import torch
     from oracle import las_oracle as O
     NL = args.num_dec_layers
@@ -159,7 +161,8 @@ def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight):
                 else:
                     stt.append(torch.cat([s[l] for s in states]))
             lg, ns, al = O.speller_decode(h.expand(N, -1, -1), el.repeat(N), stt, emb[torch.tensor(prev_ids)],
-                                          torch.tensor(np.stack(prev_al), dtype=torch.float32), po, args, cell, keys.expand(N, -1, -1))
+                                          torch.tensor(np.stack(prev_al), dtype=torch.float32), po, args, cell,
+                                          keys.expand(N, -1, -1) if hoist else None)
             outs = [tuple((ns[l][0][i:i + 1], ns[l][1][i:i + 1]) if cell == "lstm" else ns[l][i:i + 1] for l in range(NL))
                     for i in range(N)]
             return lg.numpy(), outs, al.numpy()

@@ -71,7 +71,7 @@ SHAPES = [
     (2, 64, 32, 64, 4, 21, 7, True),          # multi-layer state (generic bf rows)
     (1, 96, 136, 36, 3, 70, 5, False),        # attention width > 128 (two 16-byte chunks per lane), ragged sizes
     (1, 128, 64, 64, 3, 181, 4, False),       # T' in (160, 192]: pf<.,12>
-    (1, 128, 64, 64, 2, 214, 3, True),        # T' in (192, 224]: pf<.,14>
+    (1, 128, 64, 64, 2, 214, 4, True),        # T' in (192, 224]: pf<.,14>
     (1, 64, 32, 32, 2, 230, 3, False),        # T' > 224: generic bf16 row kernels
     # the geometry bench.py times (D = 512, A = 128, Hd = 512, T' = 160) with MORE THAN ONE utterance per XCD group of the
     # one-launch loop kernels: utterance b = 8 r + x is tile row r of group x, so B = 9 / 17 / 48 exercise Rx = 2 / 3 / 6 row
