@@ -1004,7 +1004,8 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
 template <bool ABF>
 __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
-                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias) {
+                                                             float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                             int accumulate) {
     constexpr int NW = 8;
     __shared__ float red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -1057,6 +1058,7 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) v += red[ww][l2][reg];
             if (bias) v += bias[col];
+            if (accumulate) v += C[(long long)orow * ldc + col];
             C[(long long)orow * ldc + col] = v;
         }
     }
@@ -1066,7 +1068,7 @@ int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, i
                     hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     hipLaunchKernelGGL(skinny_rows_kernel<false>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
-                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias);
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, 0);
     LAS_LAUNCHED();
     return 0;
 }
@@ -1076,7 +1078,28 @@ int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const v
                          const float* bias, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     hipLaunchKernelGGL(skinny_rows_kernel<true>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
-                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias);
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, 0);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+
+// ---- C ABI of the skinny-M product (include/las_hip.h): weights packed once, then C[M,N] (+)= bf16(A[M,K]) . bf16(W) + bias per call
+extern "C" size_t las_gemm_skinny_pack_bytes(int K, int N) { return K > 0 && N > 0 ? las_skinny_pack_bytes(K, N) : 0; }
+
+extern "C" int las_gemm_skinny_pack(const float* W, int ldw, int K, int N, void* packed, void* stream) {
+    LAS_ARG(W && packed && K > 0 && N > 0 && ldw >= N, "las_gemm_skinny_pack: bad arguments");
+    LAS_ARG((K % 8) == 0, "las_gemm_skinny_pack: K must be a multiple of 8 (got %d)", K);
+    return las_skinny_pack(W, ldw, K, N, 0, packed, (hipStream_t)stream);
+}
+
+extern "C" int las_gemm_skinny(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
+                               int accumulate, void* stream) {
+    LAS_ARG(A && packed && C && N > 0 && ldc >= N, "las_gemm_skinny: bad arguments");
+    LAS_ARG(las_skinny_ok(M, K, N, lda, A), "las_gemm_skinny: needs 1 <= M <= 1024, K %% 8 == 0, lda %% 4 == 0, A 16-byte aligned");
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    hipLaunchKernelGGL(skinny_rows_kernel<false>, dim3(nct, MT), dim3(512), 0, (hipStream_t)stream, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, accumulate ? 1 : 0);
     LAS_LAUNCHED();
     return 0;
 }

@@ -250,8 +250,12 @@ class CharRNN(object):
     def fusion_plan(self, lm_weight):
         """Constants of a beam search with shallow fusion (made once per search): the first layer's input rows for the
         one-hot case (W_x[id], rounded like a bf16 GEMM operand in speed mode) and the output projection pre-scaled by
-        lm_weight, so that the step can ADD lm_weight * lm_logits into the acoustic logits with the GEMM's own beta."""
+        lm_weight, so that the step can ADD lm_weight * lm_logits into the acoustic logits with the GEMM's own beta.
+        Speed mode: every product of the step goes through the skinny-M kernel (las_gemm_skinny, M = beam rows), so the
+        recurrent / input halves of the cell kernels and the scaled output projection are packed into bf16 MFMA fragments
+        here, once (r3 decode trace: five M = 256 GEMMs at ~30 us each were 127 of a step's 270 us)."""
         P = self.params()
+        H = self.hidden_size
         k0 = P["cells"][0][0].detach()
         plan = {"w": float(lm_weight)}
         if self.embedding_size == 0:
@@ -259,6 +263,16 @@ class CharRNN(object):
             plan["wx"] = (wx.to(torch.bfloat16).to(torch.float32) if L._prec() == _hip.PREC_BF16 else wx).contiguous()
         plan["sw"] = (P["softmax_w"].detach() * plan["w"]).contiguous()
         plan["sb"] = (P["softmax_b"].detach() * plan["w"]).contiguous()
+        if L._prec() == _hip.PREC_BF16 and H % 8 == 0 and (self.embedding_size == 0 or self.input_size % 8 == 0):
+            packs = []
+            for l, (k, b) in enumerate(P["cells"]):
+                k = k.detach()
+                I = k.shape[0] - H
+                hh = _hip.skinny_pack(k, H, 4 * H, row0=I)                         # recurrent rows
+                ih = None if (l == 0 and "wx" in plan) else _hip.skinny_pack(k, I, 4 * H)
+                packs.append((hh, ih))
+            plan["packs"] = packs
+            plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
     def step_fused(self, plan, ids, c_prev, h_prev, logits, col0):
@@ -273,19 +287,26 @@ class CharRNN(object):
         lib = _hip.lib()
         cs, hs = [], []
         x = None
+        skinny = "packs" in plan and N <= 1024
         with torch.no_grad():
             for l, (k, b) in enumerate(P["cells"]):
                 k, b = k.detach(), b.detach()
                 I = k.shape[0] - H
                 z = torch.empty(N, 4 * H, device=dev)
                 # recurrent half (+ bias), then the input half on top
-                _hip.gemm(prec, h_prev[l], k, z, False, False, N, 4 * H, H, H, 4 * H, 4 * H, bias=b, b_off=I * 4 * H)
+                if skinny:
+                    _hip.skinny_gemm(h_prev[l], plan["packs"][l][0], z, N, H, 4 * H, H, 4 * H, bias=b)
+                else:
+                    _hip.gemm(prec, h_prev[l], k, z, False, False, N, 4 * H, H, H, 4 * H, 4 * H, bias=b, b_off=I * 4 * H)
                 if l == 0 and "wx" in plan:
                     z += plan["wx"].index_select(0, ids)
                 else:
                     if l == 0:
                         x = P["embedding"].detach().index_select(0, ids)
-                    _hip.gemm(prec, x, k, z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, beta=1.0)
+                    if skinny:
+                        _hip.skinny_gemm(x, plan["packs"][l][1], z, N, I, 4 * H, I, 4 * H, accumulate=True)
+                    else:
+                        _hip.gemm(prec, x, k, z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, beta=1.0)
                 c_new = torch.empty(N, H, device=dev)
                 h_new = torch.empty(N, H, device=dev)
                 _hip.check(lib.las_lstm_pointwise(_hip.p(z), _hip.p(c_prev[l]), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
@@ -294,7 +315,10 @@ class CharRNN(object):
                 hs.append(h_new)
                 x = h_new
             V_all = logits.shape[1]
-            _hip.gemm(prec, x, plan["sw"], logits, False, False, N, Vn, H, H, Vn, V_all, beta=1.0, bias=plan["sb"], c_off=col0)
+            if skinny:
+                _hip.skinny_gemm(x, plan["swp"], logits, N, H, Vn, H, V_all, bias=plan["sb"], accumulate=True, c_off=col0)
+            else:
+                _hip.gemm(prec, x, plan["sw"], logits, False, False, N, Vn, H, H, Vn, V_all, beta=1.0, bias=plan["sb"], c_off=col0)
         return cs, hs
 
     def step(self, token_ids, states):

@@ -128,6 +128,9 @@ _SIGS = {
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_beam_loop_step": (c_int, [POINTER(BeamLoopArgs), c_void_p]),
+    "las_gemm_skinny_pack_bytes": (c_size_t, [c_int, c_int]),
+    "las_gemm_skinny_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "las_gemm_skinny": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "las_crc32c": (ctypes.c_uint, [c_char_p, c_size_t]),
     "las_input_open": (c_void_p, [POINTER(c_char_p), c_int, POINTER(InputConfig)]),
     "las_input_next": (c_int, [c_void_p, POINTER(InputBatch)]),
@@ -375,6 +378,22 @@ def gemm_kk(A, B, C, M, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, a_off=0, b
         return
     check(lib().las_gemm_kk(M, N, K, c_void_p(A.data_ptr() + 2 * a_off), lda, c_void_p(B.data_ptr() + 2 * b_off), ldb,
                             c_void_p(C.data_ptr() + C.element_size() * c_off), cdt, ldc, p(bias), act, stream()), "las_gemm_kk")
+
+
+def skinny_pack(W, K, N, ldw=None, row0=0):
+    """bf16 MFMA-fragment copy of W[row0:row0+K, :N] (fp32, row-major) for skinny_gemm; made once per weight version"""
+    require_gpu(W)
+    ldw = W.stride(0) if ldw is None else ldw
+    buf = torch.empty(int(lib().las_gemm_skinny_pack_bytes(K, N)), dtype=torch.uint8, device=W.device)
+    check(lib().las_gemm_skinny_pack(c_void_p(W.data_ptr() + 4 * row0 * ldw), ldw, K, N, p(buf), stream()), "las_gemm_skinny_pack")
+    return buf
+
+
+def skinny_gemm(A, packed, C, M, K, N, lda, ldc, bias=None, accumulate=False, c_off=0):
+    """C[M,N] (+)= bf16(A[M,K]) . packed + bias   (A, C fp32; 1 <= M <= 1024)"""
+    require_gpu(A, packed, C, bias)
+    check(lib().las_gemm_skinny(p(A), lda, M, K, p(packed), N, c_void_p(C.data_ptr() + 4 * c_off), ldc, p(bias), int(bool(accumulate)),
+                                stream()), "las_gemm_skinny")
 
 
 def _dt(t):

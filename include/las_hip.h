@@ -386,6 +386,20 @@ typedef struct {
 int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Skinny-M product for per-step recurrences driven from the host (the char RNNLM step inside beam search,
+ * lang/char_rnn_model.py:57-66 / las/beam_search.py:226-236; the Speller's own cell product uses the same kernel inside
+ * las_speller_fwd): the weight W [K, N] (row-major fp32, leading dimension ldw) is packed ONCE into bf16 MFMA fragments
+ * (las_gemm_skinny_pack_bytes(K, N) bytes), then every call computes C[M, N] = bf16(A[M, K]) . bf16(W) + bias (accumulate = 0) or
+ * C += ... (accumulate = 1) with fp32 accumulation, for 1 <= M <= 1024 rows: grid = (N / 16 column tiles) x (M / 16 row tiles),
+ * eight waves split K with every load in flight at once.  Same arithmetic as las_gemm in LAS_PREC_BF16 (operands rounded to
+ * bf16, fp32 sums) at a fifth of the time for M = 256.
+ */
+size_t las_gemm_skinny_pack_bytes(int K, int N);
+int las_gemm_skinny_pack(const float* W, int ldw, int K, int N, void* packed, void* stream);
+int las_gemm_skinny(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
+                    int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * F1  input side of the step loop: TFRecord reader + bucket_by_sequence_length + pinned batch ring + H2D upload
  * (reference tfrecord_data_loader.py:54-109: list_files / parallel_interleave(cycle_length 16) / map(data_parser) /
  * bucket_by_sequence_length(pad_to_bucket_boundary) / shuffle(64) / repeat / prefetch -- TensorFlow's C++ input threads in the

@@ -179,3 +179,30 @@ def test_weight_gradient_form_bf16_tn(M, N, K, batch):
     tol = 3e-6 * K ** 0.5 * max(1.0, ref.abs().max().item())                                  # fp32 accumulation of exact bf16 products
     assert (res[0] - ref).abs().max().item() < tol
     assert len(res) == 1 or (res[0] - res[1]).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 512, 2048), (17, 1024, 2048), (256, 512, 28), (1, 40, 16), (1000, 64, 100)])
+def test_skinny_gemm_matches_float64_on_the_rounded_operands(M, K, N):
+    """las_gemm_skinny_pack + las_gemm_skinny (the LM step's products in beam search; reference lang/char_rnn_model.py:57-66 driven
+    from las/beam_search.py:226-236): C = bf16(A) . bf16(W[row0:row0+K]) + bias, and the accumulate form into a column window of a
+    wider C -- against float64 on the same bf16-rounded operands (fp32 accumulation: 3e-6 sqrt(K))."""
+    from las import _hip
+    g = torch.Generator().manual_seed(M + K + N)
+    row0 = 24
+    W = (torch.randn(row0 + K, N + 8, generator=g) * 0.2).cuda()
+    A = (torch.randn(M, K, generator=g) * 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    packed = _hip.skinny_pack(W, K, N, row0=row0)
+    Ar, Wr = A.to(torch.bfloat16).double().cpu(), W[row0:, :N].to(torch.bfloat16).double().cpu()
+    ref = Ar @ Wr + bias.double().cpu()
+    tol = 3e-6 * K ** 0.5 * max(1.0, ref.abs().max().item())
+    C = torch.full((M, N), 7.0, device="cuda")
+    _hip.skinny_gemm(A, packed, C, M, K, N, K, N, bias=bias)
+    assert (C.double().cpu() - ref).abs().max().item() < tol
+    wide = torch.randn(M, N + 5, generator=g).cuda()
+    want = wide.double().cpu().clone()
+    want[:, 2:2 + N] += Ar @ Wr
+    _hip.skinny_gemm(A, packed, wide, M, K, N, K, N + 5, accumulate=True, c_off=2)
+    assert (wide.double().cpu() - want).abs().max().item() < tol
+    l = _hip.lib()
+    assert l.las_gemm_skinny(_hip.p(A), K, 2000, K, _hip.p(packed), N, _hip.p(C), N, None, 0, None) < 0      # M > 1024 is refused
