@@ -88,7 +88,7 @@ struct Cursor {
 };
 
 struct Record {              // one parsed utterance: pointers into the mmap'ed file, nothing copied yet
-    const float* feat = nullptr; size_t nfeat = 0;     // packed little-endian floats (alignment not assumed: memcpy only)
+    const uint8_t* feat = nullptr; size_t nfeat = 0;   // packed little-endian floats at ANY byte offset of the file: kept as bytes, memcpy only
     int T = 0, F = 0;
     std::vector<int> token;
 };
@@ -126,7 +126,7 @@ bool parse_example(const uint8_t* p, size_t n, Record& r) {
                 if (f4 == 2 && key == "feat") {                             // FloatList: one packed run (what TF writes)
                     int f5, w5; Cursor run{nullptr, nullptr};
                     while (lst.field(f5, w5, run, val))
-                        if (f5 == 1 && w5 == 2) { r.feat = (const float*)run.p; r.nfeat = (size_t)(run.e - run.p) / 4; }
+                        if (f5 == 1 && w5 == 2) { r.feat = run.p; r.nfeat = (size_t)(run.e - run.p) / 4; }
                     if (!lst.ok) return false;
                 } else if (f4 == 3 && key == "shape") { if (!parse_int64_list(lst, shape)) return false; }
                 else if (f4 == 3 && key == "token") { if (!parse_int64_list(lst, token)) return false; }

@@ -111,6 +111,46 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* re
     return bi;
 }
 
+// In-loop vocabulary projection of one row (greedy / sampled / beam steps; the after-loop GEMM serves teacher-forced training):
+// logits[v] = bv[v] + sum_d h[d] Wv[d, v] in the arithmetic of the mode, the greedy arg-max and the Gumbel-max sample.
+// Small vocabularies (char units: V = 30) left 994 of the 1024 threads idle behind 30 threads x D serial multiply-adds (~10 us per
+// decode step, every step of a beam search): now the largest power of two TPV <= min(RNT / V, 64) lanes share one logit (each sums
+// D / TPV terms, then a TPV-lane butterfly).  Large vocabularies (subword units, V = 5000) keep one thread per logit.
+template <bool FAST>
+__device__ __forceinline__ void row_logits(const DecDev& a, const float* __restrict__ h, const int t, const int b, const int tid,
+                                           float* red, int* redi, int& greedy_tok, int& sample_tok) {
+    const int V = a.V, D = a.D, B = a.B;
+    float bestv = -INFINITY, bests = -INFINITY;
+    int besti = 0x7fffffff, bestsi = 0x7fffffff;
+    float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
+    int tpv = 1;
+    while (tpv < 64 && tpv * 2 * V <= RNT) tpv *= 2;
+    if (tpv > 1) {
+        const int v = tid / tpv, part = tid - v * tpv, vc = v < V ? v : V - 1;
+        float acc = 0.f;
+        for (int d = part; d < D; d += tpv) acc = fmaf(opnd<FAST>(h[d]), opnd<FAST>(a.Wv[(size_t)d * V + vc]), acc);
+        for (int o = tpv >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (part == 0 && v < V) {
+            acc += a.bv[v];
+            lrow[v] = acc;
+            bestv = acc; besti = v;
+            bests = acc + gumbel_noise(a.seed, t, b, v); bestsi = v;
+        }
+    } else {
+        for (int v = tid; v < V; v += RNT) {
+            float acc = a.bv[v];
+            for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(h[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
+            lrow[v] = acc;
+            if (acc > bestv) { bestv = acc; besti = v; }
+            const float sc = acc + gumbel_noise(a.seed, t, b, v);
+            if (sc > bests) { bests = sc; bestsi = v; }
+        }
+    }
+    greedy_tok = block_argmax(bestv, besti, red, redi);
+    sample_tok = block_argmax(bests, bestsi, red, redi);
+    if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+}
+
 __device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane half-wave
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -209,20 +249,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
         }
         __syncthreads();
         if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
-            float bestv = -INFINITY, bests = -INFINITY;
-            int besti = 0x7fffffff, bestsi = 0x7fffffff;
-            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
-            for (int v = tid; v < V; v += RNT) {
-                float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.hl[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
-                lrow[v] = acc;
-                if (acc > bestv) { bestv = acc; besti = v; }
-                const float sc = acc + gumbel_noise(a.seed, t, b, v);
-                if (sc > bests) { bests = sc; bestsi = v; }
-            }
-            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
-            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
-            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+            row_logits<FAST>(a, L.hl, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
     if (t >= U) return;
@@ -463,20 +490,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
         }
         __syncthreads();
         if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
-            float bestv = -INFINITY, bests = -INFINITY;
-            int besti = 0x7fffffff, bestsi = 0x7fffffff;
-            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
-            for (int v = tid; v < V; v += RNT) {
-                float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.hl[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
-                lrow[v] = acc;
-                if (acc > bestv) { bestv = acc; besti = v; }
-                const float sc = acc + gumbel_noise(a.seed, t, b, v);
-                if (sc > bests) { bests = sc; bestsi = v; }
-            }
-            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
-            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
-            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+            row_logits<FAST>(a, L.hl, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
     if (t >= U) return;
@@ -801,20 +815,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         }
         lds_barrier();
         if (t > 0 && a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
-            float bestv = -INFINITY, bests = -INFINITY;
-            int besti = 0x7fffffff, bestsi = 0x7fffffff;
-            float* lrow = a.logits + ((size_t)(t - 1) * B + b) * V;
-            for (int v = tid; v < V; v += RNT) {
-                float acc = a.bv[v];
-                for (int d = 0; d < D; ++d) acc = fmaf(opnd<FAST>(L.s_state[d]), opnd<FAST>(a.Wv[(size_t)d * V + v]), acc);
-                lrow[v] = acc;
-                if (acc > bestv) { bestv = acc; besti = v; }
-                const float sc = acc + gumbel_noise(a.seed, t, b, v);
-                if (sc > bests) { bests = sc; bestsi = v; }
-            }
-            greedy_tok = block_argmax(bestv, besti, L.red, L.redi);
-            sample_tok = block_argmax(bests, bestsi, L.red, L.redi);
-            if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
+            row_logits<FAST>(a, L.s_state, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
     if (t >= U) return;
@@ -2150,7 +2151,10 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         LAS_LAUNCHED();
     }
     for (int t = 0; t <= U && !loop; ++t) {
-        if (pf && d.Tp <= 128)          hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        // (t == U only finishes the last cell [+ logits]: the prefetching kernel would issue a whole step's bulk loads first --
+        //  the generic bf16 row kernel loads on demand and returns after the cell; half of a beam-search step's Speller time)
+        if (pf && t == U)               hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, d, t);

@@ -232,8 +232,8 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     if parts:
         dom = max(parts, key=parts.get)
         byts = {"speller": sp_bytes, "lm": lm_bytes}.get(dom, 0)
-        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> + skinny_rows_kernel (256 rows: per-step kernels)",
-                                                          "lm": "gemm_bf16_fast_kernel x5 + lstm_pointwise_kernel x2",
+        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> + skinny_rows_kernel + dec_step_fwd_bf_kernel (cell finish + logits); 256 rows: per-step kernels",
+                                                          "lm": "skinny_rows_kernel x4 (las_gemm_skinny) + lstm_pointwise_kernel x2 + index_select / add",
                                                           "beam": "beam_loop_kernel + beam_gather_kernel + beam_advance_kernel"}[dom],
                 "us_per_decode_step": parts[dom], "algorithmic_bytes_per_step": int(byts),
                 "achieved": round(byts / (parts[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
