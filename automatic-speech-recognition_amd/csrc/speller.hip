@@ -75,6 +75,8 @@ struct DecDev {
     float* duRows;         // [B,A]
     float* dAext;          // [B,Tp]   grad wrt alpha_t arriving from step t+1's location conv
     float* dVbuf;          // [B,Tp,A] location-aware attention: the step's d(pre-tanh) rows (dWf is contracted from them)
+    float *fcSave, *dfcSave;   // [U,B,Tp,C] loop kernels, location-aware attention: conv output f of every step and its gradient
+                               // (the keys / Wf / filter gradients are contracted over the steps after the loop)
     float* dKeys;          // [B,Tp,A]
     float *dlocwRows, *dlocbRows, *dWfRows;   // [B,Kc*C], [B,C], [B,C*A]
     const float* rec[LAS_MAX_NL]; int recLd[LAS_MAX_NL]; int recOff[LAS_MAX_NL];
@@ -434,7 +436,12 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const float* __restrict_
     reinterpret_cast<unsigned int*>(dst)[(size_t)blockIdx.y * R2 * C + i] = f2bf2(lo, hi);
 }
 
-struct BfLds { float *s_state, *qv, *ev, *hl, *x0, *x1, *red, *scr; int* redi; };
+struct BfLds {
+    float *s_state, *qv, *ev, *hl, *x0, *x1, *red, *scr; int* redi;
+    // location-aware attention in the one-launch loop kernels: previous alignment, conv output f and its gradient, the gradient that
+    // step t + 1's conv sends back to alpha_t, the staged filter [Kc, C] and Wf [C, A]
+    float *aprev, *fc, *dfc, *daext, *locw, *wfl;
+};
 __device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
 __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     BfLds r; float* p = sm;
@@ -446,13 +453,40 @@ __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     r.x1 = p;      p += up4(a.Tp);      // bwd: d alpha / d energy
     r.red = p;     p += 32;
     r.redi = reinterpret_cast<int*>(p); p += 32;
+    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr;
+    if (a.mode == LAS_ATT_LOC) {
+        r.aprev = p; p += up4(a.Tp);
+        r.daext = p; p += up4(a.Tp);
+        r.fc = p;    p += up4(a.Tp * a.C);
+        r.dfc = p;   p += up4(a.Tp * a.C);
+        r.locw = p;  p += up4(a.Kc * a.C);
+        r.wfl = p;   p += up4(a.C * a.A);
+    }
     r.scr = p;                           // RNW x max(Hd, 2A) partials
     return r;
 }
 static size_t bf_lds_bytes(const DecDev& a) {
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
     const size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
-    return (u4((size_t)a.D * a.NL) + u4(a.A) + 2 * u4(a.Tp) + u4(a.D) + u4(a.Hd) + 64 + scr) * sizeof(float) + 64;
+    size_t loc = 0;
+    if (a.mode == LAS_ATT_LOC) loc = 2 * u4(a.Tp) + 2 * u4((size_t)a.Tp * a.C) + u4((size_t)a.Kc * a.C) + u4((size_t)a.C * a.A);
+    return (u4((size_t)a.D * a.NL) + u4(a.A) + 2 * u4(a.Tp) + u4(a.D) + u4(a.Hd) + 64 + loc + scr) * sizeof(float) + 64;
+}
+// location-aware attention, loop kernels: the conv1d over the previous alignment (las/layers.py:295-296; SAME, cross-correlation):
+// f[t', c] = bias[c] + sum_k aprev[t' + k - pad] w[k, c], filter and alignment in LDS, one (frame, channel) output per thread and round
+__device__ __forceinline__ void loc_conv_lds(const BfLds& L, const DecDev& a, const int tid) {
+    const int Tp = a.Tp, C = a.C, pad = (a.Kc - 1) / 2;
+    for (int i = tid; i < Tp * C; i += RNT) {
+        const int tt = i / C, c = i - tt * C;
+        const int k0 = pad - tt > 0 ? pad - tt : 0, k1 = a.Kc < Tp + pad - tt ? a.Kc : Tp + pad - tt;
+        float acc = a.loc_b[c];
+        for (int k = k0; k < k1; ++k) acc = fmaf(L.aprev[tt + k - pad], L.locw[k * C + c], acc);
+        L.fc[i] = acc;
+    }
+}
+__device__ __forceinline__ void loc_stage_lds(const BfLds& L, const DecDev& a, const int tid) {
+    for (int i = tid; i < a.Kc * a.C; i += RNT) L.locw[i] = a.loc_w[i];
+    for (int i = tid; i < a.C * a.A; i += RNT) L.wfl[i] = a.Wf[i];
 }
 
 template <int CELL, int NJ>
@@ -711,8 +745,9 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
 #ifndef LAS_ABL_SP
 #define LAS_ABL_SP 0   // development: bit mask of parts of the forward row to leave out (timing experiments only; make abl_sp ABL=<mask>)
 #endif
-template <int CELL, int NE, bool LOOP>
+template <int CELL, int NE, bool LOOP, bool LOC = false>
 __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, const int tid, float* sm, float& ccar, const bool local) {
+    static_assert(LOOP || !LOC, "location-aware attention is served by the loop kernels only (the per-step path is dec_step_fwd_kernel<.,.,true>)");
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
@@ -760,6 +795,16 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
     }
     STAMPX(1);
+    if (LOC) {
+        // f = conv1d(alpha_{t-1}): nothing in it depends on the gates of step t-1, so it runs while they are on their way.  The
+        // alignment of the previous step is in LDS already (written by this row's softmax; the loop's barrier orders it); step 0
+        // starts from align0 / zeros.
+        if (t == 0) {
+            if (tid < Tp) L.aprev[tid] = a.align0 ? a.align0[(size_t)b * Tp + tid] : 0.f;
+            lds_barrier();
+        }
+        if (t < U) loc_conv_lds(L, a, tid);              // (made visible by the barriers between here and the energies)
+    }
     if (LOOP && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
         const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
         u32x4_t gq[G];
@@ -875,6 +920,26 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         float q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) q8[e] = a8 < A8 ? L.qv[a8 * 8 + e] : 0.f;
+        float kf[LOC ? NK : 1][8];
+        if (LOC) {   // pre-activation = keys + q + f . Wf: channel-outer, so that a channel's Wf columns are read from LDS once
+#pragma unroll
+            for (int u = 0; u < NK; ++u) {
+                unpack8(k8[u], kf[LOC ? u : 0]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[LOC ? u : 0][e] += q8[e];
+            }
+            for (int c = 0; c < a.C; ++c) {
+                const float4 w0 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a8c * 2], w1 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a8c * 2 + 1];
+                const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+                    const float f = L.fc[ttc * a.C + c];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kf[LOC ? u : 0][e] = fmaf(f, wf[e], kf[LOC ? u : 0][e]);
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
             if (LAS_E8_LATE) {
@@ -885,10 +950,15 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             const int tt = grp + 64 * u;
             float part = 0.f;
             if (tt < len && tt < Tp) {
+                if (LOC) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) part = fmaf(u8[e], tanhx<FAST>(kf[LOC ? u : 0][e]), part);
+                } else {
                 float k[8];
                 unpack8(k8[u], k);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) part = fmaf(u8[e], (LAS_ABL_SP & 2) ? (k[e] + q8[e]) * 0.1f : tanhx<FAST>(k[e] + q8[e]), part);
+                }
             }
             part = sub16_sum(part);
             if (a8 == 0 && tt < Tp) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
@@ -911,6 +981,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             const int i0 = 2 * tid, i1 = 2 * tid + 1;
             const float al0 = expf(L.ev[i0] - m) * inv, al1 = i1 < Tp ? expf(L.ev[i1] - m) * inv : 0.f;
             ap[tid] = f2bf2(al0, al1);
+            if (LOC) { L.aprev[i0] = al0; if (i1 < Tp) L.aprev[i1] = al1; }      // next step's conv input (fp32)
             float* arow = a.alphas + ((size_t)t * B + b) * Tp;
             if (!(LAS_ABL_SP & 8)) {
             arow[i0] = al0;
@@ -1084,7 +1155,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
     }
 }
 
-template <int CELL, int NE>
+template <int CELL, int NE, bool LOC = false>
 __global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
     constexpr int TPW = 5, KW = 3;                                    // 26 x 5 column tiles >= 128, 16 waves x 3 k-steps x 32 >= 1280 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1095,10 +1166,11 @@ __global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
     const int b = (j - a.lp.pn) * 8 + x;
     if (b >= a.B) return;
     float ccar = 0.f;
+    if (LOC) loc_stage_lds(carve_bf(sm, a), a, threadIdx.x);          // filter + Wf: once per launch (step 0's barrier publishes them)
     for (int t = 0; t <= a.U; ++t) {
         int bb = b, tid = threadIdx.x;
         asm volatile("" : "+s"(bb), "+v"(tid));                       // keep the row's address arithmetic inside the iteration:
-        pf_fwd_row<CELL, NE, true>(a, t, bb, tid, sm, ccar, local);   // hoisted out of the loop it costs ~70 spilled VGPRs
+        pf_fwd_row<CELL, NE, true, LOC>(a, t, bb, tid, sm, ccar, local);   // hoisted out of the loop it costs ~70 spilled VGPRs
         lds_barrier();                                                // the next step rewrites the row's LDS state
     }
 }
@@ -1649,9 +1721,30 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 // LOOP (dec_loop_bwd_kernel): one iteration of a persistent row workgroup: the dXin0 row of step t_att (context and state
 // gradient) arrives as granules from the product workgroups, the bf16 gate gradient of step t_cell leaves as granules, dC and
 // the running du column are carried in registers.
-template <int CELL, int NE, bool LOOP>
+// sum of NV <= 16 per-lane values over the 64 lanes of a wave with 17 shuffles instead of 6 NV: a halving butterfly -- after the
+// exchange with lane ^ 32 a lane is responsible for 8 of the 16 values, after ^ 16 for 4, ... after ^ 4 for one, then two plain
+// steps.  Returns the total of value index ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
+// (every lane; lanes that differ only in bits 0-1 hold the same sum).
+__device__ __forceinline__ float wave_sum16(const float (&v)[16], const int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    float x[8], y[4], z[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = (b4 ? x[i + 4] : x[i]) + __shfl_xor(b4 ? x[i] : x[i + 4], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) z[i] = (b3 ? y[i + 2] : y[i]) + __shfl_xor(b3 ? y[i] : y[i + 2], 8, 64);
+    float w = (b2 ? z[1] : z[0]) + __shfl_xor(b2 ? z[0] : z[1], 4, 64);
+    w += __shfl_xor(w, 2, 64);
+    w += __shfl_xor(w, 1, 64);
+    return w;
+}
+
+template <int CELL, int NE, bool LOOP, bool LOC = false>
 __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, const int tid, float* sm,
                                            float& dccar, float& ducar, const bool local) {
+    static_assert(LOOP || !LOC, "location-aware attention is served by the loop kernels only");
+    constexpr int LC = 10;                            // channels the location-aware variant keeps in registers (a.C <= LC, host-checked)
     constexpr bool FAST = true;
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     constexpr int NK = (16 * NE + 63) / 64;            // frames per 16-lane group (64 groups): T' <= 16*NE
@@ -1676,6 +1769,12 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     float recv0 = 0.f;
     if (!LOOP) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
     const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
+    float apv = 0.f;                                  // LOC: the alignment that entered step t_att's conv (alpha_{t-1}, or align0 / zeros)
+    if (LOC) {
+        const float* aps = ta > 0 ? a.alphas + ((size_t)(ta - 1) * B + b) * Tp : (a.align0 ? a.align0 + (size_t)b * Tp : a.alphas + (size_t)b * Tp);
+        apv = aps[tpc];
+        if (ta == 0 && !a.align0) apv = 0.f;
+    }
     // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
     float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     if (LOOP && a2c >= A) qd = ducar;                 // (duRows starts at zero; the register copy is the live one)
@@ -1712,6 +1811,13 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
     } else {
         hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+    }
+    if (LOC && att) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way; keep it for the after-loop keys / Wf gradient
+        if (tid < Tp) L.aprev[tid] = apv;
+        lds_barrier();
+        loc_conv_lds(L, a, tid);
+        float* fs = a.fcSave + ((size_t)ta * B + b) * Tp * a.C;
+        for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];          // (a thread re-reads what it wrote itself)
     }
     if (LOOP && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
         const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
@@ -1761,7 +1867,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             for (int u = 0; u < NK; ++u) {
                 const int tt = grp + 64 * u;
                 const float v = sub16_sum(acc[u]);
-                if (a8 == 0 && tt < Tp) dal[tt] = tt < lim ? v : 0.f;
+                if (a8 == 0 && tt < Tp) dal[tt] = tt < lim ? (LOC && t + 1 < U ? v + L.daext[tt] : v) : 0.f;   // (+ what step t+1's conv sent back)
             }
         }
         // the state-gradient operand (the encoder registers are free), consumed after the energies: 128 KB per row and step.
@@ -1800,14 +1906,38 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         {   // energies backward: sums over this wave's frames stay in the lane (columns 2*lane, 2*lane+1)
             const float q0 = L.qv[2 * c2c], q1 = L.qv[2 * c2c + 1];
             float du0 = 0.f, du1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+            float2 wf2[LOC ? LC : 1];                 // LOC: this lane's two columns of every Wf row
+            if (LOC) {
+#pragma unroll
+                for (int c = 0; c < LC; ++c) wf2[c] = c < a.C ? reinterpret_cast<const float2*>(L.wfl + (size_t)c * A)[c2c] : make_float2(0.f, 0.f);
+            }
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
                 if (LAS_W8_LATE && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
                 const int t2 = wv + RNW * u;
                 const float de = t2 < lim ? dal[t2] : 0.f;
-                const float v0 = tanhx<FAST>(__uint_as_float(k2[u] << 16) + q0), v1 = tanhx<FAST>(__uint_as_float(k2[u] & 0xffff0000u) + q1);
+                float p0 = __uint_as_float(k2[u] << 16) + q0, p1 = __uint_as_float(k2[u] & 0xffff0000u) + q1;
+                if (LOC) {   // + f[t2, :] . Wf
+                    const float* fr = L.fc + (t2 < Tp ? t2 : Tp - 1) * a.C;
+#pragma unroll
+                    for (int c = 0; c < LC; ++c) {
+                        const float f = c < a.C ? fr[c] : 0.f;
+                        p0 = fmaf(f, wf2[c].x, p0); p1 = fmaf(f, wf2[c].y, p1);
+                    }
+                }
+                const float v0 = tanhx<FAST>(p0), v1 = tanhx<FAST>(p1);
                 du0 = fmaf(de, v0, du0); du1 = fmaf(de, v1, du1);
-                dq0 = fmaf(de * u2.x, 1.f - v0 * v0, dq0); dq1 = fmaf(de * u2.y, 1.f - v1 * v1, dq1);
+                if (!LOC) { dq0 = fmaf(de * u2.x, 1.f - v0 * v0, dq0); dq1 = fmaf(de * u2.y, 1.f - v1 * v1, dq1); }
+                if (LOC) {   // d f[t2, c] = sum over the attention columns of dv . Wf[c, :]: one butterfly over the wave for all channels
+                    const float dv0 = de * u2.x * (1.f - v0 * v0), dv1 = de * u2.y * (1.f - v1 * v1);
+                    dq0 += dv0; dq1 += dv1;
+                    float pv[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) pv[c] = (c < LC && lane < A2) ? dv0 * wf2[c < LC ? c : 0].x + dv1 * wf2[c < LC ? c : 0].y : 0.f;
+                    const float tot = wave_sum16(pv, lane);
+                    const int ci = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                    if (!(lane & 3) && ci < a.C && t2 < Tp) L.dfc[t2 * a.C + ci] = tot;
+                }
             }
             if (lane < A2) {
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A)[lane] = make_float2(dq0, dq1);
@@ -1841,6 +1971,34 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 acc = dot2bf(w8[u].y, q4.y, acc); acc = dot2bf(w8[u].z, q4.z, acc); acc = dot2bf(w8[u].w, q4.w, acc);
                 acc = sub16_sum(acc);
                 if (a8 == 0 && i < S) dhs[i] = acc;
+            }
+        }
+        if (LOC) {
+            // d f of this step is complete (the barriers of the dq / du reduction): keep it for the after-loop filter gradient, and send
+            // d alpha_{t-1}[src] = sum_k sum_c dfc[src - k + pad, c] w[k, c] back to the previous step: the taps of a source frame are
+            // split over NKC thread groups, the partial sums meet in the (free) partials scratch
+            const int C = a.C, pad = (a.Kc - 1) / 2;
+            float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
+            for (int i = tid; i < Tp * C; i += RNT) ds[i] = L.dfc[i];
+            const int NKC = RNT / Tp > 0 ? (RNT / Tp < 8 ? RNT / Tp : 8) : 1, kper = (a.Kc + NKC - 1) / NKC;
+            for (int i = tid; i < NKC * Tp; i += RNT) {
+                const int kc = i / Tp, src = i - kc * Tp;
+                int k0 = kc * kper, k1 = k0 + kper < a.Kc ? k0 + kper : a.Kc;
+                if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
+                if (k1 > src + pad + 1) k1 = src + pad + 1;
+                float acc = 0.f;
+                for (int k = k0; k < k1; ++k) {
+                    const float* dr = L.dfc + (src - k + pad) * C;
+                    const float* wr = L.locw + k * C;
+                    for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
+                }
+                L.scr[i] = acc;
+            }
+            lds_barrier();
+            if (tid < Tp) {
+                float acc = 0.f;
+                for (int kc = 0; kc < NKC; ++kc) acc += L.scr[kc * Tp + tid];
+                L.daext[tid] = acc;
             }
         }
         lds_barrier();
@@ -1890,7 +2048,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_at
 // dXin0[t] = dG(t) . W0^T from the gate-gradient granules of step t (plain fp32 copy of every column for the after-loop
 // contractions + granules for the chain columns [E, I0D)), the row workgroups run attention backward of step t + 1 and
 // the gate backward of step t
-template <int CELL, int NE>
+template <int CELL, int NE, bool LOC = false>
 __global__ __launch_bounds__(RNT) void dec_loop_bwd_kernel(DecDev a) {
     constexpr int TPW = 3, KW = 4;                                    // 26 x 3 column tiles >= 64, 16 waves x 4 k-steps x 32 >= 2048 (host-checked)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1900,12 +2058,105 @@ __global__ __launch_bounds__(RNT) void dec_loop_bwd_kernel(DecDev a) {
     const int b = (j - a.lp.pn) * 8 + x;
     if (b >= a.B) return;
     float dccar = 0.f, ducar = 0.f;
+    if (LOC) { loc_stage_lds(carve_bf(sm, a), a, threadIdx.x); lds_barrier(); }
     for (int t = a.U - 1; t >= -1; --t) {
         int bb = b, tid = threadIdx.x;
         asm volatile("" : "+s"(bb), "+v"(tid));                       // see dec_loop_fwd_kernel
-        pf_bwd_row<CELL, NE, true>(a, (t + 1 < a.U) ? t + 1 : -1, t, bb, tid, sm, dccar, ducar, local);
+        pf_bwd_row<CELL, NE, true, LOC>(a, (t + 1 < a.U) ? t + 1 : -1, t, bb, tid, sm, dccar, ducar, local);
         lds_barrier();
     }
+}
+
+// Location-aware attention, after the gradient loop.  (1) keys gradient as dkeys_kernel, with the conv term f[t, b, t', :] . Wf in the
+// pre-activation, and in the same pass the filter-projection gradient dWf[c, a] = sum_{t, t'} f[t, b, t', c] dv[t, b, t', a]: per
+// workgroup (utterance b, 8 frames) one [C, A] partial, written to the row-private slice dWfRows[b][blockIdx.x] (reduced over the
+// slices by las_colsum afterwards; C <= 10, A <= 128, ceil(T' / 8) <= RNG slices -- host-checked).
+__global__ __launch_bounds__(256) void dkeys_loc_kernel(DecDev a, float* __restrict__ dKeys) {
+    constexpr int LC = 10;
+    __shared__ float wf[LC * 128];
+    __shared__ float part[8][LC][128 + 4];
+    const int b = blockIdx.y, fr = threadIdx.x >> 5, tt = blockIdx.x * 8 + fr, sl = threadIdx.x & 31;
+    const int B = a.B, Tp = a.Tp, A = a.A, U = a.U, C = a.C;
+    for (int i = threadIdx.x; i < C * A; i += 256) wf[i] = a.Wf[i];
+    __syncthreads();
+    const bool on = tt < Tp && sl < A / 4;
+    const int ttc = tt < Tp ? tt : Tp - 1, a4 = sl < A / 4 ? sl : A / 4 - 1;
+    const unsigned short* kr = a.keysbf + ((size_t)b * Tp + ttc) * A + a4 * 4;
+    const float k0 = bf2f(kr[0]), k1 = bf2f(kr[1]), k2 = bf2f(kr[2]), k3 = bf2f(kr[3]);
+    const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dwf[LC];
+#pragma unroll
+    for (int c = 0; c < LC; ++c) dwf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < U; ++t) {
+        const float de = a.dE[((size_t)t * B + b) * Tp + ttc];
+        const float4 q4 = reinterpret_cast<const float4*>(a.Q + ((size_t)t * B + b) * A)[a4];
+        const float* fr_ = a.fcSave + (((size_t)t * B + b) * Tp + ttc) * C;
+        float f[LC];
+#pragma unroll
+        for (int c = 0; c < LC; ++c) f[c] = c < C ? fr_[c] : 0.f;
+        float p0 = k0 + q4.x, p1 = k1 + q4.y, p2 = k2 + q4.z, p3 = k3 + q4.w;
+#pragma unroll
+        for (int c = 0; c < LC; ++c) {
+            const float4 w4 = reinterpret_cast<const float4*>(wf + (c < C ? c : 0) * A)[a4];
+            p0 = fmaf(f[c], w4.x, p0); p1 = fmaf(f[c], w4.y, p1); p2 = fmaf(f[c], w4.z, p2); p3 = fmaf(f[c], w4.w, p3);
+        }
+        const float v0 = tanh_fast(p0), v1 = tanh_fast(p1), v2 = tanh_fast(p2), v3 = tanh_fast(p3);
+        const float4 dv = make_float4(de * u4.x * (1.f - v0 * v0), de * u4.y * (1.f - v1 * v1), de * u4.z * (1.f - v2 * v2), de * u4.w * (1.f - v3 * v3));
+        acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
+#pragma unroll
+        for (int c = 0; c < LC; ++c) {
+            dwf[c].x = fmaf(f[c], dv.x, dwf[c].x); dwf[c].y = fmaf(f[c], dv.y, dwf[c].y);
+            dwf[c].z = fmaf(f[c], dv.z, dwf[c].z); dwf[c].w = fmaf(f[c], dv.w, dwf[c].w);
+        }
+    }
+    if (on) {
+        float4* dk = reinterpret_cast<float4*>(dKeys + ((size_t)b * Tp + tt) * A) + a4;
+        float4 o = *dk;
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *dk = o;
+    }
+#pragma unroll
+    for (int c = 0; c < LC; ++c) {
+        float4 v = on ? dwf[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* pr = &part[fr][c][sl * 4];
+        pr[0] = v.x; pr[1] = v.y; pr[2] = v.z; pr[3] = v.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * A; i += 256) {
+        const int c = i / A, col = i - c * A;
+        float s_ = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) s_ += part[g8][c][col];
+        a.dWfRows[(((size_t)b * RNG + blockIdx.x) * C + c) * A + col] += s_;
+    }
+}
+
+// (2) filter and bias gradient: dlocw[k, c] = sum_{t, t'} dfc[t, b, t', c] alpha_{t-1}[b, t' + k - pad], dlocb[c] = sum dfc -- per utterance
+// (row-private slices dlocwRows[b] / dlocbRows[b], reduced over the utterances afterwards).  Workgroup = (256 of the Kc x C outputs,
+// utterance); every step's dfc row and alignment are staged in LDS once and shared by the workgroup's outputs.
+__global__ __launch_bounds__(256) void dlocw_kernel(DecDev a) {
+    extern __shared__ __attribute__((aligned(16))) float sm2[];
+    const int b = blockIdx.y, B = a.B, Tp = a.Tp, U = a.U, C = a.C, pad = (a.Kc - 1) / 2;
+    float* dfc = sm2;                    // [Tp * C]
+    float* apv = sm2 + Tp * C;           // [Tp]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < a.Kc * C;
+    const int k = on ? i / C : 0, c = on ? i - k * C : 0;
+    const int t0 = pad - k > 0 ? pad - k : 0, t1 = Tp < Tp + pad - k ? Tp : Tp + pad - k;
+    float acc = 0.f, accb = 0.f;
+    for (int t = 0; t < U; ++t) {
+        __syncthreads();
+        const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
+        for (int j = threadIdx.x; j < Tp * C; j += 256) dfc[j] = ds[j];
+        for (int j = threadIdx.x; j < Tp; j += 256)
+            apv[j] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + j] : (a.align0 ? a.align0[(size_t)b * Tp + j] : 0.f);
+        __syncthreads();
+        if (on) for (int tt = t0; tt < t1; ++tt) acc = fmaf(dfc[tt * C + c], apv[tt + k - pad], acc);
+        if (blockIdx.x == 0 && threadIdx.x < C) for (int tt = 0; tt < Tp; ++tt) accb += dfc[tt * C + threadIdx.x];
+    }
+    if (on) a.dlocwRows[(size_t)b * a.Kc * C + i] += acc;
+    if (blockIdx.x == 0 && threadIdx.x < C) a.dlocbRows[(size_t)b * C + threadIdx.x] += accb;
 }
 
 // dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)
@@ -1955,7 +2206,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, dV, gemm, total;
+    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, dV, fcS, dfcS, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -1990,6 +2241,8 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.dlocb = o;  o += align256((size_t)B * (C > 0 ? C : 1) * f);
     w.dWf = o;    o += align256((size_t)B * RNG * (C > 0 ? C : 1) * A * f);   // one slice per half-wave group
     w.dV = o;     o += align256(C > 0 ? (size_t)B * Tp * A * f : 0);
+    w.fcS = o;    o += align256(C > 0 ? (size_t)U * B * Tp * C * f : 0);
+    w.dfcS = o;   o += align256(C > 0 ? (size_t)U * B * Tp * C * f : 0);
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
@@ -2033,7 +2286,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.lp.budget = 1 << (((f->flags >> 8) & 31) ? ((f->flags >> 8) & 31) : 21);
     d.xbf = nullptr; d.dgbf = nullptr; d.Wsbf = d.keysbf = d.encbf = d.Wsbf2 = d.encbf2 = nullptr; d.dE = nullptr;
     d.dHl = nullptr; d.dH = d.dC = d.dXin0 = d.Q = d.dQ = d.duRows = d.dAext = d.dKeys = nullptr;
-    d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr; d.dVbuf = nullptr;
+    d.dlocwRows = d.dlocbRows = d.dWfRows = nullptr; d.dVbuf = d.fcSave = d.dfcSave = nullptr;
     for (int l = 0; l < LAS_MAX_NL; ++l) { d.rec[l] = nullptr; d.recLd[l] = 0; d.recOff[l] = 0; }
     return 0;
 }
@@ -2045,20 +2298,33 @@ static bool bf_rows_ok(const DecDev& d) {
     return !(d.flags & LAS_SPELLER_NO_BF_ROWS) && d.mode == LAS_ATT_ADD && (d.A % 8) == 0 && (d.Hd % 8) == 0 && d.A <= 256;
 }
 // ... and, for the common single-layer geometry, the fully prefetching variants
-static bool pf_rows_ok(const DecDev& d) {
-    return !(d.flags & LAS_SPELLER_NO_PF_ROWS) && bf_rows_ok(d) && d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 &&
-           d.E <= 1024 && (d.E % 2) == 0 && (d.D % 2) == 0;
+static bool pf_geom_ok(const DecDev& d) {
+    return d.NL == 1 && d.D <= 512 && d.A <= 128 && d.Hd <= 512 && d.Tp <= 224 && d.E <= 1024 && (d.E % 2) == 0 && (d.D % 2) == 0 &&
+           (d.A % 8) == 0 && (d.Hd % 8) == 0;
 }
+static bool pf_rows_ok(const DecDev& d) { return !(d.flags & LAS_SPELLER_NO_PF_ROWS) && bf_rows_ok(d) && pf_geom_ok(d); }
 // ... and the whole loop in one launch: 8 groups of pn product + R row workgroups, all co-resident (one per compute unit),
 // tpw column tiles per product workgroup and kw k-steps per product wave as instantiated in the kernels
 constexpr int LOOP_TPW_F = 5, LOOP_KW_F = 3, LOOP_TPW_B = 3, LOOP_KW_B = 4;
-static bool loop_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
+static bool loop_geom_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
     const int R = cdiv(d.B, 8), pn = las_device_cus() / 8 - R;
     // (U >= 4: a launch of the persistent grid costs ~100 us before its first step -- 256 workgroups, placement handshake -- which
     //  30 us saved per step only repays from the fourth step on; beam search calls the step with U = 1: 141 vs 43 us, r3 decode trace)
-    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && d.U >= 4 && pf_rows_ok(d) && (d.E % 4) == 0 && (d.D % 4) == 0 && (d.Hd % 4) == 0 &&
-           ((d.E + d.Hd + d.D) % 8) == 0 && (K % 8) == 0 && R <= 16 && pn >= 1 && pn + R <= 32 && pn * tpw >= cdiv(ncols, 16) &&
-           16 * kw >= cdiv(K, 32);
+    return d.U >= 4 && (d.E % 4) == 0 && (d.D % 4) == 0 && (d.Hd % 4) == 0 && ((d.E + d.Hd + d.D) % 8) == 0 && (K % 8) == 0 && R <= 16 &&
+           pn >= 1 && pn + R <= 32 && pn * tpw >= cdiv(ncols, 16) && 16 * kw >= cdiv(K, 32);
+}
+static bool loop_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
+    return !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && pf_rows_ok(d) && loop_geom_ok(d, ncols, K, tpw, kw);
+}
+// Location-aware attention (round 3): served by the SAME loop kernels (pf_fwd_row / pf_bwd_row with LOC = true: conv1d over the
+// previous alignment from LDS, the f . Wf term in the energies, d f / d alpha_{t-1} in the gradient loop; keys / Wf / filter gradients
+// contracted over the steps afterwards) when BOTH loops are eligible, so that forward and gradient stay in one arithmetic family
+// (bf16 row operands); otherwise the per-step fp32-operand row kernels dec_step_{fwd,bwd}_kernel<.,.,true>.
+static bool loc_loop_ok(const DecDev& d, int G) {
+    const int GD = G * d.D, I0D = d.E + d.Hd + d.D;
+    return d.mode == LAS_ATT_LOC && !(d.flags & (LAS_SPELLER_NO_PF_ROWS | LAS_SPELLER_NO_BF_ROWS | LAS_SPELLER_NO_FUSED_STEP)) &&
+           pf_geom_ok(d) && d.C >= 1 && d.C <= 10 && d.Kc * d.C <= 4096 && cdiv(d.Tp, 8) <= RNG &&
+           loop_geom_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F) && loop_geom_ok(d, d.Hd + d.D, GD, LOOP_TPW_B, LOOP_KW_B);
 }
 static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
     p.KS = cdiv(K, 32); p.K = K; p.N = ncols; p.nct = cdiv(ncols, 16); p.M = B; p.R = cdiv(B, 8);
@@ -2067,19 +2333,21 @@ static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
 template <class K> static int loop_lds_attr(K kernel) {   // the product workgroups' partial tiles need > 64 KB of dynamic LDS
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
-#define LAS_LOOP_LAUNCH1(KERNEL, CELL, NE, grid, lds, st, d)                                               \
+#define LAS_LOOP_LAUNCH1(KERNEL, CELL, NE, LOC, grid, lds, st, d)                                          \
     do {                                                                                                   \
-        static int attr__ = loop_lds_attr(KERNEL<CELL, NE>);                                               \
+        static int attr__ = loop_lds_attr(KERNEL<CELL, NE, LOC>);                                          \
         if (attr__ != 0) { las_set_error("hipFuncSetAttribute(speller loop) failed: %d", attr__); return attr__; } \
-        hipLaunchKernelGGL((KERNEL<CELL, NE>), grid, dim3(RNT), lds, st, d);                               \
+        hipLaunchKernelGGL((KERNEL<CELL, NE, LOC>), grid, dim3(RNT), lds, st, d);                          \
     } while (0)
-#define LAS_LOOP_LAUNCH(KERNEL, CELL, Tp, grid, lds, st, d)                                                \
+#define LAS_LOOP_LAUNCH2(KERNEL, CELL, Tp, LOC, grid, lds, st, d)                                          \
     do {                                                                                                   \
-        if ((Tp) <= 128)      LAS_LOOP_LAUNCH1(KERNEL, CELL, 8, grid, lds, st, d);                         \
-        else if ((Tp) <= 160) LAS_LOOP_LAUNCH1(KERNEL, CELL, 10, grid, lds, st, d);                        \
-        else if ((Tp) <= 192) LAS_LOOP_LAUNCH1(KERNEL, CELL, 12, grid, lds, st, d);                        \
-        else                  LAS_LOOP_LAUNCH1(KERNEL, CELL, 14, grid, lds, st, d);                        \
+        if ((Tp) <= 128)      LAS_LOOP_LAUNCH1(KERNEL, CELL, 8, LOC, grid, lds, st, d);                    \
+        else if ((Tp) <= 160) LAS_LOOP_LAUNCH1(KERNEL, CELL, 10, LOC, grid, lds, st, d);                   \
+        else if ((Tp) <= 192) LAS_LOOP_LAUNCH1(KERNEL, CELL, 12, LOC, grid, lds, st, d);                   \
+        else                  LAS_LOOP_LAUNCH1(KERNEL, CELL, 14, LOC, grid, lds, st, d);                   \
     } while (0)
+#define LAS_LOOP_LAUNCH(KERNEL, CELL, Tp, loc, grid, lds, st, d)                                           \
+    do { if (loc) LAS_LOOP_LAUNCH2(KERNEL, CELL, Tp, true, grid, lds, st, d); else LAS_LOOP_LAUNCH2(KERNEL, CELL, Tp, false, grid, lds, st, d); } while (0)
 static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st) {
     unsigned short* wsb = (unsigned short*)(base + w.wsbf);
     unsigned short* kb = (unsigned short*)(base + w.keysbf);
@@ -2129,13 +2397,14 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     if (skinny) d.xbf = (unsigned short*)((char*)f->ws + wl_.xbf);
     const bool bfrows = skinny && bf_rows_ok(d);
     const bool pf = bfrows && pf_rows_ok(d);
+    const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
-    if (bfrows) {
+    if (bfrows || locloop) {
         LAS_ARG(lds_bf <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
-    const bool loop = pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F);
+    const bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
     if (loop) {   // the whole loop in one launch
         const size_t lds_pr = (size_t)RNW * LOOP_TPW_F * 1024;       // the product workgroups' partial tiles (80 KB)
         const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
@@ -2147,7 +2416,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (I0D / 4) * 16, st));        // tags of an earlier call must not match
         LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * (GD / 2) * 16, st));
         LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
-        LAS_LOOP_LAUNCH(dec_loop_fwd_kernel, CELL, d.Tp, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
+        LAS_LOOP_LAUNCH(dec_loop_fwd_kernel, CELL, d.Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }
     for (int t = 0; t <= U && !loop; ++t) {
@@ -2212,7 +2481,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     d.Q = (float*)(base + w.Q); d.dQ = (float*)(base + w.dQ); d.duRows = (float*)(base + w.duRows);
     d.dAext = (float*)(base + w.dAext); d.dKeys = bk->d_keys;
     d.dlocwRows = (float*)(base + w.dlocw); d.dlocbRows = (float*)(base + w.dlocb); d.dWfRows = (float*)(base + w.dWf);
-    d.dVbuf = (float*)(base + w.dV);
+    d.dVbuf = (float*)(base + w.dV); d.fcSave = (float*)(base + w.fcS); d.dfcSave = (float*)(base + w.dfcS);
     float* tmp = (float*)(base + w.tmp);          // [NL][B][2D] input/recurrent grads of layers >= 1
     void* gws = base + w.gemm;
     const size_t gws_bytes = f->ws_bytes - w.gemm;
@@ -2230,8 +2499,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     if (skinny) d.dgbf = (unsigned short*)(base + w.dgbf);
     const bool bfrows = skinny && bf_rows_ok(d);
     const bool pf = bfrows && pf_rows_ok(d);
+    const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
-    if (bfrows) {
+    if (bfrows || locloop) {
         LAS_ARG(lds_bf <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
         if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
@@ -2239,7 +2509,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     // the whole loop in one launch: the in-loop product covers the chain columns [E, I0D) only (every product workgroup then
     // feeds granules to the rows, which is what makes the single-buffered exchange safe); the embedding columns of dXin0 are
     // one tall contraction after the loop (part 2)
-    const bool loop = pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B);
+    const bool loop = locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B));
     if (skinny && (part & 1)) {   // B[k = gate col][n = input row] = W0[n][k]
         if (loop) GEMM_OK(las_skinny_pack(f->cellW[0] + (size_t)E * GD, GD, GD, Hd + D, 1, packB, st));
         else      GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));
@@ -2249,7 +2519,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     for (int l = 1; l < NL; ++l) { d.rec[l] = tmp + (size_t)l * B * 2 * D; d.recLd[l] = 2 * D; d.recOff[l] = D; }
 
     LAS_HIP(hipMemsetAsync(base + w.dH, 0, w.dXin0 - w.dH, st));                      // dH, dC
-    LAS_HIP(hipMemsetAsync(base + w.duRows, 0, w.gemm - w.duRows, st));               // duRows .. dWfRows (incl. tmp)
+    LAS_HIP(hipMemsetAsync(base + w.duRows, 0, w.dV - w.duRows, st));                 // duRows .. dWfRows (incl. tmp)
     // dlogits . Wv^T for every step, and the queries Q = S . Ws, as dense GEMMs up front
     GEMM_OK(las_gemm(prec, 0, 1, U * B, D, V, 1.f, bk->dlogits, V, 0, d.Wv, V, 0, 0.f, dHl, D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0,
                      nullptr, 0, st));
@@ -2269,7 +2539,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (GD / 4) * 16, st));
         LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * ((Hd + D) / 2) * 16, st));
         LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
-        LAS_LOOP_LAUNCH(dec_loop_bwd_kernel, CELL, Tp, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
+        LAS_LOOP_LAUNCH(dec_loop_bwd_kernel, CELL, Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }
     for (int t = U - 1; t >= -1 && !loop; --t) {
@@ -2303,7 +2573,10 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         }
     }
 
-    if (bfrows) {   // keys gradient: contraction over the steps, every (utterance, frame) independent
+    if (locloop) {  // keys gradient with the conv term in the pre-activation; the same pass leaves the Wf-gradient partials
+        hipLaunchKernelGGL(dkeys_loc_kernel, dim3(cdiv(Tp, 8), B), dim3(256), 0, st, d, bk->d_keys);
+        LAS_LAUNCHED();
+    } else if (bfrows) {   // keys gradient: contraction over the steps, every (utterance, frame) independent
         hipLaunchKernelGGL(dkeys_kernel, dim3(cdiv(Tp, 8), B), dim3(256), 0, st, d, bk->d_keys);
         LAS_LAUNCHED();
     }
@@ -2341,6 +2614,10 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
                            E, V, d.emb_mask, epart);
         LAS_LAUNCHED();
         GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
+    }
+    if (locloop) {  // filter / bias gradient from the saved d f rows of every step
+        hipLaunchKernelGGL(dlocw_kernel, dim3(cdiv(d.Kc * d.C, 256), B), dim3(256), (size_t)(Tp * d.C + Tp) * sizeof(float), st, d);
+        LAS_LAUNCHED();
     }
     if (loc) {
         GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));

@@ -45,18 +45,48 @@ def synthetic_batch(B, T, U_max, V, seed=0, feat_dim=13, min_frac=0.5):
     return (audio, audiolen), (y, tokenlen)
 
 
-def oracle_mode_for(args, prec):
+def loc_loop_eligible(args, B, Tp, U, cell="lstm", cus=256):
+    """mirror of csrc/speller.hip loc_loop_ok: location-aware attention runs in the one-launch loop kernels (bf16 row operands)
+    when both the decode loop and the gradient loop are eligible, else in the per-step fp32-operand row kernels"""
+    if args.mode != "loc" or B is None or Tp is None or U is None:
+        return False
+    G = 4 if cell == "lstm" else 1
+    D, A, E = args.dec_units, args.attention_size, args.embedding_size
+    Hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
+    GD, I0D, C, Kc = G * D, E + Hd + D, args.loc_num_channels, args.loc_kernel_size
+    cd = lambda a, b: -(-a // b)
+    geom = (args.num_dec_layers == 1 and D <= 512 and A <= 128 and Hd <= 512 and Tp <= 224 and E <= 1024 and E % 2 == 0 and D % 2 == 0
+            and A % 8 == 0 and Hd % 8 == 0 and 1 <= C <= 10 and Kc * C <= 4096 and cd(Tp, 8) <= 32)
+    R = cd(B, 8)
+    pn = cus // 8 - R
+
+    def loop(ncols, K, tpw, kw):
+        return (U >= 4 and E % 4 == 0 and D % 4 == 0 and Hd % 4 == 0 and I0D % 8 == 0 and K % 8 == 0 and R <= 16 and pn >= 1
+                and pn + R <= 32 and pn * tpw >= cd(ncols, 16) and 16 * kw >= cd(K, 32))
+    return bool(geom and I0D % 8 == 0 and GD % 8 == 0 and B <= 1024 and loop(GD, I0D, 5, 3) and loop(Hd + D, GD, 3, 4))
+
+
+def oracle_mode_for(args, prec, B=None, Tp=None, U=None, cell="lstm"):
     """The oracle arithmetic mode that restates what the HIP path runs for this configuration (oracle.set_precision):
     speed mode rounds every contraction operand to bf16; with additive attention the Speller row kernels also keep
-    keys / context operands in bf16 ('bf' rows), otherwise only the GEMM operands are rounded ('f32' rows)."""
+    keys / context operands in bf16 ('bf' rows) -- and so do the loop kernels that serve location-aware attention when the call
+    is eligible for them (B, Tp, U given: loc_loop_eligible); otherwise only the GEMM operands are rounded ('f32' rows)."""
     if prec != "bf16":
         return ("f32", "bf", False)
     I0D = args.embedding_size + (2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units) + args.dec_units
     hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
-    bf_rows = args.mode == "add" and I0D % 8 == 0 and args.attention_size % 8 == 0 and hd % 8 == 0
+    bf_rows = (args.mode == "add" and I0D % 8 == 0 and args.attention_size % 8 == 0 and hd % 8 == 0) or \
+        loc_loop_eligible(args, B, Tp, U, cell)
     # the listener keeps its activations in HBM as bf16 when the MFMA sweeps serve the hidden size
     store = args.enc_units in (64, 128, 256, 512)
     return ("bf16", "bf" if bf_rows else "f32", store)
+
+
+def encoder_frames(args, T):
+    n = int(T)
+    for _ in range(args.num_enc_layers if str(args.enc_type).lower() == "pblstm" else 2):
+        n = (n + n % 2) // 2
+    return n
 
 
 def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", oracle_dtype=None):
@@ -68,7 +98,7 @@ def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None,
     from las.las import LAS, Listener, Speller
     from oracle import las_oracle as O
     p0 = O.init_params(args, seed=seed, cell=cell, enc_type=enc_type)
-    mode = oracle_mode_for(args, prec)
+    mode = oracle_mode_for(args, prec, B=len(xs[1]), Tp=encoder_frames(args, np.shape(xs[0])[1]), U=int(np.max(ys[1])), cell=cell)
     O.set_precision(*mode)
     try:
         po = O.to_torch(p0, requires_grad=True)

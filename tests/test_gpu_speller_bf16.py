@@ -15,7 +15,7 @@ from helpers import make_args
 pytestmark = pytest.mark.gpu
 
 
-def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed):
+def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed, loc=None):
     from las import _hip, layers as L, variables as V
     from las.las import Speller
     from oracle import las_oracle as O
@@ -26,6 +26,8 @@ def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed):
         V.reset_default_store(device="cuda", seed=3)
         args = make_args(enc_units=Hd2, num_enc_layers=2, dec_units=D, num_dec_layers=NL, embedding_size=64,
                          attention_size=A, mode="add", vocab_size=30, enc_type="pblstm")
+        if loc is not None:
+            args.mode, args.loc_kernel_size, args.loc_num_channels = "loc", loc[0], loc[1]
         sp = Speller(args)
         rng = np.random.RandomState(1)
         enc_np = rng.randn(B, Tp, 2 * Hd2).astype(np.float32) * 0.5
@@ -47,7 +49,9 @@ def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed):
         grads["enc"] = enc.grad.detach().cpu().clone()
         # oracle, bf16-operand mode; fp32-operand rows (flag 2) keep query / keys / context in fp32
         p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
-        O.set_precision("bf16", "f32" if (flags & 2) else "bf")
+        from helpers import loc_loop_eligible
+        bf_rows = not (flags & 2) and (loc is None or loc_loop_eligible(args, B, Tp, U))
+        O.set_precision("bf16", "bf" if bf_rows else "f32")
         try:
             po = O.to_torch(p0, requires_grad=True)
             enc_o = torch.tensor(enc_np, requires_grad=True)
@@ -98,6 +102,35 @@ def test_bf16_row_kernels_match_oracle(shape, flags):
         scale = max(go[n].abs().max().item(), 1e-3)
         err = (gn[n] - go[n]).abs().max().item() / scale
         assert err < 2e-2, (n, err, scale)
+
+
+LOC_SHAPES = [
+    # D,  A,   H,  B, Tp, U, mixed, (Kc, C)      -- location-aware attention in the one-launch loop kernels (round 3)
+    (512, 128, 256, 5, 37, 9, False, (201, 10)),     # reference defaults K = 201, C = 10: both borders of the filter clipped
+    (512, 128, 256, 48, 160, 6, False, (201, 10)),   # the bench geometry, 6 row workgroups per XCD group
+    (512, 128, 256, 17, 131, 5, True, (201, 10)),    # ragged T', sampled tokens
+    (128, 64, 64, 9, 181, 4, True, (7, 3)),          # small filter, T' in (160, 192]
+    (128, 128, 64, 3, 214, 4, False, (31, 10)),      # T' in (192, 224]
+]
+
+
+@pytest.mark.parametrize("shape", LOC_SHAPES)
+def test_location_aware_loop_kernels_match_oracle(shape):
+    """dec_loop_{fwd,bwd}_kernel<., ., LOC = true> (conv1d over the previous alignment from LDS, f . Wf in the energies, d f and
+    d alpha_{t-1} in the gradient loop; keys / Wf / filter gradients contracted after the loop by dkeys_loc_kernel / dlocw_kernel)
+    against the oracle's LocationAwareAttention (reference las/layers.py:259-311) in its bf16-row mode: logits, alignments, every
+    gradient including conv1d/kernel, conv1d/bias and dense_2/kernel."""
+    from helpers import loc_loop_eligible
+    D, A, H, B, Tp, U, mixed, loc = shape
+    ln, an, gn, lo, ao, go = _run(0, 1, D, A, H, B, Tp, U, mixed, loc=loc)
+    assert (an - ao).abs().max().item() < 2e-3
+    assert (ln - lo).abs().max().item() < 5e-3 * max(1.0, lo.abs().max().item())
+    for n in sorted(go):
+        scale = max(go[n].abs().max().item(), 1e-3)
+        err = (gn[n] - go[n]).abs().max().item() / scale
+        assert err < 2e-2, (n, err, scale)
+    for n in ("Speller/decode/attention/conv1d/kernel", "Speller/decode/attention/conv1d/bias", "Speller/decode/attention/dense_2/kernel"):
+        assert float(go[n].abs().max()) > 0 and n in gn
 
 
 def test_backward_reuses_the_forward_operand_copies_only_when_nobody_else_used_the_workspace():
