@@ -2400,7 +2400,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
     if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= 64 * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);
+        LAS_ARG(lds_bf <= (locloop ? 96 : 64) * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);   // (loop launches: 96 KB attribute)
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
@@ -2502,7 +2502,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
     if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= 64 * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
+        LAS_ARG(lds_bf <= (locloop ? 96 : 64) * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
         if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
     }
