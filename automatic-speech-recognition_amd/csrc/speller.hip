@@ -441,6 +441,8 @@ struct BfLds {
     // location-aware attention in the one-launch loop kernels: previous alignment, conv output f and its gradient, the gradient that
     // step t + 1's conv sends back to alpha_t, the staged filter [Kc, C] and Wf [C, A]
     float *aprev, *fc, *dfc, *daext, *locw, *wfl;
+    unsigned short* wfb;      // [16][A] bf16 copy of Wf (rows >= C zero): B operand of the d f product
+    unsigned int* dvb;        // [Tp][A/2] the step's d(pre-tanh) rows as bf16 pairs: A operand of the d f product (gradient loop)
 };
 __device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
 __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
@@ -453,40 +455,115 @@ __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     r.x1 = p;      p += up4(a.Tp);      // bwd: d alpha / d energy
     r.red = p;     p += 32;
     r.redi = reinterpret_cast<int*>(p); p += 32;
-    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr;
+    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr; r.wfb = nullptr; r.dvb = nullptr;
     if (a.mode == LAS_ATT_LOC) {
-        r.aprev = p; p += up4(a.Tp);
-        r.daext = p; p += up4(a.Tp);
-        r.fc = p;    p += up4(a.Tp * a.C);
-        r.dfc = p;   p += up4(a.Tp * a.C);
-        r.locw = p;  p += up4(a.Kc * a.C);
-        r.wfl = p;   p += up4(a.C * a.A);
+        // the conv input (previous alignment) and the transposed conv's input (d f) are zero-padded by the filter's reach on both
+        // sides (+ one unrolled block): the sliding-window loops of loc_conv_partials carry no bounds checks.  aprev / dfc point at
+        // frame 0 inside their padded arrays; the pads are zeroed once per launch (loc_stage_lds) and never written again.
+        const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
+        r.aprev = p + padl;            p += up4(a.Tp + a.Kc + 16);
+        r.daext = p;                   p += up4(a.Tp);
+        r.fc = p;                      p += up4(a.Tp * a.C);
+        r.dfc = p + padr * a.C;        p += up4((a.Tp + a.Kc + 16) * a.C);
+        r.locw = p;                    p += up4(a.Kc * a.C);
+        r.wfl = p;                     p += up4(a.C * a.A);
+        r.wfb = reinterpret_cast<unsigned short*>(p); p += up4(8 * a.A);
     }
     r.scr = p;                           // RNW x max(Hd, 2A) partials
+    if (a.mode == LAS_ATT_LOC) r.dvb = reinterpret_cast<unsigned int*>(p + RNW * 2 * a.A);   // behind the dq / du partials of the same phase
     return r;
 }
 static size_t bf_lds_bytes(const DecDev& a) {
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
-    const size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
+    size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
     size_t loc = 0;
-    if (a.mode == LAS_ATT_LOC) loc = 2 * u4(a.Tp) + 2 * u4((size_t)a.Tp * a.C) + u4((size_t)a.Kc * a.C) + u4((size_t)a.C * a.A);
+    if (a.mode == LAS_ATT_LOC) {
+        loc = u4(a.Tp + a.Kc + 16) + u4(a.Tp) + u4((size_t)a.Tp * a.C) + u4((size_t)(a.Tp + a.Kc + 16) * a.C) + u4((size_t)a.Kc * a.C) +
+              u4((size_t)a.C * a.A) + u4((size_t)8 * a.A);
+        const int items = ((a.Tp + 7) / 8) * a.C;                   // loc_conv_chunks: the conv's tap-chunk partials live in the scratch
+        int nch = 1024 / (items > 0 ? items : 1);
+        nch = nch < 1 ? 1 : (nch > 8 ? 8 : nch);
+        size_t need = (size_t)nch * a.Tp * a.C;
+        if (need > scr) scr = need;
+        need = (size_t)RNW * 2 * a.A + (size_t)((a.Tp + 15) / 16 * 16) * (a.A / 2);      // dq / du partials + the step's dv rows (bf16 pairs)
+        if (need > scr) scr = need;
+    }
     return (u4((size_t)a.D * a.NL) + u4(a.A) + 2 * u4(a.Tp) + u4(a.D) + u4(a.Hd) + 64 + loc + scr) * sizeof(float) + 64;
 }
 // location-aware attention, loop kernels: the conv1d over the previous alignment (las/layers.py:295-296; SAME, cross-correlation):
-// f[t', c] = bias[c] + sum_k aprev[t' + k - pad] w[k, c], filter and alignment in LDS, one (frame, channel) output per thread and round
-__device__ __forceinline__ void loc_conv_lds(const BfLds& L, const DecDev& a, const int tid) {
-    const int Tp = a.Tp, C = a.C, pad = (a.Kc - 1) / 2;
+// f[t', c] = bias[c] + sum_k aprev[t' + k - pad] w[k, c], filter and alignment in LDS.  The first version gave every thread one
+// (frame, channel) output and walked the 201 taps with two LDS reads per multiply-add: 3.4 MB of LDS traffic per row and step,
+// ~10 us (r3g trace).  Now a work item is (block of 8 consecutive frames, channel, chunk of the taps): the 8 alignments slide
+// through registers (ONE new alignment + one filter tap read per 8 multiply-adds), the chunks' partial sums meet in LDS.
+// `part` needs NCH * Tp * C floats (the row kernels' partials scratch).  Call with all threads; ends with the result in L.fc after
+// the caller's next barrier + loc_conv_finish.
+constexpr int LOC_FB = 8;            // frames per work item
+constexpr int LOC_UB = 8;            // taps per unrolled block
+__device__ __forceinline__ int loc_conv_chunks(const DecDev& a) {
+    const int items = ((a.Tp + LOC_FB - 1) / LOC_FB) * a.C;             // (frame block, channel) pairs
+    int n = RNT / items;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+}
+// FLIP = false: out[t', c] = sum_k in[t' + k - pad] w[k, c]            (the conv; `in` = alignment, one value per frame)
+// FLIP = true:  out[src, c] = sum_k in[(src - k + pad), c] w[k, c]     (its transpose; `in` = d f, C values per frame) -- with the
+//               taps counted from the far end (k' = Kc - 1 - k) it is the same sliding sum over the padded array.
+// P = the zero-padded input, indexed so that output f at tap k reads P[f + k]: aprev - padl resp. (dfc - padr * C).
+// 8 new inputs + 8 filter taps are read per block of 8 taps and feed 64 multiply-adds with static register indices; between
+// blocks the window moves by 7 copies.  (The rolled first version shifted the window every tap: 23 instructions and two exposed LDS
+// round trips per tap, 6-8 us per conv at K = 201 -- profiles/r3_speller_phase_stamps.txt.)
+template <bool FLIP>
+__device__ __forceinline__ void loc_conv_partials(const float* __restrict__ P, const float* __restrict__ w, float* __restrict__ part,
+                                                  const DecDev& a, const int tid) {
+    const int Tp = a.Tp, C = a.C, Kc = a.Kc;
+    const int nfb = (Tp + LOC_FB - 1) / LOC_FB, nch = loc_conv_chunks(a);
+    const int kper = ((Kc + nch - 1) / nch + LOC_UB - 1) / LOC_UB * LOC_UB;      // chunk = whole blocks
+    const int pst = FLIP ? C : 1;                                      // stride of the input along frames
+    for (int i = tid; i < nfb * C * nch; i += RNT) {
+        const int ch = i / (nfb * C), r = i - ch * nfb * C, fb = r / C, c = r - fb * C;
+        const int f0 = fb * LOC_FB, k0 = ch * kper < Kc ? ch * kper : Kc, k1 = k0 + kper < Kc ? k0 + kper : Kc;
+        const float* Pp = P + (FLIP ? c : 0) + (size_t)(f0 + k0) * pst;
+        float acc[LOC_FB], win[LOC_FB + LOC_UB - 1];
+#pragma unroll
+        for (int j = 0; j < LOC_FB; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < LOC_FB - 1; ++j) win[j] = Pp[j * pst];
+        for (int kb = k0; kb < k1; kb += LOC_UB) {
+            float wv[LOC_UB];
+#pragma unroll
+            for (int u = 0; u < LOC_UB; ++u) {
+                win[LOC_FB - 1 + u] = Pp[(kb - k0 + LOC_FB - 1 + u) * pst];
+                const int k = kb + u, kc = k < k1 ? k : k1 - 1;
+                const float t_ = w[(FLIP ? Kc - 1 - kc : kc) * C + c];
+                wv[u] = k < k1 ? t_ : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < LOC_UB; ++u)
+#pragma unroll
+                for (int j = 0; j < LOC_FB; ++j) acc[j] = fmaf(win[j + u], wv[u], acc[j]);
+#pragma unroll
+            for (int j = 0; j < LOC_FB - 1; ++j) win[j] = win[j + LOC_UB];
+        }
+#pragma unroll
+        for (int j = 0; j < LOC_FB; ++j)
+            if (f0 + j < Tp) part[(ch * Tp + f0 + j) * C + c] = acc[j];
+    }
+}
+// f = bias + sum over the tap chunks (after a barrier behind loc_conv_partials<false>)
+__device__ __forceinline__ void loc_conv_finish(const BfLds& L, const float* __restrict__ part, const DecDev& a, const int tid) {
+    const int Tp = a.Tp, C = a.C, nch = loc_conv_chunks(a);
     for (int i = tid; i < Tp * C; i += RNT) {
-        const int tt = i / C, c = i - tt * C;
-        const int k0 = pad - tt > 0 ? pad - tt : 0, k1 = a.Kc < Tp + pad - tt ? a.Kc : Tp + pad - tt;
-        float acc = a.loc_b[c];
-        for (int k = k0; k < k1; ++k) acc = fmaf(L.aprev[tt + k - pad], L.locw[k * C + c], acc);
+        float acc = a.loc_b[i % C];
+        for (int ch = 0; ch < nch; ++ch) acc += part[ch * Tp * C + i];
         L.fc[i] = acc;
     }
 }
 __device__ __forceinline__ void loc_stage_lds(const BfLds& L, const DecDev& a, const int tid) {
+    const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
     for (int i = tid; i < a.Kc * a.C; i += RNT) L.locw[i] = a.loc_w[i];
     for (int i = tid; i < a.C * a.A; i += RNT) L.wfl[i] = a.Wf[i];
+    for (int i = tid; i < a.Tp + a.Kc + 16; i += RNT) (L.aprev - padl)[i] = 0.f;
+    for (int i = tid; i < (a.Tp + a.Kc + 16) * a.C; i += RNT) (L.dfc - padr * a.C)[i] = 0.f;
+    for (int i = tid; i < 16 * a.A; i += RNT) L.wfb[i] = (i / a.A) < a.C ? f2bf(a.Wf[i]) : (unsigned short)0;
 }
 
 template <int CELL, int NJ>
@@ -762,6 +839,25 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V, U = a.U;
     const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (S + 1) >> 1, Tp2 = (Tp + 1) >> 1;
 
+    if (LOC) {
+        // f = conv1d(alpha_{t-1}): nothing in it depends on the gates of step t-1, so it runs while they are on their way -- and
+        // BEFORE the step's bulk loads are issued: behind them their 60 destination registers are live and the conv's 40 spill.  The
+        // alignment of the previous step is in LDS already (written by this row's softmax; the loop's barrier orders it); step 0
+        // starts from align0 / zeros.
+        if (t == 0) {
+            if (tid < Tp) L.aprev[tid] = a.align0 ? a.align0[(size_t)b * Tp + tid] : 0.f;
+            lds_barrier();
+        }
+        if (t < U) {
+            STAMPX(25);
+            loc_conv_partials<false>(L.aprev - (a.Kc - 1) / 2, L.locw, L.scr, a, tid);     // (the partials scratch is idle until the query projection)
+            lds_barrier();
+            STAMPX(26);
+            loc_conv_finish(L, L.scr, a, tid);
+            lds_barrier();                                                // the scratch is reused by the query partials
+            STAMPX(27);
+        }
+    }
     // ---- every load of the step whose address does not depend on the recurrence, in consumption order.
     // All of them are UNCONDITIONAL with clamped addresses: a predicated load becomes an exec-masked branch whose
     // join makes the compiler drain vmcnt, which serialises the prefetch.  Out-of-range lanes are neutralised where
@@ -795,16 +891,6 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
     }
     STAMPX(1);
-    if (LOC) {
-        // f = conv1d(alpha_{t-1}): nothing in it depends on the gates of step t-1, so it runs while they are on their way.  The
-        // alignment of the previous step is in LDS already (written by this row's softmax; the loop's barrier orders it); step 0
-        // starts from align0 / zeros.
-        if (t == 0) {
-            if (tid < Tp) L.aprev[tid] = a.align0 ? a.align0[(size_t)b * Tp + tid] : 0.f;
-            lds_barrier();
-        }
-        if (t < U) loc_conv_lds(L, a, tid);              // (made visible by the barriers between here and the energies)
-    }
     if (LOOP && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
         const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
         u32x4_t gq[G];
@@ -1721,25 +1807,6 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 // LOOP (dec_loop_bwd_kernel): one iteration of a persistent row workgroup: the dXin0 row of step t_att (context and state
 // gradient) arrives as granules from the product workgroups, the bf16 gate gradient of step t_cell leaves as granules, dC and
 // the running du column are carried in registers.
-// sum of NV <= 16 per-lane values over the 64 lanes of a wave with 17 shuffles instead of 6 NV: a halving butterfly -- after the
-// exchange with lane ^ 32 a lane is responsible for 8 of the 16 values, after ^ 16 for 4, ... after ^ 4 for one, then two plain
-// steps.  Returns the total of value index ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)
-// (every lane; lanes that differ only in bits 0-1 hold the same sum).
-__device__ __forceinline__ float wave_sum16(const float (&v)[16], const int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-    float x[8], y[4], z[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = (b4 ? x[i + 4] : x[i]) + __shfl_xor(b4 ? x[i] : x[i + 4], 16, 64);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) z[i] = (b3 ? y[i + 2] : y[i]) + __shfl_xor(b3 ? y[i] : y[i + 2], 8, 64);
-    float w = (b2 ? z[1] : z[0]) + __shfl_xor(b2 ? z[0] : z[1], 4, 64);
-    w += __shfl_xor(w, 2, 64);
-    w += __shfl_xor(w, 1, 64);
-    return w;
-}
-
 template <int CELL, int NE, bool LOOP, bool LOC = false>
 __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, const int tid, float* sm,
                                            float& dccar, float& ducar, const bool local) {
@@ -1764,17 +1831,27 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     const int ta = att ? t_att : 0, tcl = cel ? t_cell : 0;
     const int dd = tid < D ? tid : D - 1, h2c = tid < (Hd >> 1) ? tid : (Hd >> 1) - 1, tpc = tid < Tp ? tid : Tp - 1;
     const int a2c = tid < 2 * A ? tid : 2 * A - 1, a8c = a8 < A8 ? a8 : A8 - 1, l8c = lane < H8 ? lane : H8 - 1;
-    const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
-    float2 dcv = make_float2(0.f, 0.f);
-    float recv0 = 0.f;
-    if (!LOOP) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
-    const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
     float apv = 0.f;                                  // LOC: the alignment that entered step t_att's conv (alpha_{t-1}, or align0 / zeros)
     if (LOC) {
         const float* aps = ta > 0 ? a.alphas + ((size_t)(ta - 1) * B + b) * Tp : (a.align0 ? a.align0 + (size_t)b * Tp : a.alphas + (size_t)b * Tp);
         apv = aps[tpc];
         if (ta == 0 && !a.align0) apv = 0.f;
     }
+    if (LOC && att) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way -- before the bulk loads (register pressure); keep it for the after-loop keys / Wf gradient
+        if (tid < Tp) L.aprev[tid] = apv;
+        lds_barrier();
+        loc_conv_partials<false>(L.aprev - (a.Kc - 1) / 2, L.locw, L.scr, a, tid);
+        lds_barrier();
+        loc_conv_finish(L, L.scr, a, tid);
+        float* fs = a.fcSave + ((size_t)ta * B + b) * Tp * a.C;
+        for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];          // (a thread re-reads what it wrote itself)
+        lds_barrier();                                                      // the scratch is reused below
+    }
+    const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
+    float2 dcv = make_float2(0.f, 0.f);
+    float recv0 = 0.f;
+    if (!LOOP) { dcv = reinterpret_cast<const float2*>(dxr + E)[h2c]; recv0 = dxr[E + Hd + dd]; }
+    const float alv = a.alphas[((size_t)ta * B + b) * Tp + tpc];
     // threads [0, A) pick up the query column, threads [A, 2A) this row's running du column
     float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     if (LOOP && a2c >= A) qd = ducar;                 // (duRows starts at zero; the register copy is the live one)
@@ -1811,13 +1888,6 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
     } else {
         hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
-    }
-    if (LOC && att) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way; keep it for the after-loop keys / Wf gradient
-        if (tid < Tp) L.aprev[tid] = apv;
-        lds_barrier();
-        loc_conv_lds(L, a, tid);
-        float* fs = a.fcSave + ((size_t)ta * B + b) * Tp * a.C;
-        for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];          // (a thread re-reads what it wrote itself)
     }
     if (LOOP && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
         const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
@@ -1928,15 +1998,10 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 const float v0 = tanhx<FAST>(p0), v1 = tanhx<FAST>(p1);
                 du0 = fmaf(de, v0, du0); du1 = fmaf(de, v1, du1);
                 if (!LOC) { dq0 = fmaf(de * u2.x, 1.f - v0 * v0, dq0); dq1 = fmaf(de * u2.y, 1.f - v1 * v1, dq1); }
-                if (LOC) {   // d f[t2, c] = sum over the attention columns of dv . Wf[c, :]: one butterfly over the wave for all channels
+                if (LOC) {   // keep the row of d(pre-tanh) (bf16 pairs): d f = dv . Wf^T is one small MFMA product after the loop
                     const float dv0 = de * u2.x * (1.f - v0 * v0), dv1 = de * u2.y * (1.f - v1 * v1);
                     dq0 += dv0; dq1 += dv1;
-                    float pv[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) pv[c] = (c < LC && lane < A2) ? dv0 * wf2[c < LC ? c : 0].x + dv1 * wf2[c < LC ? c : 0].y : 0.f;
-                    const float tot = wave_sum16(pv, lane);
-                    const int ci = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                    if (!(lane & 3) && ci < a.C && t2 < Tp) L.dfc[t2 * a.C + ci] = tot;
+                    if (lane < A2 && t2 < Tp) L.dvb[t2 * A2 + lane] = f2bf2(dv0, dv1);
                 }
             }
             if (lane < A2) {
@@ -1945,6 +2010,23 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             }
         }
         lds_barrier();
+        if (LOC && wv * 16 < Tp) {
+            // d f[t', c] = sum_a dv[t', a] Wf[c, a]: wave w owns frames [16 w, 16 w + 16): A fragments = the dv rows (bf16), B fragments =
+            // Wf^T (bf16, channels padded to 16), fp32 accumulation.  (A first version reduced 10 per-lane partial sums per frame over
+            // the wave with a 17-shuffle butterfly: 100 butterflies per step and 43 spilled VGPRs, +11 us per step.)
+            const int g = lane >> 4, c16 = lane & 15;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < A / 32; ++ks) {
+                const u16x8_t av = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(L.dvb) + (size_t)(wv * 16 + c16) * A + ks * 32 + g * 8);
+                const u16x8_t bv = *reinterpret_cast<const u16x8_t*>(L.wfb + (size_t)c16 * A + ks * 32 + g * 8);
+                acc = mfma_bf16_16x16x32(av, bv, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = wv * 16 + g * 4 + r;
+                if (fr < Tp && c16 < a.C) L.dfc[fr * a.C + c16] = acc[r];
+            }
+        }
         {
             float sacc = 0.f;
             if (tid < 2 * A) {
@@ -1977,27 +2059,18 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             // d f of this step is complete (the barriers of the dq / du reduction): keep it for the after-loop filter gradient, and send
             // d alpha_{t-1}[src] = sum_k sum_c dfc[src - k + pad, c] w[k, c] back to the previous step: the taps of a source frame are
             // split over NKC thread groups, the partial sums meet in the (free) partials scratch
-            const int C = a.C, pad = (a.Kc - 1) / 2;
+            const int C = a.C;
             float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
             for (int i = tid; i < Tp * C; i += RNT) ds[i] = L.dfc[i];
-            const int NKC = RNT / Tp > 0 ? (RNT / Tp < 8 ? RNT / Tp : 8) : 1, kper = (a.Kc + NKC - 1) / NKC;
-            for (int i = tid; i < NKC * Tp; i += RNT) {
-                const int kc = i / Tp, src = i - kc * Tp;
-                int k0 = kc * kper, k1 = k0 + kper < a.Kc ? k0 + kper : a.Kc;
-                if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
-                if (k1 > src + pad + 1) k1 = src + pad + 1;
-                float acc = 0.f;
-                for (int k = k0; k < k1; ++k) {
-                    const float* dr = L.dfc + (src - k + pad) * C;
-                    const float* wr = L.locw + k * C;
-                    for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
-                }
-                L.scr[i] = acc;
-            }
+            STAMPX(28);
+            loc_conv_partials<true>(L.dfc - (a.Kc - 1 - (a.Kc - 1) / 2) * a.C, L.locw, L.scr, a, tid);       // [chunk][src][c] partial products
             lds_barrier();
+            STAMPX(29);
             if (tid < Tp) {
+                const int n = loc_conv_chunks(a);
                 float acc = 0.f;
-                for (int kc = 0; kc < NKC; ++kc) acc += L.scr[kc * Tp + tid];
+                for (int ch = 0; ch < n; ++ch)
+                    for (int c = 0; c < C; ++c) acc += L.scr[(ch * Tp + tid) * C + c];
                 L.daext[tid] = acc;
             }
         }
@@ -2323,7 +2396,7 @@ static bool loop_ok(const DecDev& d, int ncols, int K, int tpw, int kw) {
 static bool loc_loop_ok(const DecDev& d, int G) {
     const int GD = G * d.D, I0D = d.E + d.Hd + d.D;
     return d.mode == LAS_ATT_LOC && !(d.flags & (LAS_SPELLER_NO_PF_ROWS | LAS_SPELLER_NO_BF_ROWS | LAS_SPELLER_NO_FUSED_STEP)) &&
-           pf_geom_ok(d) && d.C >= 1 && d.C <= 10 && d.Kc * d.C <= 4096 && cdiv(d.Tp, 8) <= RNG &&
+           pf_geom_ok(d) && (d.A % 32) == 0 && d.C >= 1 && d.C <= 10 && d.Kc * d.C <= 4096 && cdiv(d.Tp, 8) <= RNG &&
            loop_geom_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F) && loop_geom_ok(d, d.Hd + d.D, GD, LOOP_TPW_B, LOOP_KW_B);
 }
 static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
@@ -2331,7 +2404,7 @@ static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
     p.pn = las_device_cus() / 8 - p.R;
 }
 template <class K> static int loop_lds_attr(K kernel) {   // the product workgroups' partial tiles need > 64 KB of dynamic LDS
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 #define LAS_LOOP_LAUNCH1(KERNEL, CELL, NE, LOC, grid, lds, st, d)                                          \
     do {                                                                                                   \
@@ -2400,7 +2473,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
     if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= (locloop ? 96 : 64) * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);   // (loop launches: 96 KB attribute)
+        LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);   // (loop launches: 96 KB attribute)
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
@@ -2502,7 +2575,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     const bool locloop = skinny && loc_loop_ok(d, G);
     const size_t lds_bf = bf_lds_bytes(d);
     if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= (locloop ? 96 : 64) * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
+        LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
         if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
     }

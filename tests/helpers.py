@@ -56,7 +56,7 @@ def loc_loop_eligible(args, B, Tp, U, cell="lstm", cus=256):
     GD, I0D, C, Kc = G * D, E + Hd + D, args.loc_num_channels, args.loc_kernel_size
     cd = lambda a, b: -(-a // b)
     geom = (args.num_dec_layers == 1 and D <= 512 and A <= 128 and Hd <= 512 and Tp <= 224 and E <= 1024 and E % 2 == 0 and D % 2 == 0
-            and A % 8 == 0 and Hd % 8 == 0 and 1 <= C <= 10 and Kc * C <= 4096 and cd(Tp, 8) <= 32)
+            and A % 32 == 0 and Hd % 8 == 0 and 1 <= C <= 10 and Kc * C <= 4096 and cd(Tp, 8) <= 32)
     R = cd(B, 8)
     pn = cus // 8 - R
 

@@ -21,6 +21,7 @@ template <class T> static T* dalloc(size_t n, float fill = 0.01f) {
 
 int main(int argc, char** argv) {
     const int nap = argc > 1 ? atoi(argv[1]) : 0;
+    const bool LOCM = argc > 2 && !strcmp(argv[2], "loc");          // location-aware attention (K = 201, C = 10) in the loop kernels
     const int B = 48, Tp = 160, Hd = 512, A = 128, D = 512, NL = 1, E = 128, V = 30, U = 191, G = 4;
     const int I0D = E + Hd + D, GD = G * D;
     DecDev d; memset(&d, 0, sizeof(d));
@@ -41,7 +42,14 @@ int main(int argc, char** argv) {
     d.dC = dalloc<float>((size_t)B * D); d.dXin0 = dalloc<float>((size_t)U * B * I0D); d.Q = dalloc<float>((size_t)U * B * A);
     d.dQ = dalloc<float>((size_t)U * B * A); d.duRows = dalloc<float>((size_t)B * A);
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;
-    const size_t lds = bf_lds_bytes(d), lds_lp = 16 * 5 * 1024;
+    if (LOCM) {
+        d.mode = LAS_ATT_LOC; d.Kc = 201; d.C = 10;
+        d.loc_w = dalloc<float>((size_t)d.Kc * d.C); d.loc_b = dalloc<float>(d.C); d.Wf = dalloc<float>((size_t)d.C * A);
+        d.fcSave = dalloc<float>((size_t)U * B * Tp * d.C); d.dfcSave = dalloc<float>((size_t)U * B * Tp * d.C);
+    }
+    const size_t lds = bf_lds_bytes(d), lds_lp = lds > 16 * 5 * 1024 ? lds : 16 * 5 * 1024;
+    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     void *packF, *packB; hipMalloc(&packF, las_skinny_pack_bytes(I0D, GD)); hipMalloc(&packB, las_skinny_pack_bytes(GD, I0D));
@@ -51,6 +59,7 @@ int main(int argc, char** argv) {
     hipMalloc(&gG, (size_t)B * (GD / 4) * 16); hipMalloc(&gB, (size_t)B * ((Hd + D) / 2) * 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int which = 0; which < 4; ++which) {
+        if (LOCM && !(which & 1)) continue;                           // (the per-step kernels serve additive attention only)
         for (int rep = 0; rep < 3; ++rep) {
             DecDev f = d;
             if (which == 0 || which == 1) las_skinny_pack(W0, GD, I0D, GD, 0, packF, 0);
@@ -73,12 +82,14 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL((dec_step_fwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, f, t);
                 if (t < U) las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + (size_t)t * B * GD, GD, b0, 0);
             }
-            if (which == 1) hipLaunchKernelGGL((dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            if (which == 1 && LOCM) hipLaunchKernelGGL((dec_loop_fwd_kernel<LAS_CELL_LSTM, 10, true>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            else if (which == 1) hipLaunchKernelGGL((dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
             if (which == 2) for (int t = U - 1; t >= -1; --t) {
                 hipLaunchKernelGGL((dec_step_bwd_pf_kernel<LAS_CELL_LSTM, 10>), dim3(B), dim3(RNT), lds, 0, f, t + 1 < U ? t + 1 : -1, t);
                 if (t >= 0) las_skinny_gemm_bf16(d.dgbf, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, 0);
             }
-            if (which == 3) hipLaunchKernelGGL((dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            if (which == 3 && LOCM) hipLaunchKernelGGL((dec_loop_bwd_kernel<LAS_CELL_LSTM, 10, true>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
+            else if (which == 3) hipLaunchKernelGGL((dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>), dim3(8 * (f.lp.pn + f.lp.R)), dim3(RNT), lds_lp, 0, f);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -92,6 +103,7 @@ int main(int argc, char** argv) {
                 printf("  same-XCD groups: %d\n", (int)hs[31]);
                 const unsigned long long z = hs[ids[which == 3][0]];
                 for (int i = 0; i < 12; ++i) printf("  stamp %2d: %+7.2f us\n", ids[which == 3][i], ((double)hs[ids[which == 3][i]] - (double)z) * 0.01);
+                for (int i = 25; i < 31; ++i) if (hs[i]) printf("  stamp %2d: %+7.2f us   (location-aware phases)\n", i, ((double)hs[i] - (double)z) * 0.01);
             }
 #endif
         }
