@@ -22,15 +22,78 @@ __device__ __forceinline__ bool bless(const BKey& a, const BKey& b) {   // a < b
     return a.v < b.v;
 }
 
+// The `beam` best candidates of one utterance, best first, into picks[] (LDS); returns how many exist.  Called by all 256
+// threads of the workgroup.  Every round takes the block-wide maximum of the candidates strictly below the previous pick: keys of a
+// grid that fits 4 candidates per thread are computed once and kept in registers, the maximum is a wave butterfly (64-lane xor
+// shuffles) plus one LDS slot per wave -- one barrier per round (the slots are double-buffered).  r3 decode trace: the former
+// version (memory re-scan + 8-level LDS tree with 9 barriers per round) was 44 us of a 170 us decode step at beam 16, V = 30.
+__device__ __forceinline__ BKey bkey_shfl_xor(const BKey& k, int off) {
+    BKey y;
+    y.norm = __shfl_xor(k.norm, off, 64); y.i = __shfl_xor(k.i, off, 64); y.l = __shfl_xor(k.l, off, 64); y.v = __shfl_xor(k.v, off, 64);
+    return y;
+}
+__device__ __forceinline__ void bkey_max(BKey& best, const BKey& y) {          // i < 0: no candidate
+    if (y.i >= 0 && (best.i < 0 || bless(best, y))) best = y;
+}
+__device__ __forceinline__ bool beam_make_key(BKey& k, const float* lg, const float* sc, const int* ln, int idx, int V, int t, int start_id) {
+    const int i = idx / V;
+    const int v = idx - i * V;
+    if (t > 0 && v == start_id) return false;           // las/beam_search.py:127-128
+    const float l = lg[idx];
+    k.norm = (sc[i] + l) / (float)(ln[i] + 1);          // float32 sum, float32 divide (las/beam_search.py:27,306)
+    k.i = i; k.l = l; k.v = idx;                        // v carries the flat candidate id until the very end
+    return k.norm == k.norm;                            // NaN never ranks
+}
+__device__ int beam_rank(const float* lg, const float* sc, const int* ln, int nb, int V, int t, int start_id, int beam,
+                         BKey* picks, BKey (*wbest)[4]) {
+    constexpr int CPT = 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ncand = nb * V;
+    const bool cached = ncand <= 256 * CPT;
+    BKey ck[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        ck[c].i = -1;
+        const int idx = tid + c * 256;
+        if (cached && idx < ncand) { BKey k; if (beam_make_key(k, lg, sc, ln, idx, V, t, start_id)) ck[c] = k; }
+    }
+    BKey last = {0.f, 0, 0.f, 0};
+    int count = 0;
+    for (int pick = 0; pick < beam; ++pick) {
+        BKey best = {0.f, -1, 0.f, 0};
+        if (cached) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (ck[c].i >= 0 && (pick == 0 || bless(ck[c], last))) bkey_max(best, ck[c]);
+        } else {
+            for (int idx = tid; idx < ncand; idx += 256) {
+                BKey k;
+                if (beam_make_key(k, lg, sc, ln, idx, V, t, start_id) && (pick == 0 || bless(k, last))) bkey_max(best, k);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bkey_max(best, bkey_shfl_xor(best, off));
+        if (lane == 0) wbest[pick & 1][w] = best;
+        __syncthreads();
+        best = wbest[pick & 1][0];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) bkey_max(best, wbest[pick & 1][ww]);
+        if (best.i < 0) break;                           // uniform: every thread combined the same four slots
+        last = best;
+        if (tid == 0) picks[pick] = best;
+        count = pick + 1;
+    }
+    __syncthreads();
+    return count;
+}
+
 __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, const float* __restrict__ score,
                                                         const int* __restrict__ length, const int* __restrict__ nlive,
                                                         int beam, int V, int t, int start_id, int* __restrict__ out_parent,
                                                         int* __restrict__ out_token, float* __restrict__ out_score,
                                                         int* __restrict__ out_n) {
-    __shared__ float s_norm[256], s_l[256];
-    __shared__ int s_i[256], s_v[256];
     __shared__ BKey picks[64];
-    __shared__ int s_count;
+    __shared__ BKey wbest[2][4];
     const int u = blockIdx.x, tid = threadIdx.x;
     int nb = nlive[u];
     if (nb > beam) nb = beam;
@@ -38,48 +101,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     const float* lg = logits + (size_t)u * beam * V;
     const float* sc = score + (size_t)u * beam;
     const int* ln = length + (size_t)u * beam;
-    BKey last = {0.f, 0, 0.f, 0};
-    int count = 0;
-    for (int pick = 0; pick < beam; ++pick) {
-        BKey best = {0.f, -1, 0.f, 0};
-        bool has = false;
-        const int ncand = nb * V;
-        for (int idx = tid; idx < ncand; idx += 256) {
-            const int i = idx / V;
-            const int v = idx - i * V;
-            if (t > 0 && v == start_id) continue;      // las/beam_search.py:127-128
-            const float l = lg[idx];
-            BKey k;
-            k.norm = (sc[i] + l) / (float)(ln[i] + 1);  // float32 sum, float32 divide (las/beam_search.py:27,306)
-            k.i = i; k.l = l; k.v = idx;                // v carries the flat candidate id until the very end
-            if (!(k.norm == k.norm)) continue;          // NaN never ranks
-            if (pick > 0 && !bless(k, last)) continue;
-            if (!has || bless(best, k)) { best = k; has = true; }
-        }
-        // block reduce through LDS (tree over 256 slots)
-        __syncthreads();
-        s_norm[tid] = best.norm; s_i[tid] = has ? best.i : -1; s_l[tid] = best.l; s_v[tid] = best.v;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) {
-                const BKey x = {s_norm[tid], s_i[tid], s_l[tid], s_v[tid]};
-                const BKey y = {s_norm[tid + off], s_i[tid + off], s_l[tid + off], s_v[tid + off]};
-                if (y.i >= 0 && (x.i < 0 || bless(x, y))) {
-                    s_norm[tid] = y.norm; s_i[tid] = y.i; s_l[tid] = y.l; s_v[tid] = y.v;
-                }
-            }
-            __syncthreads();
-        }
-        best.norm = s_norm[0]; best.i = s_i[0]; best.l = s_l[0]; best.v = s_v[0];
-        has = best.i >= 0;
-        if (!has) break;                                 // uniform: every thread reads slot 0
-        last = best;
-        if (tid == 0) picks[pick] = best;
-        count = pick + 1;
-    }
-    __syncthreads();
-    if (tid == 0) { s_count = count; out_n[u] = count; }
-    __syncthreads();
+    const int count = beam_rank(lg, sc, ln, nb, V, t, start_id, beam, picks, wbest);
+    if (tid == 0) out_n[u] = count;
     for (int j = tid; j < count; j += 256) {             // ascending, best last (las/beam_search.py:310-312)
         const BKey k = picks[count - 1 - j];
         out_parent[(size_t)u * beam + j] = k.i;
@@ -121,16 +144,28 @@ struct BeamLoopDev {
     int* src_row;                   // [nutt, beam] out: live slot k of the next step continues row src_row (global row index)
     int* next_token;                // [nutt * beam] out: token entering the next step for each live slot
     int nutt, beam, V, Umax, selcap, start_id, end_id;
+    const float* file_in; float* file_out; long long file_n;   // optional per-step record: file_out[t][0..file_n) = file_in[0..file_n) (workgroups >= nutt)
 };
 
 __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
-    __shared__ float s_norm[256], s_l[256];
-    __shared__ int s_i[256], s_v[256];
     __shared__ BKey picks[64];
+    __shared__ BKey wbest[2][4];
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
     const int t = a.step[0];
-    int* hn = a.hist_n + (size_t)t * a.nutt + u;
     if (t >= a.Umax) return;
+    if (u >= a.nutt) {                                    // filing workgroups: this step's row tensor (the alignments) under the DEVICE step counter
+        const int nf = (int)gridDim.x - a.nutt;
+        float* dst = a.file_out + (size_t)t * a.file_n;
+        if (((a.file_n & 3) | ((size_t)a.file_in & 15) | ((size_t)dst & 15)) == 0) {
+            const long long n4 = a.file_n >> 2;
+            for (long long i = (long long)(u - a.nutt) * 256 + tid; i < n4; i += (long long)nf * 256)
+                reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(a.file_in)[i];
+        } else {
+            for (long long i = (long long)(u - a.nutt) * 256 + tid; i < a.file_n; i += (long long)nf * 256) dst[i] = a.file_in[i];
+        }
+        return;
+    }
+    int* hn = a.hist_n + (size_t)t * a.nutt + u;
     if (a.done[u] || t >= a.dec_step[u]) {               // retired utterance: nothing to do (its rows compute ignored garbage)
         if (tid == 0) { *hn = 0; a.done[u] = 1; a.nlive[u] = 0; }
         for (int k = tid; k < beam; k += 256) { a.src_row[(size_t)u * beam + k] = u * beam; }
@@ -142,77 +177,40 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     const float* lg = a.logits + (size_t)u * beam * V;
     float* sc = a.score + (size_t)u * beam;
     int* ln = a.length + (size_t)u * beam;
-    BKey last = {0.f, 0, 0.f, 0};
-    int count = 0;
-    for (int pick = 0; pick < beam; ++pick) {
-        BKey best = {0.f, -1, 0.f, 0};
-        bool has = false;
-        const int ncand = nb * V;
-        for (int idx = tid; idx < ncand; idx += 256) {
-            const int i = idx / V;
-            const int v = idx - i * V;
-            if (t > 0 && v == a.start_id) continue;    // las/beam_search.py:127-128
-            const float l = lg[idx];
-            BKey k;
-            k.norm = (sc[i] + l) / (float)(ln[i] + 1);  // float32 sum, float32 divide (las/beam_search.py:27,306)
-            k.i = i; k.l = l; k.v = idx;
-            if (!(k.norm == k.norm)) continue;
-            if (pick > 0 && !bless(k, last)) continue;
-            if (!has || bless(best, k)) { best = k; has = true; }
-        }
-        __syncthreads();
-        s_norm[tid] = best.norm; s_i[tid] = has ? best.i : -1; s_l[tid] = best.l; s_v[tid] = best.v;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) {
-                const BKey x = {s_norm[tid], s_i[tid], s_l[tid], s_v[tid]};
-                const BKey y = {s_norm[tid + off], s_i[tid + off], s_l[tid + off], s_v[tid + off]};
-                if (y.i >= 0 && (x.i < 0 || bless(x, y))) {
-                    s_norm[tid] = y.norm; s_i[tid] = y.i; s_l[tid] = y.l; s_v[tid] = y.v;
-                }
-            }
-            __syncthreads();
-        }
-        best.norm = s_norm[0]; best.i = s_i[0]; best.l = s_l[0]; best.v = s_v[0];
-        has = best.i >= 0;
-        if (!has) break;
-        last = best;
-        if (tid == 0) picks[pick] = best;
-        count = pick + 1;
+    const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, picks, wbest);
+    if (tid >= 64) return;
+    // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
+    // first wave is pick j (beam <= 64); the positions of the retired / surviving picks in their lists are prefix counts of ballots
+    const int j = tid;
+    const bool act = j < count;
+    BKey k = {0.f, 0, 0.f, 0};
+    if (act) k = picks[count - 1 - j];
+    const int v = k.v - k.i * V;
+    const float news = sc[k.i] + k.l;                    // (every lane reads the old sums before any lane stores the new ones below)
+    const int newl = ln[k.i] + 1;
+    const bool isend = act && v == a.end_id, live = act && !isend;
+    const unsigned long long mend = __ballot(isend), mlive = __ballot(live), below = (1ull << j) - 1ull;
+    const int ns0 = a.nsel[u];
+    const int eidx = ns0 + __popcll(mend & below), lidx = __popcll(mlive & below);
+    const int nl = __popcll(mlive);
+    int ns = ns0 + __popcll(mend);
+    const size_t hb = ((size_t)t * a.nutt + u) * beam;
+    if (act) { a.hist_parent[hb + j] = k.i; a.hist_token[hb + j] = v; a.hist_score[hb + j] = news; }
+    if (isend && eidx < a.selcap) { a.sel_t[(size_t)u * a.selcap + eidx] = t; a.sel_j[(size_t)u * a.selcap + eidx] = j; }
+    if (live) {
+        a.hist_slot[hb + lidx] = j;                               // live slot lidx of step t+1 is pick j of step t
+        a.src_row[(size_t)u * beam + lidx] = u * beam + k.i;
+        a.next_token[(size_t)u * beam + lidx] = v;
+        sc[lidx] = news; ln[lidx] = newl;
     }
-    __syncthreads();
+    if (j >= nl && j < beam) { a.src_row[(size_t)u * beam + j] = u * beam; a.next_token[(size_t)u * beam + j] = a.start_id; }
+    const bool exhausted = (t + 1 == a.dec_step[u]);
+    if (exhausted) {                                               // `if t == dec_step: selected.extend(beam_set)` (:155-156)
+        if (live && ns + lidx < a.selcap) { a.sel_t[(size_t)u * a.selcap + ns + lidx] = t; a.sel_j[(size_t)u * a.selcap + ns + lidx] = j; }
+        ns += nl;
+    }
     if (tid == 0) {
-        // the reference's bookkeeping (las/beam_search.py:147-152), in its iteration order = ascending rank (best last)
-        float nsc[64]; int nln[64];
-        int nl = 0, ns = a.nsel[u];
-        const size_t hb = ((size_t)t * a.nutt + u) * beam;
-        for (int j = 0; j < count; ++j) {
-            const BKey k = picks[count - 1 - j];
-            const int v = k.v - k.i * V;
-            const float news = sc[k.i] + k.l;
-            const int newl = ln[k.i] + 1;
-            a.hist_parent[hb + j] = k.i; a.hist_token[hb + j] = v; a.hist_score[hb + j] = news;
-            if (v == a.end_id) {
-                if (ns < a.selcap) { a.sel_t[(size_t)u * a.selcap + ns] = t; a.sel_j[(size_t)u * a.selcap + ns] = j; }
-                ++ns;
-            } else {
-                nsc[nl] = news; nln[nl] = newl;
-                a.hist_slot[hb + nl] = j;                         // live slot nl of step t+1 is pick j of step t
-                a.src_row[(size_t)u * beam + nl] = u * beam + k.i;
-                a.next_token[(size_t)u * beam + nl] = v;
-                ++nl;
-            }
-        }
         *hn = count;
-        for (int k = nl; k < beam; ++k) { a.src_row[(size_t)u * beam + k] = u * beam; a.next_token[(size_t)u * beam + k] = a.start_id; }
-        for (int k = 0; k < nl; ++k) { sc[k] = nsc[k]; ln[k] = nln[k]; }
-        const bool exhausted = (t + 1 == a.dec_step[u]);
-        if (exhausted) {                                           // `if t == dec_step: selected.extend(beam_set)` (:155-156)
-            for (int k = 0; k < nl; ++k) {
-                if (ns < a.selcap) { a.sel_t[(size_t)u * a.selcap + ns] = t; a.sel_j[(size_t)u * a.selcap + ns] = a.hist_slot[hb + k]; }
-                ++ns;
-            }
-        }
         const bool fin = exhausted || ns >= beam || nl == 0;        // loop condition of :94 (+ no live hypothesis left)
         a.nsel[u] = ns;
         a.nlive[u] = fin ? 0 : nl;
@@ -229,6 +227,7 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(GatherDev g) {
     const float* ip = g.in[k] + (size_t)src * w;
     float* op = g.out[k] + (size_t)r * w;
     for (int i = threadIdx.x; i < w; i += 256) op[i] = ip[i];
+    if (r == 0 && k == 0 && threadIdx.x == 0) g.step[0] += 1;       // no workgroup of this kernel reads the counter
 }
 __global__ void beam_advance_kernel(int* step) { step[0] += 1; }
 
@@ -247,7 +246,14 @@ extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
     a.hist_parent = p->hist_parent; a.hist_token = p->hist_token; a.hist_slot = p->hist_slot; a.hist_score = p->hist_score; a.hist_n = p->hist_n;
     a.sel_t = p->sel_t; a.sel_j = p->sel_j; a.src_row = p->src_row; a.next_token = p->next_token;
     a.nutt = p->nutt; a.beam = p->beam; a.V = p->V; a.Umax = p->Umax; a.selcap = p->selcap; a.start_id = p->start_id; a.end_id = p->end_id;
-    hipLaunchKernelGGL(beam_loop_kernel, dim3(p->nutt), dim3(256), 0, st, a);
+    a.file_in = p->file_in; a.file_out = p->file_out; a.file_n = (long long)p->nutt * p->beam * p->file_width;
+    int nfile = 0;
+    if (p->file_in) {
+        LAS_ARG(p->file_out && p->file_width > 0, "las_beam_loop_step: file_in without file_out / file_width");
+        nfile = (int)((a.file_n + 4095) / 4096);
+        if (nfile > 64) nfile = 64;
+    }
+    hipLaunchKernelGGL(beam_loop_kernel, dim3(p->nutt + nfile), dim3(256), 0, st, a);
     LAS_LAUNCHED();
     if (p->ntens > 0) {
         GatherDev g;
@@ -256,10 +262,59 @@ extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
             LAS_ARG(p->state_in[k] && p->state_out[k] && p->state_width[k] > 0, "las_beam_loop_step: bad state tensor %d", k);
             g.in[k] = p->state_in[k]; g.out[k] = p->state_out[k]; g.width[k] = p->state_width[k];
         }
-        hipLaunchKernelGGL(beam_gather_kernel, dim3(g.nrows, p->ntens), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(beam_gather_kernel, dim3(g.nrows, p->ntens), dim3(256), 0, st, g);      // ... and *step += 1
+        LAS_LAUNCHED();
+    } else {
+        hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(1), 0, st, p->step);
         LAS_LAUNCHED();
     }
-    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(1), 0, st, p->step);
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// After the last step: the token ids of every retired hypothesis by walking the back-pointer records on the device (one thread per
+// (utterance, selection slot); the reference keeps whole token lists in its BeamState objects instead, las/beam_search.py:38-45).
+//   ids / rows [nutt * selcap, Umax]: token and global state row (utterance * beam + live slot) of the hypothesis at step p < len;
+//   len [nutt * selcap]: tokens after SOS (0 = unused slot); score [nutt * selcap]: the running float32 sum.
+// ----------------------------------------------------------------------------------------------------
+struct BacktrackDev {
+    const int *hist_parent, *hist_token, *hist_slot; const float* hist_score; const int *sel_t, *sel_j, *nsel;
+    int nutt, beam, Umax, selcap;
+    int *ids, *rows, *len; float* score;
+};
+__global__ __launch_bounds__(64) void beam_backtrack_kernel(BacktrackDev a) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= a.nutt * a.selcap) return;
+    const int u = w / a.selcap, s = w - u * a.selcap;
+    int n = a.nsel[u];
+    if (n > a.selcap) n = a.selcap;
+    if (s >= n) { a.len[w] = 0; a.score[w] = 0.f; return; }
+    const int ts = a.sel_t[w], js = a.sel_j[w];
+    int* ids = a.ids + (size_t)w * a.Umax;
+    int* rows = a.rows + (size_t)w * a.Umax;
+    int j = js;
+    for (int tt = ts; ; --tt) {
+        const size_t hb = ((size_t)tt * a.nutt + u) * a.beam;
+        const int slot = a.hist_parent[hb + j];
+        ids[tt] = a.hist_token[hb + j];
+        rows[tt] = u * a.beam + slot;
+        if (tt == 0) break;
+        j = a.hist_slot[hb - (size_t)a.nutt * a.beam + slot];       // pick of step tt-1 that became live slot `slot`
+    }
+    a.len[w] = ts + 1;
+    a.score[w] = a.hist_score[((size_t)ts * a.nutt + u) * a.beam + js];
+}
+
+extern "C" int las_beam_backtrack(const las_beam_loop_args* p, int* ids, int* rows, int* len, float* score, void* stream) {
+    LAS_ARG(p && ids && rows && len && score, "las_beam_backtrack: null pointer");
+    LAS_ARG(p->hist_parent && p->hist_token && p->hist_slot && p->hist_score && p->sel_t && p->sel_j && p->nsel, "las_beam_backtrack: null record pointer");
+    LAS_ARG(p->nutt > 0 && p->beam > 0 && p->Umax > 0 && p->selcap > 0, "las_beam_backtrack: bad dims");
+    BacktrackDev a;
+    a.hist_parent = p->hist_parent; a.hist_token = p->hist_token; a.hist_slot = p->hist_slot; a.hist_score = p->hist_score;
+    a.sel_t = p->sel_t; a.sel_j = p->sel_j; a.nsel = p->nsel;
+    a.nutt = p->nutt; a.beam = p->beam; a.Umax = p->Umax; a.selcap = p->selcap;
+    a.ids = ids; a.rows = rows; a.len = len; a.score = score;
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3(cdiv(p->nutt * p->selcap, 64)), dim3(64), 0, (hipStream_t)stream, a);
     LAS_LAUNCHED();
     return 0;
 }

@@ -182,14 +182,22 @@ extern "C" int las_clip_adam(float* theta, const float* g, float* m, float* v, l
 // las/beam_search.py:226-236): z = [x,h].kernel + bias comes from las_gemm; here
 //   i,j,f,o = split(z,4); c' = c*sigmoid(f+fb) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float* __restrict__ z, const float* __restrict__ c_prev, int N,
+__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float* __restrict__ z, const float* __restrict__ xrows,
+                                                             const int* __restrict__ ids, int id_shift, const float* __restrict__ c_prev, int N,
                                                              int H, float fb, float* __restrict__ c_out, float* __restrict__ h_out) {
     const long long total = (long long)N * H;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const long long n = idx / H;
         const int u = (int)(idx % H);
         const float* zr = z + n * 4 * H;
-        const float gi = sigmoid_acc(zr[u]), gj = tanh_acc(zr[H + u]), gf = sigmoid_acc(zr[2 * H + u] + fb), go = sigmoid_acc(zr[3 * H + u]);
+        float zi = zr[u], zj = zr[H + u], zf = zr[2 * H + u], zo = zr[3 * H + u];
+        if (xrows) {                                     // + the input half of a one-hot input: row max(ids[n] - id_shift, 0) of W_x
+            int id = ids[n] - id_shift;
+            if (id < 0) id = 0;
+            const float* xr = xrows + (long long)id * 4 * H;
+            zi += xr[u]; zj += xr[H + u]; zf += xr[2 * H + u]; zo += xr[3 * H + u];
+        }
+        const float gi = sigmoid_acc(zi), gj = tanh_acc(zj), gf = sigmoid_acc(zf + fb), go = sigmoid_acc(zo);
         const float c = c_prev[idx] * gf + gi * gj;
         c_out[idx] = c;
         h_out[idx] = tanh_acc(c) * go;
@@ -201,7 +209,21 @@ extern "C" int las_lstm_pointwise(const float* z, const float* c_prev, int N, in
     LAS_ARG(z && c_prev && c_out && h_out && N > 0 && H > 0, "las_lstm_pointwise: bad arguments");
     int nb = cdiv((long long)N * H, 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, c_prev, N, H, forget_bias, c_out, h_out);
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, nullptr, nullptr, 0, c_prev, N, H, forget_bias, c_out,
+                       h_out);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+// the same with the input half of a ONE-HOT input added on the way in: z[n] + xrows[max(ids[n] - id_shift, 0)] (xrows [V, 4H] = the input
+// rows of the TF cell kernel; the shift / clamp is the LAS-id -> LM-id map of the shallow fusion, las/beam_search.py:109-116)
+extern "C" int las_lstm_pointwise_rows(const float* z, const float* xrows, const int* ids, int id_shift, const float* c_prev, int N, int H,
+                                       float forget_bias, float* c_out, float* h_out, void* stream) {
+    LAS_ARG(z && xrows && ids && c_prev && c_out && h_out && N > 0 && H > 0, "las_lstm_pointwise_rows: bad arguments");
+    int nb = cdiv((long long)N * H, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, xrows, ids, id_shift, c_prev, N, H, forget_bias,
+                       c_out, h_out);
     LAS_LAUNCHED();
     return 0;
 }

@@ -275,10 +275,12 @@ class CharRNN(object):
             plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
-    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0):
-        """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM ids), the result is
-        ACCUMULATED into logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input
-        and recurrent halves of every cell product are separate GEMMs against row blocks of the TF kernel.
+    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0):
+        """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM id = max(ids - id_shift, 0):
+        with id_shift = 2 the beam search's LAS ids are read as they are), the result is ACCUMULATED into
+        logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input and recurrent halves
+        of every cell product are separate GEMMs against row blocks of the TF kernel, and the one-hot input's half is a row
+        look-up inside the gate kernel (las_lstm_pointwise_rows).
         Returns (c_new list, h_new list)."""
         P = self.params()
         dev = logits.device
@@ -298,19 +300,23 @@ class CharRNN(object):
                     _hip.skinny_gemm(h_prev[l], plan["packs"][l][0], z, N, H, 4 * H, H, 4 * H, bias=b)
                 else:
                     _hip.gemm(prec, h_prev[l], k, z, False, False, N, 4 * H, H, H, 4 * H, 4 * H, bias=b, b_off=I * 4 * H)
-                if l == 0 and "wx" in plan:
-                    z += plan["wx"].index_select(0, ids)
-                else:
+                rows = l == 0 and "wx" in plan
+                if not rows:
                     if l == 0:
-                        x = P["embedding"].detach().index_select(0, ids)
+                        lm_ids = (ids - id_shift).clamp_min_(0) if id_shift else ids
+                        x = P["embedding"].detach().index_select(0, lm_ids)
                     if skinny:
                         _hip.skinny_gemm(x, plan["packs"][l][1], z, N, I, 4 * H, I, 4 * H, accumulate=True)
                     else:
                         _hip.gemm(prec, x, k, z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, beta=1.0)
                 c_new = torch.empty(N, H, device=dev)
                 h_new = torch.empty(N, H, device=dev)
-                _hip.check(lib.las_lstm_pointwise(_hip.p(z), _hip.p(c_prev[l]), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
-                                                  _hip.stream()), "las_lstm_pointwise")
+                if rows:
+                    _hip.check(lib.las_lstm_pointwise_rows(_hip.p(z), _hip.p(plan["wx"]), _hip.p(ids), int(id_shift), _hip.p(c_prev[l]), N, H, 0.0,
+                                                           _hip.p(c_new), _hip.p(h_new), _hip.stream()), "las_lstm_pointwise_rows")
+                else:
+                    _hip.check(lib.las_lstm_pointwise(_hip.p(z), _hip.p(c_prev[l]), N, H, 0.0, _hip.p(c_new), _hip.p(h_new),
+                                                      _hip.stream()), "las_lstm_pointwise")
                 cs.append(c_new)
                 hs.append(h_new)
                 x = h_new

@@ -41,7 +41,8 @@ class BeamLoopArgs(Structure):
                                         "hist_parent", "hist_token", "hist_slot", "hist_score", "hist_n",
                                         "sel_t", "sel_j", "src_row", "next_token")] + \
                [(n, c_int) for n in ("nutt", "beam", "V", "Umax", "selcap", "topn", "start_id", "end_id", "ntens")] + \
-               [("state_in", c_void_p * 16), ("state_out", c_void_p * 16), ("state_width", c_int * 16)]
+               [("state_in", c_void_p * 16), ("state_out", c_void_p * 16), ("state_width", c_int * 16)] + \
+               [("file_in", c_void_p), ("file_out", c_void_p), ("file_width", c_int)]
 
 
 class SpellerBwdArgs(Structure):
@@ -124,10 +125,12 @@ _SIGS = {
     "las_rnn_seq_fwd_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                         c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "las_lstm_pointwise_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_beam_loop_step": (c_int, [POINTER(BeamLoopArgs), c_void_p]),
+    "las_beam_backtrack": (c_int, [POINTER(BeamLoopArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_gemm_skinny_pack_bytes": (c_size_t, [c_int, c_int]),
     "las_gemm_skinny_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "las_gemm_skinny": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),

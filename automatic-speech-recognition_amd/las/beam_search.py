@@ -235,9 +235,9 @@ class BeamSearch(object):
         # same sequence of launches with the same arguments every time: it is captured into a HIP graph after the first
         # (eager) step and replayed -- the loop is bound by the host's launch rate otherwise (~25 launches per step)
         alphas_cur = torch.zeros(N, Tp, device=dev)
-        step64 = torch.zeros(1, dtype=torch.int64, device=dev)
         fa.alphas = alphas_cur.data_ptr()
         ba.state_in[k_align] = alphas_cur.data_ptr()
+        ba.file_in, ba.file_out, ba.file_width = alphas_cur.data_ptr(), alphas_hist.data_ptr(), Tp
         held = []
 
         def speller_part():
@@ -249,16 +249,13 @@ class BeamSearch(object):
         def lm_part():
             # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
             # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-            lm_ids = (next_token - 2).clamp_min_(0)
-            cs_new, hs_new = lm.step_fused(lm_plan, lm_ids, lm_c, lm_h, logits, 2)
+            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2)
             for l in range(NLl):
                 ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
             held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued
 
-        def beam_part():
-            alphas_hist.index_copy_(0, step64, alphas_cur.unsqueeze(0))
+        def beam_part():                                 # files alphas_cur under the device step counter, prunes, gathers, advances the counter
             _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")
-            step64.copy_(step)
 
         def one_step():
             speller_part()
@@ -293,44 +290,33 @@ class BeamSearch(object):
                     break
         del keep
         mark("searched")
-        # ---- one read-back, then the reference's host-side objects
-        hp, ht, hsl = hist_parent[:steps_run].cpu().tolist(), hist_token[:steps_run].cpu().tolist(), hist_slot[:steps_run].cpu().tolist()
-        hsc = hist_score[:steps_run].cpu().numpy()
-        st_, sj_, ns_ = sel_t.cpu().tolist(), sel_j.cpu().tolist(), nsel.cpu().tolist()
+        # ---- the back pointers are walked on the device (las_beam_backtrack); one read-back, then the reference's host-side objects
+        W = n * selcap
+        w_ids = torch.zeros(W, Umax, **i32)
+        w_rows = torch.zeros(W, Umax, **i32)
+        w_len = torch.zeros(W, **i32)
+        w_score = torch.zeros(W, device=dev)
+        _hip.check(lib.las_beam_backtrack(ctypes.byref(ba), _hip.p(w_ids), _hip.p(w_rows), _hip.p(w_len), _hip.p(w_score), _hip.stream()),
+                   "las_beam_backtrack")
+        # every hypothesis' alignments in ONE gather: item 0 of a hypothesis is the all-zero slab [Umax], item 1 + p the row it occupied at step p
+        pos = torch.arange(Umax + 1, device=dev)
+        item = (pos.unsqueeze(0) <= w_len.unsqueeze(1)) & (w_len > 0).unsqueeze(1)                 # [W, Umax + 1]
+        t_idx = torch.cat([torch.full((1,), Umax, device=dev, dtype=torch.int64), pos[:-1]]).expand(W, -1)[item]
+        r_idx = torch.cat([torch.zeros(W, 1, **i32), w_rows], 1)[item].long()
+        g_att = alphas_hist[t_idx, r_idx]
+        lens, ids_h, sc_h = w_len.cpu().numpy(), w_ids.cpu().numpy(), w_score.cpu().numpy()
         _hip.check_status(dev)
-        walks = []                                           # (utterance, ids, score, [time indices], [row indices]) per selected hypothesis
-        for u in range(n):
-            hp_u = [row[u] for row in hp]
-            ht_u = [row[u] for row in ht]
-            hsl_u = [row[u] for row in hsl]
-            for s_i in range(min(int(ns_[u]), selcap)):
-                t_s, j_s = st_[u][s_i], sj_[u][s_i]
-                ids, tts, rows = [], [], []
-                tt, j = t_s, j_s
-                while True:                                  # walk the back pointers (plain Python ints: this loop is hot)
-                    ids.append(ht_u[tt][j])
-                    slot = hp_u[tt][j]
-                    tts.append(tt)
-                    rows.append(u * beam + slot)
-                    if tt == 0:
-                        break
-                    j = hsl_u[tt - 1][slot]
-                    tt -= 1
-                walks.append((u, [self.start_id] + ids[::-1], np.float32(hsc[t_s, u, j_s]), [Umax] + tts[::-1], [0] + rows[::-1]))
-        # every hypothesis' alignments in ONE gather ([Umax] is the all-zero slab: item 0)
-        if walks:
-            ti = torch.tensor([t_ for w_ in walks for t_ in w_[3]], dtype=torch.int64).to(dev)
-            ri = torch.tensor([r_ for w_ in walks for r_ in w_[4]], dtype=torch.int64).to(dev)
-            g_att = alphas_hist[ti, ri]
         results, off = [[] for _ in range(n)], 0
-        for u, ids, sc, tts, rows in walks:
-            results[u].append(BeamState(ids, sc, _AttRows(g_att[off:off + len(tts), :Tps[u]]), None, None))
-            off += len(tts)
+        for w in np.nonzero(lens)[0].tolist():
+            u, ln_ = w // selcap, int(lens[w])
+            results[u].append(BeamState([self.start_id] + ids_h[w, :ln_].tolist(), np.float32(sc_h[w]),
+                                        _AttRows(g_att[off:off + ln_ + 1, :Tps[u]]), None, None))
+            off += ln_ + 1
         results = [self._select_best_k(sel, NORM) for sel in results]
         mark("done")
         parts = {}
         if tm:        # device time of the three parts of a decode step (HIP events, 50 eager repetitions each, after the search)
-            step.zero_(); step64.zero_()
+            step.zero_()
             for name, fn in (("speller", speller_part), ("lm", lm_part if lm is not None else None), ("beam", beam_part)):
                 if fn is None:
                     continue
@@ -340,7 +326,7 @@ class BeamSearch(object):
                     for _ in range(50):
                         fn()
                         if name == "beam":
-                            step.zero_(); step64.zero_()
+                            step.zero_()
                     e1.record()
                 torch.cuda.synchronize(dev)
                 parts[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)

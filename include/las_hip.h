@@ -335,6 +335,12 @@ int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
  */
 int las_lstm_pointwise(const float* z, const float* c_prev, int N, int H, float forget_bias,
                        float* c_out, float* h_out, void* stream);
+/* ... with the input half of a ONE-HOT input (the LM's first layer: the reference feeds tf.one_hot ids, lang/char_rnn_model.py:106-112)
+ * added on the way in: z[n] + xrows[max(ids[n] - id_shift, 0)], xrows [V,4H] = the input rows of the cell kernel.  id_shift / the clamp
+ * are the LAS-id -> LM-id map of the shallow fusion (las/beam_search.py:109-116: LM ids = LAS ids - 2, SOS fed as id 0), so that the
+ * beam search's next_token buffer is read as it is. */
+int las_lstm_pointwise_rows(const float* z, const float* xrows, const int* ids, int id_shift, const float* c_prev, int N, int H,
+                            float forget_bias, float* c_out, float* h_out, void* stream);
 /* ... and its gradient, for training the RNNLM (lang/char_rnn_model.py:177-190, truncated BPTT over num_unrollings steps):
  * dz [N,4H] and dc_prev [N,H] from z, c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c', may be NULL). */
 int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const float* dh, const float* dc_in, int N, int H,
@@ -372,6 +378,8 @@ int las_beam_step(const float* logits, const float* score, const int* length, co
  *   - src_row [nutt,beam] (global row the new live slot continues) and next_token [nutt*beam] for the next step, and
  *     the `ntens` recurrent-state tensors gathered accordingly: state_out[k][row] = state_in[k][src_row[row]]
  *     (state_width[k] floats per row; decoder h/c, previous alignment, LM states);
+ *   - optionally a per-step record of one row tensor (the step's alignments): file_out[t][r] = file_in[r] for the nutt*beam rows of
+ *     file_width floats (file_in NULL = none);
  *   - finally *step += 1 (device-resident step counter: the launch sequence is identical every step, hipGraph friendly).
  * All state is caller-owned and caller-initialised (score 0, length 0, nlive = beam, nsel = done = 0, *step = 0,
  * next_token = start_id).  The host reads the records once after the last step and rebuilds token ids by back-tracking.
@@ -382,8 +390,15 @@ typedef struct {
     int *sel_t, *sel_j; int* src_row; int* next_token;
     int nutt, beam, V, Umax, selcap, topn, start_id, end_id;
     int ntens; const float* state_in[16]; float* state_out[16]; int state_width[16];
+    const float* file_in; float* file_out; int file_width;
 } las_beam_loop_args;
 int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
+/* After the last step: walk the back-pointer records of every retired hypothesis on the device (the reference carries whole token
+ * lists in its BeamState objects, las/beam_search.py:38-45).  For selection slot w = u*selcap + s (s < min(nsel[u], selcap)):
+ * len[w] = tokens after SOS, ids[w][p] / rows[w][p] (p < len[w]; arrays [nutt*selcap, Umax]) = token and global state row
+ * (u*beam + live slot) at step p, score[w] = running float32 sum; unused slots get len 0.  Only the record pointers and
+ * nutt / beam / Umax / selcap of `a` are read. */
+int las_beam_backtrack(const las_beam_loop_args* a, int* ids, int* rows, int* len, float* score, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Skinny-M product for per-step recurrences driven from the host (the char RNNLM step inside beam search,

@@ -59,6 +59,8 @@ def _run_loop(cases):
     for k in range(NL):
         ba.state_in[k], ba.state_out[k], ba.state_width[k] = st_new[k].data_ptr(), st_prev[k].data_ptr(), D
     ba.state_in[NL], ba.state_out[NL], ba.state_width[NL] = al_new.data_ptr(), al_prev.data_ptr(), Tp
+    al_hist, al_snap = torch.full((Umax, N, Tp), -1.0, device=dev), []       # the per-step record of the alignments (filing workgroups)
+    ba.file_in, ba.file_out, ba.file_width = al_new.data_ptr(), al_hist.data_ptr(), Tp
     natt = np.zeros((Umax, N), np.int32)
     for t in range(Umax):
         # the "model": every row of every utterance through its utterance's toy step (host numpy, as in the goldens)
@@ -74,15 +76,24 @@ def _run_loop(cases):
                 st_new[k][rows] = torch.tensor(new_u[k], device=dev)
             al_new[rows] = torch.tensor(a_u, device=dev)
         T["logits"].copy_(torch.tensor(lg))
+        al_snap.append(al_new.clone())
         _hip.check(_hip.lib().las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")
         assert int(T["step"][0]) == t + 1
         if bool(T["done"].all()):
             break
     hp, ht, hs = T["hist_parent"].cpu().numpy(), T["hist_token"].cpu().numpy(), T["hist_slot"].cpu().numpy()
     hsc, st_, sj_, ns_ = T["hist_score"].cpu().numpy(), T["sel_t"].cpu().numpy(), T["sel_j"].cpu().numpy(), T["nsel"].cpu().numpy()
+    assert torch.equal(al_hist[:len(al_snap)], torch.stack(al_snap)) and bool((al_hist[len(al_snap):] == -1.0).all())
+    # the device walk of the back pointers (las_beam_backtrack) against the host walk below
+    w_ids, w_rows = torch.full((n * selcap, Umax), -7, **i32), torch.full((n * selcap, Umax), -7, **i32)
+    w_len, w_sc = torch.full((n * selcap,), -7, **i32), torch.zeros(n * selcap, device=dev)
+    _hip.check(_hip.lib().las_beam_backtrack(ctypes.byref(ba), w_ids.data_ptr(), w_rows.data_ptr(), w_len.data_ptr(), w_sc.data_ptr(),
+                                             _hip.stream()), "las_beam_backtrack")
+    w_ids, w_rows, w_len, w_sc = w_ids.cpu().numpy(), w_rows.cpu().numpy(), w_len.cpu().numpy(), w_sc.cpu().numpy()
     out = []
     for u in range(n):
         sel = []
+        assert (w_len[u * selcap + min(int(ns_[u]), selcap):(u + 1) * selcap] == 0).all()
         for s_i in range(int(ns_[u])):
             tt, j = int(st_[u, s_i]), int(sj_[u, s_i])
             lp = np.float32(hsc[tt, u, j])
@@ -94,6 +105,9 @@ def _run_loop(cases):
                     break
                 j = int(hs[tt - 1, u, slot])
                 tt -= 1
+            w = u * selcap + s_i
+            assert w_len[w] == len(ids) and w_ids[w, :len(ids)].tolist() == ids[::-1] and w_sc[w] == lp
+            assert (w_rows[w, :len(ids)] // beam == u).all() and w_rows[w, len(ids) - 1] == u * beam + int(hp[int(st_[u, s_i]), u, int(sj_[u, s_i])])
             sel.append(([1] + ids[::-1], lp))
         norm = np.asarray([lp / (len(ids) - 1) for ids, lp in sel])
         order = np.argsort(norm, kind="stable")[-beam:]

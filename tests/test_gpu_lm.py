@@ -1,0 +1,30 @@
+"""R1 gate kernel with the one-hot input's row look-up folded in (las_lstm_pointwise_rows): bitwise the same as adding the
+looked-up input rows to z first (what CharRNN.step_fused did with index_select + add before the decode trace of round 3)."""
+import pytest
+import torch
+
+import helpers  # noqa: F401  (sys.path)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,H,V,shift", [(256, 512, 28, 2), (5, 24, 7, 0), (33, 64, 30, 2)])
+def test_pointwise_rows_equals_lookup_add_then_pointwise(N, H, V, shift):
+    from las import _hip
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(N + H)
+    z = torch.randn(N, 4 * H, generator=g).to(dev)
+    xrows = torch.randn(V, 4 * H, generator=g).to(dev)
+    c_prev = torch.randn(N, H, generator=g).to(dev)
+    ids = torch.randint(0, V + shift, (N,), generator=g).to(torch.int32).to(dev)       # ids < shift clamp to row 0 (SOS -> LM id 0)
+    lib = _hip.lib()
+    c0, h0, c1, h1 = (torch.empty(N, H, device=dev) for _ in range(4))
+    z_ref = z + xrows.index_select(0, (ids.long() - shift).clamp_min(0))
+    _hip.check(lib.las_lstm_pointwise(_hip.p(z_ref), _hip.p(c_prev), N, H, 0.0, _hip.p(c0), _hip.p(h0), _hip.stream()), "las_lstm_pointwise")
+    _hip.check(lib.las_lstm_pointwise_rows(_hip.p(z), _hip.p(xrows), _hip.p(ids), shift, _hip.p(c_prev), N, H, 0.0, _hip.p(c1), _hip.p(h1),
+                                           _hip.stream()), "las_lstm_pointwise_rows")
+    assert torch.equal(c0, c1) and torch.equal(h0, h1)
+    # and against plain torch fp32 (BasicLSTMCell gate order i, j, f, o; forget_bias 0 -- lang/char_rnn_model.py:57-66)
+    i, j, f, o = z_ref.split(H, 1)
+    c_t = c_prev * torch.sigmoid(f) + torch.sigmoid(i) * torch.tanh(j)
+    assert (c1 - c_t).abs().max() < 1e-5 and (h1 - torch.tanh(c_t) * torch.sigmoid(o)).abs().max() < 1e-5
