@@ -229,6 +229,102 @@ extern "C" int las_lstm_pointwise_rows(const float* z, const float* xrows, const
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// R1 for a whole block of rows in ONE launch: z = [x ; h] . kernel + bias and the gate math above (lang/char_rnn_model.py:57-66),
+// for the beam search's LM step (M = utterances x beam rows, a few hundred).  r3 decode trace: per LM layer the step ran two
+// skinny-M products (2048 workgroups of one 16 x 16 tile each -- a shape made for M <= 48) and a gate kernel, 14-23 us; here a
+// workgroup owns 32 rows x 16 units: the four gates' column tiles of those units (weights as las_gemm_skinny_pack fragments,
+// TF gate order i, j, f, o = column blocks of H), K = I + H contracted in chunks staged through LDS as bf16, 8 waves = 4 gates x
+// 2 row tiles, gates exchanged through LDS, then c' / h' written directly.  A one-hot first layer passes ids / xrows instead of x.
+// ------------------------------------------------------------------------------------------------
+struct LstmCellDev {
+    const float* x; int ldx, I;
+    const int* ids; int id_shift; const float* xrows;
+    const float* h; int ldh;
+    const u16x8_t *Wx, *Wh;
+    const float *bias, *c_prev;
+    float fb;
+    float *c_out, *h_out;
+    int M, H;
+};
+constexpr int LC_KC = 512, LC_LD = LC_KC + 8;      // K chunk staged per pass; LDS row stride in bf16 (16-byte reads of 16 rows hit 64 distinct banks)
+
+__global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellDev a) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[32 * LC_LD];
+    __shared__ float gates[2][4][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
+    const int gt = w & 3, rt = w >> 2;
+    const int ub = blockIdx.x, row0 = blockIdx.y * 32;
+    const int H = a.H, ct = gt * (H >> 4) + ub;                      // this wave's column tile of the [K, 4H] kernel
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int part = 0; part < 2; ++part) {
+        const float* src = part ? a.h : a.x;
+        if (!src) continue;
+        const int ld = part ? a.ldh : a.ldx, Kp = part ? H : a.I, KS = Kp >> 5;
+        const u16x8_t* bp = (part ? a.Wh : a.Wx) + (size_t)ct * KS * 64 + lane;
+        for (int k0 = 0; k0 < Kp; k0 += LC_KC) {
+            const int kc = min(LC_KC, Kp - k0), nks = kc >> 5;
+            // this chunk's weight fragments first (16 KB per wave at most, all in flight), then the rows
+            u16x8_t bv[LC_KC / 32];
+#pragma unroll
+            for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bp[(size_t)min((k0 >> 5) + u, KS - 1) * 64];
+            __syncthreads();                                          // the previous chunk's readers are done
+            for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
+                const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
+                const int row = min(row0 + r, a.M - 1);
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + k0 + q * 4);
+                uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+                *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+            }
+            __syncthreads();
+            const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
+#pragma unroll
+            for (int u = 0; u < LC_KC / 32; ++u)
+                if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gates[rt][gt][lane][r] = acc[r];
+    __syncthreads();
+    // gate math: thread = (row of the block, unit of the block); MFMA C layout: element (row r16, col u) sits in lane (r16 / 4) * 16 + u, register r16 % 4
+    const int r = tid >> 4, u = tid & 15, row = row0 + r;
+    if (row >= a.M) return;
+    const int l2 = ((r & 15) >> 2) * 16 + u, reg = r & 3, unit = ub * 16 + u;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = gates[r >> 4][g][l2][reg] + a.bias[g * H + unit];
+    if (a.xrows) {
+        int id = a.ids[row] - a.id_shift;
+        if (id < 0) id = 0;
+        const float* xr = a.xrows + (size_t)id * 4 * H + unit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] += xr[g * H];
+    }
+    const float gi = sigmoid_acc(z[0]), gj = tanh_acc(z[1]), gf = sigmoid_acc(z[2] + a.fb), go = sigmoid_acc(z[3]);
+    const size_t o = (size_t)row * H + unit;
+    const float cn = a.c_prev[o] * gf + gi * gj;
+    a.c_out[o] = cn;
+    a.h_out[o] = tanh_acc(cn) * go;
+}
+
+extern "C" int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids, int id_shift, const float* xrows, const float* h, int ldh,
+                                  const void* Wx_packed, const void* Wh_packed, const float* bias, const float* c_prev, int M, int H,
+                                  float forget_bias, float* c_out, float* h_out, void* stream) {
+    LAS_ARG(h && Wh_packed && bias && c_prev && c_out && h_out && M > 0 && H > 0, "las_lstm_cell_rows: bad arguments");
+    LAS_ARG((x != nullptr) != (xrows != nullptr), "las_lstm_cell_rows: exactly one of x (dense input rows) and xrows (one-hot input) must be given");
+    LAS_ARG(!x || (Wx_packed && I > 0 && (I % 32) == 0 && (ldx % 4) == 0 && (((uintptr_t)x) & 15) == 0), "las_lstm_cell_rows: x needs I %% 32 == 0, ldx %% 4 == 0, 16-byte alignment and Wx_packed");
+    LAS_ARG(!xrows || ids, "las_lstm_cell_rows: xrows without ids");
+    LAS_ARG((H % 32) == 0 && (ldh % 4) == 0 && (((uintptr_t)h) & 15) == 0, "las_lstm_cell_rows: needs H %% 32 == 0, ldh %% 4 == 0, h 16-byte aligned");
+    LstmCellDev a;
+    a.x = x; a.ldx = ldx; a.I = x ? I : 0; a.ids = ids; a.id_shift = id_shift; a.xrows = xrows; a.h = h; a.ldh = ldh;
+    a.Wx = reinterpret_cast<const u16x8_t*>(Wx_packed); a.Wh = reinterpret_cast<const u16x8_t*>(Wh_packed);
+    a.bias = bias; a.c_prev = c_prev; a.fb = forget_bias; a.c_out = c_out; a.h_out = h_out; a.M = M; a.H = H;
+    hipLaunchKernelGGL(lstm_cell_rows_kernel, dim3(H / 16, cdiv(M, 32)), dim3(512), 0, (hipStream_t)stream, a);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+
 // gradient of the BasicLSTMCell gate math (R1 training, reference lang/char_rnn_model.py:54-66,177-190):
 //   given z (pre-activations [N,4H], i,j,f,o), c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c' arriving from step t+1):
 //   dz [N,4H] and dc_prev [N,H].   (dc_in may be NULL = zeros.)

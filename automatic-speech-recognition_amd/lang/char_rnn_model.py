@@ -290,27 +290,38 @@ class CharRNN(object):
         cs, hs = [], []
         x = None
         skinny = "packs" in plan and N <= 1024
+        cell_rows = skinny and H % 32 == 0 and (self.embedding_size == 0 or self.input_size % 32 == 0)
         with torch.no_grad():
             for l, (k, b) in enumerate(P["cells"]):
                 k, b = k.detach(), b.detach()
                 I = k.shape[0] - H
+                rows = l == 0 and "wx" in plan
+                if l == 0 and not rows:
+                    lm_ids = (ids - id_shift).clamp_min_(0) if id_shift else ids
+                    x = P["embedding"].detach().index_select(0, lm_ids)
+                c_new = torch.empty(N, H, device=dev)
+                h_new = torch.empty(N, H, device=dev)
+                if cell_rows:                                    # the whole cell in one launch (las_lstm_cell_rows)
+                    hh, ih = plan["packs"][l]
+                    _hip.check(lib.las_lstm_cell_rows(None if rows else _hip.p(x), 0 if rows else I, 0 if rows else I,
+                                                      _hip.p(ids) if rows else None, int(id_shift), _hip.p(plan["wx"]) if rows else None,
+                                                      _hip.p(h_prev[l]), H, None if rows else _hip.p(ih), _hip.p(hh), _hip.p(b), _hip.p(c_prev[l]),
+                                                      N, H, 0.0, _hip.p(c_new), _hip.p(h_new), _hip.stream()), "las_lstm_cell_rows")
+                    cs.append(c_new)
+                    hs.append(h_new)
+                    x = h_new
+                    continue
                 z = torch.empty(N, 4 * H, device=dev)
                 # recurrent half (+ bias), then the input half on top
                 if skinny:
                     _hip.skinny_gemm(h_prev[l], plan["packs"][l][0], z, N, H, 4 * H, H, 4 * H, bias=b)
                 else:
                     _hip.gemm(prec, h_prev[l], k, z, False, False, N, 4 * H, H, H, 4 * H, 4 * H, bias=b, b_off=I * 4 * H)
-                rows = l == 0 and "wx" in plan
                 if not rows:
-                    if l == 0:
-                        lm_ids = (ids - id_shift).clamp_min_(0) if id_shift else ids
-                        x = P["embedding"].detach().index_select(0, lm_ids)
                     if skinny:
                         _hip.skinny_gemm(x, plan["packs"][l][1], z, N, I, 4 * H, I, 4 * H, accumulate=True)
                     else:
                         _hip.gemm(prec, x, k, z, False, False, N, 4 * H, I, I, 4 * H, 4 * H, beta=1.0)
-                c_new = torch.empty(N, H, device=dev)
-                h_new = torch.empty(N, H, device=dev)
                 if rows:
                     _hip.check(lib.las_lstm_pointwise_rows(_hip.p(z), _hip.p(plan["wx"]), _hip.p(ids), int(id_shift), _hip.p(c_prev[l]), N, H, 0.0,
                                                            _hip.p(c_new), _hip.p(h_new), _hip.stream()), "las_lstm_pointwise_rows")

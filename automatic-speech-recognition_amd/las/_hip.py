@@ -126,6 +126,8 @@ _SIGS = {
                                         c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "las_lstm_pointwise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "las_lstm_cell_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

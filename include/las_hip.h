@@ -341,6 +341,14 @@ int las_lstm_pointwise(const float* z, const float* c_prev, int N, int H, float 
  * beam search's next_token buffer is read as it is. */
 int las_lstm_pointwise_rows(const float* z, const float* xrows, const int* ids, int id_shift, const float* c_prev, int N, int H,
                             float forget_bias, float* c_out, float* h_out, void* stream);
+/* The whole cell for a block of rows in ONE launch (the beam search's LM step, M = utterances x beam rows): z = [x ; h] . kernel + bias
+ * with the kernel's input rows / recurrent rows given as las_gemm_skinny_pack fragments (Wx_packed: [I, 4H], Wh_packed: [H, 4H]; operands
+ * rounded to bf16, fp32 accumulation), then the gate math of las_lstm_pointwise.  Dense input: x [M, I] (I % 32 == 0) and Wx_packed; one-hot
+ * input (lang/char_rnn_model.py:106-112): x = NULL and ids / id_shift / xrows as in las_lstm_pointwise_rows (fp32 row look-up, no rounding
+ * inside the kernel).  H % 32 == 0; c_out / h_out [M, H] may not alias h / c_prev (other workgroups still read them). */
+int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids, int id_shift, const float* xrows, const float* h, int ldh,
+                       const void* Wx_packed, const void* Wh_packed, const float* bias, const float* c_prev, int M, int H,
+                       float forget_bias, float* c_out, float* h_out, void* stream);
 /* ... and its gradient, for training the RNNLM (lang/char_rnn_model.py:177-190, truncated BPTT over num_unrollings steps):
  * dz [N,4H] and dc_prev [N,H] from z, c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c', may be NULL). */
 int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const float* dh, const float* dc_in, int N, int H,

@@ -28,3 +28,42 @@ def test_pointwise_rows_equals_lookup_add_then_pointwise(N, H, V, shift):
     i, j, f, o = z_ref.split(H, 1)
     c_t = c_prev * torch.sigmoid(f) + torch.sigmoid(i) * torch.tanh(j)
     assert (c1 - c_t).abs().max() < 1e-5 and (h1 - torch.tanh(c_t) * torch.sigmoid(o)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("M,I,H,onehot", [(256, 512, 512, False), (256, 0, 512, True), (5, 64, 32, False), (33, 0, 64, True), (70, 1024, 96, False)])
+def test_lstm_cell_rows_matches_bf16_operand_reference(M, I, H, onehot):
+    """las_lstm_cell_rows (the LM step of the beam search in one launch per layer) against torch: operands rounded to bf16, fp32
+    accumulation, then the BasicLSTMCell gate math; and against the two-product + gate-kernel path it replaces."""
+    from las import _hip
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + H)
+    V, shift = 28, 2
+    kern = (torch.randn((V if onehot else I) + H, 4 * H, generator=g) * 0.08).to(dev)
+    bias = (torch.randn(4 * H, generator=g) * 0.1).to(dev)
+    h = torch.randn(M, H, generator=g).to(dev)
+    c_prev = torch.randn(M, H, generator=g).to(dev)
+    Ix = V if onehot else I
+    hh = _hip.skinny_pack(kern, H, 4 * H, row0=Ix)
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    z_ref = rnd(h).double() @ rnd(kern[Ix:]).double() + bias.double()
+    lib = _hip.lib()
+    c1, h1 = torch.empty(M, H, device=dev), torch.empty(M, H, device=dev)
+    if onehot:
+        ids = torch.randint(0, V + shift, (M,), generator=g).to(torch.int32).to(dev)
+        wx = rnd(kern[:V]).contiguous()                                                # CharRNN.fusion_plan rounds the rows once
+        z_ref = z_ref + wx.index_select(0, (ids.long() - shift).clamp_min(0)).double()
+        _hip.check(lib.las_lstm_cell_rows(None, 0, 0, _hip.p(ids), shift, _hip.p(wx), _hip.p(h), H, None, _hip.p(hh), _hip.p(bias), _hip.p(c_prev),
+                                          M, H, 0.0, _hip.p(c1), _hip.p(h1), _hip.stream()), "las_lstm_cell_rows")
+    else:
+        x = torch.randn(M, I, generator=g).to(dev)
+        ih = _hip.skinny_pack(kern, I, 4 * H)
+        z_ref = z_ref + rnd(x).double() @ rnd(kern[:I]).double()
+        _hip.check(lib.las_lstm_cell_rows(_hip.p(x), I, I, None, 0, None, _hip.p(h), H, _hip.p(ih), _hip.p(hh), _hip.p(bias), _hip.p(c_prev),
+                                          M, H, 0.0, _hip.p(c1), _hip.p(h1), _hip.stream()), "las_lstm_cell_rows")
+    i, j, f, o = z_ref.split(H, 1)
+    c_t = c_prev.double() * torch.sigmoid(f) + torch.sigmoid(i) * torch.tanh(j)
+    h_t = torch.tanh(c_t) * torch.sigmoid(o)
+    assert (c1.double() - c_t).abs().max() < 2e-5 and (h1.double() - h_t).abs().max() < 2e-5
+    # bad arguments are refused before any launch
+    assert lib.las_lstm_cell_rows(None, 0, 0, None, 0, None, _hip.p(h), H, None, _hip.p(hh), _hip.p(bias), _hip.p(c_prev), M, H, 0.0, _hip.p(c1),
+                                  _hip.p(h1), _hip.stream()) < 0
