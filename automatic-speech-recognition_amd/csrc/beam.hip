@@ -22,11 +22,27 @@ __device__ __forceinline__ bool bless(const BKey& a, const BKey& b) {   // a < b
     return a.v < b.v;
 }
 
-// The `beam` best candidates of one utterance, best first, into picks[] (LDS); returns how many exist.  Called by all 256
-// threads of the workgroup.  Every round takes the block-wide maximum of the candidates strictly below the previous pick: keys of a
-// grid that fits 4 candidates per thread are computed once and kept in registers, the maximum is a wave butterfly (64-lane xor
-// shuffles) plus one LDS slot per wave -- one barrier per round (the slots are double-buffered).  r3 decode trace: the former
-// version (memory re-scan + 8-level LDS tree with 9 barriers per round) was 44 us of a 170 us decode step at beam 16, V = 30.
+// The `beam` best candidates of one utterance, best first, into L.picks[] (LDS); returns how many exist.  Called by all 256 threads.
+//
+// Up to 512 candidates (beam x V of a char model): ONE wave holds them all, 8 per lane, as two sortable 64-bit integers --
+// K1 = order(norm) : hypothesis, K2 = order(logit) : token, order() = the usual monotone map of float bits -- and finds the value of the
+// beam-th largest K1 by bisection over its 38 bits: every probe is 8 compares whose ballots are counted on the scalar unit, no data
+// crosses lanes.  Ties at the threshold (same hypothesis, same normalised score) are cut the same way on K2.  The <= 64 selected
+// candidates are compacted into LDS through ballot prefix counts and ranked among themselves by counting.  r3 decode traces at beam 16,
+// V = 30: 16 rounds of (re-scan + 8-level LDS tree, 9 barriers) 44 us -> 16 rounds of (wave butterfly + 1 barrier) 28 us -> this.
+// Larger grids (subword vocabularies) take the round-based path: block-wide maximum of the candidates strictly below the previous pick,
+// wave butterfly (64-lane xor shuffles) + one LDS slot per wave, one barrier per round (the slots are double-buffered).
+struct BeamLds {
+    BKey picks[64];
+    BKey wbest[2][4];
+    unsigned long long k1[64], k2[64];
+    int ci[64], cv[64]; float cl[64];
+    int count;
+};
+__device__ __forceinline__ unsigned f_order(float f) {                         // unsigned order == float order (-0 canonicalised by the caller)
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
 __device__ __forceinline__ BKey bkey_shfl_xor(const BKey& k, int off) {
     BKey y;
     y.norm = __shfl_xor(k.norm, off, 64); y.i = __shfl_xor(k.i, off, 64); y.l = __shfl_xor(k.l, off, 64); y.v = __shfl_xor(k.v, off, 64);
@@ -44,43 +60,107 @@ __device__ __forceinline__ bool beam_make_key(BKey& k, const float* lg, const fl
     k.i = i; k.l = l; k.v = idx;                        // v carries the flat candidate id until the very end
     return k.norm == k.norm;                            // NaN never ranks
 }
-__device__ int beam_rank(const float* lg, const float* sc, const int* ln, int nb, int V, int t, int start_id, int beam,
-                         BKey* picks, BKey (*wbest)[4]) {
-    constexpr int CPT = 4;
+// value of the need-th largest key among the flagged candidates (bits [nbits-1, 0]): largest T with count(key >= T) >= need
+template <int NS>
+__device__ __forceinline__ unsigned long long beam_bisect(const unsigned long long (&key)[NS], const unsigned on, int ns, int nbits, int need) {
+    unsigned long long T = 0;
+    for (int b = nbits - 1; b >= 0; --b) {
+        const unsigned long long probe = T | (1ull << b);
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s < ns) cnt += __popcll(__ballot(((on >> s) & 1u) && key[s] >= probe));
+        if (cnt >= need) T = probe;                      // uniform (ballots)
+    }
+    return T;
+}
+__device__ __forceinline__ int beam_rank(const float* lg, const float* sc, const int* ln, int nb, int V, int t, int start_id, int beam, BeamLds& L) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ncand = nb * V;
-    const bool cached = ncand <= 256 * CPT;
-    BKey ck[CPT];
+    constexpr int NS = 8;
+    if (ncand <= 64 * NS) {
+        if (w == 0) {
+            const int ns = (ncand + 63) >> 6;
+            unsigned long long K1[NS], K2[NS];
+            unsigned on = 0;                                 // bit s: this lane's candidate of slot s ranks
+            BKey ck[NS];
+            int nvalid = 0;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        ck[c].i = -1;
-        const int idx = tid + c * 256;
-        if (cached && idx < ncand) { BKey k; if (beam_make_key(k, lg, sc, ln, idx, V, t, start_id)) ck[c] = k; }
+            for (int s = 0; s < NS; ++s) {
+                K1[s] = 0; K2[s] = 0;
+                const int idx = s * 64 + lane;
+                if (s < ns && idx < ncand && beam_make_key(ck[s], lg, sc, ln, idx, V, t, start_id)) {
+                    on |= 1u << s;
+                    K1[s] = ((unsigned long long)f_order(ck[s].norm + 0.f) << 6) | (unsigned)ck[s].i;
+                    K2[s] = ((unsigned long long)f_order(ck[s].l + 0.f) << 20) | (unsigned)(ck[s].v - ck[s].i * V);
+                }
+                if (s < ns) nvalid += __popcll(__ballot((on >> s) & 1u));
+            }
+            const int need = nvalid < beam ? nvalid : beam;
+            if (need > 0) {
+                const unsigned long long T1 = beam_bisect<NS>(K1, on, ns, 38, need);
+                int gt = 0, eq = 0;
+                unsigned tie = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bool o = (on >> s) & 1u;
+                    if (o && K1[s] == T1) tie |= 1u << s;
+                    if (s < ns) { gt += __popcll(__ballot(o && K1[s] > T1)); eq += __popcll(__ballot((tie >> s) & 1u)); }
+                }
+                unsigned long long T2 = 0;
+                if (eq > need - gt) T2 = beam_bisect<NS>(K2, tie, ns, 52, need - gt);      // rare: equal normalised scores inside one hypothesis
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int base = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s < ns) {
+                        const bool sel = ((on >> s) & 1u) && (K1[s] > T1 || (K1[s] == T1 && K2[s] >= T2));
+                        const unsigned long long m = __ballot(sel);
+                        if (sel) {
+                            const int pos = base + __popcll(m & lt);
+                            L.k1[pos] = K1[s]; L.k2[pos] = K2[s]; L.ci[pos] = ck[s].i; L.cl[pos] = ck[s].l; L.cv[pos] = ck[s].v;
+                        }
+                        base += __popcll(m);
+                    }
+                }
+                // (one wave: its LDS writes are ordered before its later LDS reads; keep the compiler from moving them)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < need) {
+                    const unsigned long long m1 = L.k1[lane], m2 = L.k2[lane];
+                    int r = 0;
+                    for (int q = 0; q < need; ++q) {
+                        const unsigned long long q1 = L.k1[q], q2 = L.k2[q];
+                        r += (q1 > m1 || (q1 == m1 && q2 > m2)) ? 1 : 0;
+                    }
+                    const BKey k = {0.f, L.ci[lane], L.cl[lane], L.cv[lane]};
+                    L.picks[r] = k;
+                }
+            }
+            if (lane == 0) L.count = need;
+        }
+        __syncthreads();
+        return L.count;
     }
     BKey last = {0.f, 0, 0.f, 0};
     int count = 0;
     for (int pick = 0; pick < beam; ++pick) {
         BKey best = {0.f, -1, 0.f, 0};
-        if (cached) {
-#pragma unroll
-            for (int c = 0; c < CPT; ++c)
-                if (ck[c].i >= 0 && (pick == 0 || bless(ck[c], last))) bkey_max(best, ck[c]);
-        } else {
-            for (int idx = tid; idx < ncand; idx += 256) {
-                BKey k;
-                if (beam_make_key(k, lg, sc, ln, idx, V, t, start_id) && (pick == 0 || bless(k, last))) bkey_max(best, k);
-            }
+        for (int idx = tid; idx < ncand; idx += 256) {
+            BKey k;
+            if (beam_make_key(k, lg, sc, ln, idx, V, t, start_id) && (pick == 0 || bless(k, last))) bkey_max(best, k);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) bkey_max(best, bkey_shfl_xor(best, off));
-        if (lane == 0) wbest[pick & 1][w] = best;
+        if (lane == 0) L.wbest[pick & 1][w] = best;
         __syncthreads();
-        best = wbest[pick & 1][0];
+        best = L.wbest[pick & 1][0];
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) bkey_max(best, wbest[pick & 1][ww]);
+        for (int ww = 1; ww < 4; ++ww) bkey_max(best, L.wbest[pick & 1][ww]);
         if (best.i < 0) break;                           // uniform: every thread combined the same four slots
         last = best;
-        if (tid == 0) picks[pick] = best;
+        if (tid == 0) L.picks[pick] = best;
         count = pick + 1;
     }
     __syncthreads();
@@ -92,8 +172,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
                                                         int beam, int V, int t, int start_id, int* __restrict__ out_parent,
                                                         int* __restrict__ out_token, float* __restrict__ out_score,
                                                         int* __restrict__ out_n) {
-    __shared__ BKey picks[64];
-    __shared__ BKey wbest[2][4];
+    __shared__ BeamLds L;
     const int u = blockIdx.x, tid = threadIdx.x;
     int nb = nlive[u];
     if (nb > beam) nb = beam;
@@ -101,10 +180,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     const float* lg = logits + (size_t)u * beam * V;
     const float* sc = score + (size_t)u * beam;
     const int* ln = length + (size_t)u * beam;
-    const int count = beam_rank(lg, sc, ln, nb, V, t, start_id, beam, picks, wbest);
+    const int count = beam_rank(lg, sc, ln, nb, V, t, start_id, beam, L);
     if (tid == 0) out_n[u] = count;
     for (int j = tid; j < count; j += 256) {             // ascending, best last (las/beam_search.py:310-312)
-        const BKey k = picks[count - 1 - j];
+        const BKey k = L.picks[count - 1 - j];
         out_parent[(size_t)u * beam + j] = k.i;
         out_token[(size_t)u * beam + j] = k.v - k.i * V;
         out_score[(size_t)u * beam + j] = sc[k.i] + k.l;
@@ -148,8 +227,7 @@ struct BeamLoopDev {
 };
 
 __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
-    __shared__ BKey picks[64];
-    __shared__ BKey wbest[2][4];
+    __shared__ BeamLds L;
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
     const int t = a.step[0];
     if (t >= a.Umax) return;
@@ -177,14 +255,14 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     const float* lg = a.logits + (size_t)u * beam * V;
     float* sc = a.score + (size_t)u * beam;
     int* ln = a.length + (size_t)u * beam;
-    const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, picks, wbest);
+    const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, L);
     if (tid >= 64) return;
     // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
     // first wave is pick j (beam <= 64); the positions of the retired / surviving picks in their lists are prefix counts of ballots
     const int j = tid;
     const bool act = j < count;
     BKey k = {0.f, 0, 0.f, 0};
-    if (act) k = picks[count - 1 - j];
+    if (act) k = L.picks[count - 1 - j];
     const int v = k.v - k.i * V;
     const float news = sc[k.i] + k.l;                    // (every lane reads the old sums before any lane stores the new ones below)
     const int newl = ln[k.i] + 1;

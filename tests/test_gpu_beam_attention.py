@@ -218,3 +218,52 @@ def test_beam_search_with_lm_fusion_matches_oracle():
     assert [b.token_ids for b in res] == [b.token_ids for b in ref]
     for a, b in zip(res, ref):
         assert float(a.log_prob) == pytest.approx(float(b.log_prob), abs=2e-3)
+
+
+@pytest.mark.parametrize("beam,V,t", [(16, 30, 3), (16, 30, 0), (4, 7, 2), (8, 64, 5), (16, 5000, 2), (3, 200, 1), (33, 15, 4)])
+def test_beam_step_ordering_with_ties_matches_a_stable_sort(beam, V, t):
+    """The ranking of las_beam_step on grids full of ties against a plain sort by the reference's key (score / len, hypothesis, logit,
+    token -- the order a stable ascending sort of las/beam_search.py:119-152's candidate bank gives): equal logits inside a
+    hypothesis, equal normalised scores across hypotheses, -inf, NaN (never ranks), +-0.  beam x V <= 512 takes the one-wave
+    bisection path, larger grids the round-based path."""
+    import numpy as np
+    from las import _hip
+    dev = "cuda"
+    rng = np.random.RandomState(beam * 131 + V + t)
+    nutt = 5
+    lg = rng.choice(np.array([-2.5, -1.0, -0.5, 0.0, -0.0, 0.25, 1.0, 3.0], np.float32), size=(nutt, beam, V)).astype(np.float32)
+    lg[0] = rng.randn(beam, V).astype(np.float32)                               # one utterance without engineered ties
+    lg[1, :, : V // 2] = -np.inf
+    lg[2, 0, 1::3] = np.nan
+    if nutt > 3:
+        lg[3] = 0.5                                                             # everything ties on the logit
+    score = rng.choice(np.array([0.0, -1.0, -2.0, 2.0], np.float32), size=(nutt, beam)).astype(np.float32)
+    length = rng.randint(0, 4, size=(nutt, beam)).astype(np.int32)
+    nlive = np.array([beam, beam, max(beam - 1, 1), beam, 1], np.int32)
+    start_id = 1
+    d = lambda a: torch.tensor(a, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    outp, outt, outn = torch.full((nutt, beam), -1, **i32), torch.full((nutt, beam), -1, **i32), torch.zeros(nutt, **i32)
+    outs = torch.zeros(nutt, beam, device=dev)
+    d_lg, d_score, d_length, d_nlive = d(lg), d(score), d(length), d(nlive)      # (alive until the results are read)
+    _hip.check(_hip.lib().las_beam_step(_hip.p(d_lg), _hip.p(d_score), _hip.p(d_length), _hip.p(d_nlive), nutt, beam, V, 64, t, start_id,
+                                        _hip.p(outp), _hip.p(outt), _hip.p(outs), _hip.p(outn), _hip.stream()), "las_beam_step")
+    outp, outt, outs, outn = outp.cpu().numpy(), outt.cpu().numpy(), outs.cpu().numpy(), outn.cpu().numpy()
+    for u in range(nutt):
+        nb = 1 if t == 0 else int(min(nlive[u], beam))
+        cands = []
+        for i in range(nb):
+            for v in range(V):
+                if t > 0 and v == start_id:
+                    continue
+                l = lg[u, i, v]
+                norm = np.float32(np.float32(score[u, i] + l) / np.float32(length[u, i] + 1))
+                if np.isnan(norm):
+                    continue
+                cands.append((float(norm), i, float(l), v))
+        cands.sort()                                                             # -0.0 == 0.0 in the tuple compare, like the float compares of the kernel
+        top = cands[-beam:]                                                      # ascending, best last
+        assert outn[u] == len(top), (u, outn[u], len(top))
+        assert [(int(outp[u, j]), int(outt[u, j])) for j in range(len(top))] == [(c[1], c[3]) for c in top], u
+        for j, c in enumerate(top):
+            assert outs[u, j] == np.float32(score[u, c[1]] + np.float32(c[2]))
