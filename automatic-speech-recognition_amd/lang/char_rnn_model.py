@@ -275,12 +275,13 @@ class CharRNN(object):
             plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
-    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0):
+    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0, project=True):
         """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM id = max(ids - id_shift, 0):
         with id_shift = 2 the beam search's LAS ids are read as they are), the result is ACCUMULATED into
         logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input and recurrent halves
         of every cell product are separate GEMMs against row blocks of the TF kernel, and the one-hot input's half is a row
-        look-up inside the gate kernel (las_lstm_pointwise_rows).
+        look-up inside the gate kernel (las_lstm_pointwise_rows).  project=False stops after the cells (the caller runs them beside
+        the acoustic model's step on another stream and calls project_fused once both are done).
         Returns (c_new list, h_new list)."""
         P = self.params()
         dev = logits.device
@@ -331,12 +332,18 @@ class CharRNN(object):
                 cs.append(c_new)
                 hs.append(h_new)
                 x = h_new
-            V_all = logits.shape[1]
-            if skinny:
-                _hip.skinny_gemm(x, plan["swp"], logits, N, H, Vn, H, V_all, bias=plan["sb"], accumulate=True, c_off=col0)
-            else:
-                _hip.gemm(prec, x, plan["sw"], logits, False, False, N, Vn, H, H, Vn, V_all, beta=1.0, bias=plan["sb"], c_off=col0)
+            if project:
+                self.project_fused(plan, x, logits, col0)
         return cs, hs
+
+    def project_fused(self, plan, h_top, logits, col0):
+        """logits[:, col0:col0 + V_lm] += lm_weight * (h_top . softmax_w + softmax_b)   (the weights were pre-scaled by fusion_plan)"""
+        N, H, Vn = h_top.shape[0], self.hidden_size, self.vocab_size
+        V_all = logits.shape[1]
+        if "packs" in plan and N <= 1024:
+            _hip.skinny_gemm(h_top, plan["swp"], logits, N, H, Vn, H, V_all, bias=plan["sb"], accumulate=True, c_off=col0)
+        else:
+            _hip.gemm(L._prec(), h_top, plan["sw"], logits, False, False, N, Vn, H, H, Vn, V_all, beta=1.0, bias=plan["sb"], c_off=col0)
 
     def step(self, token_ids, states):
         """token_ids [N] (LM ids), states: list over hypotheses of tuple over layers of (c,h) rows.

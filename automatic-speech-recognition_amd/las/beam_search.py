@@ -246,18 +246,24 @@ class BeamSearch(object):
 
         lm_plan = lm.fusion_plan(lm_w) if lm is not None else None
 
-        def lm_part():
+        def lm_cells():
             # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
             # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2)
+            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False)
             for l in range(NLl):
                 ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
             held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued
+
+        def lm_part():
+            lm_cells()
+            lm.project_fused(lm_plan, held[1][-1], logits, 2)
 
         def beam_part():                                 # files alphas_cur under the device step counter, prunes, gathers, advances the counter
             _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")
 
         def one_step():
+            # (the LM's cells depend only on the tokens, but running them as a parallel branch on a second stream beside the Speller
+            # step LOSES on this device: 111 against 99.5 us per captured step -- the cross-queue joins cost more than the overlap gives)
             speller_part()
             if lm is not None:
                 lm_part()
