@@ -421,19 +421,26 @@ __device__ __forceinline__ float sub16_sum(float v) {  // sum over a 16-lane gro
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = f2bf(src[i]);
-}
-
-// src [batch][R][C] fp32 -> dst [batch][ceil(R/2)][C][2] bf16: rows 2r and 2r+1 interleaved per column (zero past R)
-__global__ __launch_bounds__(256) void pair_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int R, int C) {
-    const int R2 = (R + 1) / 2;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)R2 * C) return;
-    const int r2 = (int)(i / C), c = (int)(i % C);
-    const float* sp = src + (size_t)blockIdx.y * R * C;
-    const float lo = sp[(size_t)(2 * r2) * C + c], hi = (2 * r2 + 1 < R) ? sp[(size_t)(2 * r2 + 1) * C + c] : 0.f;
-    reinterpret_cast<unsigned int*>(dst)[(size_t)blockIdx.y * R2 * C + i] = f2bf2(lo, hi);
+// the speed mode's operand copies in one launch: job y = plain bf16 copy of n elements (R == 0) or row-pair interleaved copy of
+// `batch` matrices: src [batch][R][C] fp32 -> dst [batch][ceil(R/2)][C][2] bf16, rows 2r and 2r+1 interleaved per column (zero past R)
+struct BfCopyJob { const float* src; unsigned short* dst; size_t n; int R, C, batch; };
+struct BfCopyJobs { BfCopyJob j[5]; };
+__global__ __launch_bounds__(256) void bf_copies_kernel(BfCopyJobs jobs) {
+    const BfCopyJob jb = jobs.j[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (jb.R == 0) {
+        for (size_t i = i0; i < jb.n; i += stride) jb.dst[i] = f2bf(jb.src[i]);
+        return;
+    }
+    const int R2 = (jb.R + 1) / 2;
+    const size_t per = (size_t)R2 * jb.C, total = per * jb.batch;
+    for (size_t i = i0; i < total; i += stride) {
+        const size_t bt = i / per, q = i - bt * per;
+        const int r2 = (int)(q / jb.C), c = (int)(q % jb.C);
+        const float* sp = jb.src + bt * (size_t)jb.R * jb.C;
+        const float lo = sp[(size_t)(2 * r2) * jb.C + c], hi = (2 * r2 + 1 < jb.R) ? sp[(size_t)(2 * r2 + 1) * jb.C + c] : 0.f;
+        reinterpret_cast<unsigned int*>(jb.dst)[i] = f2bf2(lo, hi);
+    }
 }
 
 struct BfLds {
@@ -2431,15 +2438,18 @@ static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st)
         d.Wsbf2 = (unsigned short*)(base + w.wsbf2); d.encbf2 = (unsigned short*)(base + w.encbf2);
         return 0;
     }
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nW, 1024)), dim3(256), 0, st, d.Ws, wsb, nW);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nK, 2048)), dim3(256), 0, st, d.keys, kb, nK);
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(cdiv(nE, 2048)), dim3(256), 0, st, d.enc, eb, nE);
-    // row-pair interleaved copies for the packed dot products of the prefetching forward kernel
+    // ... and row-pair interleaved copies for the packed dot products of the prefetching forward kernel: all five in ONE launch
+    // (they sit on the chain between the Listener's last sweep and the decode loop; five launches were 25 us)
     unsigned short* wsb2 = (unsigned short*)(base + w.wsbf2);
     unsigned short* eb2 = (unsigned short*)(base + w.encbf2);
-    const int S = d.D * d.NL, S2 = (S + 1) / 2, Tp2 = (d.Tp + 1) / 2;
-    hipLaunchKernelGGL(pair_rows_kernel, dim3(cdiv((size_t)S2 * d.A, 256), 1), dim3(256), 0, st, d.Ws, wsb2, S, d.A);
-    hipLaunchKernelGGL(pair_rows_kernel, dim3(cdiv((size_t)Tp2 * d.Hd, 256), d.B), dim3(256), 0, st, d.enc, eb2, d.Tp, d.Hd);
+    const int S = d.D * d.NL;
+    BfCopyJobs jobs;
+    jobs.j[0] = {d.Ws, wsb, nW, 0, 0, 1};
+    jobs.j[1] = {d.keys, kb, nK, 0, 0, 1};
+    jobs.j[2] = {d.enc, eb, nE, 0, 0, 1};
+    jobs.j[3] = {d.Ws, wsb2, 0, S, d.A, 1};
+    jobs.j[4] = {d.enc, eb2, 0, d.Tp, d.Hd, d.B};
+    hipLaunchKernelGGL(bf_copies_kernel, dim3(512, 5), dim3(256), 0, st, jobs);
     LAS_LAUNCHED();
     d.Wsbf = wsb; d.keysbf = kb; d.encbf = eb; d.Wsbf2 = wsb2; d.encbf2 = eb2;
     return 0;
@@ -2486,9 +2496,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         d.lp.gA = (unsigned long long*)((char*)f->ws + wl_.granX); d.lp.gA_row = I0D / 4;
         d.lp.gC = (unsigned long long*)((char*)f->ws + wl_.granF); d.lp.gC_row = GD / 2;
         d.lp.xcc = (unsigned long long*)((char*)f->ws + wl_.xccs);
-        LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (I0D / 4) * 16, st));        // tags of an earlier call must not match
-        LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * (GD / 2) * 16, st));
-        LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
+        // tags of an earlier call must not match: granX, granF, (granG, granB,) xccs are one contiguous stretch -> one fill
+        LAS_HIP(hipMemsetAsync((char*)f->ws + wl_.granX, 0, wl_.xccs + 256 * 8 - wl_.granX, st));
         LAS_LOOP_LAUNCH(dec_loop_fwd_kernel, CELL, d.Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }
@@ -2609,9 +2618,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         d.lp.gA = (unsigned long long*)(base + w.granG); d.lp.gA_row = GD / 4;
         d.lp.gC = (unsigned long long*)(base + w.granB); d.lp.gC_row = (Hd + D) / 2;
         d.lp.xcc = (unsigned long long*)(base + w.xccs);
-        LAS_HIP(hipMemsetAsync(d.lp.gA, 0, (size_t)B * (GD / 4) * 16, st));
-        LAS_HIP(hipMemsetAsync(d.lp.gC, 0, (size_t)B * ((Hd + D) / 2) * 16, st));
-        LAS_HIP(hipMemsetAsync(d.lp.xcc, 0, 256 * 8, st));
+        LAS_HIP(hipMemsetAsync(base + w.granG, 0, w.xccs + 256 * 8 - w.granG, st));       // granG, granB, xccs: contiguous, one fill
         LAS_LOOP_LAUNCH(dec_loop_bwd_kernel, CELL, Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }

@@ -599,6 +599,13 @@ def hold_until_next_sweep(dev, max_us=1500):
     check(lib().las_wait_word(c_void_p(status_word(dev).data_ptr() + 4), next_announce(), max_us, stream()), "las_wait_word")
 
 
+def hold_until_last_sweep(dev, max_us=1500):
+    """... for the announcement of the BPTT sweep that was launched LAST (for side work that the sweep's own node releases after its
+    launch -- run_deferred -- but that could start on the device before the sweep does)."""
+    if _announce[0]:
+        check(lib().las_wait_word(c_void_p(status_word(dev).data_ptr() + 4), (_announce[0] - 1) % 1023 + 1, max_us, stream()), "las_wait_word")
+
+
 def check_status(dev=None):
     """Synchronising check of the sweep status word(s): raises RuntimeError if any sweep reported a timeout.
     Call it wherever the host already waits for the device (loss read-out, end of a bench loop, checkpoint)."""

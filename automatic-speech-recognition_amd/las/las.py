@@ -213,6 +213,10 @@ class _SpellerLoop(torch.autograd.Function):
                 with _hip.on_side_stream(after=main_done):
                     for t in held:
                         t.record_stream(side)
+                    if L.HOLD_SIDE and _hip.streams_overlap(enc.device):
+                        # these products would otherwise start beside the chain GEMMs in front of the listener's first BPTT sweep
+                        # (r3 timeline: the dense layer's dX product took 101 us next to them): wait until that sweep is resident
+                        _hip.hold_until_last_sweep(enc.device)
                     _hip.check(lib.las_speller_bwd_part(ctypes.byref(ba), 2, _hip.stream()), "las_speller_bwd_part(2)")
                     _hip.gemm(prec, enc, d_keys, dWh, True, False, Hd, A, B * Tp, Hd, A, A, beta=1.0)  # dWh += enc^T . d_keys
 
@@ -561,14 +565,20 @@ class LAS:
         self.speller._params()
         st.flatten()
 
-    def _get_loss(self, logits, y, n_total=None):
+    @staticmethod
+    def _loss_scale(n_total):
+        return (1.0 / (n_total + 1e-9)).reshape(1).to(torch.float32)
+
+    def _get_loss(self, logits, y, n_total=None, scale=None):
         """las/las.py:320-333.  n_total (device scalar) overrides the local non-PAD count so that
-        data-parallel ranks normalise by the GLOBAL token count."""
+        data-parallel ranks normalise by the GLOBAL token count; scale = _loss_scale(n_total) when the
+        caller has already computed it (off the chain)."""
         B, U, V_ = logits.shape
         y = y[:, :U].contiguous()
-        if n_total is None:
-            n_total = (y != 0).sum().to(torch.float32)
-        scale = (1.0 / (n_total + 1e-9)).reshape(1).to(torch.float32)
+        if scale is None:
+            if n_total is None:
+                n_total = (y != 0).sum().to(torch.float32)
+            scale = self._loss_scale(n_total)
         return _CELoss.apply(logits, y, V_, self.args.label_smoothing, scale)
 
     def _scheduled_learning_rate(self, start=50000, decay_step=100000, decay_rate=0.5, min_rate=0.01, global_step=0):
@@ -602,6 +612,7 @@ class LAS:
             st.zero_grad()
             n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
             n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
+            loss_scale = self._loss_scale(n_total)
             # the Speller's host-side preparation: token schedule, encoder lengths, masks
             prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
                                         True, coins, sampled)
@@ -612,7 +623,7 @@ class LAS:
             logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
         with _hip.roctx_range("loss"):
-            loss = self._get_loss(logits, y, n_total)                                     # sum_local / n_total
+            loss = self._get_loss(logits, y, n_total, loss_scale)                         # sum_local / n_total
         early = []
         if self.dp is not None:
             def before_tail(P4, st=st, dev=dev):
