@@ -449,9 +449,12 @@ struct BfLds {
     // step t + 1's conv sends back to alpha_t, the staged filter [Kc, C] and Wf [C, A]
     float *aprev, *fc, *dfc, *daext, *locw, *wfl;
     unsigned short* wfb;      // [16][A] bf16 copy of Wf (rows >= C zero): B operand of the d f product
+    unsigned short* wcf;      // [ceil(Kc/32)][2][64][8] the conv filter as MFMA B fragments, bf16 high and low parts (loc_conv_mfma)
     unsigned int* dvb;        // [Tp][A/2] the step's d(pre-tanh) rows as bf16 pairs: A operand of the d f product (gradient loop)
 };
 __device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
+// floats of the zero-padded previous-alignment array: the filter's reach on both sides, rounded up to what the MFMA conv's fragments touch
+__host__ __device__ __forceinline__ int loc_apad(const DecDev& a) { return (a.Tp + 15) / 16 * 16 + (a.Kc + 31) / 32 * 32 + 16; }
 __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     BfLds r; float* p = sm;
     r.s_state = p; p += up4(a.D * a.NL);
@@ -462,19 +465,20 @@ __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     r.x1 = p;      p += up4(a.Tp);      // bwd: d alpha / d energy
     r.red = p;     p += 32;
     r.redi = reinterpret_cast<int*>(p); p += 32;
-    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr; r.wfb = nullptr; r.dvb = nullptr;
+    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr; r.wfb = nullptr; r.wcf = nullptr; r.dvb = nullptr;
     if (a.mode == LAS_ATT_LOC) {
         // the conv input (previous alignment) and the transposed conv's input (d f) are zero-padded by the filter's reach on both
         // sides (+ one unrolled block): the sliding-window loops of loc_conv_partials carry no bounds checks.  aprev / dfc point at
         // frame 0 inside their padded arrays; the pads are zeroed once per launch (loc_stage_lds) and never written again.
         const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
-        r.aprev = p + padl;            p += up4(a.Tp + a.Kc + 16);
+        r.aprev = p + padl;            p += up4(loc_apad(a));             // (frame tiles of 16 x tap steps of 32 for loc_conv_mfma)
         r.daext = p;                   p += up4(a.Tp);
         r.fc = p;                      p += up4(a.Tp * a.C);
         r.dfc = p + padr * a.C;        p += up4((a.Tp + a.Kc + 16) * a.C);
         r.locw = p;                    p += up4(a.Kc * a.C);
         r.wfl = p;                     p += up4(a.C * a.A);
         r.wfb = reinterpret_cast<unsigned short*>(p); p += up4(8 * a.A);
+        r.wcf = reinterpret_cast<unsigned short*>(p); p += ((a.Kc + 31) / 32) * 2 * 256;
     }
     r.scr = p;                           // RNW x max(Hd, 2A) partials
     if (a.mode == LAS_ATT_LOC) r.dvb = reinterpret_cast<unsigned int*>(p + RNW * 2 * a.A);   // behind the dq / du partials of the same phase
@@ -485,8 +489,8 @@ static size_t bf_lds_bytes(const DecDev& a) {
     size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
     size_t loc = 0;
     if (a.mode == LAS_ATT_LOC) {
-        loc = u4(a.Tp + a.Kc + 16) + u4(a.Tp) + u4((size_t)a.Tp * a.C) + u4((size_t)(a.Tp + a.Kc + 16) * a.C) + u4((size_t)a.Kc * a.C) +
-              u4((size_t)a.C * a.A) + u4((size_t)8 * a.A);
+        loc = u4(loc_apad(a)) + u4(a.Tp) + u4((size_t)a.Tp * a.C) + u4((size_t)(a.Tp + a.Kc + 16) * a.C) + u4((size_t)a.Kc * a.C) +
+              u4((size_t)a.C * a.A) + u4((size_t)8 * a.A) + (size_t)((a.Kc + 31) / 32) * 2 * 256;
         const int items = ((a.Tp + 7) / 8) * a.C;                   // loc_conv_chunks: the conv's tap-chunk partials live in the scratch
         int nch = 1024 / (items > 0 ? items : 1);
         nch = nch < 1 ? 1 : (nch > 8 ? 8 : nch);
@@ -555,6 +559,47 @@ __device__ __forceinline__ void loc_conv_partials(const float* __restrict__ P, c
             if (f0 + j < Tp) part[(ch * Tp + f0 + j) * C + c] = acc[j];
     }
 }
+// The conv on the matrix cores: f = T(aprev) . w with T the Toeplitz matrix of the zero-padded alignment, T[t', k] = P[t' + k]
+// (M = frames in tiles of 16, K = taps in steps of 32, N = channels <= 16).  Lane (g, r) of an A fragment holds 8 CONSECUTIVE
+// alignments P[16 mt + r + 32 ks + 8 g ...] -- read straight from the padded fp32 array in LDS, no Toeplitz matrix is ever built.
+// fp32 accuracy from bf16 MFMAs by the usual split x = hi + lo (both bf16): hi.hi + hi.lo + lo.hi, the dropped lo.lo term is 2^-16
+// relative.  One wave per frame tile walks all tap steps (no cross-wave reduction, no partials, no finish pass): 21 MFMAs + 56 LDS
+// reads per wave instead of 314 multiply-adds + 80 LDS reads per thread -- r3 stamps: 5.0 us -> see profiles/r3_speller_loc_phase_stamps.txt.
+// Call with all threads, after a barrier behind the writes of L.aprev; the result is in L.fc after the caller's next barrier.
+__device__ __forceinline__ void loc_conv_mfma(const BfLds& L, const DecDev& a, const int tid) {
+    const int lane = tid & 63, mt = tid >> 6, g = lane >> 4, r = lane & 15;
+    if (mt * 16 >= a.Tp) return;
+    const int NKS = (a.Kc + 31) >> 5;
+    const float* Pp = L.aprev - (a.Kc - 1) / 2 + mt * 16 + r + g * 8;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    for (int ks = 0; ks < NKS; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = Pp[ks * 32 + e];
+        unsigned int h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short h0 = f2bf(x[2 * e]), h1 = f2bf(x[2 * e + 1]);
+            h[e] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+            l[e] = f2bf2(x[2 * e] - bf2f(h0), x[2 * e + 1] - bf2f(h1));
+        }
+        const u16x8_t ah = __builtin_bit_cast(u16x8_t, (u32x4_t){h[0], h[1], h[2], h[3]});
+        const u16x8_t al = __builtin_bit_cast(u16x8_t, (u32x4_t){l[0], l[1], l[2], l[3]});
+        const u16x8_t bh = *reinterpret_cast<const u16x8_t*>(L.wcf + ((size_t)(ks * 2) * 64 + lane) * 8);
+        const u16x8_t bl = *reinterpret_cast<const u16x8_t*>(L.wcf + ((size_t)(ks * 2 + 1) * 64 + lane) * 8);
+        acc0 = mfma_bf16_16x16x32(ah, bh, acc0);
+        acc1 = mfma_bf16_16x16x32(ah, bl, acc1);
+        acc2 = mfma_bf16_16x16x32(al, bh, acc2);
+    }
+    if (r < a.C) {                                                    // C layout: lane (g, n = r) holds frames 16 mt + 4 g + i, channel n
+        const float bias = a.loc_b[r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = mt * 16 + g * 4 + i;
+            if (t < a.Tp) L.fc[t * a.C + r] = (acc0[i] + (acc1[i] + acc2[i])) + bias;
+        }
+    }
+}
 // f = bias + sum over the tap chunks (after a barrier behind loc_conv_partials<false>)
 __device__ __forceinline__ void loc_conv_finish(const BfLds& L, const float* __restrict__ part, const DecDev& a, const int tid) {
     const int Tp = a.Tp, C = a.C, nch = loc_conv_chunks(a);
@@ -568,7 +613,14 @@ __device__ __forceinline__ void loc_stage_lds(const BfLds& L, const DecDev& a, c
     const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
     for (int i = tid; i < a.Kc * a.C; i += RNT) L.locw[i] = a.loc_w[i];
     for (int i = tid; i < a.C * a.A; i += RNT) L.wfl[i] = a.Wf[i];
-    for (int i = tid; i < a.Tp + a.Kc + 16; i += RNT) (L.aprev - padl)[i] = 0.f;
+    for (int i = tid; i < loc_apad(a); i += RNT) (L.aprev - padl)[i] = 0.f;
+    for (int i = tid; i < (a.Kc + 31) / 32 * 1024; i += RNT) {          // filter as B fragments: lane l holds w[ks*32 + 8*(l>>4) + e][l&15]
+        const int e = i & 7, l = (i >> 3) & 63, part = (i >> 9) & 1, ks = i >> 10;
+        const int k = ks * 32 + (l >> 4) * 8 + e, n = l & 15;
+        const float v = (k < a.Kc && n < a.C) ? a.loc_w[k * a.C + n] : 0.f;
+        const unsigned short hi = f2bf(v);
+        L.wcf[i] = part ? f2bf(v - bf2f(hi)) : hi;
+    }
     for (int i = tid; i < (a.Tp + a.Kc + 16) * a.C; i += RNT) (L.dfc - padr * a.C)[i] = 0.f;
     for (int i = tid; i < 16 * a.A; i += RNT) L.wfb[i] = (i / a.A) < a.C ? f2bf(a.Wf[i]) : (unsigned short)0;
 }
@@ -857,11 +909,9 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         }
         if (t < U) {
             STAMPX(25);
-            loc_conv_partials<false>(L.aprev - (a.Kc - 1) / 2, L.locw, L.scr, a, tid);     // (the partials scratch is idle until the query projection)
-            lds_barrier();
+            loc_conv_mfma(L, a, tid);
             STAMPX(26);
-            loc_conv_finish(L, L.scr, a, tid);
-            lds_barrier();                                                // the scratch is reused by the query partials
+            lds_barrier();
             STAMPX(27);
         }
     }
@@ -1847,12 +1897,10 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     if (LOC && att) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way -- before the bulk loads (register pressure); keep it for the after-loop keys / Wf gradient
         if (tid < Tp) L.aprev[tid] = apv;
         lds_barrier();
-        loc_conv_partials<false>(L.aprev - (a.Kc - 1) / 2, L.locw, L.scr, a, tid);
+        loc_conv_mfma(L, a, tid);
         lds_barrier();
-        loc_conv_finish(L, L.scr, a, tid);
         float* fs = a.fcSave + ((size_t)ta * B + b) * Tp * a.C;
-        for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];          // (a thread re-reads what it wrote itself)
-        lds_barrier();                                                      // the scratch is reused below
+        for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];
     }
     const float* dxr = a.dXin0 + ((size_t)ta * B + b) * I0D;
     float2 dcv = make_float2(0.f, 0.f);
