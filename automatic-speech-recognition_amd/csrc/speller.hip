@@ -447,7 +447,7 @@ struct BfLds {
     float *s_state, *qv, *ev, *hl, *x0, *x1, *red, *scr; int* redi;
     // location-aware attention in the one-launch loop kernels: previous alignment, conv output f and its gradient, the gradient that
     // step t + 1's conv sends back to alpha_t, the staged filter [Kc, C] and Wf [C, A]
-    float *aprev, *fc, *dfc, *daext, *locw, *wfl;
+    float *aprev, *fc, *dfc, *daext, *wft, *wfl;
     unsigned short* wfb;      // [16][A] bf16 copy of Wf (rows >= C zero): B operand of the d f product
     unsigned short* wcf;      // [ceil(Kc/32)][2][64][8] the conv filter as MFMA B fragments, bf16 high and low parts (loc_conv_mfma)
     unsigned int* dvb;        // [Tp][A/2] the step's d(pre-tanh) rows as bf16 pairs: A operand of the d f product (gradient loop)
@@ -455,6 +455,10 @@ struct BfLds {
 __device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
 // floats of the zero-padded previous-alignment array: the filter's reach on both sides, rounded up to what the MFMA conv's fragments touch
 __host__ __device__ __forceinline__ int loc_apad(const DecDev& a) { return (a.Tp + 15) / 16 * 16 + (a.Kc + 31) / 32 * 32 + 16; }
+// frames of the zero-padded d f array (C values per frame) and floats per channel of the flipped, zero-padded filter: what the
+// fragments of the transposed conv (loc_convT_mfma: blocks of 16 source frames x 16 shifts) touch
+__host__ __device__ __forceinline__ int loc_dpad(const DecDev& a) { return (a.Tp + 15) / 16 * 16 + (a.Kc + 15 + 31) / 32 * 32 + 16; }
+__host__ __device__ __forceinline__ int loc_wft_ld(const DecDev& a) { return 16 + (a.Kc + 15 + 31) / 32 * 32; }
 __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     BfLds r; float* p = sm;
     r.s_state = p; p += up4(a.D * a.NL);
@@ -465,17 +469,17 @@ __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     r.x1 = p;      p += up4(a.Tp);      // bwd: d alpha / d energy
     r.red = p;     p += 32;
     r.redi = reinterpret_cast<int*>(p); p += 32;
-    r.aprev = r.fc = r.dfc = r.daext = r.locw = r.wfl = nullptr; r.wfb = nullptr; r.wcf = nullptr; r.dvb = nullptr;
+    r.aprev = r.fc = r.dfc = r.daext = r.wft = r.wfl = nullptr; r.wfb = nullptr; r.wcf = nullptr; r.dvb = nullptr;
     if (a.mode == LAS_ATT_LOC) {
         // the conv input (previous alignment) and the transposed conv's input (d f) are zero-padded by the filter's reach on both
-        // sides (+ one unrolled block): the sliding-window loops of loc_conv_partials carry no bounds checks.  aprev / dfc point at
+        // sides and up to whole MFMA fragments (loc_apad / loc_dpad): the convs' fragment reads carry no bounds checks.  aprev / dfc point at
         // frame 0 inside their padded arrays; the pads are zeroed once per launch (loc_stage_lds) and never written again.
         const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
         r.aprev = p + padl;            p += up4(loc_apad(a));             // (frame tiles of 16 x tap steps of 32 for loc_conv_mfma)
         r.daext = p;                   p += up4(a.Tp);
         r.fc = p;                      p += up4(a.Tp * a.C);
-        r.dfc = p + padr * a.C;        p += up4((a.Tp + a.Kc + 16) * a.C);
-        r.locw = p;                    p += up4(a.Kc * a.C);
+        r.dfc = p + padr;              p += up4(loc_dpad(a) * a.C);       // CHANNEL-major: row c = loc_dpad frames, frame 0 at r.dfc + c * loc_dpad
+        r.wft = p;                     p += up4(a.C * loc_wft_ld(a));
         r.wfl = p;                     p += up4(a.C * a.A);
         r.wfb = reinterpret_cast<unsigned short*>(p); p += up4(8 * a.A);
         r.wcf = reinterpret_cast<unsigned short*>(p); p += ((a.Kc + 31) / 32) * 2 * 256;
@@ -489,12 +493,9 @@ static size_t bf_lds_bytes(const DecDev& a) {
     size_t scr = (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A);
     size_t loc = 0;
     if (a.mode == LAS_ATT_LOC) {
-        loc = u4(loc_apad(a)) + u4(a.Tp) + u4((size_t)a.Tp * a.C) + u4((size_t)(a.Tp + a.Kc + 16) * a.C) + u4((size_t)a.Kc * a.C) +
+        loc = u4(loc_apad(a)) + u4(a.Tp) + u4((size_t)a.Tp * a.C) + u4((size_t)loc_dpad(a) * a.C) + u4((size_t)a.C * loc_wft_ld(a)) +
               u4((size_t)a.C * a.A) + u4((size_t)8 * a.A) + (size_t)((a.Kc + 31) / 32) * 2 * 256;
-        const int items = ((a.Tp + 7) / 8) * a.C;                   // loc_conv_chunks: the conv's tap-chunk partials live in the scratch
-        int nch = 1024 / (items > 0 ? items : 1);
-        nch = nch < 1 ? 1 : (nch > 8 ? 8 : nch);
-        size_t need = (size_t)nch * a.Tp * a.C;
+        size_t need = (size_t)RNW * 256;                             // loc_convT_mfma: one 16 x 16 partial tile per wave
         if (need > scr) scr = need;
         need = (size_t)RNW * 2 * a.A + (size_t)((a.Tp + 15) / 16 * 16) * (a.A / 2);      // dq / du partials + the step's dv rows (bf16 pairs)
         if (need > scr) scr = need;
@@ -502,63 +503,10 @@ static size_t bf_lds_bytes(const DecDev& a) {
     return (u4((size_t)a.D * a.NL) + u4(a.A) + 2 * u4(a.Tp) + u4(a.D) + u4(a.Hd) + 64 + loc + scr) * sizeof(float) + 64;
 }
 // location-aware attention, loop kernels: the conv1d over the previous alignment (las/layers.py:295-296; SAME, cross-correlation):
-// f[t', c] = bias[c] + sum_k aprev[t' + k - pad] w[k, c], filter and alignment in LDS.  The first version gave every thread one
-// (frame, channel) output and walked the 201 taps with two LDS reads per multiply-add: 3.4 MB of LDS traffic per row and step,
-// ~10 us (r3g trace).  Now a work item is (block of 8 consecutive frames, channel, chunk of the taps): the 8 alignments slide
-// through registers (ONE new alignment + one filter tap read per 8 multiply-adds), the chunks' partial sums meet in LDS.
-// `part` needs NCH * Tp * C floats (the row kernels' partials scratch).  Call with all threads; ends with the result in L.fc after
-// the caller's next barrier + loc_conv_finish.
-constexpr int LOC_FB = 8;            // frames per work item
-constexpr int LOC_UB = 8;            // taps per unrolled block
-__device__ __forceinline__ int loc_conv_chunks(const DecDev& a) {
-    const int items = ((a.Tp + LOC_FB - 1) / LOC_FB) * a.C;             // (frame block, channel) pairs
-    int n = RNT / items;
-    return n < 1 ? 1 : (n > 8 ? 8 : n);
-}
-// FLIP = false: out[t', c] = sum_k in[t' + k - pad] w[k, c]            (the conv; `in` = alignment, one value per frame)
-// FLIP = true:  out[src, c] = sum_k in[(src - k + pad), c] w[k, c]     (its transpose; `in` = d f, C values per frame) -- with the
-//               taps counted from the far end (k' = Kc - 1 - k) it is the same sliding sum over the padded array.
-// P = the zero-padded input, indexed so that output f at tap k reads P[f + k]: aprev - padl resp. (dfc - padr * C).
-// 8 new inputs + 8 filter taps are read per block of 8 taps and feed 64 multiply-adds with static register indices; between
-// blocks the window moves by 7 copies.  (The rolled first version shifted the window every tap: 23 instructions and two exposed LDS
-// round trips per tap, 6-8 us per conv at K = 201 -- profiles/r3_speller_phase_stamps.txt.)
-template <bool FLIP>
-__device__ __forceinline__ void loc_conv_partials(const float* __restrict__ P, const float* __restrict__ w, float* __restrict__ part,
-                                                  const DecDev& a, const int tid) {
-    const int Tp = a.Tp, C = a.C, Kc = a.Kc;
-    const int nfb = (Tp + LOC_FB - 1) / LOC_FB, nch = loc_conv_chunks(a);
-    const int kper = ((Kc + nch - 1) / nch + LOC_UB - 1) / LOC_UB * LOC_UB;      // chunk = whole blocks
-    const int pst = FLIP ? C : 1;                                      // stride of the input along frames
-    for (int i = tid; i < nfb * C * nch; i += RNT) {
-        const int ch = i / (nfb * C), r = i - ch * nfb * C, fb = r / C, c = r - fb * C;
-        const int f0 = fb * LOC_FB, k0 = ch * kper < Kc ? ch * kper : Kc, k1 = k0 + kper < Kc ? k0 + kper : Kc;
-        const float* Pp = P + (FLIP ? c : 0) + (size_t)(f0 + k0) * pst;
-        float acc[LOC_FB], win[LOC_FB + LOC_UB - 1];
-#pragma unroll
-        for (int j = 0; j < LOC_FB; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int j = 0; j < LOC_FB - 1; ++j) win[j] = Pp[j * pst];
-        for (int kb = k0; kb < k1; kb += LOC_UB) {
-            float wv[LOC_UB];
-#pragma unroll
-            for (int u = 0; u < LOC_UB; ++u) {
-                win[LOC_FB - 1 + u] = Pp[(kb - k0 + LOC_FB - 1 + u) * pst];
-                const int k = kb + u, kc = k < k1 ? k : k1 - 1;
-                const float t_ = w[(FLIP ? Kc - 1 - kc : kc) * C + c];
-                wv[u] = k < k1 ? t_ : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < LOC_UB; ++u)
-#pragma unroll
-                for (int j = 0; j < LOC_FB; ++j) acc[j] = fmaf(win[j + u], wv[u], acc[j]);
-#pragma unroll
-            for (int j = 0; j < LOC_FB - 1; ++j) win[j] = win[j + LOC_UB];
-        }
-#pragma unroll
-        for (int j = 0; j < LOC_FB; ++j)
-            if (f0 + j < Tp) part[(ch * Tp + f0 + j) * C + c] = acc[j];
-    }
-}
+// f[t', c] = bias[c] + sum_k aprev[t' + k - pad] w[k, c] and, in the gradient loop, its transpose
+// d alpha_{t-1}[src] = sum_c sum_k d f[src - k + pad, c] w[k, c]; alignment, d f and the filter live in LDS.  History (r3 traces): one
+// thread per output walking the 201 taps, ~10 us per conv; sliding register windows of 8 frames x 8 taps, 5.0-5.6 us (fp32 VALU issue:
+// 321,600 multiply-adds per row and step); now both run on the matrix cores.
 // The conv on the matrix cores: f = T(aprev) . w with T the Toeplitz matrix of the zero-padded alignment, T[t', k] = P[t' + k]
 // (M = frames in tiles of 16, K = taps in steps of 32, N = channels <= 16).  Lane (g, r) of an A fragment holds 8 CONSECUTIVE
 // alignments P[16 mt + r + 32 ks + 8 g ...] -- read straight from the padded fp32 array in LDS, no Toeplitz matrix is ever built.
@@ -600,18 +548,70 @@ __device__ __forceinline__ void loc_conv_mfma(const BfLds& L, const DecDev& a, c
         }
     }
 }
-// f = bias + sum over the tap chunks (after a barrier behind loc_conv_partials<false>)
-__device__ __forceinline__ void loc_conv_finish(const BfLds& L, const float* __restrict__ part, const DecDev& a, const int tid) {
-    const int Tp = a.Tp, C = a.C, nch = loc_conv_chunks(a);
-    for (int i = tid; i < Tp * C; i += RNT) {
-        float acc = a.loc_b[i % C];
-        for (int ch = 0; ch < nch; ++ch) acc += part[ch * Tp * C + i];
-        L.fc[i] = acc;
+// The transposed conv on the matrix cores.  With P = the zero-padded d f array (P[x, c], indexed so that source frame s at flipped tap
+// k' = Kc - 1 - k reads P[s + k', c]) and wf_c[k'] = w[Kc - 1 - k', c]:  out[s] = sum_c sum_k' P[s + k', c] wf_c[k'].  A plain
+// Toeplitz product would have ONE useful output column per channel.  Instead the 16 frames of a block are the N dimension:
+// s = 16 a + n, u = n + k'  ->  out[16 a + n] = sum_c sum_u P[16 a + u, c] wf_c[u - n]:  per channel a [frame blocks, u] x [u, 16 shifts]
+// product -- A fragments are 8 consecutive frames of one channel (d f is kept channel-major in LDS), B fragments 8 consecutive taps of the flipped,
+// zero-padded filter row (L.wft, written once per launch) -- all 16 columns useful.  The (channel, u step) pairs are dealt to the 16
+// waves; their partial tiles meet in the scratch.  Same bf16 hi/lo split as loc_conv_mfma.  Needs ceil(Tp / 16) <= 16.
+// Call with all threads after a barrier behind the writes of L.dfc; ends with d alpha_{t-1} in L.daext (barrier inside; the caller's
+// next barrier publishes it).
+__device__ __forceinline__ void loc_convT_mfma(const BfLds& L, const DecDev& a, const int tid) {
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int C = a.C, nA = (a.Tp + 15) >> 4, NKS = (a.Kc + 15 + 31) >> 5, ld = loc_wft_ld(a);
+    const int ldd = loc_dpad(a);
+    const float* P = L.dfc - (a.Kc - 1 - (a.Kc - 1) / 2);                           // channel-major rows of ldd frames (16-byte aligned starts)
+    const float* pa = P + 16 * (r < nA ? r : nA - 1) + g * 8;                      // rows >= nA: any valid address, their outputs are dropped
+    const float* pb = L.wft + 15 + g * 8 - r;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    for (int it = wv; it < C * NKS; it += RNW) {
+        const int c = it / NKS, ks = it - c * NKS;
+        float x[8], y[8];
+        {
+            const float4 x0 = *reinterpret_cast<const float4*>(pa + c * ldd + ks * 32), x1 = *reinterpret_cast<const float4*>(pa + c * ldd + ks * 32 + 4);
+            x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = pb[c * ld + ks * 32 + e];
+        unsigned int xh[4], xl[4], yh[4], yl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short h0 = f2bf(x[2 * e]), h1 = f2bf(x[2 * e + 1]), k0 = f2bf(y[2 * e]), k1 = f2bf(y[2 * e + 1]);
+            xh[e] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+            xl[e] = f2bf2(x[2 * e] - bf2f(h0), x[2 * e + 1] - bf2f(h1));
+            yh[e] = (unsigned int)k0 | ((unsigned int)k1 << 16);
+            yl[e] = f2bf2(y[2 * e] - bf2f(k0), y[2 * e + 1] - bf2f(k1));
+        }
+        const u16x8_t ah = __builtin_bit_cast(u16x8_t, (u32x4_t){xh[0], xh[1], xh[2], xh[3]});
+        const u16x8_t al = __builtin_bit_cast(u16x8_t, (u32x4_t){xl[0], xl[1], xl[2], xl[3]});
+        const u16x8_t bh = __builtin_bit_cast(u16x8_t, (u32x4_t){yh[0], yh[1], yh[2], yh[3]});
+        const u16x8_t bl = __builtin_bit_cast(u16x8_t, (u32x4_t){yl[0], yl[1], yl[2], yl[3]});
+        acc0 = mfma_bf16_16x16x32(ah, bh, acc0);
+        acc1 = mfma_bf16_16x16x32(ah, bl, acc1);
+        acc2 = mfma_bf16_16x16x32(al, bh, acc2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L.scr[(wv * 64 + lane) * 4 + i] = acc0[i] + (acc1[i] + acc2[i]);
+    lds_barrier();
+    if (tid < a.Tp) {                                   // C layout: (frame block a, shift n) sits in lane (a / 4) * 16 + n, register a % 4
+        const int ab = tid >> 4, n = tid & 15;
+        const float* sp = L.scr + (((ab >> 2) * 16 + n) * 4 + (ab & 3));
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < RNW; ++w) acc += sp[w * 256];
+        L.daext[tid] = acc;
     }
 }
 __device__ __forceinline__ void loc_stage_lds(const BfLds& L, const DecDev& a, const int tid) {
     const int padl = (a.Kc - 1) / 2, padr = a.Kc - 1 - padl;
-    for (int i = tid; i < a.Kc * a.C; i += RNT) L.locw[i] = a.loc_w[i];
+    {   // flipped filter rows for the transposed conv: wft[c][15 + x] = w[Kc - 1 - x, c] for 0 <= x < Kc, zero around
+        const int ld = loc_wft_ld(a);
+        for (int i = tid; i < a.C * ld; i += RNT) {
+            const int c = i / ld, x = i - c * ld - 15;
+            L.wft[i] = (x >= 0 && x < a.Kc) ? a.loc_w[(a.Kc - 1 - x) * a.C + c] : 0.f;
+        }
+    }
     for (int i = tid; i < a.C * a.A; i += RNT) L.wfl[i] = a.Wf[i];
     for (int i = tid; i < loc_apad(a); i += RNT) (L.aprev - padl)[i] = 0.f;
     for (int i = tid; i < (a.Kc + 31) / 32 * 1024; i += RNT) {          // filter as B fragments: lane l holds w[ks*32 + 8*(l>>4) + e][l&15]
@@ -621,7 +621,7 @@ __device__ __forceinline__ void loc_stage_lds(const BfLds& L, const DecDev& a, c
         const unsigned short hi = f2bf(v);
         L.wcf[i] = part ? f2bf(v - bf2f(hi)) : hi;
     }
-    for (int i = tid; i < (a.Tp + a.Kc + 16) * a.C; i += RNT) (L.dfc - padr * a.C)[i] = 0.f;
+    for (int i = tid; i < loc_dpad(a) * a.C; i += RNT) (L.dfc - padr)[i] = 0.f;
     for (int i = tid; i < 16 * a.A; i += RNT) L.wfb[i] = (i / a.A) < a.C ? f2bf(a.Wf[i]) : (unsigned short)0;
 }
 
@@ -2079,7 +2079,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int fr = wv * 16 + g * 4 + r;
-                if (fr < Tp && c16 < a.C) L.dfc[fr * a.C + c16] = acc[r];
+                if (fr < Tp && c16 < a.C) L.dfc[c16 * loc_dpad(a) + fr] = acc[r];
             }
         }
         {
@@ -2112,22 +2112,13 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         }
         if (LOC) {
             // d f of this step is complete (the barriers of the dq / du reduction): keep it for the after-loop filter gradient, and send
-            // d alpha_{t-1}[src] = sum_k sum_c dfc[src - k + pad, c] w[k, c] back to the previous step: the taps of a source frame are
-            // split over NKC thread groups, the partial sums meet in the (free) partials scratch
+            // d alpha_{t-1}[src] = sum_k sum_c dfc[src - k + pad, c] w[k, c] back to the previous step (loc_convT_mfma; the scratch is free)
             const int C = a.C;
             float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
-            for (int i = tid; i < Tp * C; i += RNT) ds[i] = L.dfc[i];
+            for (int i = tid; i < Tp * C; i += RNT) ds[i] = L.dfc[(i % C) * loc_dpad(a) + i / C];      // (saved frame-major, as the after-loop kernels read it)
             STAMPX(28);
-            loc_conv_partials<true>(L.dfc - (a.Kc - 1 - (a.Kc - 1) / 2) * a.C, L.locw, L.scr, a, tid);       // [chunk][src][c] partial products
-            lds_barrier();
+            loc_convT_mfma(L, a, tid);
             STAMPX(29);
-            if (tid < Tp) {
-                const int n = loc_conv_chunks(a);
-                float acc = 0.f;
-                for (int ch = 0; ch < n; ++ch)
-                    for (int c = 0; c < C; ++c) acc += L.scr[(ch * Tp + tid) * C + c];
-                L.daext[tid] = acc;
-            }
         }
         lds_barrier();
     } else {
