@@ -2038,7 +2038,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             }
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
-                if (LAS_W8_LATE && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
+                if (LAS_W8_LATE && !LOC && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
                 const int t2 = wv + RNW * u;
                 const float de = t2 < lim ? dal[t2] : 0.f;
                 float p0 = __uint_as_float(k2[u] << 16) + q0, p1 = __uint_as_float(k2[u] & 0xffff0000u) + q1;
@@ -2062,6 +2062,10 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             if (lane < A2) {
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A)[lane] = make_float2(dq0, dq1);
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A + A)[lane] = make_float2(du0, du1);
+            }
+            if (LAS_W8_LATE && LOC) {   // location-aware: the loop above is at the register limit (Wf columns, d v rows) -- the Ws rows are
+#pragma unroll                  // requested here; the d f product and the dq / du reduction below cover their latency
+                for (int u = 0; u < 8; ++u) w8_load(u);
             }
         }
         lds_barrier();
