@@ -24,19 +24,22 @@ __device__ __forceinline__ bool bless(const BKey& a, const BKey& b) {   // a < b
 
 // The `beam` best candidates of one utterance, best first, into L.picks[] (LDS); returns how many exist.  Called by all 256 threads.
 //
-// Up to 512 candidates (beam x V of a char model): ONE wave holds them all, 8 per lane, as two sortable 64-bit integers --
-// K1 = order(norm) : hypothesis, K2 = order(logit) : token, order() = the usual monotone map of float bits -- and finds the value of the
-// beam-th largest K1 by bisection over its 38 bits: every probe is 8 compares whose ballots are counted on the scalar unit, no data
-// crosses lanes.  Ties at the threshold (same hypothesis, same normalised score) are cut the same way on K2.  The <= 64 selected
-// candidates are compacted into LDS through ballot prefix counts and ranked among themselves by counting.  r3 decode traces at beam 16,
-// V = 30: 16 rounds of (re-scan + 8-level LDS tree, 9 barriers) 44 us -> 16 rounds of (wave butterfly + 1 barrier) 28 us -> this.
+// Up to 512 candidates (beam x V of a char model): a candidate becomes two sortable integers -- KA = order(norm) (32 bits) and
+// KB = hypothesis : order(logit) : token (58 bits), order() = the usual monotone map of float bits -- and a WAVE finds the value of the
+// n-th largest KA among its candidates by bisection over the 32 bits: every probe is one compare per candidate slot whose ballot is
+// counted on the scalar unit, no data crosses lanes.  Ties at the threshold (equal normalised scores) are cut the same way on KB.
+// Two levels: each of the 4 waves selects the `beam` best of its quarter of the grid (2 candidates per lane), the <= 4 x beam survivors
+// meet in LDS and wave 0 selects among them again, then ranks the <= 64 winners among themselves by counting.  r3 decode traces at
+// beam 16, V = 30: 16 rounds of (re-scan + 8-level LDS tree, 9 barriers) 44 us -> 16 rounds of (wave butterfly + 1 barrier) 28 us ->
+// one wave bisecting 8 slots of 64-bit keys 19 us -> this.
 // Larger grids (subword vocabularies) take the round-based path: block-wide maximum of the candidates strictly below the previous pick,
 // wave butterfly (64-lane xor shuffles) + one LDS slot per wave, one barrier per round (the slots are double-buffered).
 struct BeamLds {
     BKey picks[64];
     BKey wbest[2][4];
-    unsigned long long k1[64], k2[64];
-    int ci[64], cv[64]; float cl[64];
+    unsigned ka[320]; unsigned long long kb[320];        // [0, 256): the waves' survivors (wave w at 64 w), [256, 320): the winners
+    int ci[320], cv[320]; float cl[320];
+    int cnt[4];
     int count;
 };
 __device__ __forceinline__ unsigned f_order(float f) {                         // unsigned order == float order (-0 canonicalised by the caller)
@@ -60,83 +63,106 @@ __device__ __forceinline__ bool beam_make_key(BKey& k, const float* lg, const fl
     k.i = i; k.l = l; k.v = idx;                        // v carries the flat candidate id until the very end
     return k.norm == k.norm;                            // NaN never ranks
 }
-// value of the need-th largest key among the flagged candidates (bits [nbits-1, 0]): largest T with count(key >= T) >= need
+// One wave: the `beam` largest (KA, KB) among its flagged candidates (bit s of `on`: this lane's slot s) are appended to the LDS lists at
+// [obase, obase + n); returns n = min(beam, flagged).  Largest T with count(key >= T) >= n is the n-th largest key.
 template <int NS>
-__device__ __forceinline__ unsigned long long beam_bisect(const unsigned long long (&key)[NS], const unsigned on, int ns, int nbits, int need) {
-    unsigned long long T = 0;
-    for (int b = nbits - 1; b >= 0; --b) {
-        const unsigned long long probe = T | (1ull << b);
+__device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const unsigned long long (&KB)[NS], const int (&ci)[NS],
+                                                const float (&cl)[NS], const int (&cv)[NS], const unsigned on, const int beam, const int lane,
+                                                BeamLds& L, const int obase) {
+    int nvalid = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) nvalid += __popcll(__ballot((on >> s) & 1u));
+    const int need = nvalid < beam ? nvalid : beam;
+    if (need == 0) return 0;
+    unsigned TA = 0;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned probe = TA | (1u << b);
         int cnt = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (s < ns) cnt += __popcll(__ballot(((on >> s) & 1u) && key[s] >= probe));
-        if (cnt >= need) T = probe;                      // uniform (ballots)
+        for (int s = 0; s < NS; ++s) cnt += __popcll(__ballot(((on >> s) & 1u) && KA[s] >= probe));
+        if (cnt >= need) TA = probe;                     // uniform (ballots)
     }
-    return T;
+    int gt = 0, eq = 0;
+    unsigned tie = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool o = (on >> s) & 1u;
+        if (o && KA[s] == TA) tie |= 1u << s;
+        gt += __popcll(__ballot(o && KA[s] > TA)); eq += __popcll(__ballot((tie >> s) & 1u));
+    }
+    unsigned long long TB = 0;
+    if (eq > need - gt) {                                // equal normalised scores at the threshold: the (need - gt) largest KB of the ties
+        for (int b = 57; b >= 0; --b) {
+            const unsigned long long probe = TB | (1ull << b);
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) cnt += __popcll(__ballot(((tie >> s) & 1u) && KB[s] >= probe));
+            if (cnt >= need - gt) TB = probe;
+        }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = obase;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool sel = ((on >> s) & 1u) && (KA[s] > TA || (KA[s] == TA && KB[s] >= TB));
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int pos = base + __popcll(m & lt);
+            L.ka[pos] = KA[s]; L.kb[pos] = KB[s]; L.ci[pos] = ci[s]; L.cl[pos] = cl[s]; L.cv[pos] = cv[s];
+        }
+        base += __popcll(m);
+    }
+    return need;
 }
 __device__ __forceinline__ int beam_rank(const float* lg, const float* sc, const int* ln, int nb, int V, int t, int start_id, int beam, BeamLds& L) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ncand = nb * V;
-    constexpr int NS = 8;
-    if (ncand <= 64 * NS) {
-        if (w == 0) {
-            const int ns = (ncand + 63) >> 6;
-            unsigned long long K1[NS], K2[NS];
-            unsigned on = 0;                                 // bit s: this lane's candidate of slot s ranks
-            BKey ck[NS];
-            int nvalid = 0;
+    if (ncand <= 512) {
+        {   // level 1: every wave, the two candidates per lane of its quarter of the grid
+            unsigned KA[2]; unsigned long long KB[2]; int ci[2], cv[2]; float cl[2];
+            unsigned on = 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                K1[s] = 0; K2[s] = 0;
-                const int idx = s * 64 + lane;
-                if (s < ns && idx < ncand && beam_make_key(ck[s], lg, sc, ln, idx, V, t, start_id)) {
+            for (int s = 0; s < 2; ++s) {
+                KA[s] = 0; KB[s] = 0; ci[s] = 0; cv[s] = 0; cl[s] = 0.f;
+                const int idx = s * 256 + tid;
+                BKey k;
+                if (idx < ncand && beam_make_key(k, lg, sc, ln, idx, V, t, start_id)) {
                     on |= 1u << s;
-                    K1[s] = ((unsigned long long)f_order(ck[s].norm + 0.f) << 6) | (unsigned)ck[s].i;
-                    K2[s] = ((unsigned long long)f_order(ck[s].l + 0.f) << 20) | (unsigned)(ck[s].v - ck[s].i * V);
+                    KA[s] = f_order(k.norm + 0.f);
+                    KB[s] = ((unsigned long long)(unsigned)k.i << 52) | ((unsigned long long)f_order(k.l + 0.f) << 20) | (unsigned)(k.v - k.i * V);
+                    ci[s] = k.i; cl[s] = k.l; cv[s] = k.v;
                 }
-                if (s < ns) nvalid += __popcll(__ballot((on >> s) & 1u));
             }
-            const int need = nvalid < beam ? nvalid : beam;
-            if (need > 0) {
-                const unsigned long long T1 = beam_bisect<NS>(K1, on, ns, 38, need);
-                int gt = 0, eq = 0;
-                unsigned tie = 0;
+            const int n = beam_wave_select<2>(KA, KB, ci, cl, cv, on, beam, lane, L, w * 64);
+            if (lane == 0) L.cnt[w] = n;
+        }
+        __syncthreads();
+        if (w == 0) {   // level 2: the survivors (wave s's list = slot s), then the winners' order
+            unsigned KA[4]; unsigned long long KB[4]; int ci[4], cv[4]; float cl[4];
+            unsigned on = 0;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const bool o = (on >> s) & 1u;
-                    if (o && K1[s] == T1) tie |= 1u << s;
-                    if (s < ns) { gt += __popcll(__ballot(o && K1[s] > T1)); eq += __popcll(__ballot((tie >> s) & 1u)); }
+            for (int s = 0; s < 4; ++s) {
+                const bool o = lane < L.cnt[s];
+                const int e = s * 64 + (o ? lane : 0);
+                KA[s] = L.ka[e]; KB[s] = L.kb[e]; ci[s] = L.ci[e]; cl[s] = L.cl[e]; cv[s] = L.cv[e];
+                if (o) on |= 1u << s;
+            }
+            const int need = beam_wave_select<4>(KA, KB, ci, cl, cv, on, beam, lane, L, 256);
+            // (one wave: its LDS writes are ordered before its later LDS reads; keep the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < need) {
+                const unsigned ma = L.ka[256 + lane];
+                const unsigned long long mb = L.kb[256 + lane];
+                int r = 0;
+                for (int q = 0; q < need; ++q) {
+                    const unsigned qa = L.ka[256 + q];
+                    const unsigned long long qb = L.kb[256 + q];
+                    r += (qa > ma || (qa == ma && qb > mb)) ? 1 : 0;
                 }
-                unsigned long long T2 = 0;
-                if (eq > need - gt) T2 = beam_bisect<NS>(K2, tie, ns, 52, need - gt);      // rare: equal normalised scores inside one hypothesis
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                int base = 0;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (s < ns) {
-                        const bool sel = ((on >> s) & 1u) && (K1[s] > T1 || (K1[s] == T1 && K2[s] >= T2));
-                        const unsigned long long m = __ballot(sel);
-                        if (sel) {
-                            const int pos = base + __popcll(m & lt);
-                            L.k1[pos] = K1[s]; L.k2[pos] = K2[s]; L.ci[pos] = ck[s].i; L.cl[pos] = ck[s].l; L.cv[pos] = ck[s].v;
-                        }
-                        base += __popcll(m);
-                    }
-                }
-                // (one wave: its LDS writes are ordered before its later LDS reads; keep the compiler from moving them)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane < need) {
-                    const unsigned long long m1 = L.k1[lane], m2 = L.k2[lane];
-                    int r = 0;
-                    for (int q = 0; q < need; ++q) {
-                        const unsigned long long q1 = L.k1[q], q2 = L.k2[q];
-                        r += (q1 > m1 || (q1 == m1 && q2 > m2)) ? 1 : 0;
-                    }
-                    const BKey k = {0.f, L.ci[lane], L.cl[lane], L.cv[lane]};
-                    L.picks[r] = k;
-                }
+                const BKey k = {0.f, L.ci[256 + lane], L.cl[256 + lane], L.cv[256 + lane]};
+                L.picks[r] = k;
             }
             if (lane == 0) L.count = need;
         }
