@@ -605,6 +605,7 @@ class LAS:
         # everything that does not depend on the encoder goes first, off the chain between the decode loop and its
         # gradient: gradient bucket reset, global token count (one small all-reduce under data parallelism)
         st.flatten()
+        L.begin_step(dev)
         self.speller.rank = self.dp.rank if self.dp is not None else 0
         # ... and on the auxiliary ("chain") stream: a dozen tiny kernels (0.1 ms back to back) that only the Speller and the
         # backward pass need run next to the first Listener sweep instead of in front of it
