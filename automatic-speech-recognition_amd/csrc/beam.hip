@@ -239,7 +239,7 @@ extern "C" int las_beam_step(const float* logits, const float* score, const int*
 // after the last step.
 // ====================================================================================================
 struct BeamLoopDev {
-    const float* logits;            // [nutt, beam, V] raw logits of this step (row = utterance * beam + live slot)
+    float* logits;                  // [nutt, beam, V] raw logits of this step (row = utterance * beam + live slot); written when proj_w is set
     float* score; int* length;      // [nutt, beam] live hypotheses: running float32 sum / tokens after SOS
     int* nlive; int* nsel; int* done;      // [nutt]
     const int* dec_step;            // [nutt] step bound int(audiolen * convert_rate) (las/beam_search.py:78)
@@ -250,7 +250,10 @@ struct BeamLoopDev {
     int* next_token;                // [nutt * beam] out: token entering the next step for each live slot
     int nutt, beam, V, Umax, selcap, start_id, end_id;
     const float* file_in; float* file_out; long long file_n;   // optional per-step record: file_out[t][0..file_n) = file_in[0..file_n) (workgroups >= nutt)
+    // optional vocabulary projection inside the kernel: logits[r] = proj_b + bf16([h0[r] ; h1[r]]) . proj_w (fragments of a [k0 + k1, V] matrix)
+    const float *proj_h0, *proj_h1; int proj_k0, proj_k1; const u16x8_t* proj_w; const float* proj_b;
 };
+constexpr int BEAM_PROJ_TILES = 8;      // (row tiles of 16 hypotheses) x (column tiles of 16 tokens) the in-kernel projection handles
 
 __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
@@ -281,6 +284,50 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     const float* lg = a.logits + (size_t)u * beam * V;
     float* sc = a.score + (size_t)u * beam;
     int* ln = a.length + (size_t)u * beam;
+    if (a.proj_w) {
+        // the step's logits are computed HERE: [beam rows] x [K = k0 + k1] x [V] on the matrix cores (the Speller's output layer and the
+        // LM's, pre-scaled by lm_weight and shifted to its token columns, are one concatenated product) -- the 4 waves split the k-steps,
+        // their partial tiles meet in LDS; the ranking then reads the logits from LDS.  Saves two launches per decode step.
+        __shared__ float red[4][BEAM_PROJ_TILES][64][4];
+        __shared__ float lgs[BEAM_PROJ_TILES * 256];
+        const int lane = tid & 63, w = tid >> 6, g = lane >> 4, r = lane & 15;
+        const int RT = (beam + 15) >> 4, CT = (V + 15) >> 4, KS0 = a.proj_k0 >> 5, KS = KS0 + (a.proj_k1 >> 5);
+        f32x4_t acc[BEAM_PROJ_TILES];
+#pragma unroll
+        for (int i = 0; i < BEAM_PROJ_TILES; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = w; ks < KS; ks += 4) {
+#pragma unroll
+            for (int rt = 0; rt < BEAM_PROJ_TILES; ++rt) {
+                if (rt >= RT) break;
+                const int hr = rt * 16 + r, row = u * beam + (hr < beam ? hr : beam - 1);
+                const float* src = ks < KS0 ? a.proj_h0 + (size_t)row * a.proj_k0 + ks * 32 + g * 8
+                                            : a.proj_h1 + (size_t)row * a.proj_k1 + (ks - KS0) * 32 + g * 8;
+                const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+                const u32x4_t pk = {f2bf2(x0.x, x0.y), f2bf2(x0.z, x0.w), f2bf2(x1.x, x1.y), f2bf2(x1.z, x1.w)};
+                const u16x8_t av = __builtin_bit_cast(u16x8_t, pk);
+#pragma unroll
+                for (int ct = 0; ct < BEAM_PROJ_TILES; ++ct) {
+                    if (rt * CT + ct >= BEAM_PROJ_TILES || ct >= CT) break;
+                    acc[rt * CT + ct] = mfma_bf16_16x16x32(av, a.proj_w[((size_t)ct * KS + ks) * 64 + lane], acc[rt * CT + ct]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BEAM_PROJ_TILES; ++i)
+            if (i < RT * CT) *reinterpret_cast<f32x4_t*>(&red[w][i][lane][0]) = acc[i];
+        __syncthreads();
+        for (int idx = tid; idx < RT * CT * 256; idx += 256) {        // C layout: (row r16, col c16) of a tile sits in lane (r16 / 4) * 16 + c16, register r16 % 4
+            const int tile = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15, l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
+            const int rt = tile / CT, ct = tile - rt * CT, hr = rt * 16 + r16, col = ct * 16 + c16;
+            if (hr < beam && col < V) {
+                const float v = ((red[0][tile][l2][reg] + red[1][tile][l2][reg]) + (red[2][tile][l2][reg] + red[3][tile][l2][reg])) + a.proj_b[col];
+                lgs[hr * V + col] = v;
+                if (a.logits) a.logits[((size_t)u * beam + hr) * V + col] = v;
+            }
+        }
+        __syncthreads();
+        lg = lgs;
+    }
     const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, L);
     if (tid >= 64) return;
     // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
@@ -337,7 +384,7 @@ __global__ void beam_advance_kernel(int* step) { step[0] += 1; }
 
 extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
     LAS_ARG(p, "las_beam_loop_step: null args");
-    LAS_ARG(p->logits && p->score && p->length && p->nlive && p->nsel && p->done && p->dec_step && p->step, "las_beam_loop_step: null state pointer");
+    LAS_ARG(p->score && p->length && p->nlive && p->nsel && p->done && p->dec_step && p->step, "las_beam_loop_step: null state pointer");
     LAS_ARG(p->hist_parent && p->hist_token && p->hist_slot && p->hist_score && p->hist_n && p->sel_t && p->sel_j && p->src_row && p->next_token,
             "las_beam_loop_step: null record pointer");
     LAS_ARG(p->nutt > 0 && p->beam > 0 && p->V > 0 && p->Umax > 0 && p->selcap >= 3 * p->beam, "las_beam_loop_step: bad dims");
@@ -350,6 +397,17 @@ extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
     a.hist_parent = p->hist_parent; a.hist_token = p->hist_token; a.hist_slot = p->hist_slot; a.hist_score = p->hist_score; a.hist_n = p->hist_n;
     a.sel_t = p->sel_t; a.sel_j = p->sel_j; a.src_row = p->src_row; a.next_token = p->next_token;
     a.nutt = p->nutt; a.beam = p->beam; a.V = p->V; a.Umax = p->Umax; a.selcap = p->selcap; a.start_id = p->start_id; a.end_id = p->end_id;
+    a.proj_w = reinterpret_cast<const u16x8_t*>(p->proj_w); a.proj_b = p->proj_b; a.proj_h0 = p->proj_h0; a.proj_h1 = p->proj_h1;
+    a.proj_k0 = p->proj_k0; a.proj_k1 = p->proj_h1 ? p->proj_k1 : 0;
+    if (p->proj_w) {
+        LAS_ARG(p->proj_h0 && p->proj_b && p->proj_k0 > 0 && (p->proj_k0 % 32) == 0 && (a.proj_k1 % 32) == 0,
+                "las_beam_loop_step: proj_w needs proj_h0, proj_b and row widths that are multiples of 32");
+        LAS_ARG(((p->beam + 15) / 16) * ((p->V + 15) / 16) <= BEAM_PROJ_TILES && p->beam * p->V <= BEAM_PROJ_TILES * 256,
+                "las_beam_loop_step: the in-kernel projection handles ceil(beam / 16) * ceil(V / 16) <= %d tiles (beam %d, V %d)", BEAM_PROJ_TILES, p->beam, p->V);
+        LAS_ARG((((uintptr_t)p->proj_h0 | (uintptr_t)p->proj_h1) & 15) == 0, "las_beam_loop_step: proj_h0 / proj_h1 must be 16-byte aligned");
+    } else {
+        LAS_ARG(p->logits, "las_beam_loop_step: null logits (and no projection)");
+    }
     a.file_in = p->file_in; a.file_out = p->file_out; a.file_n = (long long)p->nutt * p->beam * p->file_width;
     int nfile = 0;
     if (p->file_in) {

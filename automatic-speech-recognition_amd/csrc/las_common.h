@@ -164,3 +164,19 @@ int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, i
 int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
                          const float* bias, hipStream_t st);
 bool las_skinny_ok(int M, int K, int N, int lda, const void* A);
+
+// ---- one LSTM cell step for a block of rows in one launch (loss_opt.hip, C entry las_lstm_cell_rows): z = [x ; h] . kernel + bias from
+// las_skinny_pack fragments (Wx: [I, 4H], Wh: [H, 4H]; either part may be absent), TF gate order i, j, f, o, then the gate math.
+// x fp32 or bf16 (x_bf16); one-hot input: x = NULL + ids / id_shift / xrows.  fast: the Speller's approximated transcendentals;
+// gates_out (optional [M, 4H]): the ACTIVATED gates, as the Speller's backward pass reads them.
+struct LstmCellLaunch {
+    const void* x; int x_bf16, ldx, I;
+    const int* ids; int id_shift; const float* xrows;
+    const float* h; int ldh;
+    const void *Wx, *Wh;
+    const float *bias, *c_prev;
+    float fb;
+    float *c_out, *h_out, *gates_out;
+    int M, H, fast;
+};
+int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st);

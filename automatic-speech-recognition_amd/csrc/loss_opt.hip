@@ -237,19 +237,11 @@ extern "C" int las_lstm_pointwise_rows(const float* z, const float* xrows, const
 // TF gate order i, j, f, o = column blocks of H), K = I + H contracted in chunks staged through LDS as bf16, 8 waves = 4 gates x
 // 2 row tiles, gates exchanged through LDS, then c' / h' written directly.  A one-hot first layer passes ids / xrows instead of x.
 // ------------------------------------------------------------------------------------------------
-struct LstmCellDev {
-    const float* x; int ldx, I;
-    const int* ids; int id_shift; const float* xrows;
-    const float* h; int ldh;
-    const u16x8_t *Wx, *Wh;
-    const float *bias, *c_prev;
-    float fb;
-    float *c_out, *h_out;
-    int M, H;
-};
 constexpr int LC_KC = 512, LC_LD = LC_KC + 8;      // K chunk staged per pass; LDS row stride in bf16 (16-byte reads of 16 rows hit 64 distinct banks)
 
-__global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellDev a) {
+// FAST: the Speller's approximated transcendentals (its cell in a beam-search step, see las_common.h); XBF: x is already bf16
+template <bool FAST, bool XBF>
+__global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellLaunch a) {
     __shared__ __attribute__((aligned(16))) unsigned short As[32 * LC_LD];
     __shared__ float gates[2][4][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
@@ -258,10 +250,11 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellDev a) {
     const int H = a.H, ct = gt * (H >> 4) + ub;                      // this wave's column tile of the [K, 4H] kernel
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     for (int part = 0; part < 2; ++part) {
-        const float* src = part ? a.h : a.x;
+        const void* src = part ? (const void*)a.h : a.x;
         if (!src) continue;
+        const bool sbf = XBF && part == 0;
         const int ld = part ? a.ldh : a.ldx, Kp = part ? H : a.I, KS = Kp >> 5;
-        const u16x8_t* bp = (part ? a.Wh : a.Wx) + (size_t)ct * KS * 64 + lane;
+        const u16x8_t* bp = reinterpret_cast<const u16x8_t*>(part ? a.Wh : a.Wx) + (size_t)ct * KS * 64 + lane;
         for (int k0 = 0; k0 < Kp; k0 += LC_KC) {
             const int kc = min(LC_KC, Kp - k0), nks = kc >> 5;
             // this chunk's weight fragments first (16 KB per wave at most, all in flight), then the rows
@@ -269,12 +262,21 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellDev a) {
 #pragma unroll
             for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bp[(size_t)min((k0 >> 5) + u, KS - 1) * 64];
             __syncthreads();                                          // the previous chunk's readers are done
-            for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
-                const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
-                const int row = min(row0 + r, a.M - 1);
-                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + k0 + q * 4);
-                uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
-                *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+            if (sbf) {
+                for (int idx = tid; idx < 32 * (kc >> 3); idx += 512) {
+                    const int r = idx / (kc >> 3), q = idx - r * (kc >> 3);
+                    const int row = min(row0 + r, a.M - 1);
+                    *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
+                        *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                }
+            } else {
+                for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
+                    const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
+                    const int row = min(row0 + r, a.M - 1);
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
+                    uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+                    *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+                }
             }
             __syncthreads();
             const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
@@ -300,28 +302,44 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellDev a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) z[g] += xr[g * H];
     }
-    const float gi = sigmoid_acc(z[0]), gj = tanh_acc(z[1]), gf = sigmoid_acc(z[2] + a.fb), go = sigmoid_acc(z[3]);
+    const float gi = sigm<FAST>(z[0]), gj = tanhx<FAST>(z[1]), gf = sigm<FAST>(z[2] + a.fb), go = sigm<FAST>(z[3]);
     const size_t o = (size_t)row * H + unit;
     const float cn = a.c_prev[o] * gf + gi * gj;
     a.c_out[o] = cn;
-    a.h_out[o] = tanh_acc(cn) * go;
+    a.h_out[o] = tanhx<FAST>(cn) * go;
+    if (a.gates_out) {                                   // the activated gates, as the Speller's backward pass reads them
+        float* gp = a.gates_out + (size_t)row * 4 * H + unit;
+        gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+    }
+}
+
+int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
+    LAS_ARG((a.x || a.h) && a.bias && a.c_prev && a.c_out && a.h_out && a.M > 0 && a.H > 0, "las_lstm_cell_rows: bad arguments");
+    LAS_ARG(!(a.x && a.xrows), "las_lstm_cell_rows: x (dense input rows) and xrows (one-hot input) are exclusive");
+    LAS_ARG(!a.x || (a.Wx && a.I > 0 && (a.I % 32) == 0 && (a.ldx % (a.x_bf16 ? 8 : 4)) == 0 && (((uintptr_t)a.x) & 15) == 0),
+            "las_lstm_cell_rows: x needs I %% 32 == 0, ldx %% 4 == 0 (8 for bf16), 16-byte alignment and Wx_packed");
+    LAS_ARG(!a.xrows || a.ids, "las_lstm_cell_rows: xrows without ids");
+    LAS_ARG(!a.h || (a.Wh && (a.ldh % 4) == 0 && (((uintptr_t)a.h) & 15) == 0), "las_lstm_cell_rows: h needs ldh %% 4 == 0, 16-byte alignment and Wh_packed");
+    LAS_ARG((a.H % 32) == 0, "las_lstm_cell_rows: needs H %% 32 == 0");
+    const dim3 grid(a.H / 16, cdiv(a.M, 32));
+    if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_kernel<true, true>), grid, dim3(512), 0, st, a);
+    else if (a.fast)        hipLaunchKernelGGL((lstm_cell_rows_kernel<true, false>), grid, dim3(512), 0, st, a);
+    else if (a.x_bf16)      hipLaunchKernelGGL((lstm_cell_rows_kernel<false, true>), grid, dim3(512), 0, st, a);
+    else                    hipLaunchKernelGGL((lstm_cell_rows_kernel<false, false>), grid, dim3(512), 0, st, a);
+    LAS_LAUNCHED();
+    return 0;
 }
 
 extern "C" int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids, int id_shift, const float* xrows, const float* h, int ldh,
                                   const void* Wx_packed, const void* Wh_packed, const float* bias, const float* c_prev, int M, int H,
                                   float forget_bias, float* c_out, float* h_out, void* stream) {
-    LAS_ARG(h && Wh_packed && bias && c_prev && c_out && h_out && M > 0 && H > 0, "las_lstm_cell_rows: bad arguments");
+    LAS_ARG(h && Wh_packed, "las_lstm_cell_rows: h and Wh_packed are required");
     LAS_ARG((x != nullptr) != (xrows != nullptr), "las_lstm_cell_rows: exactly one of x (dense input rows) and xrows (one-hot input) must be given");
-    LAS_ARG(!x || (Wx_packed && I > 0 && (I % 32) == 0 && (ldx % 4) == 0 && (((uintptr_t)x) & 15) == 0), "las_lstm_cell_rows: x needs I %% 32 == 0, ldx %% 4 == 0, 16-byte alignment and Wx_packed");
-    LAS_ARG(!xrows || ids, "las_lstm_cell_rows: xrows without ids");
-    LAS_ARG((H % 32) == 0 && (ldh % 4) == 0 && (((uintptr_t)h) & 15) == 0, "las_lstm_cell_rows: needs H %% 32 == 0, ldh %% 4 == 0, h 16-byte aligned");
-    LstmCellDev a;
-    a.x = x; a.ldx = ldx; a.I = x ? I : 0; a.ids = ids; a.id_shift = id_shift; a.xrows = xrows; a.h = h; a.ldh = ldh;
-    a.Wx = reinterpret_cast<const u16x8_t*>(Wx_packed); a.Wh = reinterpret_cast<const u16x8_t*>(Wh_packed);
-    a.bias = bias; a.c_prev = c_prev; a.fb = forget_bias; a.c_out = c_out; a.h_out = h_out; a.M = M; a.H = H;
-    hipLaunchKernelGGL(lstm_cell_rows_kernel, dim3(H / 16, cdiv(M, 32)), dim3(512), 0, (hipStream_t)stream, a);
-    LAS_LAUNCHED();
-    return 0;
+    LstmCellLaunch a;
+    a.x = x; a.x_bf16 = 0; a.ldx = ldx; a.I = x ? I : 0; a.ids = ids; a.id_shift = id_shift; a.xrows = xrows; a.h = h; a.ldh = ldh;
+    a.Wx = Wx_packed; a.Wh = Wh_packed; a.bias = bias; a.c_prev = c_prev; a.fb = forget_bias; a.c_out = c_out; a.h_out = h_out;
+    a.gates_out = nullptr; a.M = M; a.H = H; a.fast = 0;
+    return las_lstm_cell_rows_launch(a, (hipStream_t)stream);
 }
 
 

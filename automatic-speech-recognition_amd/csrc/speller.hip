@@ -2531,6 +2531,9 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     const bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
+    if (d.flags & LAS_SPELLER_NO_LOGITS)
+        LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
+                "speller: LAS_SPELLER_NO_LOGITS needs U = 1, one LSTM layer, speed mode with the prefetching row kernels, D and E + Hd + D multiples of 32");
     if (loop) {   // the whole loop in one launch
         const size_t lds_pr = (size_t)RNW * LOOP_TPW_F * 1024;       // the product workgroups' partial tiles (80 KB)
         const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
@@ -2558,6 +2561,14 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         else                            hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, false>), dim3(B), dim3(RNT), lds, st, d, t);
         LAS_LAUNCHED();
         if (t == U) break;
+        if (d.flags & LAS_SPELLER_NO_LOGITS) {   // beam-search step: the cell (product + gate math) in one launch, no projection
+            LstmCellLaunch c;
+            c.x = d.xbf; c.x_bf16 = 1; c.ldx = I0D; c.I = I0D; c.ids = nullptr; c.id_shift = 0; c.xrows = nullptr; c.h = nullptr; c.ldh = 0;
+            c.Wx = packF; c.Wh = nullptr; c.bias = f->cellb[0]; c.c_prev = d.cs; c.fb = d.fb;
+            c.c_out = d.cs + (size_t)B * D; c.h_out = d.hs + (size_t)B * D; c.gates_out = d.gates; c.M = B; c.H = D; c.fast = 1;
+            if (int rc = las_lstm_cell_rows_launch(c, st)) return rc;
+            break;
+        }
         if (skinny) {
             GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD, f->cellb[0], st));
         } else {

@@ -42,7 +42,8 @@ class BeamLoopArgs(Structure):
                                         "sel_t", "sel_j", "src_row", "next_token")] + \
                [(n, c_int) for n in ("nutt", "beam", "V", "Umax", "selcap", "topn", "start_id", "end_id", "ntens")] + \
                [("state_in", c_void_p * 16), ("state_out", c_void_p * 16), ("state_width", c_int * 16)] + \
-               [("file_in", c_void_p), ("file_out", c_void_p), ("file_width", c_int)]
+               [("file_in", c_void_p), ("file_out", c_void_p), ("file_width", c_int)] + \
+               [("proj_h0", c_void_p), ("proj_k0", c_int), ("proj_h1", c_void_p), ("proj_k1", c_int), ("proj_w", c_void_p), ("proj_b", c_void_p)]
 
 
 class SpellerBwdArgs(Structure):
@@ -494,7 +495,7 @@ class _timed:
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS = 1, 2, 4, 8, 16
-SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP = 1, 2, 4, 8
+SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS = 1, 2, 4, 8, 16
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
                  "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_XPROJ_CHUNK=0)",

@@ -79,6 +79,7 @@ class BeamSearch(object):
             self.lm = language_model
         self._las = las
         self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
+        self.fuse_projection = os.environ.get("LAS_NO_DECODE_FUSED_PROJ") != "1"   # decode_batch: cell in one launch, projection inside the beam kernel
         self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
         self.last_timing = None
 
@@ -240,11 +241,41 @@ class BeamSearch(object):
         ba.file_in, ba.file_out, ba.file_width = alphas_cur.data_ptr(), alphas_hist.data_ptr(), Tp
         held = []
 
+        mode = {"fused": False}
+
         def speller_part():
-            _hip.check(lib.las_speller_fwd(ctypes.byref(fa), _hip.stream()), "las_speller_fwd")
+            rc = lib.las_speller_fwd(ctypes.byref(fa), _hip.stream())
+            if rc < 0 and mode["fused"] and not (fa.flags & _hip.SPELLER_REUSE_PREP):
+                # the library refuses the short form for this geometry (it needs its prefetching row kernels): the long form it is
+                mode["fused"] = False
+                fa.flags &= ~_hip.SPELLER_NO_LOGITS
+                ba.proj_w = None
+                rc = lib.las_speller_fwd(ctypes.byref(fa), _hip.stream())
+            _hip.check(rc, "las_speller_fwd")
             fa.flags |= _hip.SPELLER_REUSE_PREP      # enc / keys / weights are fixed for the search: their bf16 copies are made once
 
         lm_plan = lm.fusion_plan(lm_w) if lm is not None else None
+        # ---- the short form of a step (speed mode, one LSTM layer): the Speller call stops after its cell (LAS_SPELLER_NO_LOGITS: attention
+        # rows + ONE cell launch) and the vocabulary projection -- the Speller's output layer and, concatenated along K, the LM's softmax
+        # layer scaled by lm_weight and shifted to its token columns -- happens inside las_beam_loop_step: 5 launches per step instead of 8
+        E_ = a.embedding_size
+        fused_proj = (prec == _hip.PREC_BF16 and lstm and NL == 1 and self.fuse_projection and D % 32 == 0 and (E_ + Hd + D) % 32 == 0 and
+                      ((beam + 15) // 16) * ((V_ + 15) // 16) <= 8 and (lm is None or (lm.hidden_size % 32 == 0 and "packs" in lm_plan)))
+        proj_keep = None
+        mode["fused"] = fused_proj
+        if fused_proj:
+            Wcat, bcat = Pd["Wv"].contiguous(), Pd["bv"].clone()
+            if lm is not None:
+                Wl = torch.zeros(lm.hidden_size, V_, device=dev)
+                Wl[:, 2:2 + lm.vocab_size] = lm_plan["sw"]
+                bcat[2:2 + lm.vocab_size] += lm_plan["sb"]
+                Wcat = torch.cat([Wcat, Wl], 0)
+            Wcat = Wcat.contiguous()
+            proj_keep = (_hip.skinny_pack(Wcat, Wcat.shape[0], V_), bcat.contiguous())
+            fa.flags |= _hip.SPELLER_NO_LOGITS
+            ba.proj_w, ba.proj_b = proj_keep[0].data_ptr(), proj_keep[1].data_ptr()
+            ba.proj_h0, ba.proj_k0 = bufs["hs"][NL - 1, 1].data_ptr(), D
+            ba.proj_h1, ba.proj_k1 = None, (lm.hidden_size if lm is not None else 0)
 
         def lm_cells():
             # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
@@ -252,11 +283,14 @@ class BeamSearch(object):
             cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False)
             for l in range(NLl):
                 ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
+            if mode["fused"]:
+                ba.proj_h1 = hs_new[-1].data_ptr()
             held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued
 
         def lm_part():
             lm_cells()
-            lm.project_fused(lm_plan, held[1][-1], logits, 2)
+            if not mode["fused"]:
+                lm.project_fused(lm_plan, held[1][-1], logits, 2)
 
         def beam_part():                                 # files alphas_cur under the device step counter, prunes, gathers, advances the counter
             _hip.check(lib.las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")

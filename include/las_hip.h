@@ -229,6 +229,10 @@ enum { LAS_SPELLER_NO_PF_ROWS = 1,    /* speed mode without the fully prefetchin
        LAS_SPELLER_REUSE_PREP = 8 };    /* (las_speller_bwd: operand copies only) the workspace still holds the bf16 copies of enc / keys / Ws and the
                                            packed cell weights that an earlier call made from the SAME tensors -- skip rebuilding
                                            them (beam search calls the step U = 1 at a time against a fixed encoder output) */
+enum { LAS_SPELLER_NO_LOGITS = 16 };    /* (las_speller_fwd, U = 1, speed mode, one LSTM layer, D and E + Hd + D multiples of 32) the beam search's step:
+                                           attention row kernel, then the cell in ONE launch (product + gate math: hs / cs slot 1 and the activated
+                                           gates); NO vocabulary projection, logits / tokens_out are left alone -- the caller projects inside
+                                           las_beam_loop_step (proj_*) */
 #define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
@@ -386,6 +390,7 @@ int las_beam_step(const float* logits, const float* score, const int* length, co
  *   - src_row [nutt,beam] (global row the new live slot continues) and next_token [nutt*beam] for the next step, and
  *     the `ntens` recurrent-state tensors gathered accordingly: state_out[k][row] = state_in[k][src_row[row]]
  *     (state_width[k] floats per row; decoder h/c, previous alignment, LM states);
+ *   - optionally the logits themselves are computed by the call (proj_*, below) instead of being read;
  *   - optionally a per-step record of one row tensor (the step's alignments): file_out[t][r] = file_in[r] for the nutt*beam rows of
  *     file_width floats (file_in NULL = none);
  *   - finally *step += 1 (device-resident step counter: the launch sequence is identical every step, hipGraph friendly).
@@ -393,12 +398,18 @@ int las_beam_step(const float* logits, const float* score, const int* length, co
  * next_token = start_id).  The host reads the records once after the last step and rebuilds token ids by back-tracking.
  */
 typedef struct {
-    const float* logits; float* score; int* length; int* nlive; int* nsel; int* done; const int* dec_step; int* step;
+    float* logits; float* score; int* length; int* nlive; int* nsel; int* done; const int* dec_step; int* step;
     int *hist_parent, *hist_token, *hist_slot; float* hist_score; int* hist_n;
     int *sel_t, *sel_j; int* src_row; int* next_token;
     int nutt, beam, V, Umax, selcap, topn, start_id, end_id;
     int ntens; const float* state_in[16]; float* state_out[16]; int state_width[16];
     const float* file_in; float* file_out; int file_width;
+    /* optional: the vocabulary projection inside the step (two launches less per decode step): with proj_w != NULL
+     * logits[row] = proj_b + bf16([proj_h0[row] ; proj_h1[row]]) . proj_w, proj_w = las_gemm_skinny_pack fragments of a [proj_k0 + proj_k1, V]
+     * matrix (the Speller's output kernel on top of the LM's softmax kernel, pre-scaled by lm_weight and shifted to its token columns;
+     * proj_h1 NULL = no second part), proj_h0 / proj_h1 fp32 [nutt*beam, proj_k0 / proj_k1] (multiples of 32), fp32 accumulation.
+     * ceil(beam/16) * ceil(V/16) <= 8.  `logits` (may be NULL then) additionally receives the values. */
+    const float* proj_h0; int proj_k0; const float* proj_h1; int proj_k1; const void* proj_w; const float* proj_b;
 } las_beam_loop_args;
 int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
 /* After the last step: walk the back-pointer records of every retired hypothesis on the device (the reference carries whole token

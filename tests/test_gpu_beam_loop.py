@@ -198,3 +198,56 @@ def test_beam16_with_2x512_char_rnnlm_matches_oracle():
         assert [b.token_ids for b in res] == [b.token_ids for b in ref]
         for a, b in zip(res, ref):
             assert float(a.log_prob) == pytest.approx(float(b.log_prob), abs=5e-3)
+
+
+@pytest.mark.parametrize("nutt,beam,V,k0,k1", [(3, 16, 30, 512, 512), (2, 4, 7, 64, 0), (2, 33, 30, 96, 32), (1, 16, 128, 64, 64)])
+def test_projection_inside_the_beam_step_equals_projecting_first(nutt, beam, V, k0, k1):
+    """las_beam_loop_step with proj_*: the logits it computes itself (bf16 operands, fp32 accumulation, written to `logits`) against torch,
+    and its records against a second call from the same state that is GIVEN those logits."""
+    import ctypes
+    from las import _hip
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(nutt * 100 + beam + V)
+    N, Umax, selcap = nutt * beam, 4, 3 * beam
+    h0 = torch.randn(N, k0, generator=g).to(dev)
+    h1 = torch.randn(N, k1, generator=g).to(dev) if k1 else None
+    W = (torch.randn(k0 + k1, V, generator=g) * 0.2).to(dev)
+    b = torch.randn(V, generator=g).to(dev)
+    packed = _hip.skinny_pack(W, k0 + k1, V)
+    rnd = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ref = rnd(h0).double() @ rnd(W[:k0]).double() + b.double()
+    if k1:
+        ref = ref + rnd(h1).double() @ rnd(W[k0:]).double()
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    def state():
+        return dict(logits=torch.zeros(nutt, beam, V, device=dev), score=torch.zeros(nutt, beam, device=dev), length=torch.zeros(nutt, beam, **i32),
+                    nlive=torch.full((nutt,), beam, **i32), nsel=torch.zeros(nutt, **i32), done=torch.zeros(nutt, **i32),
+                    dec_step=torch.full((nutt,), Umax, **i32), step=torch.ones(1, **i32),           # t = 1: every live hypothesis expands
+                    hist_parent=torch.zeros(Umax, nutt, beam, **i32), hist_token=torch.zeros(Umax, nutt, beam, **i32),
+                    hist_slot=torch.zeros(Umax, nutt, beam, **i32), hist_score=torch.zeros(Umax, nutt, beam, device=dev),
+                    hist_n=torch.zeros(Umax, nutt, **i32), sel_t=torch.zeros(nutt, selcap, **i32), sel_j=torch.zeros(nutt, selcap, **i32),
+                    src_row=torch.zeros(nutt, beam, **i32), next_token=torch.full((N,), 1, **i32))
+
+    def run(T, proj):
+        ba = _hip.BeamLoopArgs()
+        for k, t in T.items():
+            setattr(ba, k, t.data_ptr())
+        ba.nutt, ba.beam, ba.V, ba.Umax, ba.selcap, ba.topn, ba.start_id, ba.end_id, ba.ntens = nutt, beam, V, Umax, selcap, 64, 1, 2, 0
+        if proj:
+            ba.proj_h0, ba.proj_k0, ba.proj_h1, ba.proj_k1 = h0.data_ptr(), k0, (h1.data_ptr() if k1 else None), k1
+            ba.proj_w, ba.proj_b = packed.data_ptr(), b.data_ptr()
+        _hip.check(_hip.lib().las_beam_loop_step(ctypes.byref(ba), _hip.stream()), "las_beam_loop_step")
+        torch.cuda.synchronize()
+
+    T1 = state()
+    run(T1, True)
+    got = T1["logits"].reshape(N, V)
+    assert (got.double() - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+    T2 = state()
+    T2["logits"].copy_(T1["logits"])
+    run(T2, False)
+    for k in ("score", "length", "nlive", "nsel", "done", "hist_parent", "hist_token", "hist_slot", "hist_score", "hist_n", "sel_t", "sel_j",
+              "src_row", "next_token", "step"):
+        assert torch.equal(T1[k], T2[k]), k
+    assert int(T1["hist_n"][1].min()) == min(beam, beam * (V - 1))
