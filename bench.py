@@ -232,13 +232,13 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     if parts:
         dom = max(parts, key=parts.get)
         byts = {"speller": sp_bytes, "lm": lm_bytes}.get(dom, 0)
-        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> + skinny_rows_kernel + dec_step_fwd_bf_kernel (cell finish + logits); 256 rows: per-step kernels",
-                                                          "lm": "skinny_rows_kernel x4 (las_gemm_skinny) + lstm_pointwise_kernel x2 + index_select / add",
-                                                          "beam": "beam_loop_kernel + beam_gather_kernel + beam_advance_kernel"}[dom],
+        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> (attention rows) + lstm_cell_rows_kernel<fast, bf16 x> (cell product + gate math); 256 rows",
+                                                          "lm": "lstm_cell_rows_kernel x2 (las_lstm_cell_rows: one launch per LM layer)",
+                                                          "beam": "beam_loop_kernel (both vocabulary projections + ranking + bookkeeping + alignment filing) + beam_gather_kernel"}[dom],
                 "us_per_decode_step": parts[dom], "algorithmic_bytes_per_step": int(byts),
                 "achieved": round(byts / (parts[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(byts / (parts[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "latency-bound: one decode step is a chain of ~25 dependent small kernels over %d rows" % N}
+                "note": "latency-bound: one decode step is a chain of 5 dependent launches over %d rows (8-13 us each in the replayed graph)" % N}
     return {"value": round(nutt / dt, 2), "unit": "utterances/s", "beam": beam, "lm": "2x512 char RNNLM, lm_weight 0.5",
             "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 3),
             "us_per_decode_step": round((tm.get("searched", 0.0)) / max(tm.get("steps", 1), 1) * 1e6, 1) if tm else None,
