@@ -295,6 +295,30 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         f32x4_t acc[BEAM_PROJ_TILES];
 #pragma unroll
         for (int i = 0; i < BEAM_PROJ_TILES; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (RT == 1 && CT <= 2 && KS <= 32) {
+            // the usual geometry (beam <= 16, a char vocabulary, K <= 1024): every operand of this wave's <= 8 k-steps is requested
+            // before the first product (a loop with one round trip to L2 per k-step was 8 us of this kernel)
+            const int hr = r < beam ? r : beam - 1, row = u * beam + hr;
+            float4 xa[8][2]; u16x8_t bw[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ks = w + 4 * j, kc = ks < KS ? ks : KS - 1;
+                const float* src = kc < KS0 ? a.proj_h0 + (size_t)row * a.proj_k0 + kc * 32 + g * 8
+                                            : a.proj_h1 + (size_t)row * a.proj_k1 + (kc - KS0) * 32 + g * 8;
+                xa[j][0] = *reinterpret_cast<const float4*>(src); xa[j][1] = *reinterpret_cast<const float4*>(src + 4);
+                bw[j][0] = a.proj_w[(size_t)kc * 64 + lane];
+                bw[j][1] = a.proj_w[((size_t)(CT > 1 ? KS : 0) + kc) * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (w + 4 * j < KS) {
+                    const u32x4_t pk = {f2bf2(xa[j][0].x, xa[j][0].y), f2bf2(xa[j][0].z, xa[j][0].w), f2bf2(xa[j][1].x, xa[j][1].y), f2bf2(xa[j][1].z, xa[j][1].w)};
+                    const u16x8_t av = __builtin_bit_cast(u16x8_t, pk);
+                    acc[0] = mfma_bf16_16x16x32(av, bw[j][0], acc[0]);
+                    if (CT > 1) acc[1] = mfma_bf16_16x16x32(av, bw[j][1], acc[1]);
+                }
+            }
+        } else
         for (int ks = w; ks < KS; ks += 4) {
 #pragma unroll
             for (int rt = 0; rt < BEAM_PROJ_TILES; ++rt) {

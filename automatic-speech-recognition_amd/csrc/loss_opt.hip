@@ -249,40 +249,92 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellLaunch a) {
     const int ub = blockIdx.x, row0 = blockIdx.y * 32;
     const int H = a.H, ct = gt * (H >> 4) + ub;                      // this wave's column tile of the [K, 4H] kernel
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (int part = 0; part < 2; ++part) {
-        const void* src = part ? (const void*)a.h : a.x;
-        if (!src) continue;
-        const bool sbf = XBF && part == 0;
-        const int ld = part ? a.ldh : a.ldx, Kp = part ? H : a.I, KS = Kp >> 5;
-        const u16x8_t* bp = reinterpret_cast<const u16x8_t*>(part ? a.Wh : a.Wx) + (size_t)ct * KS * 64 + lane;
-        for (int k0 = 0; k0 < Kp; k0 += LC_KC) {
-            const int kc = min(LC_KC, Kp - k0), nks = kc >> 5;
-            // this chunk's weight fragments first (16 KB per wave at most, all in flight), then the rows
-            u16x8_t bv[LC_KC / 32];
+    // K = [x ; h] in chunks of <= LC_KC that do not straddle the two parts.  Software pipeline: while chunk c is multiplied, the weight
+    // fragments and the rows of chunk c + 1 are already on their way (one round trip to L2 / HBM per chunk was ~1.5 us of a 3-chunk call)
+    const int KSx = a.x ? a.I >> 5 : 0, KSh = a.h ? H >> 5 : 0;
+    const int ncx = (KSx + 15) >> 4, nch = ncx + ((KSh + 15) >> 4);
+    u16x8_t bv[LC_KC / 32], bn[LC_KC / 32];
+    float4 ra[8];                                                     // fp32 rows: 32 x 512 floats / 512 threads; bf16 rows use ra[0..3] as uint4
+    auto chunk = [&](const int ci, const void*& src, int& ld, int& k0, int& kc, const u16x8_t*& bp, bool& sbf) {
+        const bool hp = ci >= ncx;
+        const int cj = hp ? ci - ncx : ci, Kp = hp ? H : a.I, KS = Kp >> 5;
+        src = hp ? (const void*)a.h : a.x; ld = hp ? a.ldh : a.ldx; k0 = cj * LC_KC; kc = min(LC_KC, Kp - k0);
+        bp = reinterpret_cast<const u16x8_t*>(hp ? a.Wh : a.Wx) + ((size_t)ct * KS + (k0 >> 5)) * 64 + lane;
+        sbf = XBF && !hp;
+    };
+    auto load_b = [&](const int ci, u16x8_t (&dst)[LC_KC / 32]) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        const int nks = kc >> 5;
 #pragma unroll
-            for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bp[(size_t)min((k0 >> 5) + u, KS - 1) * 64];
-            __syncthreads();                                          // the previous chunk's readers are done
-            if (sbf) {
-                for (int idx = tid; idx < 32 * (kc >> 3); idx += 512) {
-                    const int r = idx / (kc >> 3), q = idx - r * (kc >> 3);
-                    const int row = min(row0 + r, a.M - 1);
+        for (int u = 0; u < LC_KC / 32; ++u) dst[u] = bp[(size_t)(u < nks ? u : nks - 1) * 64];
+    };
+    auto load_a = [&](const int ci) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        if (sbf) {
+            const int per = kc >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
+                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        } else {
+            const int per = kc >> 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
+                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
+            }
+        }
+    };
+    auto store_a = [&](const int ci) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        if (sbf) {
+            const int per = kc >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = tid + j * 512;
+                if (idx < 32 * per) {
+                    const int r = idx / per, q = idx - r * per;
                     *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
-                        *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                        make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
                 }
-            } else {
-                for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
-                    const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
-                    const int row = min(row0 + r, a.M - 1);
-                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
-                    uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+            }
+        } else {
+            const int per = kc >> 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + j * 512;
+                if (idx < 32 * per) {
+                    const int r = idx / per, q = idx - r * per;
+                    uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
                     *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
                 }
             }
-            __syncthreads();
-            const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
+        }
+    };
+    load_b(0, bv);
+    load_a(0);
+    for (int ci = 0; ci < nch; ++ci) {
+        __syncthreads();                                              // the previous chunk's readers are done
+        store_a(ci);
+        if (ci + 1 < nch) { load_b(ci + 1, bn); load_a(ci + 1); }
+        __syncthreads();
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        const int nks = kc >> 5;
+        const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
 #pragma unroll
-            for (int u = 0; u < LC_KC / 32; ++u)
-                if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
+        for (int u = 0; u < LC_KC / 32; ++u)
+            if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
+        if (ci + 1 < nch) {
+#pragma unroll
+            for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bn[u];
         }
     }
 #pragma unroll
