@@ -234,7 +234,7 @@ class BeamSearch(object):
         mark("encoded")
         # the step's alignments land in a fixed buffer and are filed under the DEVICE step counter, so that one step is the
         # same sequence of launches with the same arguments every time: it is captured into a HIP graph after the first
-        # (eager) step and replayed -- the loop is bound by the host's launch rate otherwise (~25 launches per step)
+        # (eager) step and replayed -- the loop is bound by the host's launch rate otherwise (5-8 launches and their Python glue per step)
         alphas_cur = torch.zeros(N, Tp, device=dev)
         fa.alphas = alphas_cur.data_ptr()
         ba.state_in[k_align] = alphas_cur.data_ptr()
