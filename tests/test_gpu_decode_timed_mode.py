@@ -49,7 +49,7 @@ def _norm(b):
 
 def test_bf16_beam16_lm_eight_utterances_match_the_bf16_oracle_and_graph_equals_eager():
     args, p0, plm, bs, utts = _setup("bf16")
-    assert NUTT * BEAM >= 128                            # per-step row kernels + skinny products (the loop kernel serves B <= 128 rows of U > 1)
+    assert NUTT * BEAM >= 128                            # the row count of a search step (per-step kernels, not the one-launch training loop)
     bs.use_graph = True
     got = bs.decode_batch(None, utts)
     bs.use_graph = False
@@ -58,6 +58,17 @@ def test_bf16_beam16_lm_eight_utterances_match_the_bf16_oracle_and_graph_equals_
         assert [b.token_ids for b in g] == [b.token_ids for b in e]
         assert [float(b.log_prob) for b in g] == [float(b.log_prob) for b in e]
         assert torch.equal(g[-1].att[-1], e[-1].att[-1])
+    # the 5-launch step (Speller cell in one launch, both vocabulary projections inside the beam kernel -- the default, what `got` ran)
+    # against the 8-launch step (skinny cell product + finishing kernel with its own logits, LM projection as a GEMM on top)
+    assert bs.fuse_projection
+    bs.fuse_projection = False
+    long_form = bs.decode_batch(None, utts)
+    bs.fuse_projection = True
+    agree = 0
+    for g, l in zip(got, long_form):
+        assert abs(_norm(g[-1]) - _norm(l[-1])) <= 2e-3
+        agree += g[-1].token_ids == l[-1].token_ids
+    assert agree >= NUTT - 1
     olm = (oracle_lm(plm, 0, 2), 512, 2)
     same, worst = 0, 0.0
     for u, (xs, res) in enumerate(zip(utts, got)):
