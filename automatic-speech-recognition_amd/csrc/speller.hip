@@ -2447,6 +2447,7 @@ static bool loc_loop_ok(const DecDev& d, int G) {
     const int GD = G * d.D, I0D = d.E + d.Hd + d.D;
     return d.mode == LAS_ATT_LOC && !(d.flags & (LAS_SPELLER_NO_PF_ROWS | LAS_SPELLER_NO_BF_ROWS | LAS_SPELLER_NO_FUSED_STEP)) &&
            pf_geom_ok(d) && (d.A % 32) == 0 && d.C >= 1 && d.C <= 10 && d.Kc * d.C <= 4096 && cdiv(d.Tp, 8) <= RNG &&
+           cdiv(d.Tp, 16) <= RNW && bf_lds_bytes(d) <= 128 * 1024 &&     // the MFMA convs: one wave per 16-frame tile; the row state in LDS
            loop_geom_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F) && loop_geom_ok(d, d.Hd + d.D, GD, LOOP_TPW_B, LOOP_KW_B);
 }
 static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {

@@ -63,7 +63,14 @@ def loc_loop_eligible(args, B, Tp, U, cell="lstm", cus=256):
     def loop(ncols, K, tpw, kw):
         return (U >= 4 and E % 4 == 0 and D % 4 == 0 and Hd % 4 == 0 and I0D % 8 == 0 and K % 8 == 0 and R <= 16 and pn >= 1
                 and pn + R <= 32 and pn * tpw >= cd(ncols, 16) and 16 * kw >= cd(K, 32))
-    return bool(geom and I0D % 8 == 0 and GD % 8 == 0 and B <= 1024 and loop(GD, I0D, 5, 3) and loop(Hd + D, GD, 3, 4))
+    # the MFMA convs: (channel, u step) pairs of the transposed conv per wave, frame tiles per wave, and the row state in 128 KB of LDS
+    u4, u16 = (lambda x: (x + 3) // 4 * 4), (lambda x: (x + 15) // 16 * 16)
+    apad, dpad, wld = u16(Tp) + cd(Kc, 32) * 32 + 16, u16(Tp) + cd(Kc + 15, 32) * 32 + 16, 16 + cd(Kc + 15, 32) * 32
+    lds = (u4(D) + u4(A) + 2 * u4(Tp) + u4(D) + u4(Hd) + 64 +
+           u4(apad) + u4(Tp) + u4(Tp * C) + u4(dpad * C) + u4(C * wld) + u4(C * A) + u4(8 * A) + cd(Kc, 32) * 512 +
+           max(16 * max(Hd, 2 * A), 16 * 256, 16 * 2 * A + u16(Tp) * (A // 2))) * 4 + 64
+    conv = cd(Tp, 16) <= 16 and lds <= 128 * 1024
+    return bool(geom and conv and I0D % 8 == 0 and GD % 8 == 0 and B <= 1024 and loop(GD, I0D, 5, 3) and loop(Hd + D, GD, 3, 4))
 
 
 def oracle_mode_for(args, prec, B=None, Tp=None, U=None, cell="lstm"):
