@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the per-round measurement evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_evidence.sh r3        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,bucket_sweep.txt,
-#                                          decode_{bench.json,kernel_stats.csv,pmc.csv,pmc.json},speller_phase_stamps.txt}
+#   tools/collect_evidence.sh r3        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,phase_stamps_insitu.txt,
+#                                          timeline.txt,bucket_sweep.txt,decode_{bench.json,kernel_stats.csv,pmc.csv,pmc.json},speller_phase_stamps.txt,
+#                                          speller_loc_phase_stamps.txt,bench_config3.json,config3_kernel_stats.csv}
 # (build first: make -C automatic-speech-recognition_amd/csrc all prof; hipcc ... -DLAS_ROW_STAMPS tools/micro/bench_fused.hip -o tools/micro/bin/bench_fused_stamps)
 # rocprofv3 databases go to /tmp (they exceed gpurun's 64 MiB merge limit); only the summaries are kept.  Counter passes are
 # separate runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); python3 bench.py directly after `--`.
@@ -27,6 +28,8 @@ unset LAS_XPROJ_CHUNK LAS_DOUT_CHUNK
 cp gpurun_out/${P}_pmc.json profiles/${P}_pmc.json 2>/dev/null
 LAS_PHASES=1 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_phases.txt     # stderr: spans of the phases / sweeps (HIP events)
 python3 tools/prof_rnn.py > gpurun_out/${P}_phase_stamps.txt 2>&1
+python3 tools/prof_rnn_insitu.py > gpurun_out/${P}_phase_stamps_insitu.txt 2>&1          # the last BPTT sweep's split inside a whole step
+python3 tools/timeline.py "$(ls /tmp/kt_$P/*/*_results.db /tmp/kt_$P/*_results.db 2>/dev/null | head -1)" --list > gpurun_out/${P}_timeline.txt 2>&1
 # ---- decode leg (BASELINE configs[4]: beam 16 + 2x512 char RNNLM, 16 utterances x 16 beams = 256 rows per step): its own kernel
 # trace, counter passes (HBM bytes, MFMA busy, waits) and bench object with the per-part timing / roofline
 rocprofv3 --kernel-trace --stats -d /tmp/kt_dec_$P -o b -- python3 bench.py --decode-only > gpurun_out/${P}_decode_kt.log 2>&1
@@ -40,5 +43,10 @@ python3 tools/pmc_summary.py gpurun_out/${P}_decode /tmp/pmc_dec_${P}_FETCH_SIZE
 python3 bench.py --decode-only > gpurun_out/${P}_decode_bench.json 2> /dev/null
 # ---- Speller loop kernels: phase stamps of one decode step (row workgroup 0 and product workgroup 0 on one clock)
 [ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps > gpurun_out/${P}_speller_phase_stamps.txt 2>&1
+[ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps 0 loc > gpurun_out/${P}_speller_loc_phase_stamps.txt 2>&1
+# ---- the second configuration (BASELINE configs[3]: V = 5000 + location-aware attention) on one rank
+rocprofv3 --kernel-trace --stats -d /tmp/kt_c3_$P -o b -- python3 bench.py --config 3 --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_c3_kt.log 2>&1
+python3 tools/kernel_stats.py /tmp/kt_c3_$P 3 gpurun_out/${P}_config3_kernel_stats.csv > /dev/null
+python3 bench.py --config 3 --no-decode --no-train-loop > gpurun_out/${P}_bench_config3.json 2> /dev/null
 python3 tools/bucket_sweep.py > gpurun_out/${P}_bucket_sweep.txt 2>&1
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300
