@@ -169,14 +169,7 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A);
 // las_skinny_pack fragments (Wx: [I, 4H], Wh: [H, 4H]; either part may be absent), TF gate order i, j, f, o, then the gate math.
 // x fp32 or bf16 (x_bf16); one-hot input: x = NULL + ids / id_shift / xrows.  fast: the Speller's approximated transcendentals;
 // gates_out (optional [M, 4H]): the ACTIVATED gates, as the Speller's backward pass reads them.
-struct LstmCellLaunch {
-    const void* x; int x_bf16, ldx, I;
-    const int* ids; int id_shift; const float* xrows;
-    const float* h; int ldh;
-    const void *Wx, *Wh;
-    const float *bias, *c_prev;
-    float fb;
-    float *c_out, *h_out, *gates_out;
-    int M, H, fast;
-};
+typedef las_lstm_cell_args LstmCellLaunch;            // (the public struct of include/las_hip.h)
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st);
+// two independent cell steps as the two problems of ONE grid (a: fast + bf16 x = the Speller's; b: exact + fp32 / one-hot = the LM's)
+int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b, hipStream_t st);

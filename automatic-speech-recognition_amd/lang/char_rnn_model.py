@@ -275,13 +275,14 @@ class CharRNN(object):
             plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
-    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0, project=True):
+    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0, project=True, layer0=None):
         """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM id = max(ids - id_shift, 0):
         with id_shift = 2 the beam search's LAS ids are read as they are), the result is ACCUMULATED into
         logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input and recurrent halves
         of every cell product are separate GEMMs against row blocks of the TF kernel, and the one-hot input's half is a row
         look-up inside the gate kernel (las_lstm_pointwise_rows).  project=False stops after the cells (the caller runs them beside
-        the acoustic model's step on another stream and calls project_fused once both are done).
+        the acoustic model's step on another stream and calls project_fused once both are done).  layer0 = (c_new, h_new) of the first
+        layer when somebody else has already computed it (first_cell_args: the Speller call launches it beside its own cell).
         Returns (c_new list, h_new list)."""
         P = self.params()
         dev = logits.device
@@ -294,6 +295,10 @@ class CharRNN(object):
         cell_rows = skinny and H % 32 == 0 and (self.embedding_size == 0 or self.input_size % 32 == 0)
         with torch.no_grad():
             for l, (k, b) in enumerate(P["cells"]):
+                if l == 0 and layer0 is not None:
+                    cs.append(layer0[0]); hs.append(layer0[1])
+                    x = layer0[1]
+                    continue
                 k, b = k.detach(), b.detach()
                 I = k.shape[0] - H
                 rows = l == 0 and "wx" in plan
@@ -335,6 +340,21 @@ class CharRNN(object):
             if project:
                 self.project_fused(plan, x, logits, col0)
         return cs, hs
+
+    def first_cell_args(self, plan, ids, id_shift, c_prev, h_prev, c_out, h_out):
+        """las_lstm_cell_args (ctypes) of the FIRST layer's step for a one-hot LM in speed mode, or None when step_fused would not run
+        that layer through las_lstm_cell_rows.  (ids, c_prev, h_prev, c_out, h_out: the tensors of every step -- fixed buffers.)"""
+        P = self.params()
+        H, N = self.hidden_size, ids.shape[0]
+        if not ("packs" in plan and "wx" in plan and N <= 1024 and H % 32 == 0):
+            return None
+        a = _hip.LstmCellArgs()
+        a.x, a.x_bf16, a.ldx, a.I = None, 0, 0, 0
+        a.ids, a.id_shift, a.xrows = ids.data_ptr(), int(id_shift), plan["wx"].data_ptr()
+        a.h, a.ldh, a.Wx, a.Wh = h_prev.data_ptr(), H, None, plan["packs"][0][0].data_ptr()
+        a.bias, a.c_prev, a.fb = P["cells"][0][1].detach().data_ptr(), c_prev.data_ptr(), 0.0
+        a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c_out.data_ptr(), h_out.data_ptr(), None, N, H, 0
+        return a
 
     def project_fused(self, plan, h_top, logits, col0):
         """logits[:, col0:col0 + V_lm] += lm_weight * (h_top . softmax_w + softmax_b)   (the weights were pre-scaled by fusion_plan)"""

@@ -22,6 +22,13 @@ LIB_PATH = os.environ.get("LAS_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 _lib = None
 
 
+class LstmCellArgs(Structure):
+    """include/las_hip.h las_lstm_cell_args"""
+    _fields_ = [("x", c_void_p), ("x_bf16", c_int), ("ldx", c_int), ("I", c_int), ("ids", c_void_p), ("id_shift", c_int), ("xrows", c_void_p),
+                ("h", c_void_p), ("ldh", c_int), ("Wx", c_void_p), ("Wh", c_void_p), ("bias", c_void_p), ("c_prev", c_void_p), ("fb", c_float),
+                ("c_out", c_void_p), ("h_out", c_void_p), ("gates_out", c_void_p), ("M", c_int), ("H", c_int), ("fast", c_int)]
+
+
 class SpellerFwdArgs(Structure):
     _fields_ = [(n, c_int) for n in ("B", "Tp", "Hd", "A", "D", "NL", "E", "V", "U", "cell", "mode", "prec", "Kc", "C",
                                      "step_logits", "keep_state0", "flags")] + [
@@ -33,7 +40,7 @@ class SpellerFwdArgs(Structure):
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
         ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
         ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p),
-        ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p)]
+        ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p), ("companion", POINTER(LstmCellArgs))]
 
 
 class BeamLoopArgs(Structure):
@@ -129,6 +136,7 @@ _SIGS = {
     "las_lstm_pointwise_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_lstm_cell_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "las_lstm_cell_rows_args": (c_int, [POINTER(LstmCellArgs), c_void_p]),
     "las_lstm_pointwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "las_beam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

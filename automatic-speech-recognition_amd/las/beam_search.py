@@ -249,6 +249,7 @@ class BeamSearch(object):
                 # the library refuses the short form for this geometry (it needs its prefetching row kernels): the long form it is
                 mode["fused"] = False
                 fa.flags &= ~_hip.SPELLER_NO_LOGITS
+                fa.companion = None
                 ba.proj_w = None
                 rc = lib.las_speller_fwd(ctypes.byref(fa), _hip.stream())
             _hip.check(rc, "las_speller_fwd")
@@ -276,11 +277,19 @@ class BeamSearch(object):
             ba.proj_w, ba.proj_b = proj_keep[0].data_ptr(), proj_keep[1].data_ptr()
             ba.proj_h0, ba.proj_k0 = bufs["hs"][NL - 1, 1].data_ptr(), D
             ba.proj_h1, ba.proj_k1 = None, (lm.hidden_size if lm is not None else 0)
+            if lm is not None:
+                # the LM's first layer depends on the tokens only: it rides with the Speller's cell as the second problem of one grid
+                lm0 = (torch.empty(N, lm.hidden_size, device=dev), torch.empty(N, lm.hidden_size, device=dev))
+                lm0_args = lm.first_cell_args(lm_plan, next_token, 2, lm_c[0], lm_h[0], lm0[0], lm0[1])
+                if lm0_args is not None:
+                    fa.companion = ctypes.pointer(lm0_args)
+                    mode["lm0"] = lm0
 
         def lm_cells():
             # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
             # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False)
+            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False,
+                                           layer0=mode.get("lm0") if mode["fused"] else None)
             for l in range(NLl):
                 ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
             if mode["fused"]:

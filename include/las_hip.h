@@ -257,6 +257,9 @@ typedef struct {
                                       within the poll bound stores LAS_SPELLER_STATUS_TIMEOUT here and the launch DRAINS
                                       (every workgroup finishes its steps without waiting) instead of hanging or trapping --
                                       results of that call are invalid, the host checks the word at its next synchronisation */
+    const struct las_lstm_cell_args* companion;   /* optional, LAS_SPELLER_NO_LOGITS calls only: ANOTHER cell step (the LM's first layer in a beam
+                                      search -- it depends on the tokens only) that is launched together with the Speller's cell, as
+                                      the second problem of one grid: two dependent-launch slots of a search step become one */
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
 int las_speller_fwd(const las_speller_fwd_args* a, void* stream);
@@ -353,6 +356,20 @@ int las_lstm_pointwise_rows(const float* z, const float* xrows, const int* ids, 
 int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids, int id_shift, const float* xrows, const float* h, int ldh,
                        const void* Wx_packed, const void* Wh_packed, const float* bias, const float* c_prev, int M, int H,
                        float forget_bias, float* c_out, float* h_out, void* stream);
+/* The same call with its arguments in a struct (what las_speller_fwd_args.companion points to): x fp32 or, with x_bf16, bf16; either
+ * of x / h may be NULL (with its packed weights); fast = the Speller's approximated transcendentals instead of expf / tanhf;
+ * gates_out (optional [M, 4H]) receives the ACTIVATED gates i, j, f, o. */
+typedef struct las_lstm_cell_args {
+    const void* x; int x_bf16, ldx, I;
+    const int* ids; int id_shift; const float* xrows;
+    const float* h; int ldh;
+    const void *Wx, *Wh;
+    const float *bias, *c_prev;
+    float fb;
+    float *c_out, *h_out, *gates_out;
+    int M, H, fast;
+} las_lstm_cell_args;
+int las_lstm_cell_rows_args(const las_lstm_cell_args* a, void* stream);
 /* ... and its gradient, for training the RNNLM (lang/char_rnn_model.py:177-190, truncated BPTT over num_unrollings steps):
  * dz [N,4H] and dc_prev [N,H] from z, c_prev, dh (gradient w.r.t. h') and dc_in (gradient w.r.t. c', may be NULL). */
 int las_lstm_pointwise_bwd(const float* z, const float* c_prev, const float* dh, const float* dc_in, int N, int H,

@@ -67,3 +67,31 @@ def test_lstm_cell_rows_matches_bf16_operand_reference(M, I, H, onehot):
     # bad arguments are refused before any launch
     assert lib.las_lstm_cell_rows(None, 0, 0, None, 0, None, _hip.p(h), H, None, _hip.p(hh), _hip.p(bias), _hip.p(c_prev), M, H, 0.0, _hip.p(c1),
                                   _hip.p(h1), _hip.stream()) < 0
+
+
+@pytest.mark.parametrize("M,I,H", [(256, 1152, 512), (40, 160, 64)])
+def test_lstm_cell_rows_struct_entry_bf16_rows_fast_gates(M, I, H):
+    """las_lstm_cell_rows_args with the options the beam search's Speller step uses: x already bf16, no separate h part, the Speller's
+    approximated transcendentals (fast), activated gates written -- against the bf16-operand reference (tolerance of the fast
+    sigmoid / tanh: 2e-3)."""
+    import ctypes
+    from las import _hip
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(M + I)
+    kern = (torch.randn(I, 4 * H, generator=g) * 0.05).to(dev)
+    bias = (torch.randn(4 * H, generator=g) * 0.1).to(dev)
+    x = torch.randn(M, I, generator=g).to(dev).to(torch.bfloat16).contiguous()
+    c_prev = torch.randn(M, H, generator=g).to(dev)
+    packed = _hip.skinny_pack(kern, I, 4 * H)
+    c1, h1, gt = torch.empty(M, H, device=dev), torch.empty(M, H, device=dev), torch.empty(M, 4 * H, device=dev)
+    a = _hip.LstmCellArgs()
+    a.x, a.x_bf16, a.ldx, a.I = x.data_ptr(), 1, I, I
+    a.h, a.Wx, a.Wh, a.bias, a.c_prev, a.fb = None, packed.data_ptr(), None, bias.data_ptr(), c_prev.data_ptr(), 1.0
+    a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c1.data_ptr(), h1.data_ptr(), gt.data_ptr(), M, H, 1
+    _hip.check(_hip.lib().las_lstm_cell_rows_args(ctypes.byref(a), _hip.stream()), "las_lstm_cell_rows_args")
+    z = x.double() @ kern.to(torch.bfloat16).double() + bias.double()
+    i, j, f, o = z.split(H, 1)
+    gi, gj, gf, go = torch.sigmoid(i), torch.tanh(j), torch.sigmoid(f + 1.0), torch.sigmoid(o)
+    c_t = c_prev.double() * gf + gi * gj
+    assert (c1.double() - c_t).abs().max() < 2e-3 and (h1.double() - torch.tanh(c_t) * go).abs().max() < 2e-3
+    assert (gt.double() - torch.cat([gi, gj, gf, go], 1)).abs().max() < 2e-3
