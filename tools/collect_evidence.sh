@@ -26,7 +26,8 @@ unset LAS_XPROJ_CHUNK LAS_DOUT_CHUNK
 # the bench line comes AFTER the counter passes: bench.py takes the dominant kernel's HBM traffic from the newest profiles/*_pmc.json
 # that was recorded from this very csrc/rnn_seq.hip
 cp gpurun_out/${P}_pmc.json profiles/${P}_pmc.json 2>/dev/null
-LAS_PHASES=1 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_phases.txt     # stderr: spans of the phases / sweeps (HIP events)
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> /dev/null             # the bench line exactly as the driver runs it
+LAS_PHASES=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-decode --no-train-loop > /dev/null 2> gpurun_out/${P}_phases.txt   # spans of the phases / sweeps (HIP events; their recording costs ~0.1 ms per step)
 python3 tools/prof_rnn.py > gpurun_out/${P}_phase_stamps.txt 2>&1
 python3 tools/prof_rnn_insitu.py > gpurun_out/${P}_phase_stamps_insitu.txt 2>&1          # the last BPTT sweep's split inside a whole step
 python3 tools/timeline.py "$(ls /tmp/kt_$P/*/*_results.db /tmp/kt_$P/*_results.db 2>/dev/null | head -1)" --list > gpurun_out/${P}_timeline.txt 2>&1
