@@ -251,3 +251,33 @@ def test_projection_inside_the_beam_step_equals_projecting_first(nutt, beam, V, 
               "src_row", "next_token", "step"):
         assert torch.equal(T1[k], T2[k]), k
     assert int(T1["hist_n"][1].min()) == min(beam, beam * (V - 1))
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_decode_batch_subword_vocabulary_v5000_location_aware(prec):
+    """BASELINE configs[3]'s decode shape class: V = 5000 (beam x V = 20,000 candidates: the round-based ranking inside the loop kernel, the
+    long form of the step -- the in-kernel projection serves <= 8 tiles) with location-aware attention, against the oracle's search."""
+    from las import layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    from las.beam_search import BeamSearch
+    from oracle import las_oracle as O
+    args = make_args(enc_units=48, num_enc_layers=2, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32, unit="subword",
+                     vocab_size=5000, mode="loc", loc_kernel_size=7, loc_num_channels=3, beam_size=4, convert_rate=0.3, apply_lm=False)
+    p0 = O.init_params(args, seed=5, cell="lstm")
+    p0["Speller/decode/dense/kernel"] = (p0["Speller/decode/dense/kernel"] * 6).astype(np.float32)   # spread the 5000 logits: no near ties
+    p0["Speller/decode/dense/bias"][2] = 1.5
+    L.set_cell("lstm"); L.set_precision(prec)
+    st = V.reset_default_store(device="cuda"); st.load(p0)
+    tok = {"<PAD>": 0, "<SOS>": 1, "<EOS>": 2}
+    las = LAS(args, Listener, Speller, tok)
+    bs = BeamSearch(args, las, tok, None)
+    utts = [synthetic_batch(1, T, 8, 30, seed=3 + k)[0] for k, T in enumerate((37, 52))]
+    got = bs.decode_batch(None, utts)
+    for xs, res in zip(utts, got):
+        ref = oracle_decode(xs, p0, args, "lstm", 4, prec=prec)
+        assert len(res) == len(ref) > 0
+        if prec == "f32":
+            assert [b.token_ids for b in res] == [b.token_ids for b in ref]
+        else:
+            assert res[-1].token_ids == ref[-1].token_ids
+        assert float(res[-1].log_prob) == pytest.approx(float(ref[-1].log_prob), abs=2e-3 if prec == "f32" else 5e-2)
