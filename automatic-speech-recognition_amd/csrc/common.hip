@@ -45,6 +45,27 @@ extern "C" int las_wait_word(const int* word, int value, int max_us, void* strea
     return 0;
 }
 
+// The same for the sweeps' announcement word (LAS_SEQ_ANNOUNCE numbers run cyclically through 1..1023): passes as soon as the word HAS
+// REACHED n, i.e. also when a later sweep has announced itself meanwhile -- a hold that is enqueued late (its stream was busy) must
+// not sit out its whole bound because the number it waits for has come and gone.
+__global__ __launch_bounds__(64) void wait_announce_kernel(const int* word, int n, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();                      // 100 MHz
+    for (;;) {
+        const int w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w >= 1 && w <= 1023 && ((w - n + 1023) % 1023) < 512) break;
+        if (wall_clock64() - t0 > max_ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+extern "C" int las_wait_announce(const int* word, int n, int max_us, void* stream) {
+    LAS_ARG(word && max_us >= 0 && n >= 1 && n <= 1023, "las_wait_announce: bad arguments");
+    hipLaunchKernelGGL(wait_announce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, n, (long long)max_us * 100);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 // stream-ordered store of a device word (the completion flag behind a chunk of work that another, already running, kernel waits for)
 __global__ __launch_bounds__(64) void set_word_kernel(int* word, int value) {
     if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -122,6 +122,7 @@ _SIGS = {
                               c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "las_wait_announce": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_set_word": (c_int, [c_void_p, c_int, c_void_p]),
     "las_gemm_kk_frames": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong,
                                    c_void_p, c_int, c_longlong, c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
@@ -605,14 +606,14 @@ def streams_overlap(dev):
 
 def hold_until_next_sweep(dev, max_us=1500):
     """Enqueue (on the current = side stream) a bounded wait for the next BPTT sweep's announcement."""
-    check(lib().las_wait_word(c_void_p(status_word(dev).data_ptr() + 4), next_announce(), max_us, stream()), "las_wait_word")
+    check(lib().las_wait_announce(c_void_p(status_word(dev).data_ptr() + 4), next_announce(), max_us, stream()), "las_wait_announce")
 
 
 def hold_until_last_sweep(dev, max_us=1500):
     """... for the announcement of the BPTT sweep that was launched LAST (for side work that the sweep's own node releases after its
     launch -- run_deferred -- but that could start on the device before the sweep does)."""
     if _announce[0]:
-        check(lib().las_wait_word(c_void_p(status_word(dev).data_ptr() + 4), (_announce[0] - 1) % 1023 + 1, max_us, stream()), "las_wait_word")
+        check(lib().las_wait_announce(c_void_p(status_word(dev).data_ptr() + 4), (_announce[0] - 1) % 1023 + 1, max_us, stream()), "las_wait_announce")
 
 
 def check_status(dev=None):

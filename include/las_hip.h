@@ -316,6 +316,9 @@ int las_ce_loss(const float* logits, long long sb, long long st, const int* y, i
  * held back until the next recurrent sweep has announced itself (LAS_SEQ_ANNOUNCE), so that they neither delay its start nor
  * compete with the chain GEMMs in front of it.  No reference counterpart (the reference has one stream). */
 int las_wait_word(const int* word, int value, int max_us, void* stream);
+/* ... for the announcement word itself (status[1] of LAS_SEQ_ANNOUNCE): passes once the word HAS REACHED n in the cyclic order of
+ * 1..1023 -- also when later sweeps have announced themselves meanwhile (a hold enqueued late must not sit out its bound). */
+int las_wait_announce(const int* word, int n, int max_us, void* stream);
 
 /* bf16 (or fp32) weight shadows of the speed mode, rebuilt after every optimiser step by ONE launch over a device-resident
  * descriptor table: D = zero-pad(op([src0 | src1])), op = transpose or identity; src1 may be NULL (cols1 = 0).

@@ -337,3 +337,31 @@ def test_chunked_upstream_gradient_is_waited_for(pairs):
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError):
         _hip.check_status()
+
+
+def test_wait_announce_passes_for_numbers_that_have_come_and_gone():
+    """las_wait_announce: the hold of side-stream work on a sweep's announcement passes at once when that sweep -- or a later one -- has
+    announced itself (cyclic numbers 1..1023), and sits out its bound otherwise (las_wait_word waits for equality only)."""
+    import time
+    from las import _hip
+    lib = _hip.lib()
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def timed(n, bound_us):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _hip.check(lib.las_wait_announce(_hip.p(word), n, bound_us, _hip.stream()), "las_wait_announce")
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e6
+
+    timed(1, 10)                                          # warm-up
+    bound = 20000
+    word.fill_(7)
+    assert timed(7, bound) < bound / 4                    # reached exactly
+    assert timed(5, bound) < bound / 4                    # two later sweeps have announced themselves meanwhile
+    assert timed(8, bound) > bound * 0.9                  # not yet
+    word.fill_(3)
+    assert timed(1020, bound) < bound / 4                 # wrapped: 1020, 1021, 1022, 1023, 1, 2, 3
+    word.zero_()
+    assert timed(1, bound) > bound * 0.9                  # nothing announced yet
+    assert lib.las_wait_announce(_hip.p(word), 0, 10, _hip.stream()) < 0
