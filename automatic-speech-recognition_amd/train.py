@@ -47,6 +47,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dp = DataParallel()
+        # the ranks share the host with each other and with their reader threads: no machine-wide intra-op pools per rank
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
 
     # tokenizer (the reference always builds SubwordEncoder, train.py:60 -- SURVEY Q15; --unit is honoured here)
     tokenizer = CharEncoder() if args.unit.lower() == "char" else SubwordEncoder(args.subword_dir)

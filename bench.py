@@ -399,6 +399,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (a.gpus, world, a.gpus))
+    if world > 1:
+        # N ranks share the host: a rank's few CPU-side torch ops must not each fork a pool as wide as the machine (the launch thread of
+        # every rank competes with them; cf. tests/conftest.py)
+        torch.set_num_threads(max(1, min(8, usable_cores() // world)))
     # the driver stack may print to fd 1 while the device is initialised (libdrm's "amdgpu.ids" notice): keep stdout
     # for the ONE JSON line by pointing fd 1 at stderr until the result is printed
     sys.stdout.flush()
