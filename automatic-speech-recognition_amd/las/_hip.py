@@ -658,7 +658,8 @@ def poll_status(dev):
 
 
 def rnn_seq_ws(cell, prec, H, B, dev):
-    return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H, B), "rnn_seq")
+    # per STREAM (_tag): the encoders of utterances of different lengths run side by side on several streams in beam search
+    return workspace(dev, lib().las_rnn_seq_workspace_bytes(cell, prec, H, B), _tag("rnn_seq"))
 
 
 def rnn_seq_io_dtype(cell, prec, H):

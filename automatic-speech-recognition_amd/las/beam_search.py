@@ -80,6 +80,8 @@ class BeamSearch(object):
         self._las = las
         self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
         self.fuse_projection = os.environ.get("LAS_NO_DECODE_FUSED_PROJ") != "1"   # decode_batch: cell in one launch, projection inside the beam kernel
+        self.parallel_encoders = os.environ.get("LAS_NO_PARALLEL_ENCODERS") != "1"   # decode_batch: encoders of different lengths on several streams
+        self._enc_streams = None
         self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
         self.last_timing = None
 
@@ -144,7 +146,7 @@ class BeamSearch(object):
             al = np.asarray(audiolen).reshape(-1)
             groups.setdefault((tuple(np.shape(audio)[1:]), float(al[0])), []).append(u)
             dec_steps.append(int(al[0] * a.convert_rate))                                       # las/beam_search.py:78
-        for us in groups.values():
+        def encode_group(us):
             # utterances of the SAME shape and length share one encoder launch: every row of the encoder is computed
             # independently of the other rows, so this is exactly the one-at-a-time result (unlike padding, see above)
             audio = np.concatenate([np.asarray(xs_list[u][0]) for u in us], 0)
@@ -154,6 +156,35 @@ class BeamSearch(object):
             for i, u in enumerate(us):
                 encs[u] = h[i:i + 1]
                 enc_lens[u] = float(el[i])
+            return h
+
+        glist = list(groups.values())
+        encode_group(glist[0])
+        if len(glist) > 1 and self.parallel_encoders:
+            # Groups of DIFFERENT lengths (a real test set: every utterance its own) run side by side on a few streams: an encoder is
+            # four latency-bound sweeps that occupy 8-16 of the 256 CUs each, one after the other they are the bulk of a search
+            # (16 x 4 ms against 15 ms of search).  The first group ran on this stream (it also builds the weights' bf16 shadows once);
+            # the others start behind it.  The chunked x-projection hand-over shares one side stream and one ring of flag words:
+            # it is off for these launches (whole products in front of the sweeps -- they overlap across the streams anyway).
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record()
+            if self._enc_streams is None:
+                self._enc_streams = [torch.cuda.Stream() for _ in range(8)]
+            saved, L.XPROJ_CHUNK_STEPS = L.XPROJ_CHUNK_STEPS, 0
+            try:
+                for i, us in enumerate(glist[1:]):
+                    s_ = self._enc_streams[i % len(self._enc_streams)]
+                    s_.wait_event(ready)
+                    with torch.cuda.stream(s_):
+                        encode_group(us).record_stream(cur)
+            finally:
+                L.XPROJ_CHUNK_STEPS = saved
+            for s_ in self._enc_streams:
+                cur.wait_stream(s_)
+        else:
+            for us in glist[1:]:
+                encode_group(us)
         Tps = [h.shape[1] for h in encs]
         Tp, Hd = max(Tps), encs[0].shape[2]
         N = n * beam

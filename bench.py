@@ -219,6 +219,23 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     bs.decode_batch(None, utts)
     tm = bs.last_timing or {}
     bs.measure = False
+    # what a real test set looks like: every utterance its own length (the reference encoder has no length mask, so nothing is padded):
+    # 16 encoders instead of one -- side by side on several streams (BeamSearch.parallel_encoders), and for comparison one after the other
+    ragged = []
+    for k in range(nutt):
+        Tk = T - 18 * k                                  # 1274 ... 1004 frames
+        xs, _ = synthetic_batch(1, Tk, 8, 30, seed=300 + k)
+        ragged.append(xs)
+    rag = {}
+    for name, par in (("parallel_encoders", True), ("one_encoder_at_a_time", False)):
+        bs.parallel_encoders = par
+        bs.decode_batch(None, ragged[:3])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        bs.decode_batch(None, ragged)
+        torch.cuda.synchronize()
+        rag[name] = round(nutt / (time.perf_counter() - t1), 1)
+    bs.parallel_encoders = True
     parts = tm.get("parts_us", {})
     N, Tp = nutt * beam, tm.get("frames", 160)
     D, A, Hd, E = args.dec_units, args.attention_size, 2 * args.enc_units, args.embedding_size
@@ -243,6 +260,7 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
             "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 3),
             "us_per_decode_step": round((tm.get("searched", 0.0)) / max(tm.get("steps", 1), 1) * 1e6, 1) if tm else None,
             "phases_s": {k: tm[k] for k in ("encoded", "searched", "done") if k in tm}, "step_parts_us": parts, "roofline": roof,
+            "ragged": dict(rag, unit="utterances/s", frames="%d utterances of %d ... %d frames, all different" % (nutt, T - 18 * (nutt - 1), T)),
             "note": "utterances of equal length share one encoder launch (rows are independent; the reference encoder has no length "
                     "mask, so utterances are never padded to a common length); the search runs all utterances x beam rows per "
                     "step on the device, one captured step replayed as a HIP graph"}
