@@ -51,6 +51,7 @@ struct RnnArgs {
                                              // both ends of the sequence; *dflag = chunks complete
     int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
+    const int* row_T;                        // forward, optional: frames of every batch row (<= T); a row's state and outputs are ZERO at t >= row_T[row]
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
@@ -656,7 +657,11 @@ struct HwCfg {
 
 // RB = 8: see rnn_seq_bwd_ks_kernel -- the A operand repeats rows 0..7 in rows 8..15, every lane keeps the two accumulator rows
 // r = 2*hsel + {0,1} of its (gl, unit) position: half the transcendentals, ring traffic and granule bytes per CU and step.
-template <int CELL, int UT, int P, int RB>
+// RAGGED: rows of different lengths in one launch (beam search encodes utterances the reference feeds one at a time, unpadded): at
+// frames t >= row_T[row] the row's h and c are forced to zero -- the backward direction, which starts in a short row's padding,
+// reaches that row's last real frame with the zero state an unpadded run starts from; the forward direction's real frames come first;
+// and the pad frames hold zeros, which is also the zero frame the pyramid appends to an odd-length utterance.
+template <int CELL, int UT, int P, int RB, bool RAGGED = false>
 __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
     static_assert(RB == 16 || RB == 8, "row tile");
     using C = RnnCfg<CELL, UT, P>;
@@ -856,6 +861,9 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
     for (int j = 0; j < UTP; ++j)
 #pragma unroll
         for (int r = 0; r < NV; ++r) cst[j][r] = 0.f;
+    int rowT[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) rowT[r] = RAGGED ? a.row_T[(b0 + row0 + r) < B ? (b0 + row0 + r) : B - 1] : 0x7fffffff;
     int cur = 0;
 #ifdef LAS_PROF
     const bool hprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
@@ -931,12 +939,14 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                     const float gj = TR ? tanhx<true>(pre[G > 1 ? 1 : 0][j][r]) : pre[G > 1 ? 1 : 0][j][r] * 0.25f;
                     const float gf = TR ? sigm<true>(pre[G > 2 ? 2 : 0][j][r] + a.fb) : pre[G > 2 ? 2 : 0][j][r] * 0.125f;
                     const float go = TR ? sigm<true>(pre[G > 3 ? 3 : 0][j][r]) : pre[G > 3 ? 3 : 0][j][r] * 0.75f;
-                    const float cc = cst[j][r] * gf + gi * gj;
-                    cst[j][r] = cc;
+                    float cc = cst[j][r] * gf + gi * gj;
                     h = (TR ? tanhx<true>(cc) : cc * 0.3f) * go;
+                    if (RAGGED && t0 + s * (int)tstep >= rowT[r]) { cc = 0.f; h = 0.f; }
+                    cst[j][r] = cc;
                     res[r][0] = gi; res[r][1] = gj; res[r][2] = gf; res[r][3] = go; res[r][4] = cc;
                 } else {
                     h = tanhx<true>(pre[0][j][r]);
+                    if (RAGGED && t0 + s * (int)tstep >= rowT[r]) h = 0.f;
                 }
                 res[r][5] = h;
                 hb[r] = f2bf(h);
@@ -1790,6 +1800,11 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
                                                                           //  198 registers x 8 waves -- a 64 KB / 110-register GEMM workgroup fits next to it)
                 static int attr = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>, HL);
                 if (attr != 0) { las_set_error("hipFuncSetAttribute(fwd hw) failed: %d", attr); return attr; }
+                if (a.row_T) {
+                    static int attr2 = set_lds(rnn_seq_fwd_hw_kernel<CELL, UT, P, 8, true>, HL);
+                    if (attr2 != 0) { las_set_error("hipFuncSetAttribute(fwd hw, ragged) failed: %d", attr2); return attr2; }
+                    hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8, true>), gridw, dim3(512), HL, st, a);
+                } else
                 hipLaunchKernelGGL((rnn_seq_fwd_hw_kernel<CELL, UT, P, 8>), gridw, dim3(512), HL, st, a);
             }
         } else if (!bwd && RT == 1 && HwCfg<CELL, UT, P>::OK && !a0.no_helpers) {
@@ -1963,6 +1978,7 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
 }
 
 static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
+    a.row_T = nullptr;
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
     a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
     a.warm = (flags & LAS_SEQ_NO_WARMERS) ? 0 : 1;
@@ -1988,6 +2004,17 @@ extern "C" int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int f
     return ((q & 2) && cdiv(B, 16) <= max_tiles) ? 1 : 0;
 }
 
+// rows of different lengths (las_rnn_seq_fwd_rows): the 8-row helper-wave kernel, whole batch in one launch
+extern "C" int las_rnn_seq_fwd_rows_ok(int cell, int prec, int B, int H, int flags) {
+    if (prec != LAS_PREC_BF16 || !mfma_shape_ok(H) || B <= 0 || (flags & (LAS_SEQ_NO_HELPER_WAVES | LAS_SEQ_ROWS16))) return 0;
+    const int P = pick_cluster(cell, H, flags);
+    if (P <= 1) return 0;
+    RnnArgs a; a.H = H; a.B = B;
+    const int q = dispatch_bf16(cell, P, false, a, nullptr, true);
+    const int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
+    return (max_tiles >= 1 && cdiv(B, 8) <= max_tiles && (q & 1)) ? 1 : 0;
+}
+
 extern "C" int las_rnn_seq_io_dtype(int cell, int prec, int H) {
     (void)cell;
     return (prec == LAS_PREC_BF16 && mfma_shape_ok(H)) ? LAS_DT_BF16 : LAS_DT_F32;
@@ -2006,10 +2033,29 @@ extern "C" int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* ga
                                    status, nullptr, 0, ws, ws_bytes, stream);
 }
 
+static int rnn_seq_fwd_impl(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                            const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                            void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
+                            const int* row_T, void* ws, size_t ws_bytes, void* stream);
 extern "C" int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                        const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
                                        void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
                                        void* ws, size_t ws_bytes, void* stream) {
+    return rnn_seq_fwd_impl(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, forget_bias, flags, status,
+                            chunk_flag, chunk_steps, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int las_rnn_seq_fwd_rows(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                    const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                                    void* cstate, float forget_bias, int flags, int* status, const int* row_T,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(row_T, "las_rnn_seq_fwd_rows: null row_T");
+    return rnn_seq_fwd_impl(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, forget_bias, flags, status,
+                            nullptr, 0, row_T, ws, ws_bytes, stream);
+}
+static int rnn_seq_fwd_impl(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                            const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                            void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
+                            const int* row_T, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_fwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     hipStream_t st = (hipStream_t)stream;
     RnnArgs a;
@@ -2021,6 +2067,9 @@ extern "C" int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, 
     LAS_ARG(!chunk_flag || (chunk_steps > 0 && las_rnn_seq_fwd_chunks_ok(cell, prec, B, H, flags)),
             "las_rnn_seq_fwd_chunked: this configuration is not served by the kernel that waits for x-projection chunks");
     a.xflag = chunk_flag; a.xsc = chunk_steps;
+    a.row_T = row_T;
+    LAS_ARG(!row_T || las_rnn_seq_fwd_rows_ok(cell, prec, B, H, flags), "las_rnn_seq_fwd_rows: rows of different lengths are served by the 8-row "
+            "helper-wave kernel only (speed mode, clustered, the whole batch in one launch): ask las_rnn_seq_fwd_rows_ok");
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif

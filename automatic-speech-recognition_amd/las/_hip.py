@@ -130,6 +130,9 @@ _SIGS = {
     "las_rnn_seq_bwd_db_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
                                            c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_rnn_seq_fwd_rows_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "las_rnn_seq_fwd_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong,
+                                     c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_fwd_chunks_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "las_rnn_seq_fwd_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                         c_longlong, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -692,12 +695,25 @@ def rnn_seq_fwd_chunks_ok(cell, prec, B, H, flags=None):
     return bool(lib().las_rnn_seq_fwd_chunks_ok(cell, prec, B, H, seq_flags if flags is None else flags))
 
 
+def rnn_seq_fwd_rows_ok(cell, prec, B, H, flags=None):
+    return bool(lib().las_rnn_seq_fwd_rows_ok(cell, prec, B, H, seq_flags if flags is None else flags))
+
+
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                forget_bias=1.0, wf_off=0, wb_off=0, flags=None, chunk_flag=None, chunk_steps=0):
+                forget_bias=1.0, wf_off=0, wb_off=0, flags=None, chunk_flag=None, chunk_steps=0, row_T=None):
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
     _check_io(cell, prec, H, gates, out, cstate)
     ws = rnn_seq_ws(cell, prec, H, B, gates.device)
     fl = seq_flags if flags is None else flags
+    if row_T is not None:
+        require_gpu(row_T)
+        assert chunk_flag is None and row_T.dtype == torch.int32 and row_T.numel() == B
+        with _timed("rnn_seq_fwd_rows[T=%d,H=%d]" % (T, H)):
+            check(lib().las_rnn_seq_fwd_rows(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                             c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                             p(cstate), forget_bias, fl, p(status_word(gates.device)), p(row_T),
+                                             p(ws), ws.numel(), stream()), "las_rnn_seq_fwd_rows")
+        return
     if chunk_flag is not None:
         with _timed("rnn_seq_fwd[T=%d,H=%d]" % (T, H)):
             check(lib().las_rnn_seq_fwd_chunked(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),

@@ -80,6 +80,7 @@ class BeamSearch(object):
         self._las = las
         self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
         self.fuse_projection = os.environ.get("LAS_NO_DECODE_FUSED_PROJ") != "1"   # decode_batch: cell in one launch, projection inside the beam kernel
+        self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
         self.parallel_encoders = os.environ.get("LAS_NO_PARALLEL_ENCODERS") != "1"   # decode_batch: encoders of different lengths on several streams
         self._enc_streams = None
         self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
@@ -159,8 +160,40 @@ class BeamSearch(object):
             return h
 
         glist = list(groups.values())
-        encode_group(glist[0])
-        if len(glist) > 1 and self.parallel_encoders:
+        cellid = L._cellid(sp.cell)
+        H_enc = a.enc_units
+        ragged = (len(glist) > 1 and self.ragged_encoder and prec == _hip.PREC_BF16 and a.enc_type.lower() == "pblstm" and
+                  len({np.shape(x[0])[2:] for x in xs_list}) == 1 and
+                  _hip.rnn_seq_io_dtype(cellid, prec, H_enc) == torch.bfloat16 and _hip.rnn_seq_fwd_rows_ok(cellid, prec, n, H_enc))
+        if ragged:
+            # ONE encoder pass over all utterances although their lengths differ (the reference feeds them one at a time, unpadded):
+            # the forward sweeps take the rows' frame counts (las_rnn_seq_fwd_rows: a row's state and outputs are zero behind its last
+            # frame, so its backward direction starts from the zero state at ITS last frame and an odd length pairs with a zero frame,
+            # exactly as alone); the products in between are row-wise.  Every real frame equals the one-at-a-time result.
+            lens = [int(np.shape(x[0])[1]) for x in xs_list]
+            Tmax = max(lens)
+            audio = np.zeros((n, Tmax) + tuple(np.shape(xs_list[0][0])[2:]), np.float32)
+            for u, x in enumerate(xs_list):
+                audio[u, :lens[u]] = np.asarray(x[0])[0]
+            audiolen = np.concatenate([np.asarray(x[1]).reshape(-1)[:1] for x in xs_list], 0)
+            L.ROW_T[0] = torch.tensor(lens, dtype=torch.int32, device=dev)
+            try:
+                h, enc_len = self._get_encode(sess, audio, audiolen)
+            finally:
+                L.ROW_T[0] = None
+            el = torch.as_tensor(enc_len).reshape(-1)
+            for u in range(n):
+                tp = lens[u]
+                for _ in range(a.num_enc_layers):
+                    tp = (tp + 1) // 2
+                encs[u] = h[u:u + 1, :tp]
+                enc_lens[u] = float(el[u])
+            glist = []
+        else:
+            encode_group(glist[0])
+        if ragged:
+            pass
+        elif len(glist) > 1 and self.parallel_encoders:
             # Groups of DIFFERENT lengths (a real test set: every utterance its own) run side by side on a few streams: an encoder is
             # four latency-bound sweeps that occupy 8-16 of the 256 CUs each, one after the other they are the bulk of a search
             # (16 x 4 ms against 15 ms of search).  The first group ran on this stream (it also builds the weights' bf16 shadows once);

@@ -109,6 +109,8 @@ _DCHUNK = {}          # data_ptr of a dPre whose producer (a recurrent layer's d
 _DOUT_CHUNKS = {}     # data_ptr of a dense layer's dX that is still being produced in chunks on the chain stream: (flag, chunk rows, rows)
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
+ROW_T = [None]        # inference over a batch of utterances of DIFFERENT lengths: int32 [B] device tensor of the current layer's frames per row
+                      # (set around the listener call by BeamSearch.decode_batch; the pyramid layers halve it) -- las_rnn_seq_fwd_rows
 XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
 DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
@@ -503,6 +505,8 @@ class _BLSTM16(torch.autograd.Function):
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
             bias = _shadow("ihb", (bfw, bbw), 1, False, 1, 2 * GH, bf16=False).view(-1)
             chunk_flag, cs = None, XPROJ_CHUNK_STEPS
+            if ROW_T[0] is not None:
+                cs = 0                                   # rows of different lengths (inference): whole x-projection, las_rnn_seq_fwd_rows
             if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H) and _hip.streams_overlap(dev):
                 # The sweep consumes the x-projection in time order (forward direction from t = 0, backward from t = T - 1), so only
                 # the first chunk of frames -- both ends of the sequence -- has to exist when it starts: chunk 0 on this stream,
@@ -536,8 +540,12 @@ class _BLSTM16(torch.autograd.Function):
         if Tp != T:
             out[:, T:].zero_()                           # only the pad frame (the sweep writes every real frame)
         cst = torch.empty(B, T, 2, H, device=dev, dtype=bf) if cell == "lstm" else None
+        row_T = ROW_T[0]
+        if row_T is not None and (two or torch.is_grad_enabled() or not _hip.rnn_seq_fwd_rows_ok(_cellid(cell), prec, B, H)):
+            raise RuntimeError("rows of different lengths (layers.ROW_T) are an inference-only path of the 8-row speed-mode sweep")
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
-                         1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs)
+                         1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs,
+                         row_T=row_T)
         if not two and chunk_flag is not None:
             _hip.join_side_stream()          # (the chunks are long finished; this orders later users of `gates` after them)
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
@@ -768,6 +776,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
                         st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=l == num_layers - 1)   # :89-93
         # (the listener's LAST dense output feeds the Speller, whose interface is fp32; everything before it stays bf16)
         audiolen = (audiolen + audiolen % 2) / 2                                          # :94
+        if ROW_T[0] is not None:
+            ROW_T[0] = (ROW_T[0] + 1) // 2               # a row's frame pairs (an odd last frame pairs with the zero frame behind it)
     return rnn_out, states, audiolen
 
 

@@ -220,22 +220,23 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     tm = bs.last_timing or {}
     bs.measure = False
     # what a real test set looks like: every utterance its own length (the reference encoder has no length mask, so nothing is padded):
-    # 16 encoders instead of one -- side by side on several streams (BeamSearch.parallel_encoders), and for comparison one after the other
+    # ONE encoder pass over rows of different lengths (las_rnn_seq_fwd_rows; BeamSearch.ragged_encoder), and for comparison 16 encoders
+    # side by side on several streams (parallel_encoders) and one after the other
     ragged = []
     for k in range(nutt):
         Tk = T - 18 * k                                  # 1274 ... 1004 frames
         xs, _ = synthetic_batch(1, Tk, 8, 30, seed=300 + k)
         ragged.append(xs)
     rag = {}
-    for name, par in (("parallel_encoders", True), ("one_encoder_at_a_time", False)):
-        bs.parallel_encoders = par
+    for name, rg, par in (("one_ragged_encoder_pass", True, True), ("parallel_encoders", False, True), ("one_encoder_at_a_time", False, False)):
+        bs.ragged_encoder, bs.parallel_encoders = rg, par
         bs.decode_batch(None, ragged[:3])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         bs.decode_batch(None, ragged)
         torch.cuda.synchronize()
         rag[name] = round(nutt / (time.perf_counter() - t1), 1)
-    bs.parallel_encoders = True
+    bs.ragged_encoder = bs.parallel_encoders = True
     parts = tm.get("parts_us", {})
     N, Tp = nutt * beam, tm.get("frames", 160)
     D, A, Hd, E = args.dec_units, args.attention_size, 2 * args.enc_units, args.embedding_size

@@ -162,6 +162,16 @@ int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates
                             const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
                             void* cstate, float forget_bias, int flags, int* status, const int* chunk_flag, int chunk_steps,
                             void* ws, size_t ws_bytes, void* stream);
+/* las_rnn_seq_fwd for a batch whose rows have DIFFERENT lengths (beam search encodes utterances the reference feeds one at a time,
+ * unpadded -- its encoder has no length mask): row_T [B] device ints, row_T[b] <= T frames of row b.  At frames t >= row_T[b] the row's
+ * state and outputs are forced to ZERO: the backward direction reaches the row's last real frame with the zero state of an unpadded run,
+ * the forward direction's real frames come first, and the zero pad frame is the one the pyramid appends to an odd-length utterance --
+ * every real frame equals the one-utterance-at-a-time result.  Served by the 8-row helper-wave kernel (las_rnn_seq_fwd_rows_ok). */
+int las_rnn_seq_fwd_rows_ok(int cell, int prec, int B, int H, int flags);
+int las_rnn_seq_fwd_rows(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                         const float* whh_bw, int ldw, void* out, int ld_out, long long out_bstride,
+                         void* cstate, float forget_bias, int flags, int* status, const int* row_T,
+                         void* ws, size_t ws_bytes, void* stream);
 /* C = act(A . B^T + bias) like las_gemm_kk, restricted to the frames [lo0, lo0+nlo) and [hi0, hi0+nhi) of every utterance of
  * [nb, T, *] tensors A and C (row pitches lda / ldc per frame); las_set_word: stream-ordered store of a device word. */
 int las_gemm_kk_frames(int nb, int T, int lo0, int nlo, int hi0, int nhi, int N, int K, const void* A, long long lda,

@@ -103,3 +103,21 @@ def test_f32_beam16_lm_at_the_bench_architecture_is_exact():
         assert [b.token_ids for b in res] == [b.token_ids for b in ref]
         for a, b in zip(res, ref):
             assert float(a.log_prob) == pytest.approx(float(b.log_prob), abs=5e-3)
+
+
+def test_bf16_utterances_of_different_lengths_one_ragged_encoder_pass_equals_one_encoder_each():
+    """decode_batch over utterances of DIFFERENT (odd and even) lengths: the single encoder pass with per-row frame counts
+    (las_rnn_seq_fwd_rows) against one encoder per utterance -- side by side on several streams, and one after the other: hypotheses,
+    scores and alignments must be bit-identical (every real frame of the ragged pass is the frame the utterance gets alone)."""
+    args, p0, plm, bs, _ = _setup("bf16")
+    utts = [synthetic_batch(1, T_, 8, 30, seed=60 + k)[0] for k, T_ in enumerate((300, 287, 251, 300, 199, 274))]
+    res = {}
+    for name, rg, par in (("ragged", True, True), ("streams", False, True), ("serial", False, False)):
+        bs.ragged_encoder, bs.parallel_encoders = rg, par
+        res[name] = bs.decode_batch(None, utts)
+    bs.ragged_encoder = bs.parallel_encoders = True
+    for other in ("streams", "serial"):
+        for a, b in zip(res["ragged"], res[other]):
+            assert [h.token_ids for h in a] == [h.token_ids for h in b], other
+            assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], other
+            assert torch.equal(a[-1].att[-1], b[-1].att[-1])
