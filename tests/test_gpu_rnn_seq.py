@@ -365,3 +365,34 @@ def test_wait_announce_passes_for_numbers_that_have_come_and_gone():
     word.zero_()
     assert timed(1, bound) > bound * 0.9                  # nothing announced yet
     assert lib.las_wait_announce(_hip.p(word), 0, 10, _hip.stream()) < 0
+
+
+@pytest.mark.parametrize("cell", [1, 0])
+def test_forward_sweep_over_rows_of_different_lengths_equals_each_row_alone(cell):
+    """las_rnn_seq_fwd_rows: every real frame of a row (both directions, h and c) is bit-identical to sweeping that row alone at its own
+    length; behind a row's last frame h and c are zero."""
+    from las import _hip
+    dev = "cuda"
+    B, T, H = 11, 77, 256
+    G = 4 if cell else 1
+    if not _hip.rnn_seq_fwd_rows_ok(cell, 1, B, H):
+        pytest.skip("the 8-row helper-wave kernel does not serve this configuration here")
+    g = torch.Generator().manual_seed(5)
+    io = _hip.rnn_seq_io_dtype(cell, 1, H)
+    xp = (torch.randn(B, T, 2, G * H, generator=g) * 0.5).to(dev).to(io)
+    w0 = (torch.randn(H, G * H, generator=g) * 0.05).to(dev)
+    w1 = (torch.randn(H, G * H, generator=g) * 0.05).to(dev)
+    lens = [77, 1, 40, 76, 13, 77, 2, 55, 31, 64, 9]
+    row_T = torch.tensor(lens, dtype=torch.int32, device=dev)
+    out = torch.full((B, T, 2 * H), 7.0, device=dev, dtype=io)
+    cst = torch.full((B, T, 2, H), 7.0, device=dev, dtype=io) if cell else None
+    _hip.rnn_seq_fwd(cell, 1, B, T, H, xp.clone(), w0, w1, G * H, out, 2 * H, T * 2 * H, cst, row_T=row_T)
+    for b, n in enumerate(lens):
+        o1 = torch.empty(1, n, 2 * H, device=dev, dtype=io)
+        c1 = torch.empty(1, n, 2, H, device=dev, dtype=io) if cell else None
+        _hip.rnn_seq_fwd(cell, 1, 1, n, H, xp[b:b + 1, :n].clone().contiguous(), w0, w1, G * H, o1, 2 * H, n * 2 * H, c1)
+        assert torch.equal(out[b, :n], o1[0]), (b, n)
+        assert bool((out[b, n:] == 0).all())
+        if cell:
+            assert torch.equal(cst[b, :n], c1[0]) and bool((cst[b, n:] == 0).all())
+    _hip.check_status(dev)
