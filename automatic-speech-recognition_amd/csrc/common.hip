@@ -12,7 +12,7 @@ void las_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int las_version(void) { return 100; }  // 0.1.0
+extern "C" int las_version(void) { return LAS_HIP_ABI_VERSION; }
 extern "C" const char* las_last_error(void) { return g_err; }
 
 // compute units of the current device (init-once attribute cache; partitioned / CU-masked devices report fewer than 256)

@@ -159,6 +159,9 @@ _SIGS = {
 }
 
 
+ABI_VERSION = 300      # include/las_hip.h LAS_HIP_ABI_VERSION
+
+
 def declared_symbols():
     return sorted(_SIGS)
 
@@ -182,6 +185,9 @@ def lib():
             fn.argtypes = args
         if missing and not os.environ.get("LAS_ALLOW_PARTIAL"):
             raise RuntimeError("liblas_hip.so does not export: %s" % ", ".join(missing))
+        if "las_version" not in missing and l.las_version() != ABI_VERSION:       # argument structs are laid out by this file: a stale build
+            raise RuntimeError("liblas_hip.so at %s was built from another include/las_hip.h (ABI %d, this package binds %d): rebuild it"
+                               % (LIB_PATH, l.las_version(), ABI_VERSION))
         # development switches (A/B measurements, `make prof` builds only -- the shipping library does not export them): LAS_DEV_KK_BIG=0 -> 128 x 128 tiles only in las_gemm_kk;
         # LAS_DEV_ZGROUP=0 -> 3-D grid order for split-K / batched las_gemm; LAS_DEV_TN_TR=0 -> weight gradients through the
         # register-transposing kernel instead of the LDS-transposing one

@@ -37,6 +37,8 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
+#define LAS_HIP_ABI_VERSION 300      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+                                        built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
 

@@ -36,7 +36,8 @@ def test_library_exports_every_declared_symbol(libpath):
     from las import _hip
     assert sorted(_hip.declared_symbols()) == names          # the ctypes table covers the whole header
     l = _hip.lib()
-    assert l.las_version() >= 100
+    hdr = open(os.path.join(helpers.ROOT, 'include', 'las_hip.h')).read()
+    assert l.las_version() == _hip.ABI_VERSION == int(re.search(r'#define LAS_HIP_ABI_VERSION (\d+)', hdr).group(1))   # header, library, binding
     assert l.las_last_error() is not None
     # workspace queries are pure host arithmetic: callable without a GPU
     assert l.las_rnn_seq_workspace_bytes(1, 1, 256, 48) >= 2 * 4 * 256 * 256 * 4
