@@ -533,6 +533,10 @@ static bool g_tn_tr_on = true;
 #ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_tn_tr(int on) { g_tn_tr_on = on != 0; }       // development switch (A/B measurements)
 #endif
+static bool g_f32_valu = false;      // parity-mode products through the round-1 VALU tile loop instead of the exact-fp32 MFMA kernel
+#ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
+extern "C" void las_dev_gemm_f32_valu(int on) { g_f32_valu = on != 0; }
+#endif
 static bool g_zgroup_on = true;
 #ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_zgroup(int on) { g_zgroup_on = on != 0; }     // development switch (A/B measurements)
@@ -561,6 +565,116 @@ template <int WM, int WN, int TM, int TN>
 static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
     if (g.in_bf16) launch_fast_t<WM, WN, TM, TN, unsigned short>(g, zdim, st);
     else           launch_fast_t<WM, WN, TM, TN, float>(g, zdim, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact-fp32 MFMA kernel (parity mode, round 4).  v_mfma_f32_16x16x4_f32 is a k-ordered fp32 fma chain -- one rounding per
+// product, bitwise what a per-thread v_fmac loop gives -- at the VALU's peak rate but from one operand register per lane and
+// with the VALU free for addressing: the 64x64x16 VALU tile loop below it replaced ran at ~10 % of that peak.  Same strided
+// operand description as the other kernels (NN / NT / TN, batching, contraction mask, deterministic split-K, fused bias /
+// beta / tanh epilogue), the guarded generic loader, register double buffering: the next k-tile's global loads fly under the
+// 32 x TM x TN MFMAs of the current one.  LDS tiles are k-major ([32][BM + 16] fp32: a lane's A operand is row k0 + (lane >> 4),
+// column m0 + (lane & 15) -- 64 distinct banks).
+// ------------------------------------------------------------------------------------------------
+template <int ROWS>
+struct F32Lds { static constexpr int PITCH = ROWS + 16; };
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void tile_sstore_f32(float* S, const TileRegs<ROWS, NT>& r, long long ks) {
+    constexpr int NCH = ROWS * 8, RQ = ROWS / 4, LP = F32Lds<ROWS>::PITCH;
+#pragma unroll
+    for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (c < NCH) {
+            const float4 v = r.v[i];
+            if (ks == 1) {                           // the chunk runs along k: four rows of the k-major tile
+                const int row = c >> 3, kq = (c & 7) * 4;
+                S[(kq + 0) * LP + row] = v.x; S[(kq + 1) * LP + row] = v.y; S[(kq + 2) * LP + row] = v.z; S[(kq + 3) * LP + row] = v.w;
+            } else {                                 // the chunk runs along the row index: one 16-byte store
+                const int k = c / RQ, rq = (c % RQ) * 4;
+                *reinterpret_cast<float4*>(&S[k * LP + rq]) = v;
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
+    __shared__ __attribute__((aligned(16))) float lds[32 * (PA + PB)];
+    float* As = lds;
+    float* Bs = lds + 32 * PA;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1, li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)blockIdx.z * g.strideA;
+        B += (long long)blockIdx.z * g.strideB;
+        C += (long long)blockIdx.z * g.strideC;
+    }
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    TileRegs<BM, NT> ra;
+    TileRegs<BN, NT> rb;
+    if (kbeg < kend) {
+        tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend, g.vecB, 0, 0);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();
+        tile_sstore_f32<BM, NT>(As, ra, g.ksA);
+        tile_sstore_f32<BN, NT>(Bs, rb, g.ksB);
+        __syncthreads();
+        if (k0 + 32 < kend) {
+            tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+            tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend, g.vecB, 0, 0);
+        }
+        const float* ap = As + lk * PA + wm * TM * 16 + li;
+        const float* bp = Bs + lk * PB + wn * TN * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {             // (k beyond kend was loaded as zeros: whole k-steps always)
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[ks * 4 * PA + i * 16];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[ks * 4 * PB + j * 16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds rows (lane >> 4) * 4 + r, column lane & 15 of each 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * TM + i) * 16 + lk * 4 + r;
+                if (row < g.M && col < g.N) {
+                    if (g.splitk > 1) {
+                        g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r];
+                        if (g.bias) v += g.bias[col];
+                        float* cp = C + (long long)row * g.ldc + col;
+                        if (g.beta != 0.f) v += g.beta * (*cp);
+                        *cp = apply_act(v, g.act);
+                    }
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,6 +783,21 @@ static int launch_bf16(const GemmArgs& g, int zdim, hipStream_t st) {
     return 0;
 }
 
+// Scratch the deterministic split-K of las_gemm would use for this product if it could have all it wants (never more than
+// LAS_GEMM_WS_CAP: beyond that the split degree is cut to fit, with any workspace): tile counts as in las_gemm_dt below.
+extern "C" size_t las_gemm_workspace_bytes(int prec, int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || batch != 1 || K < 2048) return 0;
+    (void)prec;
+    const int b = (M < 128 || N < 128) ? 64 : 128;        // (both precisions; the bf16 48-row tile has one row block like the 64-row one)
+    const long long tiles = (long long)cdiv(M, b) * cdiv(N, b);
+    if (tiles >= 256) return 0;
+    const int want = (int)((512 + tiles - 1) / tiles), maxs = K / 512;
+    const int s = want < maxs ? want : maxs;
+    if (s <= 1) return 0;
+    const size_t need = (size_t)s * M * N * sizeof(float);
+    return need < LAS_GEMM_WS_CAP ? need : LAS_GEMM_WS_CAP;
+}
+
 extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A,
                         int lda, long long strideA, const float* B, int ldb, long long strideB, float beta,
                         float* C, int ldc, long long strideC, const float* bias, int act, int batch,
@@ -713,7 +842,7 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
     const bool fastA = g.vecA && (g.ksA == 1 ? (K % 4 == 0) : (M % 4 == 0 && M >= 4));
     const bool fastB = g.vecB && (g.ksB == 1 ? (K % 4 == 0) : (N % 4 == 0 && N >= 4));
     const bool fast_ok = prec == LAS_PREC_BF16 && fastA && fastB && a_mask_period == 0 && K > 0;
-    if (prec == LAS_PREC_F32) { cfg = 0; BM = 64; BN = 64; }
+    if (prec == LAS_PREC_F32) { cfg = 0; BM = BN = (M < 128 || N < 128) ? 64 : 128; }    // exact-fp32 MFMA tiles
     else if (M <= 48 && !(fast_ok && K >= 4096)) { cfg = 3; BM = 48; BN = 64; }   // tall contractions: 64-row fast tiles win
     else if (M < 128 || N < 128) { cfg = 2; BM = 64; BN = 64; }
     else                      { cfg = 1; BM = 128; BN = 128; }
@@ -780,8 +909,10 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
     }
     switch (cfg) {
         case 0: {
-            dim3 grid(cdiv(N, 64), cdiv(M, 64), zdim);
-            hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
+            dim3 grid(cdiv(N, BN), cdiv(M, BM), zdim);
+            if (g_f32_valu) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64), zdim), dim3(256), 0, st, g);
+            else if (BM == 128) hipLaunchKernelGGL((gemm_mf32_kernel<4, 4>), grid, dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_mf32_kernel<2, 2>), grid, dim3(256), 0, st, g);
         } break;
         case 1: launch_bf16<2, 2, 4, 4>(g, zdim, st); break;
         case 2: launch_bf16<2, 2, 2, 2>(g, zdim, st); break;

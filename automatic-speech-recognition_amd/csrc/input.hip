@@ -31,22 +31,50 @@
 
 namespace {
 
-// ---- crc32c (Castagnoli), masked as the TFRecord framing does (the 8-byte length is always verified) -------------------------
-uint32_t crc_tab[256];
+// ---- crc32c (Castagnoli), masked as the TFRecord framing does.  The 8-byte length is verified when a record is framed, the
+// payload when the batch that contains it is assembled (only the rows this rank keeps: a rank never touches the other rows' pages).
+// Eight bytes per step: the host's crc32 instruction when it has one, slicing-by-8 tables otherwise.
+uint32_t crc_tab[8][256];
+bool crc_hw = false;
 void crc_init() {
     static std::once_flag once;
     std::call_once(once, [] {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            crc_tab[i] = c;
+            crc_tab[0][i] = c;
         }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) crc_tab[t][i] = crc_tab[0][crc_tab[t - 1][i] & 0xFF] ^ (crc_tab[t - 1][i] >> 8);
+#if defined(__x86_64__)
+        crc_hw = __builtin_cpu_supports("sse4.2");
+#endif
     });
 }
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) uint32_t crc_update_hw(uint32_t c, const uint8_t* p, size_t n) {
+    uint64_t c64 = c;
+    while (n && ((uintptr_t)p & 7)) { c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) { uint64_t w; memcpy(&w, p, 8); c64 = __builtin_ia32_crc32di(c64, w); }
+    while (n--) c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++);
+    return (uint32_t)c64;
+}
+#endif
+uint32_t crc_update(uint32_t c, const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+    if (crc_hw) return crc_update_hw(c, p, n);
+#endif
+    for (; n >= 8; n -= 8, p += 8) {
+        uint32_t lo, hi; memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = crc_tab[7][lo & 0xFF] ^ crc_tab[6][(lo >> 8) & 0xFF] ^ crc_tab[5][(lo >> 16) & 0xFF] ^ crc_tab[4][lo >> 24] ^
+            crc_tab[3][hi & 0xFF] ^ crc_tab[2][(hi >> 8) & 0xFF] ^ crc_tab[1][(hi >> 16) & 0xFF] ^ crc_tab[0][hi >> 24];
+    }
+    while (n--) c = crc_tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c;
+}
 uint32_t masked_crc32c(const uint8_t* p, size_t n) {
-    uint32_t c = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; ++i) c = crc_tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
-    c ^= 0xFFFFFFFFu;
+    const uint32_t c = crc_update(0xFFFFFFFFu, p, n) ^ 0xFFFFFFFFu;
     return ((c >> 15) | (c << 17)) + 0xA282EAD8u;
 }
 
@@ -91,6 +119,7 @@ struct Record {              // one parsed utterance: pointers into the mmap'ed 
     const uint8_t* feat = nullptr; size_t nfeat = 0;   // packed little-endian floats at ANY byte offset of the file: kept as bytes, memcpy only
     int T = 0, F = 0;
     std::vector<int> token;
+    const uint8_t* payload = nullptr; size_t npayload = 0;   // the framed record (its trailing masked crc32c sits right behind it)
 };
 
 bool parse_int64_list(Cursor c, std::vector<long long>& out) {
@@ -165,11 +194,11 @@ struct MappedFile {
     // 1: a record, 0: end of file, -1: corrupt
     int next(const uint8_t*& payload, size_t& n) {
         if (pos == size) return 0;
-        if (size - pos < 12) return -1;
+        if (size - pos < 16) return -1;                                    // header + both checksums do not fit: a truncated file
         uint64_t len; uint32_t lcrc;
         memcpy(&len, base + pos, 8); memcpy(&lcrc, base + pos + 8, 4);
         if (masked_crc32c(base + pos, 8) != lcrc) return -1;
-        if (len > size - pos - 16) return -1;
+        if (len > size - pos - 16) return -1;                              // (size - pos >= 16 was checked: no wrap-around)
         payload = base + pos + 12; n = (size_t)len;
         pos += 12 + len + 4;
         return 1;
@@ -216,6 +245,10 @@ struct Reader {
         std::vector<const Record*> mine;
         for (size_t i = rank; i < pb.items.size(); i += world) mine.push_back(&pb.items[i]);
         if (pb.items.size() < (size_t)world) return true;                 // a leftover smaller than the world: dropped on EVERY rank
+        for (const Record* r : mine) {                                    // payload checksum of the rows this rank keeps
+            uint32_t want; memcpy(&want, r->payload + r->npayload, 4);
+            if (masked_crc32c(r->payload, r->npayload) != want) return fail("corrupted TFRecord payload (crc32c mismatch)");
+        }
         const int k = pb.bucket;
         int T = cfg.bounds[k] - 1;
         int s = -1;
@@ -293,6 +326,7 @@ struct Reader {
                     if (rc < 0) { fail("corrupted TFRecord framing in " + mf->path); ok = false; break; }
                     Record r;
                     if (!parse_example(p, n, r) || r.F != cfg.feat_dim) { fail("malformed Example in " + mf->path); ok = false; break; }
+                    r.payload = p; r.npayload = n;
                     ++records;
                     const int k = (int)(std::upper_bound(cfg.bounds, cfg.bounds + nb, r.T) - cfg.bounds);
                     if (k >= nb) { fail("utterance of " + std::to_string(r.T) + " frames exceeds the last bucket boundary " + std::to_string(cfg.bounds[nb - 1])); ok = false; break; }
@@ -334,10 +368,16 @@ struct Reader {
 
 extern "C" unsigned int las_crc32c(const void* data, size_t n) {
     crc_init();
-    const uint8_t* p = (const uint8_t*)data;
-    uint32_t c = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; ++i) c = crc_tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
-    return c ^ 0xFFFFFFFFu;
+    return crc_update(0xFFFFFFFFu, (const uint8_t*)data, n) ^ 0xFFFFFFFFu;
+}
+
+static void destroy(Reader* r) {                       // slots (whatever part of them exists) + the reader itself
+    for (Slot& s : r->slots) {
+        if (s.ev_pending) (void)hipEventSynchronize(s.ev);
+        if (r->pinned) { if (s.feat) (void)hipHostFree(s.feat); if (s.token) (void)hipHostFree(s.token); if (s.ev) (void)hipEventDestroy(s.ev); }
+        else { free(s.feat); free(s.token); }
+    }
+    delete r;
 }
 
 extern "C" void* las_input_open(const char* const* files, int nfiles, const las_input_config* cfg) {
@@ -350,6 +390,11 @@ extern "C" void* las_input_open(const char* const* files, int nfiles, const las_
         if (cfg->batch_limit[k] <= 0 || cfg->bounds[k] <= 1 || (k && cfg->bounds[k] <= cfg->bounds[k - 1])) {
             las_set_error("las_input_open: bucket boundaries must increase and batch limits be positive"); return nullptr;
         }
+    if (!cfg->is_training && cfg->world > 1) {       // an end-of-data leftover smaller than the world would be skipped silently
+        las_set_error("las_input_open: evaluation data is not sharded by the reader (is_training = 0 needs world = 1): read every "
+                      "batch and take this rank's share (las.parallel.shard; test.py / decode.py do)");
+        return nullptr;
+    }
     Reader* r = new Reader();
     r->cfg = *cfg;
     for (int i = 0; i < nfiles; ++i) r->files.emplace_back(files[i]);
@@ -367,10 +412,10 @@ extern "C" void* las_input_open(const char* const* files, int nfiles, const las_
         if (r->pinned && (hipHostMalloc((void**)&s.feat, fb, hipHostMallocDefault) != hipSuccess ||
                           hipHostMalloc((void**)&s.token, tb, hipHostMallocDefault) != hipSuccess ||
                           hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess)) {
-            las_set_error("las_input_open: pinned host allocation failed"); return nullptr;
+            las_set_error("las_input_open: pinned host allocation failed"); destroy(r); return nullptr;
         }
         if (!r->pinned) { s.feat = (float*)aligned_alloc(4096, (fb + 4095) / 4096 * 4096); s.token = (int*)aligned_alloc(4096, (tb + 4095) / 4096 * 4096); }
-        if (!s.feat || !s.token) { las_set_error("las_input_open: host allocation failed"); return nullptr; }
+        if (!s.feat || !s.token) { las_set_error("las_input_open: host allocation failed"); destroy(r); return nullptr; }
     }
     (void)hipGetLastError();
     r->th = std::thread([r] { r->run(); });
@@ -436,10 +481,5 @@ extern "C" void las_input_close(void* h) {
     }
     r->cv_free.notify_all();
     if (r->th.joinable()) r->th.join();
-    for (Slot& s : r->slots) {
-        if (s.ev_pending) (void)hipEventSynchronize(s.ev);
-        if (r->pinned) { (void)hipHostFree(s.feat); (void)hipHostFree(s.token); if (s.ev) (void)hipEventDestroy(s.ev); }
-        else { free(s.feat); free(s.token); }
-    }
-    delete r;
+    destroy(r);
 }

@@ -2282,6 +2282,106 @@ __global__ __launch_bounds__(256) void dlocw_kernel(DecDev a) {
     if (blockIdx.x == 0 && threadIdx.x < C) a.dlocbRows[(size_t)b * C + threadIdx.x] += accb;
 }
 
+// (2b) The same contraction on the matrix cores (round 4; the VALU kernel above took 1.44 ms per step at K = 201, C = 10, B = 48 --
+// two LDS reads per multiply-add).  Per (step, utterance) it is a Toeplitz product
+//     dlocw[k, c] += sum_t' P[t' + k] . dfc[t', c],     P = the previous alignment, zero-padded by (Kc - 1) / 2 on both sides,
+// i.e. [M = taps] x [K = frames] x [N = channels] with A[k][t'] = P[t' + k]: lane (g, r) of an A fragment is 8 CONSECUTIVE elements
+// of the padded array in LDS (no Toeplitz matrix is built, as in loc_conv_mfma); the B fragments are 8 consecutive frames of one
+// channel from a channel-major LDS copy of the step's d f.  fp32 accuracy from bf16 MFMAs by x = hi + lo (hi.hi + hi.lo + lo.hi).
+// Workgroup = (slice s of the decode steps, utterance b), 4 waves x up to 4 tap tiles; the slices' partial sums are reduced in fixed
+// order afterwards (las_colsum over [B * DLW_SPLIT] rows): deterministic.  The bias gradient (column sums of d f) rides along.
+constexpr int DLW_SPLIT = 8;
+__global__ __launch_bounds__(256) void dlocw_mfma_kernel(DecDev a, float* __restrict__ wpart, float* __restrict__ bpart) {
+    extern __shared__ __attribute__((aligned(16))) float sm3[];
+    const int b = blockIdx.y, sp = blockIdx.x, B = a.B, Tp = a.Tp, U = a.U, C = a.C, Kc = a.Kc, pad = (Kc - 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int NKS = (Tp + 31) >> 5, TK = NKS * 32;            // frames rounded up to whole k-steps (the tail holds zeros)
+    const int NMT = (Kc + 15) >> 4;                           // tap tiles (<= 16: Kc <= 256)
+    const int LP = TK + 16 * NMT + 8;                         // padded alignment: index j <-> frame j - pad
+    const int DP = TK + 4;                                    // pitch of the channel-major d f rows
+    float* P = sm3;                                           // [LP]
+    float* dT = sm3 + ((LP + 3) & ~3);                        // [16][DP]
+    float* red = dT + 16 * DP;                                // [16][16] bias-gradient partials
+    const int per = (U + DLW_SPLIT - 1) / DLW_SPLIT, ta = sp * per, tb = min(U, ta + per);
+    f32x4_t acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (int i = tid; i < LP; i += 256) P[i] = 0.f;
+    for (int i = tid; i < 16 * DP; i += 256) dT[i] = 0.f;
+    for (int t = ta; t < tb; ++t) {
+        __syncthreads();
+        const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
+        for (int j = tid; j < Tp * C; j += 256) { const int tt = j / C, c = j - tt * C; dT[c * DP + tt] = ds[j]; }
+        for (int j = tid; j < Tp; j += 256)
+            P[pad + j] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + j] : (a.align0 ? a.align0[(size_t)b * Tp + j] : 0.f);
+        __syncthreads();
+        {   // bias gradient: thread (channel tid >> 4, residue tid & 15) sums its frames
+            const float* row = dT + (tid >> 4) * DP;
+            for (int tt = tid & 15; tt < Tp; tt += 16) accb += row[tt];
+        }
+        for (int ks = 0; ks < NKS; ++ks) {
+            unsigned int bh[4], bl[4];
+            {
+                const float4 x0 = *reinterpret_cast<const float4*>(dT + r * DP + ks * 32 + g * 8);
+                const float4 x1 = *reinterpret_cast<const float4*>(dT + r * DP + ks * 32 + g * 8 + 4);
+                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned short h0 = f2bf(x[2 * e]), h1 = f2bf(x[2 * e + 1]);
+                    bh[e] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+                    bl[e] = f2bf2(x[2 * e] - bf2f(h0), x[2 * e + 1] - bf2f(h1));
+                }
+            }
+            const u16x8_t Bh = __builtin_bit_cast(u16x8_t, (u32x4_t){bh[0], bh[1], bh[2], bh[3]});
+            const u16x8_t Bl = __builtin_bit_cast(u16x8_t, (u32x4_t){bl[0], bl[1], bl[2], bl[3]});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int mt = wv + 4 * i;
+                if (mt < NMT) {
+                    const float* Pp = P + ks * 32 + g * 8 + mt * 16 + r;
+                    unsigned int ah[4], al[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = Pp[2 * e], x1 = Pp[2 * e + 1];
+                        const unsigned short h0 = f2bf(x0), h1 = f2bf(x1);
+                        ah[e] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+                        al[e] = f2bf2(x0 - bf2f(h0), x1 - bf2f(h1));
+                    }
+                    const u16x8_t Ah = __builtin_bit_cast(u16x8_t, (u32x4_t){ah[0], ah[1], ah[2], ah[3]});
+                    const u16x8_t Al = __builtin_bit_cast(u16x8_t, (u32x4_t){al[0], al[1], al[2], al[3]});
+                    acc[i][0] = mfma_bf16_16x16x32(Ah, Bh, acc[i][0]);
+                    acc[i][1] = mfma_bf16_16x16x32(Ah, Bl, acc[i][1]);
+                    acc[i][2] = mfma_bf16_16x16x32(Al, Bh, acc[i][2]);
+                }
+            }
+        }
+    }
+    // C layout: lane (g, n = r) holds taps 16 mt + 4 g + i, channel n
+    float* wo = wpart + ((size_t)b * DLW_SPLIT + sp) * Kc * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mt = wv + 4 * i;
+        if (mt < NMT && r < C)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = mt * 16 + g * 4 + q;
+                if (k < Kc) wo[k * C + r] = acc[i][0][q] + (acc[i][1][q] + acc[i][2][q]);
+            }
+    }
+    __syncthreads();
+    red[tid] = accb;
+    __syncthreads();
+    if (tid < C) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_ += red[tid * 16 + q];
+        bpart[((size_t)b * DLW_SPLIT + sp) * C + tid] = s_;
+    }
+}
+
 // dKeys[b,t',:] = sum over steps t of dE[t,b,t'] * u * (1 - tanh^2(keys[b,t',:] + Q[t,b,:]))  (speed mode, after the loop)
 // workgroup = (utterance, 8 encoder frames); 32 lanes x float4 over the attention dim per frame
 __global__ __launch_bounds__(256) void dkeys_kernel(DecDev a, float* __restrict__ dKeys) {
@@ -2307,8 +2407,92 @@ __global__ __launch_bounds__(256) void dkeys_kernel(DecDev a, float* __restrict_
     }
 }
 
-// demb[v,:] += sum over (t,b) with token v of dXin0[t,b,0:E]  -- stage 1: per (vocab row, row chunk) partials
-// (fixed chunking -> deterministic); stage 2 is las_colsum over the chunk axis.
+// demb[v,:] += sum over the positions (t,b) with token v of dXin0[t,b,0:E] (* the dropout mask).
+// Round 4: the positions are bucketed by token ONCE per step on the device and only the rows that occur are reduced -- the old
+// kernel (grid V x 32, every block scanning its share of the positions for `tok[i] == v`: O(V n) compares) took 1.22 ms at V = 5000.
+//   (1) emb_hist_kernel   one workgroup: token histogram (integer LDS atomics: counts do not depend on the order) + exclusive scan
+//   (2) emb_place_kernel  position i goes to slot start[v] + #{j < i : tok[j] == v}: a STABLE counting sort, each thread counts its
+//                         predecessors in an LDS copy of the token list -- the order inside a bucket is by position, always
+//   (3) emb_reduce_kernel one workgroup per vocabulary row that occurs: four 64-lane groups take its positions round robin, their
+//                         partial sums meet in LDS in fixed order -> deterministic, no atomics on floats
+// Tokens outside [0, V) are ignored, as before.  Serves V <= EMB_MAX_V and n <= EMB_MAX_N (the token list as 16-bit values in LDS).
+constexpr int EMB_MAX_V = 16384, EMB_MAX_N = 49152;
+__global__ __launch_bounds__(1024) void emb_hist_kernel(const int* __restrict__ tok, int n, int V, int* __restrict__ start) {
+    extern __shared__ int cnt[];                  // [V] counts, then [1024] scan partials behind them
+    int* part = cnt + V;
+    const int tid = threadIdx.x;
+    for (int v = tid; v < V; v += 1024) cnt[v] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) { const int v = tok[i]; if (v >= 0 && v < V) atomicAdd(&cnt[v], 1); }
+    __syncthreads();
+    const int per = (V + 1023) / 1024, v0 = tid * per, v1 = min(V, v0 + per);
+    int s_ = 0;
+    for (int v = v0; v < v1; ++v) s_ += cnt[v];
+    part[tid] = s_;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {    // inclusive scan of the partials
+        const int x = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int v = v0; v < v1; ++v) { start[v] = run; run += cnt[v]; }
+    if (tid == 1023) start[V] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void emb_place_kernel(const int* __restrict__ tok, int n, int V, const int* __restrict__ start,
+                                                        int* __restrict__ pos) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short tk[];       // tokens [0, end of this block) (0xFFFF = ignored)
+    const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x, iend = min(n, i0 + 256);
+    for (int j = threadIdx.x; j < ((iend + 7) & ~7); j += 256) {
+        const int v = j < iend ? tok[j] : -1;
+        tk[j] = (v >= 0 && v < V) ? (unsigned short)v : (unsigned short)0xFFFF;
+    }
+    __syncthreads();
+    if (i >= n) return;
+    const unsigned v = tk[i];
+    if (v == 0xFFFFu) return;
+    int rank = 0;
+    const uint4* t8 = reinterpret_cast<const uint4*>(tk);
+    const unsigned vv = v | (v << 16);
+    for (int j8 = 0; j8 < i0 / 8; ++j8) {          // whole groups of 8 in front of this block: the same address for every thread
+        const uint4 q = t8[j8];
+        const unsigned w[4] = {q.x ^ vv, q.y ^ vv, q.z ^ vv, q.w ^ vv};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rank += ((w[e] & 0xFFFFu) == 0) + ((w[e] >> 16) == 0);
+    }
+    for (int j = i0; j < i; ++j) rank += tk[j] == v;
+    pos[start[v] + rank] = i;
+}
+
+__global__ __launch_bounds__(256) void emb_reduce_kernel(const int* __restrict__ start, const int* __restrict__ pos,
+                                                         const float* __restrict__ dXin0, int ld, int E, const float* __restrict__ mask,
+                                                         float* __restrict__ demb) {
+    __shared__ float red[4][256];
+    const int v = blockIdx.x, s0 = start[v], s1 = start[v + 1];
+    if (s0 == s1) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = s0 + grp; k < s1; k += 4) {
+            const size_t i = (size_t)pos[k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + lane + 64 * q;
+                if (e < E) acc[q] += dXin0[i * ld + e] * (mask ? mask[i * E + e] : 1.f);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[grp][lane + 64 * q] = acc[q];
+        __syncthreads();
+        const int e = e0 + threadIdx.x;
+        if (e < E) demb[(size_t)v * E + e] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+
+// the round-1 form (any V, any n): per (vocab row, row chunk) partials, then las_colsum over the chunk axis
 constexpr int EMB_CHUNKS = 32;
 __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const float* dXin0, int n, int ld, int E, int V,
                                                        const float* mask, float* part) {
@@ -2329,7 +2513,7 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dWf, dV, fcS, dfcS, gemm, total;
+    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dlocwP, dlocbP, dWf, dV, fcS, dfcS, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -2350,7 +2534,8 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.encbf = o;  o += align256((size_t)B * Tp * Hd * 2);
     w.encbf2 = o; o += align256((size_t)B * (Tp + 1) * Hd * 2);
     w.dE = o;     o += align256((size_t)U * B * Tp * f);
-    w.embp = o;   o += align256((size_t)EMB_CHUNKS * V * E * f);
+    w.embp = o;   o += align256((V <= EMB_MAX_V && (size_t)U * B <= EMB_MAX_N) ? ((size_t)V + 1 + (size_t)U * B) * sizeof(int)      // start[V + 1] + pos[n]
+                                                                                   : (size_t)EMB_CHUNKS * V * E * f);
     w.dHl = o;    o += align256((size_t)U * B * D * f);
     w.dH = o;     o += align256((size_t)NL * B * D * f);
     w.dC = o;     o += align256((size_t)NL * B * D * f);
@@ -2366,6 +2551,8 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.dV = o;     o += align256(C > 0 ? (size_t)B * Tp * A * f : 0);
     w.fcS = o;    o += align256(C > 0 ? (size_t)U * B * Tp * C * f : 0);
     w.dfcS = o;   o += align256(C > 0 ? (size_t)U * B * Tp * C * f : 0);
+    w.dlocwP = o; o += align256(C > 0 ? (size_t)B * DLW_SPLIT * Kc * C * f : 0);      // dlocw_mfma_kernel: one partial per (utterance, step slice); written whole
+    w.dlocbP = o; o += align256(C > 0 ? (size_t)B * DLW_SPLIT * C * f : 0);
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
@@ -2743,20 +2930,46 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     if (loop)   // dXin0[:, :, 0:E] = dG . W0[0:E, :]^T for all steps at once (the loop kernel left these columns out)
         GEMM_OK(las_gemm(prec, 0, 1, UB, E, GD, 1.f, d.gates, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0, I0D, 0, nullptr, LAS_ACT_NONE, 1,
                          0, 0, nullptr, 0, st));
-    {
+    if (V <= EMB_MAX_V && UB <= EMB_MAX_N) {      // bucket the positions by token, reduce the rows that occur (accumulates into demb)
+        int* estart = (int*)(base + w.embp);
+        int* epos = estart + V + 1;
+        hipLaunchKernelGGL(emb_hist_kernel, dim3(1), dim3(1024), (size_t)(V + 1024) * sizeof(int), st, (const int*)d.tok_in, UB, V, estart);
+        LAS_LAUNCHED();
+        hipLaunchKernelGGL(emb_place_kernel, dim3(cdiv(UB, 256)), dim3(256), (size_t)((UB + 263) & ~7) * sizeof(unsigned short), st,
+                           (const int*)d.tok_in, UB, V, (const int*)estart, epos);
+        LAS_LAUNCHED();
+        hipLaunchKernelGGL(emb_reduce_kernel, dim3(V), dim3(256), 0, st, (const int*)estart, (const int*)epos, (const float*)d.dXin0, I0D, E,
+                           (const float*)d.emb_mask, bk->demb);
+        LAS_LAUNCHED();
+    } else {
         float* epart = (float*)(base + w.embp);
         hipLaunchKernelGGL(emb_grad_kernel, dim3(V, EMB_CHUNKS), dim3(256), 0, st, (const int*)d.tok_in, (const float*)d.dXin0, UB, I0D,
                            E, V, d.emb_mask, epart);
         LAS_LAUNCHED();
         GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
     }
+    bool loc_rows = loc;                           // the per-utterance rows dlocwRows / dlocbRows hold the filter / bias gradient
     if (locloop) {  // filter / bias gradient from the saved d f rows of every step
-        hipLaunchKernelGGL(dlocw_kernel, dim3(cdiv(d.Kc * d.C, 256), B), dim3(256), (size_t)(Tp * d.C + Tp) * sizeof(float), st, d);
-        LAS_LAUNCHED();
+        const int nks = (Tp + 31) / 32, nmt = (d.Kc + 15) / 16;
+        const size_t lds = (size_t)(((nks * 32 + 16 * nmt + 8 + 3) & ~3) + 16 * (nks * 32 + 4) + 256) * sizeof(float);
+        if (nmt <= 16 && lds <= 64 * 1024) {
+            float* wp = (float*)(base + w.dlocwP);
+            float* bp = (float*)(base + w.dlocbP);
+            hipLaunchKernelGGL(dlocw_mfma_kernel, dim3(DLW_SPLIT, B), dim3(256), lds, st, d, wp, bp);
+            LAS_LAUNCHED();
+            GEMM_OK(las_colsum(wp, B * DLW_SPLIT, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
+            GEMM_OK(las_colsum(bp, B * DLW_SPLIT, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
+            loc_rows = false;
+        } else {
+            hipLaunchKernelGGL(dlocw_kernel, dim3(cdiv(d.Kc * d.C, 256), B), dim3(256), (size_t)(Tp * d.C + Tp) * sizeof(float), st, d);
+            LAS_LAUNCHED();
+        }
     }
-    if (loc) {
+    if (loc_rows) {
         GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
         GEMM_OK(las_colsum(d.dlocbRows, B, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
+    }
+    if (loc) {
         GEMM_OK(las_colsum(d.dWfRows, B * RNG, d.C * A, d.C * A, 1.f, bk->dWf, gws, gws_bytes, st));
     }
     return 0;

@@ -180,8 +180,9 @@ class CharRNN(object):
     def run_epoch(self, session, data_size, batch_generator, is_training, verbose=0, freq=10, summary_writer=None, debug=False,
                   divide_by_n=1):
         """One pass over `data_size` characters (the reference's epoch driver, lang/char_rnn_model.py:195-244: same signature and
-        return value).  Returns (perplexity of the mean batch loss, None, global_step).  The per-batch losses stay on the device and
-        are read back once per progress report / once at the end, so the loop never waits for a step."""
+        return value).  Returns (perplexity of the mean batch loss, None, global_step).  The losses are summed ON THE DEVICE into one
+        running scalar that is read back once per progress report / once at the end: the loop never waits for a step, and a pass of
+        millions of one-character batches (train_lm's test pass: batch_size = num_unrollings = 1) keeps one tensor alive, not one each."""
         per_batch = self.batch_size * self.num_unrollings
         n_batches = -(-data_size // per_batch) // divide_by_n
         if verbose > 0:
@@ -190,21 +191,24 @@ class CharRNN(object):
             logging.info('num_unrollings: %d', self.num_unrollings)
             logging.info('batch_size: %d', self.batch_size)
         t0 = time.time()
-        losses, state = [], None
+        total, count, state = None, 0, None
         self._sum_mean_loss, self._count = 0.0, 0.0
 
         def perplexity():
-            self._sum_mean_loss = float(torch.stack(losses).sum()) if losses else 0.0
-            self._count = float(len(losses))
-            return float(np.exp(self._sum_mean_loss / self._count)) if losses else float("nan")
+            self._sum_mean_loss = float(total) if total is not None else 0.0       # the one read-back
+            self._count = float(count)
+            return float(np.exp(self._sum_mean_loss / self._count)) if count else float("nan")
 
         def rate():
-            return len(losses) * per_batch / max(time.time() - t0, 1e-9)
+            return count * per_batch / max(time.time() - t0, 1e-9)
 
         for k in range(n_batches):
             ids = batch_generator.next_ids()                            # [U + 1, B]: row u + 1 is the target of row u
             loss, state = self.train_step(ids[:-1].T, ids[1:].T, state, train=is_training)
-            losses.append(loss.detach())
+            # the reference's loss monitor is a running sum too (tf.Variable sum_mean_loss, lang/char_rnn_model.py:151-166); float64
+            # here: a float32 running sum stops taking the per-batch terms in after ~1e7 of them
+            total = loss.detach().to(torch.float64) if total is None else total + loss.detach()
+            count += 1
             if verbose > 0 and (k + 1) % freq == 0:
                 logging.info("%.1f%%, step:%d, perplexity: %.3f, speed: %.0f words", 100.0 * (k + 1) / max(n_batches * divide_by_n, 1), k,
                              perplexity(), rate())

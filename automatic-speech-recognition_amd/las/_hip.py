@@ -90,6 +90,7 @@ _SIGS = {
     "las_gemm_dt": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_longlong,
                             c_void_p, c_int, c_longlong, c_int, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "las_gemm_kk": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
                             c_void_p, c_int, c_void_p]),
     "las_gemm_kk_tanhgrad": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
@@ -159,7 +160,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 300      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 400      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():
@@ -192,7 +193,7 @@ def lib():
         # LAS_DEV_ZGROUP=0 -> 3-D grid order for split-K / batched las_gemm; LAS_DEV_TN_TR=0 -> weight gradients through the
         # register-transposing kernel instead of the LDS-transposing one
         for env, sym in (("LAS_DEV_KK_BIG", "las_dev_gemm_kk_big"), ("LAS_DEV_ZGROUP", "las_dev_gemm_zgroup"),
-                         ("LAS_DEV_TN_TR", "las_dev_gemm_tn_tr")):
+                         ("LAS_DEV_TN_TR", "las_dev_gemm_tn_tr"), ("LAS_DEV_F32_VALU", "las_dev_gemm_f32_valu")):
             if os.environ.get(env) is not None and hasattr(l, sym):
                 getattr(l, sym)(int(os.environ[env]))
         _lib = l
@@ -246,20 +247,45 @@ def workspace_epoch(dev, tag):
     return _ws_epoch.get((_devkey(dev), tag), 0)
 
 
-GEMM_WS_BYTES = 256 << 20
+GEMM_WS_BYTES = 256 << 20        # include/las_hip.h LAS_GEMM_WS_CAP
 
 
-# ---- side stream for work that is off the dependency chain (weight gradients during the BPTT sweeps) ----
-_side_stream = None
+# ---- auxiliary streams ------------------------------------------------------------------------------------------------------------
+# The train step hands work between the launch stream and three auxiliary streams WHILE kernels of both run: side (weight gradients
+# during the BPTT sweeps, x-projection chunks a running forward sweep waits for), chain (the backward hand-over's chunks), comm (the
+# data-parallel exchange's early part).  That only works when every one of them has a hardware queue of its own: HIP multiplexes the
+# streams of one priority onto GPU_MAX_HW_QUEUES (4) hardware queues in the order of their first use, and two streams on one queue
+# serialise (tools/probe_streams.py, profiles/r4_probe_streams.txt: with nine other streams used first, a fresh torch.cuda.Stream()
+# lands on the launch stream's queue one time in four -- round 3's silent loss of the hand-overs in the driver's pytest process).
+# So the three are created TOGETHER, at the first use of the library on a device, at HIGH priority: HIP keeps a separate queue pool per
+# priority, so no stream anybody else creates (torch's pool hands out normal-priority streams) can ever share a queue with them,
+# whatever the process did before.  LAS_AUX_PRIORITY=0 puts them back into the normal pool (A/B measurements).
+AUX_PRIORITY = int(os.environ.get("LAS_AUX_PRIORITY", "-1"))
+_aux = {}
 _side_used = False
 _on_side = False
+_chain_used = False
+
+
+def aux_streams(dev=None):
+    """{'side', 'chain', 'comm'} of a device, created (and given their hardware queues: a stream's first launch does that) on first use"""
+    key = _devkey("cuda" if dev is None else dev)
+    a = _aux.get(key)
+    if a is None:
+        d = torch.device(key)
+        with torch.cuda.device(d):
+            a = {n: torch.cuda.Stream(device=d, priority=AUX_PRIORITY) for n in ("side", "chain", "comm")}
+            w = torch.zeros(4, dtype=torch.int32, device=d)
+            for i, st in enumerate(a.values()):
+                with torch.cuda.stream(st):
+                    check(lib().las_set_word(p(w[i:]), 1, stream()), "las_set_word")
+            torch.cuda.synchronize(d)
+        _aux[key] = a
+    return a
 
 
 def side_stream():
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
-    return _side_stream
+    return aux_streams()["side"]
 
 
 class on_side_stream:
@@ -287,17 +313,10 @@ class on_side_stream:
         return self.ctx.__exit__(*exc)
 
 
-_chain_stream = None
-_chain_used = False
-
-
 def chain_stream():
     """Second auxiliary stream: chunks of dependency-chain GEMMs that run WHILE the sweep that consumes them runs (the side
     stream cannot carry them: its weight-gradient GEMMs are held back / long)."""
-    global _chain_stream
-    if _chain_stream is None:
-        _chain_stream = torch.cuda.Stream()
-    return _chain_stream
+    return aux_streams()["chain"]
 
 
 class on_chain_stream:
@@ -328,16 +347,10 @@ def join_chain_stream():
         _chain_used = False
 
 
-_comm_stream = None
-
-
 def comm_stream():
     """Stream the data-parallel exchange of the bucket's early part is issued from (orders it behind main / side / chain work
     without making any of those streams wait for the collective)."""
-    global _comm_stream
-    if _comm_stream is None:
-        _comm_stream = torch.cuda.Stream()
-    return _comm_stream
+    return aux_streams()["comm"]
 
 
 _deferred = []
@@ -379,13 +392,17 @@ def gemm(prec, A, B, C, transA=False, transB=False, M=None, N=None, K=None, lda=
     require_gpu(A, B, C, bias)
     if A.dtype != B.dtype:
         raise RuntimeError("las_gemm: operands must share one element type (got %s, %s)" % (A.dtype, B.dtype))
-    ws = workspace(C.device, GEMM_WS_BYTES, _tag("gemm"))
+    # split-K scratch sized by what THIS product's split wants (las_gemm_workspace_bytes; the buffer per (device, stream) only grows):
+    # nine streams used to pin 256 MB each whatever they ran.  The byte count handed over is capped so a buffer grown by another
+    # product cannot change this one's split degree (= its summation order).
+    need = int(lib().las_gemm_workspace_bytes(prec, M, N, K, batch))
+    ws = workspace(C.device, need, _tag("gemm")) if need else None
     es = A.element_size()
     rc = lib().las_gemm_dt(prec, int(transA), int(transB), M, N, K, alpha,
                            c_void_p(A.data_ptr() + es * a_off), lda, strideA,
                            c_void_p(B.data_ptr() + es * b_off), ldb, strideB, DT_BF16 if A.dtype == torch.bfloat16 else DT_F32, beta,
                            c_void_p(C.data_ptr() + 4 * c_off), ldc, strideC, p(bias), act, batch,
-                           mask_period, mask_skip, p(ws), ws.numel(), stream())
+                           mask_period, mask_skip, p(ws), min(ws.numel(), GEMM_WS_BYTES) if need else 0, stream())
     check(rc, "las_gemm")
 
 
@@ -516,7 +533,7 @@ SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARME
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS = 1, 2, 4, 8, 16
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
-                 "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_XPROJ_CHUNK=0)",
+                 "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_ALLOW_SERIAL_STREAMS=1)",
               2: "BPTT sweep: a cluster partner did not publish its partial dh within the spin bound",
               3: "Speller loop kernel: a partner workgroup was not seen within the poll bound (the one-launch decode loop needs one "
                  "workgroup per compute unit co-resident; on a shared / partitioned device set LAS_NO_FUSED_STEP=1)"}
@@ -581,36 +598,65 @@ def next_announce():
 
 
 _overlap = {}
+ALLOW_SERIAL_STREAMS = bool(os.environ.get("LAS_ALLOW_SERIAL_STREAMS"))
+
+
+def _probe_overlap(dev, other):
+    """ms a bounded (4 ms) waiter on the current stream needs when the store it waits for is issued on `other` right behind it
+    (best of two): ~0.03 when the two streams' kernels run side by side, the bound when they share a queue / are serialised"""
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    best = 1e9
+    for _ in range(2):
+        flag[0:1].zero_()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().las_wait_word(p(flag), 1, 4000, stream()), "las_wait_word")
+        e1.record()
+        with torch.cuda.stream(other):
+            check(lib().las_set_word(p(flag), 1, stream()), "las_set_word")
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1))
+    return best
 
 
 def streams_overlap(dev):
     """True if kernels of the launch stream and of BOTH auxiliary streams (side: x-projection chunks, held weight gradients;
-    chain: the backward hand-over's chunks) really run concurrently on this device (probed once per stream): a bounded waiter on
-    the current stream, then the store it waits for on the other stream.  Under a tool that serialises kernels (rocprofv3
-    --pmc), or when two streams share one hardware queue, the waiter runs into its bound; the cross-stream hand-overs are then
-    switched off."""
-    key = _devkey(dev)
-    if key not in _overlap:
-        ok = True
-        for other in (side_stream(), chain_stream()):
-            flag = torch.zeros(2, dtype=torch.int32, device=dev)
-            with torch.cuda.stream(other):                            # (a stream's first launch creates its hardware queue)
-                check(lib().las_set_word(p(flag[1:]), 1, stream()), "las_set_word")
-            best = 1e9
-            for _ in range(2):
-                flag[0:1].zero_()
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                check(lib().las_wait_word(p(flag), 1, 4000, stream()), "las_wait_word")
-                e1.record()
-                with torch.cuda.stream(other):
-                    check(lib().las_set_word(p(flag), 1, stream()), "las_set_word")
-                torch.cuda.synchronize(dev)
-                best = min(best, e0.elapsed_time(e1))
-            ok = ok and best < 2.0
-        _overlap[key] = ok
-    return _overlap[key]
+    chain: the backward hand-over's chunks) really run concurrently on this device: a bounded waiter on the current stream,
+    then the store it waits for on the other stream.  Probed once per (device, launch stream); a True is cached.
+
+    The auxiliary streams own their hardware queues by construction (aux_streams), so on a bare MI355X this cannot fail; it does
+    under a tool that serialises kernels (rocprofv3 --pmc), or with another high-priority stream of the caller's on the same queue.
+    The cross-stream hand-overs are what the timed step runs, so losing them is an ERROR, not a mode to fall into quietly: a failed
+    probe is repeated once and then raises -- unless LAS_ALLOW_SERIAL_STREAMS=1 says that serialised streams are expected (counter
+    passes), in which case the hand-overs are switched off and `last_variants` of the step says so."""
+    a = aux_streams(dev)
+    cur = torch.cuda.current_stream(dev)
+    if any(cur == st for st in a.values()):
+        # asked from inside an auxiliary stream's context (the Speller's side-stream part): the answer is the launch stream's
+        known = [v for (d, _), v in _overlap.items() if d == _devkey(dev)]
+        if known:
+            return all(known)
+        with torch.cuda.stream(torch.cuda.default_stream(dev)):
+            return streams_overlap(dev)
+    key = (_devkey(dev), cur.stream_id)
+    ok = _overlap.get(key)
+    if ok is None:
+        worst = 0.0
+        for attempt in range(2):
+            worst = max(_probe_overlap(dev, a["side"]), _probe_overlap(dev, a["chain"]))
+            if worst < 2.0:
+                break
+        ok = worst < 2.0
+        if not ok and not ALLOW_SERIAL_STREAMS:
+            raise RuntimeError(
+                "liblas_hip: kernels of the launch stream and of the auxiliary streams do not run concurrently on %s (a waiter needed "
+                "%.1f ms for a store issued on another stream).  The train step's cross-stream hand-overs (x-projection chunks, "
+                "backward hand-over, held weight gradients) need that.  Under a tool that serialises kernels (rocprofv3 --pmc) set "
+                "LAS_ALLOW_SERIAL_STREAMS=1 (the hand-overs are then switched off); otherwise run the step on the default stream."
+                % (key[0], worst))
+        _overlap[key] = ok                      # (a False is only ever cached when the environment asked for it)
+    return ok
 
 
 def hold_until_next_sweep(dev, max_us=1500):

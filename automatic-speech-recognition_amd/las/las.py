@@ -214,6 +214,7 @@ class _SpellerLoop(torch.autograd.Function):
                     for t in held:
                         t.record_stream(side)
                     if L.HOLD_SIDE and _hip.streams_overlap(enc.device):
+                        L.VARIANTS["hold_side"] += 1
                         # these products would otherwise start beside the chain GEMMs in front of the listener's first BPTT sweep
                         # (r3 timeline: the dense layer's dX product took 101 us next to them): wait until that sweep is resident
                         _hip.hold_until_last_sweep(enc.device)
@@ -524,6 +525,7 @@ class LAS:
         self.id_to_token = id_to_token
         self.dp = None            # optional las.parallel.DataParallel (set by train.py)
         self.last = {}
+        self.last_variants = {}   # layers.VARIANTS of the last train step: which cross-stream hand-overs it used
 
     # -- helpers -----------------------------------------------------------------------------------
     @staticmethod
@@ -649,6 +651,7 @@ class LAS:
                 L.BEFORE_TAIL_HOOK[0] = None
             _hip.join_side_stream()                   # weight gradients accumulated on the side stream
             L.check_handovers_consumed()
+        self.last_variants = dict(L.VARIANTS)          # which cross-stream hand-overs this step really used (tests / bench.py assert on it)
         if self.dp is not None:
             # one flat bucket (C1); its first slot carries this rank's sweep status, so that a time-out on ANY rank makes EVERY
             # rank skip the update (las_clip_adam's guard) and the replicas stay identical

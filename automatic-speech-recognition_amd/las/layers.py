@@ -343,9 +343,20 @@ def _chunk_flag(dev):
 _RING = 32
 
 
+# Which schedule variants the current step used (LAS.train copies it into `las.last_variants`): sweeps launched with their x-projection
+# still arriving in chunks (-> rnn_seq_fwd_hw_kernel's chunk waits), BPTT sweeps launched on an upstream gradient still arriving in
+# chunks (-> the rnn_seq_bwd_ks_kernel<..., CH = true> instance), side-stream weight-gradient groups held until the next sweep is
+# resident; "serial": hand-overs that ran with their producers in front of the consumer on one stream (LAS_ALLOW_SERIAL_STREAMS=1 under a
+# tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
+# that is timed must be the variant that is tested.
+VARIANTS = {"xproj_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0}
+
+
 def begin_step(dev):
     """Called by LAS.train at the start of a step (all streams of the previous step joined): ONE fill zeroes the whole ring of
     hand-over words instead of one 5 us fill in front of every sweep and every chunked dense product (11 per step, on the chain)."""
+    for k in VARIANTS:
+        VARIANTS[k] = 0
     ring = _CHUNK_FLAGS.setdefault(str(dev), [torch.zeros(_RING, dtype=torch.int32, device=dev), 0, 0])
     ring[0].zero_()
     ring[1], ring[2] = 0, _RING
@@ -437,9 +448,16 @@ class _Dense16(torch.autograd.Function):
                     # in front of that launch); at the latest by the next run_deferred()
                     if chain_done:
                         return
-                    with _hip.on_chain_stream(after=first):
-                        for t in (dpre, dx, flag):
-                            t.record_stream(_hip.chain_stream())
+                    if _hip.streams_overlap(dy.device):
+                        with _hip.on_chain_stream(after=first):
+                            for t in (dpre, dx, flag):
+                                t.record_stream(_hip.chain_stream())
+                            for k in range(1, nch):
+                                produce(k)
+                                mine(k)
+                            chain_done.append(torch.cuda.Event())
+                            chain_done[0].record()
+                    else:                              # serialised streams: same products, this stream, in front of the consumer
                         for k in range(1, nch):
                             produce(k)
                             mine(k)
@@ -507,7 +525,7 @@ class _BLSTM16(torch.autograd.Function):
             chunk_flag, cs = None, XPROJ_CHUNK_STEPS
             if ROW_T[0] is not None:
                 cs = 0                                   # rows of different lengths (inference): whole x-projection, las_rnn_seq_fwd_rows
-            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H) and _hip.streams_overlap(dev):
+            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H):
                 # The sweep consumes the x-projection in time order (forward direction from t = 0, backward from t = T - 1), so only
                 # the first chunk of frames -- both ends of the sequence -- has to exist when it starts: chunk 0 on this stream,
                 # the others on the side stream WHILE the sweep runs (it holds a fifth of the CUs); the sweep's helper waves wait
@@ -523,10 +541,17 @@ class _BLSTM16(torch.autograd.Function):
                     _hip.set_word(chunk_flag, k + 1)
 
                 chunk(0)
-                with _hip.on_side_stream():
-                    side = _hip.side_stream()
-                    for t in (x, gates, chunk_flag):
-                        t.record_stream(side)
+                if _hip.streams_overlap(dev):
+                    with _hip.on_side_stream():
+                        side = _hip.side_stream()
+                        for t in (x, gates, chunk_flag):
+                            t.record_stream(side)
+                        for k in range(1, nch):
+                            chunk(k)
+                else:
+                    # serialised streams (LAS_ALLOW_SERIAL_STREAMS=1, counter passes): the SAME kernel instances -- chunk products and
+                    # the chunk-aware sweep -- with every producer in front of its consumer on this stream
+                    VARIANTS["serial"] += 1
                     for k in range(1, nch):
                         chunk(k)
             else:
@@ -543,6 +568,8 @@ class _BLSTM16(torch.autograd.Function):
         row_T = ROW_T[0]
         if row_T is not None and (two or torch.is_grad_enabled() or not _hip.rnn_seq_fwd_rows_ok(_cellid(cell), prec, B, H)):
             raise RuntimeError("rows of different lengths (layers.ROW_T) are an inference-only path of the 8-row speed-mode sweep")
+        VARIANTS["sweeps_fwd"] += 1
+        VARIANTS["xproj_chunks"] += int(not two and chunk_flag is not None)
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs,
                          row_T=row_T)
@@ -580,13 +607,19 @@ class _BLSTM16(torch.autograd.Function):
             dc[3]()
             _hip.join_chain_stream()
             dc = None
+        VARIANTS["sweeps_bwd"] += 1
+        VARIANTS["dout_chunks"] += int(dc is not None)
+        serial = dc is not None and not _hip.streams_overlap(dev)
+        if serial:
+            VARIANTS["serial"] += 1
+            dc[3]()                          # serialised streams: every chunk in front of the (same, chunk-aware) sweep
         # gates: activated gates -> d(pre-activation) (bf16), in place; the sweep accumulates the bias gradients in fp32
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
                          db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None,
                          chunk_flag=None if dc is None else dc[0], chunk_rows=0 if dc is None else dc[1],
                          n_rows=0 if dc is None else dc[2])
-        if dc is not None:
+        if dc is not None and not serial:
             dc[3]()                          # the other chunks: chain stream, enqueued behind the sweep's launch
             _hip.join_chain_stream()         # (they are finished when the sweep is; this orders later readers of dout)
         dx = dx_bw = None
@@ -595,14 +628,14 @@ class _BLSTM16(torch.autograd.Function):
             Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
             c = DOUT_CHUNK_ROWS
-            if ctx.x_is_tanh and ctx.in_pyramid and c and T >= 4 * c and direct and _hip.streams_overlap(dev):
+            if ctx.x_is_tanh and ctx.in_pyramid and c and T >= 4 * c and direct:
                 # first time chunk only; the dense node below (the consumer of this dPre) interleaves the others with its own.
                 # (Only inside pBLSTMLayer's stack, where that dense node's input gradient goes to the recurrent layer below and
                 #  nowhere else: a consumer that does not know about the chunks would read an unfinished tensor.)
                 th = (T + 1) // 2
 
                 def produce(k):
-                    if k == 1:
+                    if k == 1 and _hip.streams_overlap(dev):
                         for t in (gates, x, dx):
                             t.record_stream(_hip.chain_stream())
                     lo0, lo1 = k * c, min((k + 1) * c, th)
@@ -658,6 +691,7 @@ class _BLSTM16(torch.autograd.Function):
                         if chain_done:
                             side.wait_event(chain_done[0])
                     elif hold:
+                        VARIANTS["hold_side"] += 1
                         # keep the side stream (these GEMMs and whatever is queued behind them) off the machine until the NEXT
                         # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
                         # front of it; bounded wait, scheduling only

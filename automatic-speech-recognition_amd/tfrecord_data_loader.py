@@ -286,6 +286,10 @@ class _BucketedIterator:
         self.shuffle_buffer = shuffle_buffer if is_training else 0
         self.cycle_length = cycle_length
         self.rank, self.world = int(rank), max(int(world), 1)
+        if not is_training and self.world > 1:
+            # an end-of-data leftover smaller than the world would be skipped on every rank: WER / loss from an incomplete set
+            raise ValueError("evaluation data is not sharded by the reader (is_training=False needs world=1): read every batch "
+                             "and take this rank's share (las.parallel.shard; test.py / decode.py do)")
         self.initializer = None                                           # API parity with make_initializable_iterator
         self._gen = self._batches()
 
@@ -297,7 +301,7 @@ class _BucketedIterator:
         while True:
             while len(active) < self.cycle_length:
                 try:
-                    active.append(tf_record_iterator(next(it)))
+                    active.append(tf_record_iterator(next(it), verify_payload_crc=True))     # as TFRecordDataset does (and csrc/input.hip)
                 except StopIteration:
                     break
             if not active:

@@ -567,6 +567,9 @@ def main():
                        "cell": a.cell, "per_gpu_batch": B, "global_batch": B * world, "frames": T, "dec_steps": U,
                        "parallelism": "dp%d" % world, "params": st.num_params()},
             "roofline": roof,
+            # which cross-stream hand-overs the timed steps really ran (las.layers.VARIANTS; the GPU tests assert the same dict at this
+            # geometry): chunked x-projections / chunked upstream gradients (-> rnn_seq_bwd_ks_kernel<...,CH=true>) / held weight gradients
+            "schedule": dict(las.last_variants, aux_stream_priority=_hip.AUX_PRIORITY),
             "loss": round(loss, 4),
             "kernel_ms": {k: [round(v[0], 3), v[1] // a.steps] for k, v in sorted(per.items())},
         }

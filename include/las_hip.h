@@ -37,7 +37,7 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
-#define LAS_HIP_ABI_VERSION 300      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+#define LAS_HIP_ABI_VERSION 400      /* bumped whenever an argument struct or a signature changes: las_version() of a library
                                         built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
@@ -61,6 +61,11 @@ int las_gemm(int prec, int transA, int transB, int M, int N, int K,
              float beta, float* C, int ldc, long long strideC,
              const float* bias, int act, int batch,
              int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream);
+
+/* Scratch las_gemm's split-K wants for this product (0: it runs unsplit); at most LAS_GEMM_WS_CAP.  A caller that passes at least
+ * this much gets the same split -- hence bit-identical sums -- whatever else its buffer could hold. */
+#define LAS_GEMM_WS_CAP ((size_t)256 << 20)
+size_t las_gemm_workspace_bytes(int prec, int M, int N, int K, int batch);
 
 /* las_gemm with both operands in `in_dtype` (LAS_DT_F32 = las_gemm; LAS_DT_BF16: activations / gradients that already
  * live in HBM as bf16 -- the weight-gradient contractions X^T . dZ of the speed mode; branch-free path only: aligned

@@ -131,6 +131,28 @@ def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None,
                 tokens_in=las.speller.last_tokens_in.cpu())
 
 
+def expect_handovers(las, cell, B, H=256, on=True):
+    """The schedule of the step that was just run (las.last_variants) must be the one bench.py times: x-projections and upstream
+    gradients handed over in chunks across streams, weight gradients held -- wherever the kernels serve the configuration
+    (las_rnn_seq_*_chunks_ok) and the knobs are at their defaults.  on=False: the step was run with every hand-over off.
+    A process in which the auxiliary streams cannot overlap with the launch stream never gets here: _hip.streams_overlap raises."""
+    from las import _hip, layers as L
+    v = las.last_variants
+    cid = 1 if cell == "lstm" else 0
+    assert v["sweeps_fwd"] >= 1 and v["sweeps_bwd"] >= 1, v
+    if not on:
+        assert v["xproj_chunks"] == 0 and v["dout_chunks"] == 0 and v["hold_side"] == 0, v
+        return v
+    assert v["serial"] == 0, v
+    if L.XPROJ_CHUNK_STEPS and _hip.rnn_seq_fwd_chunks_ok(cid, 1, B, H):
+        assert v["xproj_chunks"] >= 1, v
+    if L.DOUT_CHUNK_ROWS and _hip.rnn_seq_bwd_chunks_ok(cid, 1, B, H):
+        assert v["dout_chunks"] >= 1, v
+    if L.HOLD_SIDE:
+        assert v["hold_side"] >= 1, v
+    return v
+
+
 def grad_errors(r):
     """{name: max-abs error / max(|oracle gradient|, 1e-3)} for every parameter."""
     out = {}

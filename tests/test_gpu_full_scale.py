@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import grad_errors, make_args, synthetic_batch, train_step_pair
+from helpers import expect_handovers, grad_errors, make_args, synthetic_batch, train_step_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,8 @@ def test_bench_architecture_full_T_train_step(prec, cell):
     assert 150 < U <= 200
     r = train_step_pair(args, cell, prec, xs, ys, seed=3)
     assert r["alphas"].shape[-1] == 160                       # T' in (128, 160]: the <.,10> row-kernel instances
+    if prec == "bf16":
+        expect_handovers(r["las"], cell, 4)                   # the schedule bench.py times (chunked hand-overs), not a serial fallback
     tol = FULL_T_TOL[(prec, cell)]
     errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(),
                 alphas=(r["alphas"] - r["alphas_o"]).abs().max().item(),

@@ -194,8 +194,9 @@ def test_backward_hand_over_in_chunks_gives_the_same_gradients():
     schedule: the chain values bit for bit (same tiles per row), the weight gradients up to split-K summation order."""
     from las import _hip, layers as L, variables as V
     B, T, F, H, layers = 8, 1100, 39, 256, 2
-    if not (_hip.rnn_seq_bwd_chunks_ok(1, 1, B, H) and _hip.streams_overlap(torch.device("cuda", 0))):
-        pytest.skip("chunk-aware BPTT kernel / stream overlap not available in this configuration")
+    assert _hip.rnn_seq_bwd_chunks_ok(1, 1, B, H), "the chunk-aware BPTT kernel must serve the bench's listener configuration"
+    assert _hip.streams_overlap(torch.device("cuda", 0))        # (raises by itself when the auxiliary streams cannot overlap)
+    used = {}
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, T, F, generator=g).cuda()
     dy = None
@@ -214,14 +215,19 @@ def test_backward_hand_over_in_chunks_gives_the_same_gradients():
                 if dy is None:
                     dy = torch.randn(y.shape, generator=g).cuda() * 0.1
                 st.flat_grad.zero_()
+                for k in L.VARIANTS:
+                    L.VARIANTS[k] = 0
                 y.backward(dy)
                 _hip.join_side_stream()
             torch.cuda.synchronize()
             _hip.check_status()
             got[rows] = st.flat_grad.clone()
+            used[rows] = dict(L.VARIANTS)
     finally:
         L.DOUT_CHUNK_ROWS = old
         L.set_cell("rnn"); L.set_precision("f32")
     a, b = got[0], got[64]
+    # the two runs really were two schedules: whole GEMMs between the sweeps vs the CH = true BPTT instance behind chunked products
+    assert used[0]["dout_chunks"] == 0 and (used[64]["sweeps_bwd"], used[64]["dout_chunks"]) == (layers + 1, layers), used   # (every BPTT sweep but the top one)
     assert torch.isfinite(a).all() and a.abs().max().item() > 0
     assert (a - b).abs().max().item() <= 1e-3 * max(1.0, a.abs().max().item())

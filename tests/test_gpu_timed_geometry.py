@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_args, synthetic_batch
+from helpers import expect_handovers, make_args, synthetic_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,8 @@ def test_b48_rows_equal_twelve_b4_batches():
     _, _, _, logits, alphas, _, _ = las.train(xs, ys)
     torch.cuda.synchronize()
     las.check_status()
+    v = expect_handovers(las, "lstm", B)
+    assert (v["sweeps_fwd"], v["xproj_chunks"], v["sweeps_bwd"], v["dout_chunks"]) == (4, 4, 4, 3), v    # = profiles/*_kernel_stats.csv: 3 of 4 BPTT launches CH = true
     logits, alphas, g48 = logits.cpu(), alphas.cpu(), st.flat_grad.cpu().clone()
     assert alphas.shape[-1] == 160
     n_tot = int((ys[0][:, :int(ys[1].max())] != 0).sum())
@@ -63,6 +65,7 @@ def test_b48_rows_equal_twelve_b4_batches():
         _, _, _, lk, ak, _, _ = las_k.train(xk, yk)
         torch.cuda.synchronize()
         las_k.check_status()
+        expect_handovers(las_k, "lstm", 4)            # the oracle-checked B = 4 steps run the same schedule
         Uk = int(yk[1].max())
         n_k = int((yk[0][:, :Uk] != 0).sum())
         gsum += st_k.flat_grad.cpu() * (n_k / n_tot)
@@ -77,11 +80,12 @@ def test_b48_rows_equal_twelve_b4_batches():
     assert gerr <= 2e-3, gerr
 
 
-def _three_steps(args, p0, xs, ys):
+def _three_steps(args, p0, xs, ys, handovers=True):
     las, st = _fresh(args, p0)
     out = []
     for _ in range(3):
         loss = las.train(xs, ys)[0]
+        expect_handovers(las, "lstm", B, on=handovers)
         if not out:
             torch.cuda.synchronize()
             g0 = st.flat_grad.clone()
@@ -105,7 +109,7 @@ def test_three_b48_steps_are_bit_reproducible_and_independent_of_the_hand_overs(
     saved = (L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS)
     try:
         L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = 0, 0, False, False
-        f3, g3, l3 = _three_steps(args, p0, xs, ys)
+        f3, g3, l3 = _three_steps(args, p0, xs, ys, handovers=False)      # (asserts that nothing was handed over)
     finally:
         L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = saved
     gerr = (g1 - g3).abs().max().item() / g1.abs().max().item()

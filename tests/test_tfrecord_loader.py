@@ -210,3 +210,52 @@ def test_native_reader_reports_bad_input(tmp_path):
     r.close()
     with pytest.raises(IOError):
         tdl.NativeReader([str(tmp_path / "missing.tfrecord")], 13, False).get_next()
+
+
+def test_native_reader_truncation_inside_the_framing_window_is_reported(tmp_path):
+    """a file cut so that 12..15 bytes remain behind a record boundary (a whole header, part of the checksums) must be
+    reported as corrupt framing -- `len > size - pos - 16` alone wraps around there and the payload pointer leaves the map."""
+    rng = np.random.RandomState(4)
+    feats, toks = _utts(rng, [50, 60], feat_dim=13)
+    p = str(tmp_path / "t-0.tfrecord")
+    tdl.write_tfrecord(p, feats, toks)
+    raw = open(p, "rb").read()
+    first = 12 + struct.unpack("<Q", raw[:8])[0] + 4                   # end of the first record
+    for keep in (12, 13, 15):
+        q = str(tmp_path / ("cut%d-0.tfrecord" % keep))
+        open(q, "wb").write(raw[:first + keep])
+        r = tdl.NativeReader([q], 13, False)
+        with pytest.raises(IOError, match="corrupted TFRecord framing"):
+            while True:
+                r.get_next()
+        r.close()
+
+
+def test_both_readers_verify_the_payload_checksum(tmp_path):
+    """A flipped bit inside the float payload: TFRecordDataset raises DataLossError; so do both readers here."""
+    rng = np.random.RandomState(5)
+    feats, toks = _utts(rng, [50, 70, 90], feat_dim=13)
+    p = str(tmp_path / "c-0.tfrecord")
+    tdl.write_tfrecord(p, feats, toks)
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0x10                                          # inside the second record's float block
+    open(p, "wb").write(raw)
+    r = tdl.NativeReader([p], 13, False)
+    with pytest.raises(IOError, match="payload"):
+        while True:
+            r.get_next()
+    r.close()
+    it = tdl._BucketedIterator([p], tdl.data_parser, 13, False)
+    with pytest.raises(IOError, match="payload"):
+        list(it)
+
+
+def test_evaluation_passes_are_not_sharded_by_the_reader(tmp_path):
+    rng = np.random.RandomState(6)
+    feats, toks = _utts(rng, [50], feat_dim=13)
+    p = str(tmp_path / "e-0.tfrecord")
+    tdl.write_tfrecord(p, feats, toks)
+    with pytest.raises(ValueError, match="world=1"):
+        tdl._BucketedIterator([p], tdl.data_parser, 13, False, rank=0, world=2)
+    with pytest.raises(IOError, match="world = 1"):
+        tdl.NativeReader([p], 13, False, rank=1, world=2)

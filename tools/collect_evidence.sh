@@ -15,14 +15,14 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$P -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_kt.log 2>&1
 python3 tools/kernel_stats.py /tmp/kt_$P 3 gpurun_out/${P}_kernel_stats.csv > /dev/null
 # counter passes serialise kernels: the x-projection chunks (another stream's kernels the running sweep waits for) must be off there
-export LAS_XPROJ_CHUNK=0 LAS_DOUT_CHUNK=0
+export LAS_ALLOW_SERIAL_STREAMS=1      # (r4: the SAME kernel instances as the timed step -- chunk products, chunk-aware sweeps, CH = true BPTT -- with every producer in front of its consumer)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${P}_$c -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --no-train-loop > /tmp/pmc_${P}_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   -d /tmp/pmc_${P}_SQ -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-decode --no-train-loop > /tmp/pmc_${P}_SQ.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/$P /tmp/pmc_${P}_FETCH_SIZE /tmp/pmc_${P}_WRITE_SIZE /tmp/pmc_${P}_SQ > gpurun_out/${P}_pmc_summary.log 2>&1
-unset LAS_XPROJ_CHUNK LAS_DOUT_CHUNK
+unset LAS_ALLOW_SERIAL_STREAMS
 # the bench line comes AFTER the counter passes: bench.py takes the dominant kernel's HBM traffic from the newest profiles/*_pmc.json
 # that was recorded from this very csrc/rnn_seq.hip
 cp gpurun_out/${P}_pmc.json profiles/${P}_pmc.json 2>/dev/null
