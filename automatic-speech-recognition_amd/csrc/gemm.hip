@@ -677,6 +677,88 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
         }
 }
 
+// Skinny form, M <= 64 (the parity mode's per-decode-step products: [B rows] x [1152] x [2048] and its transpose, 382 of them per
+// B = 48 train step -- 129 us each through the 64 x 64 tile above, 50 of the parity step's 97 ms: 32 workgroups, each walking
+// K in 32-wide stages whose loads it waits for).  Here a workgroup owns 64 x 32 outputs and a stage is 128 k: twelve 16-byte
+// loads per thread in flight, the four waves split the stage's k-steps (8 each), their partial tiles meet in LDS in fixed order.
+template <int TMS>
+__global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 32, BK = 128, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
+    __shared__ __attribute__((aligned(16))) float lds[BK * (PA + PB)];          // 64 KB
+    float* As = lds;
+    float* Bs = lds + BK * PA;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* A = g.A + (long long)blockIdx.z * g.strideA;
+    const float* B = g.B + (long long)blockIdx.z * g.strideB;
+    float* C = g.C + (long long)blockIdx.z * g.strideC;
+    f32x4_t acc[TMS][2];
+#pragma unroll
+    for (int i = 0; i < TMS; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    TileRegs<BM, NT> ra[4];
+    TileRegs<BN, NT> rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, 32 * q, g.M, g.K, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, 32 * q, g.N, g.K, g.vecB, 0, 0);
+    }
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tile_sstore_f32<BM, NT>(As + q * 32 * PA, ra[q], g.ksA);
+            tile_sstore_f32<BN, NT>(Bs + q * 32 * PB, rb[q], g.ksB);
+        }
+        __syncthreads();
+        if (k0 + BK < g.K) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, k0 + BK + 32 * q, g.M, g.K, g.vecA, g.mask_period, g.mask_skip);
+                tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, k0 + BK + 32 * q, g.N, g.K, g.vecB, 0, 0);
+            }
+        }
+        const float* ap = As + (w * 32 + lk) * PA + li;
+        const float* bp = Bs + (w * 32 + lk) * PB + li;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float a[TMS], b[2];
+#pragma unroll
+            for (int i = 0; i < TMS; ++i) a[i] = ap[ks * 4 * PA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = bp[ks * 4 * PB + j * 16];
+#pragma unroll
+            for (int i = 0; i < TMS; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = lds;                                                            // [wave][tile i][tile j][16 x 16]
+#pragma unroll
+    for (int i = 0; i < TMS; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((w * TMS + i) * 2 + j) * 256 + (lk * 4 + r) * 16 + li] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < TMS * 2; ++e) {
+        const int idx = tid + 256 * e, rl = idx >> 5, cl = idx & 31;             // 16 TMS rows x 32 columns
+        const int o = ((rl >> 4) * 2 + (cl >> 4)) * 256 + (rl & 15) * 16 + (cl & 15);
+        const float sum = ((red[o] + red[TMS * 512 + o]) + red[2 * TMS * 512 + o]) + red[3 * TMS * 512 + o];
+        const int row = m0 + rl, col = n0 + cl;
+        if (row < g.M && col < g.N) {
+            float v = g.alpha * sum;
+            if (g.bias) v += g.bias[col];
+            float* cp = C + (long long)row * g.ldc + col;
+            if (g.beta != 0.f) v += g.beta * (*cp);
+            *cp = apply_act(v, g.act);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp32 VALU kernel (parity mode)
 // ------------------------------------------------------------------------------------------------
@@ -911,6 +993,15 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
         case 0: {
             dim3 grid(cdiv(N, BN), cdiv(M, BM), zdim);
             if (g_f32_valu) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64), zdim), dim3(256), 0, st, g);
+            else if (M <= 64 && g.splitk == 1) {
+                const dim3 sg(cdiv(N, 32), 1, zdim);
+                switch (cdiv(M, 16)) {
+                    case 1: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<1>, sg, dim3(256), 0, st, g); break;
+                    case 2: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<2>, sg, dim3(256), 0, st, g); break;
+                    case 3: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<3>, sg, dim3(256), 0, st, g); break;
+                    default: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<4>, sg, dim3(256), 0, st, g); break;
+                }
+            }
             else if (BM == 128) hipLaunchKernelGGL((gemm_mf32_kernel<4, 4>), grid, dim3(256), 0, st, g);
             else hipLaunchKernelGGL((gemm_mf32_kernel<2, 2>), grid, dim3(256), 0, st, g);
         } break;

@@ -15,7 +15,15 @@ int las_device_cus();   // compute units of the current device (cached)
     do { hipError_t e__ = (expr);                            \
          if (e__ != hipSuccess) { las_set_error("%s -> %s", #expr, hipGetErrorString(e__)); \
                                   return (int)e__; } } while (0)
+#ifdef LAS_DEBUG_SYNC   // `make dbg`: every launch is waited for, a faulting kernel is reported with the file and line of its launch
+#define LAS_LAUNCHED()                                       \
+    do { hipError_t e__ = hipGetLastError();                 \
+         if (e__ == hipSuccess) e__ = hipDeviceSynchronize(); \
+         if (e__ != hipSuccess) { las_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+                                  return (int)e__; } } while (0)
+#else
 #define LAS_LAUNCHED() LAS_HIP(hipGetLastError())
+#endif
 
 // ---- vector types for MFMA --------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

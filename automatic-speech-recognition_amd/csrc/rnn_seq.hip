@@ -20,39 +20,7 @@
 #ifndef LAS_ABL
 #define LAS_ABL 0      // development: bit mask of parts of the forward sweep to leave out (timing experiments, tools/abl_rnn.py)
 #endif
-struct RnnArgs {
-    int B, T, H;
-    float* gates;
-    const float* whh[2];
-    int ldw;
-    float* out; int ld_out; long long obs;
-    float* cstate;
-    const float* dout; int ld_dout; long long dobs;
-    // the same tensors as seen by the speed-mode (bf16 storage) kernels; exactly one family is used per launch
-    unsigned short *gates16, *out16, *cstate16; const unsigned short* dout16; unsigned short* sink16;
-    float fb;
-    const void* wpack;
-    long long* dbg;   // LAS_PROF builds only: device buffer for s_memtime stamps (env LAS_DBG_PTR)
-    unsigned long long* xbuf; int* err;     // cluster exchange granules / bounded-spin error flag
-    unsigned long long* xcc;                 // [cluster][member] placement handshake granules (zeroed per launch)
-    float* bpart;                            // BPTT: [cluster][G*H] column sums of d(pre-activation) over the tile's rows and all steps
-    int force_agent;                         // env LAS_AGENT_GRANULES=1: never use the same-XCD transport
-    float* sink;                             // scratch rows for the padded part of a ragged batch tile
-    int ncl, ncl_pad;                        // clusters = batch tiles x 2 directions (padded to a multiple of 8)
-    int ks_packed;                           // wpack holds the K-split BPTT fragment order
-    int spin;                                // bound of every exchange spin (polls); a timeout is reported through `status`
-    int* status;                             // caller-owned sticky device word (may be NULL): LAS_SEQ_STATUS_* on failure
-    int status_code;
-    int no_helpers;                          // LAS_SEQ_NO_HELPER_WAVES
-    int announce;                            // LAS_SEQ_ANNOUNCE(n): cluster 0 stores n into status[1] once its members are resident
-    const int* xflag; int xsc;               // forward: the x-projection arrives in time chunks of xsc steps from both ends of the sequence,
-                                             // *xflag = number of chunks complete (another stream's kernels write it); NULL: all there
-    const int* dflag; int dcp, dTq, dshift;  // BPTT: dout arrives in chunks of 2^dcp producer rows (dTq per utterance; row = frame >> dshift) from
-                                             // both ends of the sequence; *dflag = chunks complete
-    int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
-    int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
-    const int* row_T;                        // forward, optional: frames of every batch row (<= T); a row's state and outputs are ZERO at t >= row_T[row]
-};
+#include "rnn_seq_args.h"
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would stall
 // every recurrent step on the completion of that step's global stores and of the NEXT step's x-projection
@@ -274,7 +242,6 @@ struct BfPtr {
 #define GF(p) (BfPtr{(gio*)(p)})
 #define GCF(p) (BfPtr{(gio*)(p)})
 typedef __attribute__((address_space(1))) float gfloat;          // fp32 globals (helper waves' LDS rings stay fp32)
-#define LAS_SPIN_BUDGET_DEFAULT (1 << 22)
 
 // `local` = every member of this cluster runs on the same XCD (verified at kernel start, cluster_same_xcd): the
 // granule then only has to reach that XCD's L2, so a workgroup-scope (sc0) store is enough and the consumers' sc1
@@ -285,19 +252,6 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned ta
     if (local) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (the 16-byte granule form {tag, a, b, tag} -- granule_rsrc / granule16_store / granule16_load -- lives in las_common.h:
-// the Speller's fused step kernels use the same transport)
-__device__ __forceinline__ unsigned granule_wait(const unsigned long long* p, unsigned tag, int* err, int spin) {
-    unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int budget = *err ? 1 : spin;                     // sticky: after one timeout never wait again (no hang)
-    while ((unsigned)(x >> 32) != tag) {
-        if (--budget == 0) { *err = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-        x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return (unsigned)x;
-}
-
 // Fetch this thread's N granules (all loads in flight at once), then re-poll only the stale ones.
 template <int N, int P, int GPM>
 __device__ __forceinline__ void gather_granules(unsigned long long (&xv)[N], const unsigned long long* xslot, int pm, int tid,
@@ -324,17 +278,6 @@ __device__ __forceinline__ void gather_granules(unsigned long long (&xv)[N], con
             }
         }
     }
-}
-
-// Placement handshake: every member publishes the XCC_ID it runs on (agent-scope granule, valid under any placement)
-// and reads its partners'; true only if all P agree.  A timeout or a mismatch selects the agent-scope transport.
-__device__ __forceinline__ bool cluster_same_xcd(unsigned long long* slots, int pm, int P, int tid, int* err, int spin) {
-    const unsigned tag = 0x58434400u;                                           // "XCD\0"
-    const unsigned mine = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;      // HW_REG_XCC_ID[3:0]
-    if (tid == 0) __hip_atomic_store(slots + pm, ((unsigned long long)tag << 32) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int same = 1;
-    if (tid < P) same = (granule_wait(slots + tid, tag, err, spin) == mine) && !*err;
-    return __syncthreads_and(same) != 0;
 }
 
 template <int CELL, int UT, int P>
@@ -1758,7 +1701,8 @@ static SeqWs seq_ws_layout(int cell, int H, int B) {
 
 extern "C" size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B) {
     (void)prec;
-    return seq_ws_layout(cell, H, B > 0 ? B : 1).total;
+    const size_t a = seq_ws_layout(cell, H, B > 0 ? B : 1).total, b = las_rnn_seq_mf32_ws_bytes(cell, H);
+    return a > b ? a : b;
 }
 
 template <typename K>
@@ -2077,6 +2021,8 @@ static int rnn_seq_fwd_impl(int cell, int prec, int B, int T, int H, void* gates
         LAS_ARG(ld_out % 4 == 0 && out_bstride % 4 == 0 && (((uintptr_t)gates | (uintptr_t)out | (uintptr_t)cstate) & 15) == 0,
                 "las_rnn_seq_fwd: bf16 tensors must be 16-byte aligned with pitches that are multiples of 4");
         if (int rc = run_bf16(false, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st)) return rc;
+    } else if (prec == LAS_PREC_F32 && !(flags & LAS_SEQ_F32_VALU) && las_rnn_seq_mf32_ok(cell, H)) {
+        return las_rnn_seq_mf32_run(false, cell, a, ws, ws_bytes, flags, st);
     } else {
         const size_t lds = (size_t)H * F32_BT * sizeof(float);
         dim3 grid(cdiv(B, F32_BT), 2);
@@ -2146,6 +2092,8 @@ extern "C" int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int 
         int db_done = 0;
         if (int rc = run_bf16(true, cell, a, whh_fw, whh_bw, ldw, ws, ws_bytes, flags, st, dbias_fw, dbias_bw, &db_done)) return rc;
         if (db_done) return 0;
+    } else if (prec == LAS_PREC_F32 && !(flags & LAS_SEQ_F32_VALU) && las_rnn_seq_mf32_ok(cell, H)) {
+        if (int rc = las_rnn_seq_mf32_run(true, cell, a, ws, ws_bytes, flags, st)) return rc;
     } else {
         LAS_ARG(ws && ws_bytes >= (size_t)2 * G * H * H * sizeof(float), "las_rnn_seq_bwd: workspace too small");
         hipLaunchKernelGGL(transpose_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, whh_fw, whh_bw, ldw,

@@ -2413,8 +2413,8 @@ __global__ __launch_bounds__(256) void dkeys_kernel(DecDev a, float* __restrict_
 //   (1) emb_hist_kernel   one workgroup: token histogram (integer LDS atomics: counts do not depend on the order) + exclusive scan
 //   (2) emb_place_kernel  position i goes to slot start[v] + #{j < i : tok[j] == v}: a STABLE counting sort, each thread counts its
 //                         predecessors in an LDS copy of the token list -- the order inside a bucket is by position, always
-//   (3) emb_reduce_kernel one workgroup per vocabulary row that occurs: four 64-lane groups take its positions round robin, their
-//                         partial sums meet in LDS in fixed order -> deterministic, no atomics on floats
+//   (3) emb_reduce_kernel one workgroup per vocabulary row that occurs: sixteen 64-lane groups take its positions four at a time,
+//                         their partial sums meet in LDS in fixed order -> deterministic, no atomics on floats
 // Tokens outside [0, V) are ignored, as before.  Serves V <= EMB_MAX_V and n <= EMB_MAX_N (the token list as 16-bit values in LDS).
 constexpr int EMB_MAX_V = 16384, EMB_MAX_N = 49152;
 __global__ __launch_bounds__(1024) void emb_hist_kernel(const int* __restrict__ tok, int n, int V, int* __restrict__ start) {
@@ -2456,6 +2456,7 @@ __global__ __launch_bounds__(256) void emb_place_kernel(const int* __restrict__ 
     int rank = 0;
     const uint4* t8 = reinterpret_cast<const uint4*>(tk);
     const unsigned vv = v | (v << 16);
+#pragma unroll 8
     for (int j8 = 0; j8 < i0 / 8; ++j8) {          // whole groups of 8 in front of this block: the same address for every thread
         const uint4 q = t8[j8];
         const unsigned w[4] = {q.x ^ vv, q.y ^ vv, q.z ^ vv, q.w ^ vv};
@@ -2466,28 +2467,51 @@ __global__ __launch_bounds__(256) void emb_place_kernel(const int* __restrict__ 
     pos[start[v] + rank] = i;
 }
 
-__global__ __launch_bounds__(256) void emb_reduce_kernel(const int* __restrict__ start, const int* __restrict__ pos,
-                                                         const float* __restrict__ dXin0, int ld, int E, const float* __restrict__ mask,
-                                                         float* __restrict__ demb) {
-    __shared__ float red[4][256];
+__global__ __launch_bounds__(1024) void emb_reduce_kernel(const int* __restrict__ start, const int* __restrict__ pos,
+                                                          const float* __restrict__ dXin0, int ld, int E, const float* __restrict__ mask,
+                                                          float* __restrict__ demb) {
+    // sixteen 64-lane groups; group g takes the bucket's positions 4 g .. 4 g + 3, then 64 further on: four independent row loads in
+    // flight per lane (a bucket of a frequent token is hundreds of positions long; HBM latency, not bytes, is what a serial walk pays)
+    __shared__ float red[16][256];
     const int v = blockIdx.x, s0 = start[v], s1 = start[v + 1];
     if (s0 == s1) return;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const bool small = s1 - s0 <= 4;                 // (block-uniform) one group's work: no cross-group reduction
+    if (small && grp) return;
     for (int e0 = 0; e0 < E; e0 += 256) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = s0 + grp; k < s1; k += 4) {
-            const size_t i = (size_t)pos[k];
+        for (int k = s0 + grp * 4; k < s1; k += 64) {
+            size_t i[4];
+            float x[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = e0 + lane + 64 * q;
-                if (e < E) acc[q] += dXin0[i * ld + e] * (mask ? mask[i * E + e] : 1.f);
-            }
+            for (int j = 0; j < 4; ++j) i[j] = (size_t)pos[min(k + j, s1 - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = e0 + lane + 64 * q;
+                    x[j][q] = (e < E && k + j < s1) ? dXin0[i[j] * ld + e] * (mask ? mask[i[j] * E + e] : 1.f) : 0.f;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += x[j][q];
+        }
+        if (small) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = e0 + lane + 64 * q; if (e < E) demb[(size_t)v * E + e] += acc[q]; }
+            continue;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[grp][lane + 64 * q] = acc[q];
         __syncthreads();
-        const int e = e0 + threadIdx.x;
-        if (e < E) demb[(size_t)v * E + e] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < 256) {
+            const int e = e0 + threadIdx.x;
+            float s_ = 0.f;
+#pragma unroll
+            for (int g16 = 0; g16 < 16; ++g16) s_ += red[g16][threadIdx.x];
+            if (e < E) demb[(size_t)v * E + e] += s_;
+        }
         __syncthreads();
     }
 }
@@ -2938,7 +2962,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         hipLaunchKernelGGL(emb_place_kernel, dim3(cdiv(UB, 256)), dim3(256), (size_t)((UB + 263) & ~7) * sizeof(unsigned short), st,
                            (const int*)d.tok_in, UB, V, (const int*)estart, epos);
         LAS_LAUNCHED();
-        hipLaunchKernelGGL(emb_reduce_kernel, dim3(V), dim3(256), 0, st, (const int*)estart, (const int*)epos, (const float*)d.dXin0, I0D, E,
+        hipLaunchKernelGGL(emb_reduce_kernel, dim3(V), dim3(1024), 0, st, (const int*)estart, (const int*)epos, (const float*)d.dXin0, I0D, E,
                            (const float*)d.emb_mask, bk->demb);
         LAS_LAUNCHED();
     } else {

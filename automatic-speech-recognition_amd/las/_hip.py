@@ -529,7 +529,7 @@ class _timed:
 # ---- development switches of the sweeps / the Speller (explicit `flags` arguments of the C ABI).  The library itself
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
-SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS = 1, 2, 4, 8, 16
+SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS, SEQ_F32_VALU = 1, 2, 4, 8, 16, 32
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS = 1, 2, 4, 8, 16
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
@@ -555,7 +555,7 @@ def _flags_from_env():
     e = os.environ.get
     f = (SEQ_AGENT_GRANULES if e("LAS_AGENT_GRANULES") == "1" else 0) | (SEQ_NO_KSPLIT if e("LAS_NO_KSPLIT") else 0) | \
         (SEQ_NO_HELPER_WAVES if e("LAS_NO_HELPER_WAVES") else 0) | (SEQ_ROWS16 if e("LAS_ROWS16") else 0) | \
-        (SEQ_NO_WARMERS if e("LAS_NO_WARMERS") else 0)
+        (SEQ_NO_WARMERS if e("LAS_NO_WARMERS") else 0) | (SEQ_F32_VALU if e("LAS_F32_VALU") else 0)
     if e("LAS_SEQ_P"):
         f |= seq_p(e("LAS_SEQ_P"))
     if e("LAS_SPIN_LOG2"):

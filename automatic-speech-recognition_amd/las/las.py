@@ -696,6 +696,32 @@ class LAS:
         st.shadows.clear()                            # bf16 weight shadows are rebuilt from the updated masters
         self.last_grad_sumsq = sumsq
 
+    def train_stacked(self, batches, coins=None, sampled=None):
+        """ONE optimisation step on k batches of one bucket stacked along the batch axis: batches = [(xs, ys), ...] with equal frame
+        counts T.  The rows of a batch never interact in the forward pass (las/las.py:93-117 run every utterance through the same
+        weights) and the loss is the token sum over ALL rows divided by their token count (las/las.py:329-331), so this IS the update
+        of k data-parallel ranks that hold one of the batches each (las/parallel.py) -- on one GPU, where the recurrent sweeps are
+        latency-bound on a fifth of the compute units and k times the rows cost them (almost) nothing.  Returns what train() does."""
+        if len(batches) == 1:
+            return self.train(batches[0][0], batches[0][1], coins=coins, sampled=sampled)
+        dev = self._device()
+        T = {tuple(b[0][0].shape[1:]) for b in batches}
+        if len(T) != 1:
+            raise ValueError("train_stacked: the batches must come from one bucket (equal frame count and feature shape), got %s" % sorted(T))
+        W = max(int(b[1][0].shape[1]) for b in batches)
+
+        def cat(parts, dtype, pad_to=None):
+            ts = [self._to_dev(x, dev, dtype) for x in parts]
+            if pad_to is not None:
+                ts = [torch.nn.functional.pad(t, (0, pad_to - t.shape[1])) for t in ts]
+            return torch.cat(ts, 0)
+
+        audio = cat([b[0][0] for b in batches], torch.float32)
+        audiolen = np.concatenate([np.asarray(torch.as_tensor(b[0][1]).cpu()) for b in batches])
+        y = cat([b[1][0] for b in batches], torch.int32, W)
+        tokenlen = np.concatenate([np.asarray(torch.as_tensor(b[1][1]).cpu()) for b in batches])
+        return self.train((audio, audiolen), (y, tokenlen), coins=coins, sampled=sampled)
+
     def check_status(self):
         """Synchronising check that no recurrent sweep reported an exchange timeout (raises RuntimeError)."""
         _hip.check_status(self._device())

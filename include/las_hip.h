@@ -134,13 +134,16 @@ int las_tanh_bwd_dt(const void* Y, int y_dt, int ldy, const void* dY, int dy_dt,
  *                            the per-lane work of a dependent step, whenever the whole batch fits one launch that way)
  *   LAS_SEQ_NO_WARMERS       clustered sweeps without the per-cluster "L2 warmer" workgroup (one extra workgroup on the cluster's
  *                            XCD that touches the operands of the next steps so that the cluster's own loads hit in L2)
+ *   LAS_SEQ_F32_VALU         LAS_PREC_F32: the round-1 VALU kernels (one workgroup per (direction, 8 rows), W_hh streamed from L2)
+ *                            instead of the clustered exact-fp32 MFMA kernels (csrc/rnn_seq_f32.hip) -- tests cross-check the two
  *   LAS_SEQ_P(p)             cluster width override (1, 2, 4, 8 workgroups per (direction, 16-row tile))
  *   LAS_SEQ_SPIN_LOG2(n)     bound of every exchange spin = 2^n polls (default 2^22)
  * `status` (may be NULL): caller-owned, caller-zeroed int32 DEVICE word.  The clustered bf16 sweeps exchange h / dh
  *   between workgroups with bounded spins; if a partner does not publish within the bound (it is not co-resident:
  *   shared or partitioned device) the launch finishes with undefined results and stores LAS_SEQ_STATUS_* here.
  *   The word is sticky (never cleared by the library); the caller reads it at its next synchronisation point. */
-enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVES = 4, LAS_SEQ_ROWS16 = 8, LAS_SEQ_NO_WARMERS = 16 };
+enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVES = 4, LAS_SEQ_ROWS16 = 8, LAS_SEQ_NO_WARMERS = 16,
+       LAS_SEQ_F32_VALU = 32 };
 #define LAS_SEQ_P(p) (((p) & 0xf) << 8)
 #define LAS_SEQ_SPIN_LOG2(n) (((n) & 0x1f) << 16)
 /* LAS_SEQ_ANNOUNCE(n), n in 1..1023 (las_rnn_seq_bwd*, clustered kernels): `status` then points to TWO ints and the launch

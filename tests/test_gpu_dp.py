@@ -76,7 +76,9 @@ def test_two_rank_steps_equal_single_rank_full_batch(tmp_path, prec):
     losses = []
     for k in range(3):
         xs, ys = synthetic_batch(6, 40 + 8 * k, 8, 30, seed=11 + k)
-        losses.append(float(las.train(xs, ys)[0]))
+        # the two ranks' shards as TWO stacked batches of one step (LAS.train_stacked: the single-GPU form of the same update)
+        shards = [((xs[0][r::2], xs[1][r::2]), (ys[0][r::2], ys[1][r::2])) for r in range(2)]
+        losses.append(float(las.train_stacked(shards)[0]))
     torch.cuda.synchronize()
     tol = 1.0 if prec == "f32" else 20.0                 # bf16: near-zero gradients whose Adam steps are sign-like, then 2 more steps
     assert max(abs(a - b) for a, b in zip(got["loss"], losses)) < 2e-4 * tol

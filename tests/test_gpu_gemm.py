@@ -29,6 +29,7 @@ CASES = [
     (48, 64, 39, 0, 0), (130, 70, 100, 0, 0), (256, 256, 512, 0, 0), (300, 512, 64, 0, 1),
     (512, 1024, 3000, 1, 0), (128, 30, 512, 0, 0), (48, 2048, 1152, 0, 0), (48, 1152, 2048, 0, 1),
     (39, 256, 2500, 1, 0), (7, 5, 3, 0, 0), (1, 128, 64, 0, 0), (200, 200, 33, 1, 1),
+    (33, 100, 300, 0, 0), (64, 96, 130, 1, 0), (17, 40, 260, 0, 1), (48, 30, 512, 0, 0),       # M <= 64: the parity mode's skinny exact-fp32 MFMA kernel
 ]
 
 

@@ -10,6 +10,10 @@ CASES = [
     ("rnn", 0, 5, 7, 48), ("lstm", 0, 5, 7, 48), ("rnn", 0, 9, 12, 100), ("lstm", 0, 17, 9, 64),
     ("rnn", 1, 5, 7, 64), ("lstm", 1, 5, 7, 64), ("rnn", 1, 20, 33, 128), ("lstm", 1, 20, 33, 128),
     ("rnn", 1, 48, 40, 256), ("lstm", 1, 48, 40, 256), ("lstm", 0, 48, 20, 256), ("rnn", 1, 3, 5, 512), ("lstm", 1, 37, 23, 256), ("lstm", 1, 3, 1, 256),
+    # parity mode on the clustered exact-fp32 MFMA sweeps (csrc/rnn_seq_f32.hip: H in {64, 128, 256, 512}; P = G H / 64 members per
+    # (direction, 16-row tile): 1 ... 32), ragged last tiles, T = 1, and enough steps to go round the two exchange slots many times
+    ("rnn", 0, 7, 9, 64), ("rnn", 0, 6, 10, 128), ("rnn", 0, 20, 15, 256), ("rnn", 0, 19, 8, 512),
+    ("lstm", 0, 33, 11, 128), ("lstm", 0, 5, 6, 512), ("lstm", 0, 3, 1, 256), ("lstm", 0, 48, 300, 256), ("rnn", 0, 48, 300, 256),
 ]
 
 
@@ -83,6 +87,49 @@ def test_rnn_seq_fwd_bwd(case):
     scale = refg.abs().max().item()
     tolb = (5e-5 if prec == 0 else 6e-2) * max(1.0, scale)
     assert err < tolb, ("bwd", case, err, scale)
+
+
+@pytest.mark.parametrize("cell,B,T,H", [("lstm", 21, 40, 256), ("rnn", 21, 40, 256), ("lstm", 9, 17, 64)])
+def test_fp32_cluster_sweeps_equal_the_valu_kernels(cell, B, T, H):
+    """The parity mode's two kernel families on the same inputs: clustered exact-fp32 MFMA (default) vs the round-1 VALU kernels
+    (LAS_SEQ_F32_VALU).  Both are fp32 fma chains; they differ in summation order only (the MFMA form splits K into quarters)."""
+    from las import _hip
+    c = _hip.CELL_LSTM if cell == "lstm" else _hip.CELL_RNN
+    G = 4 if cell == "lstm" else 1
+    GH = G * H
+    g = torch.Generator().manual_seed(5 + B + H)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).cuda()
+    lim = (6.0 / (H + GH)) ** 0.5 * 1.5
+    w0, w1 = [((torch.rand(H, GH, generator=g) * 2 - 1) * lim).cuda() for _ in range(2)]
+    dout = torch.randn(B, T, 2 * H, generator=g).cuda()
+    res = []
+    for flags in (0, _hip.SEQ_F32_VALU):
+        gates = xp.clone()
+        out = torch.zeros(B, T, 2 * H, device="cuda")
+        cst = torch.zeros(B, T, 2, H, device="cuda") if cell == "lstm" else None
+        _hip.rnn_seq_fwd(c, 0, B, T, H, gates, w0, w1, GH, out, 2 * H, T * 2 * H, cst, flags=flags)
+        act = gates.clone()
+        _hip.rnn_seq_bwd(c, 0, B, T, H, gates, w0, w1, GH, out, 2 * H, T * 2 * H, cst, dout, 2 * H, T * 2 * H, flags=flags)
+        torch.cuda.synchronize()
+        _hip.check_status()
+        res.append((out, act, gates) + ((cst,) if cst is not None else ()))
+    for x, y in zip(*res):
+        assert (x - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+
+
+def test_fp32_cluster_sweep_reports_an_exchange_timeout():
+    from las import _hip
+    B, T, H = 48, 256, 256
+    gates = torch.randn(B, T, 2, 4 * H, device="cuda")
+    w0 = torch.randn(H, 4 * H, device="cuda") * 0.05
+    out = torch.zeros(B, T, 2 * H, device="cuda")
+    cst = torch.zeros(B, T, 2, H, device="cuda")
+    _hip.check_status()
+    _hip.rnn_seq_fwd(1, 0, B, T, H, gates, w0, w0, 4 * H, out, 2 * H, T * 2 * H, cst, flags=_hip.seq_spin_log2(1))
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="did not publish"):
+        _hip.check_status()
+    _hip.check_status()
 
 
 def test_rnn_seq_rejects_bad_args():
