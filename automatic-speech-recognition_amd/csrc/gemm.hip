@@ -573,11 +573,14 @@ static void launch_fast(const GemmArgs& g, int zdim, hipStream_t st) {
 // with the VALU free for addressing: the 64x64x16 VALU tile loop below it replaced ran at ~10 % of that peak.  Same strided
 // operand description as the other kernels (NN / NT / TN, batching, contraction mask, deterministic split-K, fused bias /
 // beta / tanh epilogue), the guarded generic loader, register double buffering: the next k-tile's global loads fly under the
-// 32 x TM x TN MFMAs of the current one.  LDS tiles are k-major ([32][BM + 16] fp32: a lane's A operand is row k0 + (lane >> 4),
-// column m0 + (lane & 15) -- 64 distinct banks).
+// 32 x TM x TN MFMAs of the current one.  LDS tiles are k-major ([32][BM + 20] fp32: a lane's A operand is row k0 + (lane >> 4),
+// column m0 + (lane & 15)).
 // ------------------------------------------------------------------------------------------------
+// Pitch ROWS + 20 (20 mod 64 banks): the k-contiguous operand's staging stores -- four scalar stores per 16-byte chunk, rows (c >> 3),
+// k (c & 7) * 4 + e -- hit 32 banks per wave instead of 8 (pitch ROWS + 16 made the reads conflict-free but these stores 8-way
+// conflicted: 1024 LDS cycles per k-tile and workgroup next to 4096 cycles of MFMA); the operand reads stay within 1.25-way.
 template <int ROWS>
-struct F32Lds { static constexpr int PITCH = ROWS + 16; };
+struct F32Lds { static constexpr int PITCH = ROWS + 20; };
 
 template <int ROWS, int NT>
 __device__ __forceinline__ void tile_sstore_f32(float* S, const TileRegs<ROWS, NT>& r, long long ks) {
@@ -679,50 +682,60 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
 
 // Skinny form, M <= 64 (the parity mode's per-decode-step products: [B rows] x [1152] x [2048] and its transpose, 382 of them per
 // B = 48 train step -- 129 us each through the 64 x 64 tile above, 50 of the parity step's 97 ms: 32 workgroups, each walking
-// K in 32-wide stages whose loads it waits for).  Here a workgroup owns 64 x 32 outputs and a stage is 128 k: twelve 16-byte
-// loads per thread in flight, the four waves split the stage's k-steps (8 each), their partial tiles meet in LDS in fixed order.
+// K in 32-wide stages whose loads it waits for).  Here a workgroup owns 64 x 32 outputs and a stage is 96 k: nine 16-byte
+// loads per thread in flight, the four waves split the stage's k-steps (6 each), their partial tiles meet in LDS in fixed order;
+// with scratch the contraction is also cut into K slices over blockIdx.z (las_gemm_dt), reduced in fixed order afterwards.
 template <int TMS>
 __global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
-    constexpr int BM = 64, BN = 32, BK = 128, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
-    __shared__ __attribute__((aligned(16))) float lds[BK * (PA + PB)];          // 64 KB
+    constexpr int BM = 64, BN = 32, NQ = 3, BK = 32 * NQ, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
+    __shared__ __attribute__((aligned(16))) float lds[BK * (PA + PB)];          // 51 KB
     float* As = lds;
     float* Bs = lds + BK * PA;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* A = g.A + (long long)blockIdx.z * g.strideA;
-    const float* B = g.B + (long long)blockIdx.z * g.strideB;
-    float* C = g.C + (long long)blockIdx.z * g.strideC;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int kbeg = 0, kend = g.K;
+    if (g.splitk > 1) {                          // K slices over blockIdx.z: 64 column blocks alone leave three quarters of the chip idle
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    } else {
+        A += (long long)blockIdx.z * g.strideA;
+        B += (long long)blockIdx.z * g.strideB;
+        C += (long long)blockIdx.z * g.strideC;
+    }
     f32x4_t acc[TMS][2];
 #pragma unroll
     for (int i = 0; i < TMS; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    TileRegs<BM, NT> ra[4];
-    TileRegs<BN, NT> rb[4];
+    TileRegs<BM, NT> ra[NQ];
+    TileRegs<BN, NT> rb[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, 32 * q, g.M, g.K, g.vecA, g.mask_period, g.mask_skip);
-        tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, 32 * q, g.N, g.K, g.vecB, 0, 0);
+    for (int q = 0; q < NQ; ++q) {
+        tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, kbeg + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, kbeg + 32 * q, g.N, kend, g.vecB, 0, 0);
     }
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             tile_sstore_f32<BM, NT>(As + q * 32 * PA, ra[q], g.ksA);
             tile_sstore_f32<BN, NT>(Bs + q * 32 * PB, rb[q], g.ksB);
         }
         __syncthreads();
-        if (k0 + BK < g.K) {
+        if (k0 + BK < kend) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, k0 + BK + 32 * q, g.M, g.K, g.vecA, g.mask_period, g.mask_skip);
-                tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, k0 + BK + 32 * q, g.N, g.K, g.vecB, 0, 0);
+            for (int q = 0; q < NQ; ++q) {
+                tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, k0 + BK + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+                tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, k0 + BK + 32 * q, g.N, kend, g.vecB, 0, 0);
             }
         }
-        const float* ap = As + (w * 32 + lk) * PA + li;
-        const float* bp = Bs + (w * 32 + lk) * PB + li;
+        const float* ap = As + (w * (BK / 4) + lk) * PA + li;
+        const float* bp = Bs + (w * (BK / 4) + lk) * PB + li;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             float a[TMS], b[2];
 #pragma unroll
             for (int i = 0; i < TMS; ++i) a[i] = ap[ks * 4 * PA + i * 16];
@@ -749,7 +762,9 @@ __global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
         const int o = ((rl >> 4) * 2 + (cl >> 4)) * 256 + (rl & 15) * 16 + (cl & 15);
         const float sum = ((red[o] + red[TMS * 512 + o]) + red[2 * TMS * 512 + o]) + red[3 * TMS * 512 + o];
         const int row = m0 + rl, col = n0 + cl;
-        if (row < g.M && col < g.N) {
+        if (row < g.M && col < g.N && g.splitk > 1) {
+            g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = sum;
+        } else if (row < g.M && col < g.N) {
             float v = g.alpha * sum;
             if (g.bias) v += g.bias[col];
             float* cp = C + (long long)row * g.ldc + col;
@@ -868,13 +883,18 @@ static int launch_bf16(const GemmArgs& g, int zdim, hipStream_t st) {
 // Scratch the deterministic split-K of las_gemm would use for this product if it could have all it wants (never more than
 // LAS_GEMM_WS_CAP: beyond that the split degree is cut to fit, with any workspace): tile counts as in las_gemm_dt below.
 extern "C" size_t las_gemm_workspace_bytes(int prec, int M, int N, int K, int batch) {
-    if (M <= 0 || N <= 0 || batch != 1 || K < 2048) return 0;
-    (void)prec;
+    if (M <= 0 || N <= 0 || batch != 1) return 0;
     const int b = (M < 128 || N < 128) ? 64 : 128;        // (both precisions; the bf16 48-row tile has one row block like the 64-row one)
     const long long tiles = (long long)cdiv(M, b) * cdiv(N, b);
-    if (tiles >= 256) return 0;
-    const int want = (int)((512 + tiles - 1) / tiles), maxs = K / 512;
-    const int s = want < maxs ? want : maxs;
+    int s = 1;
+    if (K >= 2048 && tiles < 256) {                        // the tall-contraction rule
+        const int want = (int)((512 + tiles - 1) / tiles), maxs = K / 512;
+        s = want < maxs ? want : maxs;
+    }
+    if (s <= 1 && prec == LAS_PREC_F32 && M <= 64 && K >= 512) {       // the parity mode's skinny products: K slices (las_gemm_dt)
+        s = K / 256;
+        if (s > 512 / cdiv(N, 32)) s = 512 / cdiv(N, 32);
+    }
     if (s <= 1) return 0;
     const size_t need = (size_t)s * M * N * sizeof(float);
     return need < LAS_GEMM_WS_CAP ? need : LAS_GEMM_WS_CAP;
@@ -942,6 +962,17 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
             g.splitk = s; g.kchunk = kchunk; g.partial = (float*)ws;
         }
     }
+    // parity mode, skinny products (the Speller's per-step cell products): 64 / 36 column blocks of a latency-bound K walk -> K slices
+    if (prec == LAS_PREC_F32 && !g_f32_valu && M <= 64 && batch == 1 && ws && g.splitk == 1 && K >= 512) {
+        const int blocks = cdiv(N, 32);
+        int s = K / 256, want = 512 / blocks;
+        if (s > want) s = want;
+        while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
+        if (s > 1) {
+            const int kchunk = ((K + s - 1) / s + 31) / 32 * 32;
+            g.splitk = (K + kchunk - 1) / kchunk; g.kchunk = kchunk; g.partial = (float*)ws;
+        }
+    }
     const int zdim = g.splitk > 1 ? g.splitk : batch;
 
     if (K == 0 && g.splitk == 1) {
@@ -993,7 +1024,7 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
         case 0: {
             dim3 grid(cdiv(N, BN), cdiv(M, BM), zdim);
             if (g_f32_valu) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64), zdim), dim3(256), 0, st, g);
-            else if (M <= 64 && g.splitk == 1) {
+            else if (M <= 64) {
                 const dim3 sg(cdiv(N, 32), 1, zdim);
                 switch (cdiv(M, 16)) {
                     case 1: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<1>, sg, dim3(256), 0, st, g); break;

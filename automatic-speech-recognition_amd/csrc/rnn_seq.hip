@@ -1674,7 +1674,7 @@ static bool mfma_shape_ok(int H) { return H == 64 || H == 128 || H == 256 || H =
 static int pick_cluster(int cell, int H, int flags) {
     int P;
     if (cell == LAS_CELL_LSTM) P = H >= 512 ? 8 : (H >= 256 ? 4 : (H >= 128 ? 2 : 1));
-    else                       P = H >= 512 ? 2 : 1;
+    else                       P = H >= 256 ? 2 : 1;     // (r4: the tanh cell at H = 256 on two CUs serves the 8-row helper-wave / K-split kernels: BPTT 1.77 -> 1.25 us per step)
     const int v = (flags >> 8) & 0xf;
     if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
     return P;
@@ -1935,6 +1935,11 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
 
 // 1 if las_rnn_seq_fwd would serve (cell, prec, B, H, flags) with ONE launch of the helper-wave kernel -- the only kernel that
 // understands x-projection chunks (las_rnn_seq_fwd_chunked)
+static bool handover_room(int B, int rows_per_tile, int P) {
+    const int ncl_pad = (cdiv(B, rows_per_tile) * 2 + 7) / 8 * 8;
+    return (long long)ncl_pad * (P + 1) * 2 <= las_device_cus();
+}
+
 extern "C" int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int flags) {
     if (prec != LAS_PREC_BF16 || !mfma_shape_ok(H) || B <= 0 || (flags & LAS_SEQ_NO_HELPER_WAVES)) return 0;
     const int P = pick_cluster(cell, H, flags);
@@ -1944,6 +1949,10 @@ extern "C" int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int f
     const int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
     if (max_tiles < 1) return 0;
     const bool k8 = !(flags & LAS_SEQ_ROWS16) && cdiv(B, 8) <= max_tiles && (q & 1);
+    // The chunks' producers run WHILE the sweep holds its compute units (whole CUs: 159 KB of LDS each): the hand-over only makes sense
+    // while the sweep -- clusters + warmers -- leaves at least half of the machine to them.  r4, B = 144 / 192 at H = 256 (180 / 240 of 256
+    // CUs): the x-projection chunks crawl on the few free CUs, 52 ms per step instead of 26 / the sweep runs into its chunk-wait bound.
+    if (!handover_room(B, k8 ? 8 : 16, P)) return 0;
     if (k8) return 1;
     return ((q & 2) && cdiv(B, 16) <= max_tiles) ? 1 : 0;
 }
@@ -2040,7 +2049,7 @@ extern "C" int las_rnn_seq_bwd_chunks_ok(int cell, int prec, int B, int H, int f
     RnnArgs a; a.H = H; a.B = B;
     const int q = dispatch_bf16(cell, P, true, a, nullptr, true);
     const int max_tiles = (las_device_cus() / P / 8) * 8 / 2;
-    return (max_tiles >= 1 && (q & 1) && cdiv(B, 8) <= max_tiles) ? 1 : 0;      // served by ONE launch of the 8-row K-split kernel
+    return (max_tiles >= 1 && (q & 1) && cdiv(B, 8) <= max_tiles && handover_room(B, 8, P)) ? 1 : 0;      // served by ONE launch of the 8-row K-split kernel, with room beside it
 }
 
 extern "C" int las_rnn_seq_bwd(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,

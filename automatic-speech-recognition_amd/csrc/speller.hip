@@ -2784,8 +2784,11 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         if (skinny) {
             GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, d.gates + ((size_t)0 * U + t) * B * GD, GD, f->cellb[0], st));
         } else {
+            // (parity mode: the skinny fp32 product takes K slices when it is given scratch -- the after-loop contractions' region)
+            const bool hw = f->ws && f->ws_bytes > wl_.gemm;
             GEMM_OK(las_gemm(f->prec, 0, 0, B, GD, I0D, 1.f, d.xin0 + (size_t)t * B * I0D, I0D, 0, f->cellW[0], GD, 0, 0.f,
-                             d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+                             d.gates + ((size_t)0 * U + t) * B * GD, GD, 0, f->cellb[0], LAS_ACT_NONE, 1, 0, 0,
+                             hw ? (char*)f->ws + wl_.gemm : nullptr, hw ? f->ws_bytes - wl_.gemm : 0, st));
         }
         for (int l = 1; l < NL; ++l) {
             hipLaunchKernelGGL((dec_pointwise_fwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, l - 1, t);
@@ -2908,7 +2911,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
                 GEMM_OK(las_skinny_gemm_bf16(d.dgbf, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, st));
             } else if (l == 0) {
                 GEMM_OK(las_gemm(prec, 0, 1, B, I0D, GD, 1.f, dG, GD, 0, f->cellW[0], GD, 0, 0.f, d.dXin0 + (size_t)t * B * I0D,
-                                 I0D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+                                 I0D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
             } else {
                 float* tl = tmp + (size_t)l * B * 2 * D;
                 GEMM_OK(las_gemm(prec, 0, 1, B, 2 * D, GD, 1.f, dG, GD, 0, f->cellW[l], GD, 0, 0.f, tl, 2 * D, 0, nullptr,

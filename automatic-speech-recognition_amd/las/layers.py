@@ -628,7 +628,7 @@ class _BLSTM16(torch.autograd.Function):
             Wb = _shadow("ih", (kfw, kbw), I0, False, Ik, 2 * GH)                           # rows padded to Ik: [Ik, 2GH]
             dx = torch.empty(B, T, Ik, device=dev, dtype=bf)
             c = DOUT_CHUNK_ROWS
-            if ctx.x_is_tanh and ctx.in_pyramid and c and T >= 4 * c and direct:
+            if ctx.x_is_tanh and ctx.in_pyramid and c and T >= 4 * c and direct and _hip.rnn_seq_bwd_chunks_ok(_cellid(cell), prec, B, H):
                 # first time chunk only; the dense node below (the consumer of this dPre) interleaves the others with its own.
                 # (Only inside pBLSTMLayer's stack, where that dense node's input gradient goes to the recurrent layer below and
                 #  nowhere else: a consumer that does not know about the chunks would read an unfinished tensor.)

@@ -1,0 +1,33 @@
+"""Eight ranks on one host.  No 8-GPU node has been available to any round, so what CAN be measured on
+the one-GPU box is the host side of eight ranks: eight processes enqueue a bench-geometry train step at the same time (default
+affinity, no taskset), each behind a closed command-processor gate; the steps then run on the device one rank at a time
+(tools/host_time_ranks.py).  A rank's Python thread must stay well below the step time, or eight ranks on a 16-core host would be
+host-bound before a single byte is exchanged."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eight_ranks_enqueue_a_step_in_less_than_half_its_device_time(tmp_path):
+    out = str(tmp_path / "ranks.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_time_ranks.py"), "--ranks", "8", "--steps", "4", "--out", out],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.load(open(out))
+    print("8 ranks on %d usable cores: host enqueue %s ms per step and rank" % (rec["usable_cores"], rec["host_enqueue_ms"]))
+    path = os.environ.get("LAS_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test="eight_ranks_host", **rec)) + "\n")
+    assert rec["ranks"] == 8 and rec["schedule"]["dout_chunks"] == 3 and rec["schedule"]["serial"] == 0      # the timed schedule was enqueued
+    # the bench step is 14.8 ms on the device (profiles/r4_bench.json): a rank's launch thread must need less than half of that while
+    # seven other ranks do the same (r4 on the pool's box, 16 usable cores: median 6.6, max 8.6 ms; one rank alone: 4.2 ms)
+    assert rec["host_enqueue_ms"]["median"] < 0.5 * 14.8, rec
+    assert rec["host_enqueue_ms"]["max"] < 25.0, rec                 # a hidden host synchronisation would show as the 30 s watchdog
