@@ -238,6 +238,9 @@ def workspace(dev, nbytes, tag="default"):
     _ws_epoch[key] = _ws_epoch.get(key, 0) + 1
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("liblas_hip: scratch '%s' (%d bytes) would have to be allocated inside a HIP graph capture; run the step "
+                               "once eagerly before capturing it (the buffer then exists and the graph only records launches)" % (tag, nbytes))
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
         _ws_cache[key] = buf
     return buf
@@ -379,7 +382,11 @@ def join_side_stream():
 
 
 def _tag(t):
-    """scratch is per STREAM (split-K partials, column-sum partials): launches of two streams may overlap"""
+    """scratch is per STREAM (split-K partials, column-sum partials): launches of two streams may overlap.  While a HIP graph is being
+    captured the launch stream's scratch is used: the captured step replays on the launch stream, in order with its eager users (and a
+    buffer allocated on torch's capture stream would come from the graph's private pool and outlive the graph in this cache)."""
+    if torch.cuda.is_current_stream_capturing():
+        return t
     sid = torch.cuda.current_stream().stream_id
     return t if sid == 0 else "%s_s%d" % (t, sid)
 
@@ -599,6 +606,7 @@ def next_announce():
 
 _overlap = {}
 ALLOW_SERIAL_STREAMS = bool(os.environ.get("LAS_ALLOW_SERIAL_STREAMS"))
+FORCE_SERIAL_STREAMS = os.environ.get("LAS_ALLOW_SERIAL_STREAMS") == "force"     # no probe: every hand-over with its producers first
 
 
 def _probe_overlap(dev, other):
@@ -631,6 +639,8 @@ def streams_overlap(dev):
     probe is repeated once and then raises -- unless LAS_ALLOW_SERIAL_STREAMS=1 says that serialised streams are expected (counter
     passes), in which case the hand-overs are switched off and `last_variants` of the step says so."""
     a = aux_streams(dev)
+    if FORCE_SERIAL_STREAMS:
+        return False
     cur = torch.cuda.current_stream(dev)
     if any(cur == st for st in a.values()):
         # asked from inside an auxiliary stream's context (the Speller's side-stream part): the answer is the launch stream's

@@ -422,8 +422,6 @@ def test_forward_sweep_over_rows_of_different_lengths_equals_each_row_alone(cell
     dev = "cuda"
     B, T, H = 11, 77, 256
     G = 4 if cell else 1
-    if not _hip.rnn_seq_fwd_rows_ok(cell, 1, B, H):
-        pytest.skip("the 8-row helper-wave kernel does not serve this configuration here")
     g = torch.Generator().manual_seed(5)
     io = _hip.rnn_seq_io_dtype(cell, 1, H)
     xp = (torch.randn(B, T, 2, G * H, generator=g) * 0.5).to(dev).to(io)
@@ -433,6 +431,12 @@ def test_forward_sweep_over_rows_of_different_lengths_equals_each_row_alone(cell
     row_T = torch.tensor(lens, dtype=torch.int32, device=dev)
     out = torch.full((B, T, 2 * H), 7.0, device=dev, dtype=io)
     cst = torch.full((B, T, 2, H), 7.0, device=dev, dtype=io) if cell else None
+    if not _hip.rnn_seq_fwd_rows_ok(cell, 1, B, H):
+        # (the tanh cell: no 8-row helper-wave kernel) the contract is "ask las_rnn_seq_fwd_rows_ok": a configuration it does not serve
+        # must be REFUSED, not swept as if the rows were of equal length
+        with pytest.raises(RuntimeError, match="rows of different lengths"):
+            _hip.rnn_seq_fwd(cell, 1, B, T, H, xp.clone(), w0, w1, G * H, out, 2 * H, T * 2 * H, cst, row_T=row_T)
+        return
     _hip.rnn_seq_fwd(cell, 1, B, T, H, xp.clone(), w0, w1, G * H, out, 2 * H, T * 2 * H, cst, row_T=row_T)
     for b, n in enumerate(lens):
         o1 = torch.empty(1, n, 2 * H, device=dev, dtype=io)

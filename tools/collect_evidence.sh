@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round measurement evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_evidence.sh r3        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,phase_stamps_insitu.txt,
+#   tools/collect_evidence.sh r4        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,phase_stamps_insitu.txt,
 #                                          timeline.txt,bucket_sweep.txt,decode_{bench.json,kernel_stats.csv,pmc.csv,pmc.json},speller_phase_stamps.txt,
 #                                          speller_loc_phase_stamps.txt,bench_config3.json,config3_kernel_stats.csv}
 # (build first: make -C automatic-speech-recognition_amd/csrc all prof; hipcc ... -DLAS_ROW_STAMPS tools/micro/bench_fused.hip -o tools/micro/bin/bench_fused_stamps)
@@ -50,4 +50,16 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt_c3_$P -o b -- python3 bench.py --con
 python3 tools/kernel_stats.py /tmp/kt_c3_$P 3 gpurun_out/${P}_config3_kernel_stats.csv > /dev/null
 python3 bench.py --config 3 --no-decode --no-train-loop > gpurun_out/${P}_bench_config3.json 2> /dev/null
 python3 tools/bucket_sweep.py > gpurun_out/${P}_bucket_sweep.txt 2>&1
+# ---- round 4: the parity mode (exact-fp32 MFMA kernels) -- its own kernel trace and the GEMM shapes against the 157 TF/s fp32 peak
+rocprofv3 --kernel-trace --stats -d /tmp/kt_f32_$P -o b -- python3 bench.py --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_f32_kt.log 2>&1
+python3 tools/kernel_stats.py /tmp/kt_f32_$P 1 gpurun_out/${P}_f32_kernel_stats.csv > /dev/null
+python3 tools/bench_gemm_f32.py > gpurun_out/${P}_f32_gemm_shapes.txt 2>&1
+python3 bench.py --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_bench_f32.json 2> /dev/null
+# ---- the cell the reference builds (BasicRNNCell), speed mode: kernel trace
+rocprofv3 --kernel-trace --stats -d /tmp/kt_rnn_$P -o b -- python3 bench.py --cell rnn --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_rnn_kt.log 2>&1
+python3 tools/kernel_stats.py /tmp/kt_rnn_$P 3 gpurun_out/${P}_rnn_kernel_stats.csv > /dev/null
+# ---- eight ranks' host side on this box (one GPU: the steps run one rank at a time behind command-processor gates)
+timeout 900 python3 tools/host_time_ranks.py --ranks 8 --steps 4 --out gpurun_out/${P}_host_ranks_8.json > /dev/null 2>&1
+# ---- the whole GPU suite as the driver runs it (one process, -rs: every skip with its reason)
+python3 -m pytest tests -m gpu -q -rs > gpurun_out/${P}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${P}_pytest_gpu.log
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300

@@ -5,6 +5,8 @@ No multi-GPU node has been available to any round, and N ranks cannot really sha
 Speller loops need all their workgroups co-resident.  So the ranks here take turns ON THE DEVICE but not on the host:
 
   * every rank (one process, gloo for the barriers only) builds the bench model and batch on cuda:0;
+  * the chunked hand-overs run producers-first (LAS_ALLOW_SERIAL_STREAMS=force: same kernels, same launches, no kernel spins on another
+    queue's output -- with 8 x 5 hardware queues alive not every queue of a process is mapped at every moment);
   * per step every rank first puts a GATE into its launch stream -- hipStreamWaitValue32 on a word of signal memory: the command
     processor waits, no compute unit is occupied -- then all ranks enqueue their whole step CONCURRENTLY (this is what is timed:
     `LAS.train` returning, ~180 launches on four streams), then the gates are opened one rank at a time and the step runs alone.
@@ -37,6 +39,11 @@ def worker(rank, world, port, steps, B, T, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    # `world` processes x 5 streams keep more hardware queues alive than the device schedules at once; a kernel that SPINS on data a
+    # kernel of another queue of its process produces (the chunked hand-overs) can then wait for a queue that is not mapped: every
+    # hand-over runs producers-first here ("force": the same kernel instances and the same number of launches -- the host cost that
+    # is measured -- without cross-queue spin waits)
+    os.environ["LAS_ALLOW_SERIAL_STREAMS"] = "force"
     from bench import bench_args, usable_cores
     from helpers import synthetic_batch
     from las import _hip, layers as L, variables as V
@@ -54,10 +61,7 @@ def worker(rank, world, port, steps, B, T, out_path):
     def open_gate(v):
         assert hip.hipStreamWriteValue32(ctypes.c_void_p(opener.cuda_stream), sig, v, 0) == 0
 
-    # `world` processes x 5 streams keep more hardware queues alive than the device has; the scheduler time-slices them, and a
-    # persistent kernel whose partner workgroups are switched out mid-step polls longer than on a device of its own: wide poll bounds
-    # here (they are time-outs, not part of the measurement)
-    _hip.speller_flags |= _hip.speller_spin_log2(25)
+    _hip.speller_flags |= _hip.speller_spin_log2(25)             # (wide poll bounds: time-outs, not part of the measurement)
     _hip.seq_flags |= _hip.seq_spin_log2(25)
     L.set_cell("lstm"); L.set_precision("bf16")
     V.reset_default_store(device=dev, seed=0)
@@ -123,7 +127,10 @@ def main():
     ap.add_argument("--out", default="/tmp/host_time_ranks.json")
     a = ap.parse_args()
     import torch.multiprocessing as mp
-    port = 29700 + os.getpid() % 200
+    import socket
+    with socket.socket() as sk:                                    # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(worker, args=(a.ranks, port, a.steps, a.batch, a.frames, a.out), nprocs=a.ranks, join=True)
 
 
