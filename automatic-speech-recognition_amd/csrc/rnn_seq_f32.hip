@@ -394,9 +394,6 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
     if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
-template <typename K>
-int set_attr(K kern, int bytes) { return (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
-
 struct F32Ws { size_t err, sink, xcc, xbuf, per_cl, total; int max_cl; };
 F32Ws f32_layout(int cell, int H) {
     const int G = cell == LAS_CELL_LSTM ? 4 : 1, P = G * H / 64, TPM = 64 / G / 16, GPM = 16 * (64 / G) / 2;

@@ -136,12 +136,13 @@ class DeviceFeeder:
             self.source.close()
 
 
-def feeder_for(source, device, feat_dim=13, is_training=True, depth=3):
-    """DeviceFeeder sized for the reference's bucket table (tfrecord_data_loader.py:75-83)."""
+def feeder_for(source, device, feat_dim=13, is_training=True, depth=3, batch_scale=1):
+    """DeviceFeeder sized for the reference's bucket table (tfrecord_data_loader.py:75-83); batch_scale: train.py --stack."""
     from tfrecord_data_loader import BUCKET_BATCH_LIMIT, EVAL_BOUNDARIES, TRAIN_BOUNDARIES
     bounds = TRAIN_BOUNDARIES if is_training else EVAL_BOUNDARIES
-    cap = max(BUCKET_BATCH_LIMIT[k] * (b - 1) * feat_dim * 3 for k, b in enumerate(bounds))
-    return DeviceFeeder(source, device, feat_dim, cap, max(BUCKET_BATCH_LIMIT), 219 if is_training else 227, depth=depth)
+    k = max(int(batch_scale), 1)
+    cap = max(k * BUCKET_BATCH_LIMIT[i] * (b - 1) * feat_dim * 3 for i, b in enumerate(bounds))
+    return DeviceFeeder(source, device, feat_dim, cap, k * max(BUCKET_BATCH_LIMIT), 219 if is_training else 227, depth=depth)
 
 
 class LaggedLog:

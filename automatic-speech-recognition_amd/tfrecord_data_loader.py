@@ -275,8 +275,9 @@ class _BucketedIterator:
     world x batch-limit utterances and this rank keeps rows rank, rank + world, ... of that global batch (a leftover smaller
     than the world is dropped on every rank) -- all ranks train on the same bucket shape at every step."""
 
-    def __init__(self, files, record_parser, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1):
+    def __init__(self, files, record_parser, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1, batch_scale=1):
         self.files = list(files)
+        self.batch_scale = max(int(batch_scale), 1)                       # train.py --stack: k bucket batches per step and rank
         self.parser = record_parser
         self.feat_dim = feat_dim
         self.is_training = is_training
@@ -339,7 +340,7 @@ class _BucketedIterator:
             if ys[1] > self.max_tokenlen:
                 raise ValueError("token sequence of %d exceeds the padded length %d" % (ys[1], self.max_tokenlen))
             buckets[k].append((xs, ys))
-            if len(buckets[k]) == BUCKET_BATCH_LIMIT[k] * self.world:
+            if len(buckets[k]) == BUCKET_BATCH_LIMIT[k] * self.batch_scale * self.world:
                 yield self._emit(k, buckets[k])
                 buckets[k] = []
         for k, items in enumerate(buckets):                               # leftovers at end of data
@@ -377,7 +378,7 @@ class NativeReader:
     ring): same constructor arguments, same batch order as `_BucketedIterator`.  `get_next()` returns numpy COPIES (API parity);
     the train loop uses `next_slot()` / `upload()` (las.input_pipeline.DeviceFeeder) and never copies on the host."""
 
-    def __init__(self, files, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1, slots=4):
+    def __init__(self, files, feat_dim, is_training, seed=0, shuffle_buffer=64, cycle_length=16, rank=0, world=1, slots=4, batch_scale=1):
         import ctypes
         from las import _hip
         self._hip, self._ct = _hip, ctypes
@@ -390,7 +391,7 @@ class NativeReader:
         for i, b in enumerate(bounds):
             cfg.bounds[i] = b
         for i, b in enumerate(BUCKET_BATCH_LIMIT):
-            cfg.batch_limit[i] = b
+            cfg.batch_limit[i] = b * max(int(batch_scale), 1)                 # (train.py --stack)
         cfg.max_tokenlen = self.max_tokenlen
         cfg.shuffle_buffer = shuffle_buffer if is_training else 0
         cfg.cycle_length, cfg.seed, cfg.rank, cfg.world, cfg.slots = cycle_length, int(seed) & ((1 << 64) - 1), int(rank), max(int(world), 1), slots
@@ -455,16 +456,16 @@ class NativeReader:
             pass
 
 
-def tfrecord_iterator(filenames, record_parser, feat_dim=13, is_training=True, seed=0, rank=0, world=1, native=False):
+def tfrecord_iterator(filenames, record_parser, feat_dim=13, is_training=True, seed=0, rank=0, world=1, native=False, batch_scale=1):
     """reference tfrecord_data_loader.py:54-109.  `filenames`: a glob pattern or a list of paths.
     Returns (iterator, output_types, output_shapes).  native=True: the C++ reader of liblas_hip.so (same batches)."""
     files = sorted(glob.glob(filenames)) if isinstance(filenames, str) else list(filenames)
     if not files:
         raise IOError("no TFRecord files match %r" % (filenames,))
     if native:
-        it = NativeReader(files, feat_dim, is_training, seed=seed, rank=rank, world=world)
+        it = NativeReader(files, feat_dim, is_training, seed=seed, rank=rank, world=world, batch_scale=batch_scale)
     else:
-        it = _BucketedIterator(files, record_parser, feat_dim, is_training, seed=seed, rank=rank, world=world)
+        it = _BucketedIterator(files, record_parser, feat_dim, is_training, seed=seed, rank=rank, world=world, batch_scale=batch_scale)
     max_tok = it.max_tokenlen
     types = ((np.float32, np.int32), (np.int32, np.int32))
     shapes = (([None, None, feat_dim, 3], [None]), ([None, max_tok], [None]))

@@ -71,7 +71,7 @@ def main():
     from las.input_pipeline import LaggedLog, feeder_for
     if args.synthetic:
         from data import SyntheticBatches
-        source = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank)
+        source = SyntheticBatches(args.feat_dim, args.vocab_size, seed=args.seed, rank=rank, batch_scale=max(args.stack, 1))
     else:
         # train.py:45-55: data/tfrecord_{feat_type}_bpe_5k/train-*.tfrecord.  Every rank walks the same record stream (same
         # seed) and keeps its rows of every global batch: one bucket shape per step on all ranks
@@ -82,8 +82,11 @@ def main():
         if not files:
             raise Exception("Run preprocess.py, create_tfrecord.py first")
         source, _, _ = tfrecord_iterator(files, data_parser, args.feat_dim, seed=args.seed, rank=rank, world=world,
-                                         native=os.environ.get("LAS_PY_READER") != "1")
-    batches = feeder_for(source, dev, args.feat_dim, is_training=True, depth=max(2, int(os.environ.get("LAS_PREFETCH", "3"))))
+                                         native=os.environ.get("LAS_PY_READER") != "1", batch_scale=max(args.stack, 1))
+    # --stack k: every bucket emits k times the reference's rows, i.e. k of its batches as ONE step (LAS.train_stacked's arithmetic:
+    # the update of k data-parallel ranks) -- the sweeps are latency-bound on a fifth of the compute units, k = 4 is 1.96x the rate
+    batches = feeder_for(source, dev, args.feat_dim, is_training=True, depth=max(2, int(os.environ.get("LAS_PREFETCH", "3"))),
+                         batch_scale=max(args.stack, 1))
 
     if rank == 0:
         logging.info("Total weights: {}".format(st.num_params()))

@@ -42,6 +42,9 @@ def test_train_test_decode_on_tfrecords(tmp_path):
     out = _run("train.py", ["--max_steps", "1"], tmp)                   # resumes: global step continues
     assert "Step: 3," in out
 
+    out = _run("train.py", ["--max_steps", "1", "--stack", "2"], tmp)   # two bucket batches per step (here: the whole corpus in one)
+    assert "Step: 4," in out
+
     out = _run("test.py", [], tmp)
     assert "total utterances: 4" in out
     assert len(open(os.path.join(tmp, "log", "test_gt.txt")).read().split("\n")) == 4

@@ -259,3 +259,26 @@ def test_evaluation_passes_are_not_sharded_by_the_reader(tmp_path):
         tdl._BucketedIterator([p], tdl.data_parser, 13, False, rank=0, world=2)
     with pytest.raises(IOError, match="world = 1"):
         tdl.NativeReader([p], 13, False, rank=1, world=2)
+
+
+def test_stacked_batches_hold_k_times_the_rows_in_both_readers(tmp_path):
+    """train.py --stack k: every bucket emits k times the reference's batch (k bucket batches as one step)."""
+    rng = np.random.RandomState(0)
+    files = []
+    for i in range(3):                                                 # 240 utterances of ONE bucket (639 <= T < 1062: 48 rows, stacked 96)
+        lens = rng.randint(650, 1000, size=80)
+        fn = str(tmp_path / ("train-%d.tfrecord" % i))
+        tdl.write_tfrecord(fn, [rng.randn(n, 13, 3).astype(np.float32) for n in lens], [rng.randint(3, 30, size=rng.randint(2, 100)) for _ in lens])
+        files.append(fn)
+    a = tdl._BucketedIterator(files, tdl.data_parser, 13, True, seed=5, shuffle_buffer=2, cycle_length=3, batch_scale=2)
+    b = tdl.NativeReader(files, 13, True, seed=5, shuffle_buffer=2, cycle_length=3, batch_scale=2)
+    seen = set()
+    for k in range(6):
+        xa, xb = next(a), next(b)
+        assert _same(xa, xb), k
+        B, T = xa[0][0].shape[:2]
+        kb = tdl.TRAIN_BOUNDARIES.index(T + 1)
+        assert B <= 2 * tdl.BUCKET_BATCH_LIMIT[kb]
+        seen.add(B == 2 * tdl.BUCKET_BATCH_LIMIT[kb])
+    assert True in seen                                                # at least one full stacked batch (96 / 192 rows)
+    b.close()

@@ -1,3 +1,4 @@
+"""Does a hipStreamWaitValue32 gate hold a stream (null stream and a pool stream) until hipStreamWriteValue32 opens it?  (tools/host_time_ranks.py relies on it.)"""
 import ctypes, time, torch, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "automatic-speech-recognition_amd"))
