@@ -2960,6 +2960,12 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     if (V <= EMB_MAX_V && UB <= EMB_MAX_N) {      // bucket the positions by token, reduce the rows that occur (accumulates into demb)
         int* estart = (int*)(base + w.embp);
         int* epos = estart + V + 1;
+        // (the token list / the histogram in LDS: up to 96 / 68 KB at the limits -- above the 64 KB a launch gets without asking)
+        static int attr_h = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(emb_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (EMB_MAX_V + 1024) * (int)sizeof(int));
+        static int attr_p = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(emb_place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (EMB_MAX_N + 264) * (int)sizeof(unsigned short));
+        LAS_ARG(attr_h == 0 && attr_p == 0, "hipFuncSetAttribute(emb_*_kernel) failed: %d %d", attr_h, attr_p);
         hipLaunchKernelGGL(emb_hist_kernel, dim3(1), dim3(1024), (size_t)(V + 1024) * sizeof(int), st, (const int*)d.tok_in, UB, V, estart);
         LAS_LAUNCHED();
         hipLaunchKernelGGL(emb_place_kernel, dim3(cdiv(UB, 256)), dim3(256), (size_t)((UB + 263) & ~7) * sizeof(unsigned short), st,

@@ -104,6 +104,16 @@ def test_bf16_row_kernels_match_oracle(shape, flags):
         assert err < 2e-2, (n, err, scale)
 
 
+def test_embedding_gradient_buckets_with_more_than_32k_positions():
+    """The embedding gradient's token buckets (emb_hist / emb_place / emb_reduce) keep the token list in LDS: at B U = 35,200
+    positions that is more than the 64 KB a launch gets without asking (a stacked B = 192 step has 36,672)."""
+    ln, an, gn, lo, ao, go = _run(0, 1, 64, 32, 32, 176, 20, 200, False)
+    n = "embedding/embedding_matrix"
+    scale = max(go[n].abs().max().item(), 1e-3)
+    assert (gn[n] - go[n]).abs().max().item() / scale < 2e-2
+    assert (ln - lo).abs().max().item() < 5e-3 * max(1.0, lo.abs().max().item())
+
+
 LOC_SHAPES = [
     # D,  A,   H,  B, Tp, U, mixed, (Kc, C)      -- location-aware attention in the one-launch loop kernels (round 3)
     (512, 128, 256, 5, 37, 9, False, (201, 10)),     # reference defaults K = 201, C = 10: both borders of the filter clipped
