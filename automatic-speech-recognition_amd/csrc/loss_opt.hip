@@ -45,9 +45,10 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
     }
 }
 
-// fixed-order sum of n values (single workgroup), out[0] += sum(a), out[1] += sum(b)
+// fixed-order sum of n values (single workgroup), out[0] += sum(a), out[1] += sum(b);  scale != NULL (bit 2 of las_ce_loss's `smooth`):
+// out[0] = sum(a), out[1] = sum(b), out[2] = sum(a) * scale[0] -- the caller neither zeroes `out` nor multiplies afterwards
 __global__ __launch_bounds__(1024) void sum2_kernel(const float* __restrict__ a, const float* __restrict__ b2, long long n,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, const float* __restrict__ scale) {
     __shared__ float red[2][16];
     float s0 = 0.f, s1 = 0.f;
     for (long long i = threadIdx.x; i < n; i += 1024) { s0 += a[i]; if (b2) s1 += b2[i]; }
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(1024) void sum2_kernel(const float* __restrict__ a,
     if (threadIdx.x == 0) {
         float t0 = 0.f, t1 = 0.f;
         for (int i = 0; i < 16; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
-        out[0] += t0;
-        if (b2) out[1] += t1;
+        if (scale) { out[0] = t0; out[1] = b2 ? t1 : 0.f; out[2] = t0 * scale[0]; }
+        else { out[0] += t0; if (b2) out[1] += t1; }
     }
 }
 
@@ -76,7 +77,9 @@ extern "C" int las_ce_loss(const float* logits, long long sb, long long st, cons
     hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv((long long)B * U, 4)), dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V,
                        epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
     LAS_LAUNCHED();
-    hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_ce, (const float*)row_mask, (long long)B * U, sums);
+    LAS_ARG(!(smooth & 4) || scale_ptr, "las_ce_loss: bit 2 of smooth (write sums, sums[2] = scaled loss) needs scale_ptr");
+    hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_ce, (const float*)row_mask, (long long)B * U, sums,
+                       (smooth & 4) ? scale_ptr : (const float*)nullptr);
     LAS_LAUNCHED();
     return 0;
 }

@@ -497,22 +497,32 @@ class _CELoss(torch.autograd.Function):
         B, U, _ = logits_bt.shape
         sb, st_, sv = logits_bt.stride()
         assert sv == 1
-        dev = logits_bt.device
-        sums = torch.zeros(2, device=dev)
-        dl = torch.empty_strided(logits_bt.shape, logits_bt.stride(), device=dev)
-        nb = _hip.lib().las_ce_loss_workspace_bytes(B, U)
-        ws = _hip.workspace(dev, nb, "ce")
-        _hip.check(_hip.lib().las_ce_loss(_hip.p(logits_bt), sb, st_, _hip.p(y_i32), y_i32.shape[1], B, U, V_, 0.01,
-                                          int(bool(smooth)), _hip.p(sums), _hip.p(scale), _hip.p(dl), _hip.p(ws), ws.numel(),
-                                          _hip.stream()), "las_ce_loss")
+        loss, dl, sums = _ce_loss(logits_bt, y_i32, V_, smooth, scale)
         ctx.save_for_backward(dl)
         ctx.sums = sums
-        return sums[0] * scale[0]
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return dl * g, None, None, None, None
+
+
+def _ce_loss(logits_bt, y_i32, V_, smooth, scale):
+    """-> (loss = sum(ce * mask) * scale as a 0-d view, dlogits with `scale` already in it, sums [3]).  One kernel pair: the sums are
+    written (no fill in front), the scaled loss is sums[2] (no multiply behind)."""
+    B, U, _ = logits_bt.shape
+    sb, st_, sv = logits_bt.stride()
+    assert sv == 1
+    dev = logits_bt.device
+    sums = torch.empty(3, device=dev)
+    dl = torch.empty_strided(logits_bt.shape, logits_bt.stride(), device=dev)
+    nb = _hip.lib().las_ce_loss_workspace_bytes(B, U)
+    ws = _hip.workspace(dev, nb, "ce")
+    _hip.check(_hip.lib().las_ce_loss(_hip.p(logits_bt), sb, st_, _hip.p(y_i32), y_i32.shape[1], B, U, V_, 0.01,
+                                      int(bool(smooth)) | 4, _hip.p(sums), _hip.p(scale), _hip.p(dl), _hip.p(ws), ws.numel(),
+                                      _hip.stream()), "las_ce_loss")
+    return sums[2], dl, sums
 
 
 class LAS:
@@ -616,6 +626,7 @@ class LAS:
             n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
             n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
             loss_scale = self._loss_scale(n_total)
+            y_u = y[:, :dec_steps].contiguous()               # (the loss's label block: copied here, off the chain)
             # the Speller's host-side preparation: token schedule, encoder lengths, masks
             prep = self.speller.prepare(audio.shape[0], self.listener.output_length(audiolen, enc_type), dec_steps, dev, y,
                                         True, coins, sampled)
@@ -626,7 +637,9 @@ class LAS:
             logits, ctc_logits, alphas = self.speller(h, enc_len, dec_steps, y, coins=coins, sampled=sampled, prepared=prep)
 
         with _hip.roctx_range("loss"):
-            loss = self._get_loss(logits, y, n_total, loss_scale)                         # sum_local / n_total
+            # the loss is the root of the graph: its gradient w.r.t. the logits (scale included) comes out of the same kernel pair and is
+            # handed to the Speller's node directly -- no ones_like fill, no [B, U, V] multiply by 1.0, no scalar multiply on the chain
+            loss, dlogits, _ = _ce_loss(logits.detach(), y_u, logits.shape[2], self.args.label_smoothing, loss_scale)   # sum_local / n_total
         early = []
         if self.dp is not None:
             def before_tail(P4, st=st, dev=dev):
@@ -646,7 +659,7 @@ class LAS:
             L.BEFORE_TAIL_HOOK[0] = before_tail
         with _hip.roctx_range("backward"):
             try:
-                loss.backward()
+                logits.backward(dlogits)
             finally:
                 L.BEFORE_TAIL_HOOK[0] = None
             _hip.join_side_stream()                   # weight gradients accumulated on the side stream

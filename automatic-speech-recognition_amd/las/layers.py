@@ -329,18 +329,29 @@ _CHUNK_FLAGS = {}
 def _chunk_flag(dev):
     """A zeroed device word for the completion count of one layer's x-projection chunks (a small ring: a word is reused only
     after several later sweeps have been enqueued behind the one that reads it)."""
-    ring = _CHUNK_FLAGS.setdefault(str(dev), [torch.zeros(_RING, dtype=torch.int32, device=dev), 0, 0])
+    ring = _flag_ring(dev)
     i = ring[1] % _RING
     ring[1] += 1
     w = ring[0][i:i + 1]
     if ring[2] > 0:
         ring[2] -= 1                                     # zeroed with the whole ring by begin_step
     else:
+        VARIANTS["flag_fills"] += 1                      # (a fill on the chain: more hand-overs in one step than the ring holds, or no begin_step)
         w.zero_()
     return w
 
 
 _RING = 32
+
+
+def _flag_ring(dev):
+    # (r4: this used to be `_CHUNK_FLAGS.setdefault(key, [torch.zeros(...), 0, 0])` -- Python evaluates the default on EVERY call, i.e. one
+    #  allocation + one 5-7 us fill kernel per hand-over word, eleven per step, seven of them on the dependency chain)
+    key = str(dev)
+    ring = _CHUNK_FLAGS.get(key)
+    if ring is None:
+        ring = _CHUNK_FLAGS[key] = [torch.zeros(_RING, dtype=torch.int32, device=dev), 0, 0]
+    return ring
 
 
 # Which schedule variants the current step used (LAS.train copies it into `las.last_variants`): sweeps launched with their x-projection
@@ -349,7 +360,7 @@ _RING = 32
 # resident; "serial": hand-overs that ran with their producers in front of the consumer on one stream (LAS_ALLOW_SERIAL_STREAMS=1 under a
 # tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
 # that is timed must be the variant that is tested.
-VARIANTS = {"xproj_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0}
+VARIANTS = {"xproj_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0}
 
 
 def begin_step(dev):
@@ -357,7 +368,7 @@ def begin_step(dev):
     hand-over words instead of one 5 us fill in front of every sweep and every chunked dense product (11 per step, on the chain)."""
     for k in VARIANTS:
         VARIANTS[k] = 0
-    ring = _CHUNK_FLAGS.setdefault(str(dev), [torch.zeros(_RING, dtype=torch.int32, device=dev), 0, 0])
+    ring = _flag_ring(dev)
     ring[0].zero_()
     ring[1], ring[2] = 0, _RING
 

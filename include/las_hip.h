@@ -312,6 +312,8 @@ int las_speller_bwd_part(const las_speller_bwd_args* a, int part, void* stream);
  * position counts (the RNNLM's mean sparse cross entropy, lang/char_rnn_model.py:146-149).
  * sums[0] += sum(ce*mask), sums[1] += sum(mask)   (caller zeroes sums; the division
  * sum/(n+1e-9) is the caller's so that data-parallel ranks can all-reduce both terms first).
+ * bit 2 of `smooth` (needs scale_ptr; sums then has THREE floats): sums[0] = sum(ce*mask), sums[1] = sum(mask),
+ * sums[2] = sums[0] * scale_ptr[0] are WRITTEN -- the scaled loss without a fill in front and a multiply behind.
  * dlogits = scale_ptr[0] * mask * (softmax - smoothed_onehot)    (scale = 1/(n_total+1e-9), a
  * device scalar; NULL dlogits skips the gradient).
  */
