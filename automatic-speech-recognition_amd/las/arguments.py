@@ -89,7 +89,8 @@ _EXTRA = [
     (("--tfrecord_dir",), str, "", "Directory holding train-*.tfrecord / dev-1.tfrecord (default data/tfrecord_<feat>_bpe_5k)."),
     (("--stack",), int, 1, "Bucket batches per train step on one GPU (the reference's 48 / 96 rows times this; 1 = the reference). k batches in one "
                            "step are the update of k data-parallel ranks; the latency-bound recurrent sweeps make k = 2 / 4 cost 1.4 / 2.0 steps."),
-    (("--decode_batch",), int, 16, "Utterances per device-resident beam-search batch in decode.py."),
+    (("--decode_batch",), int, 64, "Utterances per device-resident beam-search batch in decode.py (rows of a search step = this x beam_size; "
+                                  "64 x 16 rows decode 1.8x the utterances/s of 16 x 16)."),
     (("--lm_dir",), str, "lang/output/", "Output directory of train_lm.py (result.json, vocab.json, models) for --apply_lm."),
 ]
 

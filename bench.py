@@ -246,6 +246,26 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
         torch.cuda.synchronize()
         rag[name] = round(nutt / (time.perf_counter() - t1), 1)
     bs.ragged_encoder = bs.parallel_encoders = True
+    # more utterances per device-resident batch (decode.py --decode_batch, default 64): the step's kernels are latency-bound at 256 rows,
+    # so 512 / 1024 rows per step cost 1.4x / 2.2x the step time for 2x / 4x the utterances
+    larger = {}
+    for nb in (32, 64):
+        try:
+            more = []
+            for k in range(nb):
+                xs, _ = synthetic_batch(1, T, 8, 30, seed=100 + k)
+                more.append(xs)
+            bs.decode_batch(None, more)
+            torch.cuda.synchronize()
+            rs = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                bs.decode_batch(None, more)
+                torch.cuda.synchronize()
+                rs.append(nb / (time.perf_counter() - t1))
+            larger[str(nb)] = round(sorted(rs)[1], 1)
+        except Exception as e:
+            larger[str(nb)] = "%s: %s" % (type(e).__name__, str(e)[:120])
     parts = tm.get("parts_us", {})
     N, Tp = nutt * beam, tm.get("frames", 160)
     D, A, Hd, E = args.dec_units, args.attention_size, 2 * args.enc_units, args.embedding_size
@@ -273,6 +293,8 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
             "us_per_decode_step": round((tm.get("searched", 0.0)) / max(tm.get("steps", 1), 1) * 1e6, 1) if tm else None,
             "phases_s": {k: tm[k] for k in ("encoded", "searched", "done") if k in tm}, "step_parts_us": parts, "roofline": roof,
             "ragged": dict(rag, unit="utterances/s", frames="%d utterances of %d ... %d frames, all different" % (nutt, T - 18 * (nutt - 1), T)),
+            "utterances_per_batch": dict(larger, unit="utterances/s", note="the same search with 32 / 64 utterances (512 / 1024 hypothesis rows) per "
+                                         "device-resident batch; `value` is quoted at %d (BASELINE configs[4]'s geometry of rounds 1-3)" % nutt),
             "note": "utterances of equal length share one encoder launch (rows are independent; the reference encoder has no length "
                     "mask, so utterances are never padded to a common length); the search runs all utterances x beam rows per "
                     "step on the device, one captured step replayed as a HIP graph"}

@@ -121,3 +121,20 @@ def test_bf16_utterances_of_different_lengths_one_ragged_encoder_pass_equals_one
             assert [h.token_ids for h in a] == [h.token_ids for h in b], other
             assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], other
             assert torch.equal(a[-1].att[-1], b[-1].att[-1])
+
+
+def test_forty_utterances_in_one_batch_equal_the_same_utterances_in_groups_of_eight():
+    """decode.py's --decode_batch (default 64 since round 4: 1,300 instead of 720 utterances/s at 16) only changes how many hypothesis rows
+    share a launch: 40 utterances x beam 16 = 640 rows in one device-resident search must give every utterance the hypotheses, scores and
+    alignments it gets in a batch of 8 (rows never interact; the beam kernel ranks per utterance)."""
+    args, p0, plm, bs, _ = _setup("bf16")
+    utts = [synthetic_batch(1, 150 - 7 * (k % 5), 8, 30, seed=400 + k)[0] for k in range(40)]
+    big = bs.decode_batch(None, utts)
+    small = []
+    for c0 in range(0, 40, 8):
+        small += bs.decode_batch(None, utts[c0:c0 + 8])
+    assert len(big) == len(small) == 40
+    for u, (a, b) in enumerate(zip(big, small)):
+        assert [h.token_ids for h in a] == [h.token_ids for h in b], u
+        assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], u
+        assert torch.equal(a[-1].att[-1], b[-1].att[-1]), u
