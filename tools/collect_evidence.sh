@@ -61,5 +61,5 @@ python3 tools/kernel_stats.py /tmp/kt_rnn_$P 3 gpurun_out/${P}_rnn_kernel_stats.
 # ---- eight ranks' host side on this box (one GPU: the steps run one rank at a time behind command-processor gates)
 timeout 900 python3 tools/host_time_ranks.py --ranks 8 --steps 4 --out gpurun_out/${P}_host_ranks_8.json > /dev/null 2>&1
 # ---- the whole GPU suite as the driver runs it (one process, -rs: every skip with its reason)
-python3 -m pytest tests -m gpu -q -rs > gpurun_out/${P}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${P}_pytest_gpu.log
+LAS_PARITY_LOG=$PWD/gpurun_out/${P}_parity_full_T.jsonl python3 -m pytest tests -m gpu -q -rs > gpurun_out/${P}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${P}_pytest_gpu.log
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300

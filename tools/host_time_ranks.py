@@ -71,11 +71,17 @@ def worker(rank, world, port, steps, B, T, out_path):
     xs, ys = synthetic_batch(B, T, 256, args.vocab_size, seed=rank, min_frac=0.834)
     xs = (torch.tensor(xs[0], device=dev), xs[1])
     ys = (torch.tensor(ys[0], device=dev), ys[1])
+    alone_ms = 0.0
     for r in range(world):                                         # warm-up, one rank at a time: probes, allocator, weight shadows
         if r == rank:
             for _ in range(2):
                 las.train(xs, ys)
             torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):                                     # ... and the step time of this box, one rank alone on the device
+                las.train(xs, ys)
+            torch.cuda.synchronize()
+            alone_ms = (time.perf_counter() - t0) / 3 * 1e3
             las.check_status()
         dist.barrier()
     host_ms, dev_ms = [], []
@@ -100,12 +106,14 @@ def worker(rank, world, port, steps, B, T, out_path):
         dog.cancel()
     las.check_status()
     allh = [None] * world
-    dist.all_gather_object(allh, (host_ms, dev_ms))
+    dist.all_gather_object(allh, (host_ms, dev_ms, alone_ms))
     if rank == 0:
-        h = sorted(x for hm, _ in allh for x in hm)
-        d = sorted(x for _, dm in allh for x in dm)
+        h = sorted(x for hm, _, _ in allh for x in hm)
+        d = sorted(x for _, dm, _ in allh for x in dm)
+        al = sorted(x for _, _, x in allh)
         rec = {"ranks": world, "steps": steps, "B": B, "T": T, "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
                "host_enqueue_ms": {"median": round(h[len(h) // 2], 2), "max": round(h[-1], 2), "min": round(h[0], 2)},
+               "step_ms_one_rank_alone": round(al[len(al) // 2], 2),
                "device_ms_behind_the_gate": {"median": round(d[len(d) // 2], 2), "min": round(d[0], 2)},
                "schedule": dict(las.last_variants),
                "note": "all ranks enqueue one bench-geometry step concurrently behind a closed hipStreamWaitValue32 gate; the steps then run "
