@@ -529,6 +529,167 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Both weight gradients of one direction of a recurrent layer in ONE pass over d(pre-activation) (round 4):
+//     dW[0 : I, :]     += X^T . dZ                      (dW_ih: contraction over all B T frames)
+//     dW[I : I + H, :] += sum_b sum_t h_prev(b, t)^T . dZ(b, t)     (dW_hh: h_prev = the layer's own output one step back in sweep order)
+// i.e. dW = [X | H_prev]^T . dZ with a VIRTUAL left operand: row blocks below `nb1` read X, the others read the layer output shifted by
+// one frame (out[b, t - 1] forward direction, out[b, t + 1] backward direction; the frame without a predecessor contributes zero).  Until
+// round 3 these were two products -- a flat split-K TN product for dW_ih and a per-utterance batched one for dW_hh whose 48 partial
+// [H, G H] tiles went through HBM and a column-sum kernel -- each reading all of dZ (125 MB per direction at T = 1274): 1.8 GB per train
+// step of side-stream traffic next to the BPTT sweeps.  Same tile machinery as gemm_tn_tr_kernel<128> (k-major LDS tiles, transposing
+// LDS reads), all row blocks of one k-chunk on ONE XCD so that the dZ rows enter that L2 once.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const unsigned short* X; int ldx, M1;          // layer input [K, ldx] bf16; M1 = columns of X that exist (multiple of 8)
+    const unsigned short* O; int ldo; long long obs; int shift;   // layer output (this direction's column block), row pitch, batch stride, -1 / +1
+    const unsigned short* Z; int ldz;              // d(pre-activation) [K, ldz] bf16 (this direction's column block)
+    int T, K, N, nb1, nb2;                         // frames per utterance, K = B T, N = G H, row blocks from X / from the output
+    float invT;
+    int splitk, kchunk;
+    float* partial;                                // [splitk][(nb1 + nb2) * 128][N]
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int nx = g.N / BN, ny = g.nb1 + g.nb2, nt = nx * ny;
+    const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
+    const int bz = xcd + 8 * (li / nt);
+    if (bz >= g.splitk) return;
+    const int t_ = li % nt, by = t_ / nx, bx = t_ % nx;
+    const int n0 = bx * BN;
+    const bool hsrc = by >= g.nb1;
+    const int m0 = (hsrc ? by - g.nb1 : by) * BM;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int pk = tid >> 4, pc = (tid & 15) * 8;                   // a piece is 16 bytes = 8 columns of one k-row: piece tid + 256 u of k-row pk + 16 u
+    const unsigned short* pb = g.Z + (long long)(kbeg + pk) * g.ldz + n0 + pc;
+    const long long sb16 = 16LL * g.ldz, sb32 = 32LL * g.ldz;
+    const int so = pk * TR_PITCH + pc * 2;
+    u32x4_t ra[2], rb[2];
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + pk + 16 * u;
+            bool on = k < kend;
+            const unsigned short* src = g.X;
+            if (!hsrc) {
+                on = on && m0 + pc < g.M1;
+                src = g.X + (long long)(on ? k : 0) * g.ldx + m0 + pc;
+            } else {
+                int b = (int)((float)k * g.invT);                    // k = b T + t  (k < 2^24: the float quotient is off by at most one)
+                if (b * g.T > k) --b;
+                if ((b + 1) * g.T <= k) ++b;
+                const int tp = k - b * g.T + g.shift;
+                on = on && tp >= 0 && tp < g.T;
+                src = g.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
+            }
+            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : g.Z);
+            ra[u] = on ? va : zero;
+            const bool onb = k < kend;
+            const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? pb + u * sb16 : g.Z);
+            rb[u] = onb ? vb : zero;
+        }
+        pb += sb32;
+    };
+    gload(kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        unsigned char* As = lds + buf * 2 * TR_TILE;
+        unsigned char* Bs = As + TR_TILE;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<u32x4_t*>(As + so + u * 16 * TR_PITCH) = ra[u];
+            *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = rb[u];
+        }
+        __syncthreads();
+        if (k0 + 32 < kend) gload(k0 + 32);
+        u16x8_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = tr_frag(Bs, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+        buf ^= 1;
+    }
+    float* P = g.partial + ((long long)bz * ny + by) * BM * g.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + (wn * 4 + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(long long)((wm * 4 + i) * 16 + (lane >> 4) * 4 + r) * g.N + col] = acc[i][j][r];
+        }
+}
+
+// fixed-order reduction of the k-chunks: virtual row r of block row `by` -> dW row (X blocks: r < I; output blocks: I + r)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int I, int H, float* __restrict__ dW) {
+    const int ny = g.nb1 + g.nb2;
+    const long long total = (long long)ny * 128 * g.N;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int vr = (int)(idx / g.N), col = (int)(idx % g.N), by = vr >> 7, r = vr & 127;
+        int row;
+        if (by < g.nb1) { row = by * 128 + r; if (row >= I) continue; }
+        else { row = (by - g.nb1) * 128 + r; if (row >= H) continue; row += I; }
+        float s_ = 0.f;
+        for (int z = 0; z < g.splitk; ++z) s_ += g.partial[(long long)z * total + idx];
+        dW[(long long)row * g.N + col] += s_;
+    }
+}
+
+extern "C" size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T) {
+    if (I <= 0 || H <= 0 || GH <= 0 || B <= 0 || T <= 0) return 0;
+    const int ny = cdiv(I, 128) + H / 128, tiles = ny * (GH / 128);
+    const long long K = (long long)B * T;
+    int s = (int)((512 + tiles - 1) / tiles);
+    const int maxs = (int)(K / 512);
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (size_t)s * ny * 128 * GH * sizeof(float);
+}
+
+extern "C" int las_wgrad_ih_hh(const void* X, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                               int B, int T, int H, int GH, int dir, float* dW, void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(X && out && dZ && dW && ws, "las_wgrad_ih_hh: null pointer");
+    LAS_ARG(B > 0 && T > 0 && I > 0 && H > 0 && H % 128 == 0 && GH % 128 == 0, "las_wgrad_ih_hh: needs H and G H multiples of 128 (I=%d H=%d GH=%d)", I, H, GH);
+    LAS_ARG((long long)B * T < (1 << 24), "las_wgrad_ih_hh: B T must stay below 2^24");
+    LAS_ARG(ldx % 8 == 0 && ldx >= (I + 7) / 8 * 8 && ld_out % 8 == 0 && lddz % 8 == 0 && out_bstride % 8 == 0 &&
+            (((uintptr_t)X | (uintptr_t)out | (uintptr_t)dZ) & 15) == 0, "las_wgrad_ih_hh: operands must be 16-byte aligned with pitches that are multiples of 8");
+    WgradArgs g;
+    g.X = (const unsigned short*)X; g.ldx = ldx; g.M1 = (I + 7) / 8 * 8;
+    g.O = (const unsigned short*)out; g.ldo = ld_out; g.obs = out_bstride; g.shift = dir ? 1 : -1;
+    g.Z = (const unsigned short*)dZ; g.ldz = lddz;
+    g.T = T; g.K = B * T; g.N = GH; g.nb1 = cdiv(I, 128); g.nb2 = H / 128;
+    g.invT = 1.0f / (float)T;
+    const int ny = g.nb1 + g.nb2, nt = ny * (GH / 128);
+    int s = (512 + nt - 1) / nt;
+    if (s > g.K / 512) s = g.K / 512;
+    if (s < 1) s = 1;
+    int kchunk = ((g.K + s - 1) / s + 31) / 32 * 32;
+    s = (g.K + kchunk - 1) / kchunk;
+    g.splitk = s; g.kchunk = kchunk; g.partial = (float*)ws;
+    LAS_ARG(ws_bytes >= (size_t)s * ny * 128 * GH * sizeof(float), "las_wgrad_ih_hh: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_tn_tr_kernel, dim3(nt * ((s + 7) / 8 * 8)), dim3(256), 0, st, g);
+    LAS_LAUNCHED();
+    int nb = cdiv((long long)ny * 128 * GH, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, g, I, H, dW);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 static bool g_tn_tr_on = true;
 #ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_tn_tr(int on) { g_tn_tr_on = on != 0; }       // development switch (A/B measurements)

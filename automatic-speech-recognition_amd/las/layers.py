@@ -10,6 +10,8 @@ Two module-level knobs select what the reference cannot express:
                              (reference las/layers.py:31); 'lstm' = BasicLSTMCell (north-star).
     set_precision('f32'|'bf16')  arithmetic of the contractions (see include/las_hip.h).
 """
+import os
+
 import torch
 
 from las import _hip
@@ -34,6 +36,9 @@ def get_cell():
 
 def _prec():
     return _hip.PREC_BF16 if _CFG["prec"] == "bf16" else _hip.PREC_F32
+
+
+WGRAD_ONE_PASS = os.environ.get("LAS_WGRAD_ONE_PASS", "1") != "0"
 
 
 def _cellid(cell):
@@ -677,8 +682,12 @@ class _BLSTM16(torch.autograd.Function):
             # dW_ih = x^T . dG_d (contraction over all B*T frames; split-K inside las_gemm); dW_hh = sum_b sum_t h_prev^T . dG_d
             # (`part` is allocated HERE, i.e. on the stream that uses it: a block of the main stream's pool handed to the
             #  side stream would be recycled by the allocator while the side stream still writes it)
-            part = torch.empty(B, H, GH, device=dev) if T > 1 else None
             gk = gk_of(d)
+            if WGRAD_ONE_PASS and T > 1 and H % 128 == 0 and GH % 128 == 0 and B * T < (1 << 24) and out.dtype == bf and xs[d].dtype == bf:
+                # one pass over dG_d for both (round 4): the left operand is [x | h_prev] with h_prev read from `out` one frame back
+                _hip.wgrad_ih_hh(xs[d], Ik, I0, out, 2 * H, Tp * 2 * H, gates, 2 * GH, B, T, H, GH, d, gk, d * H, d * GH)
+                return
+            part = torch.empty(B, H, GH, device=dev) if T > 1 else None
             _hip.gemm(prec, xs[d], gates, gk, True, False, Ig, GH, B * T, Ik, 2 * GH, GH, beta=1.0, b_off=d * GH)
             if T > 1:
                 a_off = d * H + (0 if d == 0 else 2 * H)

@@ -207,3 +207,54 @@ def test_skinny_gemm_matches_float64_on_the_rounded_operands(M, K, N):
     assert (wide.double().cpu() - want).abs().max().item() < tol
     l = _hip.lib()
     assert l.las_gemm_skinny(_hip.p(A), K, 2000, K, _hip.p(packed), N, _hip.p(C), N, None, 0, None) < 0      # M > 1024 is refused
+
+
+@pytest.mark.parametrize("I,H,G,B,T", [(40, 128, 4, 3, 50), (240, 256, 4, 5, 333), (512, 256, 4, 48, 160), (1024, 256, 4, 4, 77),
+                                       (512, 256, 1, 7, 129), (100, 128, 1, 2, 2)])
+def test_both_weight_gradients_in_one_pass_over_dz(I, H, G, B, T):
+    """las_wgrad_ih_hh: dW[0:I] += X^T dZ_d and dW[I:I+H] += sum_b sum_t h_prev(b,t)^T dZ_d(b,t) with h_prev read from the layer output one
+    frame back (direction 0) / ahead (direction 1), against float64 on the same bf16 values and against the two las_gemm products +
+    column sum it replaces (the matmul gradient of the cell kernel under bidirectional_dynamic_rnn, reference las/layers.py:49-53)."""
+    from las import _hip
+    GH = G * H
+    Ik = (I + 63) // 64 * 64
+    Tp = T + 3                                                      # the layer output is stored with padded frames
+    g = torch.Generator().manual_seed(I + H + B + T)
+    X = torch.zeros(B, T, Ik)
+    X[:, :, :I] = torch.randn(B, T, I, generator=g) * 0.5
+    X = X.cuda().to(torch.bfloat16)
+    out = (torch.randn(B, Tp, 2 * H, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    dZ = (torch.randn(B, T, 2 * GH, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    for d in (0, 1):
+        dW0 = torch.randn(I + H, GH, generator=g).cuda()
+        dW = dW0.clone()
+        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, d, dW, d * H, d * GH)
+        Zd = dZ[:, :, d * GH:(d + 1) * GH].double().cpu()
+        Od = out[:, :T, d * H:(d + 1) * H].double().cpu()
+        hp = torch.zeros(B, T, H, dtype=torch.float64)
+        if d == 0:
+            hp[:, 1:] = Od[:, :-1]
+        else:
+            hp[:, :-1] = Od[:, 1:]
+        ref = dW0.double().cpu()
+        ref[:I] += X[:, :, :I].double().cpu().reshape(B * T, I).t() @ Zd.reshape(B * T, GH)
+        ref[I:] += hp.reshape(B * T, H).t() @ Zd.reshape(B * T, GH)
+        tol = 3e-6 * (B * T) ** 0.5 * max(1.0, ref.abs().max().item())
+        assert (dW.double().cpu() - ref).abs().max().item() < tol, (d,)
+        # the two products it replaces
+        old = dW0.clone()
+        Ig = (I + 3) // 4 * 4
+        if Ig == I:
+            _hip.gemm(_hip.PREC_BF16, X, dZ, old, True, False, Ig, GH, B * T, Ik, 2 * GH, GH, beta=1.0, b_off=d * GH)
+            part = torch.empty(B, H, GH, device="cuda")
+            a_off = d * H + (0 if d == 0 else 2 * H)
+            b_off = d * GH + (2 * GH if d == 0 else 0)
+            _hip.gemm(_hip.PREC_BF16, out, dZ, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
+                      strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
+            _hip.colsum(part, B, H * GH, H * GH, old[I:].reshape(-1), beta=1.0)
+            assert (dW - old).abs().max().item() < tol
+    # run to run: bit-identical (fixed-order split-K)
+    a, b = torch.zeros(I + H, GH, device="cuda"), torch.zeros(I + H, GH, device="cuda")
+    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, a, 0, 0)
+    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, b, 0, 0)
+    assert torch.equal(a, b)
