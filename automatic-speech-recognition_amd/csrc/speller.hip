@@ -1224,17 +1224,23 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
     const int ks0 = w * KW;                                           // the 16 waves split K, KW k-steps each (16 * KW >= KS)
     u16x8_t bf[TPW][KW];
     unsigned aoff[KW];
+    bool need[KW];
     {
-        const int rr = c < Rx ? c : Rx - 1;                           // padded tile rows: garbage that is never stored
+        // tile rows >= Rx and k-steps >= KS do not exist: their loads get an offset beyond the buffer's range (the hardware returns
+        // zeros without a memory access) -- 6 of 16 tile rows exist at B = 48, and the row's 36 k-steps leave 4 of the 16 waves empty:
+        // 98 KB -> 28 KB through the workgroup's vector-memory path per poll round
 #pragma unroll
         for (int u = 0; u < KW; ++u) {
             const int kk = min(ks0 + u, p.KS - 1);
 #pragma unroll
             for (int tl = 0; tl < TPW; ++tl) bf[tl][u] = p.Bp[((size_t)min(j * TPW + tl, p.nct - 1) * p.KS + kk) * 64 + lane];
             const int k = min(kk * 32 + g * 8, p.K - 8);
-            aoff[u] = (unsigned)(((size_t)(rr * 8 + x) * p.gA_row + (k >> 2)) * 16);
+            need[u] = c < Rx && ks0 + u < p.KS && (ks0 + u) * 32 + g * 8 + 8 <= p.K;
+            aoff[u] = need[u] ? (unsigned)(((size_t)(c * 8 + x) * p.gA_row + (k >> 2)) * 16) : 0x80000000u;
         }
     }
+    const int on_ = Rx * 16;                                          // outputs of one column tile that exist
+    const int rd_tl = tid / on_, rd_o = tid - rd_tl * on_;            // the (tile, row, column) this thread reduces in the first trip
     const __amdgpu_buffer_rsrc_t ars = granule_rsrc(p.gA), crs = granule_rsrc(p.gC);
     for (int s = 0; s < U; ++s) {
         const int step = reverse ? U - 1 - s : s;
@@ -1249,7 +1255,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int u = 0; u < KW; ++u) ok &= q0[u].x == tag && q0[u].w == tag && q1[u].x == tag && q1[u].w == tag;
+                for (int u = 0; u < KW; ++u) ok &= !need[u] || (q0[u].x == tag && q0[u].w == tag && q1[u].x == tag && q1[u].w == tag);
                 if (ok) break;
                 if (--budget == 0) LOOP_POLL_TIMEOUT(p);
                 __builtin_amdgcn_s_sleep(1);
@@ -1263,20 +1269,23 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             for (int tl = 0; tl < TPW; ++tl) acc[tl] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < KW; ++u) {
-                const int kk = ks0 + u;
-                const bool on = kk < p.KS && kk * 32 + g * 8 + 8 <= p.K;
+                const bool on = need[u];
                 const u32x4_t av = {on ? q0[u].y : 0u, on ? q0[u].z : 0u, on ? q1[u].y : 0u, on ? q1[u].z : 0u};
 #pragma unroll
                 for (int tl = 0; tl < TPW; ++tl) acc[tl] = mfma_bf16_16x16x32(__builtin_bit_cast(u16x8_t, av), bf[tl][u], acc[tl]);
             }
         }
+        if (g * 4 < Rx) {                                             // lanes whose four tile rows do not exist keep their partials
 #pragma unroll
-        for (int tl = 0; tl < TPW; ++tl) *reinterpret_cast<f32x4_t*>(red + ((size_t)(w * TPW + tl) * 64 + lane) * 4) = acc[tl];
+            for (int tl = 0; tl < TPW; ++tl) *reinterpret_cast<f32x4_t*>(red + ((size_t)(w * TPW + tl) * 64 + lane) * 4) = acc[tl];
+        }
         if (tid == 0 && blockIdx.x == 0) { STAMPQ(21); }
         __syncthreads();
         if (tid == 0 && blockIdx.x == 0) { STAMPQ(22); }
-        for (int idx = tid; idx < TPW * 256; idx += RNT) {            // whole waves: TPW * 256 is a multiple of 64
-            const int tl = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15;
+        for (int idx = tid; idx < TPW * on_; idx += RNT) {            // existing rows only (Rx * 16 is a multiple of 16: the pair shuffle stays inside the trip)
+            int tl = rd_tl, o = rd_o;
+            if (idx != tid) { tl = idx / on_; o = idx - tl * on_; }
+            const int r16 = o >> 4, c16 = o & 15;
             const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
             float v = 0.f;
 #pragma unroll
