@@ -13,6 +13,7 @@
 // the gate backward of step t) + one las_gemm (dG.W^T) per step; every weight gradient is a single
 // tall contraction after the loop (split-K, deterministic).  No atomics anywhere.
 #include "las_common.h"
+#include <type_traits>
 #include <math.h>
 
 #define LAS_MAX_NL 4
@@ -62,6 +63,8 @@ struct DecDev {
     const float* emb_mask;
     const float* emb_noise;   // [U,V,E] variational noise added to the embedding matrix at the look-up of step t (las/las.py:164-166), or null
     float *logits, *alphas, *hs, *cs, *gates, *xin0;
+    unsigned* actS;        // optional (speed mode, prefetching row kernels): 32-byte header + [U,B,Tp,A] fp16 tanh(keys + q [+ f . Wf]) of every
+                           // step, written by the forward rows and read by the gradient rows instead of recomputing it (las_speller_fwd_args.act_save)
     unsigned short* xbf;   // [B,I0D]  bf16 copy of the current step's cell input row (A operand of the skinny product)
     unsigned short* dgbf;  // [B,G*D]  bf16 copy of the current step's layer-0 gate gradient
     const unsigned short *Wsbf, *keysbf, *encbf;   // bf16 copies of Ws [S,A], keys [B,Tp,A], enc [B,Tp,Hd] (speed mode)
@@ -451,7 +454,28 @@ struct BfLds {
     unsigned short* wfb;      // [16][A] bf16 copy of Wf (rows >= C zero): B operand of the d f product
     unsigned short* wcf;      // [ceil(Kc/32)][2][64][8] the conv filter as MFMA B fragments, bf16 high and low parts (loc_conv_mfma)
     unsigned int* dvb;        // [Tp][A/2] the step's d(pre-tanh) rows as bf16 pairs: A operand of the d f product (gradient loop)
+    uint4* encl;              // loop kernels, additive attention: the first ENC_RES slabs of the utterance's encoder rows, resident for the whole loop
 };
+// Encoder rows that stay in the row workgroup's LDS for the whole loop (round 4).  A row pulled its utterance's 164 KB of encoder rows
+// through the CU's 64 B / clock vector-memory path at EVERY decode step (1.07 us of issue time, exposed: their destination registers are
+// only free after the query projection); the rows do not change over the loop, a CU runs one loop workgroup, and the row state needs
+// 41 KB of the 160 KB: ENC_RES slabs of 32 Hd bytes (16 frames; 7 x 16 KB at Hd = 512 = 112 of 160 frames) are copied in once, the
+// rest is streamed per step -- few enough registers to be requested at the head of the step with the other bulk loads.
+#ifndef LAS_ENC_RES_F
+#define LAS_ENC_RES_F 7
+#endif
+#ifndef LAS_ENC_RES_B
+#define LAS_ENC_RES_B 0
+#endif
+template <int NE, bool LOC, bool BWD = false> struct EncRes {
+    static constexpr int M = BWD ? LAS_ENC_RES_B : LAS_ENC_RES_F;
+    static constexpr int N = LOC ? 0 : (NE < M ? NE : M);
+};
+__host__ __device__ __forceinline__ size_t enc_res_bytes(const DecDev& a, bool loc, int ne, bool bwd = false) {
+    const int m = bwd ? LAS_ENC_RES_B : LAS_ENC_RES_F;
+    return loc ? 0 : (size_t)(ne < m ? ne : m) * 32 * a.Hd;
+}
+static int loop_ne(int Tp) { return Tp <= 128 ? 8 : Tp <= 160 ? 10 : Tp <= 192 ? 12 : 14; }
 __device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
 // floats of the zero-padded previous-alignment array: the filter's reach on both sides, rounded up to what the MFMA conv's fragments touch
 __host__ __device__ __forceinline__ int loc_apad(const DecDev& a) { return (a.Tp + 15) / 16 * 16 + (a.Kc + 31) / 32 * 32 + 16; }
@@ -486,6 +510,7 @@ __device__ __forceinline__ BfLds carve_bf(float* sm, const DecDev& a) {
     }
     r.scr = p;                           // RNW x max(Hd, 2A) partials
     if (a.mode == LAS_ATT_LOC) r.dvb = reinterpret_cast<unsigned int*>(p + RNW * 2 * a.A);   // behind the dq / du partials of the same phase
+    r.encl = reinterpret_cast<uint4*>(p + (size_t)RNW * (a.Hd > 2 * a.A ? a.Hd : 2 * a.A));   // (loop kernels, additive attention only: behind the scratch)
     return r;
 }
 static size_t bf_lds_bytes(const DecDev& a) {
@@ -853,6 +878,13 @@ __device__ __forceinline__ float dot2bf(unsigned int a, unsigned int b, float ac
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
 }
 
+// fp16 pairs (round to nearest): the saved attention activations lie in (-1, 1), where fp16 resolves 2^-11
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f2h2(float a, float b) { const h16x2_t v = {(_Float16)a, (_Float16)b}; return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float2 h22f(unsigned u) { const h16x2_t v = __builtin_bit_cast(h16x2_t, u); return make_float2((float)v.x, (float)v.y); }
+#define LAS_ACT_MAGIC 0x4c415354u          // header word 0 of act_save once a forward kernel has filled it
+#define LAS_ACT_HDR 8                       // header, in 32-bit words
+
 // The row kernels run one workgroup per utterance and are bound by instruction issue on that one CU, so the
 // contractions use packed-pair dot products: q = s.Ws over k-pairs (Wsbf2 [S/2][A][2]), context over frame pairs
 // (encbf2 [B][T'/2][Hd][2]); the softmax statistics are computed per wave (no block reductions).
@@ -874,6 +906,9 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
 //       of all at once in front of a barrier: 10.75 -> 10.50 us per step -> on.
 #ifndef LAS_E8_LATE
 #define LAS_E8_LATE 0
+#endif
+#ifndef LAS_E8_EARLY
+#define LAS_E8_EARLY 0      // (the streamed slabs requested at the head of the step instead of behind the query projection: 10.2 vs 10.0 us, 6 spilled VGPRs)
 #endif
 #ifndef LAS_W8_LATE
 #define LAS_W8_LATE 1
@@ -945,7 +980,19 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1024) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
+    }
+    constexpr int NEL = LOOP ? EncRes<NE, LOC>::N : 0;      // encoder slabs resident in LDS (loop kernels): see EncRes
+    constexpr int NER = NE - NEL > 0 ? NE - NEL : 1;
+    uint4 e8[NER];
+    auto e8_load = [&](const int u) __attribute__((always_inline)) {
+        const int tp = fg + 8 * u;
+        const int tpc = tp < Tp2 ? tp : Tp2 - 1;
+        e8[u - NEL] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 2048) ? (size_t)(tid & 63) : ((size_t)b * Tp2 + tpc) * H4 + h4c];
+    };
+    if (NEL > 0 && LAS_E8_EARLY) {                            // the streamed slabs ride with the other bulk loads
+#pragma unroll
+        for (int u = NEL; u < NE; ++u) e8_load(u);
     }
     STAMPX(1);
     if (LOOP && t > 0 && wv * 64 < D) {   // gates of step t-1 from the product workgroups: the data is the flag
@@ -1007,6 +1054,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         }
     }
     if (t >= U) return;
+    if (a.actS && t == 0 && b == 0 && tid == 0) a.actS[0] = LAS_ACT_MAGIC;     // (the gradient rows check it: a forward that ran other kernels clears it)
 
     STAMPX(2);
     if (tok < 0) {
@@ -1039,15 +1087,9 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     // barrier (phase stamps: 1.32 us for a 16-term sum).  LAS_E8_LATE: the loads are issued in NK portions between the frames of
     // the energies phase instead, where the other waves of a SIMD have transcendental work to cover a wave that waits to issue.
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
-    uint4 e8[NE];
-    auto e8_load = [&](const int u) __attribute__((always_inline)) {
-        const int tp = fg + 8 * u;
-        const int tpc = tp < Tp2 ? tp : Tp2 - 1;
-        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : ((size_t)b * Tp2 + tpc) * H4 + h4c];
-    };
-    if (!LAS_E8_LATE) {
+    if (!LAS_E8_LATE && (NEL == 0 || !LAS_E8_EARLY)) {
 #pragma unroll
-        for (int u = 0; u < NE; ++u) e8_load(u);
+        for (int u = NEL; u < NE; ++u) e8_load(u);
     }
     for (int i = tid; i < A; i += RNT) {
         float q = 0.f;
@@ -1085,7 +1127,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         }
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
-            if (LAS_E8_LATE) {
+            if (LAS_E8_LATE && NEL == 0) {
 #pragma unroll
                 for (int v = u * NE / NK; v < (u + 1) * NE / NK; ++v) e8_load(v);
                 __builtin_amdgcn_sched_barrier(0);       // keep the portion in front of THIS frame's arithmetic
@@ -1093,15 +1135,21 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             const int tt = grp + 64 * u;
             float part = 0.f;
             if (tt < len && tt < Tp) {
+                float th[8];
                 if (LOC) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) part = fmaf(u8[e], tanhx<FAST>(kf[LOC ? u : 0][e]), part);
+                    for (int e = 0; e < 8; ++e) th[e] = tanhx<FAST>(kf[LOC ? u : 0][e]);
                 } else {
-                float k[8];
-                unpack8(k8[u], k);
+                    float k[8];
+                    unpack8(k8[u], k);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) part = fmaf(u8[e], (LAS_ABL_SP & 2) ? (k[e] + q8[e]) * 0.1f : tanhx<FAST>(k[e] + q8[e]), part);
+                    for (int e = 0; e < 8; ++e) th[e] = (LAS_ABL_SP & 2) ? (k[e] + q8[e]) * 0.1f : tanhx<FAST>(k[e] + q8[e]);
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part = fmaf(u8[e], th[e], part);
+                if (a.actS && a8 < A8)      // kept for the gradient rows (fp16: |error| <= 2^-12), which would otherwise recompute all of them
+                    reinterpret_cast<uint4*>(a.actS + LAS_ACT_HDR)[(((size_t)t * B + b) * Tp + tt) * A8 + a8] =
+                        make_uint4(f2h2(th[0], th[1]), f2h2(th[2], th[3]), f2h2(th[4], th[5]), f2h2(th[6], th[7]));
             }
             part = sub16_sum(part);
             if (a8 == 0 && tt < Tp) L.ev[tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
@@ -1145,8 +1193,9 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         for (int u = 0; u < NE; ++u) {
             const int tp = fg + 8 * u;
             const unsigned int al2 = 2 * tp < lim ? ap[tp] : 0u;
-            acc[0] = dot2bf(e8[u].x, al2, acc[0]); acc[1] = dot2bf(e8[u].y, al2, acc[1]);
-            acc[2] = dot2bf(e8[u].z, al2, acc[2]); acc[3] = dot2bf(e8[u].w, al2, acc[3]);
+            const uint4 ev = u < NEL ? L.encl[(size_t)tp * H4 + h4c] : e8[u < NEL ? 0 : u - NEL];
+            acc[0] = dot2bf(ev.x, al2, acc[0]); acc[1] = dot2bf(ev.y, al2, acc[1]);
+            acc[2] = dot2bf(ev.z, al2, acc[2]); acc[3] = dot2bf(ev.w, al2, acc[3]);
         }
         if (h4 < H4) reinterpret_cast<float4*>(L.scr + fg * Hd)[h4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         lds_barrier();
@@ -1289,13 +1338,13 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
             float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < RNW; ++ww) v += red[((size_t)(ww * TPW + tl) * 64 + l2) * 4 + reg];
+            for (int ww = 0; ww < ((LAS_ABL_SP & 32) ? 1 : RNW); ++ww) v += red[((size_t)(ww * TPW + tl) * 64 + l2) * 4 + reg];
             const int ct = j * TPW + tl, col = ct * 16 + c16, orow = r16 * 8 + x;
             const bool valid = r16 < Rx && ct < p.nct && col < p.N;
             if (!(LAS_ABL_SP & 4) && p.bias && valid) v += p.bias[col];
             const float nb = __shfl_xor(v, 1, 64);
             if (valid) {
-                if (p.C) p.C[(long long)step * p.c_step + (long long)orow * p.ldc + col] = v;
+                if (p.C && !(LAS_ABL_SP & 64)) p.C[(long long)step * p.c_step + (long long)orow * p.ldc + col] = v;
                 if (!(c16 & 1))
                     granule16_store(crs, (unsigned)(((size_t)orow * p.gC_row + (col >> 1)) * 16), tag, __float_as_uint(v), __float_as_uint(nb), local);
             }
@@ -1319,6 +1368,15 @@ __global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
     if (b >= a.B) return;
     float ccar = 0.f;
     if (LOC) loc_stage_lds(carve_bf(sm, a), a, threadIdx.x);          // filter + Wf: once per launch (step 0's barrier publishes them)
+    if (EncRes<NE, LOC>::N > 0) {                                     // resident encoder slabs (pair-interleaved copy): once per launch
+        const int H4 = a.Hd >> 2, Tp2 = (a.Tp + 1) >> 1;
+        uint4* dst = carve_bf(sm, a).encl;
+        const uint4* src = reinterpret_cast<const uint4*>(a.encbf2) + (size_t)b * Tp2 * H4;
+        for (int i = threadIdx.x; i < EncRes<NE, LOC>::N * 8 * H4; i += RNT) {
+            const int tp = i / H4;
+            dst[i] = src[(size_t)(tp < Tp2 ? tp : Tp2 - 1) * H4 + (i - tp * H4)];
+        }
+    }
     for (int t = 0; t <= a.U; ++t) {
         int bb = b, tid = threadIdx.x;
         asm volatile("" : "+s"(bb), "+v"(tid));                       // keep the row's address arithmetic inside the iteration:
@@ -1873,9 +1931,23 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 // LOOP (dec_loop_bwd_kernel): one iteration of a persistent row workgroup: the dXin0 row of step t_att (context and state
 // gradient) arrives as granules from the product workgroups, the bf16 gate gradient of step t_cell leaves as granules, dC and
 // the running du column are carried in registers.
+#ifndef LAS_KEYS_HOISTED
+#define LAS_KEYS_HOISTED 1
+#endif
+// the keys of the energies gradient: one column pair per lane, frame wv + 16 u.  They do not change over the loop: the loop kernel
+// loads them ONCE (NE registers) -- requested per step they cost 1.2 us of the 10.5 (tools/micro/bench_fused.hip, round 4)
+template <int NE>
+__device__ __forceinline__ void bwd_keys_load(const DecDev& a, const int b, const int tid, unsigned (&k2)[NE]) {
+    const int lane = tid & 63, wv = tid >> 6, A2 = a.A >> 1, c2c = lane < A2 ? lane : A2 - 1;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int t2 = wv + RNW * u, t2c = t2 < a.Tp ? t2 : a.Tp - 1;
+        k2[u] = reinterpret_cast<const unsigned*>(a.keysbf)[(LAS_ABL_SP & 256) ? (size_t)(tid & 63) : ((size_t)b * a.Tp + t2c) * A2 + c2c];
+    }
+}
 template <int CELL, int NE, bool LOOP, bool LOC = false>
 __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, const int t_cell, const int b, const int tid, float* sm,
-                                           float& dccar, float& ducar, const bool local) {
+                                           float& dccar, float& ducar, const bool local, const unsigned (&k2h)[NE], const bool acts) {
     static_assert(LOOP || !LOC, "location-aware attention is served by the loop kernels only");
     constexpr int LC = 10;                            // channels the location-aware variant keeps in registers (a.C <= LC, host-checked)
     constexpr bool FAST = true;
@@ -1920,25 +1992,42 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     float qd = a2c < A ? a.Q[((size_t)ta * B + b) * A + a2c] : a.duRows[(size_t)b * A + (a2c - A)];
     if (LOOP && a2c >= A) qd = ducar;                 // (duRows starts at zero; the register copy is the live one)
     const int len = a.enc_len[b];
-    // encoder rows for dalpha: 16-lane group per frame (3 frames per group), lane a8 covers column chunks a8 + 16 i
-    uint4 e8[NK][4];
+    // encoder rows for dalpha: 16-lane group per frame (3 frames per group), lane a8 covers column chunks a8 + 16 i.
+    // Loop kernels, additive attention: the first TRES frames are resident in LDS (EncRes; copied in by dec_loop_bwd_kernel); their
+    // lanes request an offset beyond the buffer's range instead (zeros, no memory access), rounds that are resident as a whole hold
+    // no registers at all.
+    constexpr int TRES = LOOP ? 16 * EncRes<NE, LOC, true>::N : 0;        // resident frames
+    constexpr int UF = TRES / 64;                                  // rounds of 64 frames that are resident as a whole
+    constexpr int NKR = NK - UF > 0 ? NK - UF : 1;
+    uint4 e8[NKR][4];
+    {
+        const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.encbf) + (size_t)b * Tp * Hd, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+        for (int u = UF; u < NK; ++u) {
+            const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
-            e8[u][i] = reinterpret_cast<const uint4*>(a.encbf)[((size_t)b * Tp + ttc) * H8 + hcc];
+            for (int i = 0; i < 4; ++i) {
+                const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
+                const unsigned off = (LAS_ABL_SP & 16) ? (unsigned)(tid & 63) * 16u : (unsigned)(((size_t)ttc * H8 + hcc) * 16);
+                e8[u - UF][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ers, tt < TRES ? 0x80000000u : off, 0, 0));
+            }
         }
     }
     // keys for the energies gradient: one column pair per lane, one frame per wave and round (sums over frames stay
     // inside the lane, no cross-lane reduction)
     const int A2 = A >> 1, c2c = lane < A2 ? lane : A2 - 1;
     unsigned k2[NE];
+    if (acts) {   // the forward rows kept tanh(keys + q [+ f . Wf]) of this step (fp16 pairs): nothing to recompute
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
-        k2[u] = reinterpret_cast<const unsigned*>(a.keysbf)[((size_t)b * Tp + t2c) * A2 + c2c];
+        for (int u = 0; u < NE; ++u) {
+            const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
+            k2[u] = (a.actS + LAS_ACT_HDR)[(LAS_ABL_SP & 256) ? (size_t)(tid & 63) : (((size_t)ta * B + b) * Tp + t2c) * A2 + c2c];
+        }
+    } else if (LOOP && LAS_KEYS_HOISTED && !LOC) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) k2[u] = k2h[u];
+    } else {
+        bwd_keys_load<NE>(a, b, tid, k2);
     }
     const float2 u2 = reinterpret_cast<const float2*>(a.u)[c2c];
     // cell part operands (saved by the forward pass)
@@ -1993,8 +2082,11 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 const uint4 d4 = hc < H8 ? reinterpret_cast<const uint4*>(dcp)[hc] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                 for (int u = 0; u < NK; ++u) {
-                    acc[u] = dot2bf(e8[u][i].x, d4.x, acc[u]); acc[u] = dot2bf(e8[u][i].y, d4.y, acc[u]);
-                    acc[u] = dot2bf(e8[u][i].z, d4.z, acc[u]); acc[u] = dot2bf(e8[u][i].w, d4.w, acc[u]);
+                    const int tt = grp + 64 * u;
+                    uint4 ev = e8[u < UF ? 0 : u - UF][i];
+                    if (u < UF || (u * 64 < TRES && tt < TRES)) ev = L.encl[(size_t)tt * H8 + (hc < H8 ? hc : H8 - 1)];   // (whole 16-lane groups: wave-uniform up to the group)
+                    acc[u] = dot2bf(ev.x, d4.x, acc[u]); acc[u] = dot2bf(ev.y, d4.y, acc[u]);
+                    acc[u] = dot2bf(ev.z, d4.z, acc[u]); acc[u] = dot2bf(ev.w, d4.w, acc[u]);
                 }
             }
 #pragma unroll
@@ -2011,7 +2103,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         auto w8_load = [&](const int u) __attribute__((always_inline)) {
             const int kk = grp + 64 * u;
             const int kkc = kk < S ? kk : S - 1;
-            w8[u] = reinterpret_cast<const uint4*>(a.Wsbf)[(size_t)kkc * A8 + a8c];
+            w8[u] = reinterpret_cast<const uint4*>(a.Wsbf)[(LAS_ABL_SP & 512) ? (size_t)(tid & 63) : (size_t)kkc * A8 + a8c];
         };
         if (!LAS_W8_LATE) {
 #pragma unroll
@@ -2037,11 +2129,15 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
         if (tid < Tp) dal[tid] = de_own;
         lds_barrier();
     STAMPX(15);
-        {   // energies backward: sums over this wave's frames stay in the lane (columns 2*lane, 2*lane+1)
-            const float q0 = L.qv[2 * c2c], q1 = L.qv[2 * c2c + 1];
-            float du0 = 0.f, du1 = 0.f, dq0 = 0.f, dq1 = 0.f;
-            float2 wf2[LOC ? LC : 1];                 // LOC: this lane's two columns of every Wf row
-            if (LOC) {
+        float du0 = 0.f, du1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+        // energies backward: sums over this wave's frames stay in the lane (columns 2*lane, 2*lane+1).  Two instances of the same
+        // loop: the saved activations (acts, wave-uniform) or their recomputation from keys + q [+ f . Wf] -- 20 tanh per lane and,
+        // location-aware, 20 FMAs per frame: 1.2 of the 10.5 us of a gradient step (tools/micro/bench_fused.hip)
+        auto energies_bwd = [&](auto ACT) __attribute__((always_inline)) {
+            constexpr bool ACTS = decltype(ACT)::value;
+            const float q0 = ACTS ? 0.f : L.qv[2 * c2c], q1 = ACTS ? 0.f : L.qv[2 * c2c + 1];
+            float2 wf2[LOC && !ACTS ? LC : 1];        // LOC: this lane's two columns of every Wf row
+            if (LOC && !ACTS) {
 #pragma unroll
                 for (int c = 0; c < LC; ++c) wf2[c] = c < a.C ? reinterpret_cast<const float2*>(L.wfl + (size_t)c * A)[c2c] : make_float2(0.f, 0.f);
             }
@@ -2050,16 +2146,23 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 if (LAS_W8_LATE && !LOC && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
                 const int t2 = wv + RNW * u;
                 const float de = t2 < lim ? dal[t2] : 0.f;
-                float p0 = __uint_as_float(k2[u] << 16) + q0, p1 = __uint_as_float(k2[u] & 0xffff0000u) + q1;
-                if (LOC) {   // + f[t2, :] . Wf
-                    const float* fr = L.fc + (t2 < Tp ? t2 : Tp - 1) * a.C;
+                float v0, v1;
+                if (ACTS) {
+                    const float2 h = h22f(k2[u]);
+                    const bool on = t2 < len && t2 < Tp;          // (frames the forward row did not visit hold no value)
+                    v0 = on ? h.x : 0.f; v1 = on ? h.y : 0.f;
+                } else {
+                    float p0 = __uint_as_float(k2[u] << 16) + q0, p1 = __uint_as_float(k2[u] & 0xffff0000u) + q1;
+                    if (LOC) {   // + f[t2, :] . Wf
+                        const float* fr = L.fc + (t2 < Tp ? t2 : Tp - 1) * a.C;
 #pragma unroll
-                    for (int c = 0; c < LC; ++c) {
-                        const float f = c < a.C ? fr[c] : 0.f;
-                        p0 = fmaf(f, wf2[c].x, p0); p1 = fmaf(f, wf2[c].y, p1);
+                        for (int c = 0; c < LC; ++c) {
+                            const float f = c < a.C ? fr[c] : 0.f;
+                            p0 = fmaf(f, wf2[LOC && !ACTS ? c : 0].x, p0); p1 = fmaf(f, wf2[LOC && !ACTS ? c : 0].y, p1);
+                        }
                     }
+                    v0 = tanhx<FAST>(p0); v1 = tanhx<FAST>(p1);
                 }
-                const float v0 = tanhx<FAST>(p0), v1 = tanhx<FAST>(p1);
                 du0 = fmaf(de, v0, du0); du1 = fmaf(de, v1, du1);
                 if (!LOC) { dq0 = fmaf(de * u2.x, 1.f - v0 * v0, dq0); dq1 = fmaf(de * u2.y, 1.f - v1 * v1, dq1); }
                 if (LOC) {   // keep the row of d(pre-tanh) (bf16 pairs): d f = dv . Wf^T is one small MFMA product after the loop
@@ -2068,6 +2171,10 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                     if (lane < A2 && t2 < Tp) L.dvb[t2 * A2 + lane] = f2bf2(dv0, dv1);
                 }
             }
+        };
+        {
+            if (acts) energies_bwd(std::true_type{}); else energies_bwd(std::false_type{});
+    STAMPX(16);
             if (lane < A2) {
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A)[lane] = make_float2(dq0, dq1);
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A + A)[lane] = make_float2(du0, du1);
@@ -2173,7 +2280,9 @@ template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_bwd_pf_kernel(DecDev a, int t_att, int t_cell) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float dccar = 0.f, ducar = 0.f;
-    pf_bwd_row<CELL, NE, false>(a, t_att, t_cell, blockIdx.x, threadIdx.x, sm, dccar, ducar, false);
+    unsigned nok[NE] = {};
+    const bool acts = a.actS && a.actS[0] == LAS_ACT_MAGIC;
+    pf_bwd_row<CELL, NE, false>(a, t_att, t_cell, blockIdx.x, threadIdx.x, sm, dccar, ducar, false, nok, acts);
 }
 
 // the whole gradient loop in one launch (see dec_loop_fwd_kernel): the product workgroups compute
@@ -2191,10 +2300,22 @@ __global__ __launch_bounds__(RNT) void dec_loop_bwd_kernel(DecDev a) {
     if (b >= a.B) return;
     float dccar = 0.f, ducar = 0.f;
     if (LOC) { loc_stage_lds(carve_bf(sm, a), a, threadIdx.x); lds_barrier(); }
+    if (EncRes<NE, LOC, true>::N > 0) {                               // resident encoder frames (natural layout): once per launch
+        const int H8 = a.Hd >> 3;
+        uint4* dst = carve_bf(sm, a).encl;
+        const uint4* src = reinterpret_cast<const uint4*>(a.encbf) + (size_t)b * a.Tp * H8;
+        for (int i = threadIdx.x; i < EncRes<NE, LOC, true>::N * 16 * H8; i += RNT) {
+            const int tt = i / H8;
+            dst[i] = src[(size_t)(tt < a.Tp ? tt : a.Tp - 1) * H8 + (i - tt * H8)];
+        }
+    }
+    unsigned k2[NE] = {};
+    const bool acts = a.actS && a.actS[0] == LAS_ACT_MAGIC;           // the forward rows kept their attention activations
+    if (LAS_KEYS_HOISTED && !LOC && !acts) bwd_keys_load<NE>(a, b, threadIdx.x, k2);      // (location-aware: the loop is at the register limit)
     for (int t = a.U - 1; t >= -1; --t) {
         int bb = b, tid = threadIdx.x;
         asm volatile("" : "+s"(bb), "+v"(tid));                       // see dec_loop_fwd_kernel
-        pf_bwd_row<CELL, NE, true, LOC>(a, (t + 1 < a.U) ? t + 1 : -1, t, bb, tid, sm, dccar, ducar, local);
+        pf_bwd_row<CELL, NE, true, LOC>(a, (t + 1 < a.U) ? t + 1 : -1, t, bb, tid, sm, dccar, ducar, local, k2, acts);
         lds_barrier();
     }
 }
@@ -2595,6 +2716,9 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     return w;
 }
 
+extern "C" size_t las_speller_act_save_bytes(int U, int B, int Tp, int A) {
+    return (size_t)LAS_ACT_HDR * 4 + (size_t)U * B * Tp * A * 2;
+}
 extern "C" size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell) {
     const int G = cell == LAS_CELL_LSTM ? 4 : 1;
     return bwd_layout(B, Tp, Hd, A, D, NL, E, V, U, G, 256, 16).total;
@@ -2623,7 +2747,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
-    d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0;
+    d.hs = f->hs; d.cs = f->cs; d.gates = f->gates; d.xin0 = f->xin0; d.actS = nullptr;
     d.lp = LoopProd{};
     d.lp.status = f->status;
     d.lp.budget = 1 << (((f->flags >> 8) & 31) ? ((f->flags >> 8) & 31) : 21);
@@ -2674,8 +2798,9 @@ static void loop_prod_dims(LoopProd& p, int B, int ncols, int K) {
     p.KS = cdiv(K, 32); p.K = K; p.N = ncols; p.nct = cdiv(ncols, 16); p.M = B; p.R = cdiv(B, 8);
     p.pn = las_device_cus() / 8 - p.R;
 }
+static constexpr size_t LOOP_LDS_MAX = 159 * 1024;                 // a loop workgroup has its CU to itself (160 KB less the kernels' static LDS)
 template <class K> static int loop_lds_attr(K kernel) {   // the product workgroups' partial tiles need > 64 KB of dynamic LDS
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOOP_LDS_MAX);
 }
 #define LAS_LOOP_LAUNCH1(KERNEL, CELL, NE, LOC, grid, lds, st, d)                                          \
     do {                                                                                                   \
@@ -2752,12 +2877,18 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     const bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
+    if (f->act_save) {   // the prefetching rows keep their attention activations for the gradient rows; any other kernel family leaves the header cleared
+        if (FAST && (loop || pf) && U > 1) d.actS = (unsigned*)f->act_save;
+        else LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
+    }
     if (d.flags & LAS_SPELLER_NO_LOGITS)
         LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
                 "speller: LAS_SPELLER_NO_LOGITS needs U = 1, one LSTM layer, speed mode with the prefetching row kernels, D and E + Hd + D multiples of 32");
     if (loop) {   // the whole loop in one launch
         const size_t lds_pr = (size_t)RNW * LOOP_TPW_F * 1024;       // the product workgroups' partial tiles (80 KB)
-        const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
+        const size_t lds_rw = lds_bf + enc_res_bytes(d, locloop, loop_ne(d.Tp));   // row state + resident encoder slabs
+        const size_t lds_lp = lds_rw < lds_pr ? lds_pr : lds_rw;
+        LAS_ARG(lds_lp <= LOOP_LDS_MAX, "speller: the loop's row state does not fit LDS (%zu bytes)", lds_lp);
         loop_prod_dims(d.lp, B, GD, I0D);
         d.lp.Bp = reinterpret_cast<const u16x8_t*>(packF); d.lp.bias = f->cellb[0]; d.lp.C = nullptr; d.lp.c_step = 0; d.lp.ldc = 0;
         d.lp.gA = (unsigned long long*)((char*)f->ws + wl_.granX); d.lp.gA_row = I0D / 4;
@@ -2870,6 +3001,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     // feeds granules to the rows, which is what makes the single-buffered exchange safe); the embedding columns of dXin0 are
     // one tall contraction after the loop (part 2)
     const bool loop = locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B));
+    if (loop || pf) d.actS = (unsigned*)bk->f.act_save;               // (the rows check the header: only what a forward of the same family left is used)
     if (skinny && (part & 1)) {   // B[k = gate col][n = input row] = W0[n][k]
         if (loop) GEMM_OK(las_skinny_pack(f->cellW[0] + (size_t)E * GD, GD, GD, Hd + D, 1, packB, st));
         else      GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));
@@ -2889,7 +3021,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
 
     if (loop) {
         const size_t lds_pr = (size_t)RNW * LOOP_TPW_B * 1024;
-        const size_t lds_lp = lds_bf < lds_pr ? lds_pr : lds_bf;
+        const size_t lds_rw = lds_bf + enc_res_bytes(d, locloop, loop_ne(Tp), true);     // row state + resident encoder frames
+        const size_t lds_lp = lds_rw < lds_pr ? lds_pr : lds_rw;
+        LAS_ARG(lds_lp <= LOOP_LDS_MAX, "speller bwd: the loop's row state does not fit LDS (%zu bytes)", lds_lp);
         loop_prod_dims(d.lp, B, Hd + D, GD);
         d.lp.Bp = reinterpret_cast<const u16x8_t*>(packB); d.lp.bias = nullptr;
         d.lp.C = d.dXin0 + E; d.lp.c_step = (long long)B * I0D; d.lp.ldc = I0D;

@@ -39,7 +39,7 @@ class SpellerFwdArgs(Structure):
         ("cellW", POINTER(c_void_p)), ("cellb", POINTER(c_void_p)),
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
         ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
-        ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p),
+        ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p), ("act_save", c_void_p),
         ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p), ("companion", POINTER(LstmCellArgs))]
 
 
@@ -114,6 +114,7 @@ _SIGS = {
                                    c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
                                    c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
+    "las_speller_act_save_bytes": (c_size_t, [c_int] * 4),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
     "las_speller_bwd_part": (c_int, [POINTER(SpellerBwdArgs), c_int, c_void_p]),
@@ -163,7 +164,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 401      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 402      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():

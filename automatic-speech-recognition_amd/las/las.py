@@ -7,6 +7,7 @@ returns the same 7-tuple with concrete values, `LAS.inference(xs)` executes gree
 arithmetic runs in liblas_hip.so (`las._hip`); there is no CPU path.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -105,6 +106,7 @@ def _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, b
     fa.hs = bufs["hs"].data_ptr()
     fa.cs = bufs["cs"].data_ptr() if bufs["cs"] is not None else None
     fa.gates, fa.xin0 = bufs["gates"].data_ptr(), bufs["xin0"].data_ptr()
+    fa.act_save = bufs["act"].data_ptr() if bufs.get("act") is not None else None
     fa.ws, fa.ws_bytes = None, 0
     fa.status = _hip.status_word(enc.device).data_ptr()      # a loop-kernel poll time-out is reported here (never a trap / hang)
     return keep
@@ -119,6 +121,9 @@ def _alloc_bufs(dims, dev):
         "cs": torch.empty(NL, U + 1, B, D, device=dev) if G == 4 else None,
         "gates": torch.empty(NL, U, B, G * D, device=dev), "xin0": torch.empty(U, B, E + Hd + D, device=dev),
     }
+
+
+SAVE_ACTIVATIONS = os.environ.get("LAS_SPELLER_SAVE_ACT", "1") != "0"
 
 
 class _SpellerLoop(torch.autograd.Function):
@@ -137,6 +142,11 @@ class _SpellerLoop(torch.autograd.Function):
         P = {"Ws": Ws, "u": u, "emb": emb, "Wv": Wv, "bv": bv, "loc_w": loc_w, "loc_b": loc_b, "Wf": Wf,
              "cellW": list(cell_params[:NL]), "cellb": list(cell_params[NL:])}
         bufs = _alloc_bufs(dims, dev)
+        if SAVE_ACTIVATIONS and prec == _hip.PREC_BF16 and dims["mode"] == _hip.ATT_LOC and any(ctx.needs_input_grad):
+            # location-aware attention: the rows' tanh(keys + q + f . Wf), kept for the gradient loop (fp16, 2 A T' bytes per row and step)
+            # -- recomputing it there costs 20 FMAs + 2 tanh per lane and frame (23 -> 20.4 us per gradient step at K = 201, C = 10).  The
+            # additive loop recomputes: its tanh hides under the Ws loads, the saved values' 41 KB per step do not (10.4 -> 10.6 us)
+            bufs["act"] = torch.empty(_hip.lib().las_speller_act_save_bytes(dims["U"], B, Tp, A), dtype=torch.uint8, device=dev)
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
         keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,

@@ -44,17 +44,18 @@ int main(int argc, char** argv) {
     d.dE = dalloc<float>((size_t)U * B * Tp); d.dHl = dalloc<float>((size_t)U * B * D); d.dH = dalloc<float>((size_t)B * D);
     d.dC = dalloc<float>((size_t)B * D); d.dXin0 = dalloc<float>((size_t)U * B * I0D); d.Q = dalloc<float>((size_t)U * B * A);
     d.dQ = dalloc<float>((size_t)U * B * A); d.duRows = dalloc<float>((size_t)B * A);
+    if (!getenv("NO_ACT_SAVE")) { d.actS = (unsigned*)dalloc<unsigned short>((size_t)U * B * Tp * A + 16); }
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;
     if (LOCM) {
         d.mode = LAS_ATT_LOC; d.Kc = 201; d.C = 10;
         d.loc_w = dalloc<float>((size_t)d.Kc * d.C); d.loc_b = dalloc<float>(d.C); d.Wf = dalloc<float>((size_t)d.C * A);
         d.fcSave = dalloc<float>((size_t)U * B * Tp * d.C); d.dfcSave = dalloc<float>((size_t)U * B * Tp * d.C);
     }
-    const size_t lds = bf_lds_bytes(d), lds_lp = lds > 16 * 5 * 1024 ? lds : 16 * 5 * 1024;
-    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const size_t lds = bf_lds_bytes(d), lds_rw = lds + enc_res_bytes(d, LOCM, 10, false), lds_lp = lds_rw > 16 * 5 * 1024 ? lds_rw : 16 * 5 * 1024;
+    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    hipFuncSetAttribute((const void*)dec_loop_fwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    hipFuncSetAttribute((const void*)dec_loop_bwd_kernel<LAS_CELL_LSTM, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     void *packF, *packB; hipMalloc(&packF, las_skinny_pack_bytes(I0D, GD)); hipMalloc(&packB, las_skinny_pack_bytes(GD, I0D));
     float* W0 = dalloc<float>((size_t)I0D * GD); float* b0 = dalloc<float>(GD);
     unsigned long long *gX, *gF, *gG, *gB, *xcc; hipMalloc(&xcc, 256 * 8);
@@ -102,7 +103,7 @@ int main(int argc, char** argv) {
             if (rep == 2 && (which == 1 || which == 3)) {   // last iteration of the loop: product (ct 0) and row 0 phases on one clock
                 unsigned long long hs[32];
                 hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamps), sizeof(hs));
-                const int ids[2][12] = {{0, 1, 9, 2, 3, 4, 5, 6, 8, 21, 22, 23}, {10, 24, 11, 12, 14, 15, 17, 19, 20, 21, 22, 23}};
+                const int ids[2][12] = {{0, 1, 9, 2, 3, 4, 5, 6, 8, 21, 22, 23}, {10, 24, 12, 14, 15, 16, 17, 19, 20, 21, 22, 23}};
                 printf("  same-XCD groups: %d\n", (int)hs[31]);
                 const unsigned long long z = hs[ids[which == 3][0]];
                 for (int i = 0; i < 12; ++i) printf("  stamp %2d: %+7.2f us\n", ids[which == 3][i], ((double)hs[ids[which == 3][i]] - (double)z) * 0.01);
