@@ -112,11 +112,15 @@ _DCHUNK = {}          # data_ptr of a dPre whose producer (a recurrent layer's d
                       # (chunk rows, rows per utterance, chunks, fn(k), holder) -- the dense node below runs fn(k) interleaved with its
                       # own chunks and puts the event behind the last one into `holder`
 _DOUT_CHUNKS = {}     # data_ptr of a dense layer's dX that is still being produced in chunks on the chain stream: (flag, chunk rows, rows)
+_XCHUNK = {}          # data_ptr of a dense + tanh output (pBLSTMLayer, forward) of which only the first time chunk exists: (chunk steps,
+                      # frames per utterance, chunks, fn(k)) -- the recurrent layer that consumes it runs fn(k) in front of chunk k of its
+                      # own x-projection (round 4: the dense product between two sweeps was 65 us of the forward chain per pyramid level)
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
 ROW_T = [None]        # inference over a batch of utterances of DIFFERENT lengths: int32 [B] device tensor of the current layer's frames per row
                       # (set around the listener call by BeamSearch.decode_batch; the pyramid layers halve it) -- las_rnn_seq_fwd_rows
 XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
+DENSE_CHUNKS = os.environ.get("LAS_DENSE_CHUNK", "1") != "0"         # the dense + tanh in front of a chunked x-projection follows the same chunks
 DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 TAIL_TWO_STREAMS = not os.environ.get("LAS_NO_TAIL_TWO_STREAMS")   # bottom layer's weight gradients: one direction per auxiliary stream
@@ -131,13 +135,24 @@ def _direct_ok(p):
             and V.default_store().flat_grad is not None and p.grad.is_contiguous())
 
 
+def _xproj_chunk_steps(B, T, H, cell):
+    """Sweep steps per time chunk of a layer's x-projection hand-over (0: the whole projection before the sweep)."""
+    cs = XPROJ_CHUNK_STEPS
+    if ROW_T[0] is not None:
+        return 0                                     # rows of different lengths (inference): whole x-projection, las_rnn_seq_fwd_rows
+    if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), _hip.PREC_BF16, B, H):
+        return cs
+    return 0
+
+
 def check_handovers_consumed():
     """Called when a backward pass is complete (LAS.train): every chunked hand-over registered by a producer must have been
     taken by its consumer -- a left-over entry means some node read a tensor whose later chunks were never computed."""
-    left = [n for n, r in (("_DCHUNK", _DCHUNK), ("_DOUT_CHUNKS", _DOUT_CHUNKS)) if r]
+    left = [n for n, r in (("_DCHUNK", _DCHUNK), ("_DOUT_CHUNKS", _DOUT_CHUNKS), ("_XCHUNK", _XCHUNK)) if r]
     if left:
         _DCHUNK.clear()
         _DOUT_CHUNKS.clear()
+        _XCHUNK.clear()
         raise RuntimeError("las.layers: chunked gradient hand-over left unconsumed (%s): the autograd graph between two recurrent "
                            "layers is not the pBLSTMLayer stack -- set LAS_DOUT_CHUNK=0 for such graphs" % ", ".join(left))
 
@@ -365,7 +380,7 @@ def _flag_ring(dev):
 # resident; "serial": hand-overs that ran with their producers in front of the consumer on one stream (LAS_ALLOW_SERIAL_STREAMS=1 under a
 # tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
 # that is timed must be the variant that is tested.
-VARIANTS = {"xproj_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0}
+VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0}
 
 
 def begin_step(dev):
@@ -400,7 +415,22 @@ class _Dense16(torch.autograd.Function):
         Kw, N = W.shape
         WT = _shadow("denseT", (W,), Kw, True, N, _k64(Kw))                              # W^T: [N, K64]
         y = torch.empty(M, N, device=x2d.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-        _hip.gemm_kk(x2d, WT, y, M, N, K, K, K, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
+        xc = _PARAMS.pop("xchunk", None)              # (cs, B, T): the consumer is a recurrent layer that takes its input in time chunks
+        if xc is not None and not out_f32 and xc[1] * xc[2] == M:
+            cs, nb, Tq = xc
+            th = (Tq + 1) // 2
+            nch = (th + cs - 1) // cs
+            a = _hip.ACT_TANH if act else _hip.ACT_NONE
+
+            def produce(k):
+                lo0, lo1 = k * cs, min((k + 1) * cs, th)
+                hi0, hi1 = max(Tq - lo1, lo1), Tq - lo0
+                _hip.gemm_kk_frames(x2d, WT, y, nb, Tq, lo0, lo1 - lo0, hi0, hi1 - hi0, N, K, K, K, N, bias=b, act=a)
+
+            produce(0)
+            _XCHUNK[y.data_ptr()] = (cs, Tq, nch, produce, (x2d, WT, y) + ((b,) if b is not None else ()))
+        else:
+            _hip.gemm_kk(x2d, WT, y, M, N, K, K, K, N, bias=b, act=_hip.ACT_TANH if act else _hip.ACT_NONE)
         ctx.save_for_backward(x2d, W, y)
         ctx.act, ctx.has_b = act, b is not None
         ctx.params = (_PARAMS.get("W"), _PARAMS.get("b"))
@@ -538,10 +568,13 @@ class _BLSTM16(torch.autograd.Function):
             # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
             bias = _shadow("ihb", (bfw, bbw), 1, False, 1, 2 * GH, bf16=False).view(-1)
-            chunk_flag, cs = None, XPROJ_CHUNK_STEPS
-            if ROW_T[0] is not None:
-                cs = 0                                   # rows of different lengths (inference): whole x-projection, las_rnn_seq_fwd_rows
-            if cs and T >= 4 * cs and _hip.rnn_seq_fwd_chunks_ok(_cellid(cell), prec, B, H):
+            chunk_flag, cs = None, _xproj_chunk_steps(B, T, H, cell)
+            xc = _XCHUNK.pop(x.data_ptr(), None)         # the dense + tanh below has only produced its first time chunk
+            if xc is not None and (xc[0] != cs or xc[1] != T):
+                for k in range(1, xc[2]):                # not the chunks this layer takes: finish the producer first
+                    xc[3](k)
+                xc = None
+            if cs:
                 # The sweep consumes the x-projection in time order (forward direction from t = 0, backward from t = T - 1), so only
                 # the first chunk of frames -- both ends of the sequence -- has to exist when it starts: chunk 0 on this stream,
                 # the others on the side stream WHILE the sweep runs (it holds a fifth of the CUs); the sweep's helper waves wait
@@ -551,16 +584,19 @@ class _BLSTM16(torch.autograd.Function):
                 chunk_flag = _chunk_flag(dev)
 
                 def chunk(k):
+                    if xc is not None and k > 0:
+                        xc[3](k)                         # the input frames of this chunk (dense + tanh of the layer below)
                     lo0, lo1 = k * cs, min((k + 1) * cs, th)
                     hi0, hi1 = max(T - lo1, lo1), T - lo0
                     _hip.gemm_kk_frames(x, WT, gates, B, T, lo0, lo1 - lo0, hi0, hi1 - hi0, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
                     _hip.set_word(chunk_flag, k + 1)
 
                 chunk(0)
+                VARIANTS["dense_chunks"] += int(xc is not None)
                 if _hip.streams_overlap(dev):
                     with _hip.on_side_stream():
                         side = _hip.side_stream()
-                        for t in (x, gates, chunk_flag):
+                        for t in (x, gates, chunk_flag) + (xc[4] if xc is not None else ()):
                             t.record_stream(side)
                         for k in range(1, nch):
                             chunk(k)
@@ -814,7 +850,18 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     _EXPECT_DPRE.clear()
     _DCHUNK.clear()
     _DOUT_CHUNKS.clear()
+    _XCHUNK.clear()
+
+    def hint(B, Tn):
+        # the dense + tanh whose output goes straight into the next recurrent layer (no dropout mask in between) follows that
+        # layer's time chunks: only the first chunk of frames is on the chain in front of the sweep
+        cs = _xproj_chunk_steps(B, Tn, H, _CFG["cell"]) if DENSE_CHUNKS and not (is_training is True and dropout_rate) else 0
+        if cs and _prec() == _hip.PREC_BF16:
+            _PARAMS["xchunk"] = (cs, B, Tn)
+
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)
+    if num_layers > 0:
+        hint(out.shape[0], out.shape[1])
     rnn_out = dense(out, st.get(sc + "/dense/kernel", (2 * H, 2 * H)),
                     st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=num_layers == 0)       # :71-74
     audiolen = torch.as_tensor(audiolen).to(torch.float64)
@@ -826,6 +873,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
         B, Tp, _ = out.shape
         # Eq (5): pad T to even, concat frame pairs -- a pure view of the zero-padded buffer (:83-88)
         pairs = out.view(B, Tp // 2, 4 * H)
+        if l + 1 < num_layers:
+            hint(B, Tp // 2)
         rnn_out = dense(pairs, st.get(sc + "/dense/kernel", (4 * H, 2 * H)),
                         st.get(sc + "/dense/bias", (2 * H,), init="zeros"), tanh=True, out_f32=l == num_layers - 1)   # :89-93
         # (the listener's LAST dense output feeds the Speller, whose interface is fp32; everything before it stays bf16)

@@ -141,11 +141,13 @@ def expect_handovers(las, cell, B, H=256, on=True):
     cid = 1 if cell == "lstm" else 0
     assert v["sweeps_fwd"] >= 1 and v["sweeps_bwd"] >= 1, v
     if not on:
-        assert v["xproj_chunks"] == 0 and v["dout_chunks"] == 0 and v["hold_side"] == 0, v
+        assert v["xproj_chunks"] == 0 and v["dense_chunks"] == 0 and v["dout_chunks"] == 0 and v["hold_side"] == 0, v
         return v
     assert v["serial"] == 0, v
     if L.XPROJ_CHUNK_STEPS and _hip.rnn_seq_fwd_chunks_ok(cid, 1, B, H):
         assert v["xproj_chunks"] >= 1, v
+        if L.DENSE_CHUNKS and v["xproj_chunks"] >= 2:      # a pyramid level that takes its input in chunks: the dense + tanh below it follows them
+            assert v["dense_chunks"] >= 1, v
     if L.DOUT_CHUNK_ROWS and _hip.rnn_seq_bwd_chunks_ok(cid, 1, B, H):
         assert v["dout_chunks"] >= 1, v
     if L.HOLD_SIDE:

@@ -53,6 +53,7 @@ def test_b48_rows_equal_twelve_b4_batches():
     torch.cuda.synchronize()
     las.check_status()
     v = expect_handovers(las, "lstm", B)
+    assert v["dense_chunks"] == 3, v                  # every dense + tanh between two sweeps follows the next layer's time chunks
     assert (v["sweeps_fwd"], v["xproj_chunks"], v["sweeps_bwd"], v["dout_chunks"]) == (4, 4, 4, 3), v    # = profiles/*_kernel_stats.csv: 3 of 4 BPTT launches CH = true
     logits, alphas, g48 = logits.cpu(), alphas.cpu(), st.flat_grad.cpu().clone()
     assert alphas.shape[-1] == 160
