@@ -540,25 +540,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(GemmArgs g) {
 // step of side-stream traffic next to the BPTT sweeps.  Same tile machinery as gemm_tn_tr_kernel<128> (k-major LDS tiles, transposing
 // LDS reads), all row blocks of one k-chunk on ONE XCD so that the dZ rows enter that L2 once.
 // ------------------------------------------------------------------------------------------------
+struct WgradDir {
+    const unsigned short* X;                       // layer input [K, ldx] bf16 (the direction's own copy under input dropout)
+    const unsigned short* O; int shift;            // this direction's column block of the layer output; h_prev = frame t + shift (-1 / +1)
+    const unsigned short* Z;                       // this direction's column block of d(pre-activation) [K, ldz] bf16
+    float* dW;                                     // [I + H, N] fp32, accumulated
+};
 struct WgradArgs {
-    const unsigned short* X; int ldx, M1;          // layer input [K, ldx] bf16; M1 = columns of X that exist (multiple of 8)
-    const unsigned short* O; int ldo; long long obs; int shift;   // layer output (this direction's column block), row pitch, batch stride, -1 / +1
-    const unsigned short* Z; int ldz;              // d(pre-activation) [K, ldz] bf16 (this direction's column block)
+    WgradDir d[2]; int ndir;
+    int ldx, M1;                                   // M1 = columns of X that exist (multiple of 8)
+    int ldo; long long obs;                        // layer output: row pitch, batch stride
+    int ldz;
     int T, K, N, nb1, nb2;                         // frames per utterance, K = B T, N = G H, row blocks from X / from the output
     float invT;
     int splitk, kchunk;
-    float* partial;                                // [splitk][(nb1 + nb2) * 128][N]
+    float* partial;                                // [ndir][splitk][(nb1 + nb2) * 128][N]
 };
 
+// (Measured, round 4: two or three k-steps requested ahead of the one in the matrix cores -- 16 staging registers each -- do NOT make it
+//  faster: 150 / 163 vs 144 us for a direction of the bottom layer.  The kernel is not waiting for memory: per k-step and CU the
+//  vector-memory path (32 KB), the LDS (64 KB of fragment reads + 32 KB of tile writes) and the matrix cores (2 x 512 clocks) are each
+//  25-50 % busy and overlap poorly with two workgroups per CU; four per CU (twice the k-chunks) is what helps the two-direction launch.)
 __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
     constexpr int BM = 128, BN = 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int nx = g.N / BN, ny = g.nb1 + g.nb2, nt = nx * ny;
+    const int nx = g.N / BN, ny = g.nb1 + g.nb2, nt = nx * ny, ntd = nt * g.ndir;
     const int L = blockIdx.x, xcd = L & 7, li = L >> 3;
-    const int bz = xcd + 8 * (li / nt);
+    const int bz = xcd + 8 * (li / ntd);
     if (bz >= g.splitk) return;
-    const int t_ = li % nt, by = t_ / nx, bx = t_ % nx;
+    const int td = li % ntd, dir = td / nt, t_ = td - dir * nt, by = t_ / nx, bx = t_ % nx;   // both directions of a k-chunk on one XCD: X enters that L2 once
+    const WgradDir gd = g.d[dir];
     const int n0 = bx * BN;
     const bool hsrc = by >= g.nb1;
     const int m0 = (hsrc ? by - g.nb1 : by) * BM;
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int pk = tid >> 4, pc = (tid & 15) * 8;                   // a piece is 16 bytes = 8 columns of one k-row: piece tid + 256 u of k-row pk + 16 u
-    const unsigned short* pb = g.Z + (long long)(kbeg + pk) * g.ldz + n0 + pc;
+    const unsigned short* pb = gd.Z + (long long)(kbeg + pk) * g.ldz + n0 + pc;
     const long long sb16 = 16LL * g.ldz, sb32 = 32LL * g.ldz;
     const int so = pk * TR_PITCH + pc * 2;
     u32x4_t ra[2], rb[2];
@@ -579,22 +591,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
         for (int u = 0; u < 2; ++u) {
             const int k = k0 + pk + 16 * u;
             bool on = k < kend;
-            const unsigned short* src = g.X;
+            const unsigned short* src;
             if (!hsrc) {
                 on = on && m0 + pc < g.M1;
-                src = g.X + (long long)(on ? k : 0) * g.ldx + m0 + pc;
+                src = gd.X + (long long)(on ? k : 0) * g.ldx + m0 + pc;
             } else {
                 int b = (int)((float)k * g.invT);                    // k = b T + t  (k < 2^24: the float quotient is off by at most one)
                 if (b * g.T > k) --b;
                 if ((b + 1) * g.T <= k) ++b;
-                const int tp = k - b * g.T + g.shift;
+                const int tp = k - b * g.T + gd.shift;
                 on = on && tp >= 0 && tp < g.T;
-                src = g.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
+                src = gd.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
             }
-            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : g.Z);
+            const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : gd.Z);
             ra[u] = on ? va : zero;
             const bool onb = k < kend;
-            const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? pb + u * sb16 : g.Z);
+            const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? pb + u * sb16 : gd.Z);
             rb[u] = onb ? vb : zero;
         }
         pb += sb32;
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
         buf ^= 1;
     }
-    float* P = g.partial + ((long long)bz * ny + by) * BM * g.N;
+    float* P = g.partial + (((long long)dir * g.splitk + bz) * ny + by) * BM * g.N;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -634,58 +646,73 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
 }
 
 // fixed-order reduction of the k-chunks: virtual row r of block row `by` -> dW row (X blocks: r < I; output blocks: I + r)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int I, int H, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g, int I, int H) {
     const int ny = g.nb1 + g.nb2;
-    const long long total = (long long)ny * 128 * g.N;
+    const long long per = (long long)ny * 128 * g.N, total = per * g.ndir;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int vr = (int)(idx / g.N), col = (int)(idx % g.N), by = vr >> 7, r = vr & 127;
+        const int dir = (int)(idx / per);
+        const long long e = idx - dir * per;
+        const int vr = (int)(e / g.N), col = (int)(e % g.N), by = vr >> 7, r = vr & 127;
         int row;
         if (by < g.nb1) { row = by * 128 + r; if (row >= I) continue; }
         else { row = (by - g.nb1) * 128 + r; if (row >= H) continue; row += I; }
+        const float* P = g.partial + (long long)dir * g.splitk * per + e;
         float s_ = 0.f;
-        for (int z = 0; z < g.splitk; ++z) s_ += g.partial[(long long)z * total + idx];
-        dW[(long long)row * g.N + col] += s_;
+        for (int z = 0; z < g.splitk; ++z) s_ += P[(long long)z * per];
+        g.d[dir].dW[(long long)row * g.N + col] += s_;
     }
 }
 
-extern "C" size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T) {
-    if (I <= 0 || H <= 0 || GH <= 0 || B <= 0 || T <= 0) return 0;
-    const int ny = cdiv(I, 128) + H / 128, tiles = ny * (GH / 128);
-    const long long K = (long long)B * T;
-    int s = (int)((512 + tiles - 1) / tiles);
-    const int maxs = (int)(K / 512);
-    if (s > maxs) s = maxs;
+static int wgrad_split(int I, int H, int GH, long long K, int ndir, int* kchunk) {
+    const int ny = cdiv(I, 128) + H / 128, tiles = ny * (GH / 128) * ndir;
+    const int wgs = ndir == 2 ? 1024 : 512;       // workgroups a launch aims at: two per CU; four for the two-direction launch (383 -> 260 us at the bottom layer)
+    int s = (wgs + tiles - 1) / tiles;
+    if (s > K / 512) s = (int)(K / 512);
     if (s < 1) s = 1;
-    return (size_t)s * ny * 128 * GH * sizeof(float);
+    const int kc = (int)(((K + s - 1) / s + 31) / 32 * 32);
+    if (kchunk) *kchunk = kc;
+    return (int)((K + kc - 1) / kc);
+}
+extern "C" size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T, int ndir) {
+    if (I <= 0 || H <= 0 || GH <= 0 || B <= 0 || T <= 0 || ndir < 1 || ndir > 2) return 0;
+    const int ny = cdiv(I, 128) + H / 128;
+    int s = wgrad_split(I, H, GH, (long long)B * T, ndir, nullptr);
+    if (s < wgrad_split(I, H, GH, (long long)B * T, 1, nullptr)) s = wgrad_split(I, H, GH, (long long)B * T, 1, nullptr);
+    return (size_t)ndir * s * ny * 128 * GH * sizeof(float);
 }
 
-extern "C" int las_wgrad_ih_hh(const void* X, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
-                               int B, int T, int H, int GH, int dir, float* dW, void* ws, size_t ws_bytes, void* stream) {
-    LAS_ARG(X && out && dZ && dW && ws, "las_wgrad_ih_hh: null pointer");
+// dir = 0 / 1: one direction (dW = that direction's gradient, dW2 ignored); dir = 2: BOTH in one launch (dW = forward, dW2 = backward
+// direction, X2 = the backward direction's input copy or NULL = X).  out / dZ: the [.., 2 H] / [.., 2 G H] tensors of both directions.
+extern "C" int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                               int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(X && out && dZ && dW && ws && dir >= 0 && dir <= 2 && (dir < 2 || dW2), "las_wgrad_ih_hh: null pointer / bad direction");
     LAS_ARG(B > 0 && T > 0 && I > 0 && H > 0 && H % 128 == 0 && GH % 128 == 0, "las_wgrad_ih_hh: needs H and G H multiples of 128 (I=%d H=%d GH=%d)", I, H, GH);
     LAS_ARG((long long)B * T < (1 << 24), "las_wgrad_ih_hh: B T must stay below 2^24");
     LAS_ARG(ldx % 8 == 0 && ldx >= (I + 7) / 8 * 8 && ld_out % 8 == 0 && lddz % 8 == 0 && out_bstride % 8 == 0 &&
-            (((uintptr_t)X | (uintptr_t)out | (uintptr_t)dZ) & 15) == 0, "las_wgrad_ih_hh: operands must be 16-byte aligned with pitches that are multiples of 8");
+            (((uintptr_t)X | (uintptr_t)X2 | (uintptr_t)out | (uintptr_t)dZ) & 15) == 0, "las_wgrad_ih_hh: operands must be 16-byte aligned with pitches that are multiples of 8");
     WgradArgs g;
-    g.X = (const unsigned short*)X; g.ldx = ldx; g.M1 = (I + 7) / 8 * 8;
-    g.O = (const unsigned short*)out; g.ldo = ld_out; g.obs = out_bstride; g.shift = dir ? 1 : -1;
-    g.Z = (const unsigned short*)dZ; g.ldz = lddz;
+    g.ndir = dir == 2 ? 2 : 1;
+    for (int i = 0; i < g.ndir; ++i) {
+        const int d = dir == 2 ? i : dir;
+        g.d[i].X = (const unsigned short*)((d == 1 && X2) ? X2 : X);
+        g.d[i].O = (const unsigned short*)out + (size_t)d * H; g.d[i].shift = d ? 1 : -1;
+        g.d[i].Z = (const unsigned short*)dZ + (size_t)d * GH;
+        g.d[i].dW = (dir == 2 && i == 1) ? dW2 : dW;
+    }
+    if (g.ndir == 1) g.d[1] = g.d[0];
+    g.ldx = ldx; g.M1 = (I + 7) / 8 * 8; g.ldo = ld_out; g.obs = out_bstride; g.ldz = lddz;
     g.T = T; g.K = B * T; g.N = GH; g.nb1 = cdiv(I, 128); g.nb2 = H / 128;
     g.invT = 1.0f / (float)T;
-    const int ny = g.nb1 + g.nb2, nt = ny * (GH / 128);
-    int s = (512 + nt - 1) / nt;
-    if (s > g.K / 512) s = g.K / 512;
-    if (s < 1) s = 1;
-    int kchunk = ((g.K + s - 1) / s + 31) / 32 * 32;
-    s = (g.K + kchunk - 1) / kchunk;
-    g.splitk = s; g.kchunk = kchunk; g.partial = (float*)ws;
-    LAS_ARG(ws_bytes >= (size_t)s * ny * 128 * GH * sizeof(float), "las_wgrad_ih_hh: workspace too small");
+    const int ny = g.nb1 + g.nb2, nt = ny * (GH / 128) * g.ndir;
+    g.splitk = wgrad_split(I, H, GH, g.K, g.ndir, &g.kchunk);
+    g.partial = (float*)ws;
+    LAS_ARG(ws_bytes >= (size_t)g.ndir * g.splitk * ny * 128 * GH * sizeof(float), "las_wgrad_ih_hh: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_tn_tr_kernel, dim3(nt * ((s + 7) / 8 * 8)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(wgrad_tn_tr_kernel, dim3(nt * ((g.splitk + 7) / 8 * 8)), dim3(256), 0, st, g);
     LAS_LAUNCHED();
-    int nb = cdiv((long long)ny * 128 * GH, 256);
+    int nb = cdiv((long long)g.ndir * ny * 128 * GH, 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, g, I, H, dW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, g, I, H);
     LAS_LAUNCHED();
     return 0;
 }

@@ -91,9 +91,9 @@ _SIGS = {
                             c_void_p, c_int, c_longlong, c_int, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
                             c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "las_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "las_wgrad_ih_hh_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "las_wgrad_ih_hh": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "las_wgrad_ih_hh_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "las_wgrad_ih_hh": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_gemm_kk": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
                             c_void_p, c_int, c_void_p]),
     "las_gemm_kk_tanhgrad": (c_int, [c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_longlong,
@@ -164,7 +164,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 402      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 403      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():
@@ -432,15 +432,15 @@ def gemm_kk(A, B, C, M, N, K, lda, ldb, ldc, bias=None, act=ACT_NONE, a_off=0, b
                             c_void_p(C.data_ptr() + C.element_size() * c_off), cdt, ldc, p(bias), act, stream()), "las_gemm_kk")
 
 
-def wgrad_ih_hh(x, ldx, I, out, ld_out, out_bstride, gates, lddz, B, T, H, GH, d, dW, o_off, z_off):
-    """dW[0:I] += x^T . dZ_d, dW[I:I+H] += h_prev^T . dZ_d in one pass over dZ_d (las_wgrad_ih_hh); o_off / z_off: element offsets of
-    direction d's column block in `out` / `gates` (both bf16)."""
-    require_gpu(x, out, gates, dW)
+def wgrad_ih_hh(x, ldx, I, out, ld_out, out_bstride, gates, lddz, B, T, H, GH, d, dW, dW2=None, x2=None):
+    """dW[0:I] += x^T . dZ_d, dW[I:I+H] += h_prev^T . dZ_d in one pass over dZ_d (las_wgrad_ih_hh); d = 2: both directions in one launch
+    (dW forward, dW2 backward direction; x2: the backward direction's input copy).  out / gates: the tensors of both directions (bf16)."""
+    require_gpu(x, out, gates, dW, dW2, x2)
     assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and gates.dtype == torch.bfloat16 and dW.dtype == torch.float32
-    nb = int(lib().las_wgrad_ih_hh_workspace_bytes(I, H, GH, B, T))
+    nb = int(lib().las_wgrad_ih_hh_workspace_bytes(I, H, GH, B, T, 2 if d == 2 else 1))
     ws = workspace(dW.device, nb, _tag("wgrad"))
-    check(lib().las_wgrad_ih_hh(p(x), ldx, I, c_void_p(out.data_ptr() + 2 * o_off), ld_out, out_bstride, c_void_p(gates.data_ptr() + 2 * z_off), lddz,
-                                B, T, H, GH, d, p(dW), p(ws), ws.numel(), stream()), "las_wgrad_ih_hh")
+    check(lib().las_wgrad_ih_hh(p(x), p(x2), ldx, I, p(out), ld_out, out_bstride, p(gates), lddz, B, T, H, GH, d, p(dW), p(dW2),
+                                p(ws), ws.numel(), stream()), "las_wgrad_ih_hh")
 
 
 def skinny_pack(W, K, N, ldw=None, row0=0):

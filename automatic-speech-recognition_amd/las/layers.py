@@ -123,6 +123,7 @@ XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the wh
 DENSE_CHUNKS = os.environ.get("LAS_DENSE_CHUNK", "1") != "0"         # the dense + tanh in front of a chunked x-projection follows the same chunks
 DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
+TAIL_ONE_LAUNCH = os.environ.get("LAS_TAIL_ONE_LAUNCH", "1") != "0"   # bottom layer's weight gradients: both directions in one launch on the launch stream
 TAIL_TWO_STREAMS = not os.environ.get("LAS_NO_TAIL_TWO_STREAMS")   # bottom layer's weight gradients: one direction per auxiliary stream
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 BEFORE_TAIL_HOOK = [None]   # callable(bottom layer's parameters) run right before the end-of-step tail is enqueued (data parallel)
@@ -714,14 +715,16 @@ class _BLSTM16(torch.autograd.Function):
         _hip.run_deferred()
         Ig = (I0 + 3) // 4 * 4          # rows of dW_ih the TN product writes; rows I0..Ig meet zero operand columns (exact zeros)
 
+        one_pass = WGRAD_ONE_PASS and T > 1 and H % 128 == 0 and GH % 128 == 0 and B * T < (1 << 24) and out.dtype == bf and x.dtype == bf
+
         def wgrads(gk_of, d):
             # dW_ih = x^T . dG_d (contraction over all B*T frames; split-K inside las_gemm); dW_hh = sum_b sum_t h_prev^T . dG_d
             # (`part` is allocated HERE, i.e. on the stream that uses it: a block of the main stream's pool handed to the
             #  side stream would be recycled by the allocator while the side stream still writes it)
             gk = gk_of(d)
-            if WGRAD_ONE_PASS and T > 1 and H % 128 == 0 and GH % 128 == 0 and B * T < (1 << 24) and out.dtype == bf and xs[d].dtype == bf:
+            if one_pass:
                 # one pass over dG_d for both (round 4): the left operand is [x | h_prev] with h_prev read from `out` one frame back
-                _hip.wgrad_ih_hh(xs[d], Ik, I0, out, 2 * H, Tp * 2 * H, gates, 2 * GH, B, T, H, GH, d, gk, d * H, d * GH)
+                _hip.wgrad_ih_hh(xs[d], Ik, I0, out, 2 * H, Tp * 2 * H, gates, 2 * GH, B, T, H, GH, d, gk)
                 return
             part = torch.empty(B, H, GH, device=dev) if T > 1 else None
             _hip.gemm(prec, xs[d], gates, gk, True, False, Ig, GH, B * T, Ik, 2 * GH, GH, beta=1.0, b_off=d * GH)
@@ -731,6 +734,13 @@ class _BLSTM16(torch.autograd.Function):
                 _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
                           strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
                 _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
+
+        def wgrads_both(gk_of, pair=False):
+            if one_pass and pair:                      # both directions in one launch
+                _hip.wgrad_ih_hh(x, Ik, I0, out, 2 * H, Tp * 2 * H, gates, 2 * GH, B, T, H, GH, 2, gk_of(0), gk_of(1), x_bw if two else None)
+            else:
+                for d in range(2):
+                    wgrads(gk_of, d)
 
         if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
@@ -752,8 +762,7 @@ class _BLSTM16(torch.autograd.Function):
                         # BPTT sweep is resident: they would delay its start (it needs whole CUs) and slow the chain GEMMs in
                         # front of it; bounded wait, scheduling only
                         _hip.hold_until_next_sweep(dev)
-                    for d in range(2):
-                        wgrads(lambda d: P4[2 * d].grad, d)
+                    wgrads_both(lambda d: P4[2 * d].grad)
 
             if produced is not None:
                 _hip.defer_side(lambda: side_work(produced))      # run by the next sweep's node, after its launch
@@ -762,8 +771,12 @@ class _BLSTM16(torch.autograd.Function):
                     # data parallel: every gradient but this layer's is final once the work queued so far has run -- the
                     # all-reduce of that part of the bucket starts now, under the tail (las.las.LAS.train)
                     BEFORE_TAIL_HOOK[0](P4)
-                # bottom layer = the end-of-step tail, nothing left to hide behind: the two directions' weight gradients on two
-                # streams (with the LDS-transposing kernel a single one of these products no longer fills the chip: 15.07 -> 14.99 ms)
+                # bottom layer = the end-of-step tail, nothing left to hide behind.  Round 4: both directions in ONE launch on THIS
+                # stream (no event hand-over to another queue in front of it and behind it: 28 + 67 us of the 347 us tail).  Without the
+                # one-pass kernel: the two directions' products on two streams (a single one of them does not fill the chip)
+                if one_pass and TAIL_ONE_LAUNCH:
+                    wgrads_both(lambda d: P4[2 * d].grad, pair=True)
+                    return (dx, None, None, None, None, None, None, None, None, dx_bw)
                 with _hip.on_side_stream():
                     for t in (x, gates, out):
                         t.record_stream(_hip.side_stream())

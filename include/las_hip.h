@@ -37,7 +37,7 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
-#define LAS_HIP_ABI_VERSION 402      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+#define LAS_HIP_ABI_VERSION 403      /* bumped whenever an argument struct or a signature changes: las_version() of a library
                                         built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
@@ -77,17 +77,19 @@ int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K,
                 const float* bias, int act, int batch,
                 int a_mask_period, int a_mask_skip, void* ws, size_t ws_bytes, void* stream);
 
-/* Both weight gradients of ONE direction of a recurrent layer (the matmul gradient of the cell's kernel, las/layers.py:31 under
+/* Both weight gradients of a recurrent layer's direction(s) (the matmul gradient of the cell's kernel, las/layers.py:31 under
  * bidirectional_dynamic_rnn, las/layers.py:49-53) in one pass over d(pre-activation):
- *   dW[0:I, :] += X^T . dZ        dW[I:I+H, :] += sum over utterances and frames of h_prev^T . dZ
- * X bf16 [B*T, ldx] (layer input; columns >= I up to the next multiple of 8 must be zero), out bf16 = this direction's column block
- * of the layer output ([B, Tp, ld_out] with batch stride out_bstride elements), dZ bf16 = this direction's column block of the
- * d(pre-activation) tensor ([B*T, lddz]), dir 0: h_prev(b, t) = out[b, t-1] (zero at t = 0), dir 1: out[b, t+1] (zero at t = T-1).
- * dW fp32 [I + H, GH], accumulated.  Needs H % 128 == 0, GH % 128 == 0, 16-byte aligned operands, pitches multiples of 8.
- * Deterministic split-K over the frames (scratch from las_wgrad_ih_hh_workspace_bytes, reduced in fixed order). */
-size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T);
-int las_wgrad_ih_hh(const void* X, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
-                    int B, int T, int H, int GH, int dir, float* dW, void* ws, size_t ws_bytes, void* stream);
+ *   dW[0:I, :] += X^T . dZ_d        dW[I:I+H, :] += sum over utterances and frames of h_prev^T . dZ_d
+ * X bf16 [B*T, ldx] (layer input; columns >= I up to the next multiple of 8 must be zero), out bf16 [B, Tp, ld_out >= 2 H] (batch stride
+ * out_bstride elements) and dZ bf16 [B*T, lddz >= 2 GH]: the layer's output / d(pre-activation) tensors of BOTH directions (direction d's
+ * column block starts at d H / d GH).  dir 0: h_prev(b, t) = out_fw[b, t-1] (zero at t = 0); dir 1: out_bw[b, t+1] (zero at t = T-1);
+ * dir 2: both directions in ONE launch (dW = forward, dW2 = backward direction's gradient; X2 = the backward direction's own input copy
+ * -- input dropout draws one mask per direction -- or NULL = X).  dW fp32 [I + H, GH], accumulated.  Needs H % 128 == 0, GH % 128 == 0,
+ * 16-byte aligned operands, pitches multiples of 8.  Deterministic split-K over the frames (scratch from
+ * las_wgrad_ih_hh_workspace_bytes(.., ndir), reduced in fixed order). */
+size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T, int ndir);
+int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                    int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream);
 
 /* Speed-mode storage type of activations in HBM.  LAS_PREC_BF16 keeps the Listener's activations (x-projections /
  * saved gates, cell states, h, dense outputs and their gradients) as bf16 -- SURVEY 8(d)'s algorithmic bytes -- while

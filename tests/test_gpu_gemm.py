@@ -228,7 +228,7 @@ def test_both_weight_gradients_in_one_pass_over_dz(I, H, G, B, T):
     for d in (0, 1):
         dW0 = torch.randn(I + H, GH, generator=g).cuda()
         dW = dW0.clone()
-        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, d, dW, d * H, d * GH)
+        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, d, dW)
         Zd = dZ[:, :, d * GH:(d + 1) * GH].double().cpu()
         Od = out[:, :T, d * H:(d + 1) * H].double().cpu()
         hp = torch.zeros(B, T, H, dtype=torch.float64)
@@ -255,6 +255,16 @@ def test_both_weight_gradients_in_one_pass_over_dz(I, H, G, B, T):
             assert (dW - old).abs().max().item() < tol
     # run to run: bit-identical (fixed-order split-K)
     a, b = torch.zeros(I + H, GH, device="cuda"), torch.zeros(I + H, GH, device="cuda")
-    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, a, 0, 0)
-    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, b, 0, 0)
+    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, a)
+    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 0, b)
     assert torch.equal(a, b)
+    # both directions in one launch (the backward direction with its own input copy, as under input dropout)
+    X2 = torch.zeros(B, T, Ik)
+    X2[:, :, :I] = torch.randn(B, T, I, generator=g) * 0.5
+    X2 = X2.cuda().to(torch.bfloat16)
+    f2, b2 = torch.zeros(I + H, GH, device="cuda"), torch.zeros(I + H, GH, device="cuda")
+    _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 2, f2, b2, X2)
+    b1 = torch.zeros(I + H, GH, device="cuda")
+    _hip.wgrad_ih_hh(X2, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 1, b1)
+    tol2 = 3e-6 * (B * T) ** 0.5 * max(1.0, a.abs().max().item(), b1.abs().max().item())     # (the pair splits the frames differently)
+    assert (f2 - a).abs().max().item() < tol2 and (b2 - b1).abs().max().item() < tol2

@@ -35,7 +35,12 @@ for (I, T) in ((240, 1274), (1024, 637), (1024, 319), (1024, 160)):
                   strideA=T * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=0, b_off=2 * GH)
         _hip.colsum(part, B, H * GH, H * GH, dW[I:].reshape(-1), beta=1.0)
 
-    def new(d=0):
-        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, T * 2 * H, dZ, 2 * GH, B, T, H, GH, d, dW, 0, 0)
+    dW2 = torch.zeros(I + H, GH, device="cuda")
 
-    print("I=%d T=%d  old %.1f us   new %.1f us" % (I, T, timed(old), timed(new)), flush=True)
+    def new(d=0):
+        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, T * 2 * H, dZ, 2 * GH, B, T, H, GH, d, dW)
+
+    def pair():
+        _hip.wgrad_ih_hh(X, Ik, I, out, 2 * H, T * 2 * H, dZ, 2 * GH, B, T, H, GH, 2, dW, dW2)
+
+    print("I=%d T=%d  old %.1f us   new %.1f us   both directions in one launch %.1f us" % (I, T, timed(old), timed(new), timed(pair)), flush=True)
