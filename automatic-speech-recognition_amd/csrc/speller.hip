@@ -948,6 +948,10 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             STAMPX(26);
             lds_barrier();
             STAMPX(27);
+            if (a.actS && a.fcSave) {          // kept for the gradient loop and the after-loop filter / keys gradients (else: recomputed there)
+                float* fs = a.fcSave + ((size_t)t * B + b) * Tp * a.C;
+                for (int i = tid; i < Tp * a.C; i += RNT) fs[i] = L.fc[i];
+            }
         }
     }
     // ---- every load of the step whose address does not depend on the recurrence, in consumption order.
@@ -1970,12 +1974,12 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     const int dd = tid < D ? tid : D - 1, h2c = tid < (Hd >> 1) ? tid : (Hd >> 1) - 1, tpc = tid < Tp ? tid : Tp - 1;
     const int a2c = tid < 2 * A ? tid : 2 * A - 1, a8c = a8 < A8 ? a8 : A8 - 1, l8c = lane < H8 ? lane : H8 - 1;
     float apv = 0.f;                                  // LOC: the alignment that entered step t_att's conv (alpha_{t-1}, or align0 / zeros)
-    if (LOC) {
+    if (LOC && !acts) {
         const float* aps = ta > 0 ? a.alphas + ((size_t)(ta - 1) * B + b) * Tp : (a.align0 ? a.align0 + (size_t)b * Tp : a.alphas + (size_t)b * Tp);
         apv = aps[tpc];
         if (ta == 0 && !a.align0) apv = 0.f;
     }
-    if (LOC && att) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way -- before the bulk loads (register pressure); keep it for the after-loop keys / Wf gradient
+    if (LOC && att && !acts) {   // recompute f = conv1d(alpha_{t-1}) of step t_att while dXin0 is on its way -- before the bulk loads (register pressure); keep it for the after-loop keys / Wf gradient
         if (tid < Tp) L.aprev[tid] = apv;
         lds_barrier();
         loc_conv_mfma(L, a, tid);
@@ -2000,64 +2004,138 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
     constexpr int UF = TRES / 64;                                  // rounds of 64 frames that are resident as a whole
     constexpr int NKR = NK - UF > 0 ? NK - UF : 1;
     uint4 e8[NKR][4];
-    {
-        const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.encbf) + (size_t)b * Tp * Hd, 0, 0x7fffffff, 0x00020000);
+    const int A2 = A >> 1, c2c = lane < A2 ? lane : A2 - 1;
+    unsigned k2[NE];                                  // keys for the energies gradient (or the saved activations): one column pair per lane,
+                                                      // one frame per wave and round (sums over frames stay inside the lane, no cross-lane reduction)
+    float2 u2;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dcr = 0.f, dhl;     // cell part operands (saved by the forward pass)
+    float* gp = a.gates + (((size_t)0 * U + tcl) * B + b) * GD;
+    const bool polls = LOOP && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1));   // dXin0[t_att] from the product workgroups
+    if (!LOC) {
+        {
+            const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.encbf) + (size_t)b * Tp * Hd, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int u = UF; u < NK; ++u) {
-            const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+            for (int u = UF; u < NK; ++u) {
+                const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
-                const unsigned off = (LAS_ABL_SP & 16) ? (unsigned)(tid & 63) * 16u : (unsigned)(((size_t)ttc * H8 + hcc) * 16);
-                e8[u - UF][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ers, tt < TRES ? 0x80000000u : off, 0, 0));
+                for (int i = 0; i < 4; ++i) {
+                    const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
+                    const unsigned off = (LAS_ABL_SP & 16) ? (unsigned)(tid & 63) * 16u : (unsigned)(((size_t)ttc * H8 + hcc) * 16);
+                    e8[u - UF][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ers, tt < TRES ? 0x80000000u : off, 0, 0));
+                }
             }
         }
-    }
-    // keys for the energies gradient: one column pair per lane, one frame per wave and round (sums over frames stay
-    // inside the lane, no cross-lane reduction)
-    const int A2 = A >> 1, c2c = lane < A2 ? lane : A2 - 1;
-    unsigned k2[NE];
-    if (acts) {   // the forward rows kept tanh(keys + q [+ f . Wf]) of this step (fp16 pairs): nothing to recompute
+        if (acts) {   // the forward rows kept tanh(keys + q) of this step (fp16 pairs): nothing to recompute
 #pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
-            k2[u] = (a.actS + LAS_ACT_HDR)[(LAS_ABL_SP & 256) ? (size_t)(tid & 63) : (((size_t)ta * B + b) * Tp + t2c) * A2 + c2c];
+            for (int u = 0; u < NE; ++u) {
+                const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
+                k2[u] = (a.actS + LAS_ACT_HDR)[(LAS_ABL_SP & 256) ? (size_t)(tid & 63) : (((size_t)ta * B + b) * Tp + t2c) * A2 + c2c];
+            }
+        } else if (LOOP && LAS_KEYS_HOISTED) {
+#pragma unroll
+            for (int u = 0; u < NE; ++u) k2[u] = k2h[u];
+        } else {
+            bwd_keys_load<NE>(a, b, tid, k2);
         }
-    } else if (LOOP && LAS_KEYS_HOISTED && !LOC) {
-#pragma unroll
-        for (int u = 0; u < NE; ++u) k2[u] = k2h[u];
+        u2 = reinterpret_cast<const float2*>(a.u)[c2c];
+        dhl = a.dHl[((size_t)tcl * B + b) * D + dd];
+        if (CELL == LAS_CELL_LSTM) {
+            gs[0] = gp[dd]; gs[1] = gp[D + dd]; gs[2] = gp[2 * D + dd]; gs[3] = gp[3 * D + dd];
+            cv = a.cs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+            cpv = a.cs[(((size_t)0 * (U + 1) + tcl) * B + b) * D + dd];
+            dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
+        } else {
+            hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+        }
+        if (polls) {
+            const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
+            const unsigned tag = (unsigned)t_att + 1u;
+            const unsigned o0 = (unsigned)(((size_t)b * a.lp.gC_row + h2c) * 16), o1 = (unsigned)(((size_t)b * a.lp.gC_row + ((Hd + dd) >> 1)) * 16);
+            u32x4_t q0 = granule16_load(rs, o0), q1 = granule16_load(rs, o1);
+            int budget = a.lp.budget;
+            for (;;) {
+                const bool ok0 = q0.x == tag && q0.w == tag, ok1 = q1.x == tag && q1.w == tag;
+                if (ok0 && ok1) break;
+                if (--budget == 0) LOOP_POLL_TIMEOUT(a.lp);    // a product workgroup never ran: report, never hang
+                __builtin_amdgcn_s_sleep(1);
+                if (!ok0) q0 = granule16_load(rs, o0);
+                if (!ok1) q1 = granule16_load(rs, o1);
+            }
+            dcv = make_float2(__uint_as_float(q0.y), __uint_as_float(q0.z));
+            recv0 = __uint_as_float((dd & 1) ? q1.z : q1.y);
+        }
     } else {
-        bwd_keys_load<NE>(a, b, tid, k2);
-    }
-    const float2 u2 = reinterpret_cast<const float2*>(a.u)[c2c];
-    // cell part operands (saved by the forward pass)
-    float gs[4] = {0.f, 0.f, 0.f, 0.f}, cv = 0.f, cpv = 0.f, hv = 0.f, dcr = 0.f;
-    float* gp = a.gates + (((size_t)0 * U + tcl) * B + b) * GD;
-    const float dhl = a.dHl[((size_t)tcl * B + b) * D + dd];
-    if (CELL == LAS_CELL_LSTM) {
-        gs[0] = gp[dd]; gs[1] = gp[D + dd]; gs[2] = gp[2 * D + dd]; gs[3] = gp[3 * D + dd];
-        cv = a.cs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
-        cpv = a.cs[(((size_t)0 * (U + 1) + tcl) * B + b) * D + dd];
-        dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
-    } else {
-        hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
-    }
-    if (LOOP && att && wv * 64 < (D > (Hd >> 1) ? D : (Hd >> 1))) {   // dXin0[t_att] from the product workgroups
+        // location-aware rows that were handed f and the activations (acts) run the transposed conv of the PREVIOUS iteration while dXin0 is on
+        // its way: the encoder rows' 48 destination registers and the late operands are requested behind it (in front of it they spill, and
+        // a reload from scratch drains every load in flight), the dXin0 granules in front of it
+        const bool convT_first = LOC && acts && att && t_att + 1 < U;
+        auto e8_issue = [&]() __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.encbf) + (size_t)b * Tp * Hd, 0, 0x7fffffff, 0x00020000);
+    #pragma unroll
+            for (int u = UF; u < NK; ++u) {
+                const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hc = a8 + 16 * i, hcc = hc < H8 ? hc : H8 - 1;
+                    const unsigned off = (LAS_ABL_SP & 16) ? (unsigned)(tid & 63) * 16u : (unsigned)(((size_t)ttc * H8 + hcc) * 16);
+                    e8[u - UF][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ers, tt < TRES ? 0x80000000u : off, 0, 0));
+                }
+            }
+        };
+        auto late_operands = [&]() __attribute__((always_inline)) {      // consumed behind the attention part
+            if (acts) {   // the forward rows kept tanh(keys + q [+ f . Wf]) of this step (fp16 pairs): nothing to recompute
+    #pragma unroll
+                for (int u = 0; u < NE; ++u) {
+                    const int t2 = wv + RNW * u, t2c = t2 < Tp ? t2 : Tp - 1;
+                    k2[u] = (a.actS + LAS_ACT_HDR)[(LAS_ABL_SP & 256) ? (size_t)(tid & 63) : (((size_t)ta * B + b) * Tp + t2c) * A2 + c2c];
+                }
+            } else if (LOOP && LAS_KEYS_HOISTED && !LOC) {
+    #pragma unroll
+                for (int u = 0; u < NE; ++u) k2[u] = k2h[u];
+            } else {
+                bwd_keys_load<NE>(a, b, tid, k2);
+            }
+            u2 = reinterpret_cast<const float2*>(a.u)[c2c];
+            dhl = a.dHl[((size_t)tcl * B + b) * D + dd];
+            if (CELL == LAS_CELL_LSTM) {
+                gs[0] = gp[dd]; gs[1] = gp[D + dd]; gs[2] = gp[2 * D + dd]; gs[3] = gp[3 * D + dd];
+                cv = a.cs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+                cpv = a.cs[(((size_t)0 * (U + 1) + tcl) * B + b) * D + dd];
+                dcr = LOOP ? dccar : a.dC[(size_t)b * D + dd];
+            } else {
+                hv = a.hs[(((size_t)0 * (U + 1) + tcl + 1) * B + b) * D + dd];
+            }
+        };
+        if (!convT_first) { e8_issue(); late_operands(); }
         const __amdgpu_buffer_rsrc_t rs = granule_rsrc(a.lp.gC);
-        const unsigned tag = (unsigned)t_att + 1u;
         const unsigned o0 = (unsigned)(((size_t)b * a.lp.gC_row + h2c) * 16), o1 = (unsigned)(((size_t)b * a.lp.gC_row + ((Hd + dd) >> 1)) * 16);
-        u32x4_t q0 = granule16_load(rs, o0), q1 = granule16_load(rs, o1);
-        int budget = a.lp.budget;
-        for (;;) {
-            const bool ok0 = q0.x == tag && q0.w == tag, ok1 = q1.x == tag && q1.w == tag;
-            if (ok0 && ok1) break;
-            if (--budget == 0) LOOP_POLL_TIMEOUT(a.lp);    // a product workgroup never ran: report, never hang
-            __builtin_amdgcn_s_sleep(1);
-            if (!ok0) q0 = granule16_load(rs, o0);
-            if (!ok1) q1 = granule16_load(rs, o1);
+        u32x4_t q0 = {0u, 0u, 0u, 0u}, q1 = q0;
+        if (polls) { q0 = granule16_load(rs, o0); q1 = granule16_load(rs, o1); }
+        if (convT_first) {
+            // the forward rows kept f and the activations: nothing to recompute in this iteration.  The wait for dXin0 takes the transposed
+            // conv of the PREVIOUS iteration instead (d f of step t_att + 1 is still in LDS; what it sends back to alpha_{t_att} is consumed
+            // by this iteration's softmax gradient): 4 us per step off the chain
+            STAMPX(28);
+            loc_convT_mfma(L, a, tid);
+            STAMPX(29);
+            lds_barrier();
+            e8_issue();
+            late_operands();
         }
-        dcv = make_float2(__uint_as_float(q0.y), __uint_as_float(q0.z));
-        recv0 = __uint_as_float((dd & 1) ? q1.z : q1.y);
+        if (polls) {
+            const unsigned tag = (unsigned)t_att + 1u;
+            int budget = a.lp.budget;
+            for (;;) {
+                const bool ok0 = q0.x == tag && q0.w == tag, ok1 = q1.x == tag && q1.w == tag;
+                if (ok0 && ok1) break;
+                if (--budget == 0) LOOP_POLL_TIMEOUT(a.lp);    // a product workgroup never ran: report, never hang
+                __builtin_amdgcn_s_sleep(1);
+                if (!ok0) q0 = granule16_load(rs, o0);
+                if (!ok1) q1 = granule16_load(rs, o1);
+            }
+            dcv = make_float2(__uint_as_float(q0.y), __uint_as_float(q0.z));
+            recv0 = __uint_as_float((dd & 1) ? q1.z : q1.y);
+        }
     }
     STAMPX(24);
     const float recv = att ? recv0 : 0.f;
@@ -2143,7 +2221,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             }
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
-                if (LAS_W8_LATE && !LOC && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
+                if (LAS_W8_LATE && (!LOC || ACTS) && u < 8) { w8_load(u); __builtin_amdgcn_sched_barrier(0); }
                 const int t2 = wv + RNW * u;
                 const float de = t2 < lim ? dal[t2] : 0.f;
                 float v0, v1;
@@ -2179,7 +2257,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A)[lane] = make_float2(dq0, dq1);
                 reinterpret_cast<float2*>(L.scr + wv * 2 * A + A)[lane] = make_float2(du0, du1);
             }
-            if (LAS_W8_LATE && LOC) {   // location-aware: the loop above is at the register limit (Wf columns, d v rows) -- the Ws rows are
+            if (LAS_W8_LATE && LOC && !acts) {   // location-aware, recomputing: the loop above is at the register limit (Wf columns, d v rows) -- the Ws rows are
 #pragma unroll                  // requested here; the d f product and the dq / du reduction below cover their latency
                 for (int u = 0; u < 8; ++u) w8_load(u);
             }
@@ -2236,9 +2314,11 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
             const int C = a.C;
             float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
             for (int i = tid; i < Tp * C; i += RNT) ds[i] = L.dfc[(i % C) * loc_dpad(a) + i / C];      // (saved frame-major, as the after-loop kernels read it)
-            STAMPX(28);
-            loc_convT_mfma(L, a, tid);
-            STAMPX(29);
+            if (!acts) {
+                STAMPX(28);
+                loc_convT_mfma(L, a, tid);
+                STAMPX(29);
+            }
         }
         lds_barrier();
     } else {
@@ -2716,8 +2796,9 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     return w;
 }
 
-extern "C" size_t las_speller_act_save_bytes(int U, int B, int Tp, int A) {
-    return (size_t)LAS_ACT_HDR * 4 + (size_t)U * B * Tp * A * 2;
+static size_t act_save_f_offset(int U, int B, int Tp, int A) { return align256((size_t)LAS_ACT_HDR * 4 + (size_t)U * B * Tp * A * 2); }
+extern "C" size_t las_speller_act_save_bytes(int U, int B, int Tp, int A, int C) {
+    return act_save_f_offset(U, B, Tp, A) + (size_t)U * B * Tp * (C > 0 ? C : 0) * sizeof(float);    // header, activations (fp16), conv outputs f (fp32, location-aware)
 }
 extern "C" size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell) {
     const int G = cell == LAS_CELL_LSTM ? 4 : 1;
@@ -2878,8 +2959,10 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
     const bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
     if (f->act_save) {   // the prefetching rows keep their attention activations for the gradient rows; any other kernel family leaves the header cleared
-        if (FAST && (loop || pf) && U > 1) d.actS = (unsigned*)f->act_save;
-        else LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
+        if (FAST && (loop || pf) && U > 1) {
+            d.actS = (unsigned*)f->act_save;
+            if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)f->act_save + act_save_f_offset(U, B, d.Tp, d.A));
+        } else LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
     }
     if (d.flags & LAS_SPELLER_NO_LOGITS)
         LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
@@ -3001,7 +3084,10 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     // feeds granules to the rows, which is what makes the single-buffered exchange safe); the embedding columns of dXin0 are
     // one tall contraction after the loop (part 2)
     const bool loop = locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B));
-    if (loop || pf) d.actS = (unsigned*)bk->f.act_save;               // (the rows check the header: only what a forward of the same family left is used)
+    if ((loop || pf) && bk->f.act_save) {   // (the rows check the header: only what a forward of the same family left is used)
+        d.actS = (unsigned*)bk->f.act_save;
+        if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)bk->f.act_save + act_save_f_offset(U, B, Tp, A));   // f of every step: kept by the forward rows, or recomputed into the same place
+    }
     if (skinny && (part & 1)) {   // B[k = gate col][n = input row] = W0[n][k]
         if (loop) GEMM_OK(las_skinny_pack(f->cellW[0] + (size_t)E * GD, GD, GD, Hd + D, 1, packB, st));
         else      GEMM_OK(las_skinny_pack(f->cellW[0], GD, GD, I0D, 1, packB, st));

@@ -114,7 +114,7 @@ _SIGS = {
                                    c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
                                    c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_speller_workspace_bytes": (c_size_t, [c_int] * 10),
-    "las_speller_act_save_bytes": (c_size_t, [c_int] * 4),
+    "las_speller_act_save_bytes": (c_size_t, [c_int] * 5),
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
     "las_speller_bwd_part": (c_int, [POINTER(SpellerBwdArgs), c_int, c_void_p]),
@@ -164,7 +164,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 403      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 404      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():

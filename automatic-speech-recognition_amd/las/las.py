@@ -146,7 +146,7 @@ class _SpellerLoop(torch.autograd.Function):
             # location-aware attention: the rows' tanh(keys + q + f . Wf), kept for the gradient loop (fp16, 2 A T' bytes per row and step)
             # -- recomputing it there costs 20 FMAs + 2 tanh per lane and frame (23 -> 20.4 us per gradient step at K = 201, C = 10).  The
             # additive loop recomputes: its tanh hides under the Ws loads, the saved values' 41 KB per step do not (10.4 -> 10.6 us)
-            bufs["act"] = torch.empty(_hip.lib().las_speller_act_save_bytes(dims["U"], B, Tp, A), dtype=torch.uint8, device=dev)
+            bufs["act"] = torch.empty(_hip.lib().las_speller_act_save_bytes(dims["U"], B, Tp, A, dims["C"]), dtype=torch.uint8, device=dev)
         tokens_out = torch.zeros(dims["U"], B, dtype=torch.int32, device=dev) if step_logits else None
         fa = _hip.SpellerFwdArgs()
         keep = _fill_fwd_args(fa, dims, P, enc, keys, enc_len_i32, tokens_in, tokens_out, bufs, step_logits, seed,

@@ -37,7 +37,7 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
-#define LAS_HIP_ABI_VERSION 403      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+#define LAS_HIP_ABI_VERSION 404      /* bumped whenever an argument struct or a signature changes: las_version() of a library
                                         built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
@@ -286,8 +286,9 @@ typedef struct {
                                       [V,E] noise matrix per decode step, shared by the rows that look up the same token */
     float *hs, *cs, *gates, *xin0;
     void* act_save;                /* optional, saved for backward like the four above (las_speller_act_save_bytes): speed mode's row kernels keep
-                                      tanh(keys + q [+ f . Wf]) of every step here (fp16 [U,B,Tp,A] behind a 32-byte header) and the gradient
-                                      rows read it instead of recomputing 2 A Tp transcendentals per row and step; NULL (or a forward
+                                      tanh(keys + q [+ f . Wf]) of every step here (fp16 [U,B,Tp,A] behind a 32-byte header; location-aware: also
+                                      the conv outputs f, fp32 [U,B,Tp,C]) and the gradient rows read them instead of recomputing the conv, C FMAs
+                                      and a tanh per (frame, column) of every step; NULL (or a forward
                                       that ran another kernel family: the header says so) = recompute */
     void* ws; size_t ws_bytes;
     int* status;                   /* optional device int (the sweeps' status word): the one-launch loop kernels need all their
@@ -300,7 +301,7 @@ typedef struct {
                                       the second problem of one grid: two dependent-launch slots of a search step become one */
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
-size_t las_speller_act_save_bytes(int U, int B, int Tp, int A);
+size_t las_speller_act_save_bytes(int U, int B, int Tp, int A, int C);   /* C = location-aware channels (0: additive attention) */
 int las_speller_fwd(const las_speller_fwd_args* a, void* stream);
 
 /* Backward of the loop above for the tokens recorded in tokens_in (gradients do not flow through

@@ -44,7 +44,8 @@ int main(int argc, char** argv) {
     d.dE = dalloc<float>((size_t)U * B * Tp); d.dHl = dalloc<float>((size_t)U * B * D); d.dH = dalloc<float>((size_t)B * D);
     d.dC = dalloc<float>((size_t)B * D); d.dXin0 = dalloc<float>((size_t)U * B * I0D); d.Q = dalloc<float>((size_t)U * B * A);
     d.dQ = dalloc<float>((size_t)U * B * A); d.duRows = dalloc<float>((size_t)B * A);
-    if (!getenv("NO_ACT_SAVE")) { d.actS = (unsigned*)dalloc<unsigned short>((size_t)U * B * Tp * A + 16); }
+    const bool act_save = !getenv("NO_ACT_SAVE");
+    if (act_save) { d.actS = (unsigned*)dalloc<unsigned short>((size_t)U * B * Tp * A + 16); }
     d.rec[0] = d.dXin0; d.recLd[0] = I0D; d.recOff[0] = E + Hd;
     if (LOCM) {
         d.mode = LAS_ATT_LOC; d.Kc = 201; d.C = 10;
