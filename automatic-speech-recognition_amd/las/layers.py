@@ -120,6 +120,7 @@ import os
 ROW_T = [None]        # inference over a batch of utterances of DIFFERENT lengths: int32 [B] device tensor of the current layer's frames per row
                       # (set around the listener call by BeamSearch.decode_batch; the pyramid layers halve it) -- las_rnn_seq_fwd_rows
 XPROJ_CHUNK_STEPS = int(os.environ.get("LAS_XPROJ_CHUNK", "64"))     # 0: the whole x-projection before the sweep
+DENSE_CHUNK_MAX_ROWS = 64
 DENSE_CHUNKS = os.environ.get("LAS_DENSE_CHUNK", "1") != "0"         # the dense + tanh in front of a chunked x-projection follows the same chunks
 DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
@@ -869,7 +870,9 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
         # the dense + tanh whose output goes straight into the next recurrent layer (no dropout mask in between) follows that
         # layer's time chunks: only the first chunk of frames is on the chain in front of the sweep
         cs = _xproj_chunk_steps(B, Tn, H, _CFG["cell"]) if DENSE_CHUNKS and not (is_training is True and dropout_rate) else 0
-        if cs and _prec() == _hip.PREC_BF16:
+        # (B <= 64: the sweep's clusters must leave most of the machine to the chunk products -- at B = 96, the stacked steps, the sweep holds
+        #  120 of the 256 CUs and the dense chunks arrive late: 22.9 vs 21.4 ms per step with the x-projection's chunks alone)
+        if cs and B <= DENSE_CHUNK_MAX_ROWS and _prec() == _hip.PREC_BF16:
             _PARAMS["xchunk"] = (cs, B, Tn)
 
     _, _, out = _blstm_full(inputs, H, dropout_rate, is_training, scope=sc)

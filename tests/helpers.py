@@ -146,7 +146,7 @@ def expect_handovers(las, cell, B, H=256, on=True):
     assert v["serial"] == 0, v
     if L.XPROJ_CHUNK_STEPS and _hip.rnn_seq_fwd_chunks_ok(cid, 1, B, H):
         assert v["xproj_chunks"] >= 1, v
-        if L.DENSE_CHUNKS and v["xproj_chunks"] >= 2:      # a pyramid level that takes its input in chunks: the dense + tanh below it follows them
+        if L.DENSE_CHUNKS and v["xproj_chunks"] >= 2 and B <= L.DENSE_CHUNK_MAX_ROWS:      # a pyramid level that takes its input in chunks: the dense + tanh below it follows them
             assert v["dense_chunks"] >= 1, v
     if L.DOUT_CHUNK_ROWS and _hip.rnn_seq_bwd_chunks_ok(cid, 1, B, H):
         assert v["dout_chunks"] >= 1, v

@@ -143,6 +143,31 @@ def test_location_aware_loop_kernels_match_oracle(shape):
         assert float(go[n].abs().max()) > 0 and n in gn
 
 
+@pytest.mark.parametrize("shape", [LOC_SHAPES[0], LOC_SHAPES[2], LOC_SHAPES[3]])
+def test_location_aware_gradient_loop_with_and_without_the_saved_activations(shape):
+    """The location-aware forward rows hand tanh(keys + q + f . Wf) (fp16) and the conv outputs f to the gradient loop
+    (las_speller_fwd_args.act_save); without the buffer (LAS_SPELLER_SAVE_ACT=0, or a caller of the C ABI that passes NULL) the gradient rows
+    recompute both and run the transposed conv at the end of the iteration.  Same forward bit for bit, gradients equal up to the fp16 rounding of
+    the activations (|error| <= 2^-12 on values in (-1, 1)) -- and both are held against the oracle above / here."""
+    from las import las as LL
+    D, A, H, B, Tp, U, mixed, loc = shape
+    assert LL.SAVE_ACTIVATIONS, "the default is to save"
+    ln, an, gn, lo, ao, go = _run(0, 1, D, A, H, B, Tp, U, mixed, loc=loc)
+    LL.SAVE_ACTIVATIONS = False
+    try:
+        ln2, an2, gn2, _, _, _ = _run(0, 1, D, A, H, B, Tp, U, mixed, loc=loc)
+    finally:
+        LL.SAVE_ACTIVATIONS = True
+    assert torch.equal(ln, ln2) and torch.equal(an, an2)
+    differ = 0
+    for n in sorted(go):
+        scale = max(go[n].abs().max().item(), 1e-3)
+        assert (gn[n] - gn2[n]).abs().max().item() / scale < 1e-2, n        # (measured: up to 4.4e-3 on conv1d/bias)
+        assert (gn2[n] - go[n]).abs().max().item() / scale < 2e-2, n
+        differ += int(not torch.equal(gn[n], gn2[n]))
+    assert differ > 0, "the two gradient loops are different kernels paths: identical bits mean the switch did nothing"
+
+
 def test_backward_reuses_the_forward_operand_copies_only_when_nobody_else_used_the_workspace():
     """_SpellerLoop.backward passes LAS_SPELLER_REUSE_PREP when no other Speller call asked for the workspace since its own
     forward (the bf16 copies of enc / keys / Ws are still there).  An interleaved call on OTHER inputs must switch the reuse
