@@ -1363,11 +1363,12 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
     }
 }
 
-// REGISTER BUDGET (round 4): a loop workgroup is 16 waves on one CU; at 121-128 VGPRs per lane it needs the CU's whole register file, and
-// one small wave of anybody else on ANY CU -- another process's stream gate, a monitoring tool -- keeps the grid from becoming resident:
-// the placement handshake / the polls time out (tools/host_time_ranks.py, 2 to 8 processes on one device: 9 of 10 runs failed with this
-// kernel at 122 VGPRs, 0 of 20 at <= 120).  The additive-attention kernels of T' <= 160 are kept at <= 120 (tests/test_cabi_and_host.py
-// reads the compiler's report); T' > 160 and the location-aware instances use all 128 and need the device to themselves.
+// REGISTER BUDGET (round 4): a loop workgroup is 16 waves on one CU; at 121-128 VGPRs per lane it needs the CU's WHOLE register file, so that
+// one small wave of anybody else on any CU would keep the grid from becoming resident.  The additive-attention kernels of T' <= 160 are kept
+// at <= 120 (tests/test_cabi_and_host.py reads the compiler's report); T' > 160 and the location-aware instances use all 128.  (Found while
+// chasing exchange time-outs of tools/host_time_ranks.py -- several PROCESSES on one device; the rule did not end them: they occur with every
+// kernel variant tried, and in sweeps this round did not touch, on some of the pool's boxes and not on others.  Sharing the device between processes is not a
+// supported way to run the one-launch kernels; a time-out is reported through the status word, nothing hangs.)
 template <int CELL, int NE, bool LOC = false>
 __global__ __launch_bounds__(RNT) void dec_loop_fwd_kernel(DecDev a) {
     constexpr int TPW = 5, KW = 3;                                    // 26 x 5 column tiles >= 128, 16 waves x 3 k-steps x 32 >= 1280 (host-checked)
