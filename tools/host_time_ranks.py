@@ -61,8 +61,8 @@ def worker(rank, world, port, steps, B, T, out_path):
     def open_gate(v):
         assert hip.hipStreamWriteValue32(ctypes.c_void_p(opener.cuda_stream), sig, v, 0) == 0
 
-    _hip.speller_flags |= _hip.speller_spin_log2(25)             # (wide poll bounds: time-outs, not part of the measurement)
-    _hip.seq_flags |= _hip.seq_spin_log2(25)
+    _hip.speller_flags |= _hip.speller_spin_log2(23)             # (wide poll bounds: time-outs, not part of the measurement)
+    _hip.seq_flags |= _hip.seq_spin_log2(23)
     L.set_cell("lstm"); L.set_precision("bf16")
     V.reset_default_store(device=dev, seed=0)
     args = bench_args("lstm", 1)
