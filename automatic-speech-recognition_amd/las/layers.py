@@ -113,7 +113,7 @@ _DCHUNK = {}          # data_ptr of a dPre whose producer (a recurrent layer's d
                       # own chunks and puts the event behind the last one into `holder`
 _DOUT_CHUNKS = {}     # data_ptr of a dense layer's dX that is still being produced in chunks on the chain stream: (flag, chunk rows, rows)
 _XCHUNK = {}          # data_ptr of a dense + tanh output (pBLSTMLayer, forward) of which only the first time chunk exists: (chunk steps,
-                      # frames per utterance, chunks, fn(k)) -- the recurrent layer that consumes it runs fn(k) in front of chunk k of its
+                      # frames per utterance, chunks, fn(k), tensors to keep alive on the side stream) -- the recurrent layer that consumes it runs fn(k) in front of chunk k of its
                       # own x-projection (round 4: the dense product between two sweeps was 65 us of the forward chain per pyramid level)
 _PARAMS = {}          # hand-over of the leaf parameter objects to the autograd node being built (same thread, immediate)
 import os
