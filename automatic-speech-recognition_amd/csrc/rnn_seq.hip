@@ -550,7 +550,8 @@ __device__ __forceinline__ void l2_warmer(const WarmSeg (&seg)[NSEG], int rows, 
         if (to > T - 1) to = T - 1;
         if (xflag) {       // chunked x-projection: a line must never be touched before the chunk that writes it is complete (a stale
                            // copy in this XCD's L2 would be what the cluster reads later)
-            const int have = __hip_atomic_load(xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            int have = __hip_atomic_load(xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (have < 1) have = 1;                // chunk 0 is complete by stream order (las_rnn_seq_fwd_chunked's precondition)
             const int th = (T + 1) / 2;
             if (have * xsc < th && to > have * xsc - 1) to = have * xsc - 1;      // (second half: every chunk is complete by then)
         }
@@ -677,7 +678,8 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             *reinterpret_cast<f4v*>(xr + off) = lo;
             *reinterpret_cast<f4v*>(xr + off + 4) = hi;
         };
-        int have = 0;                                   // chunks of the x-projection known to be complete (a.xflag)
+        int have = 1;                                   // chunks of the x-projection known to be complete (a.xflag); chunk 0 was produced in
+                                                        // front of this launch in stream order (round 5: no set_word launch between the two)
         auto wait_chunk = [&](int st) __attribute__((always_inline)) {
             if (!a.xflag) return;
             const int mm = st < T - 1 - st ? st : T - 1 - st;
@@ -1306,7 +1308,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     }
     constexpr int NG = CELL == LAS_CELL_LSTM ? 4 : 1;
     // chunked dout (las_rnn_seq_bwd_db_chunked): the frame of step st may be read once the chunk of its producer row is complete
-    int dhave = 0;
+    int dhave = 1;                           // chunk 0: produced in front of this launch in stream order (no flag launch on the chain)
     auto wait_dout = [&](int st) __attribute__((always_inline)) {
         if constexpr (!CH) return;
         const int f = dir ? st : T - 1 - st, pr = f >> a.dshift;

@@ -390,6 +390,12 @@ def _tag(t):
     captured the launch stream's scratch is used: the captured step replays on the launch stream, in order with its eager users (and a
     buffer allocated on torch's capture stream would come from the graph's private pool and outlive the graph in this cache)."""
     if torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream()
+        if any(cur == st for a in _aux.values() for st in a.values()):
+            # a captured region that forks onto the side / chain streams would give concurrently replaying branches ONE set of
+            # split-K / column-sum / weight-gradient partial buffers: refuse instead of racing (only single-stream regions are captured)
+            raise RuntimeError("liblas_hip: library work on an auxiliary stream inside a HIP graph capture is not supported "
+                               "(per-stream scratch cannot be told apart during capture); capture single-stream regions only")
         return t
     sid = torch.cuda.current_stream().stream_id
     return t if sid == 0 else "%s_s%d" % (t, sid)
@@ -620,7 +626,10 @@ def next_announce():
 
 
 _overlap = {}
-ALLOW_SERIAL_STREAMS = bool(os.environ.get("LAS_ALLOW_SERIAL_STREAMS"))
+_overlap_failed = {}
+# (the `make dbg` library synchronises the device after every launch: streams cannot overlap there by construction, so loading it
+#  implies the serial schedule -- same kernel instances, every producer in front of its consumer)
+ALLOW_SERIAL_STREAMS = bool(os.environ.get("LAS_ALLOW_SERIAL_STREAMS")) or os.path.basename(LIB_PATH).endswith("_dbg.so")
 FORCE_SERIAL_STREAMS = os.environ.get("LAS_ALLOW_SERIAL_STREAMS") == "force"     # no probe: every hand-over with its producers first
 
 
@@ -666,6 +675,8 @@ def streams_overlap(dev):
             return streams_overlap(dev)
     key = (_devkey(dev), cur.stream_id)
     ok = _overlap.get(key)
+    if ok is None and key in _overlap_failed:
+        raise RuntimeError(_overlap_failed[key])      # probed once per (device, launch stream): a failure is remembered, not re-measured
     if ok is None:
         worst = 0.0
         for attempt in range(2):
@@ -674,12 +685,13 @@ def streams_overlap(dev):
                 break
         ok = worst < 2.0
         if not ok and not ALLOW_SERIAL_STREAMS:
-            raise RuntimeError(
+            _overlap_failed[key] = (
                 "liblas_hip: kernels of the launch stream and of the auxiliary streams do not run concurrently on %s (a waiter needed "
                 "%.1f ms for a store issued on another stream).  The train step's cross-stream hand-overs (x-projection chunks, "
-                "backward hand-over, held weight gradients) need that.  Under a tool that serialises kernels (rocprofv3 --pmc) set "
-                "LAS_ALLOW_SERIAL_STREAMS=1 (the hand-overs are then switched off); otherwise run the step on the default stream."
-                % (key[0], worst))
+                "backward hand-over, held weight gradients) need that.  Under a tool that serialises kernels (rocprofv3 --pmc, "
+                "AMD_SERIALIZE_KERNEL, a debugger) set LAS_ALLOW_SERIAL_STREAMS=1 (the same kernels then run with every producer "
+                "enqueued in front of its consumer); otherwise run the step on the default stream." % (key[0], worst))
+            raise RuntimeError(_overlap_failed[key])
         _overlap[key] = ok                      # (a False is only ever cached when the environment asked for it)
     return ok
 

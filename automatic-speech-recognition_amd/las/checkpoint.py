@@ -43,5 +43,6 @@ def restore(save_dir, restore_epoch=-1, store=None):
     path = latest_checkpoint(save_dir) if restore_epoch == -1 else os.path.join(save_dir, "las_E%d" % restore_epoch)
     if path is None or not os.path.exists(path):
         return None
-    store.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+    # weights_only: the payload is tensors, ints and dicts of them; a checkpoint path must never be able to run pickled code
+    store.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
     return path

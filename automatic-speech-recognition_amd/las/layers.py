@@ -390,6 +390,8 @@ def begin_step(dev):
     hand-over words instead of one 5 us fill in front of every sweep and every chunked dense product (11 per step, on the chain)."""
     for k in VARIANTS:
         VARIANTS[k] = 0
+    if _prec() == _hip.PREC_BF16:
+        _hip.streams_overlap(dev)       # probed (once) HERE: a device whose streams cannot overlap raises before any hand-over state exists
     ring = _flag_ring(dev)
     ring[0].zero_()
     ring[1], ring[2] = 0, _RING
@@ -484,7 +486,8 @@ class _Dense16(torch.autograd.Function):
                     lo0, lo1 = k * c, min((k + 1) * c, th)
                     hi0, hi1 = max(Tq - lo1, lo1), Tq - lo0
                     _hip.gemm_kk_frames(dpre, Wb, dx, nb, Tq, lo0, lo1 - lo0, hi0, hi1 - hi0, K, N, N, N, K)
-                    _hip.set_word(flag, k + 1)
+                    if k > 0:                          # (chunk 0 precedes the consumer sweep in stream order: never waited for)
+                        _hip.set_word(flag, k + 1)
 
                 mine(0)
                 first = torch.cuda.Event()
@@ -566,6 +569,7 @@ class _BLSTM16(torch.autograd.Function):
             x_bw = x_bw.contiguous()
         bf = torch.bfloat16
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=bf)
+        rest_chunks = None
         if not two:
             # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
@@ -591,17 +595,27 @@ class _BLSTM16(torch.autograd.Function):
                     lo0, lo1 = k * cs, min((k + 1) * cs, th)
                     hi0, hi1 = max(T - lo1, lo1), T - lo0
                     _hip.gemm_kk_frames(x, WT, gates, B, T, lo0, lo1 - lo0, hi0, hi1 - hi0, 2 * GH, Ik, Ik, Ik, 2 * GH, bias=bias)
-                    _hip.set_word(chunk_flag, k + 1)
+                    if k > 0:                            # (chunk 0 precedes the sweep in stream order: the sweep never waits for it)
+                        _hip.set_word(chunk_flag, k + 1)
 
                 chunk(0)
                 VARIANTS["dense_chunks"] += int(xc is not None)
                 if _hip.streams_overlap(dev):
-                    with _hip.on_side_stream():
-                        side = _hip.side_stream()
-                        for t in (x, gates, chunk_flag) + (xc[4] if xc is not None else ()):
-                            t.record_stream(side)
-                        for k in range(1, nch):
-                            chunk(k)
+                    # Round 5: the SWEEP is launched right behind chunk 0 and the other chunks are enqueued behind its launch, on the side
+                    # stream, ordered after chunk 0 by an event (r4 timeline: the host needed 0.36 ms to enqueue the 18 launches of layer 0's
+                    # nine chunks in front of the sweep's launch -- the first sweep of a step started 547 us into it)
+                    chunk0_done = torch.cuda.Event()
+                    chunk0_done.record()
+
+                    def rest_chunks(pad=None):
+                        with _hip.on_side_stream(after=chunk0_done):
+                            side = _hip.side_stream()
+                            for t in (x, gates, chunk_flag) + (xc[4] if xc is not None else ()) + (() if pad is None else (pad,)):
+                                t.record_stream(side)
+                            if pad is not None:
+                                pad.zero_()              # the zero frame behind an odd T (nobody reads it before the join below)
+                            for k in range(1, nch):
+                                chunk(k)
                 else:
                     # serialised streams (LAS_ALLOW_SERIAL_STREAMS=1, counter passes): the SAME kernel instances -- chunk products and
                     # the chunk-aware sweep -- with every producer in front of its consumer on this stream
@@ -616,8 +630,6 @@ class _BLSTM16(torch.autograd.Function):
                 _hip.gemm_kk(xd, WTd, gates, B * T, GH, Ik, Ik, Ik, 2 * GH, bias=b.detach(), c_off=d * GH)
         Tp = T + (T % 2) if pad_even else T
         out = torch.empty(B, Tp, 2 * H, device=dev, dtype=bf)
-        if Tp != T:
-            out[:, T:].zero_()                           # only the pad frame (the sweep writes every real frame)
         cst = torch.empty(B, T, 2, H, device=dev, dtype=bf) if cell == "lstm" else None
         row_T = ROW_T[0]
         if row_T is not None and (two or torch.is_grad_enabled() or not _hip.rnn_seq_fwd_rows_ok(_cellid(cell), prec, B, H)):
@@ -627,6 +639,11 @@ class _BLSTM16(torch.autograd.Function):
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs,
                          row_T=row_T)
+        if rest_chunks is not None:
+            # chunks 1 .. of the x-projection: side stream, enqueued behind the sweep's launch (with the pad frame's fill, off the chain)
+            rest_chunks(out[:, T:] if Tp != T else None)
+        elif Tp != T:
+            out[:, T:].zero_()               # only the pad frame (the sweep writes every real frame, and never this one)
         if not two and chunk_flag is not None:
             _hip.join_side_stream()          # (the chunks are long finished; this orders later users of `gates` after them)
         ctx.save_for_backward(x, kfw, kbw, gates, out, cst, x_bw)
@@ -859,6 +876,8 @@ def pBLSTMLayer(inputs, audiolen, num_layers, cell_units, dropout_rate, is_train
     H = int(cell_units)
     st = V.default_store()
     sc = scope + "/blstm"
+    if _prec() == _hip.PREC_BF16 and XPROJ_CHUNK_STEPS and ROW_T[0] is None:
+        _hip.streams_overlap(inputs.device)     # (callers that do not go through LAS.train: probe before the first chunk is issued)
     _TANH_OUT.clear()
     _DPRE.clear()
     _EXPECT_DPRE.clear()

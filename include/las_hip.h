@@ -178,8 +178,9 @@ int las_rnn_seq_fwd(int cell, int prec, int B, int T, int H, void* gates,
  * chunk k = frames [k*cs, (k+1)*cs) and [T-(k+1)*cs, T-k*cs) of every utterance (both ends of the sequence first: the forward
  * direction consumes t = 0, 1, .., the backward direction t = T-1, T-2, ..), e.g. by las_gemm_kk_frames launches on ANOTHER
  * stream, each followed by las_set_word(chunk_flag, k+1).  The sweep reads a frame only after *chunk_flag has reached its chunk
- * (bounded wait -> LAS_SEQ_STATUS_FWD_TIMEOUT).  Chunk 0 must be complete (and *chunk_flag >= 1) before this call is
- * enqueued work reaches the device, or at least be enqueued where it cannot be blocked by the sweep.  Only the helper-wave kernel
+ * (bounded wait -> LAS_SEQ_STATUS_FWD_TIMEOUT).  Chunk 0 must be complete IN STREAM ORDER in front of this call (produced on `stream`,
+ * or on a stream `stream` has waited for): the sweep never waits for it and the value of *chunk_flag only matters from 2 on -- no
+ * flag launch is needed between chunk 0's product and the sweep (round 5).  Only the helper-wave kernel
  * supports this: ask las_rnn_seq_fwd_chunks_ok first.  chunk_flag = NULL: las_rnn_seq_fwd. */
 int las_rnn_seq_fwd_chunks_ok(int cell, int prec, int B, int H, int flags);
 int las_rnn_seq_fwd_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
@@ -222,7 +223,7 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates,
  * of `chunk_rows` (a power of two) of those rows from both ends of the sequence (chunk k = rows [k*c, (k+1)*c) and
  * [n_rows-(k+1)*c, n_rows-k*c) of every utterance), e.g. by las_gemm_kk_frames launches on another stream each followed by
  * las_set_word(chunk_flag, k+1).  The sweep reads a frame of dout only after *chunk_flag has reached the chunk of its row
- * (bounded wait -> LAS_SEQ_STATUS_BWD_TIMEOUT).  Only the 8-row K-split cluster kernel supports it (las_rnn_seq_bwd_chunks_ok). */
+ * (bounded wait -> LAS_SEQ_STATUS_BWD_TIMEOUT); chunk 0 must be complete in stream order in front of this call and is never waited for.  Only the 8-row K-split cluster kernel supports it (las_rnn_seq_bwd_chunks_ok). */
 int las_rnn_seq_bwd_chunks_ok(int cell, int prec, int B, int H, int flags);
 int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,

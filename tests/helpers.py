@@ -131,6 +131,24 @@ def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None,
                 tokens_in=las.speller.last_tokens_in.cpu())
 
 
+def oracle_grads(args, cell, mode, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm"):
+    """Gradients (and logits) of the oracle's train step in an explicit arithmetic mode (a set_precision tuple): the second oracle run a
+    test needs to measure the ORACLE's own sensitivity to the arithmetic on an input (f32 mode against the bf16-emulating mode)."""
+    import torch
+    from oracle import las_oracle as O
+    p0 = O.init_params(args, seed=seed, cell=cell, enc_type=enc_type)
+    O.set_precision(*mode)
+    try:
+        po = O.to_torch(p0, requires_grad=True)
+        zeros = {k: torch.zeros_like(v) for k, v in po.items()}
+        _, logits_o, _, g_o, *_ = O.train_step(po, zeros, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
+                                               (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, coins=coins,
+                                               sampled=None if sampled is None else torch.tensor(sampled))
+    finally:
+        O.set_precision("f32")
+    return g_o, logits_o
+
+
 def expect_handovers(las, cell, B, H=256, on=True):
     """The schedule of the step that was just run (las.last_variants) must be the one bench.py times: x-projections and upstream
     gradients handed over in chunks across streams, weight gradients held -- wherever the kernels serve the configuration

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 NUTT, BEAM, T = 8, 16, 300
 
 
-def _setup(prec):
+def _setup(prec, seed=17):
     from las import layers as L, variables as V
     from las.las import LAS, Listener, Speller
     from las.beam_search import BeamSearch
@@ -27,7 +27,7 @@ def _setup(prec):
     from utils.tokenizer import CharEncoder
     args = make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128,
                      mode="add", beam_size=BEAM, convert_rate=0.166, apply_lm=True, lm_weight=0.5)
-    p0 = O.init_params(args, seed=17, cell="lstm")
+    p0 = O.init_params(args, seed=seed, cell="lstm")
     p0["Speller/decode/dense/bias"][2] = 0.4          # some hypotheses end before the step bound, some do not
     plm = lm_params(np.random.RandomState(8), 28, 0, 512, 2)
     for k in plm:
@@ -138,3 +138,41 @@ def test_forty_utterances_in_one_batch_equal_the_same_utterances_in_groups_of_ei
         assert [h.token_ids for h in a] == [h.token_ids for h in b], u
         assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], u
         assert torch.equal(a[-1].att[-1], b[-1].att[-1]), u
+
+
+def test_bf16_sixty_four_utterances_at_T_1274_match_the_bf16_oracle():
+    """The geometry bench.py's decode `value` is quoted on since round 4: 64 utterances x beam 16 = 1024 hypothesis
+    rows per step, T = 1274 frames (T' = 160), 2 x 512 LM fused in, one captured step replayed -- `lstm_cell_rows` at M = 1024, the
+    attention rows at 1024 rows x 160 frames, the beam kernel over 64 utterances.  Three of the 64 utterances (first, one in the middle,
+    last: different row blocks of every launch) against the oracle's beam search in its bf16 mode with the hoisted key projection, and the
+    same three decoded in a batch of their own (the rows of a search never interact: bit-identical)."""
+    args, p0, plm, bs, _ = _setup("bf16")
+    n, Tf = 64, 1274
+    utts = [synthetic_batch(1, Tf, 8, 30, seed=100 + k)[0] for k in range(n)]        # bench.py decode_bench's utterances
+    got = bs.decode_batch(None, utts)
+    assert len(got) == n and bs.use_graph
+    pick = (0, 37, 63)
+    alone = bs.decode_batch(None, [utts[u] for u in pick])
+    olm = (oracle_lm(plm, 0, 2), 512, 2)
+    same, worst = 0, 0.0
+    for u, small in zip(pick, alone):
+        res = got[u]
+        assert [b.token_ids for b in res] == [b.token_ids for b in small], u
+        assert [float(b.log_prob) for b in res] == [float(b.log_prob) for b in small], u
+        assert res[-1].att[-1].shape[-1] == 160
+        ref = oracle_decode(utts[u], p0, args, "lstm", BEAM, lm=olm, lm_weight=0.5, prec="bf16", hoist=True)
+        best, rbest = res[-1], ref[-1]
+        assert len(best.token_ids) - 1 > 100                                        # a search of the bench's length, not an early stop
+        d = abs(_norm(best) - _norm(rbest))
+        worst = max(worst, d)
+        assert d <= 5e-3, (u, _norm(best), _norm(rbest))
+        if best.token_ids == rbest.token_ids:
+            same += 1
+            assert np.abs(best.att[-1].cpu().numpy() - rbest.att[-1]).max() < 2e-3
+        else:                                                                       # acceptable only as a near tie in the oracle
+            ids = [b.token_ids for b in ref]
+            assert best.token_ids in ids, (u, "best hypothesis is not among the oracle's final beam")
+            assert abs(_norm(ref[ids.index(best.token_ids)]) - _norm(rbest)) <= 5e-3, u
+    print("bf16 decode at the `value` geometry (64 utterances x beam 16, T = 1274): best hypothesis identical for %d / %d checked, worst "
+          "normalised-score gap %.2e" % (same, len(pick), worst))
+    assert same >= len(pick) - 1
