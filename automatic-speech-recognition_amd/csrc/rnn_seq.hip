@@ -1611,8 +1611,8 @@ __device__ __forceinline__ void zero_region(uint4* z, long long n16) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-__global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const float* W1, int ldw, int H, int G, int P,
-                                                          unsigned short* out, uint4* zero, long long zero16) {
+__device__ __forceinline__ void pack_whh_ks_body(const float* W0, const float* W1, int ldw, int H, int G, int P,
+                                                 unsigned short* out, uint4* zero, long long zero16) {
     zero_region(zero, zero16);
     const int UTP = H / 64 / P, UPM = H / P, KP = G * UPM, KSP = KP / 32, NFR = P * UTP * KSP, NVW = 4 * P;
     const long long total = 2LL * NVW * NFR * 512;
@@ -1633,12 +1633,16 @@ __global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const
         out[idx] = f2bf(W[(long long)unit * ldw + col]);
     }
 }
+__global__ __launch_bounds__(256) void pack_whh_ks_kernel(const float* W0, const float* W1, int ldw, int H, int G, int P,
+                                                          unsigned short* out, uint4* zero, long long zero16) {
+    pack_whh_ks_body(W0, W1, ldw, H, G, P, out, zero, zero16);
+}
 
 // W_hh (fp32 [H, G*H]) -> bf16 MFMA B-fragment order for 4*P "virtual waves" of 16*UTP units each.
 //  fwd: frag (dir,vw,q,j,ks): B[k][n] = W[ks*32 + 8*(lane>>4)+e][q*H + vw*16*UTP + j*16 + (lane&15)]
 //  bwd: frag (dir,vw,j,ks):   B[k][n] = W[vw*16*UTP + j*16 + (lane&15)][ks*32 + 8*(lane>>4)+e]   (= W^T)
-__global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const float* W1, int ldw, int H, int G,
-                                                       int bwd, int P, unsigned short* out, uint4* zero, long long zero16) {
+__device__ __forceinline__ void pack_whh_body(const float* W0, const float* W1, int ldw, int H, int G,
+                                              int bwd, int P, unsigned short* out, uint4* zero, long long zero16) {
     zero_region(zero, zero16);
     const int UTP = H / 64 / P, GH = G * H, NVW = 4 * P;
     const int KS = bwd ? GH / 32 : H / 32;
@@ -1664,6 +1668,22 @@ __global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const fl
         }
         out[idx] = f2bf(W[(long long)row * ldw + col]);
     }
+}
+__global__ __launch_bounds__(256) void pack_whh_kernel(const float* W0, const float* W1, int ldw, int H, int G,
+                                                       int bwd, int P, unsigned short* out, uint4* zero, long long zero16) {
+    pack_whh_body(W0, W1, ldw, H, G, bwd, P, out, zero, zero16);
+}
+
+// Round 5 (las_rnn_seq_prepare): the packs and exchange-state clears of up to SEQ_PREP_MAX sweeps in ONE launch, once per optimiser step
+// -- a pack depends only on the weights, and the r4 timeline had one pack launch (8-11 us + a launch boundary) on the dependency chain in
+// front of each of a step's eight sweeps.  blockIdx.y = job.
+constexpr int SEQ_PREP_MAX = 8;
+struct SeqPrepJob { const float* w0; const float* w1; int ldw, H, G, P, kind; unsigned short* out; uint4* zero; long long zero16; };   // kind 0 / 1: pack_whh (fwd / bwd), 2: pack_whh_ks
+struct SeqPrepJobs { SeqPrepJob j[SEQ_PREP_MAX]; };
+__global__ __launch_bounds__(256) void seq_prepare_kernel(SeqPrepJobs jobs) {
+    const SeqPrepJob& q = jobs.j[blockIdx.y];
+    if (q.kind == 2) pack_whh_ks_body(q.w0, q.w1, q.ldw, q.H, q.G, q.P, q.out, q.zero, q.zero16);
+    else pack_whh_body(q.w0, q.w1, q.ldw, q.H, q.G, q.kind, q.P, q.out, q.zero, q.zero16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1883,7 +1903,10 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         // (err, sink, and for clusters the handshake / bias partials / granule tags: multiples of 256 bytes by construction)
         uint4* zr = (uint4*)(base + L.err);
         const long long z16 = (long long)(((P > 1 ? L.total : L.xbuf) - L.err) / 16);
-        if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
+        // LAS_SEQ_PREPARED: las_rnn_seq_prepare left this cluster width's pack and a clean exchange state in `ws` (first attempt only:
+        // a narrower fall-back cluster packs for itself)
+        if ((flags & LAS_SEQ_PREPARED) && attempt == 0) {}
+        else if (a.ks_packed) hipLaunchKernelGGL(pack_whh_ks_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, P,
                                             (unsigned short*)a.wpack, zr, z16);
         else hipLaunchKernelGGL(pack_whh_kernel, dim3(cdiv(2LL * G * H * H, 256 * 4)), dim3(256), 0, st, w0, w1, ldw, H, G, bwd ? 1 : 0, P,
                                 (unsigned short*)a.wpack, zr, z16);
@@ -1921,6 +1944,38 @@ static int run_bf16(bool bwd, int cell, const RnnArgs& a_in, const float* w0, co
         }
     }
     return rc;
+}
+
+extern "C" int las_rnn_seq_prepare(const las_seq_prepare_desc* descs, int n, void* stream) {
+    LAS_ARG(descs && n > 0, "las_rnn_seq_prepare: no descriptors");
+    for (int i0 = 0; i0 < n; i0 += SEQ_PREP_MAX) {
+        const int m = n - i0 < SEQ_PREP_MAX ? n - i0 : SEQ_PREP_MAX;
+        SeqPrepJobs jobs;
+        long long most = 0;
+        for (int i = 0; i < m; ++i) {
+            const las_seq_prepare_desc& d = descs[i0 + i];
+            LAS_ARG(d.cell == LAS_CELL_RNN || d.cell == LAS_CELL_LSTM, "las_rnn_seq_prepare: bad cell %d", d.cell);
+            LAS_ARG(mfma_shape_ok(d.H) && d.B > 0 && d.whh_fw && d.whh_bw && d.ws, "las_rnn_seq_prepare: bad descriptor %d (H = %d: only the speed mode's clustered sweeps take a prepared workspace)", i0 + i, d.H);
+            const int G = d.cell == LAS_CELL_LSTM ? 4 : 1;
+            LAS_ARG(d.ldw >= G * d.H, "las_rnn_seq_prepare: leading dimension too small");
+            const SeqWs L = seq_ws_layout(d.cell, d.H, d.B);
+            LAS_ARG(d.ws_bytes >= L.total, "las_rnn_seq_prepare: workspace too small (%zu < %zu)", d.ws_bytes, L.total);
+            const int P = pick_cluster(d.cell, d.H, d.flags);
+            const bool ks = d.bwd && P > 1 && !(d.flags & LAS_SEQ_NO_KSPLIT);
+            char* base = (char*)d.ws;
+            SeqPrepJob& q = jobs.j[i];
+            q.w0 = d.whh_fw; q.w1 = d.whh_bw; q.ldw = d.ldw; q.H = d.H; q.G = G; q.P = P; q.kind = ks ? 2 : (d.bwd ? 1 : 0);
+            q.out = (unsigned short*)(base + L.pack); q.zero = (uint4*)(base + L.err);
+            q.zero16 = (long long)(((P > 1 ? L.total : L.xbuf) - L.err) / 16);
+            const long long work = 2LL * G * d.H * d.H / 4 + q.zero16;
+            if (work > most) most = work;
+        }
+        long long nb = cdiv(most, 256 * 8);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(seq_prepare_kernel, dim3((unsigned)nb, m), dim3(256), 0, (hipStream_t)stream, jobs);
+        LAS_LAUNCHED();
+    }
+    return 0;
 }
 
 static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {

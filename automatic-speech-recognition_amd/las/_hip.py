@@ -81,8 +81,15 @@ class ShadowDesc(ctypes.Structure):
                 ("dst_ld", c_int), ("dst_bf16", c_int)]
 
 
+class SeqPrepareDesc(ctypes.Structure):
+    """include/las_hip.h las_seq_prepare_desc"""
+    _fields_ = [("whh_fw", c_void_p), ("whh_bw", c_void_p), ("ldw", c_int), ("cell", c_int), ("H", c_int), ("B", c_int), ("bwd", c_int),
+                ("flags", c_int), ("ws", c_void_p), ("ws_bytes", c_size_t)]
+
+
 _SIGS = {
     "las_version": (c_int, []),
+    "las_rnn_seq_prepare": (c_int, [POINTER(SeqPrepareDesc), c_int, c_void_p]),
     "las_last_error": (c_char_p, []),
     "las_gemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_longlong,
                          c_void_p, c_int, c_longlong, c_float, c_void_p, c_int, c_longlong, c_void_p, c_int,
@@ -164,7 +171,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 404      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 500      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():
@@ -557,7 +564,7 @@ class _timed:
 # ---- development switches of the sweeps / the Speller (explicit `flags` arguments of the C ABI).  The library itself
 # reads no environment; this host layer maps the documented LAS_* variables to flags ONCE, at import, so the
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
-SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS, SEQ_F32_VALU = 1, 2, 4, 8, 16, 32
+SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS, SEQ_F32_VALU, SEQ_PREPARED = 1, 2, 4, 8, 16, 32, 64
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS = 1, 2, 4, 8, 16
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
@@ -788,12 +795,25 @@ def rnn_seq_fwd_rows_ok(cell, prec, B, H, flags=None):
     return bool(lib().las_rnn_seq_fwd_rows_ok(cell, prec, B, H, seq_flags if flags is None else flags))
 
 
+def rnn_seq_prepare(jobs):
+    """las_rnn_seq_prepare: jobs = [(cell, H, B, bwd, whh_fw, whh_bw, ldw, wf_off, wb_off, ws), ...] (fp32 kernels, element offsets of W_hh,
+    one workspace tensor per job) -- packs + exchange-state clears of all of them in one launch on the current stream."""
+    arr = (SeqPrepareDesc * len(jobs))()
+    for d, (cell, H, B, bwd, wf, wb, ldw, wf_off, wb_off, ws) in zip(arr, jobs):
+        require_gpu(wf, wb, ws)
+        d.whh_fw, d.whh_bw, d.ldw = wf.data_ptr() + 4 * wf_off, wb.data_ptr() + 4 * wb_off, ldw
+        d.cell, d.H, d.B, d.bwd, d.flags = cell, H, B, int(bool(bwd)), seq_flags
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    check(lib().las_rnn_seq_prepare(arr, len(jobs), stream()), "las_rnn_seq_prepare")
+
+
 def rnn_seq_fwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
-                forget_bias=1.0, wf_off=0, wb_off=0, flags=None, chunk_flag=None, chunk_steps=0, row_T=None):
+                forget_bias=1.0, wf_off=0, wb_off=0, flags=None, chunk_flag=None, chunk_steps=0, row_T=None, prepared_ws=None):
+    """prepared_ws: a workspace rnn_seq_prepare has prepared for exactly this sweep (LAS_SEQ_PREPARED: no pack launch in front of it)."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate)
     _check_io(cell, prec, H, gates, out, cstate)
-    ws = rnn_seq_ws(cell, prec, H, B, gates.device)
-    fl = seq_flags if flags is None else flags
+    ws = rnn_seq_ws(cell, prec, H, B, gates.device) if prepared_ws is None else prepared_ws
+    fl = (seq_flags if flags is None else flags) | (SEQ_PREPARED if prepared_ws is not None else 0)
     if row_T is not None:
         require_gpu(row_T)
         assert chunk_flag is None and row_T.dtype == torch.int32 and row_T.numel() == B
@@ -823,13 +843,13 @@ def rnn_seq_bwd_chunks_ok(cell, prec, B, H, flags=None):
 
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None,
-                chunk_flag=None, chunk_rows=0, n_rows=0):
+                chunk_flag=None, chunk_rows=0, n_rows=0, prepared_ws=None):
     """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself.
     chunk_flag / chunk_rows / n_rows: dout is still being produced in chunks (las_rnn_seq_bwd_db_chunked)."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
     _check_io(cell, prec, H, gates, out, cstate, dout)
-    ws = rnn_seq_ws(cell, prec, H, B, gates.device)
-    fl = seq_flags if flags is None else flags
+    ws = rnn_seq_ws(cell, prec, H, B, gates.device) if prepared_ws is None else prepared_ws
+    fl = (seq_flags if flags is None else flags) | (SEQ_PREPARED if prepared_ws is not None else 0)
     fl |= next_announce() << 21                    # LAS_SEQ_ANNOUNCE: status_word[1] = this number once the sweep is resident
     _announce[0] += 1
     if chunk_flag is not None:

@@ -716,7 +716,7 @@ class LAS:
                                      _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps,
                                      _hip.p(_hip.status_word(dev)), _hip.p(st.guard), _hip.stream()),
                    "las_clip_adam")
-        st.shadows.clear()                            # bf16 weight shadows are rebuilt from the updated masters
+        st.weights_changed()                          # bf16 weight shadows / prepared sweep workspaces are rebuilt from the updated masters
         self.last_grad_sumsq = sumsq
 
     def train_stacked(self, batches, coins=None, sampled=None):

@@ -322,6 +322,7 @@ def _shadow(tag, srcs, rows, transpose, dst_rows, dst_cols, bf16=True):
         _hip.check(_hip.lib().las_build_shadows(tab.data_ptr(), n, mt, _hip.stream()), "las_build_shadows")
         for k, r in st.shadow_recipes.items():
             st.shadows[k] = r[0]
+        _prepare_sweeps(st)              # ... and, with the same trigger, everything the step's sweeps need from the weights
         return st.shadows[key]
     with torch.no_grad():
         mats = [(q.detach().reshape(1, -1) if q.dim() == 1 else q.detach())[:rows] for q in srcs]
@@ -343,6 +344,61 @@ def _shadow(tag, srcs, rows, transpose, dst_rows, dst_cols, bf16=True):
     st.shadow_table = None
     st.shadows[key] = sh
     return sh
+
+
+PREPARED_SWEEPS = os.environ.get("LAS_NO_PREPARED_SWEEPS") != "1"
+_STEP_START = [None]  # event on the launch stream at the start of the current train step (begin_step)
+_STEP_ROWS = [0]      # batch rows of the recurrent layer that is being built (the prepared workspaces are laid out for it)
+
+
+def _prepare_sweeps(st):
+    """Round 5: the weight packs and exchange-state clears of ALL the recurrent sweeps of a training step -- forward and BPTT of every layer
+    seen in the previous step -- in ONE launch (las_rnn_seq_prepare), at the first request after the weights changed.  Until round 4 every
+    sweep launched its own pack kernel in front of itself: 8 launches of 8-11 us on the dependency chain per step."""
+    if not (PREPARED_SWEEPS and st.seq_recipes and _STEP_ROWS[0] > 0):
+        return
+    B = _STEP_ROWS[0]
+    jobs = []
+    for key, r in st.seq_recipes.items():
+        need = int(_hip.lib().las_rnn_seq_workspace_bytes(r["cell"], _hip.PREC_BF16, r["H"], B))
+        if r["ws"] is None or r["ws"].numel() < need:
+            r["ws"] = torch.empty(need, dtype=torch.uint8, device=r["wf"].device)      # (lives as long as the recipe: never recycled by the allocator)
+        jobs.append((r["cell"], r["H"], B, key[-1], r["wf"], r["wb"], r["ldw"], r["off"], r["off"], r["ws"]))
+    # on the side stream, ordered behind the START of the step (= behind the optimiser step that changed the weights), beside the step's
+    # head on the launch stream: ~65 MB of packs and clears that nothing on the chain waits for until the first sweep
+    ev = _STEP_START[0]
+    _STEP_START[0] = None
+    if ev is not None and _hip.streams_overlap(jobs[0][4].device):
+        with _hip.on_side_stream(after=ev):
+            _hip.rnn_seq_prepare(jobs)
+            st.seq_prep_done = torch.cuda.Event()
+            st.seq_prep_done.record()
+    else:
+        _hip.rnn_seq_prepare(jobs)
+        st.seq_prep_done = None
+    for key in st.seq_recipes:
+        st.seq_ready[key] = B
+
+
+def _prepared_ws(kfw, kbw, cell, H, GH, off, B, bwd):
+    """The workspace las_rnn_seq_prepare has made ready for this sweep (None: the sweep packs for itself); registers the sweep so
+    that the NEXT step prepares it.  Training steps only (gradient mode, rows of one length)."""
+    if not PREPARED_SWEEPS or ROW_T[0] is not None:
+        return None
+    st = V.default_store()
+    key = (int(kfw.data_ptr()), int(kbw.data_ptr()), cell, int(H), int(bool(bwd)))
+    r = st.seq_recipes.get(key)
+    if r is None:
+        st.seq_recipes[key] = {"cell": _cellid(cell), "H": int(H), "wf": kfw, "wb": kbw, "ldw": int(GH), "off": int(off), "ws": None}
+        return None
+    have = st.seq_ready.pop(key, 0)          # consumed: the exchange state is dirty after one sweep
+    if have >= B and r["ws"] is not None:
+        VARIANTS["prepared_sweeps"] += 1
+        if getattr(st, "seq_prep_done", None) is not None:          # the step's first prepared sweep orders the launch stream behind the prepare
+            torch.cuda.current_stream().wait_event(st.seq_prep_done)
+            st.seq_prep_done = None
+        return r["ws"]
+    return None
 
 
 _CHUNK_FLAGS = {}
@@ -382,7 +438,8 @@ def _flag_ring(dev):
 # resident; "serial": hand-overs that ran with their producers in front of the consumer on one stream (LAS_ALLOW_SERIAL_STREAMS=1 under a
 # tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
 # that is timed must be the variant that is tested.
-VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0}
+VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0,
+            "prepared_sweeps": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
 
 
 def begin_step(dev):
@@ -395,6 +452,8 @@ def begin_step(dev):
     ring = _flag_ring(dev)
     ring[0].zero_()
     ring[1], ring[2] = 0, _RING
+    _STEP_START[0] = torch.cuda.Event()
+    _STEP_START[0].record()
 
 
 def _k64(k):
@@ -570,6 +629,9 @@ class _BLSTM16(torch.autograd.Function):
         bf = torch.bfloat16
         gates = torch.empty(B, T, 2, GH, device=dev, dtype=bf)
         rest_chunks = None
+        training = any(ctx.needs_input_grad) and ROW_T[0] is None      # (grad mode itself is off inside an autograd node's forward)
+        if training:
+            _STEP_ROWS[0] = B                        # (the first shadow request after an optimiser step prepares every sweep of the step for B rows)
         if not two:
             # both directions in ONE product over the concatenated weights: B operand = shadow of [W_ih_fw | W_ih_bw]^T
             WT = _shadow("ihT", (kfw, kbw), I0, True, 2 * GH, _k64(I0))                     # [W_ih_fw | W_ih_bw]^T: [2GH, Ik]
@@ -638,7 +700,7 @@ class _BLSTM16(torch.autograd.Function):
         VARIANTS["xproj_chunks"] += int(not two and chunk_flag is not None)
         _hip.rnn_seq_fwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          1.0, wf_off=I0 * GH, wb_off=I0 * GH, chunk_flag=None if two else chunk_flag, chunk_steps=0 if two else cs,
-                         row_T=row_T)
+                         row_T=row_T, prepared_ws=_prepared_ws(kfw, kbw, cell, H, GH, I0 * GH, B, False) if training else None)
         if rest_chunks is not None:
             # chunks 1 .. of the x-projection: side stream, enqueued behind the sweep's launch (with the pad frame's fill, off the chain)
             rest_chunks(out[:, T:] if Tp != T else None)
@@ -689,7 +751,7 @@ class _BLSTM16(torch.autograd.Function):
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
                          db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None,
                          chunk_flag=None if dc is None else dc[0], chunk_rows=0 if dc is None else dc[1],
-                         n_rows=0 if dc is None else dc[2])
+                         n_rows=0 if dc is None else dc[2], prepared_ws=_prepared_ws(kfw, kbw, cell, H, GH, I0 * GH, B, True))
         if dc is not None and not serial:
             dc[3]()                          # the other chunks: chain stream, enqueued behind the sweep's launch
             _hip.join_chain_stream()         # (they are finished when the sweep is; this orders later readers of dout)

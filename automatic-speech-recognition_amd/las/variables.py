@@ -30,6 +30,17 @@ class VariableStore:
         self.shadows = {}         # bf16 copies of weights for the speed-mode products (las.layers._shadow); cleared when weights change
         self.shadow_recipes = {}  # key -> (tensor, ShadowDesc): how to rebuild every shadow in ONE launch (cleared when storage moves)
         self.shadow_table = None
+        self.seq_recipes = {}     # (W_hh pointers, cell, H, pass) -> how to prepare that sweep's workspace (las.layers._prepare_sweeps)
+        self.seq_ready = {}       # ... -> batch rows it has been prepared for since the weights last changed (consumed by ONE sweep)
+
+    def weights_changed(self, storage_moved=False):
+        """Everything derived from the parameter VALUES is stale (optimiser step, load); storage_moved: their addresses too (flatten)."""
+        self.shadows.clear()
+        self.seq_ready.clear()
+        if storage_moved:
+            self.shadow_recipes.clear()
+            self.shadow_table = None
+            self.seq_recipes.clear()
 
     # ---- creation ----------------------------------------------------------------------------
     def get(self, name, shape=None, init="glorot", fan=None):
@@ -73,9 +84,7 @@ class VariableStore:
 
     def load(self, params):
         """Install externally supplied values {name: array} (parity tests, checkpoints)."""
-        self.shadows.clear()
-        self.shadow_recipes.clear()
-        self.shadow_table = None
+        self.weights_changed(storage_moved=True)
         for name, val in params.items():
             val = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val,
                                   dtype=torch.float32, device=self.device)
@@ -97,9 +106,7 @@ class VariableStore:
     def flatten(self):
         if self.flat is not None:
             return
-        self.shadows.clear()
-        self.shadow_recipes.clear()
-        self.shadow_table = None
+        self.weights_changed(storage_moved=True)
         names = list(self.order)
         sizes = [self.vars[n].numel() for n in names]
         offs, o = [], 0

@@ -37,7 +37,7 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
-#define LAS_HIP_ABI_VERSION 404      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+#define LAS_HIP_ABI_VERSION 500      /* bumped whenever an argument struct or a signature changes: las_version() of a library
                                         built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
@@ -152,12 +152,15 @@ int las_tanh_bwd_dt(const void* Y, int y_dt, int ldy, const void* dY, int dy_dt,
  *                            instead of the clustered exact-fp32 MFMA kernels (csrc/rnn_seq_f32.hip) -- tests cross-check the two
  *   LAS_SEQ_P(p)             cluster width override (1, 2, 4, 8 workgroups per (direction, 16-row tile))
  *   LAS_SEQ_SPIN_LOG2(n)     bound of every exchange spin = 2^n polls (default 2^22)
+ *   LAS_SEQ_PREPARED         NOT a development switch: `ws` was prepared by las_rnn_seq_prepare (below) for these weights, this cell / H /
+ *                            direction of the pass / flags and a batch >= B, and no sweep has used it since -- the launch then skips its own
+ *                            weight pack + exchange-state clear (one launch less on the dependency chain per sweep)
  * `status` (may be NULL): caller-owned, caller-zeroed int32 DEVICE word.  The clustered bf16 sweeps exchange h / dh
  *   between workgroups with bounded spins; if a partner does not publish within the bound (it is not co-resident:
  *   shared or partitioned device) the launch finishes with undefined results and stores LAS_SEQ_STATUS_* here.
  *   The word is sticky (never cleared by the library); the caller reads it at its next synchronisation point. */
 enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVES = 4, LAS_SEQ_ROWS16 = 8, LAS_SEQ_NO_WARMERS = 16,
-       LAS_SEQ_F32_VALU = 32 };
+       LAS_SEQ_F32_VALU = 32, LAS_SEQ_PREPARED = 64 };
 #define LAS_SEQ_P(p) (((p) & 0xf) << 8)
 #define LAS_SEQ_SPIN_LOG2(n) (((n) & 0x1f) << 16)
 /* LAS_SEQ_ANNOUNCE(n), n in 1..1023 (las_rnn_seq_bwd*, clustered kernels): `status` then points to TWO ints and the launch
@@ -166,6 +169,20 @@ enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVE
 enum { LAS_SEQ_STATUS_OK = 0, LAS_SEQ_STATUS_FWD_TIMEOUT = 1, LAS_SEQ_STATUS_BWD_TIMEOUT = 2 };
 
 size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
+/* Everything a speed-mode sweep does in front of its persistent kernel depends on the weights only: W_hh of both directions re-packed into
+ * MFMA fragment order (forward, BPTT and K-split BPTT layouts differ) and the cleared exchange state of the workspace.  The reference
+ * rebuilds nothing per layer call either (its weights are graph variables, las/layers.py:28-54).  las_rnn_seq_prepare does that work for n
+ * (layer, pass) pairs in ONE launch -- once per optimiser step, off the dependency chain -- each into a workspace of its own
+ * (las_rnn_seq_workspace_bytes(cell, LAS_PREC_BF16, H, B)); the sweep that then gets such a workspace together with LAS_SEQ_PREPARED in
+ * `flags` launches nothing but its persistent kernel.  A prepared workspace serves ONE sweep (the exchange state is dirty afterwards) with
+ * the same cell / H / flags / direction of the pass (bwd = 0: las_rnn_seq_fwd*, 1: las_rnn_seq_bwd*) and any batch B' <= B.
+ * whh_fw / whh_bw: as for las_rnn_seq_fwd.  Only LAS_PREC_BF16 shapes (H in {64,128,256,512}).  `descs` is HOST memory. */
+typedef struct las_seq_prepare_desc {
+    const float* whh_fw; const float* whh_bw; int ldw;
+    int cell, H, B, bwd, flags;
+    void* ws; size_t ws_bytes;
+} las_seq_prepare_desc;
+int las_rnn_seq_prepare(const las_seq_prepare_desc* descs, int n, void* stream);
 /* Element type of gates / out / cstate / dout for (cell, prec, H): LAS_DT_BF16 when the speed-mode MFMA sweeps serve the
  * shape (prec = LAS_PREC_BF16 and H in {64,128,256,512}), else LAS_DT_F32 (parity mode, or a speed-mode shape that falls
  * back to the fp32 VALU sweep).  The caller allocates those tensors -- and makes the K1 product write them -- accordingly. */

@@ -220,7 +220,8 @@ def oracle_decode(xs, p0, args, cell, beam, lm=None, lm_weight=0.0, prec="f32", 
         O.set_precision("f32")
 
 
-def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist=True):
+def _oracle_fns(xs, p0, args, cell, lm, hoist=True):
+    """(step_fn, lm_fn, lm_init, dec_init, T', dec_steps) of one utterance for oracle.beam_search / oracle_score_tokens"""
     import torch
     from oracle import las_oracle as O
     NL = args.num_dec_layers
@@ -231,7 +232,8 @@ def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist=True):
         keys = O.project_keys(h, po)                  # (f32 mode: h @ Wh)
         emb = po["embedding/embedding_matrix"]
 
-        def step_fn(prev_ids, prev_al, states):
+    def step_fn(prev_ids, prev_al, states):
+        with torch.no_grad():
             N = len(prev_ids)
             stt = []
             for l in range(NL):
@@ -245,16 +247,47 @@ def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist=True):
             outs = [tuple((ns[l][0][i:i + 1], ns[l][1][i:i + 1]) if cell == "lstm" else ns[l][i:i + 1] for l in range(NL))
                     for i in range(N)]
             return lg.numpy(), outs, al.numpy()
-        lm_fn, lm0 = None, None
-        if lm is not None:
-            olm, Hl, NLl = lm
+    lm_fn, lm0 = None, None
+    if lm is not None:
+        olm, Hl, NLl = lm
 
-            def lm_fn(ids, states):
+        def lm_fn(ids, states):
+            with torch.no_grad():
                 stt = [(torch.stack([s[l][0] for s in states]), torch.stack([s[l][1] for s in states])) for l in range(NLl)]
                 lo, ns = O.lm_step(torch.tensor(ids), stt, olm)
                 return lo.numpy(), [tuple((ns[l][0][i], ns[l][1][i]) for l in range(NLl)) for i in range(len(ids))]
-            lm0 = tuple((torch.zeros(Hl), torch.zeros(Hl)) for _ in range(NLl))
-        z = torch.zeros(1, args.dec_units)
-        init = tuple((z, z) if cell == "lstm" else z for _ in range(NL))
-        return O.beam_search(step_fn, init, h.shape[1], int(xs[1][0] * args.convert_rate), beam, 1, 2,
-                             lm_fn=lm_fn, lm_init=lm0, lm_weight=lm_weight)
+        lm0 = tuple((torch.zeros(Hl), torch.zeros(Hl)) for _ in range(NLl))
+    z = torch.zeros(1, args.dec_units)
+    init = tuple((z, z) if cell == "lstm" else z for _ in range(NL))
+    return step_fn, lm_fn, lm0, init, h.shape[1], int(xs[1][0] * args.convert_rate)
+
+
+def _oracle_decode(xs, p0, args, cell, beam, lm, lm_weight, hoist=True):
+    from oracle import las_oracle as O
+    step_fn, lm_fn, lm0, init, Tp, dec_step = _oracle_fns(xs, p0, args, cell, lm, hoist)
+    return O.beam_search(step_fn, init, Tp, dec_step, beam, 1, 2, lm_fn=lm_fn, lm_init=lm0, lm_weight=lm_weight)
+
+
+def oracle_score_tokens(xs, p0, args, cell, token_ids, lm=None, lm_weight=0.0, prec="f32"):
+    """The score the oracle's search gives a GIVEN hypothesis (token_ids incl. the leading SOS): the same per-step quantities
+    oracle.beam_search accumulates (raw Speller logit of the chosen token + lm_weight x LM logit, las/beam_search.py:94-135 restated there),
+    teacher-forced along the hypothesis.  -> (score, [alignment of every step]).  Lets a test check the ARITHMETIC of a long search whose
+    final ranking is a near tie (so that the token sequences of two correct searches need not agree)."""
+    from oracle import las_oracle as O
+    O.set_precision(*oracle_mode_for(args, prec))
+    try:
+        step_fn, lm_fn, lm_state, state, Tp, _ = _oracle_fns(xs, p0, args, cell, lm, True)
+        score, al, atts = np.float32(0.0), np.zeros(Tp, np.float32), []
+        for prev, tok in zip(token_ids[:-1], token_ids[1:]):
+            logits, states, alphas = step_fn([prev], [al], [state])
+            lg = np.array(logits[0], dtype=np.float32, copy=True)
+            if lm_fn is not None:
+                lo, lms = lm_fn([max(prev - 2, 0)], [lm_state])
+                lg[2:] += np.asarray(lo[0], np.float32) * np.float32(lm_weight)
+                lm_state = lms[0]
+            score = np.float32(score + lg[tok])
+            state, al = states[0], alphas[0]
+            atts.append(al)
+        return float(score), atts
+    finally:
+        O.set_precision("f32")

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 NUTT, BEAM, T = 8, 16, 300
 
 
-def _setup(prec, seed=17):
+def _setup(prec, seed=17, eos_bias=0.4):
     from las import layers as L, variables as V
     from las.las import LAS, Listener, Speller
     from las.beam_search import BeamSearch
@@ -28,7 +28,7 @@ def _setup(prec, seed=17):
     args = make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128,
                      mode="add", beam_size=BEAM, convert_rate=0.166, apply_lm=True, lm_weight=0.5)
     p0 = O.init_params(args, seed=seed, cell="lstm")
-    p0["Speller/decode/dense/bias"][2] = 0.4          # some hypotheses end before the step bound, some do not
+    p0["Speller/decode/dense/bias"][2] = eos_bias     # 0.4: some hypotheses end before the step bound, some do not
     plm = lm_params(np.random.RandomState(8), 28, 0, 512, 2)
     for k in plm:
         plm[k] = (plm[k] * 0.3).astype(np.float32)
@@ -143,10 +143,18 @@ def test_forty_utterances_in_one_batch_equal_the_same_utterances_in_groups_of_ei
 def test_bf16_sixty_four_utterances_at_T_1274_match_the_bf16_oracle():
     """The geometry bench.py's decode `value` is quoted on since round 4: 64 utterances x beam 16 = 1024 hypothesis
     rows per step, T = 1274 frames (T' = 160), 2 x 512 LM fused in, one captured step replayed -- `lstm_cell_rows` at M = 1024, the
-    attention rows at 1024 rows x 160 frames, the beam kernel over 64 utterances.  Three of the 64 utterances (first, one in the middle,
-    last: different row blocks of every launch) against the oracle's beam search in its bf16 mode with the hoisted key projection, and the
-    same three decoded in a batch of their own (the rows of a search never interact: bit-identical)."""
-    args, p0, plm, bs, _ = _setup("bf16")
+    attention rows at 1024 rows x 160 frames, the beam kernel over 64 utterances -- and, as in the bench, no hypothesis ends before the
+    step bound: all 211 steps of the search run.  Three of the 64 utterances (first, one in the middle, last: different row blocks of every
+    launch) against the oracle in its bf16 mode with the hoisted key projection, and the same three decoded in a batch of their own (the
+    rows of a search never interact: bit-identical).
+
+    With random weights the 16 final hypotheses of an utterance are 211-token sequences whose normalised scores lie within 1e-3 of each
+    other (oracle: 0.3082 ... 0.3093), i.e. every one of the 211 prunings is a near tie and two correct searches need not keep the same
+    sequences.  What is asserted therefore: (a) ARITHMETIC -- the score the search accumulated for its best hypothesis equals the oracle's
+    teacher-forced score of the SAME 211 tokens (Speller logit + 0.5 x LM logit per step) to 1e-3 per token, and the last step's alignment
+    to 2e-3; (b) SEARCH QUALITY -- the best normalised score is within 5e-3 of the best the oracle's own beam search finds."""
+    from helpers import oracle_score_tokens
+    args, p0, plm, bs, _ = _setup("bf16", eos_bias=0.0)
     n, Tf = 64, 1274
     utts = [synthetic_batch(1, Tf, 8, 30, seed=100 + k)[0] for k in range(n)]        # bench.py decode_bench's utterances
     got = bs.decode_batch(None, utts)
@@ -154,25 +162,21 @@ def test_bf16_sixty_four_utterances_at_T_1274_match_the_bf16_oracle():
     pick = (0, 37, 63)
     alone = bs.decode_batch(None, [utts[u] for u in pick])
     olm = (oracle_lm(plm, 0, 2), 512, 2)
-    same, worst = 0, 0.0
+    worst_tf, worst_best = 0.0, 0.0
     for u, small in zip(pick, alone):
         res = got[u]
         assert [b.token_ids for b in res] == [b.token_ids for b in small], u
         assert [float(b.log_prob) for b in res] == [float(b.log_prob) for b in small], u
-        assert res[-1].att[-1].shape[-1] == 160
+        best = res[-1]
+        L_ = len(best.token_ids) - 1
+        assert L_ == int(Tf * args.convert_rate) == 211 and best.att[-1].shape[-1] == 160          # the bench's search length and T'
+        sc, atts = oracle_score_tokens(utts[u], p0, args, "lstm", best.token_ids, lm=olm, lm_weight=0.5, prec="bf16")
+        worst_tf = max(worst_tf, abs(float(best.log_prob) - sc) / L_)
+        assert abs(float(best.log_prob) - sc) <= 1e-3 * L_, (u, float(best.log_prob), sc)
+        assert np.abs(best.att[-1].cpu().numpy() - atts[-1]).max() < 2e-3
+        assert np.abs(best.att[L_ // 2].cpu().numpy() - atts[L_ // 2 - 1]).max() < 2e-3            # att[0] is the all-zero item
         ref = oracle_decode(utts[u], p0, args, "lstm", BEAM, lm=olm, lm_weight=0.5, prec="bf16", hoist=True)
-        best, rbest = res[-1], ref[-1]
-        assert len(best.token_ids) - 1 > 100                                        # a search of the bench's length, not an early stop
-        d = abs(_norm(best) - _norm(rbest))
-        worst = max(worst, d)
-        assert d <= 5e-3, (u, _norm(best), _norm(rbest))
-        if best.token_ids == rbest.token_ids:
-            same += 1
-            assert np.abs(best.att[-1].cpu().numpy() - rbest.att[-1]).max() < 2e-3
-        else:                                                                       # acceptable only as a near tie in the oracle
-            ids = [b.token_ids for b in ref]
-            assert best.token_ids in ids, (u, "best hypothesis is not among the oracle's final beam")
-            assert abs(_norm(ref[ids.index(best.token_ids)]) - _norm(rbest)) <= 5e-3, u
-    print("bf16 decode at the `value` geometry (64 utterances x beam 16, T = 1274): best hypothesis identical for %d / %d checked, worst "
-          "normalised-score gap %.2e" % (same, len(pick), worst))
-    assert same >= len(pick) - 1
+        worst_best = max(worst_best, abs(_norm(best) - _norm(ref[-1])))
+        assert abs(_norm(best) - _norm(ref[-1])) <= 5e-3, (u, _norm(best), _norm(ref[-1]))
+    print("bf16 decode at the `value` geometry (64 utterances x beam 16, T = 1274, 211 steps): accumulated score vs the oracle's score of the "
+          "same tokens %.2e per token (worst of %d utterances), best normalised score vs the oracle's search %.2e" % (worst_tf, len(pick), worst_best))

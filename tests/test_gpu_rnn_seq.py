@@ -388,6 +388,47 @@ def test_chunked_upstream_gradient_is_waited_for(pairs):
         _hip.check_status()
 
 
+@pytest.mark.parametrize("cell,H,B,Bprep", [(1, 256, 48, 48), (1, 256, 20, 48), (1, 128, 9, 16), (0, 256, 24, 24), (1, 512, 16, 16)])
+def test_prepared_workspace_sweeps_equal_self_packing_sweeps(cell, H, B, Bprep):
+    """las_rnn_seq_prepare (round 5): weight packs + exchange-state clears of several sweeps in one launch; a sweep that gets such a
+    workspace with LAS_SEQ_PREPARED launches only its persistent kernel.  Forward and BPTT through prepared workspaces (prepared for a
+    batch >= the one swept, both passes' jobs in ONE prepare call) must equal the self-packing launches bit for bit -- and a workspace
+    used twice without a new prepare must NOT be relied on (the host layer consumes it once): here only the documented use is checked."""
+    from las import _hip
+    T = 77
+    G = 4 if cell == 1 else 1
+    GH = G * H
+    g = torch.Generator().manual_seed(100 + H + B)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).cuda().to(torch.bfloat16)
+    w = [((torch.rand(H + 8, GH, generator=g) * 2 - 1) * 0.06).cuda() for _ in range(2)]        # W_hh = rows 8.. of a larger kernel (an offset, as in the layers)
+    off = 8 * GH
+    dfull = (torch.randn(B, T, 2 * H, generator=g) * 0.1).cuda().to(torch.bfloat16)
+
+    def run(ws_f=None, ws_b=None):
+        act = xp.clone()
+        out = torch.zeros(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+        cst = torch.zeros(B, T, 2, H, device="cuda", dtype=torch.bfloat16) if cell == 1 else None
+        _hip.rnn_seq_fwd(cell, 1, B, T, H, act, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst, wf_off=off, wb_off=off, prepared_ws=ws_f)
+        gz = act.clone()
+        db = [torch.zeros(GH, device="cuda") for _ in range(2)]
+        _hip.rnn_seq_bwd(cell, 1, B, T, H, gz, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst, dfull, 2 * H, T * 2 * H,
+                         wf_off=off, wb_off=off, db_fw=db[0], db_bw=db[1], prepared_ws=ws_b)
+        torch.cuda.synchronize()
+        _hip.check_status()
+        return act, out, cst, gz, db
+
+    ref = run()
+    nb = int(_hip.lib().las_rnn_seq_workspace_bytes(cell, 1, H, Bprep))
+    ws = [torch.full((nb,), 0x5a, dtype=torch.uint8, device="cuda") for _ in range(2)]                 # poison: the prepare must clear what matters
+    for rep in range(2):                                                                                 # (second round: a DIRTY workspace is prepared again)
+        _hip.rnn_seq_prepare([(cell, H, Bprep, False, w[0], w[1], GH, off, off, ws[0]), (cell, H, Bprep, True, w[0], w[1], GH, off, off, ws[1])])
+        got = run(ws[0], ws[1])
+        for a, b in zip(ref[:4], got[:4]):
+            assert (a is None and b is None) or torch.equal(a, b)
+        for a, b in zip(ref[4], got[4]):
+            assert torch.equal(a, b)
+
+
 def test_wait_announce_passes_for_numbers_that_have_come_and_gone():
     """las_wait_announce: the hold of side-stream work on a sweep's announcement passes at once when that sweep -- or a later one -- has
     announced itself (cyclic numbers 1..1023), and sits out its bound otherwise (las_wait_word waits for equality only)."""

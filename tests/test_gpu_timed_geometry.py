@@ -81,12 +81,15 @@ def test_b48_rows_equal_twelve_b4_batches():
     assert gerr <= 2e-3, gerr
 
 
-def _three_steps(args, p0, xs, ys, handovers=True):
+def _three_steps(args, p0, xs, ys, handovers=True, prepared=True):
     las, st = _fresh(args, p0)
     out = []
-    for _ in range(3):
+    for i in range(3):
         loss = las.train(xs, ys)[0]
         expect_handovers(las, "lstm", B, on=handovers)
+        # round 5: from a model's second step on, every sweep (4 forward + 4 BPTT) finds its weight pack and a clean exchange state
+        # prepared by ONE launch at the start of the step (las_rnn_seq_prepare) -- no pack launch on the chain
+        assert las.last_variants["prepared_sweeps"] == (8 if (prepared and i > 0) else 0), (i, las.last_variants)
         if not out:
             torch.cuda.synchronize()
             g0 = st.flat_grad.clone()
@@ -113,6 +116,14 @@ def test_three_b48_steps_are_bit_reproducible_and_independent_of_the_hand_overs(
         f3, g3, l3 = _three_steps(args, p0, xs, ys, handovers=False)      # (asserts that nothing was handed over)
     finally:
         L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = saved
+    # ... and with every sweep packing for itself (rounds 1-4's launches): the prepared workspaces must change nothing, bit for bit
+    saved_p = L.PREPARED_SWEEPS
+    try:
+        L.PREPARED_SWEEPS = False
+        f4, g4, l4 = _three_steps(args, p0, xs, ys, prepared=False)
+    finally:
+        L.PREPARED_SWEEPS = saved_p
+    assert l1 == l4 and torch.equal(g1, g4) and torch.equal(f1, f4), "prepared sweep workspaces changed the result"
     gerr = (g1 - g3).abs().max().item() / g1.abs().max().item()
     print("hand-overs on vs off: first-step gradient %.2e of max |g| (bitwise equal: %s), losses %s vs %s"
           % (gerr, torch.equal(g1, g3), l1, l3))
