@@ -252,14 +252,52 @@ struct BeamLoopDev {
     const float* file_in; float* file_out; long long file_n;   // optional per-step record: file_out[t][0..file_n) = file_in[0..file_n) (workgroups >= nutt)
     // optional vocabulary projection inside the kernel: logits[r] = proj_b + bf16([h0[r] ; h1[r]]) . proj_w (fragments of a [k0 + k1, V] matrix)
     const float *proj_h0, *proj_h1; int proj_k0, proj_k1; const u16x8_t* proj_w; const float* proj_b;
+    // fold_gather (round 5): the state gather of the surviving parents inside this launch
+    int gather, ntens; const float* g_in[16]; float* g_out[16]; int g_width[16];
 };
-constexpr int BEAM_PROJ_TILES = 8;      // (row tiles of 16 hypotheses) x (column tiles of 16 tokens) the in-kernel projection handles
+constexpr int BEAM_PROJ_TILES = 8;
+
+// The last workgroup to finish advances the device step counter: every workgroup has read step[0] (at its start) by then, and nothing else
+// of this launch reads it afterwards.  step[1] counts the arrivals and is reset for the next launch.
+__device__ __forceinline__ void beam_finish(const BeamLoopDev& a) {
+    if (!a.gather) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int n = atomicAdd(a.step + 1, 1);
+        if (n == (int)gridDim.x - 1) { a.step[1] = 0; __threadfence(); a.step[0] += 1; }
+    }
+}
+// state rows of utterance u follow their hypotheses: out[k][u * beam + j] = in[k][src_row[u * beam + j]] (all sources are rows of the
+// SAME utterance, read from `in`, written to `out`: no hazard inside the launch)
+__device__ __forceinline__ void beam_gather_rows(const BeamLoopDev& a, const int u, const int* srcs) {
+    const int tid = threadIdx.x, beam = a.beam;
+    for (int k = 0; k < a.ntens; ++k) {
+        const int w = a.g_width[k];
+        const float* ip = a.g_in[k];
+        float* op = a.g_out[k];
+        if (((w & 3) | ((size_t)ip & 15) | ((size_t)op & 15)) == 0) {
+            const int w4 = w >> 2;
+            for (int i = tid; i < beam * w4; i += 256) {
+                const int j = i / w4, c = i - j * w4;
+                const int src = srcs[j];
+                reinterpret_cast<float4*>(op + ((size_t)u * beam + j) * w)[c] = reinterpret_cast<const float4*>(ip + (size_t)src * w)[c];
+            }
+        } else {
+            for (int i = tid; i < beam * w; i += 256) {
+                const int j = i / w, c = i - j * w;
+                op[((size_t)u * beam + j) * w + c] = ip[(size_t)srcs[j] * w + c];
+            }
+        }
+    }
+}      // (row tiles of 16 hypotheses) x (column tiles of 16 tokens) the in-kernel projection handles
 
 __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
+    __shared__ int srcs[64];                                // fold_gather: the rows the utterance's new live slots continue (beam <= 64)
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
     const int t = a.step[0];
-    if (t >= a.Umax) return;
+    if (t >= a.Umax) { beam_finish(a); return; }
     if (u >= a.nutt) {                                    // filing workgroups: this step's row tensor (the alignments) under the DEVICE step counter
         const int nf = (int)gridDim.x - a.nutt;
         float* dst = a.file_out + (size_t)t * a.file_n;
@@ -270,12 +308,15 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         } else {
             for (long long i = (long long)(u - a.nutt) * 256 + tid; i < a.file_n; i += (long long)nf * 256) dst[i] = a.file_in[i];
         }
+        beam_finish(a);
         return;
     }
     int* hn = a.hist_n + (size_t)t * a.nutt + u;
     if (a.done[u] || t >= a.dec_step[u]) {               // retired utterance: nothing to do (its rows compute ignored garbage)
         if (tid == 0) { *hn = 0; a.done[u] = 1; a.nlive[u] = 0; }
-        for (int k = tid; k < beam; k += 256) { a.src_row[(size_t)u * beam + k] = u * beam; }
+        for (int k = tid; k < beam; k += 256) { a.src_row[(size_t)u * beam + k] = u * beam; srcs[k] = u * beam; }
+        if (a.gather) { __syncthreads(); beam_gather_rows(a, u, srcs); }      // (rows of a retired utterance: ignored garbage, but finite)
+        beam_finish(a);
         return;
     }
     int nb = a.nlive[u];
@@ -353,7 +394,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         lg = lgs;
     }
     const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, L);
-    if (tid >= 64) return;
+    if (tid < 64) {
     // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
     // first wave is pick j (beam <= 64); the positions of the retired / surviving picks in their lists are prefix counts of ballots
     const int j = tid;
@@ -375,10 +416,11 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     if (live) {
         a.hist_slot[hb + lidx] = j;                               // live slot lidx of step t+1 is pick j of step t
         a.src_row[(size_t)u * beam + lidx] = u * beam + k.i;
+        srcs[lidx] = u * beam + k.i;
         a.next_token[(size_t)u * beam + lidx] = v;
         sc[lidx] = news; ln[lidx] = newl;
     }
-    if (j >= nl && j < beam) { a.src_row[(size_t)u * beam + j] = u * beam; a.next_token[(size_t)u * beam + j] = a.start_id; }
+    if (j >= nl && j < beam) { a.src_row[(size_t)u * beam + j] = u * beam; srcs[j] = u * beam; a.next_token[(size_t)u * beam + j] = a.start_id; }
     const bool exhausted = (t + 1 == a.dec_step[u]);
     if (exhausted) {                                               // `if t == dec_step: selected.extend(beam_set)` (:155-156)
         if (live && ns + lidx < a.selcap) { a.sel_t[(size_t)u * a.selcap + ns + lidx] = t; a.sel_j[(size_t)u * a.selcap + ns + lidx] = j; }
@@ -390,6 +432,12 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         a.nsel[u] = ns;
         a.nlive[u] = fin ? 0 : nl;
         if (fin) a.done[u] = 1;
+    }
+    }
+    if (a.gather) {
+        __syncthreads();                                               // wave 0's src_row stores (workgroup scope) before the other waves read them
+        beam_gather_rows(a, u, srcs);
+        beam_finish(a);
     }
 }
 
@@ -439,8 +487,15 @@ extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
         nfile = (int)((a.file_n + 4095) / 4096);
         if (nfile > 64) nfile = 64;
     }
+    a.gather = (p->fold_gather && p->ntens > 0) ? 1 : 0;
+    a.ntens = a.gather ? p->ntens : 0;
+    for (int k = 0; k < a.ntens; ++k) {
+        LAS_ARG(p->state_in[k] && p->state_out[k] && p->state_width[k] > 0, "las_beam_loop_step: bad state tensor %d", k);
+        a.g_in[k] = p->state_in[k]; a.g_out[k] = p->state_out[k]; a.g_width[k] = p->state_width[k];
+    }
     hipLaunchKernelGGL(beam_loop_kernel, dim3(p->nutt + nfile), dim3(256), 0, st, a);
     LAS_LAUNCHED();
+    if (a.gather) return 0;                                            // gathered and counted inside the launch
     if (p->ntens > 0) {
         GatherDev g;
         g.ntens = p->ntens; g.src_row = p->src_row; g.step = p->step; g.nrows = p->nutt * p->beam;

@@ -179,5 +179,6 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A);
 // gates_out (optional [M, 4H]): the ACTIVATED gates, as the Speller's backward pass reads them.
 typedef las_lstm_cell_args LstmCellLaunch;            // (the public struct of include/las_hip.h)
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st);
+int las_lstm_cell_check(const LstmCellLaunch& a);
 // two independent cell steps as the two problems of ONE grid (a: fast + bf16 x = the Speller's; b: exact + fp32 / one-hot = the LM's)
 int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b, hipStream_t st);

@@ -240,172 +240,7 @@ extern "C" int las_lstm_pointwise_rows(const float* z, const float* xrows, const
 // TF gate order i, j, f, o = column blocks of H), K = I + H contracted in chunks staged through LDS as bf16, 8 waves = 4 gates x
 // 2 row tiles, gates exchanged through LDS, then c' / h' written directly.  A one-hot first layer passes ids / xrows instead of x.
 // ------------------------------------------------------------------------------------------------
-constexpr int LC_KC = 512, LC_LD = LC_KC + 8;      // K chunk staged per pass; LDS row stride in bf16 (16-byte reads of 16 rows hit 64 distinct banks)
-
-// FAST: the Speller's approximated transcendentals (its cell in a beam-search step, see las_common.h); XBF: x is already bf16
-// PIPE: the software pipeline over the K chunks (190-200 VGPRs: one workgroup per CU); without it 92 VGPRs, two workgroups per CU --
-// what the pair kernel wants: its two problems then run side by side on every CU and hide each other's round trips
-template <bool FAST, bool XBF, bool PIPE>
-__device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, unsigned short* As, float (&gates)[2][4][64][4], const int ub,
-                                                    const int row0) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
-    const int gt = w & 3, rt = w >> 2;
-    const int H = a.H, ct = gt * (H >> 4) + ub;                      // this wave's column tile of the [K, 4H] kernel
-    if (ub * 16 >= H || row0 >= a.M) return;                         // (the pair kernel's grid covers the larger of two problems)
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    if (!PIPE) {
-        for (int part = 0; part < 2; ++part) {
-            const void* src = part ? (const void*)a.h : a.x;
-            if (!src) continue;
-            const bool sbf = XBF && part == 0;
-            const int ld = part ? a.ldh : a.ldx, Kp = part ? H : a.I, KS = Kp >> 5;
-            const u16x8_t* bp = reinterpret_cast<const u16x8_t*>(part ? a.Wh : a.Wx) + (size_t)ct * KS * 64 + lane;
-            for (int k0 = 0; k0 < Kp; k0 += LC_KC) {
-                const int kc = min(LC_KC, Kp - k0), nks = kc >> 5;
-                u16x8_t bv[LC_KC / 32];                               // this chunk's weight fragments first (all in flight), then the rows
-#pragma unroll
-                for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bp[(size_t)min((k0 >> 5) + u, KS - 1) * 64];
-                __syncthreads();                                      // the previous chunk's readers are done
-                if (sbf) {
-                    for (int idx = tid; idx < 32 * (kc >> 3); idx += 512) {
-                        const int r = idx / (kc >> 3), q = idx - r * (kc >> 3);
-                        const int row = min(row0 + r, a.M - 1);
-                        *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
-                            *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
-                    }
-                } else {
-                    for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
-                        const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
-                        const int row = min(row0 + r, a.M - 1);
-                        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
-                        uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
-                        *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
-                    }
-                }
-                __syncthreads();
-                const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
-#pragma unroll
-                for (int u = 0; u < LC_KC / 32; ++u)
-                    if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
-            }
-        }
-    } else {
-        // K = [x ; h] in chunks of <= LC_KC that do not straddle the two parts.  Software pipeline: while chunk c is multiplied, the weight
-        // fragments and the rows of chunk c + 1 are already on their way (one round trip to L2 / HBM per chunk was ~1.5 us of a 3-chunk call)
-        const int KSx = a.x ? a.I >> 5 : 0, KSh = a.h ? H >> 5 : 0;
-        const int ncx = (KSx + 15) >> 4, nch = ncx + ((KSh + 15) >> 4);
-        u16x8_t bv[LC_KC / 32], bn[LC_KC / 32];
-        float4 ra[8];                                                     // fp32 rows: 32 x 512 floats / 512 threads; bf16 rows use ra[0..3] as uint4
-        auto chunk = [&](const int ci, const void*& src, int& ld, int& k0, int& kc, const u16x8_t*& bp, bool& sbf) {
-            const bool hp = ci >= ncx;
-            const int cj = hp ? ci - ncx : ci, Kp = hp ? H : a.I, KS = Kp >> 5;
-            src = hp ? (const void*)a.h : a.x; ld = hp ? a.ldh : a.ldx; k0 = cj * LC_KC; kc = min(LC_KC, Kp - k0);
-            bp = reinterpret_cast<const u16x8_t*>(hp ? a.Wh : a.Wx) + ((size_t)ct * KS + (k0 >> 5)) * 64 + lane;
-            sbf = XBF && !hp;
-        };
-        auto load_b = [&](const int ci, u16x8_t (&dst)[LC_KC / 32]) {
-            const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-            chunk(ci, src, ld, k0, kc, bp, sbf);
-            const int nks = kc >> 5;
-    #pragma unroll
-            for (int u = 0; u < LC_KC / 32; ++u) dst[u] = bp[(size_t)(u < nks ? u : nks - 1) * 64];
-        };
-        auto load_a = [&](const int ci) {
-            const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-            chunk(ci, src, ld, k0, kc, bp, sbf);
-            if (sbf) {
-                const int per = kc >> 3;
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
-                    const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
-                    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
-                    ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                }
-            } else {
-                const int per = kc >> 2;
-    #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
-                    const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
-                    ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
-                }
-            }
-        };
-        auto store_a = [&](const int ci) {
-            const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-            chunk(ci, src, ld, k0, kc, bp, sbf);
-            if (sbf) {
-                const int per = kc >> 3;
-    #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + j * 512;
-                    if (idx < 32 * per) {
-                        const int r = idx / per, q = idx - r * per;
-                        *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
-                            make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
-                    }
-                }
-            } else {
-                const int per = kc >> 2;
-    #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = tid + j * 512;
-                    if (idx < 32 * per) {
-                        const int r = idx / per, q = idx - r * per;
-                        uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
-                        *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
-                    }
-                }
-            }
-        };
-        load_b(0, bv);
-        load_a(0);
-        for (int ci = 0; ci < nch; ++ci) {
-            __syncthreads();                                              // the previous chunk's readers are done
-            store_a(ci);
-            if (ci + 1 < nch) { load_b(ci + 1, bn); load_a(ci + 1); }
-            __syncthreads();
-            const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-            chunk(ci, src, ld, k0, kc, bp, sbf);
-            const int nks = kc >> 5;
-            const unsigned short* ar = As + (rt * 16 + c) * LC_LD + g4 * 8;
-    #pragma unroll
-            for (int u = 0; u < LC_KC / 32; ++u)
-                if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
-            if (ci + 1 < nch) {
-    #pragma unroll
-                for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bn[u];
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) gates[rt][gt][lane][r] = acc[r];
-    __syncthreads();
-    // gate math: thread = (row of the block, unit of the block); MFMA C layout: element (row r16, col u) sits in lane (r16 / 4) * 16 + u, register r16 % 4
-    const int r = tid >> 4, u = tid & 15, row = row0 + r;
-    if (row >= a.M) return;
-    const int l2 = ((r & 15) >> 2) * 16 + u, reg = r & 3, unit = ub * 16 + u;
-    float z[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = gates[r >> 4][g][l2][reg] + a.bias[g * H + unit];
-    if (a.xrows) {
-        int id = a.ids[row] - a.id_shift;
-        if (id < 0) id = 0;
-        const float* xr = a.xrows + (size_t)id * 4 * H + unit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] += xr[g * H];
-    }
-    const float gi = sigm<FAST>(z[0]), gj = tanhx<FAST>(z[1]), gf = sigm<FAST>(z[2] + a.fb), go = sigm<FAST>(z[3]);
-    const size_t o = (size_t)row * H + unit;
-    const float cn = a.c_prev[o] * gf + gi * gj;
-    a.c_out[o] = cn;
-    a.h_out[o] = tanhx<FAST>(cn) * go;
-    if (a.gates_out) {                                   // the activated gates, as the Speller's backward pass reads them
-        float* gp = a.gates_out + (size_t)row * 4 * H + unit;
-        gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
-    }
-}
+#include "lstm_cell_rows.h"
 
 template <bool FAST, bool XBF>
 __global__ __launch_bounds__(512) void lstm_cell_rows_kernel(LstmCellLaunch a) {
@@ -421,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void lstm_cell_rows_pair_kernel(LstmCellLau
     else                 lstm_cell_rows_body<false, false, false>(b, As, gates, blockIdx.x, blockIdx.y * 32);
 }
 
-static int lstm_cell_check(const LstmCellLaunch& a) {
+int las_lstm_cell_check(const LstmCellLaunch& a) {
     LAS_ARG((a.x || a.h) && a.bias && a.c_prev && a.c_out && a.h_out && a.M > 0 && a.H > 0, "las_lstm_cell_rows: bad arguments");
     LAS_ARG(!(a.x && a.xrows), "las_lstm_cell_rows: x (dense input rows) and xrows (one-hot input) are exclusive");
     LAS_ARG(!a.x || (a.Wx && a.I > 0 && (a.I % 32) == 0 && (a.ldx % (a.x_bf16 ? 8 : 4)) == 0 && (((uintptr_t)a.x) & 15) == 0),
@@ -433,7 +268,7 @@ static int lstm_cell_check(const LstmCellLaunch& a) {
 }
 
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
-    if (int rc = lstm_cell_check(a)) return rc;
+    if (int rc = las_lstm_cell_check(a)) return rc;
     const dim3 grid(a.H / 16, cdiv(a.M, 32));
     if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_kernel<true, true>), grid, dim3(512), 0, st, a);
     else if (a.fast)        hipLaunchKernelGGL((lstm_cell_rows_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -444,8 +279,8 @@ int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
 }
 
 int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b, hipStream_t st) {
-    if (int rc = lstm_cell_check(a)) return rc;
-    if (int rc = lstm_cell_check(b)) return rc;
+    if (int rc = las_lstm_cell_check(a)) return rc;
+    if (int rc = las_lstm_cell_check(b)) return rc;
     if (!(a.fast && a.x_bf16 && !b.fast && !b.x_bf16)) {             // not the pair the kernel is compiled for: two launches
         if (int rc = las_lstm_cell_rows_launch(a, st)) return rc;
         return las_lstm_cell_rows_launch(b, st);

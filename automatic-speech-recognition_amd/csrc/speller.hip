@@ -13,6 +13,7 @@
 // the gate backward of step t) + one las_gemm (dG.W^T) per step; every weight gradient is a single
 // tall contraction after the loop (split-K, deterministic).  No atomics anywhere.
 #include "las_common.h"
+#include "lstm_cell_rows.h"
 #include <type_traits>
 #include <math.h>
 
@@ -1233,6 +1234,25 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float ccar = 0.f;
     pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, threadIdx.x, sm, ccar, false);
+}
+
+// Round 5, beam search (las/beam_search.py:94-158 is ONE loop): the attention rows of a search step and ANOTHER cell step that depends on
+// the step's tokens only -- the LM's first layer (las/beam_search.py:109-116) -- as one grid.  The first `nlm` workgroups run the LM cell
+// (32 rows x 16 units each, 512 of the 1024 threads; the others leave at once), the rest one attention row each.  The LM's second layer
+// then rides with the Speller's cell (las_speller_fwd_args.companion): a search step is three dependent launches instead of five.
+constexpr int PF_LM_LDS = 32 * LC_LD * 2 + 2 * 4 * 64 * 4 * 4;      // the cell workgroups' row tile + gate exchange
+template <int CELL, int NE>
+__global__ __launch_bounds__(RNT) void dec_step_fwd_pf_lm_kernel(DecDev a, int t, LstmCellLaunch lm, int nlm) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < nlm) {
+        if (threadIdx.x >= 512) return;
+        const int nu = lm.H >> 4;
+        float (&gates)[2][4][64][4] = *reinterpret_cast<float (*)[2][4][64][4]>(sm + 32 * LC_LD / 2);
+        lstm_cell_rows_body<false, false, false>(lm, reinterpret_cast<unsigned short*>(sm), gates, (int)blockIdx.x % nu, ((int)blockIdx.x / nu) * 32);
+        return;
+    }
+    float ccar = 0.f;
+    pf_fwd_row<CELL, NE, false>(a, t, (int)blockIdx.x - nlm, threadIdx.x, sm, ccar, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2994,7 +3014,19 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     for (int t = 0; t <= U && !loop; ++t) {
         // (t == U only finishes the last cell [+ logits]: the prefetching kernel would issue a whole step's bulk loads first --
         //  the generic bf16 row kernel loads on demand and returns after the cell; half of a beam-search step's Speller time)
-        if (pf && t == U)               hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        if (pf && t == 0 && f->companion_rows && (d.flags & LAS_SPELLER_NO_LOGITS)) {
+            // beam-search step: the LM's first layer as extra workgroups of the attention-row launch
+            const LstmCellLaunch& lm = *f->companion_rows;
+            if (int rc = las_lstm_cell_check(lm)) return rc;
+            LAS_ARG(!lm.fast && !lm.x_bf16, "las_speller_fwd: companion_rows must be an exact (fast = 0) cell with fp32 rows");
+            const int nlm = (lm.H / 16) * cdiv(lm.M, 32);
+            const size_t ldsc = lds_bf > (size_t)PF_LM_LDS ? lds_bf : (size_t)PF_LM_LDS;
+            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 8>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 10>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 12>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else                  hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 14>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+        }
+        else if (pf && t == U)          hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);

@@ -360,6 +360,21 @@ class CharRNN(object):
         a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c_out.data_ptr(), h_out.data_ptr(), None, N, H, 0
         return a
 
+    def cell_args(self, plan, layer, x, c_prev, h_prev, c_out, h_out):
+        """las_lstm_cell_args of layer >= 1 (dense fp32 input rows x = the layer below's new h) in speed mode, or None when step_fused
+        would not run it through las_lstm_cell_rows.  Fixed buffers, as for first_cell_args."""
+        P = self.params()
+        H, N = self.hidden_size, x.shape[0]
+        if not ("packs" in plan and N <= 1024 and H % 32 == 0 and layer >= 1 and plan["packs"][layer][1] is not None):
+            return None
+        a = _hip.LstmCellArgs()
+        a.x, a.x_bf16, a.ldx, a.I = x.data_ptr(), 0, H, H
+        a.ids, a.id_shift, a.xrows = None, 0, None
+        a.h, a.ldh, a.Wx, a.Wh = h_prev.data_ptr(), H, plan["packs"][layer][1].data_ptr(), plan["packs"][layer][0].data_ptr()
+        a.bias, a.c_prev, a.fb = P["cells"][layer][1].detach().data_ptr(), c_prev.data_ptr(), 0.0
+        a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c_out.data_ptr(), h_out.data_ptr(), None, N, H, 0
+        return a
+
     def project_fused(self, plan, h_top, logits, col0):
         """logits[:, col0:col0 + V_lm] += lm_weight * (h_top . softmax_w + softmax_b)   (the weights were pre-scaled by fusion_plan)"""
         N, H, Vn = h_top.shape[0], self.hidden_size, self.vocab_size

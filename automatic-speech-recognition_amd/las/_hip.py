@@ -40,7 +40,8 @@ class SpellerFwdArgs(Structure):
         ("tokens_in", c_void_p), ("tokens_out", c_void_p),
         ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
         ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p), ("act_save", c_void_p),
-        ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p), ("companion", POINTER(LstmCellArgs))]
+        ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p), ("companion", POINTER(LstmCellArgs)),
+        ("companion_rows", POINTER(LstmCellArgs))]
 
 
 class BeamLoopArgs(Structure):
@@ -50,7 +51,8 @@ class BeamLoopArgs(Structure):
                [(n, c_int) for n in ("nutt", "beam", "V", "Umax", "selcap", "topn", "start_id", "end_id", "ntens")] + \
                [("state_in", c_void_p * 16), ("state_out", c_void_p * 16), ("state_width", c_int * 16)] + \
                [("file_in", c_void_p), ("file_out", c_void_p), ("file_width", c_int)] + \
-               [("proj_h0", c_void_p), ("proj_k0", c_int), ("proj_h1", c_void_p), ("proj_k1", c_int), ("proj_w", c_void_p), ("proj_b", c_void_p)]
+               [("proj_h0", c_void_p), ("proj_k0", c_int), ("proj_h1", c_void_p), ("proj_k1", c_int), ("proj_w", c_void_p), ("proj_b", c_void_p)] + \
+               [("fold_gather", c_int)]
 
 
 class SpellerBwdArgs(Structure):

@@ -80,6 +80,13 @@ class BeamSearch(object):
         self._las = las
         self.use_graph = os.environ.get("LAS_NO_DECODE_GRAPH") != "1"     # decode_batch replays one captured step
         self.fuse_projection = os.environ.get("LAS_NO_DECODE_FUSED_PROJ") != "1"   # decode_batch: cell in one launch, projection inside the beam kernel
+        # decode_batch (round 5): rows + LM 1 | Speller cell + LM 2 | pruning + gather -- three dependent launches instead of five.  OFF by
+        # default: measured in the replayed graph (profiles/r5_decode_three_launches.txt) the three launches take 73-80 us of kernel time per
+        # step against 59 us for the five (14.3 + 12.7 + 11.2 + 15.9 + 4.8): every kernel of the step fills the machine by itself (256 rows = 256
+        # workgroups of 16 waves), so rows + LM 1 run one after the other inside their launch (22-26 us), and 16 pruning workgroups gather
+        # 207 KB each more slowly (30-34 us) than 256 x ntens gather workgroups do (4.8 us); dependent launches cost ~0 us in a replayed graph
+        self.three_launches = os.environ.get("LAS_DECODE_3_LAUNCHES") == "1"
+        self.steps_per_graph = int(os.environ.get("LAS_DECODE_STEPS_PER_GRAPH", "8"))   # search steps per captured HIP graph (one replay = that many steps)
         self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
         self.parallel_encoders = os.environ.get("LAS_NO_PARALLEL_ENCODERS") != "1"   # decode_batch: encoders of different lengths on several streams
         self._enc_streams = None
@@ -240,7 +247,7 @@ class BeamSearch(object):
         nsel = torch.zeros(n, **i32)
         done = torch.zeros(n, **i32)
         dstep = torch.tensor(dec_steps, **i32)
-        step = torch.zeros(1, **i32)
+        step = torch.zeros(2, **i32)                       # [0] the device step counter, [1] arrival counter of the folded gather (fold_gather)
         hist_parent = torch.zeros(Umax, n, beam, **i32)
         hist_token = torch.zeros(Umax, n, beam, **i32)
         hist_slot = torch.zeros(Umax, n, beam, **i32)
@@ -312,9 +319,12 @@ class BeamSearch(object):
             if rc < 0 and mode["fused"] and not (fa.flags & _hip.SPELLER_REUSE_PREP):
                 # the library refuses the short form for this geometry (it needs its prefetching row kernels): the long form it is
                 mode["fused"] = False
+                mode.pop("three", None)
                 fa.flags &= ~_hip.SPELLER_NO_LOGITS
                 fa.companion = None
+                fa.companion_rows = None
                 ba.proj_w = None
+                ba.fold_gather = 0
                 rc = lib.las_speller_fwd(ctypes.byref(fa), _hip.stream())
             _hip.check(rc, "las_speller_fwd")
             fa.flags |= _hip.SPELLER_REUSE_PREP      # enc / keys / weights are fixed for the search: their bf16 copies are made once
@@ -342,10 +352,26 @@ class BeamSearch(object):
             ba.proj_h0, ba.proj_k0 = bufs["hs"][NL - 1, 1].data_ptr(), D
             ba.proj_h1, ba.proj_k1 = None, (lm.hidden_size if lm is not None else 0)
             if lm is not None:
-                # the LM's first layer depends on the tokens only: it rides with the Speller's cell as the second problem of one grid
                 lm0 = (torch.empty(N, lm.hidden_size, device=dev), torch.empty(N, lm.hidden_size, device=dev))
                 lm0_args = lm.first_cell_args(lm_plan, next_token, 2, lm_c[0], lm_h[0], lm0[0], lm0[1])
-                if lm0_args is not None:
+                lm1 = lm1_args = None
+                if self.three_launches and lm0_args is not None and NLl == 2:
+                    lm1 = (torch.empty(N, lm.hidden_size, device=dev), torch.empty(N, lm.hidden_size, device=dev))
+                    lm1_args = lm.cell_args(lm_plan, 1, lm0[1], lm_c[1], lm_h[1], lm1[0], lm1[1])
+                if lm1_args is not None:
+                    # Round 5: a search step in THREE dependent launches (las/beam_search.py:94-158 is one loop).  The LM's first layer depends
+                    # on the step's tokens only: it runs as extra workgroups of the attention-row launch; its second layer rides with the
+                    # Speller's cell (two problems of one grid); the pruning launch gathers the survivors' state rows itself.  All state in
+                    # fixed buffers: the captured step is the same three launches every time.
+                    fa.companion_rows = ctypes.pointer(lm0_args)
+                    fa.companion = ctypes.pointer(lm1_args)
+                    mode["three"] = (lm0, lm1)
+                    for l, (cn, hn) in enumerate((lm0, lm1)):
+                        ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cn.data_ptr(), hn.data_ptr()
+                    ba.proj_h1 = lm1[1].data_ptr()
+                    ba.fold_gather = 1
+                elif lm0_args is not None:
+                    # the LM's first layer depends on the tokens only: it rides with the Speller's cell as the second problem of one grid
                     fa.companion = ctypes.pointer(lm0_args)
                     mode["lm0"] = lm0
 
@@ -361,6 +387,8 @@ class BeamSearch(object):
             held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued
 
         def lm_part():
+            if mode["fused"] and mode.get("three"):
+                return                               # both LM layers ran inside the Speller call's two launches
             lm_cells()
             if not mode["fused"]:
                 lm.project_fused(lm_plan, held[1][-1], logits, 2)
@@ -379,28 +407,41 @@ class BeamSearch(object):
         steps_run = 0
         graph = None
         use_graph = self.use_graph and Umax > 2
+        # One hipGraphLaunch costs the host more than a 3-launch step costs the device (r5 probe: 75-85 us per replayed step whatever the
+        # step's kernels added up to -- 55-62 us): the captured graph holds K consecutive steps.  Every launch of a step reads the DEVICE
+        # step counter, and a step at t >= Umax does nothing that is kept (las_beam_loop_step returns before it files or records), so
+        # the last replay may run past the bound.
+        K = max(1, int(self.steps_per_graph))
         with torch.no_grad():
-            for t in range(Umax):
+            t, next_check = 0, sync_every
+            while t < Umax:
                 if graph is not None:
                     graph.replay()
+                    t += K
                 elif use_graph and t == 1:
                     try:
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g):
-                            one_step()
-                        graph = g                      # (capturing does not execute: the captured step runs as the replay)
+                            for _ in range(K):
+                                one_step()
+                        graph = g                      # (capturing does not execute: the captured steps run as the replay)
                         graph.replay()
+                        t += K
                     except Exception as e:             # capture refused (e.g. an op that allocates host memory): stay eager
                         use_graph = False
                         torch.cuda.synchronize(dev)
                         if self.args.verbose > 0:
                             print("decode_batch: graph capture failed, running eagerly: %s" % e)
                         one_step()
+                        t += 1
                 else:
                     one_step()
-                steps_run = t + 1
-                if (t + 1) % sync_every == 0 and bool(done.all()):                      # the only host wait inside the loop
-                    break
+                    t += 1
+                steps_run = min(t, Umax)
+                if t >= next_check:                                                     # the only host wait inside the loop
+                    next_check += sync_every
+                    if bool(done.all()):
+                        break
         del keep
         mark("searched")
         # ---- the back pointers are walked on the device (las_beam_backtrack); one read-back, then the reference's host-side objects

@@ -32,11 +32,13 @@ class VariableStore:
         self.shadow_table = None
         self.seq_recipes = {}     # (W_hh pointers, cell, H, pass) -> how to prepare that sweep's workspace (las.layers._prepare_sweeps)
         self.seq_ready = {}       # ... -> batch rows it has been prepared for since the weights last changed (consumed by ONE sweep)
+        self.seq_prep_done = None  # event behind the side-stream prepare launch until the launch stream has waited for it
 
     def weights_changed(self, storage_moved=False):
         """Everything derived from the parameter VALUES is stale (optimiser step, load); storage_moved: their addresses too (flatten)."""
         self.shadows.clear()
         self.seq_ready.clear()
+        self.seq_prep_done = None
         if storage_moved:
             self.shadow_recipes.clear()
             self.shadow_table = None

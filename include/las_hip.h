@@ -317,6 +317,11 @@ typedef struct {
     const struct las_lstm_cell_args* companion;   /* optional, LAS_SPELLER_NO_LOGITS calls only: ANOTHER cell step (the LM's first layer in a beam
                                       search -- it depends on the tokens only) that is launched together with the Speller's cell, as
                                       the second problem of one grid: two dependent-launch slots of a search step become one */
+    const struct las_lstm_cell_args* companion_rows;   /* optional, LAS_SPELLER_NO_LOGITS calls only (round 5): a cell step that depends on the
+                                      step's TOKENS only (the LM's first layer, las/beam_search.py:109-116; exact transcendentals, fp32 or
+                                      one-hot input) launched as extra workgroups of the attention-row launch.  With the LM's SECOND layer as
+                                      `companion` and the state gather inside las_beam_loop_step (fold_gather) a search step is three
+                                      dependent launches: rows + LM 1, Speller cell + LM 2, beam. */
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
 size_t las_speller_act_save_bytes(int U, int B, int Tp, int A, int C);   /* C = location-aware channels (0: additive attention) */
@@ -490,6 +495,10 @@ typedef struct {
      * proj_h1 NULL = no second part), proj_h0 / proj_h1 fp32 [nutt*beam, proj_k0 / proj_k1] (multiples of 32), fp32 accumulation.
      * ceil(beam/16) * ceil(V/16) <= 8.  `logits` (may be NULL then) additionally receives the values. */
     const float* proj_h0; int proj_k0; const float* proj_h1; int proj_k1; const void* proj_w; const float* proj_b;
+    /* round 5: fold_gather != 0 -- the state gather runs INSIDE the pruning launch (an utterance's workgroup copies the rows of its own
+     * surviving parents as soon as it has ranked them: rows of different utterances never mix) and the step counter is advanced by the
+     * workgroup that finishes last; `step` then points to TWO ints (step[1]: arrival counter, caller-zeroed).  One launch per step. */
+    int fold_gather;
 } las_beam_loop_args;
 int las_beam_loop_step(const las_beam_loop_args* a, void* stream);
 /* After the last step: walk the back-pointer records of every retired hypothesis on the device (the reference carries whole token

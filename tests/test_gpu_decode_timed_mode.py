@@ -58,7 +58,18 @@ def test_bf16_beam16_lm_eight_utterances_match_the_bf16_oracle_and_graph_equals_
         assert [b.token_ids for b in g] == [b.token_ids for b in e]
         assert [float(b.log_prob) for b in g] == [float(b.log_prob) for b in e]
         assert torch.equal(g[-1].att[-1], e[-1].att[-1])
-    # the 5-launch step (Speller cell in one launch, both vocabulary projections inside the beam kernel -- the default, what `got` ran)
+    # round 5: the THREE-launch step (attention rows + LM layer 1 | Speller cell + LM layer 2 | pruning + state gather; las_speller_fwd_args
+    # .companion_rows, las_beam_loop_args.fold_gather) is the same arithmetic as the five-launch step `got` ran (rows | Speller cell + LM 1 |
+    # LM 2 | pruning | gather) in other launches -- bit-identical; it is not the default because it is SLOWER (las/beam_search.py)
+    assert not bs.three_launches
+    bs.three_launches = True
+    three = bs.decode_batch(None, utts)
+    bs.three_launches = False
+    for g, e in zip(got, three):
+        assert [b.token_ids for b in g] == [b.token_ids for b in e]
+        assert [float(b.log_prob) for b in g] == [float(b.log_prob) for b in e]
+        assert torch.equal(g[-1].att[-1], e[-1].att[-1])
+    # the 5-launch step (Speller cell in one launch, both vocabulary projections inside the beam kernel)
     # against the 8-launch step (skinny cell product + finishing kernel with its own logits, LM projection as a GEMM on top)
     assert bs.fuse_projection
     bs.fuse_projection = False

@@ -1,0 +1,34 @@
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+for p in (os.path.join(ROOT, "automatic-speech-recognition_amd"), os.path.join(ROOT, "tests"), ROOT):
+    sys.path.insert(0, p)
+import torch, bench
+from helpers import synthetic_batch
+from las import layers as L, variables as V
+from las.beam_search import BeamSearch
+from las.las import LAS, Listener, Speller
+from lang.char_rnn_model import CharRNN
+from utils.tokenizer import CharEncoder
+dev = torch.device("cuda", 0)
+L.set_cell("lstm"); L.set_precision("bf16")
+st = V.reset_default_store(device=dev, seed=0)
+args = bench.bench_args("lstm")
+args.beam_size, args.apply_lm, args.lm_weight, args.convert_rate = 16, True, 0.5, 0.166
+args.verbose = 0
+tok = CharEncoder()
+las = LAS(args, Listener, Speller, tok.token_to_id)
+lm = CharRNN(False, 1, 1, 28, 512, embedding_size=0, num_layers=2, store=st)
+lm.params(); las.build_variables()
+bs = BeamSearch(args, las, tok.token_to_id, lm)
+utts = [synthetic_batch(1, 1274, 8, 30, seed=100 + k)[0] for k in range(16)]
+bs.decode_batch(None, utts[:2]); bs.decode_batch(None, utts)
+for three, spg in ((True, 8), (False, 8), (True, 1), (False, 1), (True, 16), (True, 8), (False, 8)):
+    bs.steps_per_graph = spg
+    bs.three_launches = three
+    bs.measure = True
+    bs.decode_batch(None, utts)
+    print(three, spg, bs.last_timing)
+    bs.measure = False
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(4): bs.decode_batch(None, utts)
+    torch.cuda.synchronize(); print("  utt/s", 64 / (time.perf_counter() - t0))
