@@ -256,6 +256,16 @@ __global__ __launch_bounds__(512, 2) void lstm_cell_rows_pair_kernel(LstmCellLau
     else                 lstm_cell_rows_body<false, false, false>(b, As, gates, blockIdx.x, blockIdx.y * 32);
 }
 
+// 128-row workgroups (lstm_cell_rows_big_body): M >= LB_MIN_ROWS
+template <bool FAST, bool XBF>
+__global__ __launch_bounds__(512) void lstm_cell_rows_big_kernel(LstmCellLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+    lstm_cell_rows_big_body<FAST, XBF>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+}
+constexpr int LB_MIN_ROWS = 384;          // from here on a launch of 32-row workgroups is more than one round of the 256 CUs per 512 units
+template <typename K>
+static int lb_attr(K kern) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES); }
+
 int las_lstm_cell_check(const LstmCellLaunch& a) {
     LAS_ARG((a.x || a.h) && a.bias && a.c_prev && a.c_out && a.h_out && a.M > 0 && a.H > 0, "las_lstm_cell_rows: bad arguments");
     LAS_ARG(!(a.x && a.xrows), "las_lstm_cell_rows: x (dense input rows) and xrows (one-hot input) are exclusive");
@@ -269,6 +279,18 @@ int las_lstm_cell_check(const LstmCellLaunch& a) {
 
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
     if (int rc = las_lstm_cell_check(a)) return rc;
+    if (a.M >= LB_MIN_ROWS) {
+        static int attr = lb_attr(lstm_cell_rows_big_kernel<true, true>) | lb_attr(lstm_cell_rows_big_kernel<true, false>) |
+                          lb_attr(lstm_cell_rows_big_kernel<false, true>) | lb_attr(lstm_cell_rows_big_kernel<false, false>);
+        if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big) failed: %d", attr); return attr; }
+        const dim3 gb(a.H / 16, cdiv(a.M, LB_ROWS));
+        if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else if (a.fast)        hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else if (a.x_bf16)      hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else                    hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        LAS_LAUNCHED();
+        return 0;
+    }
     const dim3 grid(a.H / 16, cdiv(a.M, 32));
     if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_kernel<true, true>), grid, dim3(512), 0, st, a);
     else if (a.fast)        hipLaunchKernelGGL((lstm_cell_rows_kernel<true, false>), grid, dim3(512), 0, st, a);
@@ -285,6 +307,8 @@ int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b,
         if (int rc = las_lstm_cell_rows_launch(a, st)) return rc;
         return las_lstm_cell_rows_launch(b, st);
     }
+    // (the 128-row body as a pair -- lstm_cell_rows_big_pair_kernel -- measured 42-48 us at M = 1024 against 39 for the pair of 32-row bodies
+    //  below: at 200 VGPRs its two problems cannot share a CU, they simply run one after the other; the single-cell launch does gain, 30 vs 37)
     const int gx = (a.H > b.H ? a.H : b.H) / 16, gy = cdiv(a.M > b.M ? a.M : b.M, 32);
     hipLaunchKernelGGL(lstm_cell_rows_pair_kernel, dim3(gx, gy, 2), dim3(512), 0, st, a, b);
     LAS_LAUNCHED();

@@ -171,3 +171,155 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the same cell step for MANY rows (a beam search over 64 utterances x beam 16 = 1024 hypothesis rows: decode.py's default batch).
+// The 32-row workgroups above are latency-bound -- three dependent load / stage / multiply phases per workgroup -- and at M = 1024 a launch
+// is four ROUNDS of them on the 256 CUs: 37-39 us per cell launch, 116-180 TFLOP/s (r5 trace, profiles/r5_decode_b64_kernels.txt).  Here a
+// workgroup owns 128 rows x 16 units, so M = 1024 is ONE round: 8 waves = 4 gates x 2 row halves, a wave multiplies four 16-row tiles
+// against its gate's fragments (the B operand is loaded once for 4x the rows), K chunks of 256 through a 67 KB LDS tile, next chunk's rows
+// and fragments in flight while the current one is multiplied.  Same arithmetic, element for element: bf16 operands, fp32 accumulation in
+// k order, gate math of the body above.
+// ------------------------------------------------------------------------------------------------
+#ifndef LB_ABL
+#define LB_ABL 0          // timing experiments (make ablf F=loss_opt D=-DLB_ABL=..): 1 no MFMAs, 2 no row loads after the first chunk, 4 no fragment loads after the first, 8 LDS-only barriers
+#endif
+constexpr int LB_KC = 256, LB_LD = LB_KC + 8, LB_ROWS = 128;
+constexpr int LB_LDS_BYTES = LB_ROWS * LB_LD * 2;      // 67,584 bytes (the gate exchange [2][4][4][64][4] floats = 32 KB reuses it)
+
+template <bool FAST, bool XBF>
+__device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a, unsigned char* smem, const int ub, const int row0) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
+    const int gt = w & 3, rh = w >> 2;
+    const int H = a.H, ct = gt * (H >> 4) + ub;
+    if (ub * 16 >= H || row0 >= a.M) return;
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+    f32x4_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int KSx = a.x ? a.I >> 5 : 0, KSh = a.h ? H >> 5 : 0;
+    constexpr int NKS = LB_KC / 32;                                       // k-steps per chunk
+    const int ncx = (KSx + NKS - 1) / NKS, nch = ncx + (KSh + NKS - 1) / NKS;
+    u16x8_t bv[NKS], bn[NKS];
+    constexpr int NRA = XBF ? 8 : 16;                                     // 16-byte pieces of the next chunk's rows per thread
+    float4 ra[16];
+    auto chunk = [&](const int ci, const void*& src, int& ld, int& k0, int& kc, const u16x8_t*& bp, bool& sbf) {
+        const bool hp = ci >= ncx;
+        const int cj = hp ? ci - ncx : ci, Kp = hp ? H : a.I, KS = Kp >> 5;
+        src = hp ? (const void*)a.h : a.x; ld = hp ? a.ldh : a.ldx; k0 = cj * LB_KC; kc = min(LB_KC, Kp - k0);
+        bp = reinterpret_cast<const u16x8_t*>(hp ? a.Wh : a.Wx) + ((size_t)ct * KS + (k0 >> 5)) * 64 + lane;
+        sbf = XBF && !hp;
+    };
+    auto load_b = [&](const int ci, u16x8_t (&dst)[NKS]) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        const int nks = kc >> 5;
+#pragma unroll
+        for (int u = 0; u < NKS; ++u) dst[u] = bp[(size_t)(u < nks ? u : nks - 1) * 64];
+    };
+    auto load_a = [&](const int ci) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        if (sbf) {
+            const int per = kc >> 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + j * 512, ic = idx < LB_ROWS * per ? idx : 0;
+                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        } else {
+            const int per = kc >> 2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int idx = tid + j * 512, ic = idx < LB_ROWS * per ? idx : 0;
+                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
+            }
+        }
+    };
+    auto store_a = [&](const int ci) {
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        if (sbf) {
+            const int per = kc >> 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + j * 512;
+                if (idx < LB_ROWS * per) {
+                    const int r = idx / per, q = idx - r * per;
+                    *reinterpret_cast<uint4*>(As + r * LB_LD + q * 8) =
+                        make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
+                }
+            }
+        } else {
+            const int per = kc >> 2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int idx = tid + j * 512;
+                if (idx < LB_ROWS * per) {
+                    const int r = idx / per, q = idx - r * per;
+                    uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
+                    *reinterpret_cast<uint2*>(As + r * LB_LD + q * 4) = pk;
+                }
+            }
+        }
+    };
+    (void)NRA;
+    load_b(0, bv);
+    load_a(0);
+    for (int ci = 0; ci < nch; ++ci) {
+        if (LB_ABL & 8) lds_barrier(); else __syncthreads();          // the previous chunk's readers are done
+        store_a(ci);
+        if (ci + 1 < nch) { if (!(LB_ABL & 4)) load_b(ci + 1, bn); if (!(LB_ABL & 2)) load_a(ci + 1); }
+        if (LB_ABL & 8) lds_barrier(); else __syncthreads();
+        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
+        chunk(ci, src, ld, k0, kc, bp, sbf);
+        const int nks = kc >> 5;
+        const unsigned short* ar = As + (rh * 64 + c) * LB_LD + g4 * 8;
+#pragma unroll
+        for (int u = 0; u < NKS; ++u) {
+            if (u < nks && !(LB_ABL & 1)) {
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    acc[rt] = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + rt * 16 * LB_LD + u * 32), bv[u], acc[rt]);
+            }
+        }
+        if (ci + 1 < nch) {
+#pragma unroll
+            for (int u = 0; u < NKS; ++u) bv[u] = bn[u];
+        }
+    }
+    __syncthreads();                                                  // every wave is done reading the row tile: its space becomes the gate exchange
+    float* gx = reinterpret_cast<float*>(smem);                       // [rh 2][rt 4][gate 4][lane 64][4]
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4_t*>(gx + ((((rh * 4 + rt) * 4 + gt) * 64 + lane) << 2)) = acc[rt];
+    __syncthreads();
+    // gate math: element (row r of the 128, unit u of the 16); MFMA C layout: (row r16, col u) of a tile sits in lane (r16 / 4) * 16 + u, register r16 % 4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + k * 512, r = idx >> 4, u = idx & 15, row = row0 + r;
+        if (row >= a.M) continue;
+        const int r16 = r & 15, l2 = (r16 >> 2) * 16 + u, reg = r16 & 3, unit = ub * 16 + u, tile = (r >> 6) * 4 + ((r >> 4) & 3);
+        float z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) z[g] = gx[(((tile * 4 + g) * 64 + l2) << 2) + reg] + a.bias[g * H + unit];
+        if (a.xrows) {
+            int id = a.ids[row] - a.id_shift;
+            if (id < 0) id = 0;
+            const float* xr = a.xrows + (size_t)id * 4 * H + unit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) z[g] += xr[g * H];
+        }
+        const float gi = sigm<FAST>(z[0]), gj = tanhx<FAST>(z[1]), gf = sigm<FAST>(z[2] + a.fb), go = sigm<FAST>(z[3]);
+        const size_t o = (size_t)row * H + unit;
+        const float cn = a.c_prev[o] * gf + gi * gj;
+        a.c_out[o] = cn;
+        a.h_out[o] = tanhx<FAST>(cn) * go;
+        if (a.gates_out) {
+            float* gp = a.gates_out + (size_t)row * 4 * H + unit;
+            gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
+        }
+    }
+}

@@ -1236,6 +1236,203 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, threadIdx.x, sm, ccar, false);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 5, beam search at decode.py's batch (64 utterances x beam 16 = 1024 hypothesis rows): the attention rows of a search step with
+// FOUR hypotheses of one utterance per workgroup (LAS_SPELLER_ROWS_SHARE4: rows 4g .. 4g+3 have identical enc / keys / enc_len -- the beam
+// search tiles an utterance's encoder output over its hypotheses, las/beam_search.py:216).  One row per workgroup pulls Ws (128 KB), the
+// keys (41 KB) and the encoder rows (164 KB) through its CU for every hypothesis: 333 KB x 1024 rows = 341 MB of L2 traffic per step, 47 us
+// at 7 TB/s (r5 trace: the kernel is bound by exactly that).  Here the three operands are read ONCE per workgroup and applied to four
+// states: a quarter of the traffic, the same arithmetic per row IN THE SAME ORDER as pf_fwd_row (query partials per k-pair group, 16-lane
+// energy sums, per-wave softmax statistics, frame-pair dot products) -- results are bit-identical to one row per workgroup.
+// Decode only: t = 0 of a U = 1 call with keep_state0 (the state comes from hs slot 0), tokens given, additive attention.
+// ------------------------------------------------------------------------------------------------
+constexpr int BR4 = 4;
+static size_t beam_rows4_lds(const DecDev& a) {
+    auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const size_t scr = (size_t)BR4 * ((size_t)RNW * a.A > (size_t)8 * a.Hd ? (size_t)RNW * a.A : (size_t)8 * a.Hd);
+    return (BR4 * (u4(a.D) + u4((a.D + 1) / 2) + u4(a.A) + u4(a.Tp) + u4((a.Tp + 1) / 2)) + scr) * sizeof(float) + 64;
+}
+template <int NE>
+__global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
+    constexpr bool FAST = true;
+    constexpr int R = BR4, NK = (16 * NE + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int a8 = tid & 15, grp = tid >> 4;           // energies: 16 lanes x 8 columns per frame
+    const int a4 = tid & 31, kg = tid >> 5;            // query:    32 lanes x 4 columns per k-pair
+    const int h4 = tid & 127, fg = tid >> 7;           // context:  128 lanes x 4 columns per frame pair
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V;
+    const int I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (D + 1) >> 1, Tp2 = (Tp + 1) >> 1;
+    const int b0 = blockIdx.x * R;
+    auto u4 = [](int x) { return (x + 3) & ~3; };
+    float* s_state = sm;                                                          // [R][D]
+    unsigned* sp = reinterpret_cast<unsigned*>(s_state + R * u4(D));              // [R][S2] packed state pairs
+    float* qv = reinterpret_cast<float*>(sp + R * u4(S2));                        // [R][A]
+    float* ev = qv + R * u4(A);                                                   // [R][Tp]
+    unsigned* ap = reinterpret_cast<unsigned*>(ev + R * u4(Tp));                  // [R][Tp2] packed alpha pairs
+    float* scr = reinterpret_cast<float*>(ap + R * u4(Tp2));                      // [R][16][A] query partials, then [R][8][Hd] context partials
+    const int SD = u4(D), SS = u4(S2), SA = u4(A), ST = u4(Tp), ST2 = u4(Tp2);
+
+    // ---- the operands every row of the workgroup shares, requested up front (clamped addresses, see pf_fwd_row)
+    const int dd = tid < D ? tid : D - 1;
+    const int len = a.enc_len[b0];
+    const int a4c = a4 < A4 ? a4 : A4 - 1, a8c = a8 < A8 ? a8 : A8 - 1, h4c = h4 < H4 ? h4 : H4 - 1;
+    uint4 w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
+        w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kpc * A4 + a4c];
+    }
+    const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
+    uint4 k8[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b0 * Tp + ttc) * A8 + a8c];
+    }
+    float s0[R];
+    int tok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int b = b0 + r < B ? b0 + r : B - 1;
+        s0[r] = a.hs[(size_t)b * D + dd];
+        tok[r] = a.tok_in[b];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {        // the states entering the step (hs slot 0: keep_state0)
+        const float h = tid < D ? s0[r] : 0.f;
+        const float hn = __shfl_xor(h, 1, 64);
+        if (tid < D) {
+            s_state[r * SD + tid] = h;
+            if (!(tid & 1)) sp[r * SS + (tid >> 1)] = f2bf2(h, (tid + 1 < D) ? hn : 0.f);
+        }
+    }
+    lds_barrier();
+    {   // query projections q_r = s_r . Ws: the Ws fragments are read once for the four states
+        float acc[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; acc[r][3] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kp = kg + 32 * u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned int s2 = kp < S2 ? sp[r * SS + kp] : 0u;
+                acc[r][0] = dot2bf(w8[u].x, s2, acc[r][0]); acc[r][1] = dot2bf(w8[u].y, s2, acc[r][1]);
+                acc[r][2] = dot2bf(w8[u].z, s2, acc[r][2]); acc[r][3] = dot2bf(w8[u].w, s2, acc[r][3]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][e] += __shfl_xor(acc[r][e], 32, 64);
+            if (lane < 32 && a4 < A4) reinterpret_cast<float4*>(scr + ((size_t)r * RNW + wv) * A)[a4] = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        }
+    }
+    lds_barrier();
+    // the encoder rows for the context (the Ws registers are free now), consumed after the softmax -- once for the four rows
+    uint4 e8[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int tp = fg + 8 * u, tpc = tp < Tp2 ? tp : Tp2 - 1;
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b0 * Tp2 + tpc) * H4 + h4c];
+    }
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
+    for (int i = tid; i < R * A; i += RNT) {
+        const int r = i / A, col = i - r * A;
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < RNW; ++w) q += scr[((size_t)r * RNW + w) * A + col];
+        qv[r * SA + col] = q;
+    }
+    lds_barrier();
+    {   // energies: a frame's keys are unpacked once and meet the four queries
+        const float um = a8 < A8 ? 1.f : 0.f;
+        const float u8[8] = {u40.x * um, u40.y * um, u40.z * um, u40.w * um, u41.x * um, u41.y * um, u41.z * um, u41.w * um};
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int tt = grp + 64 * u;
+            float k[8];
+            unpack8(k8[u], k);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float part = 0.f;
+                if (tt < len && tt < Tp) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float q = a8 < A8 ? qv[r * SA + a8 * 8 + e] : 0.f;
+                        part = fmaf(u8[e], tanhx<FAST>(k[e] + q), part);
+                    }
+                }
+                part = sub16_sum(part);
+                if (a8 == 0 && tt < Tp) ev[r * ST + tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
+            }
+        }
+    }
+    lds_barrier();
+    if (wv < 2 * R) {   // softmax: waves 2r, 2r + 1 own row r (as waves 0-1 own the single row of pf_fwd_row)
+        const int r = wv >> 1, t2 = tid & 127;
+        float ev_[NK];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) { ev_[j] = lane + 64 * j < Tp ? ev[r * ST + lane + 64 * j] : -INFINITY; m = fmaxf(m, ev_[j]); }
+        m = wave_max(m);
+        float ssum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) ssum += expf(ev_[j] - m);
+        ssum = wave_sum(ssum);
+        const float inv = 1.0f / ssum;
+        if (t2 < Tp2 && b0 + r < B) {
+            const int i0 = 2 * t2, i1 = 2 * t2 + 1;
+            const float al0 = expf(ev[r * ST + i0] - m) * inv, al1 = i1 < Tp ? expf(ev[r * ST + i1] - m) * inv : 0.f;
+            ap[r * ST2 + t2] = f2bf2(al0, al1);
+            float* arow = a.alphas + (size_t)(b0 + r) * Tp;
+            arow[i0] = al0;
+            if (i1 < Tp) arow[i1] = al1;
+        }
+    }
+    lds_barrier();
+    {   // contexts: the encoder rows in registers meet the four alignments
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int tp = fg + 8 * u;
+                const unsigned int al2 = 2 * tp < lim ? ap[r * ST2 + tp] : 0u;
+                acc[0] = dot2bf(e8[u].x, al2, acc[0]); acc[1] = dot2bf(e8[u].y, al2, acc[1]);
+                acc[2] = dot2bf(e8[u].z, al2, acc[2]); acc[3] = dot2bf(e8[u].w, al2, acc[3]);
+            }
+            if (h4 < H4) reinterpret_cast<float4*>(scr + ((size_t)r * 8 + fg) * Hd)[h4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (b0 + r >= B) break;
+        float* xrow = a.xin0 + (size_t)(b0 + r) * I0D;
+        unsigned short* xb = a.xbf + (size_t)(b0 + r) * I0D;
+        for (int hd = tid; hd < Hd; hd += RNT) {
+            float cv = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) cv += scr[((size_t)r * 8 + w) * Hd + hd];
+            xrow[E + hd] = cv;
+            xb[E + hd] = f2bf(cv);
+        }
+        if (tid < E) {
+            const float v = (a.emb[(size_t)tok[r] * E + tid] + (a.emb_noise ? a.emb_noise[(size_t)tok[r] * E + tid] : 0.f)) *
+                            (a.emb_mask ? a.emb_mask[(size_t)(b0 + r) * E + tid] : 1.f);
+            xrow[tid] = v;
+            xb[tid] = f2bf(v);
+        }
+        if (tid < D) {
+            const float v = s_state[r * SD + tid];
+            xrow[E + Hd + tid] = v;
+            xb[E + Hd + tid] = f2bf(v);
+        }
+    }
+}
+
 // Round 5, beam search (las/beam_search.py:94-158 is ONE loop): the attention rows of a search step and ANOTHER cell step that depends on
 // the step's tokens only -- the LM's first layer (las/beam_search.py:109-116) -- as one grid.  The first `nlm` workgroups run the LM cell
 // (32 rows x 16 units each, 512 of the 1024 threads; the others leave at once), the rest one attention row each.  The LM's second layer
@@ -3025,6 +3222,20 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
             else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 10>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
             else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 12>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
             else                  hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 14>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+        }
+        else if (pf && t == 0 && U == 1 && f->keep_state0 && (d.flags & LAS_SPELLER_ROWS_SHARE4) && (d.flags & LAS_SPELLER_NO_LOGITS)) {
+            // beam-search step over many rows: four hypotheses of an utterance per workgroup, shared operands read once
+            const size_t l4 = beam_rows4_lds(d);
+            static int attr4 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_beam_rows4_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) |
+                               (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_beam_rows4_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) |
+                               (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_beam_rows4_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) |
+                               (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_beam_rows4_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            LAS_ARG(attr4 == 0 && l4 <= 128 * 1024, "speller: hipFuncSetAttribute(dec_beam_rows4_kernel) failed (%d) or the rows' state does not fit LDS (%zu)", attr4, l4);
+            LAS_ARG((B % BR4) == 0 && d.tok_in, "speller: LAS_SPELLER_ROWS_SHARE4 needs a row count that is a multiple of 4");
+            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_beam_rows4_kernel<8>), dim3(B / BR4), dim3(RNT), l4, st, d);
+            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_beam_rows4_kernel<10>), dim3(B / BR4), dim3(RNT), l4, st, d);
+            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_beam_rows4_kernel<12>), dim3(B / BR4), dim3(RNT), l4, st, d);
+            else                  hipLaunchKernelGGL((dec_beam_rows4_kernel<14>), dim3(B / BR4), dim3(RNT), l4, st, d);
         }
         else if (pf && t == U)          hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);

@@ -86,6 +86,9 @@ class BeamSearch(object):
         # workgroups of 16 waves), so rows + LM 1 run one after the other inside their launch (22-26 us), and 16 pruning workgroups gather
         # 207 KB each more slowly (30-34 us) than 256 x ntens gather workgroups do (4.8 us); dependent launches cost ~0 us in a replayed graph
         self.three_launches = os.environ.get("LAS_DECODE_3_LAUNCHES") == "1"
+        # decode_batch (round 5): the attention rows of FOUR hypotheses of an utterance in one workgroup (LAS_SPELLER_ROWS_SHARE4: Ws, keys and
+        # encoder rows read once for the four) from this many hypothesis rows on (0 = never); bit-identical to one row per workgroup
+        self.share_rows_from = int(os.environ.get("LAS_DECODE_SHARE_ROWS_FROM", "512"))
         self.steps_per_graph = int(os.environ.get("LAS_DECODE_STEPS_PER_GRAPH", "8"))   # search steps per captured HIP graph (one replay = that many steps)
         self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
         self.parallel_encoders = os.environ.get("LAS_NO_PARALLEL_ENCODERS") != "1"   # decode_batch: encoders of different lengths on several streams
@@ -320,7 +323,7 @@ class BeamSearch(object):
                 # the library refuses the short form for this geometry (it needs its prefetching row kernels): the long form it is
                 mode["fused"] = False
                 mode.pop("three", None)
-                fa.flags &= ~_hip.SPELLER_NO_LOGITS
+                fa.flags &= ~(_hip.SPELLER_NO_LOGITS | _hip.SPELLER_ROWS_SHARE4)
                 fa.companion = None
                 fa.companion_rows = None
                 ba.proj_w = None
@@ -348,6 +351,8 @@ class BeamSearch(object):
             Wcat = Wcat.contiguous()
             proj_keep = (_hip.skinny_pack(Wcat, Wcat.shape[0], V_), bcat.contiguous())
             fa.flags |= _hip.SPELLER_NO_LOGITS
+            if self.share_rows_from and N >= self.share_rows_from and beam % 4 == 0 and a.mode == "add":
+                fa.flags |= _hip.SPELLER_ROWS_SHARE4         # rows 4g .. 4g+3 are hypotheses of ONE utterance: same enc / keys / length
             ba.proj_w, ba.proj_b = proj_keep[0].data_ptr(), proj_keep[1].data_ptr()
             ba.proj_h0, ba.proj_k0 = bufs["hs"][NL - 1, 1].data_ptr(), D
             ba.proj_h1, ba.proj_k1 = None, (lm.hidden_size if lm is not None else 0)

@@ -285,6 +285,10 @@ enum { LAS_SPELLER_NO_LOGITS = 16 };    /* (las_speller_fwd, U = 1, speed mode, 
                                            attention row kernel, then the cell in ONE launch (product + gate math: hs / cs slot 1 and the activated
                                            gates); NO vocabulary projection, logits / tokens_out are left alone -- the caller projects inside
                                            las_beam_loop_step (proj_*) */
+enum { LAS_SPELLER_ROWS_SHARE4 = 32 };  /* (with LAS_SPELLER_NO_LOGITS; round 5) the caller vouches that rows 4g .. 4g+3 have IDENTICAL enc / keys / enc_len
+                                           (beam search: the hypotheses of one utterance are consecutive rows, beam % 4 == 0): the attention rows of
+                                           four hypotheses run in one workgroup that reads Ws, the keys and the encoder rows once -- a quarter of
+                                           the step's L2 traffic; bit-identical to one row per workgroup.  B % 4 == 0, tokens >= 0. */
 #define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;

@@ -69,6 +69,16 @@ def test_bf16_beam16_lm_eight_utterances_match_the_bf16_oracle_and_graph_equals_
         assert [b.token_ids for b in g] == [b.token_ids for b in e]
         assert [float(b.log_prob) for b in g] == [float(b.log_prob) for b in e]
         assert torch.equal(g[-1].att[-1], e[-1].att[-1])
+    # round 5: four hypotheses of an utterance per attention workgroup (LAS_SPELLER_ROWS_SHARE4; the default from 512 rows on) -- the same
+    # arithmetic per row in the same order: bit-identical
+    saved = bs.share_rows_from
+    bs.share_rows_from = 1
+    shared = bs.decode_batch(None, utts)
+    bs.share_rows_from = saved
+    for g, e in zip(got, shared):
+        assert [b.token_ids for b in g] == [b.token_ids for b in e]
+        assert [float(b.log_prob) for b in g] == [float(b.log_prob) for b in e]
+        assert torch.equal(g[-1].att[-1], e[-1].att[-1])
     # the 5-launch step (Speller cell in one launch, both vocabulary projections inside the beam kernel)
     # against the 8-launch step (skinny cell product + finishing kernel with its own logits, LM projection as a GEMM on top)
     assert bs.fuse_projection

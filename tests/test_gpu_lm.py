@@ -30,7 +30,9 @@ def test_pointwise_rows_equals_lookup_add_then_pointwise(N, H, V, shift):
     assert (c1 - c_t).abs().max() < 1e-5 and (h1 - torch.tanh(c_t) * torch.sigmoid(o)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("M,I,H,onehot", [(256, 512, 512, False), (256, 0, 512, True), (5, 64, 32, False), (33, 0, 64, True), (70, 1024, 96, False)])
+# (M >= 384: the 128-row workgroups of round 5 -- lstm_cell_rows_big_body -- incl. a ragged last row block and K chunks that end inside a part)
+@pytest.mark.parametrize("M,I,H,onehot", [(256, 512, 512, False), (256, 0, 512, True), (5, 64, 32, False), (33, 0, 64, True), (70, 1024, 96, False),
+                                          (1024, 512, 512, False), (1024, 0, 512, True), (390, 1024, 96, False), (700, 160, 64, False)])
 def test_lstm_cell_rows_matches_bf16_operand_reference(M, I, H, onehot):
     """las_lstm_cell_rows (the LM step of the beam search in one launch per layer) against torch: operands rounded to bf16, fp32
     accumulation, then the BasicLSTMCell gate math; and against the two-product + gate-kernel path it replaces."""
@@ -69,7 +71,7 @@ def test_lstm_cell_rows_matches_bf16_operand_reference(M, I, H, onehot):
                                   _hip.p(h1), _hip.stream()) < 0
 
 
-@pytest.mark.parametrize("M,I,H", [(256, 1152, 512), (40, 160, 64)])
+@pytest.mark.parametrize("M,I,H", [(256, 1152, 512), (40, 160, 64), (1024, 1152, 512), (500, 160, 64)])
 def test_lstm_cell_rows_struct_entry_bf16_rows_fast_gates(M, I, H):
     """las_lstm_cell_rows_args with the options the beam search's Speller step uses: x already bf16, no separate h part, the Speller's
     approximated transcendentals (fast), activated gates written -- against the bf16-operand reference (tolerance of the fast
