@@ -71,6 +71,28 @@ __global__ __launch_bounds__(64) void set_word_kernel(int* word, int value) {
     if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A resident "foreign" kernel (diagnostics, round 5): `n` workgroups of 256 threads that hold their compute-unit slots -- `lds` bytes of LDS, 32 or
+// 64 VGPRs per lane: the footprint of a collective's channel -- until *stop != 0 (bounded by max_ms on the constant 100 MHz clock).
+// Workgroup L lands on XCD L % 8, so n = 8 is one per XCD.  resident[0] counts the workgroups that have started.
+template <int VGPRS>
+__global__ __launch_bounds__(256) void occupy_kernel(const int* stop, int* resident, long long max_ticks, int lds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char occ_lds[];
+    if (VGPRS > 32) asm volatile("; the wave holds 64 VGPRs" ::: "v63");
+    else            asm volatile("; the wave holds 32 VGPRs" ::: "v31");
+    if (threadIdx.x == 0) { if (lds > 0) occ_lds[0] = 1; atomicAdd(resident, 1); }
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int las_occupy(const int* stop, int* resident, int n, int lds, int vgprs, int max_ms, void* stream) {
+    LAS_ARG(stop && resident && n > 0 && n <= 1024 && lds >= 0 && lds <= 64 * 1024 && max_ms > 0 && max_ms <= 60000, "las_occupy: bad arguments");
+    const long long ticks = (long long)max_ms * 100000;
+    if (vgprs > 32) hipLaunchKernelGGL(occupy_kernel<64>, dim3(n), dim3(256), lds, (hipStream_t)stream, stop, resident, ticks, lds);
+    else            hipLaunchKernelGGL(occupy_kernel<32>, dim3(n), dim3(256), lds, (hipStream_t)stream, stop, resident, ticks, lds);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 extern "C" int las_set_word(int* word, int value, void* stream) {
     LAS_ARG(word, "las_set_word: null pointer");
     hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, value);

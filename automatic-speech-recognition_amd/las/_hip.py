@@ -138,6 +138,7 @@ _SIGS = {
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_announce": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_set_word": (c_int, [c_void_p, c_int, c_void_p]),
+    "las_occupy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "las_gemm_kk_frames": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_void_p, c_longlong,
                                    c_void_p, c_int, c_longlong, c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
     "las_rnn_seq_bwd_chunks_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),

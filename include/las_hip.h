@@ -388,6 +388,11 @@ int las_wait_word(const int* word, int value, int max_us, void* stream);
 /* ... for the announcement word itself (status[1] of LAS_SEQ_ANNOUNCE): passes once the word HAS REACHED n in the cyclic order of
  * 1..1023 -- also when later sweeps have announced themselves meanwhile (a hold enqueued late must not sit out its bound). */
 int las_wait_announce(const int* word, int n, int max_us, void* stream);
+/* Diagnostics (round 5): a "foreign" kernel that stays RESIDENT -- n workgroups of 256 threads (workgroup L on XCD L % 8), `lds` bytes of LDS
+ * and 32 or 64 VGPRs per lane each: the footprint of a collective's channel -- until *stop != 0 (or max_ms).  resident[0] (caller-zeroed)
+ * counts the workgroups that have started.  The recurrent sweeps and the one-launch Speller loops need all THEIR workgroups resident at
+ * once (LAS_SEQ_STATUS_*, LAS_SPELLER_STATUS_TIMEOUT): tests run a train step beside this kernel to show what they tolerate. */
+int las_occupy(const int* stop, int* resident, int n, int lds, int vgprs, int max_ms, void* stream);
 
 /* bf16 (or fp32) weight shadows of the speed mode, rebuilt after every optimiser step by ONE launch over a device-resident
  * descriptor table: D = zero-pad(op([src0 | src1])), op = transpose or identity; src1 may be NULL (cols1 = 0).

@@ -1,0 +1,131 @@
+"""Residency beside a co-resident kernel (VERDICT r4 "Next" #8).  The recurrent sweeps and the one-launch Speller loops exchange data between
+workgroups that must all be resident at once; a data-parallel run puts a collective's kernels on the same device.  No 8-GPU node has been
+available to any round, so this is the stand-in: a persistent "foreign" kernel (las_occupy: 256-thread workgroups, workgroup L on XCD L % 8,
+some LDS, 32 or 64 VGPRs per lane -- the footprint of a collective's channels) is resident while train steps of the timed geometry run.
+
+What must hold in every case: NOTHING HANGS, and a step either completes with the undisturbed bits or reports the documented status (never
+silent garbage: las_clip_adam skips the update on the device).
+
+* WHERE A COLLECTIVE REALLY RUNS in the data-parallel schedule (las/las.py): beside the Listener's BPTT sweeps at the earliest -- the early
+  part of the bucket is issued behind the last sweep (layers.BEFORE_TAIL_HOOK), the token count beside the first forward sweep -- never
+  beside a Speller loop.  Case "bptt": 32 workgroups x 16 KB of LDS x 64 VGPRs resident from the first BPTT sweep of a step to its end.
+  The sweeps take 60 of the 256 CUs: the steps must complete, bit-identical.
+* The Speller's loop kernels are the ones that need EVERY CU (8 x 32 workgroups of 1024 threads, <= 120 VGPRs; the forward rows keep 156 KB
+  of a CU's 160 KB of LDS).  Case "whole step, registers only" (32 VGPRs, no LDS: what that register budget leaves room for --
+  tests/test_cabi_and_host.py): must complete, bit-identical.  Case "whole step, 4 KB of LDS": a loop workgroup cannot be placed on a CU
+  that has lost 4 KB -- the outcome is RECORDED: it must be the documented status error (or identical bits), not a hang and not garbage."""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from helpers import make_args, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+B, T = 48, 1274
+
+
+def _steps(n, foreign=None, window="step"):
+    from las import _hip, layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    from oracle import las_oracle as O
+    args = make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128,
+                     mode="add", lr=1e-3, grad_clip=5.0, label_smoothing=True, vocab_size=30)
+    xs, ys = synthetic_batch(B, T, 256, 30, seed=0, min_frac=0.834)
+    L.set_cell("lstm"); L.set_precision("bf16")
+    st = V.reset_default_store(device="cuda"); st.load(O.init_params(args, seed=0, cell="lstm"))
+    las = LAS(args, Listener, Speller, {})
+    las.train(xs, ys)                                   # (workspaces, shadows, registered sweeps)
+    torch.cuda.synchronize()
+    lib = _hip.lib()
+    words = torch.zeros(2 * (n + 1), dtype=torch.int32, device="cuda")  # per launch of the foreign kernel: [stop, resident]
+    other, third = torch.cuda.Stream(), torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    launched = [0]
+
+    def occupy():
+        w = words[2 * launched[0]:]
+        launched[0] += 1
+        nwg, lds, vg = foreign
+        _hip.check(lib.las_occupy(_hip.p(w), _hip.p(w[1:]), nwg, lds, vg, 20000, _hip.stream()), "las_occupy")
+
+    def release(k, after_main):
+        if after_main:
+            third.wait_stream(main)
+        with torch.cuda.stream(third):
+            _hip.set_word(words[2 * k:], 1)
+
+    err, losses = None, []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    real_bwd = _hip.rnn_seq_bwd
+    try:
+        if foreign is not None and window == "step":
+            with torch.cuda.stream(other):
+                occupy()
+            t0 = time.time()
+            while int(words[1].item()) < foreign[0]:    # every foreign workgroup is on the machine before the steps start
+                assert time.time() - t0 < 10, "the foreign kernel did not become resident"
+        if foreign is not None and window == "bptt":
+            state = {"armed": False}
+
+            def bwd(*a, **k):                           # in front of a step's FIRST BPTT sweep: the foreign kernel starts behind everything
+                if state["armed"]:                      # enqueued so far (both Speller loops) and stays until the step's last kernel
+                    state["armed"] = False
+                    other.wait_stream(main)
+                    with torch.cuda.stream(other):
+                        occupy()
+                return real_bwd(*a, **k)
+            _hip.rnn_seq_bwd = bwd
+        e0.record()
+        for i in range(n):
+            if foreign is not None and window == "bptt":
+                state["armed"] = True
+            losses.append(las.train(xs, ys)[0])
+            if foreign is not None and window == "bptt":
+                release(i, after_main=True)
+        e1.record()
+        main.synchronize()
+        las.check_status()
+    except RuntimeError as e:
+        err = str(e)
+    finally:
+        _hip.rnn_seq_bwd = real_bwd
+        for k in range(n + 1):
+            release(k, after_main=False)                # (whatever is still resident)
+        torch.cuda.synchronize()
+        try:
+            _hip.check_status()
+        except RuntimeError as e:
+            err = err or str(e)
+    ms = e0.elapsed_time(e1) / n if err is None else float("nan")
+    return [float(v) for v in losses], st.flat.clone(), ms, err
+
+
+def test_train_steps_beside_a_resident_foreign_kernel():
+    base_l, base_p, base_ms, err = _steps(3)
+    assert err is None
+    rec = {"test": "residency", "undisturbed_ms_per_step": round(base_ms, 3)}
+    must = (("bptt_32wg_64vgpr_16KB", (32, 16384, 64), "bptt"),          # a collective where the data-parallel schedule puts it
+            ("step_8wg_32vgpr_noLDS", (8, 0, 32), "step"),               # registers only, one per XCD, the whole step
+            ("step_32wg_32vgpr_noLDS", (32, 0, 32), "step"))
+    for name, foreign, window in must:
+        l, p, ms, err = _steps(3, foreign, window)
+        rec[name] = {"ms_per_step": None if err else round(ms, 3), "status": err}
+        assert err is None, (name, err)
+        assert l == base_l and torch.equal(p, base_p), name
+        assert ms < 1.5 * base_ms, (name, ms, base_ms)
+    # footprints the Speller's loop kernels cannot share a CU with: whatever happens must be REPORTED
+    for name, foreign in (("step_8wg_32vgpr_4KB", (8, 4096, 32)), ("step_8wg_64vgpr_noLDS", (8, 0, 64))):
+        l, p, ms, err = _steps(3, foreign, "step")
+        rec[name] = {"ms_per_step": None if err else round(ms, 3), "status": err[:160] if err else None}
+        if err is None:
+            assert l == base_l and torch.equal(p, base_p), name
+        else:
+            assert "status" in err and ("Speller loop" in err or "sweep" in err), err
+    print("residency:", json.dumps(rec))
+    path = os.environ.get("LAS_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
