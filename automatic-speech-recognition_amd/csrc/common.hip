@@ -93,6 +93,27 @@ extern "C" int las_occupy(const int* stop, int* resident, int n, int lds, int vg
     return 0;
 }
 
+// Stream-ordered wait until EVERY one of n device words has reached `need` (the progress words of a BPTT sweep that publishes how far its
+// d(pre-activation) has reached memory: las_rnn_seq_bwd_db_progress).  A CORRECTNESS dependency, unlike las_wait_announce: work enqueued
+// behind it reads what the words vouch for, so a time-out (max_us on the 100 MHz clock) stores `code` into status[0] -- the step is then
+// invalid and las_clip_adam skips it.
+__global__ __launch_bounds__(256) void wait_words_min_kernel(const int* words, int n, int need, long long max_ticks, int* status, int code) {
+    const long long t0 = wall_clock64();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        while (__hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            if (wall_clock64() - t0 > max_ticks) { if (status) status[0] = code; return; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+extern "C" int las_wait_words_min(const int* words, int n, int need, int max_us, int* status, int code, void* stream) {
+    LAS_ARG(words && n > 0 && max_us > 0, "las_wait_words_min: bad arguments");
+    hipLaunchKernelGGL(wait_words_min_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, words, n, need, (long long)max_us * 100, status, code);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 extern "C" int las_set_word(int* word, int value, void* stream) {
     LAS_ARG(word, "las_set_word: null pointer");
     hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, value);

@@ -545,14 +545,16 @@ struct WgradDir {
     const unsigned short* O; int shift;            // this direction's column block of the layer output; h_prev = frame t + shift (-1 / +1)
     const unsigned short* Z;                       // this direction's column block of d(pre-activation) [K, ldz] bf16
     float* dW;                                     // [I + H, N] fp32, accumulated
+    int t0;                                        // frame window (WIN kernels): virtual row k' = b nf + i is frame t0 + i of utterance b
 };
 struct WgradArgs {
     WgradDir d[2]; int ndir;
     int ldx, M1;                                   // M1 = columns of X that exist (multiple of 8)
     int ldo; long long obs;                        // layer output: row pitch, batch stride
     int ldz;
-    int T, K, N, nb1, nb2;                         // frames per utterance, K = B T, N = G H, row blocks from X / from the output
+    int T, K, N, nb1, nb2;                         // frames per utterance, K = B T (WIN: B nf), N = G H, row blocks from X / from the output
     float invT;
+    int nf; float invnf;                           // WIN: frames per utterance inside the window
     int splitk, kchunk;
     float* partial;                                // [ndir][splitk][(nb1 + nb2) * 128][N]
 };
@@ -561,6 +563,10 @@ struct WgradArgs {
 //  faster: 150 / 163 vs 144 us for a direction of the bottom layer.  The kernel is not waiting for memory: per k-step and CU the
 //  vector-memory path (32 KB), the LDS (64 KB of fragment reads + 32 KB of tile writes) and the matrix cores (2 x 512 clocks) are each
 //  25-50 % busy and overlap poorly with two workgroups per CU; four per CU (twice the k-chunks) is what helps the two-direction launch.)
+// WIN: only a WINDOW of nf frames per utterance is contracted (las_wgrad_ih_hh_window, round 5: the bottom layer's weight gradients follow
+// the BPTT sweep that is still producing dZ, window by window, instead of waiting for its end) -- the virtual row k' = b nf + i maps to frame
+// t0 + i of utterance b for all three operands; WIN = false is the whole-sequence kernel, unchanged.
+template <bool WIN>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
     constexpr int BM = 128, BN = 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
@@ -592,6 +598,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
             const int k = k0 + pk + 16 * u;
             bool on = k < kend;
             const unsigned short* src;
+            if (WIN) {
+                int b = (int)((float)k * g.invnf);                   // k = b nf + i  (k < 2^24: the float quotient is off by at most one)
+                if (b * g.nf > k) --b;
+                if ((b + 1) * g.nf <= k) ++b;
+                const int tf = gd.t0 + k - b * g.nf;                 // the frame
+                const long long kr = (long long)b * g.T + tf;        // its row in the [B T, .] operands
+                const bool onb = on;
+                if (!hsrc) {
+                    on = on && m0 + pc < g.M1;
+                    src = gd.X + (on ? kr : 0LL) * g.ldx + m0 + pc;
+                } else {
+                    const int tp = tf + gd.shift;
+                    on = on && tp >= 0 && tp < g.T;
+                    src = gd.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
+                }
+                const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : gd.Z);
+                ra[u] = on ? va : zero;
+                const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? gd.Z + kr * g.ldz + n0 + pc : gd.Z);
+                rb[u] = onb ? vb : zero;
+                continue;
+            }
             if (!hsrc) {
                 on = on && m0 + pc < g.M1;
                 src = gd.X + (long long)(on ? k : 0) * g.ldx + m0 + pc;
@@ -683,13 +710,15 @@ extern "C" size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, i
 
 // dir = 0 / 1: one direction (dW = that direction's gradient, dW2 ignored); dir = 2: BOTH in one launch (dW = forward, dW2 = backward
 // direction, X2 = the backward direction's input copy or NULL = X).  out / dZ: the [.., 2 H] / [.., 2 G H] tensors of both directions.
-extern "C" int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
-                               int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_impl(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                      int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream,
+                      bool win, int t0_fw, int t0_bw, int nf, int max_wgs) {
     LAS_ARG(X && out && dZ && dW && ws && dir >= 0 && dir <= 2 && (dir < 2 || dW2), "las_wgrad_ih_hh: null pointer / bad direction");
     LAS_ARG(B > 0 && T > 0 && I > 0 && H > 0 && H % 128 == 0 && GH % 128 == 0, "las_wgrad_ih_hh: needs H and G H multiples of 128 (I=%d H=%d GH=%d)", I, H, GH);
     LAS_ARG((long long)B * T < (1 << 24), "las_wgrad_ih_hh: B T must stay below 2^24");
     LAS_ARG(ldx % 8 == 0 && ldx >= (I + 7) / 8 * 8 && ld_out % 8 == 0 && lddz % 8 == 0 && out_bstride % 8 == 0 &&
             (((uintptr_t)X | (uintptr_t)X2 | (uintptr_t)out | (uintptr_t)dZ) & 15) == 0, "las_wgrad_ih_hh: operands must be 16-byte aligned with pitches that are multiples of 8");
+    LAS_ARG(!win || (nf > 0 && t0_fw >= 0 && t0_bw >= 0 && t0_fw + nf <= T && t0_bw + nf <= T), "las_wgrad_ih_hh_window: bad frame window");
     WgradArgs g;
     g.ndir = dir == 2 ? 2 : 1;
     for (int i = 0; i < g.ndir; ++i) {
@@ -698,23 +727,41 @@ extern "C" int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, co
         g.d[i].O = (const unsigned short*)out + (size_t)d * H; g.d[i].shift = d ? 1 : -1;
         g.d[i].Z = (const unsigned short*)dZ + (size_t)d * GH;
         g.d[i].dW = (dir == 2 && i == 1) ? dW2 : dW;
+        g.d[i].t0 = d ? t0_bw : t0_fw;
     }
     if (g.ndir == 1) g.d[1] = g.d[0];
     g.ldx = ldx; g.M1 = (I + 7) / 8 * 8; g.ldo = ld_out; g.obs = out_bstride; g.ldz = lddz;
-    g.T = T; g.K = B * T; g.N = GH; g.nb1 = cdiv(I, 128); g.nb2 = H / 128;
+    g.T = T; g.K = win ? B * nf : B * T; g.N = GH; g.nb1 = cdiv(I, 128); g.nb2 = H / 128;
     g.invT = 1.0f / (float)T;
+    g.nf = win ? nf : T; g.invnf = 1.0f / (float)g.nf;
     const int ny = g.nb1 + g.nb2, nt = ny * (GH / 128) * g.ndir;
     g.splitk = wgrad_split(I, H, GH, g.K, g.ndir, &g.kchunk);
+    if (win && max_wgs > 0 && nt * g.splitk > max_wgs) {      // a window that runs BESIDE a sweep: few workgroups, long k-chunks
+        int s_ = max_wgs / nt;
+        if (s_ < 1) s_ = 1;
+        g.kchunk = (int)((((long long)g.K + s_ - 1) / s_ + 31) / 32 * 32);
+        g.splitk = (g.K + g.kchunk - 1) / g.kchunk;
+    }
     g.partial = (float*)ws;
     LAS_ARG(ws_bytes >= (size_t)g.ndir * g.splitk * ny * 128 * GH * sizeof(float), "las_wgrad_ih_hh: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_tn_tr_kernel, dim3(nt * ((g.splitk + 7) / 8 * 8)), dim3(256), 0, st, g);
+    if (win) hipLaunchKernelGGL(wgrad_tn_tr_kernel<true>, dim3(nt * ((g.splitk + 7) / 8 * 8)), dim3(256), 0, st, g);
+    else     hipLaunchKernelGGL(wgrad_tn_tr_kernel<false>, dim3(nt * ((g.splitk + 7) / 8 * 8)), dim3(256), 0, st, g);
     LAS_LAUNCHED();
     int nb = cdiv((long long)g.ndir * ny * 128 * GH, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, g, I, H);
     LAS_LAUNCHED();
     return 0;
+}
+extern "C" int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                               int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_impl(X, X2, ldx, I, out, ld_out, out_bstride, dZ, lddz, B, T, H, GH, dir, dW, dW2, ws, ws_bytes, stream, false, 0, 0, 0, 0);
+}
+extern "C" int las_wgrad_ih_hh_window(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                                      int B, int T, int H, int GH, int dir, int t0_fw, int t0_bw, int nframes, int max_workgroups,
+                                      float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_impl(X, X2, ldx, I, out, ld_out, out_bstride, dZ, lddz, B, T, H, GH, dir, dW, dW2, ws, ws_bytes, stream, true, t0_fw, t0_bw, nframes, max_workgroups);
 }
 
 static bool g_tn_tr_on = true;

@@ -1227,7 +1227,13 @@ struct KsCfg {
 // by hsel = lane >> 5): one row x one unit pair per lane instead of two rows, half the loads / stores / transcendentals /
 // granule bytes per step, twice as many CUs per batch.
 // CH: dout arrives in chunks (a.dflag): a separate instantiation -- the kernel sits at the register limit and the plain one must not change
-template <int CELL, int UT, int P, int RB, bool CH = false>
+// PG (round 5, with CH): the sweep PUBLISHES its progress -- dZ leaves with agent-scope (write-through) stores, and every a.pstep steps each
+// member waits for its own stores and writes the step count into a.prog -- so that the layer's weight gradients can follow the sweep window
+// by window on another stream (las_rnn_seq_bwd_db_progress) instead of starting when it ends.  A separate instantiation, like CH.
+#ifndef LAS_PG_SC1_STORES
+#define LAS_PG_SC1_STORES 0
+#endif
+template <int CELL, int UT, int P, int RB, bool CH = false, bool PG = false>
 __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
     static_assert(RB == 16 || RB == 8, "row tile");
     using K = KsCfg<CELL, UT, P, RB>;
@@ -1569,9 +1575,29 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-                for (int q = 0; q < G; ++q) gprev[rr][(q * H + j * 16) / 2] = sv_z[q][j][rr];
+                for (int q = 0; q < G; ++q) {
+#if LAS_PG_SC1_STORES
+                    if constexpr (PG) __hip_atomic_store((unsigned*)(gprev[rr] + (q * H + j * 16) / 2), sv_z[q][j][rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+#endif
+                    gprev[rr][(q * H + j * 16) / 2] = sv_z[q][j][rr];
+                }
         KSTAMP(7);
         cur ^= 1;
+        if constexpr (PG) {
+            if ((s + 1) % a.pstep == 0 || s + 1 == T) {              // (uniform: every wave of the workgroup takes the branch)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's dZ stores of the steps so far have reached the XCD's L2 ...
+                __builtin_amdgcn_s_barrier();                          // ... and every other wave's of this member
+                if (tid == 0) {
+#if !LAS_PG_SC1_STORES
+                    // plain stores + ONE write-back of the XCD's dirty L2 lines per publication (4-byte agent-scope stores are a fabric write
+                    // each: the sweep ran 1.77 -> 2.09 ms with them)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+                    __hip_atomic_store(a.prog + (size_t)cl * P + pm, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 #ifdef LAS_PROF
     if (kprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
@@ -1789,7 +1815,12 @@ static int launch_bf16_rt(bool bwd, const RnnArgs& a0, int ntiles, hipStream_t s
                 // The K-split kernel keeps its weights in registers and needs 9-17 KB of LDS and half of the register file: other
                 // kernels' workgroups (the side stream's weight-gradient GEMMs) WOULD be scheduled onto the same CU and share its
                 // SIMDs, LDS and L1 with the dependent chain.  Asking for (nearly) the whole LDS keeps the CU to the sweep (ks_lds).
-                if (a.rb == 8 && a.dflag) {
+                if (a.rb == 8 && a.dflag && a.prog) {
+                    constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 8>::DZ_BYTES);
+                    static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true, true>, KZ);
+                    if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
+                    hipLaunchKernelGGL((rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true, true>), grid, dim3(256), KZ, st, a);
+                } else if (a.rb == 8 && a.dflag) {
                     constexpr int KZ = ks_lds(KsCfg<CELL, UT, P, 8>::DZ_BYTES);
                     static int attr = set_lds(rnn_seq_bwd_ks_kernel<CELL, UT, P, 8, true>, KZ);
                     if (attr != 0) { las_set_error("hipFuncSetAttribute(bwd ks) failed: %d", attr); return attr; }
@@ -1983,7 +2014,7 @@ static void seq_common_args(RnnArgs& a, int flags, int* status, int code) {
     a.dbg = nullptr; a.xbuf = nullptr; a.xcc = nullptr; a.bpart = nullptr; a.force_agent = 0; a.err = nullptr; a.sink = nullptr;
     a.ncl = a.ncl_pad = 0; a.ks_packed = 0; a.no_helpers = 0; a.rb = 16;
     a.warm = (flags & LAS_SEQ_NO_WARMERS) ? 0 : 1;
-    a.xflag = nullptr; a.xsc = 0; a.dflag = nullptr; a.dcp = 0; a.dTq = 0; a.dshift = 0;
+    a.xflag = nullptr; a.xsc = 0; a.dflag = nullptr; a.dcp = 0; a.dTq = 0; a.dshift = 0; a.prog = nullptr; a.pstep = 0;
     const int lg = (flags >> 16) & 0x1f;                    // LAS_SEQ_SPIN_LOG2(n): bound of the exchange spins = 2^n polls
     a.spin = lg ? (1 << lg) : LAS_SPIN_BUDGET_DEFAULT;
     a.status = status; a.status_code = code;
@@ -2126,11 +2157,42 @@ extern "C" int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void*
                                       dout_bstride, forget_bias, dbias_fw, dbias_bw, flags, status, nullptr, 0, 0, ws, ws_bytes, stream);
 }
 
+static int rnn_seq_bwd_db_impl(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                               const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                               float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                               const int* chunk_flag, int chunk_rows, int n_rows, int* progress, int progress_steps,
+                               void* ws, size_t ws_bytes, void* stream);
 extern "C" int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                           const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
                                           const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
                                           float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
                                           const int* chunk_flag, int chunk_rows, int n_rows, void* ws, size_t ws_bytes, void* stream) {
+    return rnn_seq_bwd_db_impl(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout, dout_bstride,
+                               forget_bias, dbias_fw, dbias_bw, flags, status, chunk_flag, chunk_rows, n_rows, nullptr, 0, ws, ws_bytes, stream);
+}
+// words a las_rnn_seq_bwd_db_progress launch publishes (one per cluster member), 0 if the configuration has no progress-publishing kernel
+extern "C" int las_rnn_seq_bwd_progress_words(int cell, int prec, int B, int H, int flags) {
+    if (!las_rnn_seq_bwd_chunks_ok(cell, prec, B, H, flags)) return 0;
+    return 2 * cdiv(B, 8) * pick_cluster(cell, H, flags);
+}
+extern "C" int las_rnn_seq_bwd_db_progress(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                           const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                                           const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                                           float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                                           const int* chunk_flag, int chunk_rows, int n_rows, int* progress, int progress_steps,
+                                           void* ws, size_t ws_bytes, void* stream) {
+    LAS_ARG(chunk_flag && progress && progress_steps > 0 && las_rnn_seq_bwd_progress_words(cell, prec, B, H, flags) > 0,
+            "las_rnn_seq_bwd_db_progress: needs a chunked upstream gradient and a configuration the progress-publishing kernel serves");
+    return rnn_seq_bwd_db_impl(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate, dout, ld_dout, dout_bstride,
+                               forget_bias, dbias_fw, dbias_bw, flags, status, chunk_flag, chunk_rows, n_rows, progress, progress_steps, ws, ws_bytes, stream);
+}
+static int rnn_seq_bwd_db_impl(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                               const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                               const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                               float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                               const int* chunk_flag, int chunk_rows, int n_rows, int* progress, int progress_steps,
+                               void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_common("las_rnn_seq_bwd", cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, cstate)) return rc;
     LAS_ARG(dout && ld_dout >= 2 * H, "las_rnn_seq_bwd: bad dout");
     LAS_ARG(prec != LAS_PREC_BF16 || !mfma_shape_ok(H) ||
@@ -2150,6 +2212,7 @@ extern "C" int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int 
             "las_rnn_seq_bwd_db_chunked: bad chunk geometry, or a configuration the chunk-aware kernel does not serve");
     a.dflag = chunk_flag; a.dTq = n_rows; a.dshift = (chunk_flag && n_rows != T) ? 1 : 0;
     for (int c = chunk_rows; c > 1; c >>= 1) ++a.dcp;
+    a.prog = progress; a.pstep = progress_steps;
 #ifdef LAS_PROF
     if (const char* e = getenv("LAS_DBG_PTR")) a.dbg = (long long*)strtoull(e, nullptr, 0);   // development build only
 #endif

@@ -32,6 +32,8 @@ struct RnnArgs {
                                              // *xflag = number of chunks complete (another stream's kernels write it); NULL: all there
     const int* dflag; int dcp, dTq, dshift;  // BPTT: dout arrives in chunks of 2^dcp producer rows (dTq per utterance; row = frame >> dshift) from
                                              // both ends of the sequence; *dflag = chunks complete
+    int* prog; int pstep;                    // BPTT (PG instances): member m of cluster c stores the number of sweep steps whose dZ has reached memory into
+                                             // prog[c * P + m] every pstep steps and at the end (agent scope, behind write-through dZ stores)
     int warm;                                // extra "L2 warmer" workgroups (one per cluster) are part of the grid
     int rb;                                  // batch rows per tile (16; 8 for the kernels that compact duplicated MFMA rows)
     const int* row_T;                        // forward, optional: frames of every batch row (<= T); a row's state and outputs are ZERO at t >= row_T[row]

@@ -145,6 +145,13 @@ _SIGS = {
     "las_rnn_seq_bwd_db_chunked": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
                                            c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_rnn_seq_bwd_progress_words": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "las_rnn_seq_bwd_db_progress": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong,
+                                            c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "las_wait_words_min": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "las_wgrad_ih_hh_window": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_rnn_seq_fwd_rows_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "las_rnn_seq_fwd_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong,
                                      c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -457,6 +464,25 @@ def wgrad_ih_hh(x, ldx, I, out, ld_out, out_bstride, gates, lddz, B, T, H, GH, d
     ws = workspace(dW.device, nb, _tag("wgrad"))
     check(lib().las_wgrad_ih_hh(p(x), p(x2), ldx, I, p(out), ld_out, out_bstride, p(gates), lddz, B, T, H, GH, d, p(dW), p(dW2),
                                 p(ws), ws.numel(), stream()), "las_wgrad_ih_hh")
+
+
+def wgrad_ih_hh_window(x, ldx, I, out, ld_out, out_bstride, gates, lddz, B, T, H, GH, d, t0_fw, t0_bw, nframes, max_wgs, dW, dW2=None, x2=None):
+    """las_wgrad_ih_hh over a window of `nframes` frames per utterance (forward direction from t0_fw, backward direction from t0_bw)"""
+    require_gpu(x, out, gates, dW, dW2, x2)
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and gates.dtype == torch.bfloat16 and dW.dtype == torch.float32
+    nb = int(lib().las_wgrad_ih_hh_workspace_bytes(I, H, GH, B, T, 2 if d == 2 else 1))
+    ws = workspace(dW.device, nb, _tag("wgrad"))
+    check(lib().las_wgrad_ih_hh_window(p(x), p(x2), ldx, I, p(out), ld_out, out_bstride, p(gates), lddz, B, T, H, GH, d, int(t0_fw), int(t0_bw),
+                                       int(nframes), int(max_wgs), p(dW), p(dW2), p(ws), ws.numel(), stream()), "las_wgrad_ih_hh_window")
+
+
+def wait_words_min(words, n, need, max_us=50000):
+    """stream-ordered wait until every one of words[0:n] is >= need; a time-out marks the step invalid through the status word (code 2)"""
+    check(lib().las_wait_words_min(p(words), int(n), int(need), int(max_us), p(status_word(words.device)), 2, stream()), "las_wait_words_min")
+
+
+def rnn_seq_bwd_progress_words(cell, prec, B, H, flags=None):
+    return int(lib().las_rnn_seq_bwd_progress_words(cell, prec, B, H, seq_flags if flags is None else flags))
 
 
 def skinny_pack(W, K, N, ldw=None, row0=0):
@@ -846,7 +872,7 @@ def rnn_seq_bwd_chunks_ok(cell, prec, B, H, flags=None):
 
 def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, out_bstride, cstate,
                 dout, ld_dout, dout_bstride, forget_bias=1.0, wf_off=0, wb_off=0, db_fw=None, db_bw=None, flags=None,
-                chunk_flag=None, chunk_rows=0, n_rows=0, prepared_ws=None):
+                chunk_flag=None, chunk_rows=0, n_rows=0, prepared_ws=None, progress=None, progress_steps=0):
     """db_fw / db_bw: optional [G*H] bias-gradient tensors, accumulated (+=) by the sweep itself.
     chunk_flag / chunk_rows / n_rows: dout is still being produced in chunks (las_rnn_seq_bwd_db_chunked)."""
     require_gpu(gates, whh_fw, whh_bw, out, cstate, dout)
@@ -855,6 +881,14 @@ def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
     fl = (seq_flags if flags is None else flags) | (SEQ_PREPARED if prepared_ws is not None else 0)
     fl |= next_announce() << 21                    # LAS_SEQ_ANNOUNCE: status_word[1] = this number once the sweep is resident
     _announce[0] += 1
+    if chunk_flag is not None and progress is not None:
+        with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
+            check(lib().las_rnn_seq_bwd_db_progress(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),
+                                                    c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
+                                                    p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(db_fw), p(db_bw),
+                                                    fl, p(status_word(gates.device)), p(chunk_flag), chunk_rows, n_rows,
+                                                    p(progress), int(progress_steps), p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db_progress")
+        return
     if chunk_flag is not None:
         with _timed("rnn_seq_bwd[T=%d,H=%d]" % (T, H)):
             check(lib().las_rnn_seq_bwd_db_chunked(cell, prec, B, T, H, p(gates), c_void_p(whh_fw.data_ptr() + 4 * wf_off),

@@ -125,6 +125,13 @@ DENSE_CHUNKS = os.environ.get("LAS_DENSE_CHUNK", "1") != "0"         # the dense
 DOUT_CHUNK_ROWS = int(os.environ.get("LAS_DOUT_CHUNK", "64"))        # backward hand-over in chunks of this many rows (a power of two); 0 = off
 FUSE_TANH_GRAD = not os.environ.get("LAS_NO_FUSE_TANH_GRAD")
 TAIL_ONE_LAUNCH = os.environ.get("LAS_TAIL_ONE_LAUNCH", "1") != "0"   # bottom layer's weight gradients: both directions in one launch on the launch stream
+# Round 5, measured and NOT on by default (profiles/r5_tail_follow.txt): the bottom layer's weight gradients in windows that follow the last BPTT
+# sweep on the side stream hide the 240 us tail launch -- and cost the sweep as much as they hide (14.04-14.15 ms per step with 3 ... 8
+# windows against 14.05-14.09 with the one launch behind the sweep; with 4-byte agent-scope dZ stores instead of one L2 write-back per
+# publication the sweep itself ran 1.77 -> 2.09 ms: 14.25).  LAS_TAIL_WINDOW=160 switches the windows on.
+TAIL_WINDOW = int(os.environ.get("LAS_TAIL_WINDOW", "0"))              # ... contracted in windows of this many sweep steps (0 = the whole sequence at once);
+TAIL_FOLLOW = os.environ.get("LAS_TAIL_FOLLOW", "1") != "0"            # ... that FOLLOW the running BPTT sweep on the side stream (round 5)
+TAIL_WINDOW_WGS = int(os.environ.get("LAS_TAIL_WINDOW_WGS", "192"))    # workgroups of a window that runs beside the sweep (all but the last)
 TAIL_TWO_STREAMS = not os.environ.get("LAS_NO_TAIL_TWO_STREAMS")   # bottom layer's weight gradients: one direction per auxiliary stream
 HOLD_SIDE = not os.environ.get("LAS_NO_HOLD_SIDE")   # side-stream weight gradients wait for the next sweep to be resident
 BEFORE_TAIL_HOOK = [None]   # callable(bottom layer's parameters) run right before the end-of-step tail is enqueued (data parallel)
@@ -420,6 +427,19 @@ def _chunk_flag(dev):
 
 
 _RING = 32
+_PROG = 512          # progress words of a BPTT sweep that publishes how far its dZ has reached memory (behind the ring: one fill zeroes both)
+
+
+def _progress_words(dev, n):
+    """n zeroed device words for las_rnn_seq_bwd_db_progress (zeroed with the flag ring by begin_step; by a fill otherwise)"""
+    ring = _flag_ring(dev)
+    w = ring[0][_RING:_RING + n]
+    if len(ring) > 3 and ring[3]:
+        ring[3] = False
+    else:
+        VARIANTS["flag_fills"] += 1
+        w.zero_()
+    return w
 
 
 def _flag_ring(dev):
@@ -428,7 +448,7 @@ def _flag_ring(dev):
     key = str(dev)
     ring = _CHUNK_FLAGS.get(key)
     if ring is None:
-        ring = _CHUNK_FLAGS[key] = [torch.zeros(_RING, dtype=torch.int32, device=dev), 0, 0]
+        ring = _CHUNK_FLAGS[key] = [torch.zeros(_RING + _PROG, dtype=torch.int32, device=dev), 0, 0, False]
     return ring
 
 
@@ -439,7 +459,7 @@ def _flag_ring(dev):
 # tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
 # that is timed must be the variant that is tested.
 VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0,
-            "prepared_sweeps": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
+            "prepared_sweeps": 0, "tail_windows": 0, "tail_follow": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
 
 
 def begin_step(dev):
@@ -451,7 +471,7 @@ def begin_step(dev):
         _hip.streams_overlap(dev)       # probed (once) HERE: a device whose streams cannot overlap raises before any hand-over state exists
     ring = _flag_ring(dev)
     ring[0].zero_()
-    ring[1], ring[2] = 0, _RING
+    ring[1], ring[2], ring[3] = 0, _RING, True
     _STEP_START[0] = torch.cuda.Event()
     _STEP_START[0].record()
 
@@ -746,12 +766,28 @@ class _BLSTM16(torch.autograd.Function):
         if serial:
             VARIANTS["serial"] += 1
             dc[3]()                          # serialised streams: every chunk in front of the (same, chunk-aware) sweep
+        # Round 5, the end-of-step tail: the bottom layer's weight gradients are contracted in WINDOWS of TAIL_WINDOW sweep steps (the
+        # forward direction's frames from the end of the sequence, the backward direction's from its start: the order in which the sweep
+        # produces dZ), and -- when the sweep can publish its progress -- each window runs on the side stream as soon as the sweep has
+        # passed it, instead of all of them behind the sweep (a 240 us launch at the bench geometry).  The windows are the ARITHMETIC
+        # (fixed by T and TAIL_WINDOW); following the sweep is only the schedule: without it the same launches run behind the sweep.
+        one_pass_ = WGRAD_ONE_PASS and T > 1 and H % 128 == 0 and GH % 128 == 0 and B * T < (1 << 24) and out.dtype == bf and x.dtype == bf
+        is_tail = (P4 is not None and all(_direct_ok(p) for p in P4) and not ctx.needs_input_grad[0] and not two and one_pass_ and TAIL_ONE_LAUNCH)
+        windows = is_tail and TAIL_WINDOW > 0 and T >= 3 * TAIL_WINDOW
+        follow, prog, nprog = False, None, 0
+        if windows and TAIL_FOLLOW and dc is not None and not serial:
+            nprog = _hip.rnn_seq_bwd_progress_words(_cellid(cell), prec, B, H)
+            if 0 < nprog <= _PROG:
+                follow, prog = True, _progress_words(dev, nprog)
+                before_sweep = torch.cuda.Event()
+                before_sweep.record()
         # gates: activated gates -> d(pre-activation) (bf16), in place; the sweep accumulates the bias gradients in fp32
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
                          db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None,
                          chunk_flag=None if dc is None else dc[0], chunk_rows=0 if dc is None else dc[1],
-                         n_rows=0 if dc is None else dc[2], prepared_ws=_prepared_ws(kfw, kbw, cell, H, GH, I0 * GH, B, True))
+                         n_rows=0 if dc is None else dc[2], prepared_ws=_prepared_ws(kfw, kbw, cell, H, GH, I0 * GH, B, True),
+                         progress=prog, progress_steps=TAIL_WINDOW)
         if dc is not None and not serial:
             dc[3]()                          # the other chunks: chain stream, enqueued behind the sweep's launch
             _hip.join_chain_stream()         # (they are finished when the sweep is; this orders later readers of dout)
@@ -846,7 +882,7 @@ class _BLSTM16(torch.autograd.Function):
 
             if produced is not None:
                 _hip.defer_side(lambda: side_work(produced))      # run by the next sweep's node, after its launch
-            elif TAIL_TWO_STREAMS and not ctx.needs_input_grad[0] and not two:
+            elif (TAIL_TWO_STREAMS or windows) and not ctx.needs_input_grad[0] and not two:
                 if BEFORE_TAIL_HOOK[0] is not None:
                     # data parallel: every gradient but this layer's is final once the work queued so far has run -- the
                     # all-reduce of that part of the bucket starts now, under the tail (las.las.LAS.train)
@@ -854,6 +890,28 @@ class _BLSTM16(torch.autograd.Function):
                 # bottom layer = the end-of-step tail, nothing left to hide behind.  Round 4: both directions in ONE launch on THIS
                 # stream (no event hand-over to another queue in front of it and behind it: 28 + 67 us of the 347 us tail).  Without the
                 # one-pass kernel: the two directions' products on two streams (a single one of them does not fill the chip)
+                if windows:
+                    S = TAIL_WINDOW
+                    nwin = (T + S - 1) // S
+                    VARIANTS["tail_windows"] += nwin
+                    VARIANTS["tail_follow"] += int(follow)
+
+                    def window(c):
+                        lo, n = c * S, min(S, T - c * S)
+                        _hip.wgrad_ih_hh_window(x, Ik, I0, out, 2 * H, Tp * 2 * H, gates, 2 * GH, B, T, H, GH, 2, T - lo - n, lo, n,
+                                                TAIL_WINDOW_WGS if c + 1 < nwin else 0, P4[0].grad, P4[2].grad, None)
+
+                    if follow:
+                        with _hip.on_side_stream(after=before_sweep):
+                            for t in (x, gates, out, prog):
+                                t.record_stream(_hip.side_stream())
+                            for c in range(nwin):
+                                _hip.wait_words_min(prog, nprog, min((c + 1) * S, T))
+                                window(c)
+                    else:
+                        for c in range(nwin):
+                            window(c)
+                    return (dx, None, None, None, None, None, None, None, None, dx_bw)
                 if one_pass and TAIL_ONE_LAUNCH:
                     wgrads_both(lambda d: P4[2 * d].grad, pair=True)
                     return (dx, None, None, None, None, None, None, None, None, dx_bw)

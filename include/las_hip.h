@@ -88,6 +88,13 @@ int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K,
  * 16-byte aligned operands, pitches multiples of 8.  Deterministic split-K over the frames (scratch from
  * las_wgrad_ih_hh_workspace_bytes(.., ndir), reduced in fixed order). */
 size_t las_wgrad_ih_hh_workspace_bytes(int I, int H, int GH, int B, int T, int ndir);
+/* The same contraction over a WINDOW of `nframes` frames per utterance: frames [t0_fw, t0_fw + nframes) for the forward direction's gradient,
+ * [t0_bw, t0_bw + nframes) for the backward direction's (dir as below); accumulates into dW / dW2 like las_wgrad_ih_hh, so consecutive
+ * windows that tile [0, T) give the whole gradient.  max_workgroups > 0 caps the launch (longer k-chunks, fewer split-K partials): a window
+ * that runs beside the sweep that is producing dZ should stay small.  Workspace: las_wgrad_ih_hh_workspace_bytes of the whole sequence. */
+int las_wgrad_ih_hh_window(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
+                           int B, int T, int H, int GH, int dir, int t0_fw, int t0_bw, int nframes, int max_workgroups,
+                           float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream);
 int las_wgrad_ih_hh(const void* X, const void* X2, int ldx, int I, const void* out, int ld_out, long long out_bstride, const void* dZ, int lddz,
                     int B, int T, int H, int GH, int dir, float* dW, float* dW2, void* ws, size_t ws_bytes, void* stream);
 
@@ -242,6 +249,19 @@ int las_rnn_seq_bwd_db(int cell, int prec, int B, int T, int H, void* gates,
  * las_set_word(chunk_flag, k+1).  The sweep reads a frame of dout only after *chunk_flag has reached the chunk of its row
  * (bounded wait -> LAS_SEQ_STATUS_BWD_TIMEOUT); chunk 0 must be complete in stream order in front of this call and is never waited for.  Only the 8-row K-split cluster kernel supports it (las_rnn_seq_bwd_chunks_ok). */
 int las_rnn_seq_bwd_chunks_ok(int cell, int prec, int B, int H, int flags);
+/* ... and a sweep that PUBLISHES ITS PROGRESS (round 5): d(pre-activation) leaves the sweep with agent-scope (write-through) stores, and every
+ * progress_steps sweep steps -- and at the end -- member m of cluster c stores the number of steps whose dZ has reached memory into
+ * progress[c * P + m] (las_rnn_seq_bwd_progress_words(...) caller-zeroed ints; 0 = the configuration has no such kernel).  After s steps the
+ * forward direction's dZ exists for frames [T - s, T), the backward direction's for [0, s): the layer's weight gradients can follow the sweep
+ * window by window on another stream (las_wait_words_min, las_wgrad_ih_hh_window) instead of starting when it ends -- the bottom layer's are
+ * the end-of-step tail of the reference's train step (las/las.py:272-283 can only run behind them). */
+int las_rnn_seq_bwd_progress_words(int cell, int prec, int B, int H, int flags);
+int las_rnn_seq_bwd_db_progress(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
+                                const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
+                                const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
+                                float forget_bias, float* dbias_fw, float* dbias_bw, int flags, int* status,
+                                const int* chunk_flag, int chunk_rows, int n_rows, int* progress, int progress_steps,
+                                void* ws, size_t ws_bytes, void* stream);
 int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* gates, const float* whh_fw,
                                const float* whh_bw, int ldw, const void* out, int ld_out, long long out_bstride,
                                const void* cstate, const void* dout, int ld_dout, long long dout_bstride,
@@ -388,6 +408,9 @@ int las_wait_word(const int* word, int value, int max_us, void* stream);
 /* ... for the announcement word itself (status[1] of LAS_SEQ_ANNOUNCE): passes once the word HAS REACHED n in the cyclic order of
  * 1..1023 -- also when later sweeps have announced themselves meanwhile (a hold enqueued late must not sit out its bound). */
 int las_wait_announce(const int* word, int n, int max_us, void* stream);
+/* Stream-ordered wait until EVERY one of n device words is >= need (las_rnn_seq_bwd_db_progress' progress words).  Unlike las_wait_announce this
+ * is a correctness dependency: on a time-out (max_us) `code` is stored into status[0] (may be NULL) -- the step is invalid, las_clip_adam skips it. */
+int las_wait_words_min(const int* words, int n, int need, int max_us, int* status, int code, void* stream);
 /* Diagnostics (round 5): a "foreign" kernel that stays RESIDENT -- n workgroups of 256 threads (workgroup L on XCD L % 8), `lds` bytes of LDS
  * and 32 or 64 VGPRs per lane each: the footprint of a collective's channel -- until *stop != 0 (or max_ms).  resident[0] (caller-zeroed)
  * counts the workgroups that have started.  The recurrent sweeps and the one-launch Speller loops need all THEIR workgroups resident at

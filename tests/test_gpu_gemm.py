@@ -268,3 +268,52 @@ def test_both_weight_gradients_in_one_pass_over_dz(I, H, G, B, T):
     _hip.wgrad_ih_hh(X2, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 1, b1)
     tol2 = 3e-6 * (B * T) ** 0.5 * max(1.0, a.abs().max().item(), b1.abs().max().item())     # (the pair splits the frames differently)
     assert (f2 - a).abs().max().item() < tol2 and (b2 - b1).abs().max().item() < tol2
+
+
+@pytest.mark.parametrize("I,H,G,B,T,S,cap", [(40, 256, 4, 6, 500, 160, 192), (240, 256, 4, 5, 333, 100, 0), (512, 256, 1, 7, 129, 40, 48), (64, 128, 4, 48, 330, 160, 192)])
+def test_weight_gradients_in_frame_windows_sum_to_the_whole_sequence(I, H, G, B, T, S, cap):
+    """las_wgrad_ih_hh_window (round 5): the windows a BPTT sweep completes one after the other -- the forward direction's frames from the
+    END of the sequence, the backward direction's from its START -- contracted one launch per window, both directions per launch, some with
+    a workgroup cap (few long k-chunks beside a running sweep): accumulated they are the whole-sequence gradient (float64 reference on the
+    same bf16 values), bit-identical run to run; h_prev crosses window borders (frame t - 1 / t + 1 of the NEIGHBOURING window)."""
+    from las import _hip
+    GH = G * H
+    Ik = (I + 63) // 64 * 64
+    Tp = T + (T % 2)
+    g = torch.Generator().manual_seed(I + H + B + T)
+    X = torch.zeros(B, T, Ik)
+    X[:, :, :I] = torch.randn(B, T, I, generator=g) * 0.5
+    X = X.cuda().to(torch.bfloat16)
+    out = (torch.randn(B, Tp, 2 * H, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    dZ = (torch.randn(B, T, 2 * GH, generator=g) * 0.5).cuda().to(torch.bfloat16)
+
+    def run():
+        dW = [torch.zeros(I + H, GH, device="cuda") for _ in range(2)]
+        nwin = (T + S - 1) // S
+        for c in range(nwin):
+            lo, n = c * S, min(S, T - c * S)
+            _hip.wgrad_ih_hh_window(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 2, T - lo - n, lo, n, cap if c + 1 < nwin else 0,
+                                    dW[0], dW[1])
+        return dW
+
+    got, again = run(), run()
+    for d in (0, 1):
+        assert torch.equal(got[d], again[d])
+        Zd = dZ[:, :, d * GH:(d + 1) * GH].double().cpu()
+        Od = out[:, :T, d * H:(d + 1) * H].double().cpu()
+        hp = torch.zeros(B, T, H, dtype=torch.float64)
+        if d == 0:
+            hp[:, 1:] = Od[:, :-1]
+        else:
+            hp[:, :-1] = Od[:, 1:]
+        ref = torch.zeros(I + H, GH, dtype=torch.float64)
+        ref[:I] = X[:, :, :I].double().cpu().reshape(B * T, I).t() @ Zd.reshape(B * T, GH)
+        ref[I:] = hp.reshape(B * T, H).t() @ Zd.reshape(B * T, GH)
+        tol = 3e-6 * (B * T) ** 0.5 * max(1.0, ref.abs().max().item())
+        assert (got[d].double().cpu() - ref).abs().max().item() < tol, d
+    # one direction alone (dir = 0 / 1) over the same windows
+    one = torch.zeros(I + H, GH, device="cuda")
+    for c in range((T + S - 1) // S):
+        lo, n = c * S, min(S, T - c * S)
+        _hip.wgrad_ih_hh_window(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 1, 0, lo, n, 0, one)
+    assert (one - got[1]).abs().max().item() < 3e-6 * (B * T) ** 0.5 * max(1.0, got[1].abs().max().item())

@@ -429,6 +429,71 @@ def test_prepared_workspace_sweeps_equal_self_packing_sweeps(cell, H, B, Bprep):
             assert torch.equal(a, b)
 
 
+def test_bptt_sweep_that_publishes_its_progress_is_followed_window_by_window():
+    """las_rnn_seq_bwd_db_progress + las_wait_words_min (round 5): the sweep stores d(pre-activation) with agent-scope stores and publishes,
+    every `ps` steps, how many steps have reached memory.  (1) dZ and the bias gradients are bit-identical to the chunked sweep without
+    progress; (2) a FOLLOWER on another stream, gated by las_wait_words_min, copies the frames each window vouches for WHILE the sweep is
+    still running -- forward direction [T - s, T), backward direction [0, s) after s steps: every copy must equal the final dZ (stale or
+    unwritten frames would not); (3) the words end at T."""
+    from las import _hip
+    B, T, H, c, ps = 24, 640, 256, 32, 64
+    GH = 4 * H
+    nw = _hip.rnn_seq_bwd_progress_words(1, 1, B, H)
+    assert nw == 2 * ((B + 7) // 8) * 4
+    g = torch.Generator().manual_seed(21)
+    xp = (torch.randn(B, T, 2, GH, generator=g) * 0.8).cuda().to(torch.bfloat16)
+    w = [((torch.rand(H, GH, generator=g) * 2 - 1) * 0.06).cuda() for _ in range(2)]
+    out = torch.zeros(B, T, 2 * H, device="cuda", dtype=torch.bfloat16)
+    cst = torch.zeros(B, T, 2, H, device="cuda", dtype=torch.bfloat16)
+    act = xp.clone()
+    _hip.rnn_seq_fwd(1, 1, B, T, H, act, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst)
+    dfull = (torch.randn(B, T, 2 * H, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    flag = torch.full((1,), 1000, dtype=torch.int32, device="cuda")             # every chunk of dout is there
+
+    def bptt(progress=None):
+        gz = act.clone()
+        db = [torch.zeros(GH, device="cuda") for _ in range(2)]
+        _hip.rnn_seq_bwd(1, 1, B, T, H, gz, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst, dfull, 2 * H, T * 2 * H, db_fw=db[0], db_bw=db[1],
+                         chunk_flag=flag, chunk_rows=c, n_rows=T, progress=progress, progress_steps=ps)
+        return gz, db
+
+    ref_z, ref_db = bptt()
+    torch.cuda.synchronize()
+    prog = torch.zeros(nw, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    nwin = T // ps
+    copies = torch.zeros(nwin, B, ps, 2, GH, device="cuda", dtype=torch.bfloat16)
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    gz = act.clone()
+    db = [torch.zeros(GH, device="cuda") for _ in range(2)]
+    ev.record()
+    _hip.rnn_seq_bwd(1, 1, B, T, H, gz, w[0], w[1], GH, out, 2 * H, T * 2 * H, cst, dfull, 2 * H, T * 2 * H, db_fw=db[0], db_bw=db[1],
+                     chunk_flag=flag, chunk_rows=c, n_rows=T, progress=prog, progress_steps=ps)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        for k in range(nwin):
+            _hip.wait_words_min(prog, nw, (k + 1) * ps)
+            copies[k, :, :, 0] = gz[:, T - (k + 1) * ps:T - k * ps, 0]           # forward direction: frames from the end
+            copies[k, :, :, 1] = gz[:, k * ps:(k + 1) * ps, 1]                  # backward direction: frames from the start
+    main.wait_stream(side)
+    torch.cuda.synchronize()
+    _hip.check_status()
+    assert torch.equal(gz, ref_z)
+    for a, b in zip(db, ref_db):
+        assert torch.equal(a, b)
+    assert int(prog.min()) == T and int(prog.max()) == T
+    for k in range(nwin):
+        assert torch.equal(copies[k, :, :, 0], ref_z[:, T - (k + 1) * ps:T - k * ps, 0]), ("fw", k)
+        assert torch.equal(copies[k, :, :, 1], ref_z[:, k * ps:(k + 1) * ps, 1]), ("bw", k)
+    # a follower whose words never arrive marks the step invalid instead of reading on
+    _hip.check(_hip.lib().las_wait_words_min(_hip.p(torch.zeros(4, dtype=torch.int32, device="cuda")), 4, 1, 200, _hip.p(_hip.status_word("cuda")), 2,
+                                             _hip.stream()), "las_wait_words_min")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        _hip.check_status()
+
+
 def test_wait_announce_passes_for_numbers_that_have_come_and_gone():
     """las_wait_announce: the hold of side-stream work on a sweep's announcement passes at once when that sweep -- or a later one -- has
     announced itself (cyclic numbers 1..1023), and sits out its bound otherwise (las_wait_word waits for equality only)."""

@@ -82,6 +82,7 @@ def test_b48_rows_equal_twelve_b4_batches():
 
 
 def _three_steps(args, p0, xs, ys, handovers=True, prepared=True):
+    from las import layers as L
     las, st = _fresh(args, p0)
     out = []
     for i in range(3):
@@ -90,6 +91,13 @@ def _three_steps(args, p0, xs, ys, handovers=True, prepared=True):
         # round 5: from a model's second step on, every sweep (4 forward + 4 BPTT) finds its weight pack and a clean exchange state
         # prepared by ONE launch at the start of the step (las_rnn_seq_prepare) -- no pack launch on the chain
         assert las.last_variants["prepared_sweeps"] == (8 if (prepared and i > 0) else 0), (i, las.last_variants)
+        if L.TAIL_WINDOW:
+            # the bottom layer's weight gradients in windows of TAIL_WINDOW sweep steps, which FOLLOW the last BPTT sweep on the side stream when
+            # it publishes its progress (with the hand-overs off: the same launches behind the sweep -- same arithmetic)
+            nwin = -(-T // L.TAIL_WINDOW)
+            assert las.last_variants["tail_windows"] == nwin and las.last_variants["tail_follow"] == (1 if handovers else 0), las.last_variants
+        else:
+            assert las.last_variants["tail_windows"] == 0
         if not out:
             torch.cuda.synchronize()
             g0 = st.flat_grad.clone()
@@ -124,6 +132,24 @@ def test_three_b48_steps_are_bit_reproducible_and_independent_of_the_hand_overs(
     finally:
         L.PREPARED_SWEEPS = saved_p
     assert l1 == l4 and torch.equal(g1, g4) and torch.equal(f1, f4), "prepared sweep workspaces changed the result"
+    # round 5, off by default (no gain, las/layers.py TAIL_WINDOW): the end-of-step tail in windows that FOLLOW the last BPTT sweep
+    # (las_rnn_seq_bwd_db_progress -> las_wait_words_min -> las_wgrad_ih_hh_window on the side stream).  The windows are the arithmetic,
+    # following is the schedule: with the hand-overs off the same window launches run behind the sweep -- bitwise equal; against the
+    # one-launch tail the split of the contraction differs (tolerance)
+    saved_w = L.TAIL_WINDOW
+    try:
+        L.TAIL_WINDOW = 160
+        f5, g5, l5 = _three_steps(args, p0, xs, ys)
+        saved = (L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS)
+        try:
+            L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = 0, 0, False, False
+            f6, g6, l6 = _three_steps(args, p0, xs, ys, handovers=False)
+        finally:
+            L.XPROJ_CHUNK_STEPS, L.DOUT_CHUNK_ROWS, L.HOLD_SIDE, L.TAIL_TWO_STREAMS = saved
+    finally:
+        L.TAIL_WINDOW = saved_w
+    assert l5 == l6 and torch.equal(g5, g6), "tail windows: following the sweep changed the result"
+    assert (g5 - g1).abs().max().item() <= 2e-3 * g1.abs().max().item() and abs(l5[0] - l1[0]) <= 1e-5 * max(1.0, abs(l1[0]))
     gerr = (g1 - g3).abs().max().item() / g1.abs().max().item()
     print("hand-overs on vs off: first-step gradient %.2e of max |g| (bitwise equal: %s), losses %s vs %s"
           % (gerr, torch.equal(g1, g3), l1, l3))
