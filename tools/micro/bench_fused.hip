@@ -6,6 +6,7 @@
 // (the beam-search short form of las_speller_fwd lives in loss_opt.hip; this harness never takes it)
 int las_lstm_cell_rows_launch(const LstmCellLaunch&, hipStream_t) { return -1; }
 int las_lstm_cell_rows_launch2(const LstmCellLaunch&, const LstmCellLaunch&, hipStream_t) { return -1; }
+int las_lstm_cell_check(const LstmCellLaunch&) { return -1; }
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
