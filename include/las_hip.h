@@ -175,6 +175,10 @@ enum { LAS_SEQ_AGENT_GRANULES = 1, LAS_SEQ_NO_KSPLIT = 2, LAS_SEQ_NO_HELPER_WAVE
 #define LAS_SEQ_ANNOUNCE(n) (((n) & 0x3ff) << 21)
 enum { LAS_SEQ_STATUS_OK = 0, LAS_SEQ_STATUS_FWD_TIMEOUT = 1, LAS_SEQ_STATUS_BWD_TIMEOUT = 2 };
 
+/* Workspace of a sweep.  MANDATORY for every clustered kernel: LAS_PREC_BF16 with H in {64,128,256,512}, and -- since round 4 -- LAS_PREC_F32 with
+ * those H as well (the exact-fp32 MFMA sweeps; a NULL / smaller `ws` is refused with "workspace too small", it does not fall back).  Only the
+ * round-1 VALU kernels (other H, or LAS_SEQ_F32_VALU) run the forward sweep without one.  The clustered kernels also need all their workgroups
+ * resident at once: on a shared / partitioned device they report LAS_SEQ_STATUS_* instead (bounded spins); pass LAS_SEQ_F32_VALU there. */
 size_t las_rnn_seq_workspace_bytes(int cell, int prec, int H, int B);
 /* Everything a speed-mode sweep does in front of its persistent kernel depends on the weights only: W_hh of both directions re-packed into
  * MFMA fragment order (forward, BPTT and K-split BPTT layouts differ) and the cleared exchange state of the workspace.  The reference
