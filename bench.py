@@ -664,8 +664,9 @@ def main():
                                    "mfma_TFLOPps": round(STEP_FLOPS_PER_UTT * per_gpu / 1e12, 2),
                                    "frac_mfma": round(STEP_FLOPS_PER_UTT * per_gpu / 1e12 / MFMA_PEAK_TFLOPS, 5),
                                    "per_utterance": "115 MB, 34.3 GFLOP (BASELINE.md section 3; lstm, T=1274, U=200)"},
-                    "note": "sequential-dependency bound: every launch is T dependent steps (SURVEY 8(d)); the launch time "
-                            "includes the W_hh pack + memset enqueued with it; traffic = FETCH_SIZE x2 + WRITE_SIZE of the "
+                    "note": "sequential-dependency bound: every launch is T dependent steps (SURVEY 8(d)); since round 5 the W_hh packs and "
+                            "exchange-state clears of a step's eight sweeps are ONE side-stream launch at the start of the step "
+                            "(las_rnn_seq_prepare), no longer part of a launch's span; traffic = FETCH_SIZE x2 + WRITE_SIZE of the "
                             "recorded rocprofv3 --pmc passes when they were made from this kernel source, else null"}
         out = {
             "metric": "utterances/sec (train step) LibriSpeech-360 char-LAS @1/2/4/8 GPU; dev-clean WER",

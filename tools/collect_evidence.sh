@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the per-round measurement evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_evidence.sh r4        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,phase_stamps_insitu.txt,
+#   tools/collect_evidence.sh r5        -> gpurun_out/<prefix>_{bench.json,phases.txt,kernel_stats.csv,pmc.csv,pmc.json,phase_stamps.txt,phase_stamps_insitu.txt,
 #                                          timeline.txt,bucket_sweep.txt,decode_{bench.json,kernel_stats.csv,pmc.csv,pmc.json},speller_phase_stamps.txt,
 #                                          speller_loc_phase_stamps.txt,bench_config3.json,config3_kernel_stats.csv}
 # (build first: make -C automatic-speech-recognition_amd/csrc all prof; hipcc ... -DLAS_ROW_STAMPS tools/micro/bench_fused.hip -o tools/micro/bin/bench_fused_stamps)
@@ -58,6 +58,12 @@ python3 bench.py --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline --no-decode 
 # ---- the cell the reference builds (BasicRNNCell), speed mode: kernel trace
 rocprofv3 --kernel-trace --stats -d /tmp/kt_rnn_$P -o b -- python3 bench.py --cell rnn --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_rnn_kt.log 2>&1
 python3 tools/kernel_stats.py /tmp/kt_rnn_$P 3 gpurun_out/${P}_rnn_kernel_stats.csv > /dev/null
+# ---- round 5: the decode step at decode.py's batch (64 utterances x beam 16 = 1024 rows): consecutive kernels of replayed steps
+(cd /tmp && NUTT=64 rocprofv3 --kernel-trace --stats -d /tmp/kt_dec64_$P -o b -- python3 $OLDPWD/tools/probe_decode_step.py > $OLDPWD/gpurun_out/${P}_decode_b64_kt.log 2>&1)
+python3 tools/rocpd_summary.py "$(find /tmp/kt_dec64_$P -name '*_results.db' | head -1)" gpurun_out/${P}_decode_b64_kernel_stats.csv > /dev/null 2>&1
+# ---- round 5: are small launches on the chain what the profiler says they are?  (prepared sweeps vs self-packing, un-profiled, alternating)
+bash tools/ab_bench.sh LAS_NO_PREPARED_SWEEPS=0 LAS_NO_PREPARED_SWEEPS=1 3 60 > gpurun_out/${P}_ab_prepared.txt 2>&1
+python3 tools/probe_host_ahead.py > gpurun_out/${P}_host_ahead.txt 2>&1
 # ---- eight ranks' host side on this box (one GPU: the steps run one rank at a time behind command-processor gates)
 timeout 900 python3 tools/host_time_ranks.py --ranks 8 --steps 4 --out gpurun_out/${P}_host_ranks_8.json > /dev/null 2>&1
 # ---- the whole GPU suite as the driver runs it (one process, -rs: every skip with its reason)
