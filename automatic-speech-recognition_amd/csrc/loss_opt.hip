@@ -65,6 +65,55 @@ __global__ __launch_bounds__(1024) void sum2_kernel(const float* __restrict__ a,
 
 extern "C" size_t las_ce_loss_workspace_bytes(int B, int U) { return (size_t)2 * B * U * sizeof(float) + 256; }
 
+// The same row with the logits kept in REGISTERS (round 5): a subword vocabulary (V = 5000, BASELINE configs[3]) made the three passes of
+// ce_rows_kernel four trips through memory -- 183 MB of logits read three times and written once, 170 us on the dependency chain between the
+// two Speller loops; here a lane loads its NV = ceil(V / 64) values once (all loads in flight together), the statistics and the gradient come
+// from registers.  Same arithmetic in the same order: bit-identical to ce_rows_kernel.
+template <int NV>
+__global__ __launch_bounds__(256) void ce_rows_reg_kernel(const float* __restrict__ logits, long long sb, long long st,
+                                                          const int* __restrict__ y, int ldy, int B, int U, int V, float eps,
+                                                          int smooth, const float* __restrict__ scale_ptr,
+                                                          float* __restrict__ dlogits, float* __restrict__ row_ce,
+                                                          float* __restrict__ row_mask) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * U) return;
+    const int b = (int)(row / U), t = (int)(row % U);
+    const float* lp = logits + b * sb + t * st;
+    const int label = y[(long long)b * ldy + t];
+    const float mask = (label != 0 || (smooth & 2)) ? 1.f : 0.f;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int k = lane + 64 * i; v[i] = lp[k < V ? k : V - 1]; }
+    float m = -INFINITY, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (lane + 64 * i < V) { m = fmaxf(m, v[i]); lsum += v[i]; }
+    m = wave_max(m);
+    lsum = wave_sum(lsum);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (lane + 64 * i < V) se += expf(v[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    const float e = (smooth & 1) ? eps : 0.f;
+    const float ly = (label >= 0 && label < V) ? lp[label] : 0.f;
+    const float ce = lse - (1.f - e) * ly - (e / V) * lsum;
+    if (lane == 0) { row_ce[row] = ce * mask; row_mask[row] = mask; }
+    if (dlogits) {
+        const float sc = scale_ptr[0] * mask;
+        float* dp = dlogits + b * sb + t * st;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = lane + 64 * i;
+            if (k < V) {
+                const float p = expf(v[i] - lse);
+                const float soft = (k == label ? (1.f - e) : 0.f) + e / V;
+                dp[k] = sc * (p - soft);
+            }
+        }
+    }
+}
+
 extern "C" int las_ce_loss(const float* logits, long long sb, long long st, const int* y, int ldy, int B, int U, int V,
                            float epsilon, int smooth, float* sums, const float* scale_ptr, float* dlogits, void* ws,
                            size_t ws_bytes, void* stream) {
@@ -74,7 +123,15 @@ extern "C" int las_ce_loss(const float* logits, long long sb, long long st, cons
     hipStream_t s = (hipStream_t)stream;
     float* row_ce = (float*)ws;
     float* row_mask = row_ce + (size_t)B * U;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv((long long)B * U, 4)), dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V,
+    const dim3 cg(cdiv((long long)B * U, 4));
+    if (V > 1024 && V <= 64 * 40)
+        hipLaunchKernelGGL(ce_rows_reg_kernel<40>, cg, dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V, epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
+    else if (V > 1024 && V <= 64 * 80)
+        hipLaunchKernelGGL(ce_rows_reg_kernel<80>, cg, dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V, epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
+    else if (V > 1024 && V <= 64 * 128)
+        hipLaunchKernelGGL(ce_rows_reg_kernel<128>, cg, dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V, epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
+    else
+    hipLaunchKernelGGL(ce_rows_kernel, cg, dim3(256), 0, s, logits, sb, st, y, ldy, B, U, V,
                        epsilon, smooth, scale_ptr, dlogits, row_ce, row_mask);
     LAS_LAUNCHED();
     LAS_ARG(!(smooth & 4) || scale_ptr, "las_ce_loss: bit 2 of smooth (write sums, sums[2] = scaled loss) needs scale_ptr");

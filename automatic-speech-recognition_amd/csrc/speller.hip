@@ -2647,6 +2647,7 @@ __global__ __launch_bounds__(256) void dkeys_loc_kernel(DecDev a, float* __restr
     float4 dwf[LC];
 #pragma unroll
     for (int c = 0; c < LC; ++c) dwf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
     for (int t = 0; t < U; ++t) {
         const float de = a.dE[((size_t)t * B + b) * Tp + ttc];
         const float4 q4 = reinterpret_cast<const float4*>(a.Q + ((size_t)t * B + b) * A)[a4];
@@ -2828,7 +2829,8 @@ __global__ __launch_bounds__(256) void dkeys_kernel(DecDev a, float* __restrict_
         const unsigned short* kr = a.keysbf + ((size_t)b * Tp + tt) * A + a4 * 4;
         const float k0 = bf2f(kr[0]), k1 = bf2f(kr[1]), k2 = bf2f(kr[2]), k3 = bf2f(kr[3]);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < U; ++t) {
+#pragma unroll 8
+        for (int t = 0; t < U; ++t) {                  // (unrolled: eight steps' loads in flight -- the loop was bound by one L2 round trip per step)
             const float de = a.dE[((size_t)t * B + b) * Tp + tt];
             const float4 q4 = reinterpret_cast<const float4*>(a.Q + ((size_t)t * B + b) * A)[a4];
             const float v0 = tanh_fast(k0 + q4.x), v1 = tanh_fast(k1 + q4.y), v2 = tanh_fast(k2 + q4.z), v3 = tanh_fast(k3 + q4.w);

@@ -115,3 +115,35 @@ def test_greedy_inference_v5000_argmax_on_device():
     logits, y_hat = las.inference(xs)
     assert (logits.cpu() - lo).abs().max().item() < 5e-4
     assert torch.equal(y_hat.cpu(), yo)
+
+
+@pytest.mark.parametrize("V,smooth", [(5000, True), (2000, False), (8000, True), (1500, True), (30, True)])
+def test_ce_loss_with_the_row_in_registers_matches_float64(V, smooth):
+    """las_ce_loss (reference las/las.py:320-333 + las/utils.py:5-12): from V > 1024 on a row's logits are read ONCE and kept in registers
+    (ce_rows_reg_kernel<40 | 80 | 128>, round 5: the subword vocabulary's 170 us between the two Speller loops -> 105); the loss, the
+    label-smoothed gradient, PAD masking and the token normalisation against float64 on the same logits."""
+    from las.las import _ce_loss
+    B, U = 5, 7
+    g = torch.Generator().manual_seed(V)
+    logits_tm = (torch.randn(U, B, V, generator=g) * 2.0).cuda()            # time-major buffer, consumed through its [B, U, V] view
+    lb = logits_tm.permute(1, 0, 2)
+    y = torch.randint(1, V, (B, U), generator=g).to(torch.int32)
+    y[1, 4:] = 0
+    y[3, 2:] = 0                                                             # PAD positions do not count
+    y = y.cuda()
+    n = (y != 0).sum().to(torch.float32)
+    scale = (1.0 / (n + 1e-9)).reshape(1)
+    loss, dl, sums = _ce_loss(lb, y, V, smooth, scale)
+    torch.cuda.synchronize()
+    ld = lb.double().cpu()
+    logp = torch.log_softmax(ld, -1)
+    eps = 0.01 if smooth else 0.0
+    onehot = torch.zeros(B, U, V, dtype=torch.float64)
+    onehot.scatter_(2, y.cpu().long().unsqueeze(-1), 1.0)
+    soft = (1 - eps) * onehot + eps / V
+    mask = (y.cpu() != 0).double()
+    ce = -(soft * logp).sum(-1) * mask
+    ref = ce.sum() / (mask.sum() + 1e-9)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    gref = (torch.softmax(ld, -1) - soft) * mask.unsqueeze(-1) / (mask.sum() + 1e-9)
+    assert (dl.double().cpu() - gref).abs().max().item() <= 2e-7

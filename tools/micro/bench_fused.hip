@@ -26,7 +26,8 @@ template <class T> static T* dalloc(size_t n, float fill = 0.01f) {
 int main(int argc, char** argv) {
     const int nap = argc > 1 ? atoi(argv[1]) : 0;
     const bool LOCM = argc > 2 && !strcmp(argv[2], "loc");          // location-aware attention (K = 201, C = 10) in the loop kernels
-    const int B = 48, Tp = 160, Hd = 512, A = 128, D = 512, NL = 1, E = 128, V = 30, U = 191, G = 4;
+    const int Tp = argc > 3 ? atoi(argv[3]) : 160;                   // encoder frames per utterance (timing experiments)
+    const int B = 48, Hd = 512, A = 128, D = 512, NL = 1, E = 128, V = 30, U = 191, G = 4;
     const int I0D = E + Hd + D, GD = G * D;
     DecDev d; memset(&d, 0, sizeof(d));
     d.B = B; d.Tp = Tp; d.Hd = Hd; d.A = A; d.D = D; d.NL = NL; d.E = E; d.V = V; d.U = U; d.mode = LAS_ATT_ADD; d.fb = 1.f;
