@@ -772,6 +772,10 @@ static bool g_f32_valu = false;      // parity-mode products through the round-1
 #ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_f32_valu(int on) { g_f32_valu = on != 0; }
 #endif
+static bool g_f32_fast_ld = true;    // the exact-fp32 kernels' branch-free tile loader (tile_gload_f32fast)
+#ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
+extern "C" void las_dev_gemm_f32_fast_ld(int on) { g_f32_fast_ld = on != 0; }
+#endif
 static bool g_zgroup_on = true;
 #ifdef LAS_DEV   // development builds only (make prof): A/B switch, not part of the shipping library
 extern "C" void las_dev_gemm_zgroup(int on) { g_zgroup_on = on != 0; }     // development switch (A/B measurements)
@@ -836,7 +840,42 @@ __device__ __forceinline__ void tile_sstore_f32(float* S, const TileRegs<ROWS, N
     }
 }
 
-template <int TM, int TN>
+// Branch-free form of tile_gload for the exact-fp32 kernels (same register layout, same zero fill, so the arithmetic is unchanged):
+// 16-byte loads legal, whole chunks inside or outside the operand (K % 4 == 0 for a k-contiguous operand, R % 4 == 0 for a row-
+// contiguous one), no contraction mask.  The generic loader's per-chunk branches each end in s_waitcnt vmcnt(0) -- a k-tile's eight
+// chunk loads were eight round trips in a row, 44-57 % of the fp32 matrix peak (round 4's r4_f32_gemm_shapes.txt); here they are
+// all in flight before the first is needed.  KC: contraction index contiguous in memory.
+template <int ROWS, int NT, bool KC>
+__device__ __forceinline__ void tile_gload_f32fast(TileRegs<ROWS, NT>& r, const float* __restrict__ X, long long rs, long long ks,
+                                                   int row0, int k0, int R, int Kend) {
+    constexpr int NCH = ROWS * 8, RQ = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
+        const int c = threadIdx.x + i * NT;
+        if (NCH % NT != 0 && c >= NCH) { r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        if (KC) {
+            const int row = c >> 3, kq = (c & 7) * 4;
+            const int gr = row0 + row, gk = k0 + kq;
+            const bool on = gr < R && gk < Kend;
+            ld4(r.v[i], X + (on ? (long long)gr * rs + gk : 0ll), on);
+        } else {
+            const int k = c / RQ, rq = (c % RQ) * 4;
+            const int gr = row0 + rq, gk = k0 + k;
+            const bool on = gk < Kend && gr < R;
+            ld4(r.v[i], X + (on ? (long long)gk * ks + gr : 0ll), on);
+        }
+    }
+}
+template <int ROWS, int NT, int LD, bool IS_A>
+__device__ __forceinline__ void tile_gload_f32(TileRegs<ROWS, NT>& r, const float* __restrict__ X, long long rs, long long ks,
+                                               int row0, int k0, int R, int Kend, int vec, int mperiod, int mskip) {
+    if (LD == 0) tile_gload<ROWS, NT>(r, X, rs, ks, row0, k0, R, Kend, vec, mperiod, mskip);
+    else if (((LD - 1) >> (IS_A ? 0 : 1)) & 1) tile_gload_f32fast<ROWS, NT, true>(r, X, rs, ks, row0, k0, R, Kend);
+    else tile_gload_f32fast<ROWS, NT, false>(r, X, rs, ks, row0, k0, R, Kend);
+}
+
+// LD: 0 = generic loader; 1 + (A k-contiguous) + 2 (B k-contiguous) = branch-free loader (las_gemm_dt checks the conditions)
+template <int TM, int TN, int LD = 0>
 __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
     __shared__ __attribute__((aligned(16))) float lds[32 * (PA + PB)];
@@ -864,8 +903,8 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
     TileRegs<BM, NT> ra;
     TileRegs<BN, NT> rb;
     if (kbeg < kend) {
-        tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
-        tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend, g.vecB, 0, 0);
+        tile_gload_f32<BM, NT, LD, true>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload_f32<BN, NT, LD, false>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend, g.vecB, 0, 0);
     }
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         __syncthreads();
@@ -873,8 +912,8 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
         tile_sstore_f32<BN, NT>(Bs, rb, g.ksB);
         __syncthreads();
         if (k0 + 32 < kend) {
-            tile_gload<BM, NT>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
-            tile_gload<BN, NT>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend, g.vecB, 0, 0);
+            tile_gload_f32<BM, NT, LD, true>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+            tile_gload_f32<BN, NT, LD, false>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend, g.vecB, 0, 0);
         }
         const float* ap = As + lk * PA + wm * TM * 16 + li;
         const float* bp = Bs + lk * PB + wn * TN * 16 + li;
@@ -920,7 +959,7 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
 // K in 32-wide stages whose loads it waits for).  Here a workgroup owns 64 x 32 outputs and a stage is 96 k: nine 16-byte
 // loads per thread in flight, the four waves split the stage's k-steps (6 each), their partial tiles meet in LDS in fixed order;
 // with scratch the contraction is also cut into K slices over blockIdx.z (las_gemm_dt), reduced in fixed order afterwards.
-template <int TMS>
+template <int TMS, int LD = 0>
 __global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 32, NQ = 3, BK = 32 * NQ, NT = 256, PA = F32Lds<BM>::PITCH, PB = F32Lds<BN>::PITCH;
     __shared__ __attribute__((aligned(16))) float lds[BK * (PA + PB)];          // 51 KB
@@ -949,8 +988,8 @@ __global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
     TileRegs<BN, NT> rb[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, kbeg + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
-        tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, kbeg + 32 * q, g.N, kend, g.vecB, 0, 0);
+        tile_gload_f32<BM, NT, LD, true>(ra[q], A, g.rsA, g.ksA, m0, kbeg + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+        tile_gload_f32<BN, NT, LD, false>(rb[q], B, g.rsB, g.ksB, n0, kbeg + 32 * q, g.N, kend, g.vecB, 0, 0);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
@@ -963,8 +1002,8 @@ __global__ __launch_bounds__(256) void gemm_mf32_skinny_kernel(GemmArgs g) {
         if (k0 + BK < kend) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                tile_gload<BM, NT>(ra[q], A, g.rsA, g.ksA, m0, k0 + BK + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
-                tile_gload<BN, NT>(rb[q], B, g.rsB, g.ksB, n0, k0 + BK + 32 * q, g.N, kend, g.vecB, 0, 0);
+                tile_gload_f32<BM, NT, LD, true>(ra[q], A, g.rsA, g.ksA, m0, k0 + BK + 32 * q, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
+                tile_gload_f32<BN, NT, LD, false>(rb[q], B, g.rsB, g.ksB, n0, k0 + BK + 32 * q, g.N, kend, g.vecB, 0, 0);
             }
         }
         const float* ap = As + (w * (BK / 4) + lk) * PA + li;
@@ -1115,6 +1154,35 @@ static int launch_bf16(const GemmArgs& g, int zdim, hipStream_t st) {
     return 0;
 }
 
+template <int TM, int TN>
+static void launch_mf32(const GemmArgs& g, int ld, dim3 grid, hipStream_t st) {
+    switch (ld) {
+        case 1: hipLaunchKernelGGL((gemm_mf32_kernel<TM, TN, 1>), grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_mf32_kernel<TM, TN, 2>), grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL((gemm_mf32_kernel<TM, TN, 3>), grid, dim3(256), 0, st, g); break;
+        case 4: hipLaunchKernelGGL((gemm_mf32_kernel<TM, TN, 4>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_mf32_kernel<TM, TN, 0>), grid, dim3(256), 0, st, g); break;
+    }
+}
+template <int TMS>
+static void launch_mf32_skinny_t(const GemmArgs& g, int ld, dim3 grid, hipStream_t st) {
+    switch (ld) {
+        case 1: hipLaunchKernelGGL((gemm_mf32_skinny_kernel<TMS, 1>), grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_mf32_skinny_kernel<TMS, 2>), grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL((gemm_mf32_skinny_kernel<TMS, 3>), grid, dim3(256), 0, st, g); break;
+        case 4: hipLaunchKernelGGL((gemm_mf32_skinny_kernel<TMS, 4>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_mf32_skinny_kernel<TMS, 0>), grid, dim3(256), 0, st, g); break;
+    }
+}
+static void launch_mf32_skinny(const GemmArgs& g, int ld, int row_tiles, dim3 grid, hipStream_t st) {
+    switch (row_tiles) {
+        case 1: launch_mf32_skinny_t<1>(g, ld, grid, st); break;
+        case 2: launch_mf32_skinny_t<2>(g, ld, grid, st); break;
+        case 3: launch_mf32_skinny_t<3>(g, ld, grid, st); break;
+        default: launch_mf32_skinny_t<4>(g, ld, grid, st); break;
+    }
+}
+
 // Scratch the deterministic split-K of las_gemm would use for this product if it could have all it wants (never more than
 // LAS_GEMM_WS_CAP: beyond that the split degree is cut to fit, with any workspace): tile counts as in las_gemm_dt below.
 extern "C" size_t las_gemm_workspace_bytes(int prec, int M, int N, int K, int batch) {
@@ -1179,6 +1247,8 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
     const bool fastA = g.vecA && (g.ksA == 1 ? (K % 4 == 0) : (M % 4 == 0 && M >= 4));
     const bool fastB = g.vecB && (g.ksB == 1 ? (K % 4 == 0) : (N % 4 == 0 && N >= 4));
     const bool fast_ok = prec == LAS_PREC_BF16 && fastA && fastB && a_mask_period == 0 && K > 0;
+    // exact-fp32 kernels: the same conditions select their branch-free loader (1 + A k-contiguous + 2 B k-contiguous; 0 = generic)
+    const int f32_ld = (g_f32_fast_ld && fastA && fastB && a_mask_period == 0 && K > 0) ? 1 + (g.ksA == 1 ? 1 : 0) + (g.ksB == 1 ? 2 : 0) : 0;
     if (prec == LAS_PREC_F32) { cfg = 0; BM = BN = (M < 128 || N < 128) ? 64 : 128; }    // exact-fp32 MFMA tiles
     else if (M <= 48 && !(fast_ok && K >= 4096)) { cfg = 3; BM = 48; BN = 64; }   // tall contractions: 64-row fast tiles win
     else if (M < 128 || N < 128) { cfg = 2; BM = 64; BN = 64; }
@@ -1259,17 +1329,9 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
         case 0: {
             dim3 grid(cdiv(N, BN), cdiv(M, BM), zdim);
             if (g_f32_valu) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(N, 64), cdiv(M, 64), zdim), dim3(256), 0, st, g);
-            else if (M <= 64) {
-                const dim3 sg(cdiv(N, 32), 1, zdim);
-                switch (cdiv(M, 16)) {
-                    case 1: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<1>, sg, dim3(256), 0, st, g); break;
-                    case 2: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<2>, sg, dim3(256), 0, st, g); break;
-                    case 3: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<3>, sg, dim3(256), 0, st, g); break;
-                    default: hipLaunchKernelGGL(gemm_mf32_skinny_kernel<4>, sg, dim3(256), 0, st, g); break;
-                }
-            }
-            else if (BM == 128) hipLaunchKernelGGL((gemm_mf32_kernel<4, 4>), grid, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL((gemm_mf32_kernel<2, 2>), grid, dim3(256), 0, st, g);
+            else if (M <= 64) launch_mf32_skinny(g, f32_ld, cdiv(M, 16), dim3(cdiv(N, 32), 1, zdim), st);
+            else if (BM == 128) launch_mf32<4, 4>(g, f32_ld, grid, st);
+            else launch_mf32<2, 2>(g, f32_ld, grid, st);
         } break;
         case 1: launch_bf16<2, 2, 4, 4>(g, zdim, st); break;
         case 2: launch_bf16<2, 2, 2, 2>(g, zdim, st); break;
