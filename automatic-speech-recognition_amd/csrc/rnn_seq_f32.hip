@@ -98,8 +98,16 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) xn[nt] = gl[cols[nt]];
     float cst = 0.f;
+#ifdef LAS_PROF
+    const bool fprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    if (fprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
+#define FSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (fprof && s >= 200 && s < 208) a.dbg[8 + (s - 200) * 8 + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FSTAMP(k)
+#endif
 
     for (int s = 0; s < T; ++s) {
+        FSTAMP(0);
         float x[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) x[nt] = xn[nt];
@@ -125,7 +133,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) part[((w * 4 + nt) * 4 + i) * PT + lk * 16 + li] = acc[nt][i];
+        FSTAMP(1);
         lds_barrier();
+        FSTAMP(2);
         // ---- finish the member's elements: pre-activation = x-projection + the four K-quarters, in this order
         float z[4];
 #pragma unroll
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
                 hs[hs_off<H, KP>(pm * 64 + nt * 16 + ej, er)] = hv[nt];
             }
         }
+        FSTAMP(3);
         if constexpr (P > 1) if (s + 1 < T) {
             const unsigned slot_off = (unsigned)((s & 1) * P) * GPM * 16u, tag = (unsigned)(s + 1);
             // publish: lstm -- the even position of a unit pair carries both units' h; rnn -- the thread's four units as two granules
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
                         xv[n] = granule16_load(xrs, slot_off + (unsigned)(((pm + 1 + g / GPM) % P) * GPM + g % GPM) * 16u);
                 }
             }
+            FSTAMP(4);
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
                 const int g = tid + 256 * n;
@@ -200,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
             }
         }
         lds_barrier();
+        FSTAMP(5);
         // bulk results of this step (nobody waits for these stores)
         if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
@@ -212,6 +225,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
         }
         gl += gstep; gs += gsstep; cs += cstep; os += ostep;
     }
+#ifdef LAS_PROF
+    if (fprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#endif
     if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 
@@ -272,7 +288,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) ng[nt] = gl[go + cols[nt]];
             nc = cl[co + pm * 16 + ej];
-            ncp = cl[co + (hasp ? cstep : 0) + pm * 16 + ej];                    // (no predecessor: any finite value, multiplied by zero below)
+            // (no predecessor: any finite value, multiplied by zero below.  The offset is opaque to the compiler: knowing it may be
+            // zero it reused nc's register on that path -- a branch join that needed nc's load COMPLETE, s_waitcnt vmcnt(0) in the
+            // middle of the prefetch: one memory round trip, ~1200 of the step's 7700 cycles)
+            long long po = hasp ? cstep : 0;
+            asm volatile("" : "+s"(po));
+            ncp = cl[co + po + pm * 16 + ej];
             nd[0] = dl[doff + pm * 16 + ej];
         } else {
 #pragma unroll
@@ -280,7 +301,12 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         }
     };
     fetch(0, 0, 0, 0, T > 1);
+#ifdef LAS_PROF
+    const bool fprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    if (fprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
+#endif
     for (int s = 0; s < T; ++s) {
+        FSTAMP(0);
         float g_[4], d_[TPM];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) g_[nt] = ng[nt];
@@ -311,7 +337,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         }
         gl += gstep; gs += gsstep; if (CELL == LAS_CELL_LSTM) cl += cstep; ol += ostep; dl += dstep;
         if (s + 1 == T) break;                                                   // the last step's dh has no consumer
+        FSTAMP(1);
         lds_barrier();
+        FSTAMP(2);
         // ---- partial dh of ALL units from the member's 64 columns
         float av[16];
         {
@@ -326,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
             for (int x = 0; x < TW; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wreg[x][ks], acc[x], 0, 0, 0);
+        FSTAMP(3);
         const unsigned slot_off = (unsigned)((s & 1) * P) * (unsigned)(P * TPM * 128) * 16u, tag = (unsigned)(s + 1);
         // ---- reduce-scatter: every unit tile goes to the member that owns it (rows 4 lk .. 4 lk + 3, unit li of the tile per lane)
 #pragma unroll
@@ -345,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         float sa[TPM], sb[TPM];
 #pragma unroll
         for (int q = 0; q < TPM; ++q) sa[q] = sb[q] = 0.f;
+        FSTAMP(4);
         if constexpr (P > 1) {
             constexpr int NH = P / 2;                                            // list positions of one thread (the last may not exist)
             u32x4_t xv[NH * TPM];
@@ -381,7 +411,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
 #pragma unroll
                 for (int q = 0; q < TPM; ++q) { sa[q] += __uint_as_float(xv[n * TPM + q].y); sb[q] += __uint_as_float(xv[n * TPM + q].z); }
         }
+        FSTAMP(5);
         lds_barrier();                                                           // own[] is complete; dzs may be rewritten
+        FSTAMP(6);
 #pragma unroll
         for (int q = 0; q < TPM; ++q) {
             // this thread's row: even rows are the granules' first value.  partner lane = the other row of the pair (tid ^ 16)
@@ -391,6 +423,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
             dhr[q] = own[(q * 4 + (er & 3)) * PT + (er >> 2) * 16 + ej] + (se + so);
         }
     }
+#ifdef LAS_PROF
+    if (fprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#endif
     if (errflag) { if (a.err) a.err[0] = 1; if (a.status) a.status[0] = a.status_code; }
 }
 

@@ -317,3 +317,47 @@ def test_weight_gradients_in_frame_windows_sum_to_the_whole_sequence(I, H, G, B,
         lo, n = c * S, min(S, T - c * S)
         _hip.wgrad_ih_hh_window(X, Ik, I, out, 2 * H, Tp * 2 * H, dZ, 2 * GH, B, T, H, GH, 1, 0, lo, n, 0, one)
     assert (one - got[1]).abs().max().item() < 3e-6 * (B * T) ** 0.5 * max(1.0, got[1].abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(48, 2048, 1152, 0, 0), (48, 1152, 2048, 0, 1), (17, 96, 1024, 0, 0), (64, 40, 4100, 1, 0)])
+def test_skinny_f32_k_slices_are_reproducible(case):
+    """The parity mode's per-step cell products (M <= 64, K >= 512): K slices over blockIdx.z, partial tiles to the stream's scratch,
+    added in slice order (gemm.hip gemm_mf32_skinny_kernel + gemm_splitk_reduce_kernel).  40 repetitions, alone and with a second
+    stream running the same product, are bit-identical, inside a captured graph as well -- and right (float64 of the same operands)."""
+    from las import _hip
+    M, N, K, tA, tB = case
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).cuda()
+    B = torch.randn((N, K) if tB else (K, N), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+
+    def product(out):
+        out.copy_(C0)
+        _hip.gemm(0, A, B, out, bool(tA), bool(tB), M, N, K, A.shape[1], B.shape[1], N, alpha=0.25, beta=0.5, bias=bias)
+
+    first = torch.empty_like(C0)
+    product(first)
+    ref = _ref(A, B, tA, tB, 0.25, 0.5, C0, bias, 0)
+    assert (first.double().cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    side = torch.cuda.Stream()
+    other = torch.empty_like(C0)
+    outs = [torch.empty_like(C0) for _ in range(40)]
+    for i, o in enumerate(outs):
+        if i % 2:
+            with torch.cuda.stream(side):
+                product(other)
+        product(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, first) for o in outs) and torch.equal(other, first)
+    cs = torch.cuda.Stream()
+    with torch.cuda.stream(cs):
+        product(other)                       # eager first use on the capture stream
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.empty_like(C0)
+        with torch.cuda.graph(graph, stream=cs):
+            product(cap)
+        for _ in range(3):
+            graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap, first)

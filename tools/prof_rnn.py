@@ -11,15 +11,21 @@ _hip.LIB_PATH = os.path.join(ROOT, "automatic-speech-recognition_amd", "lib", "l
 dbg = torch.zeros(128, dtype=torch.int64, device="cuda")
 os.environ["LAS_DBG_PTR"] = hex(dbg.data_ptr())
 
+PREC = int(os.environ.get("PROF_PREC", "1"))        # 0: the parity mode's exact-fp32 cluster kernels (rnn_seq_f32.hip)
 FWD = ["x-ring read + 32 MFMAs (h_{t-1}.W_hh slice)", "gate math + publish h granule", "gather partners' granules (poll)", "LDS barrier"]
 BWD = ["gate backward (28 values) + dG tile to LDS", "operand prefetch issue (14 loads)", "LDS barrier", "32 MFMAs (K-split partial dh)",
        "send 3 partial tiles (granules)", "receive 3 partial tiles (poll) + sum", "dZ stores (8)"]
 
+if PREC == 0:
+    FWD = ["h tile read + 64 MFMAs + partial tiles to LDS", "LDS barrier", "sum of K-quarters + gate math (accurate) + own h to LDS",
+           "publish + gather 15 partners' granules (poll)", "partners' h to LDS + barrier"]
+    BWD = ["gate backward + dz stores + dz tile to LDS", "LDS barrier", "dz tile read + 64 MFMAs", "send 15 partial tiles (granules)",
+           "receive 15 partial tiles (poll) + sum", "LDS barrier"]
 for cell, name in ((1, "lstm"), (0, "rnn")):
     G = 4 if cell else 1
     B, T, H = 48, 1274, 256
     g = torch.Generator().manual_seed(0)
-    io = _hip.rnn_seq_io_dtype(cell, 1, H)
+    io = _hip.rnn_seq_io_dtype(cell, PREC, H)
     xp = (torch.randn(B, T, 2, G * H, generator=g) * 0.5).cuda().to(io)
     w0 = (torch.randn(H, G * H, generator=g) * 0.05).cuda(); w1 = w0.clone()
     out = torch.zeros(B, T, 2 * H, device="cuda", dtype=io)
@@ -30,13 +36,13 @@ for cell, name in ((1, "lstm"), (0, "rnn")):
             dbg.zero_()
             gates = xp.clone()
             if which == "fwd":
-                _hip.rnn_seq_fwd(cell, 1, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst)
+                _hip.rnn_seq_fwd(cell, PREC, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst)
             else:
                 os.environ.pop("LAS_DBG_PTR")                      # stamps only for the sweep under test
-                _hip.rnn_seq_fwd(cell, 1, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst)
+                _hip.rnn_seq_fwd(cell, PREC, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst)
                 os.environ["LAS_DBG_PTR"] = hex(dbg.data_ptr())
                 dbg.zero_()
-                _hip.rnn_seq_bwd(cell, 1, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst, dout, 2 * H, T * 2 * H)
+                _hip.rnn_seq_bwd(cell, PREC, B, T, H, gates, w0, w1, G * H, out, 2 * H, T * 2 * H, cst, dout, 2 * H, T * 2 * H)
             torch.cuda.synchronize()
         d = dbg.cpu().tolist()
         cyc, wall = d[2] - d[0], d[3] - d[1]
