@@ -14,13 +14,18 @@
 //
 //   forward   the four waves of a member split K = H: wave w contracts k in [w H/4, (w+1) H/4) for all 64 columns (4 accumulator
 //             tiles), the partial tiles meet in LDS, thread (row, j) finishes the member's (row, unit) elements (gate math in
-//             accurate transcendentals), h is published to the partners as tagged 16-byte granules {tag, h_j, h_j+1, tag}.
+//             accurate transcendentals), h is published to the partners as tagged 16-byte granules {tag, h_u, h_u+4, tag} -- the
+//             two values one MFMA lane needs for two consecutive k-steps: a wave polls its own K quarter straight into its A
+//             operands (round 5: no LDS h tile, one barrier per step; 2.71 -> 2.37 us per step at H = 256).
 //   BPTT      K-split like the speed mode's: a member contracts ITS 64 columns of d(pre-activation) against W_hh^T for ALL H
 //             units (wave w: unit tiles [w H/64, (w+1) H/64)), keeps the partial tile(s) of its own units and sends the others
 //             to their owners; a thread pair (rows 2r, 2r+1) shares the partners' granules, half each, fixed order.
 // Exchange transport, placement handshake, bounded polls and the status word are the speed mode's (rnn_seq_args.h).
 // No atomics; every sum has a fixed order: bit-reproducible.
 #include "rnn_seq_args.h"
+#ifndef LAS_KS_SHARE_CU
+#define LAS_KS_SHARE_CU 0        // 1: timing experiments -- other kernels may share the sweep's CUs (see las_rnn_seq_mf32_run)
+#endif
 
 namespace {
 
@@ -30,7 +35,6 @@ struct F32Cfg {
     static constexpr int UPC = 64 / G;             // hidden units a member owns
     static constexpr int P = H / UPC;              // members per (direction, 16-row tile)
     static constexpr int KS = H / 16;              // forward: k-steps (of 4) per wave
-    static constexpr int KP = KS + 4;              // LDS pitch of one (k residue, row) run of the h tile: conflict-free 16-byte reads
     static constexpr int GPM = 16 * UPC / 2;       // forward: 16-byte granules (2 fp32) a member publishes per step
     static constexpr int TPM = UPC / 16;           // 16-unit tiles a member owns (lstm 1, rnn 4)
     static constexpr int TW = H / 64;              // BPTT: unit tiles per wave
@@ -42,19 +46,11 @@ template <int CELL, int H>
 __device__ __forceinline__ int col_of(int pm, int nt, int j) {
     return CELL == LAS_CELL_LSTM ? nt * H + pm * 16 + j : pm * 64 + nt * 16 + j;
 }
-// offset of hidden unit k, batch row r in the forward h tile [k-quarter 4][k residue 4][row 16][KP]
-template <int H, int KP>
-__device__ __forceinline__ int hs_off(int k, int r) {
-    const int wq = k / (H / 4), in = k % (H / 4);
-    return ((wq * 4 + (in & 3)) * 16 + r) * KP + (in >> 2);
-}
-
 template <int CELL, int H>
 __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
     using C = F32Cfg<CELL, H>;
-    constexpr int G = C::G, GH = C::GH, P = C::P, KS = C::KS, KP = C::KP, GPM = C::GPM, PT = C::PT;
-    __shared__ __attribute__((aligned(16))) float hs[16 * 16 * KP];
-    __shared__ __attribute__((aligned(16))) float part[4 * 4 * 4 * PT];         // [wave][n-tile][acc register i][lk][li]
+    constexpr int G = C::G, GH = C::GH, P = C::P, KS = C::KS, GPM = C::GPM, PT = C::PT, UPC = C::UPC;
+    __shared__ __attribute__((aligned(16))) float part2[2][4 * 4 * 4 * PT];     // [step parity][wave][n-tile][acc register i][lk][li]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int T = a.T, B = a.B;
     const int cg = blockIdx.x % a.ncl_pad, pm = blockIdx.x / a.ncl_pad;
@@ -75,8 +71,17 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
             for (int ks = 0; ks < KS; ++ks)
                 wreg[nt][ks] = W[(long long)(w * (H / 4) + 4 * ks + lk) * a.ldw + col_of<CELL, H>(pm, nt, li)];
     }
-    for (int i = tid; i < 16 * 16 * KP; i += 256) hs[i] = 0.f;
-    __syncthreads();
+    // A operands of a step straight from the exchange (round 5; before: every thread gathered 1/256 of the partners' granules into an
+    // LDS tile [k][row], a second barrier, then the waves read their fragments back -- 865 + part of 2450 of the step's 6560 cycles).
+    // A granule is {tag, h[row][u], h[row][u + 4], tag} with u = 8 q + lk: the two values ONE lane (row li, k residue lk) needs for the
+    // k-steps 2 q and 2 q + 1, so a wave polls exactly its own K quarter (KS / 2 granules per lane, own member's units included) and
+    // starts its MFMAs the moment that quarter is there.
+    unsigned goff[KS / 2];
+#pragma unroll
+    for (int q = 0; q < KS / 2; ++q) {
+        const int u = w * (H / 4) + 8 * q + lk, m = u / UPC, j = u % UPC;
+        goff[q] = (unsigned)(m * GPM + (j >> 3) * 64 + lk * 16 + li) * 16u;        // [member][block of 8 units][k residue][row]: 1 KB per wave load
+    }
 
     // element ownership of the gate math: thread (row er, position ej) finishes n-tile column ej of all four n-tiles
     const int er = tid >> 4, ej = tid & 15;
@@ -94,10 +99,16 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
     int cols[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) cols[nt] = col_of<CELL, H>(pm, nt, ej);
-    float xn[4];
+    // x-projection two steps ahead, bulk stores one step behind, both issued right AFTER the poll: vector-memory results return in
+    // issue order, so anything still in flight in front of the poll's granule loads (a prefetch from HBM, the stores' write
+    // acknowledgements) would be waited for before the first granule can be looked at
+    float xn[4], xn2[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) xn[nt] = gl[cols[nt]];
+    for (int nt = 0; nt < 4; ++nt) { xn[nt] = gl[cols[nt]]; xn2[nt] = gl[(T > 1 ? gstep : 0) + cols[nt]]; }
     float cst = 0.f;
+    float zl[4], hl[4], cl_ = 0.f;                                              // last step's results, stored one step late
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) zl[nt] = hl[nt] = 0.f;
 #ifdef LAS_PROF
     const bool fprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     if (fprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
@@ -108,20 +119,32 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
 
     for (int s = 0; s < T; ++s) {
         FSTAMP(0);
-        float x[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) x[nt] = xn[nt];
-        {   // next step's x-projection flies under this step (unconditional, clamped: no branch join in front of the MFMAs)
-            const long long adv = s + 1 < T ? gstep : 0;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) xn[nt] = gl[adv + cols[nt]];
-        }
+        // ---- h_{s-1}: this wave's K quarter of all 16 rows, as published at the end of step s - 1 (slot (s - 1) & 1, tag s)
         float av[KS];
-        {
-            const float4* hp = reinterpret_cast<const float4*>(hs + ((w * 4 + lk) * 16 + li) * KP);
+        if (s == 0) {
 #pragma unroll
-            for (int q = 0; q < KS / 4; ++q) { const float4 v = hp[q]; av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w; }
+            for (int ks = 0; ks < KS; ++ks) av[ks] = 0.f;
+        } else {
+            const unsigned slot_off = (unsigned)(((s - 1) & 1) * P) * GPM * 16u, tag = (unsigned)s;
+            u32x4_t xv[KS / 2];
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) xv[q] = granule16_load(xrs, slot_off + goff[q]);
+            int budget = errflag ? 1 : a.spin;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < KS / 2; ++q) ok &= xv[q].x == tag && xv[q].w == tag;
+                if (ok) break;
+                if (--budget <= 0) { errflag = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < KS / 2; ++q)
+                    if (xv[q].x != tag || xv[q].w != tag) xv[q] = granule16_load(xrs, slot_off + goff[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) { av[2 * q] = __uint_as_float(xv[q].y); av[2 * q + 1] = __uint_as_float(xv[q].z); }
         }
+        FSTAMP(1);
         f32x4_t acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -129,13 +152,39 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wreg[nt][ks], acc[nt], 0, 0, 0);
+        float x[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { x[nt] = xn[nt]; xn[nt] = xn2[nt]; }
+        {   // the x-projection of step s + 2 (unconditional, clamped: no branch join -- it interleaves with the MFMAs like the stores below)
+            const long long adv = s + 2 < T ? 2 * gstep : 0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) xn2[nt] = gl[adv + cols[nt]];
+        }
+        {   // bulk results of step s - 1 (nobody waits for these stores; step 0 writes zeros into the scratch row).  No branch: the
+            // address arithmetic and the stores interleave with the MFMAs above
+            const bool st = s > 0;
+            float* gq = st ? gs - gsstep : a.sink;
+            float* cq = st ? cs - cstep : a.sink;
+            float* oq = st ? os - ostep : a.sink;
+            if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) gq[cols[nt]] = zl[nt];            // activated gates, saved for BPTT (in place of the x-projection)
+                cq[st ? pm * 16 + ej : 0] = cl_;
+                oq[st ? pm * 16 + ej : 0] = hl[0];
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) oq[st ? pm * 64 + nt * 16 + ej : 0] = hl[nt];
+            }
+        }
+        // (two copies of the partial tiles, by step parity: a wave whose quarter arrives early may be a step ahead of one still summing)
+        float* part = part2[s & 1];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) part[((w * 4 + nt) * 4 + i) * PT + lk * 16 + li] = acc[nt][i];
-        FSTAMP(1);
-        lds_barrier();
         FSTAMP(2);
+        lds_barrier();
+        FSTAMP(3);
         // ---- finish the member's elements: pre-activation = x-projection + the four K-quarters, in this order
         float z[4];
 #pragma unroll
@@ -143,87 +192,50 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
             const int o = (nt * 4 + (er & 3)) * PT + (er >> 2) * 16 + ej;
             z[nt] = x[nt] + (((part[o] + part[16 * PT + o]) + part[32 * PT + o]) + part[48 * PT + o]);
         }
-        float hv[4];
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};
         if (CELL == LAS_CELL_LSTM) {
             const float gi = sigmoid_acc(z[0]), gj = tanh_acc(z[G > 1 ? 1 : 0]), gf = sigmoid_acc(z[G > 2 ? 2 : 0] + a.fb), go = sigmoid_acc(z[G > 3 ? 3 : 0]);
             cst = cst * gf + gi * gj;
             hv[0] = tanh_acc(cst) * go;
             z[0] = gi; z[G > 1 ? 1 : 0] = gj; z[G > 2 ? 2 : 0] = gf; z[G > 3 ? 3 : 0] = go;
-            hs[hs_off<H, KP>(pm * 16 + ej, er)] = hv[0];
         } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                hv[nt] = tanh_acc(z[nt]);
-                hs[hs_off<H, KP>(pm * 64 + nt * 16 + ej, er)] = hv[nt];
-            }
+            for (int nt = 0; nt < 4; ++nt) hv[nt] = tanh_acc(z[nt]);
         }
-        FSTAMP(3);
-        if constexpr (P > 1) if (s + 1 < T) {
+        FSTAMP(4);
+        if (s + 1 < T) {
+            // publish: the thread of unit position j with (j & 4) == 0 carries units j and j + 4 of its row (lane + 4 holds the other)
             const unsigned slot_off = (unsigned)((s & 1) * P) * GPM * 16u, tag = (unsigned)(s + 1);
-            // publish: lstm -- the even position of a unit pair carries both units' h; rnn -- the thread's four units as two granules
             if (CELL == LAS_CELL_LSTM) {
-                const float hn = __shfl_xor(hv[0], 1, 64);
-                if (!(ej & 1))
-                    granule16_store(xrs, slot_off + (unsigned)(pm * GPM + er * 8 + (ej >> 1)) * 16u, tag, __float_as_uint(hv[0]), __float_as_uint(hn), local);
+                const float hn = __shfl_down(hv[0], 4, 64);
+                if (!(ej & 4))
+                    granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (ej >> 3) * 64 + (ej & 3) * 16 + er) * 16u, tag,
+                                    __float_as_uint(hv[0]), __float_as_uint(hn), local);
             } else {
-                granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (er * 16 + ej) * 2) * 16u, tag, __float_as_uint(hv[0]), __float_as_uint(hv[1]), local);
-                granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (er * 16 + ej) * 2 + 1) * 16u, tag, __float_as_uint(hv[2]), __float_as_uint(hv[3]), local);
-            }
-            // gather the partners' slices of h_t into the LDS tile: all loads in flight at once, then re-poll only the stale ones
-            constexpr int NGR = (P - 1) * GPM, NG = (NGR + 255) / 256;
-            u32x4_t xv[NG];
 #pragma unroll
-            for (int n = 0; n < NG; ++n) {
-                const int g = tid + 256 * n;
-                xv[n] = (u32x4_t){tag, 0u, 0u, tag};
-                if (g < NGR) xv[n] = granule16_load(xrs, slot_off + (unsigned)(((pm + 1 + g / GPM) % P) * GPM + g % GPM) * 16u);
-            }
-            int budget = errflag ? 1 : a.spin;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int n = 0; n < NG; ++n) ok &= xv[n].x == tag && xv[n].w == tag;
-                if (ok) break;
-                if (--budget <= 0) { errflag = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int n = 0; n < NG; ++n) {
-                    const int g = tid + 256 * n;
-                    if (g < NGR && (xv[n].x != tag || xv[n].w != tag))
-                        xv[n] = granule16_load(xrs, slot_off + (unsigned)(((pm + 1 + g / GPM) % P) * GPM + g % GPM) * 16u);
-                }
-            }
-            FSTAMP(4);
-#pragma unroll
-            for (int n = 0; n < NG; ++n) {
-                const int g = tid + 256 * n;
-                if (g < NGR) {
-                    const int m = (pm + 1 + g / GPM) % P, idx = g % GPM;
-                    if (CELL == LAS_CELL_LSTM) {
-                        const int r = idx >> 3, u = m * 16 + 2 * (idx & 7);
-                        hs[hs_off<H, KP>(u, r)] = __uint_as_float(xv[n].y);
-                        hs[hs_off<H, KP>(u + 1, r)] = __uint_as_float(xv[n].z);
-                    } else {
-                        const int r = idx >> 5, j = (idx >> 1) & 15, nt = 2 * (idx & 1);
-                        hs[hs_off<H, KP>(m * 64 + nt * 16 + j, r)] = __uint_as_float(xv[n].y);
-                        hs[hs_off<H, KP>(m * 64 + (nt + 1) * 16 + j, r)] = __uint_as_float(xv[n].z);
-                    }
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float hn = __shfl_down(hv[nt], 4, 64);
+                    if (!(ej & 4))
+                        granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (nt * 2 + (ej >> 3)) * 64 + (ej & 3) * 16 + er) * 16u, tag,
+                                        __float_as_uint(hv[nt]), __float_as_uint(hn), local);
                 }
             }
         }
-        lds_barrier();
         FSTAMP(5);
-        // bulk results of this step (nobody waits for these stores)
-        if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) gs[cols[nt]] = z[nt];                 // activated gates, saved for BPTT (in place of the x-projection)
-            cs[pm * 16 + ej] = cst;
-            os[pm * 16 + ej] = hv[0];
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) os[pm * 64 + nt * 16 + ej] = hv[nt];
-        }
+        for (int nt = 0; nt < 4; ++nt) { zl[nt] = z[nt]; hl[nt] = hv[nt]; }
+        cl_ = cst;
         gl += gstep; gs += gsstep; cs += cstep; os += ostep;
+    }
+    // the last step's results
+    if (CELL == LAS_CELL_LSTM) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) gs[cols[nt] - gsstep] = zl[nt];
+        cs[pm * 16 + ej - cstep] = cl_;
+        os[pm * 16 + ej - ostep] = hl[0];
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) os[pm * 64 + nt * 16 + ej - ostep] = hl[nt];
     }
 #ifdef LAS_PROF
     if (fprof) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
@@ -484,9 +496,20 @@ int las_rnn_seq_mf32_run(bool bwd, int cell, const RnnArgs& a_in, void* ws, size
         // err word, scratch row, handshake slots and the granule tags of the clusters this launch uses: one fill
         LAS_HIP(hipMemsetAsync(base, 0, L.xbuf + (size_t)c.ncl * L.per_cl, st));
         const dim3 grid(c.ncl_pad * P), block(256);
+        // The CU to itself, like the speed mode's sweeps (rnn_seq.hip ks_lds): the kernels need 7-41 KB of LDS and one wave per SIMD, so
+        // the side stream's weight-gradient GEMM workgroups WOULD be scheduled next to a member and share its SIMDs, LDS and L1 with
+        // the dependent chain (BPTT sweeps of a train step: 3.7-4.4 us per step in place, 2.7 alone).  Dynamic LDS that nobody touches
+        // fills the CU's allocation: nothing that uses LDS fits next to the sweep.
+        constexpr int FILL = 159 * 1024 - 42 * 1024;
 #define LAS_F32_LAUNCH(CELL, HH)                                                                                         \
-        do { if (bwd) hipLaunchKernelGGL((rnn_seq_bwd_mf32_kernel<CELL, HH>), grid, block, 0, st, c);                    \
-             else     hipLaunchKernelGGL((rnn_seq_fwd_mf32_kernel<CELL, HH>), grid, block, 0, st, c); } while (0)
+        do { static int attr__ = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_seq_bwd_mf32_kernel<CELL, HH>),     \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, FILL) |                   \
+                                 (int)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_seq_fwd_mf32_kernel<CELL, HH>),     \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, FILL);                    \
+             LAS_ARG(attr__ == 0, "hipFuncSetAttribute(fp32 sweep) failed: %d", attr__);                                  \
+             if (bwd) hipLaunchKernelGGL((rnn_seq_bwd_mf32_kernel<CELL, HH>), grid, block, fill, st, c);                 \
+             else     hipLaunchKernelGGL((rnn_seq_fwd_mf32_kernel<CELL, HH>), grid, block, fill, st, c); } while (0)
+        const size_t fill = LAS_KS_SHARE_CU ? 0 : (size_t)FILL;
         if (cell == LAS_CELL_LSTM) {
             switch (H) {
                 case 64: LAS_F32_LAUNCH(LAS_CELL_LSTM, 64); break;

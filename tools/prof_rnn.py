@@ -17,8 +17,8 @@ BWD = ["gate backward (28 values) + dG tile to LDS", "operand prefetch issue (14
        "send 3 partial tiles (granules)", "receive 3 partial tiles (poll) + sum", "dZ stores (8)"]
 
 if PREC == 0:
-    FWD = ["h tile read + 64 MFMAs + partial tiles to LDS", "LDS barrier", "sum of K-quarters + gate math (accurate) + own h to LDS",
-           "publish + gather 15 partners' granules (poll)", "partners' h to LDS + barrier"]
+    FWD = ["poll this wave's K quarter of h (granules -> registers)", "64 MFMAs + partial tiles to LDS", "LDS barrier",
+           "sum of K-quarters + gate math (accurate)", "publish the member's h"]
     BWD = ["gate backward + dz stores + dz tile to LDS", "LDS barrier", "dz tile read + 64 MFMAs", "send 15 partial tiles (granules)",
            "receive 15 partial tiles (poll) + sum", "LDS barrier"]
 for cell, name in ((1, "lstm"), (0, "rnn")):
