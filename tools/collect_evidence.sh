@@ -55,6 +55,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt_f32_$P -o b -- python3 bench.py --dt
 python3 tools/kernel_stats.py /tmp/kt_f32_$P 1 gpurun_out/${P}_f32_kernel_stats.csv > /dev/null
 python3 tools/bench_gemm_f32.py > gpurun_out/${P}_f32_gemm_shapes.txt 2>&1
 python3 bench.py --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_bench_f32.json 2> /dev/null
+PROF_PREC=0 python3 tools/prof_rnn.py > gpurun_out/${P}_f32_phase_stamps.txt 2>&1        # round 5: the exact-fp32 cluster sweeps' phases
+[ -x tools/micro/bin/bench_mfma_f32 ] && tools/micro/bin/bench_mfma_f32 > gpurun_out/${P}_mfma_f32_rate.txt 2>&1
 # ---- the cell the reference builds (BasicRNNCell), speed mode: kernel trace
 rocprofv3 --kernel-trace --stats -d /tmp/kt_rnn_$P -o b -- python3 bench.py --cell rnn --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_rnn_kt.log 2>&1
 python3 tools/kernel_stats.py /tmp/kt_rnn_$P 3 gpurun_out/${P}_rnn_kernel_stats.csv > /dev/null
