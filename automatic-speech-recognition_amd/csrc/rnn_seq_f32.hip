@@ -293,35 +293,26 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
 #pragma unroll
     for (int q = 0; q < TPM; ++q) dhr[q] = 0.f;
 
-    // operands of a step: lstm -- four gates, c_t, c_{t-1}, dout of the thread's unit; rnn -- h and dout of its four units.  They are
-    // fetched TWO steps ahead (round 5; one step ahead before): beside the side stream's weight-gradient products a load from HBM can take
-    // longer than a step, and -- vector-memory results return in issue order -- the receive poll at the end of the step would sit behind it
-    // (BPTT sweeps of a train step ran at 2.9-3.6 us per step in place, 2.7 alone).  The kernel has the registers: one wave per SIMD.
-    struct Ops { float g[4], d[TPM], c, cp; };
-    Ops n1, n2;
-    auto fetch = [&](Ops& o, long long go, long long co, long long oo, long long doff, bool hasp) {
-        o.c = o.cp = 0.f;
+    // operands of a step: lstm -- four gates, c_t, c_{t-1}, dout of the thread's unit; rnn -- h and dout of its four units
+    float ng[4], nd[TPM], nc = 0.f, ncp = 0.f;
+    auto fetch = [&](long long go, long long co, long long oo, long long doff, bool hasp) {
         if (CELL == LAS_CELL_LSTM) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) o.g[nt] = gl[go + cols[nt]];
-            o.c = cl[co + pm * 16 + ej];
+            for (int nt = 0; nt < 4; ++nt) ng[nt] = gl[go + cols[nt]];
+            nc = cl[co + pm * 16 + ej];
             // (no predecessor: any finite value, multiplied by zero below.  The offset is opaque to the compiler: knowing it may be
-            // zero it reused c's register on that path -- a branch join that needed c's load COMPLETE, s_waitcnt vmcnt(0) in the
+            // zero it reused nc's register on that path -- a branch join that needed nc's load COMPLETE, s_waitcnt vmcnt(0) in the
             // middle of the prefetch: one memory round trip, ~1200 of the step's 7700 cycles)
             long long po = hasp ? cstep : 0;
             asm volatile("" : "+s"(po));
-            o.cp = cl[co + po + pm * 16 + ej];
-            o.d[0] = dl[doff + pm * 16 + ej];
+            ncp = cl[co + po + pm * 16 + ej];
+            nd[0] = dl[doff + pm * 16 + ej];
         } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { o.g[nt] = ol[oo + pm * 64 + nt * 16 + ej]; o.d[nt % TPM] = dl[doff + pm * 64 + nt * 16 + ej]; }
+            for (int nt = 0; nt < 4; ++nt) { ng[nt] = ol[oo + pm * 64 + nt * 16 + ej]; nd[nt % TPM] = dl[doff + pm * 64 + nt * 16 + ej]; }
         }
     };
-    fetch(n1, 0, 0, 0, 0, T > 1);
-    {
-        const long long m = T > 1 ? 1 : 0;
-        fetch(n2, m * gstep, m * cstep, m * ostep, m * dstep, T > 2);
-    }
+    fetch(0, 0, 0, 0, T > 1);
 #ifdef LAS_PROF
     const bool fprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     if (fprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
@@ -330,15 +321,11 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         FSTAMP(0);
         float g_[4], d_[TPM];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) g_[nt] = n1.g[nt];
+        for (int nt = 0; nt < 4; ++nt) g_[nt] = ng[nt];
 #pragma unroll
-        for (int q = 0; q < TPM; ++q) d_[q] = n1.d[q];
-        const float c = n1.c, cp = s + 1 < T ? n1.cp : 0.f;
-        n1 = n2;
-        {   // step s + 2's operands (beyond the end: this step's row again, never used)
-            const long long m = s + 2 < T ? 2 : 0;
-            fetch(n2, m * gstep, m * cstep, m * ostep, m * dstep, s + 3 < T);
-        }
+        for (int q = 0; q < TPM; ++q) d_[q] = nd[q];
+        const float c = nc, cp = s + 1 < T ? ncp : 0.f;
+        if (s + 1 < T) fetch(gstep, cstep, ostep, dstep, s + 2 < T);
         // ---- gate backward of the thread's element(s)
         float dz[4];
         if (CELL == LAS_CELL_LSTM) {
