@@ -862,6 +862,9 @@ __device__ __forceinline__ void tile_gload_f32fast(TileRegs<ROWS, NT>& r, const 
         }
     }
 }
+#ifndef LAS_MF32_PIPE
+#define LAS_MF32_PIPE 1
+#endif
 template <int ROWS, int NT, int LD, bool IS_A>
 __device__ __forceinline__ void tile_gload_f32(TileRegs<ROWS, NT>& r, const float* __restrict__ X, long long rs, long long ks,
                                                int row0, int k0, int R, int Kend, int vec, int mperiod, int mskip) {
@@ -902,17 +905,44 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
         tile_gload_f32<BM, NT, LD, true>(ra, A, g.rsA, g.ksA, m0, kbeg, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
         tile_gload_f32<BN, NT, LD, false>(rb, B, g.rsB, g.ksB, n0, kbeg, g.N, kend, g.vecB, 0, 0);
     }
+#ifndef LAS_MF32_ABL
+#define LAS_MF32_ABL 0       // timing experiments: 1 = no global loads after the first tile, 2 = no LDS stores / barriers after the first tile
+#endif
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        if (!(LAS_MF32_ABL & 2) || k0 == kbeg) {
         __syncthreads();
         tile_sstore_f32<BM, NT>(As, ra, g.ksA);
         tile_sstore_f32<BN, NT>(Bs, rb, g.ksB);
         __syncthreads();
-        if (k0 + 32 < kend) {
+        }
+        if (k0 + 32 < kend && !(LAS_MF32_ABL & 1)) {
             tile_gload_f32<BM, NT, LD, true>(ra, A, g.rsA, g.ksA, m0, k0 + 32, g.M, kend, g.vecA, g.mask_period, g.mask_skip);
             tile_gload_f32<BN, NT, LD, false>(rb, B, g.rsB, g.ksB, n0, k0 + 32, g.N, kend, g.vecB, 0, 0);
         }
         const float* ap = As + lk * PA + wm * TM * 16 + li;
         const float* bp = Bs + lk * PB + wn * TN * 16 + li;
+#if LAS_MF32_PIPE
+        // the operands of k-step ks + 1 are read while the MFMAs of k-step ks run (two register sets)
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 16];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 16];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {             // (k beyond kend was loaded as zeros: whole k-steps always)
+            if (ks + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = ap[(ks + 1) * 4 * PA + i * 16];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = bp[(ks + 1) * 4 * PB + j * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);       // keep the next k-step's reads in front of this k-step's MFMAs
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {             // (k beyond kend was loaded as zeros: whole k-steps always)
             float a[TM], b[TN];
@@ -925,6 +955,7 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+#endif
     }
     // epilogue: lane holds rows (lane >> 4) * 4 + r, column lane & 15 of each 16 x 16 tile
 #pragma unroll
