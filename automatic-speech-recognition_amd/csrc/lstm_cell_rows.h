@@ -16,6 +16,15 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
     const int gt = w & 3, rt = w >> 2;
     const int H = a.H, ct = gt * (H >> 4) + ub;                      // this wave's column tile of the [K, 4H] kernel
     if (ub * 16 >= H || row0 >= a.M) return;                         // (the pair kernel's grid covers the larger of two problems)
+    // operands of the gate math at the END of the launch, requested here: bias, the row's c_{t-1} and the index of its x row were three
+    // dependent round trips behind the product (bias -> index -> x row + c), ~1.3 us of a 11-17 us launch (round 5)
+    const int er_ = tid >> 4, eu_ = tid & 15, erow_ = min(row0 + er_, a.M - 1), eunit_ = ub * 16 + eu_;
+    float pb_[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pb_[g] = a.bias[g * H + eunit_];
+    const float pc_ = a.c_prev[(size_t)erow_ * H + eunit_];
+    const int pid_ = a.xrows ? a.ids[erow_] : 0;
+    __builtin_amdgcn_sched_barrier(0);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (!PIPE) {
         for (int part = 0; part < 2; ++part) {
@@ -152,9 +161,9 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
     const int l2 = ((r & 15) >> 2) * 16 + u, reg = r & 3, unit = ub * 16 + u;
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = gates[r >> 4][g][l2][reg] + a.bias[g * H + unit];
+    for (int g = 0; g < 4; ++g) z[g] = gates[r >> 4][g][l2][reg] + pb_[g];
     if (a.xrows) {
-        int id = a.ids[row] - a.id_shift;
+        int id = pid_ - a.id_shift;
         if (id < 0) id = 0;
         const float* xr = a.xrows + (size_t)id * 4 * H + unit;
 #pragma unroll
@@ -162,7 +171,7 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
     }
     const float gi = sigm<FAST>(z[0]), gj = tanhx<FAST>(z[1]), gf = sigm<FAST>(z[2] + a.fb), go = sigm<FAST>(z[3]);
     const size_t o = (size_t)row * H + unit;
-    const float cn = a.c_prev[o] * gf + gi * gj;
+    const float cn = fmaf(pc_, gf, gi * gj);          // (spelled out: left to the compiler, which of the two products is fused depends on the surrounding code -- the 32-row and the 128-row body must agree bit for bit)
     a.c_out[o] = cn;
     a.h_out[o] = tanhx<FAST>(cn) * go;
     if (a.gates_out) {                                   // the activated gates, as the Speller's backward pass reads them
@@ -193,6 +202,20 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     const int gt = w & 3, rh = w >> 2;
     const int H = a.H, ct = gt * (H >> 4) + ub;
     if (ub * 16 >= H || row0 >= a.M) return;
+    // operands of the gate math at the end of the launch, requested here (see lstm_cell_rows_body): the thread's unit is the same for its
+    // four elements (rows tid / 16 + 32 k)
+    const int eunit_ = ub * 16 + (tid & 15);
+    float pb_[4], pc_[4];
+    int pid_[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pb_[g] = a.bias[g * H + eunit_];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int erow = min(row0 + ((tid + k * 512) >> 4), a.M - 1);
+        pc_[k] = a.c_prev[(size_t)erow * H + eunit_];
+        pid_[k] = a.xrows ? a.ids[erow] : 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     unsigned short* As = reinterpret_cast<unsigned short*>(smem);
     f32x4_t acc[4];
 #pragma unroll
@@ -304,9 +327,9 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         const int r16 = r & 15, l2 = (r16 >> 2) * 16 + u, reg = r16 & 3, unit = ub * 16 + u, tile = (r >> 6) * 4 + ((r >> 4) & 3);
         float z[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) z[g] = gx[(((tile * 4 + g) * 64 + l2) << 2) + reg] + a.bias[g * H + unit];
+        for (int g = 0; g < 4; ++g) z[g] = gx[(((tile * 4 + g) * 64 + l2) << 2) + reg] + pb_[g];
         if (a.xrows) {
-            int id = a.ids[row] - a.id_shift;
+            int id = pid_[k] - a.id_shift;
             if (id < 0) id = 0;
             const float* xr = a.xrows + (size_t)id * 4 * H + unit;
 #pragma unroll
@@ -314,7 +337,7 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         }
         const float gi = sigm<FAST>(z[0]), gj = tanhx<FAST>(z[1]), gf = sigm<FAST>(z[2] + a.fb), go = sigm<FAST>(z[3]);
         const size_t o = (size_t)row * H + unit;
-        const float cn = a.c_prev[o] * gf + gi * gj;
+        const float cn = fmaf(pc_[k], gf, gi * gj);
         a.c_out[o] = cn;
         a.h_out[o] = tanhx<FAST>(cn) * go;
         if (a.gates_out) {
