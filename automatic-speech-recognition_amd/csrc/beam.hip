@@ -296,7 +296,37 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
     __shared__ int srcs[64];                                // fold_gather: the rows the utterance's new live slots continue (beam <= 64)
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
+    // Every word the launch branches on, and (usual geometry) every operand of the in-kernel projection, is requested HERE, before the
+    // first branch: the step counter, the utterance's done / bound / live words and then the projection's loads were four dependent
+    // round trips in a row at the head of a 15 us launch (round 5).  All addresses are valid whatever the words turn out to be.
+    const int uc = u < a.nutt ? u : 0;
     const int t = a.step[0];
+    const int done_u = a.done[uc], bound_u = a.dec_step[uc], live_u = a.nlive[uc], nsel_u = a.nsel[uc];
+    // the live hypotheses' running sums and lengths: read by the ranking (per candidate) and again by the bookkeeping (per pick) -- one
+    // round trip each, behind the projection; requested here, kept in LDS
+    __shared__ float sc_s[64];
+    __shared__ int ln_s[64];
+    const float sc_pre = a.score[(size_t)uc * beam + (tid < beam ? tid : 0)];
+    const int ln_pre = a.length[(size_t)uc * beam + (tid < beam ? tid : 0)];
+    const int lane = tid & 63, w = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int RT = (beam + 15) >> 4, CT = (V + 15) >> 4, KS0 = a.proj_w ? a.proj_k0 >> 5 : 0, KS = KS0 + (a.proj_w ? a.proj_k1 >> 5 : 0);
+    const bool usual = a.proj_w && RT == 1 && CT <= 2 && KS <= 32 && KS > 0;
+    float4 xa[8][2]; u16x8_t bw[8][2];
+    if (usual) {
+        // (beam <= 16, a char vocabulary, K <= 1024): every operand of this wave's <= 8 k-steps is requested before the first product
+        // (a loop with one round trip to L2 per k-step was 8 us of this kernel)
+        const int hr = r < beam ? r : beam - 1, row = uc * beam + hr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ks = w + 4 * j, kc = ks < KS ? ks : KS - 1;
+            const float* src = kc < KS0 ? a.proj_h0 + (size_t)row * a.proj_k0 + kc * 32 + g * 8
+                                        : a.proj_h1 + (size_t)row * a.proj_k1 + (kc - KS0) * 32 + g * 8;
+            xa[j][0] = *reinterpret_cast<const float4*>(src); xa[j][1] = *reinterpret_cast<const float4*>(src + 4);
+            bw[j][0] = a.proj_w[(size_t)kc * 64 + lane];
+            bw[j][1] = a.proj_w[((size_t)(CT > 1 ? KS : 0) + kc) * 64 + lane];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (t >= a.Umax) { beam_finish(a); return; }
     if (u >= a.nutt) {                                    // filing workgroups: this step's row tensor (the alignments) under the DEVICE step counter
         const int nf = (int)gridDim.x - a.nutt;
@@ -312,44 +342,31 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         return;
     }
     int* hn = a.hist_n + (size_t)t * a.nutt + u;
-    if (a.done[u] || t >= a.dec_step[u]) {               // retired utterance: nothing to do (its rows compute ignored garbage)
+    if (done_u || t >= bound_u) {                        // retired utterance: nothing to do (its rows compute ignored garbage)
         if (tid == 0) { *hn = 0; a.done[u] = 1; a.nlive[u] = 0; }
         for (int k = tid; k < beam; k += 256) { a.src_row[(size_t)u * beam + k] = u * beam; srcs[k] = u * beam; }
         if (a.gather) { __syncthreads(); beam_gather_rows(a, u, srcs); }      // (rows of a retired utterance: ignored garbage, but finite)
         beam_finish(a);
         return;
     }
-    int nb = a.nlive[u];
+    int nb = live_u;
     if (nb > beam) nb = beam;
     if (t == 0 && nb > 1) nb = 1;                       // las/beam_search.py:119
     const float* lg = a.logits + (size_t)u * beam * V;
     float* sc = a.score + (size_t)u * beam;
     int* ln = a.length + (size_t)u * beam;
+    if (tid < 64) { sc_s[tid] = sc_pre; ln_s[tid] = ln_pre; }      // (beam <= 64; published by the barriers below)
+    if (!a.proj_w) __syncthreads();
     if (a.proj_w) {
         // the step's logits are computed HERE: [beam rows] x [K = k0 + k1] x [V] on the matrix cores (the Speller's output layer and the
         // LM's, pre-scaled by lm_weight and shifted to its token columns, are one concatenated product) -- the 4 waves split the k-steps,
         // their partial tiles meet in LDS; the ranking then reads the logits from LDS.  Saves two launches per decode step.
         __shared__ float red[4][BEAM_PROJ_TILES][64][4];
         __shared__ float lgs[BEAM_PROJ_TILES * 256];
-        const int lane = tid & 63, w = tid >> 6, g = lane >> 4, r = lane & 15;
-        const int RT = (beam + 15) >> 4, CT = (V + 15) >> 4, KS0 = a.proj_k0 >> 5, KS = KS0 + (a.proj_k1 >> 5);
         f32x4_t acc[BEAM_PROJ_TILES];
 #pragma unroll
         for (int i = 0; i < BEAM_PROJ_TILES; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (RT == 1 && CT <= 2 && KS <= 32) {
-            // the usual geometry (beam <= 16, a char vocabulary, K <= 1024): every operand of this wave's <= 8 k-steps is requested
-            // before the first product (a loop with one round trip to L2 per k-step was 8 us of this kernel)
-            const int hr = r < beam ? r : beam - 1, row = u * beam + hr;
-            float4 xa[8][2]; u16x8_t bw[8][2];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ks = w + 4 * j, kc = ks < KS ? ks : KS - 1;
-                const float* src = kc < KS0 ? a.proj_h0 + (size_t)row * a.proj_k0 + kc * 32 + g * 8
-                                            : a.proj_h1 + (size_t)row * a.proj_k1 + (kc - KS0) * 32 + g * 8;
-                xa[j][0] = *reinterpret_cast<const float4*>(src); xa[j][1] = *reinterpret_cast<const float4*>(src + 4);
-                bw[j][0] = a.proj_w[(size_t)kc * 64 + lane];
-                bw[j][1] = a.proj_w[((size_t)(CT > 1 ? KS : 0) + kc) * 64 + lane];
-            }
+        if (usual) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (w + 4 * j < KS) {
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         __syncthreads();
         lg = lgs;
     }
-    const int count = beam_rank(lg, sc, ln, nb, V, t, a.start_id, beam, L);
+    const int count = beam_rank(lg, sc_s, ln_s, nb, V, t, a.start_id, beam, L);
     if (tid < 64) {
     // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
     // first wave is pick j (beam <= 64); the positions of the retired / surviving picks in their lists are prefix counts of ballots
@@ -402,11 +419,11 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     BKey k = {0.f, 0, 0.f, 0};
     if (act) k = L.picks[count - 1 - j];
     const int v = k.v - k.i * V;
-    const float news = sc[k.i] + k.l;                    // (every lane reads the old sums before any lane stores the new ones below)
-    const int newl = ln[k.i] + 1;
+    const float news = sc_s[k.i] + k.l;                  // (the old sums: the LDS copies, untouched by the stores below)
+    const int newl = ln_s[k.i] + 1;
     const bool isend = act && v == a.end_id, live = act && !isend;
     const unsigned long long mend = __ballot(isend), mlive = __ballot(live), below = (1ull << j) - 1ull;
-    const int ns0 = a.nsel[u];
+    const int ns0 = nsel_u;
     const int eidx = ns0 + __popcll(mend & below), lidx = __popcll(mlive & below);
     const int nl = __popcll(mlive);
     int ns = ns0 + __popcll(mend);
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         sc[lidx] = news; ln[lidx] = newl;
     }
     if (j >= nl && j < beam) { a.src_row[(size_t)u * beam + j] = u * beam; srcs[j] = u * beam; a.next_token[(size_t)u * beam + j] = a.start_id; }
-    const bool exhausted = (t + 1 == a.dec_step[u]);
+    const bool exhausted = (t + 1 == bound_u);
     if (exhausted) {                                               // `if t == dec_step: selected.extend(beam_set)` (:155-156)
         if (live && ns + lidx < a.selcap) { a.sel_t[(size_t)u * a.selcap + ns + lidx] = t; a.sel_j[(size_t)u * a.selcap + ns + lidx] = j; }
         ns += nl;
