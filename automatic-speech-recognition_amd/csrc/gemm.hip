@@ -862,6 +862,9 @@ __device__ __forceinline__ void tile_gload_f32fast(TileRegs<ROWS, NT>& r, const 
         }
     }
 }
+#ifndef LAS_SKINNY_KSLICE
+#define LAS_SKINNY_KSLICE 256     // the skinny fp32 product's K slices: K / this many, capped by 512 / column blocks
+#endif
 #ifndef LAS_MF32_PIPE
 #define LAS_MF32_PIPE 1
 #endif
@@ -1222,7 +1225,7 @@ extern "C" size_t las_gemm_workspace_bytes(int prec, int M, int N, int K, int ba
         s = want < maxs ? want : maxs;
     }
     if (s <= 1 && prec == LAS_PREC_F32 && M <= 64 && K >= 512) {       // the parity mode's skinny products: K slices (las_gemm_dt)
-        s = K / 256;
+        s = K / LAS_SKINNY_KSLICE;
         if (s > 512 / cdiv(N, 32)) s = 512 / cdiv(N, 32);
     }
     if (s <= 1) return 0;
@@ -1297,7 +1300,7 @@ extern "C" int las_gemm_dt(int prec, int transA, int transB, int M, int N, int K
     // parity mode, skinny products (the Speller's per-step cell products): 64 / 36 column blocks of a latency-bound K walk -> K slices
     if (prec == LAS_PREC_F32 && !g_f32_valu && M <= 64 && batch == 1 && ws && g.splitk == 1 && K >= 512) {
         const int blocks = cdiv(N, 32);
-        int s = K / 256, want = 512 / blocks;
+        int s = K / LAS_SKINNY_KSLICE, want = 512 / blocks;
         if (s > want) s = want;
         while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
         if (s > 1) {

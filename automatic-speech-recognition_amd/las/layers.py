@@ -244,10 +244,13 @@ class _BLSTM(torch.autograd.Function):
         # gates: activated gates -> d(pre-activation), in place
         P4 = ctx.params
         direct = P4 is not None and all(_direct_ok(p) for p in P4)
-        # with direct gradients the sweep itself accumulates the two bias gradients (column sums of dZ held in registers)
+        # with direct gradients the sweep itself accumulates the two bias gradients (column sums of dZ held in registers) -- the speed
+        # mode's kernels do; behind the parity mode's sweeps the library would run the column sums on THIS stream (0.25 ms per layer on
+        # the dependency chain, round 5): they go to the side stream with the weight gradients instead (same kernel, same order)
+        db_in_sweep = direct and prec != _hip.PREC_F32
         _hip.rnn_seq_bwd(_cellid(cell), prec, B, T, H, gates, kfw, kbw, GH, out, 2 * H, Tp * 2 * H, cst,
                          dout, 2 * H, Tp * 2 * H, 1.0, wf_off=I0 * GH, wb_off=I0 * GH,
-                         db_fw=P4[1].grad if direct else None, db_bw=P4[3].grad if direct else None)
+                         db_fw=P4[1].grad if db_in_sweep else None, db_bw=P4[3].grad if db_in_sweep else None)
         dx = dx_bw = None
         if ctx.needs_input_grad[0] and not two:        # on the dependency chain: main stream, first
             # dZ [B*T, 2*GH] . [W_ih_fw | W_ih_bw]^T in one product (one pass over dx instead of two)
@@ -261,21 +264,32 @@ class _BLSTM(torch.autograd.Function):
         _hip.run_deferred()
         if direct:
             # weight gradients: off the chain -> side stream, accumulated straight into the flat gradient bucket
-            with _hip.on_side_stream():
-                side = _hip.side_stream()
+            def wgrad(d, strm):
                 for t in (x, gates, out) + ((x_bw,) if two else ()):
-                    t.record_stream(side)
-                part = torch.empty(B, H, GH, device=dev) if T > 1 else None
-                for d in range(2):
-                    kp, bp = P4[2 * d], P4[2 * d + 1]
-                    gk = kp.grad                       # [(I+H), GH] view of the flat bucket
-                    _hip.gemm(prec, xs[d], gates, gk, True, False, I, GH, B * T, I, 2 * GH, GH, beta=1.0, b_off=d * GH)
-                    if T > 1:
-                        a_off = d * H + (0 if d == 0 else 2 * H)
-                        b_off = d * GH + (2 * GH if d == 0 else 0)
-                        _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
-                                  strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
-                        _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
+                    t.record_stream(strm)
+                kp, bp = P4[2 * d], P4[2 * d + 1]
+                gk = kp.grad                       # [(I+H), GH] view of the flat bucket
+                if not db_in_sweep:
+                    _hip.colsum(gates, B * T, GH, 2 * GH, bp.grad, x_off=d * GH, beta=1.0)
+                _hip.gemm(prec, xs[d], gates, gk, True, False, I, GH, B * T, I, 2 * GH, GH, beta=1.0, b_off=d * GH)
+                if T > 1:
+                    part = torch.empty(B, H, GH, device=dev)
+                    a_off = d * H + (0 if d == 0 else 2 * H)
+                    b_off = d * GH + (2 * GH if d == 0 else 0)
+                    _hip.gemm(prec, out, gates, part, True, False, H, GH, T - 1, 2 * H, 2 * GH, GH, batch=B,
+                              strideA=Tp * 2 * H, strideB=T * 2 * GH, strideC=H * GH, a_off=a_off, b_off=b_off)
+                    _hip.colsum(part, B, H * GH, H * GH, gk[I0:].reshape(-1), beta=1.0)
+
+            # the bottom layer's weight gradients are the end-of-step tail (nothing left to hide behind): one direction per auxiliary
+            # stream, as in the speed mode (its products do not fill the chip alone); the other layers' run on the side stream
+            tail2 = TAIL_TWO_STREAMS and not ctx.needs_input_grad[0] and not two
+            with _hip.on_side_stream():
+                wgrad(0, _hip.side_stream())
+                if not tail2:
+                    wgrad(1, _hip.side_stream())
+            if tail2:
+                with _hip.on_chain_stream():
+                    wgrad(1, _hip.chain_stream())
             return (dx, None, None, None, None, None, None, None, None, dx_bw)
         grads = []
         part = torch.empty(B, H, GH, device=dev) if T > 1 else None
