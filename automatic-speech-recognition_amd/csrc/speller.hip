@@ -1696,9 +1696,18 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
     if (t_att >= 0) {
         const int t = t_att;
         const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D;
+        if (Hd <= RNT && Tp <= RNT && A <= RNT) {          // one pass: the three rows' loads in flight together (three loops = three round trips)
+            const float v0 = dxr[E + (tid < Hd ? tid : Hd - 1)];
+            const float v1 = a.alphas[((size_t)t * B + b) * Tp + (tid < Tp ? tid : Tp - 1)];
+            const float v2 = a.Q[((size_t)t * B + b) * A + (tid < A ? tid : A - 1)];
+            if (tid < Hd) dctx[tid] = v0;
+            if (tid < Tp) L.ev[tid] = v1;
+            if (tid < A) L.qv[tid] = v2;
+        } else {
         for (int i = tid; i < Hd; i += RNT) dctx[i] = dxr[E + i];
         for (int i = tid; i < Tp; i += RNT) L.ev[i] = a.alphas[((size_t)t * B + b) * Tp + i];
         for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
+        }
         if (loc) {
             for (int i = tid; i < Tp; i += RNT)
                 L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
@@ -1713,23 +1722,30 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
             const int sl = tid & 31, grp = tid >> 5;
             for (int tb = grp; tb < Tp; tb += 2 * RNG) {
                 float acc2[2] = {0.f, 0.f};
+                // (round 5) all eight loads of the two frames first, from clamped addresses: inside `if (tt < lim)` every frame's four
+                // loads ended in a wait at the branch join -- two memory round trips in a row per iteration instead of one
+                float4 e4[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = tb + RNG * u, ttc = tt < lim ? tt : lim - 1;
+                    const float4* ep = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + ttc) * Hd);
+#pragma unroll
+                    for (int n4 = 0; n4 < 4; ++n4) {
+                        const int h0 = sl + 32 * n4;
+                        e4[u][n4] = ep[h0 < Hd / 4 ? h0 : Hd / 4 - 1];
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int tt = tb + RNG * u;
                     if (tt < lim) {
                         const float4* ep = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd);
-                        float4 e4[4];
-#pragma unroll
-                        for (int n4 = 0; n4 < 4; ++n4) {
-                            const int h0 = sl + 32 * n4;
-                            e4[n4] = h0 < Hd / 4 ? ep[h0] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
 #pragma unroll
                         for (int n4 = 0; n4 < 4; ++n4) {
                             const int h0 = sl + 32 * n4;
                             if (h0 < Hd / 4) {
                                 const float4 d4 = reinterpret_cast<const float4*>(dctx)[h0];
-                                acc2[u] += d4.x * e4[n4].x + d4.y * e4[n4].y + d4.z * e4[n4].z + d4.w * e4[n4].w;
+                                acc2[u] += d4.x * e4[u][n4].x + d4.y * e4[u][n4].y + d4.z * e4[u][n4].z + d4.w * e4[u][n4].w;
                             }
                         }
                         for (int h0 = sl + 128; h0 < Hd / 4; h0 += 32) {       // Hd > 512
@@ -1762,6 +1778,9 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
         float du_acc[8], dq_acc[8];    // A <= 256 -> at most 2 float4 per lane
 #pragma unroll
         for (int i = 0; i < 8; ++i) { du_acc[i] = 0.f; dq_acc[i] = 0.f; }
+        float4 u4s[2];                               // (loop-invariant: was re-loaded -- and waited for -- per frame and slot)
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) u4s[slot] = reinterpret_cast<const float4*>(a.u)[min(sl + 32 * slot, A / 4 - 1)];
         for (int tb = grp; tb < Tp; tb += 2 * RNG) {
           float4 kpre[2][2], dkpre[2][2];            // [frame][a4 slot]: keys and dKeys prefetched for both frames
 #pragma unroll
@@ -1770,13 +1789,12 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
 #pragma unroll
             for (int slot = 0; slot < 2; ++slot) {
                 const int a4 = sl + 32 * slot;
-                if (tt < Tp && a4 < A / 4) {
-                    kpre[u][slot] = reinterpret_cast<const float4*>(a.keys + ((size_t)b * Tp + tt) * A)[a4];
-                    dkpre[u][slot] = reinterpret_cast<const float4*>(a.dKeys + ((size_t)b * Tp + tt) * A)[a4];
-                } else {
-                    kpre[u][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    dkpre[u][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                // (unconditional, clamped addresses, zero by select: no branch join in front of the loads that follow)
+                const bool on = tt < Tp && a4 < A / 4;
+                const size_t o4 = ((size_t)b * Tp + (tt < Tp ? tt : Tp - 1)) * (A / 4) + (a4 < A / 4 ? a4 : A / 4 - 1);
+                const float4 kv = reinterpret_cast<const float4*>(a.keys)[o4], dkv = reinterpret_cast<const float4*>(a.dKeys)[o4];
+                kpre[u][slot] = on ? kv : make_float4(0.f, 0.f, 0.f, 0.f);
+                dkpre[u][slot] = on ? dkv : make_float4(0.f, 0.f, 0.f, 0.f);
             }
           }
 #pragma unroll
@@ -1793,7 +1811,7 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
                 if (a4 >= A / 4) continue;
                 const float4 k4 = kpre[u][slot];
                 const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
-                const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+                const float4 u4 = u4s[slot];
                 float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
                 if (loc) {
                     for (int c = 0; c < a.C; ++c) {
@@ -1910,6 +1928,25 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
             const int sl2 = tid & 31, grp2 = tid >> 5;
             for (int ib = grp2; ib < S; ib += 8 * RNG) {
                 float acc8[8];
+                if (A / 4 <= 32) {
+                    // (round 5) one 16-byte piece of each of the eight rows per lane, all eight requested before the first is used: as
+                    // `if (i < S) { for (a4 ...) load, use }` the "8 rows in flight" were eight round trips in a row (16 per step)
+                    float4 w8[8];
+                    const int a4c = sl2 < A / 4 ? sl2 : A / 4 - 1;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = ib + RNG * u;
+                        w8[u] = reinterpret_cast<const float4*>(a.Ws + (size_t)(i < S ? i : S - 1) * A)[a4c];
+                    }
+                    const float4 d4 = reinterpret_cast<const float4*>(L.qv)[a4c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = ib + RNG * u;
+                        const float4 w4 = w8[u];
+                        acc8[u] = 0.f;
+                        if (i < S && sl2 < A / 4) acc8[u] += w4.x * d4.x + w4.y * d4.y + w4.z * d4.z + w4.w * d4.w;
+                    }
+                } else
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = ib + RNG * u;
@@ -1923,13 +1960,21 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_kernel(DecDev a, int t_att, 
                         }
                     }
                 }
+                // (round 5) the recurrent gradients the eight sums are added to are requested together: one lane per half-wave loaded
+                // pointer / pitch / offset of rec[l], waited, loaded the value, waited, stored -- sixteen round trips in a row
+                float r8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = ib + RNG * u, ic = i < S ? i : S - 1, l = ic / D, d = ic % D;
+                    r8[u] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = ib + RNG * u;
                     const float v = sub32_sum(acc8[u]);
                     if (sl2 == 0 && i < S) {
                         const int l = i / D, d = i % D;
-                        a.dH[((size_t)l * B + b) * D + d] = a.rec[l][(size_t)b * a.recLd[l] + a.recOff[l] + d] + v;
+                        a.dH[((size_t)l * B + b) * D + d] = r8[u] + v;
                     }
                 }
             }
