@@ -203,9 +203,10 @@ class _BLSTM(torch.autograd.Function):
         if two:
             x_bw = x_bw.contiguous()
         Ik = I
-        if prec == _hip.PREC_BF16 and I % 4 and (I + 3) // 4 * 4 <= I + H:
+        if I % 4 and (I + 3) // 4 * 4 <= I + H:
             # MFCC-39: pad the operand with zero columns up to a multiple of 4 so the contraction takes the branch-free
-            # MFMA path (16-byte loads).  The extra weight rows it meets are the first rows of W_hh: multiplied by zeros
+            # MFMA path (16-byte loads) -- in both precisions since round 5 (the parity mode's exact-fp32 kernels have one too; a zero
+            # times a weight is an exact zero at the end of the fma chain: bit-identical).  The extra weight rows it meets are the first rows of W_hh: multiplied by zeros
             # here, and given an exactly-zero gradient contribution in backward.
             Ik = (I + 3) // 4 * 4
             x = torch.nn.functional.pad(x, (0, Ik - I))
