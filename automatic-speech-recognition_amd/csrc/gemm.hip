@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0);   // (C^T tiles: see the epilogue)
             __builtin_amdgcn_sched_barrier(0);       // keep the next k-step's reads in front of this k-step's MFMAs
         }
 #else
@@ -956,28 +956,49 @@ __global__ __launch_bounds__(256) void gemm_mf32_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
 #endif
     }
-    // epilogue: lane holds rows (lane >> 4) * 4 + r, column lane & 15 of each 16 x 16 tile
+    // epilogue.  The products above are issued with the operands swapped (B fragment first): a tile comes out TRANSPOSED, lane (li, lk)
+    // holds row li and the four CONSECUTIVE columns 4 lk .. 4 lk + 3 -- one 16-byte store per tile and lane instead of four 4-byte stores
+    // to four rows (round 5; every dot product is the same k-ordered fma chain: bit-identical)
+    const bool cvec = (g.ldc % 4) == 0 && (((uintptr_t)C) & 15) == 0 && (g.N % 4) == 0;
+    const bool pvec = (g.N % 4) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 16 + li;
+            const int row = m0 + (wm * TM + i) * 16 + li, col0 = n0 + (wn * TN + j) * 16 + lk * 4;
+            if (row >= g.M || col0 >= g.N) continue;
+            if (g.splitk > 1) {
+                float* pp = g.partial + ((long long)blockIdx.z * g.M + row) * g.N + col0;
+                if (pvec) *reinterpret_cast<float4*>(pp) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (col0 + r < g.N) pp[r] = acc[i][j][r];
+                }
+                continue;
+            }
+            float* cp = C + (long long)row * g.ldc + col0;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + (wm * TM + i) * 16 + lk * 4 + r;
-                if (row < g.M && col < g.N) {
-                    if (g.splitk > 1) {
-                        g.partial[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
-                    } else {
-                        float v = g.alpha * acc[i][j][r];
-                        if (g.bias) v += g.bias[col];
-                        float* cp = C + (long long)row * g.ldc + col;
-                        if (g.beta != 0.f) v += g.beta * (*cp);
-                        *cp = apply_act(v, g.act);
+                v[r] = g.alpha * acc[i][j][r];
+                if (g.bias && col0 + r < g.N) v[r] += g.bias[col0 + r];
+            }
+            if (cvec) {
+                if (g.beta != 0.f) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(cp);
+                    v[0] += g.beta * c4.x; v[1] += g.beta * c4.y; v[2] += g.beta * c4.z; v[3] += g.beta * c4.w;
+                }
+                *reinterpret_cast<float4*>(cp) = make_float4(apply_act(v[0], g.act), apply_act(v[1], g.act), apply_act(v[2], g.act), apply_act(v[3], g.act));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (col0 + r < g.N) {
+                        if (g.beta != 0.f) v[r] += g.beta * cp[r];
+                        cp[r] = apply_act(v[r], g.act);
                     }
                 }
             }

@@ -21,7 +21,7 @@ def timeit(fn, reps=10):
 
 BT = 48 * 1274
 P = _hip.PREC_F32
-rows = [("x-proj L0  NN", BT, 2048, 39, 0, 0, 1), ("x-proj L1  NN", BT, 2048, 512, 0, 0, 1), ("dense L0   NN", BT, 512, 512, 0, 0, 1),
+rows = [("x-proj L0  NN", BT, 2048, 39, 0, 0, 1), ("x-proj L0 (K padded to 40, as the step runs it)", BT, 2048, 40, 0, 0, 1), ("x-proj L1  NN", BT, 2048, 512, 0, 0, 1), ("dense L0   NN", BT, 512, 512, 0, 0, 1),
         ("dense L1   NN", BT // 2, 512, 1024, 0, 0, 1), ("dX x-proj  NT", BT, 512, 2048, 0, 1, 1), ("dX dense   NT", BT, 512, 512, 0, 1, 1),
         ("dW_ih      TN", 512, 1024, BT, 1, 0, 1), ("dW dense   TN", 512, 512, BT, 1, 0, 1), ("dW_hh batched TN", 256, 1024, 1273, 1, 0, 48),
         ("cell step  NN", 48, 2048, 1152, 0, 0, 1), ("cell step  NT", 48, 1152, 2048, 0, 1, 1), ("dcellW     TN", 1152, 2048, 48 * 191, 1, 0, 1),
