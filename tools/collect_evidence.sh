@@ -12,6 +12,9 @@ P=${1:-r2}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+# ---- first, on the fresh box: the whole GPU suite as the driver runs it (one process, -rs: every skip with its reason).  (Round 5: run LAST, behind eleven
+# profiler passes and the eight-process host-time tool, it hit the documented exchange time-out once -- profiles/r5_pytest_gpu_behind_profilers.log)
+LAS_PARITY_LOG=$PWD/gpurun_out/${P}_parity_full_T.jsonl python3 -m pytest tests -m gpu -q -rs > gpurun_out/${P}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${P}_pytest_gpu.log
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$P -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-train-loop > gpurun_out/${P}_kt.log 2>&1
 python3 tools/kernel_stats.py /tmp/kt_$P 3 gpurun_out/${P}_kernel_stats.csv > /dev/null
 # counter passes serialise kernels: the x-projection chunks (another stream's kernels the running sweep waits for) must be off there
@@ -68,6 +71,4 @@ bash tools/ab_bench.sh LAS_NO_PREPARED_SWEEPS=0 LAS_NO_PREPARED_SWEEPS=1 3 60 > 
 python3 tools/probe_host_ahead.py > gpurun_out/${P}_host_ahead.txt 2>&1
 # ---- eight ranks' host side on this box (one GPU: the steps run one rank at a time behind command-processor gates)
 timeout 900 python3 tools/host_time_ranks.py --ranks 8 --steps 4 --out gpurun_out/${P}_host_ranks_8.json > /dev/null 2>&1
-# ---- the whole GPU suite as the driver runs it (one process, -rs: every skip with its reason)
-LAS_PARITY_LOG=$PWD/gpurun_out/${P}_parity_full_T.jsonl python3 -m pytest tests -m gpu -q -rs > gpurun_out/${P}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${P}_pytest_gpu.log
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300
