@@ -29,11 +29,21 @@ class BeamState(object):
     """hypothesis record (reference las/beam_search.py:7-30)."""
 
     def __init__(self, token_ids, log_prob, att, dec_state, lm_state):
-        self.token_ids = token_ids
+        self._token_ids = token_ids             # a list, or (round 5, decode_batch's results) a (start id, numpy row) pair turned into the list on first use
         self.log_prob = log_prob
         self.att = att
         self.dec_state = dec_state
         self.lm_state = lm_state
+
+    @property
+    def token_ids(self):
+        if isinstance(self._token_ids, tuple):
+            self._token_ids = [self._token_ids[0]] + self._token_ids[1].tolist()
+        return self._token_ids
+
+    @token_ids.setter
+    def token_ids(self, v):
+        self._token_ids = v
 
     def update(self, token_id, log_prob, att, dec_state, lm_state):
         """new state extended by one token; log_prob accumulates (float32 once a float32 logit is added)."""
@@ -45,11 +55,20 @@ class _AttRows(collections.abc.Sequence):
     las/beam_search.py:88), all items views of ONE [len, T'] tensor gathered from the device-side history in a single
     indexing operation -- building a Python list of 200 slices per hypothesis was a third of the decode time."""
 
-    def __init__(self, rows):
-        self._rows = rows
+    def __init__(self, rows, lo=None, n=None, width=None):
+        # (round 5) lazily sliced: `rows` may be the gathered tensor of ALL hypotheses of a batch, this hypothesis being rows
+        # [lo, lo + n) x [0, width) -- a torch slice per hypothesis was most of the 4 ms the host spent after a 64-utterance search
+        self._all, self._lo, self._n, self._w = rows, lo, n, width
+        self._cut = rows if lo is None else None
+
+    @property
+    def _rows(self):
+        if self._cut is None:
+            self._cut = self._all[self._lo:self._lo + self._n, :self._w]
+        return self._cut
 
     def __len__(self):
-        return self._rows.shape[0]
+        return self._rows.shape[0] if self._lo is None else self._n
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -465,13 +484,24 @@ class BeamSearch(object):
         g_att = alphas_hist[t_idx, r_idx]
         lens, ids_h, sc_h = w_len.cpu().numpy(), w_ids.cpu().numpy(), w_score.cpu().numpy()
         _hip.check_status(dev)
-        results, off = [[] for _ in range(n)], 0
-        for w in np.nonzero(lens)[0].tolist():
-            u, ln_ = w // selcap, int(lens[w])
-            results[u].append(BeamState([self.start_id] + ids_h[w, :ln_].tolist(), np.float32(sc_h[w]),
-                                        _AttRows(g_att[off:off + ln_ + 1, :Tps[u]]), None, None))
-            off += ln_ + 1
-        results = [self._select_best_k(sel, NORM) for sel in results]
+        mark("read back")
+        # The reference's final ranking (_select_best_k: stable argsort of log_prob [/ (len - 1)], the last beam_size) on the read-back
+        # arrays; host objects are built for the SELECTED hypotheses only (round 5: one BeamState + one tensor slice for each of the
+        # <= 2 x beam candidates of every utterance was 4.2 ms behind a 64-utterance search, a tenth of the batch)
+        nz = np.nonzero(lens)[0]
+        offs = np.concatenate(([0], np.cumsum(lens[nz] + 1)))[:-1] if nz.size else np.zeros(0, np.int64)
+        results = [[] for _ in range(n)]
+        first = np.searchsorted(nz, np.arange(n + 1) * selcap)
+        for u in range(n):
+            ws, of = nz[first[u]:first[u + 1]], offs[first[u]:first[u + 1]]
+            if ws.size == 0:
+                continue
+            sc = sc_h[ws].astype(np.float32)
+            key = sc / lens[ws].astype(np.float32) if NORM else sc
+            for i in np.argsort(key, kind="stable")[-self.beam_size:].tolist():
+                w, ln_ = int(ws[i]), int(lens[ws[i]])
+                results[u].append(BeamState((self.start_id, ids_h[w, :ln_]), np.float32(sc_h[w]),
+                                            _AttRows(g_att, int(of[i]), ln_ + 1, Tps[u]), None, None))
         mark("done")
         parts = {}
         if tm:        # device time of the three parts of a decode step (HIP events, 50 eager repetitions each, after the search)
