@@ -114,6 +114,7 @@ class BeamSearch(object):
         self._enc_streams = None
         self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
         self.last_timing = None
+        self._capture_stream = None
 
     # -- model calls (the reference's sess.run wrappers, las/beam_search.py:203-246) -------------------
     def _get_encode(self, sess, audio, audiolen):
@@ -182,7 +183,7 @@ class BeamSearch(object):
             audio = np.concatenate([np.asarray(xs_list[u][0]) for u in us], 0)
             audiolen = np.concatenate([np.asarray(xs_list[u][1]).reshape(-1)[:1] for u in us], 0)
             h, enc_len = self._get_encode(sess, audio, audiolen)
-            el = torch.as_tensor(enc_len).reshape(-1)
+            el = torch.as_tensor(enc_len).reshape(-1).cpu().tolist()       # (one read-back, not one per utterance)
             for i, u in enumerate(us):
                 encs[u] = h[i:i + 1]
                 enc_lens[u] = float(el[i])
@@ -210,7 +211,7 @@ class BeamSearch(object):
                 h, enc_len = self._get_encode(sess, audio, audiolen)
             finally:
                 L.ROW_T[0] = None
-            el = torch.as_tensor(enc_len).reshape(-1)
+            el = torch.as_tensor(enc_len).reshape(-1).cpu().tolist()
             for u in range(n):
                 tp = lens[u]
                 for _ in range(a.num_enc_layers):
@@ -444,10 +445,21 @@ class BeamSearch(object):
                     t += K
                 elif use_graph and t == 1:
                     try:
+                        # (capture_begin / capture_end by hand: the torch.cuda.graph context synchronises the device and EMPTIES the
+                        #  caching allocator on entry -- a millisecond per search, and every buffer of the next search a fresh hipMalloc)
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            for _ in range(K):
-                                one_step()
+                        if self._capture_stream is None:
+                            self._capture_stream = torch.cuda.Stream()
+                        cs_ = self._capture_stream
+                        cs_.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(cs_):
+                            g.capture_begin()
+                            try:
+                                for _ in range(K):
+                                    one_step()
+                            finally:
+                                g.capture_end()
+                        torch.cuda.current_stream().wait_stream(cs_)
                         graph = g                      # (capturing does not execute: the captured steps run as the replay)
                         graph.replay()
                         t += K
