@@ -190,6 +190,7 @@ class BeamSearch(object):
             return h
 
         glist = list(groups.values())
+        h_one = None                         # the encoder output of all utterances when they form one group
         cellid = L._cellid(sp.cell)
         H_enc = a.enc_units
         ragged = (len(glist) > 1 and self.ragged_encoder and prec == _hip.PREC_BF16 and a.enc_type.lower() == "pblstm" and
@@ -220,7 +221,9 @@ class BeamSearch(object):
                 enc_lens[u] = float(el[u])
             glist = []
         else:
-            encode_group(glist[0])
+            h_one = encode_group(glist[0])
+            if len(glist) > 1:
+                h_one = None
         if ragged:
             pass
         elif len(glist) > 1 and self.parallel_encoders:
@@ -254,11 +257,21 @@ class BeamSearch(object):
         enc_t = torch.zeros(N, Tp, Hd, device=dev)          # resident for the whole search; frames past T'_u are masked
         keys_t = torch.zeros(N, Tp, A, device=dev)
         Wh = P["Wh"].detach()
-        for u, h in enumerate(encs):
-            k = torch.empty(1, Tps[u], A, device=dev)
-            _hip.gemm(prec, h.contiguous(), Wh, k, False, False, Tps[u], A, Hd, Hd, A, A)
-            enc_t[u * beam:(u + 1) * beam, :Tps[u]] = h
-            keys_t[u * beam:(u + 1) * beam, :Tps[u]] = k
+        if h_one is not None and h_one.shape[0] == n:
+            # every utterance in ONE encoder group (equal lengths): the hoisted key projection as one product and two broadcast copies
+            # instead of a product and two copies per utterance (192 launches, ~2 ms of a 64-utterance batch; the same k order per
+            # element: bit-identical)
+            hc = h_one.contiguous()
+            k_all = torch.empty(n, Tp, A, device=dev)
+            _hip.gemm(prec, hc, Wh, k_all, False, False, n * Tp, A, Hd, Hd, A, A)
+            enc_t.view(n, beam, Tp, Hd).copy_(hc.unsqueeze(1).expand(n, beam, Tp, Hd))
+            keys_t.view(n, beam, Tp, A).copy_(k_all.unsqueeze(1).expand(n, beam, Tp, A))
+        else:
+            for u, h in enumerate(encs):
+                k = torch.empty(1, Tps[u], A, device=dev)
+                _hip.gemm(prec, h.contiguous(), Wh, k, False, False, Tps[u], A, Hd, Hd, A, A)
+                enc_t[u * beam:(u + 1) * beam, :Tps[u]] = h
+                keys_t[u * beam:(u + 1) * beam, :Tps[u]] = k
         enc_len_i32 = torch.tensor(np.repeat(np.asarray(enc_lens, np.float64), beam)).to(torch.int32).to(dev)
         Umax = max(max(dec_steps), 1)
         # ---- device-resident loop state
