@@ -105,13 +105,24 @@ def main():
     limit = args.max_steps if args.max_steps >= 0 else (8 if args.synthetic else len(order))
     todo = parallel.shard(list(order[:limit]), rank, world)
     nb = max(1, int(args.decode_batch))
-    for c0 in range(0, len(todo), nb):                             # decode.py:131-149, `decode_batch` utterances per call
-        chunk = todo[c0:c0 + nb]
-        xs_list = []
-        for i in chunk:
-            audio = np.asarray(dev_feats[i], np.float32)
-            xs_list.append((audio[None], np.asarray([audio.shape[0]], np.int32)))
-        for i, beam_states in zip(chunk, bs.decode_batch(None, xs_list)):
+    chunks = [todo[c0:c0 + nb] for c0 in range(0, len(todo), nb)]  # decode.py:131-149, `decode_batch` utterances per call
+
+    def batches():
+        for chunk in chunks:
+            xs_list = []
+            for i in chunk:
+                audio = np.asarray(dev_feats[i], np.float32)
+                xs_list.append((audio[None], np.asarray([audio.shape[0]], np.int32)))
+            yield xs_list
+
+    # the model's objects live as long as the process: out of the cyclic collector's way (a full collection walks them all, 30-60 ms --
+    # a batch and a half -- every few batches otherwise)
+    import gc
+    gc.collect()
+    gc.freeze()
+    # decode_batches: the encoders of the next chunk run under the search of this one
+    for chunk, results in zip(chunks, bs.decode_batches(None, batches())):
+        for i, beam_states in zip(chunk, results):
             hyp = convert_idx_to_string(beam_states[-1].token_ids[1:], id_to_token, args.unit)
             ref = convert_idx_to_string(dev_tokens[i], id_to_token, args.unit)
             dist, n = edit_distance(ref.split(" "), hyp.split(" "))

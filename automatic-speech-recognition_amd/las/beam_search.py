@@ -142,33 +142,50 @@ class BeamSearch(object):
             raise ValueError('batch size must be 1 while performing beam search.')
         return self.decode_batch(sess, [xs])[0]
 
-    def decode_batch(self, sess, xs_list, sync_every=32):
-        """Beam search for several utterances at once (what decode.py's loop over utterances, decode.py:131-149, becomes on
-        one GPU): xs_list = [(audio [1,T_u,feat_dim,3], audiolen [1]), ...] -> [list of BeamState (ascending), ...].
+    def decode_batches(self, sess, batches, sync_every=32):
+        """decode_batch over a SEQUENCE of batches (decode.py's loop over a test set), as a generator of its results -- with the encoders
+        of batch k+1 on a second stream UNDER the search of batch k.  An encoder pass is four latency-bound sweeps on 8-72 of the 256 CUs and
+        a search step is three small launches, so the two fit side by side; one after the other the encoders are a fifth of a 64-utterance
+        batch (7 of 35 ms).  The results are those of decode_batch, batch by batch (the same kernels on the same inputs; only the
+        stream differs)."""
+        dev = self._las._device()
+        main = torch.cuda.current_stream(dev)
+        # the device's `comm` auxiliary stream (idle outside training) -- it owns a hardware queue (_hip.aux_streams); a fresh stream would
+        # share one of the four queues with the launch stream or an auxiliary stream and its kernels would run in line with theirs
+        es = _hip.aux_streams(dev)["comm"]
 
-        Every utterance is ENCODED on its own, at its own length (the reference's encoder has no sequence mask, so its
-        output depends on the padded length -- SURVEY fact 4 -- and decode.py feeds unpadded utterances); the search then
-        runs all utterances x beam hypotheses as ONE batch of rows per step: fused Speller step (las_speller_fwd, U = 1)
-        [+ LM step + shallow fusion] + las_beam_loop_step (pruning, EOS retirement, termination, state gather -- all on
-        the device).  The host replays the launches without waiting and reads the back-pointer records once at the end
-        (plus one `done` poll every `sync_every` steps to stop early)."""
-        import ctypes
-        from las.las import _alloc_bufs, _fill_fwd_args
+        def launch(xs_list):
+            es.wait_stream(main)             # (everything queued so far: the first call's weight shadows, a caller's weight update)
+            with torch.cuda.stream(es):
+                pre = self._run_encoders(sess, xs_list)
+            ev = torch.cuda.Event()
+            ev.record(es)
+            seen = set()
+            for h in pre[0]:                 # allocated on `es`, read by the search on `main`
+                if h.untyped_storage().data_ptr() not in seen:
+                    seen.add(h.untyped_storage().data_ptr())
+                    h.record_stream(main)
+            return xs_list, pre, ev
+
+        it = iter(batches)
+        first = next(it, None)
+        cur = launch(first) if first is not None else None
+        while cur is not None:
+            nxt = next(it, None)
+            nxt = launch(nxt) if nxt is not None else None
+            main.wait_event(cur[2])
+            yield self.decode_batch(sess, cur[0], sync_every, _pre=cur[1])
+            cur = nxt
+
+    def _run_encoders(self, sess, xs_list):
+        """The encoders of a batch of utterances on the CURRENT stream, without waiting for the device (the encoded lengths are host
+        values): -> (encs [per utterance: [1, T'_u, Hd] views], enc_lens, dec_steps, h_one).  decode_batch's first phase; decode_batches
+        runs it for the NEXT batch on a second stream under the search of the current one."""
         a = self.args
         dev = self._las._device()
-        n, beam, V_, A, NL, D = len(xs_list), self.beam_size, a.vocab_size, a.attention_size, a.num_dec_layers, a.dec_units
+        n = len(xs_list)
         sp = self.speller
-        lstm = sp.cell == "lstm"
         prec = L._prec()
-        P = sp._params()
-        # ---- encoders (one per utterance) and the hoisted key projection
-        import time
-        tm = {}
-        def mark(name):                                  # wall-clock marks (with a device sync) only when asked for
-            if self.measure:
-                torch.cuda.synchronize(dev)
-                tm[name] = time.perf_counter()
-        mark("start")
         encs, enc_lens, dec_steps = [None] * n, [None] * n, []
         groups = {}
         for u, (audio, audiolen) in enumerate(xs_list):
@@ -251,6 +268,38 @@ class BeamSearch(object):
         else:
             for us in glist[1:]:
                 encode_group(us)
+        return encs, enc_lens, dec_steps, h_one
+
+    def decode_batch(self, sess, xs_list, sync_every=32, _pre=None):
+        """Beam search for several utterances at once (what decode.py's loop over utterances, decode.py:131-149, becomes on
+        one GPU): xs_list = [(audio [1,T_u,feat_dim,3], audiolen [1]), ...] -> [list of BeamState (ascending), ...].
+
+        Every utterance is ENCODED on its own, at its own length (the reference's encoder has no sequence mask, so its
+        output depends on the padded length -- SURVEY fact 4 -- and decode.py feeds unpadded utterances); the search then
+        runs all utterances x beam hypotheses as ONE batch of rows per step: fused Speller step (las_speller_fwd, U = 1)
+        [+ LM step + shallow fusion] + las_beam_loop_step (pruning, EOS retirement, termination, state gather -- all on
+        the device).  The host replays the launches without waiting and reads the back-pointer records once at the end
+        (plus one `done` poll every `sync_every` steps to stop early)."""
+        import ctypes
+        from las.las import _alloc_bufs, _fill_fwd_args
+        a = self.args
+        dev = self._las._device()
+        n, beam, V_, A, NL, D = len(xs_list), self.beam_size, a.vocab_size, a.attention_size, a.num_dec_layers, a.dec_units
+        sp = self.speller
+        lstm = sp.cell == "lstm"
+        prec = L._prec()
+        P = sp._params()
+        # ---- encoders (one per utterance) and the hoisted key projection
+        import time
+        tm = {}
+        def mark(name):                                  # wall-clock marks (with a device sync) only when asked for
+            if self.measure:
+                torch.cuda.synchronize(dev)
+                tm[name] = time.perf_counter()
+        mark("start")
+        if _pre is None:
+            _pre = self._run_encoders(sess, xs_list)
+        encs, enc_lens, dec_steps, h_one = _pre
         Tps = [h.shape[1] for h in encs]
         Tp, Hd = max(Tps), encs[0].shape[2]
         N = n * beam

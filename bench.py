@@ -249,7 +249,7 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     bs.ragged_encoder = bs.parallel_encoders = True
     # more utterances per device-resident batch (decode.py --decode_batch, default 64): the step's kernels are latency-bound at 256 rows,
     # so 512 / 1024 rows per step cost 1.4x / 2.2x the step time for 2x / 4x the utterances
-    larger, big = {}, None
+    larger, big, stream = {}, None, None
     for nb, nrep in ((32, 3), (64, 7)):
         try:
             more = []
@@ -270,6 +270,21 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
             if nb == 64:
                 big = {"value": round(rs[len(rs) // 2], 2), "min": round(rs[0], 1), "max": round(rs[-1], 1), "repetitions": nrep,
                        "spread": round((rs[-1] - rs[0]) / rs[len(rs) // 2], 4)}
+                # decode.py's loop over a test set (BeamSearch.decode_batches): the encoders of batch k+1 on a second stream under the
+                # search of batch k -- 6 batches per timing, the median of 5
+                list(bs.decode_batches(None, [more] * 2))
+                torch.cuda.synchronize()
+                ss = []
+                for rep in range(5):
+                    t1 = time.perf_counter()
+                    for _r in bs.decode_batches(None, [more] * 6):
+                        pass
+                    torch.cuda.synchronize()
+                    ss.append(6 * nb / (time.perf_counter() - t1))
+                ss.sort()
+                stream = {"value": round(ss[2], 2), "min": round(ss[0], 1), "max": round(ss[-1], 1), "batches_per_timing": 6, "repetitions": 5,
+                          "note": "BeamSearch.decode_batches (what decode.py runs): a stream of 64-utterance batches, the encoders of the next "
+                                  "batch overlapped with the search of the current one; `value` stays one decode_batch call at a time"}
         except Exception as e:
             larger[str(nb)] = "%s: %s" % (type(e).__name__, str(e)[:120])
     parts = tm.get("parts_us", {})
@@ -298,7 +313,7 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     return {"value": big["value"] if big else at16, "unit": "utterances/s", "beam": beam, "lm": "2x512 char RNNLM, lm_weight 0.5",
             # `value` changed geometry in round 4 (16 -> 64 utterances per device-resident batch = decode.py's default); both
             # geometries under explicit keys so that rounds compare like with like: value_b16 is rounds 1-3's `value`
-            "value_b16": at16, "value_b64": big["value"] if big else None,
+            "value_b16": at16, "value_b64": big["value"] if big else None, "value_b64_stream": stream,
             "utterances_per_batch_of_value": 64 if big else nutt, "value_timing": big, "at_16_utterances": at16,
             "utterances": nutt, "frames": T, "decode_steps": steps, "dtype": dtype, "seconds": round(dt, 4),
             "timing": {"utterances_per_timing": groups * nutt, "repetitions": reps, "value_is": "median",

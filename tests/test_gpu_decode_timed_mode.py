@@ -161,6 +161,33 @@ def test_forty_utterances_in_one_batch_equal_the_same_utterances_in_groups_of_ei
         assert torch.equal(a[-1].att[-1], b[-1].att[-1]), u
 
 
+def test_a_stream_of_batches_with_overlapped_encoders_equals_one_batch_at_a_time():
+    """BeamSearch.decode_batches (what decode.py's loop runs since round 5): the encoders of batch k+1 run on a second stream under the
+    search of batch k.  Five batches of different geometry (equal lengths, ragged lengths, a single utterance, different counts -- so the
+    search's graph is re-captured while the next encoders are in flight) must give, batch by batch, bit for bit what decode_batch gives
+    one batch at a time; run twice (the second pass reuses the first one's streams, workspaces and freed encoder buffers)."""
+    args, p0, plm, bs, _ = _setup("bf16")
+    mk = lambda T_, k: synthetic_batch(1, T_, 8, 30, seed=700 + k)[0]
+    batches = [[mk(260, k) for k in range(6)],
+               [mk(T_, 10 + k) for k, T_ in enumerate((300, 287, 251, 300, 199, 274, 131))],
+               [mk(222, 20)],
+               [mk(260, 30 + k) for k in range(6)],
+               [mk(T_, 40 + k) for k, T_ in enumerate((97, 300, 188))]]
+    want = [bs.decode_batch(None, b) for b in batches]
+    for rnd in range(2):
+        got = list(bs.decode_batches(None, iter(batches)))
+        assert len(got) == len(want)
+        for k, (gb, wb) in enumerate(zip(got, want)):
+            assert len(gb) == len(wb) == len(batches[k])
+            for a, b in zip(gb, wb):
+                assert [h.token_ids for h in a] == [h.token_ids for h in b], (rnd, k)
+                assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], (rnd, k)
+                assert torch.equal(a[-1].att[-1], b[-1].att[-1]), (rnd, k)
+    assert list(bs.decode_batches(None, [])) == []
+    from las import _hip
+    _hip.check_status()
+
+
 def test_bf16_sixty_four_utterances_at_T_1274_match_the_bf16_oracle():
     """The geometry bench.py's decode `value` is quoted on since round 4: 64 utterances x beam 16 = 1024 hypothesis
     rows per step, T = 1274 frames (T' = 160), 2 x 512 LM fused in, one captured step replayed -- `lstm_cell_rows` at M = 1024, the

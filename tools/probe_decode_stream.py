@@ -1,0 +1,59 @@
+"""utterances/s of a stream of decode batches: BeamSearch.decode_batch one call at a time against BeamSearch.decode_batches (the
+encoders of batch k+1 on a second stream under the search of batch k), for NUTT utterances per batch (default 16 32 64)."""
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+for p in (os.path.join(ROOT, "automatic-speech-recognition_amd"), os.path.join(ROOT, "tests"), ROOT):
+    sys.path.insert(0, p)
+import torch, bench
+from helpers import synthetic_batch
+from las import layers as L, variables as V
+from las.beam_search import BeamSearch
+from las.las import LAS, Listener, Speller
+from lang.char_rnn_model import CharRNN
+from utils.tokenizer import CharEncoder
+dev = torch.device("cuda", 0)
+L.set_cell("lstm"); L.set_precision("bf16")
+st = V.reset_default_store(device=dev, seed=0)
+args = bench.bench_args("lstm")
+args.beam_size, args.apply_lm, args.lm_weight, args.convert_rate = 16, True, 0.5, 0.166
+args.verbose = 0
+tok = CharEncoder()
+las = LAS(args, Listener, Speller, tok.token_to_id)
+lm = CharRNN(False, 1, 1, 28, 512, embedding_size=0, num_layers=2, store=st)
+lm.params(); las.build_variables()
+bs = BeamSearch(args, las, tok.token_to_id, lm)
+for NUTT in [int(x) for x in os.environ.get("NUTT", "16 32 64").split()]:
+    utts = [synthetic_batch(1, 1274, 8, 30, seed=100 + k)[0] for k in range(NUTT)]
+    NB = max(6, 256 // NUTT)
+    bs.decode_batch(None, utts[:2]); bs.decode_batch(None, utts); list(bs.decode_batches(None, [utts] * 2))
+    one, stream = [], []
+    for rep in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(NB): bs.decode_batch(None, utts)
+        torch.cuda.synchronize(); one.append(NB * NUTT / (time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        for _ in bs.decode_batches(None, [utts] * NB): pass
+        torch.cuda.synchronize(); stream.append(NB * NUTT / (time.perf_counter() - t0))
+    print("   one at a time:", ["%.0f" % v for v in one], "stream:", ["%.0f" % v for v in stream])
+    single = []
+    for rep in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        bs.decode_batch(None, utts)
+        torch.cuda.synchronize(); single.append(NUTT / (time.perf_counter() - t0))
+    print("   single calls:", ["%.0f" % v for v in single])
+    one.sort(); stream.sort()
+    print("%2d utterances per batch, %2d batches: one at a time %7.1f utt/s | decode_batches %7.1f utt/s (%+.1f %%)"
+          % (NUTT, NB, one[2], stream[2], 100 * (stream[2] / one[2] - 1)), flush=True)
+    for rep in range(4):
+        torch.cuda.synchronize(); ts = [time.perf_counter()]
+        for _ in bs.decode_batches(None, [utts] * 8):
+            ts.append(time.perf_counter())
+        print("   per-batch ms:", ["%.1f" % ((b - a) * 1e3) for a, b in zip(ts, ts[1:])], flush=True)
+    import gc
+    gc.collect(); gc.disable()
+    for rep in range(6):
+        torch.cuda.synchronize(); ts = [time.perf_counter()]
+        for _ in bs.decode_batches(None, [utts] * 8):
+            ts.append(time.perf_counter())
+        print("   gc off, per-batch ms:", ["%.1f" % ((b - a) * 1e3) for a, b in zip(ts, ts[1:])], flush=True)
+    gc.enable()
