@@ -319,6 +319,14 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_big_kernel(LstmCellLaunch 
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     lstm_cell_rows_big_body<FAST, XBF>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
 }
+// ... and two independent cells of 128-row workgroups in one grid (blockIdx.z as in the pair kernel above): at 240 VGPRs a CU holds one
+// workgroup, so the two problems run one behind the other -- but without the 32-row bodies' four rounds per problem (r5, M = 1024: 29 us
+// against the pair kernel's 35)
+__global__ __launch_bounds__(512) void lstm_cell_rows_big_pair_kernel(LstmCellLaunch a, LstmCellLaunch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+    if (blockIdx.z == 0) lstm_cell_rows_big_body<true, true>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+    else                 lstm_cell_rows_big_body<false, false>(b, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+}
 constexpr int LB_MIN_ROWS = 384;          // from here on a launch of 32-row workgroups is more than one round of the 256 CUs per 512 units
 template <typename K>
 static int lb_attr(K kern) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES); }
@@ -364,8 +372,14 @@ int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b,
         if (int rc = las_lstm_cell_rows_launch(a, st)) return rc;
         return las_lstm_cell_rows_launch(b, st);
     }
-    // (the 128-row body as a pair -- lstm_cell_rows_big_pair_kernel -- measured 42-48 us at M = 1024 against 39 for the pair of 32-row bodies
-    //  below: at 200 VGPRs its two problems cannot share a CU, they simply run one after the other; the single-cell launch does gain, 30 vs 37)
+    if (a.M >= LB_MIN_ROWS && b.M >= LB_MIN_ROWS) {
+        static int attr = lb_attr(lstm_cell_rows_big_pair_kernel);
+        if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big_pair) failed: %d", attr); return attr; }
+        const int bx = (a.H > b.H ? a.H : b.H) / 16, by = cdiv(a.M > b.M ? a.M : b.M, LB_ROWS);
+        hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
+        LAS_LAUNCHED();
+        return 0;
+    }
     const int gx = (a.H > b.H ? a.H : b.H) / 16, gy = cdiv(a.M > b.M ? a.M : b.M, 32);
     hipLaunchKernelGGL(lstm_cell_rows_pair_kernel, dim3(gx, gy, 2), dim3(512), 0, st, a, b);
     LAS_LAUNCHED();

@@ -39,20 +39,28 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
 #pragma unroll
                 for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bp[(size_t)min((k0 >> 5) + u, KS - 1) * 64];
                 __syncthreads();                                      // the previous chunk's readers are done
+                // thread -> (row, 16-byte piece) with COMPILE-TIME pieces per row (a chunk shorter than LC_KC leaves lanes idle): the mapping
+                // by `idx / pieces-of-this-chunk` was an integer division per load and per store -- 1,300 instructions per thread and chunk
                 if (sbf) {
-                    for (int idx = tid; idx < 32 * (kc >> 3); idx += 512) {
-                        const int r = idx / (kc >> 3), q = idx - r * (kc >> 3);
-                        const int row = min(row0 + r, a.M - 1);
-                        *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
-                            *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                    const int q = tid & 63, rb = tid >> 6;
+                    if (q < (kc >> 3)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = rb + j * 8, row = min(row0 + r, a.M - 1);
+                            *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
+                                *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
+                        }
                     }
                 } else {
-                    for (int idx = tid; idx < 32 * (kc >> 2); idx += 512) {
-                        const int r = idx / (kc >> 2), q = idx - r * (kc >> 2);
-                        const int row = min(row0 + r, a.M - 1);
-                        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
-                        uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
-                        *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+                    const int q = tid & 127, rb = tid >> 7;
+                    if (q < (kc >> 2)) {
+#pragma unroll 4                                                      // (four loads in flight: with all eight the pair kernel passes 128 VGPRs and its two problems no longer share a CU)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = rb + j * 4, row = min(row0 + r, a.M - 1);
+                            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
+                            uint2 pk; pk.x = f2bf2(v.x, v.y); pk.y = f2bf2(v.z, v.w);
+                            *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+                        }
                     }
                 }
                 __syncthreads();
@@ -86,21 +94,21 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
         auto load_a = [&](const int ci) {
             const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
             chunk(ci, src, ld, k0, kc, bp, sbf);
+            // thread -> (row, 16-byte piece), pieces per row fixed at compile time (see the unpipelined path); idle lanes of a short chunk
+            // re-read piece 0 of their row
             if (sbf) {
-                const int per = kc >> 3;
+                const int q0 = tid & 63, q = q0 < (kc >> 3) ? q0 : 0, rb = tid >> 6;
     #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
-                    const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                    const int row = min(row0 + rb + j * 8, a.M - 1);
                     const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
                     ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                 }
             } else {
-                const int per = kc >> 2;
+                const int q0 = tid & 127, q = q0 < (kc >> 2) ? q0 : 0, rb = tid >> 7;
     #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int idx = tid + j * 512, ic = idx < 32 * per ? idx : 0;
-                    const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                    const int row = min(row0 + rb + j * 4, a.M - 1);
                     ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
                 }
             }
@@ -109,25 +117,20 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
             const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
             chunk(ci, src, ld, k0, kc, bp, sbf);
             if (sbf) {
-                const int per = kc >> 3;
+                const int q = tid & 63, rb = tid >> 6;
+                if (q < (kc >> 3)) {
     #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + j * 512;
-                    if (idx < 32 * per) {
-                        const int r = idx / per, q = idx - r * per;
-                        *reinterpret_cast<uint4*>(As + r * LC_LD + q * 8) =
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint4*>(As + (rb + j * 8) * LC_LD + q * 8) =
                             make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
-                    }
                 }
             } else {
-                const int per = kc >> 2;
+                const int q = tid & 127, rb = tid >> 7;
+                if (q < (kc >> 2)) {
     #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int idx = tid + j * 512;
-                    if (idx < 32 * per) {
-                        const int r = idx / per, q = idx - r * per;
+                    for (int j = 0; j < 8; ++j) {
                         uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
-                        *reinterpret_cast<uint2*>(As + r * LC_LD + q * 4) = pk;
+                        *reinterpret_cast<uint2*>(As + (rb + j * 4) * LC_LD + q * 4) = pk;
                     }
                 }
             }
@@ -190,6 +193,9 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
 // and fragments in flight while the current one is multiplied.  Same arithmetic, element for element: bf16 operands, fp32 accumulation in
 // k order, gate math of the body above.
 // ------------------------------------------------------------------------------------------------
+#ifndef LB_STAMP
+#define LB_STAMP 0
+#endif
 #ifndef LB_ABL
 #define LB_ABL 0          // timing experiments (make ablf F=loss_opt D=-DLB_ABL=..): 1 no MFMAs, 2 no row loads after the first chunk, 4 no fragment loads after the first, 8 LDS-only barriers
 #endif
@@ -202,6 +208,15 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     const int gt = w & 3, rh = w >> 2;
     const int H = a.H, ct = gt * (H >> 4) + ub;
     if (ub * 16 >= H || row0 >= a.M) return;
+#if LB_STAMP
+    // timing build (make ablf F=loss_opt D=-DLB_STAMP=1; tools/bench_cell_rows.py STAMP=1): gates_out is a stamp buffer [workgroup][16] of
+    // 100 MHz ticks -- 0 entry, 1 first loads issued, 2+2c chunk c staged, 3+2c chunk c multiplied, 12 gates exchanged, 13 done
+    long long* lbs_ = reinterpret_cast<long long*>(a.gates_out) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+#define LBS(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0 && a.gates_out) lbs_[k] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LBS(k)
+#endif
+    LBS(0);
     // operands of the gate math at the end of the launch, requested here (see lstm_cell_rows_body): the thread's unit is the same for its
     // four elements (rows tid / 16 + 32 k)
     const int eunit_ = ub * 16 + (tid & 15);
@@ -243,21 +258,21 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     auto load_a = [&](const int ci) {
         const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
         chunk(ci, src, ld, k0, kc, bp, sbf);
+        // thread -> (row, 16-byte piece), pieces per row fixed at compile time (see lstm_cell_rows_body: the division by the chunk's piece
+        // count was 4.5 of the 5.7 us a chunk took -- r5 phase stamps); idle lanes of a short chunk re-read piece 0 of their row
         if (sbf) {
-            const int per = kc >> 3;
+            const int q0 = tid & 31, q = q0 < (kc >> 3) ? q0 : 0, rb = tid >> 5;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int idx = tid + j * 512, ic = idx < LB_ROWS * per ? idx : 0;
-                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                const int row = min(row0 + rb + j * 16, a.M - 1);
                 const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
                 ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
             }
         } else {
-            const int per = kc >> 2;
+            const int q0 = tid & 63, q = q0 < (kc >> 2) ? q0 : 0, rb = tid >> 6;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int idx = tid + j * 512, ic = idx < LB_ROWS * per ? idx : 0;
-                const int r = ic / per, q = ic - r * per, row = min(row0 + r, a.M - 1);
+                const int row = min(row0 + rb + j * 8, a.M - 1);
                 ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
             }
         }
@@ -266,25 +281,20 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
         chunk(ci, src, ld, k0, kc, bp, sbf);
         if (sbf) {
-            const int per = kc >> 3;
+            const int q = tid & 31, rb = tid >> 5;
+            if (q < (kc >> 3)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = tid + j * 512;
-                if (idx < LB_ROWS * per) {
-                    const int r = idx / per, q = idx - r * per;
-                    *reinterpret_cast<uint4*>(As + r * LB_LD + q * 8) =
+                for (int j = 0; j < 8; ++j)
+                    *reinterpret_cast<uint4*>(As + (rb + j * 16) * LB_LD + q * 8) =
                         make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
-                }
             }
         } else {
-            const int per = kc >> 2;
+            const int q = tid & 63, rb = tid >> 6;
+            if (q < (kc >> 2)) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int idx = tid + j * 512;
-                if (idx < LB_ROWS * per) {
-                    const int r = idx / per, q = idx - r * per;
+                for (int j = 0; j < 16; ++j) {
                     uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
-                    *reinterpret_cast<uint2*>(As + r * LB_LD + q * 4) = pk;
+                    *reinterpret_cast<uint2*>(As + (rb + j * 8) * LB_LD + q * 4) = pk;
                 }
             }
         }
@@ -292,11 +302,13 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     (void)NRA;
     load_b(0, bv);
     load_a(0);
+    LBS(1);
     for (int ci = 0; ci < nch; ++ci) {
         if (LB_ABL & 8) lds_barrier(); else __syncthreads();          // the previous chunk's readers are done
         store_a(ci);
         if (ci + 1 < nch) { if (!(LB_ABL & 4)) load_b(ci + 1, bn); if (!(LB_ABL & 2)) load_a(ci + 1); }
         if (LB_ABL & 8) lds_barrier(); else __syncthreads();
+        if (ci < 5) LBS(2 + 2 * ci);
         const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
         chunk(ci, src, ld, k0, kc, bp, sbf);
         const int nks = kc >> 5;
@@ -313,12 +325,14 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
 #pragma unroll
             for (int u = 0; u < NKS; ++u) bv[u] = bn[u];
         }
+        if (ci < 5) LBS(3 + 2 * ci);
     }
     __syncthreads();                                                  // every wave is done reading the row tile: its space becomes the gate exchange
     float* gx = reinterpret_cast<float*>(smem);                       // [rh 2][rt 4][gate 4][lane 64][4]
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4_t*>(gx + ((((rh * 4 + rt) * 4 + gt) * 64 + lane) << 2)) = acc[rt];
     __syncthreads();
+    LBS(12);
     // gate math: element (row r of the 128, unit u of the 16); MFMA C layout: (row r16, col u) of a tile sits in lane (r16 / 4) * 16 + u, register r16 % 4
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -340,9 +354,11 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         const float cn = fmaf(pc_[k], gf, gi * gj);
         a.c_out[o] = cn;
         a.h_out[o] = tanhx<FAST>(cn) * go;
-        if (a.gates_out) {
+        if (a.gates_out && !LB_STAMP) {
             float* gp = a.gates_out + (size_t)row * 4 * H + unit;
             gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;
         }
     }
+    LBS(13);
+#undef LBS
 }

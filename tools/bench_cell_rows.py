@@ -19,7 +19,7 @@ def timeit(fn, n=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for M in (256, 1024):
+for M in [int(v) for v in os.environ.get("MS", "256 1024").split()]:
     H, I = 512, 512
     kern = (torch.randn(I + H, 4 * H, generator=g) * 0.05).to(dev)
     bias = torch.zeros(4 * H, device=dev)
@@ -41,3 +41,28 @@ for M in (256, 1024):
     a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c1.data_ptr(), h1.data_ptr(), gt.data_ptr(), M, H, 1
     sp = lambda: lib.las_lstm_cell_rows_args(ctypes.byref(a), _hip.stream())
     print("M = %4d: LM layer 2 %.1f us, LM layer 1 %.1f us, Speller cell %.1f us" % (M, timeit(lm2), timeit(lm1), timeit(sp)))
+    if os.environ.get("STAMP") == "1" and M >= 384:
+        # phase stamps of the 128-row body (a -DLB_STAMP=1 build: gates_out is the stamp buffer): medians over the workgroups, us from entry
+        import numpy as np
+        nwg = (H // 16) * ((M + 127) // 128)
+        for name, which in (("Speller cell (K = 1152 bf16 rows)", "sp"), ("LM layer 2 (K = 512 + 512 fp32 rows)", "lm2")):
+            stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
+            if which == "sp":
+                a.gates_out = stamps.data_ptr()
+                for _ in range(3): sp()
+            else:
+                b = _hip.LstmCellArgs()
+                b.x, b.x_bf16, b.ldx, b.I = x.data_ptr(), 0, I, I
+                b.h, b.ldh, b.Wx, b.Wh, b.bias, b.c_prev, b.fb = h.data_ptr(), H, ih.data_ptr(), hh.data_ptr(), bias.data_ptr(), c.data_ptr(), 0.0
+                b.c_out, b.h_out, b.gates_out, b.M, b.H, b.fast = c1.data_ptr(), h1.data_ptr(), stamps.data_ptr(), M, H, 0
+                for _ in range(3): lib.las_lstm_cell_rows_args(ctypes.byref(b), _hip.stream())
+            torch.cuda.synchronize()
+            st = stamps.cpu().numpy().astype(np.float64)
+            t0 = st[:, 0].min()
+            used = [k for k in range(14) if st[:, k].max() > 0]
+            print("  %s: workgroup entry spread %.2f us; stamp: median (min .. max) us after the FIRST workgroup's entry" % (name, (st[:, 0].max() - t0) / 100))
+            labels = {0: "entry", 1: "first loads issued", 12: "gates exchanged", 13: "done"}
+            for k in used:
+                lab = labels.get(k, "chunk %d %s" % ((k - 2) // 2, "staged" if k % 2 == 0 else "multiplied"))
+                v = (st[:, k] - t0) / 100
+                print("    %-22s %6.2f (%5.2f .. %5.2f)   in-workgroup since entry: %5.2f" % (lab, np.median(v), v.min(), v.max(), np.median((st[:, k] - st[:, 0]) / 100)))
