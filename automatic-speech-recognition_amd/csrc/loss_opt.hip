@@ -344,7 +344,7 @@ int las_lstm_cell_check(const LstmCellLaunch& a) {
 
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
     if (int rc = las_lstm_cell_check(a)) return rc;
-    if (a.M >= LB_MIN_ROWS) {
+    if (a.M >= LB_MIN_ROWS && !(a.x_bf16 && a.x && a.h)) {      // (the 128-row body takes one element type for all its rows)
         static int attr = lb_attr(lstm_cell_rows_big_kernel<true, true>) | lb_attr(lstm_cell_rows_big_kernel<true, false>) |
                           lb_attr(lstm_cell_rows_big_kernel<false, true>) | lb_attr(lstm_cell_rows_big_kernel<false, false>);
         if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big) failed: %d", attr); return attr; }
@@ -372,7 +372,7 @@ int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b,
         if (int rc = las_lstm_cell_rows_launch(a, st)) return rc;
         return las_lstm_cell_rows_launch(b, st);
     }
-    if (a.M >= LB_MIN_ROWS && b.M >= LB_MIN_ROWS) {
+    if (a.M >= LB_MIN_ROWS && b.M >= LB_MIN_ROWS && !a.h) {
         static int attr = lb_attr(lstm_cell_rows_big_pair_kernel);
         if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big_pair) failed: %d", attr); return attr; }
         const int bx = (a.H > b.H ? a.H : b.H) / 16, by = cdiv(a.M > b.M ? a.M : b.M, LB_ROWS);

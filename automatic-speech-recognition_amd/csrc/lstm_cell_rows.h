@@ -3,6 +3,7 @@
 // search's attention-row launch).  reference lang/char_rnn_model.py:57-66 (BasicLSTMCell gate math), las/beam_search.py:109-116.
 #pragma once
 #include "las_common.h"
+#include <type_traits>
 
 constexpr int LC_KC = 512, LC_LD = LC_KC + 8;      // K chunk staged per pass; LDS row stride in bf16 (16-byte reads of 16 rows hit 64 distinct banks)
 
@@ -199,10 +200,18 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
 #ifndef LB_ABL
 #define LB_ABL 0          // timing experiments (make ablf F=loss_opt D=-DLB_ABL=..): 1 no MFMAs, 2 no row loads after the first chunk, 4 no fragment loads after the first, 8 LDS-only barriers
 #endif
-constexpr int LB_KC = 256, LB_LD = LB_KC + 8, LB_ROWS = 128;
-constexpr int LB_LDS_BYTES = LB_ROWS * LB_LD * 2;      // 67,584 bytes (the gate exchange [2][4][4][64][4] floats = 32 KB reuses it)
+constexpr int LB_KC = 128, LB_LD = LB_KC + 8, LB_ROWS = 128;
+constexpr int LB_TILE = LB_ROWS * LB_LD;                // bf16 elements of one staged row tile
+constexpr int LB_LDS_BYTES = 2 * LB_TILE * 2;          // 69,632 bytes: two row tiles (chunk c is multiplied from one while chunk c + 1 is written to the
+                                                       // other: one barrier per chunk); the gate exchange [2][4][4][64][4] floats = 32 KB reuses the first
 
-template <bool FAST, bool XBF>
+// ABF: the rows (x and / or h) are bf16; otherwise fp32.  One element type per launch: a type switch inside the chunk loop is a branch
+// around loads, and the compiler ends every such branch in s_waitcnt vmcnt(0) -- which is what the first version of this body did at the end
+// of EVERY chunk's prefetch (r5 ISA: the "pipelined" loads of chunk c + 1 were complete before the first MFMA of chunk c; a chunk took load
+// time + multiply time, 2.7 / 3.6 us per 256 columns of K).  Here every load of the loop is unconditional (chunks behind the last are the
+// last one again, K steps and pieces behind a short chunk's end re-read its first), K moves in chunks of 128 through TWO register stages:
+// the rows of chunk c + 2 are requested when chunk c's have been written to LDS, its weight fragments when chunk c has been multiplied.
+template <bool FAST, bool ABF>
 __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a, unsigned char* smem, const int ub, const int row0) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
     const int gt = w & 3, rh = w >> 2;
@@ -210,7 +219,7 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     if (ub * 16 >= H || row0 >= a.M) return;
 #if LB_STAMP
     // timing build (make ablf F=loss_opt D=-DLB_STAMP=1; tools/bench_cell_rows.py STAMP=1): gates_out is a stamp buffer [workgroup][16] of
-    // 100 MHz ticks -- 0 entry, 1 first loads issued, 2+2c chunk c staged, 3+2c chunk c multiplied, 12 gates exchanged, 13 done
+    // 100 MHz ticks -- 0 entry, 1 first loads issued, 2 + c chunk c multiplied (c < 10), 12 gates exchanged, 13 done
     long long* lbs_ = reinterpret_cast<long long*>(a.gates_out) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
 #define LBS(k) do { __builtin_amdgcn_sched_barrier(0); if (tid == 0 && a.gates_out) lbs_[k] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -238,94 +247,97 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
     const int KSx = a.x ? a.I >> 5 : 0, KSh = a.h ? H >> 5 : 0;
     constexpr int NKS = LB_KC / 32;                                       // k-steps per chunk
     const int ncx = (KSx + NKS - 1) / NKS, nch = ncx + (KSh + NKS - 1) / NKS;
-    u16x8_t bv[NKS], bn[NKS];
-    constexpr int NRA = XBF ? 8 : 16;                                     // 16-byte pieces of the next chunk's rows per thread
-    float4 ra[16];
-    auto chunk = [&](const int ci, const void*& src, int& ld, int& k0, int& kc, const u16x8_t*& bp, bool& sbf) {
+    constexpr int NRA = ABF ? 4 : 8;                                      // 16-byte pieces of a chunk's rows per thread
+    constexpr int PPR = ABF ? LB_KC / 8 : LB_KC / 4;                      // 16-byte pieces per row and chunk
+    constexpr int RPP = 512 / PPR;                                        // rows per pass of the 512 threads
+    u16x8_t bq[2][NKS];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));       // (a native vector: HIP's uint4 struct stayed in scratch)
+    u32x4_t ra[2][NRA];
+    const int aq0 = tid & (PPR - 1), arb = tid / PPR;
+    // chunk ci (clamped to the last one): source rows, leading dimension, first column, columns (0 behind the last chunk), weight fragments
+    auto chunk = [&](const int ci_, const void*& src, int& ld, int& k0, int& kc, const u16x8_t*& bp) {
+        const int ci = ci_ < nch ? ci_ : nch - 1;
         const bool hp = ci >= ncx;
         const int cj = hp ? ci - ncx : ci, Kp = hp ? H : a.I, KS = Kp >> 5;
         src = hp ? (const void*)a.h : a.x; ld = hp ? a.ldh : a.ldx; k0 = cj * LB_KC; kc = min(LB_KC, Kp - k0);
         bp = reinterpret_cast<const u16x8_t*>(hp ? a.Wh : a.Wx) + ((size_t)ct * KS + (k0 >> 5)) * 64 + lane;
-        sbf = XBF && !hp;
+        if (ci_ >= nch) kc = 0;
     };
-    auto load_b = [&](const int ci, u16x8_t (&dst)[NKS]) {
-        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-        chunk(ci, src, ld, k0, kc, bp, sbf);
+    auto load_b = [&](auto SI, const int ci) {
+        constexpr int S = decltype(SI)::value;
+        const void* src; int ld, k0, kc; const u16x8_t* bp;
+        chunk(ci, src, ld, k0, kc, bp);
         const int nks = kc >> 5;
 #pragma unroll
-        for (int u = 0; u < NKS; ++u) dst[u] = bp[(size_t)(u < nks ? u : nks - 1) * 64];
+        for (int u = 0; u < NKS; ++u) bq[S][u] = bp[(size_t)(u < nks ? u : 0) * 64];
     };
-    auto load_a = [&](const int ci) {
-        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-        chunk(ci, src, ld, k0, kc, bp, sbf);
-        // thread -> (row, 16-byte piece), pieces per row fixed at compile time (see lstm_cell_rows_body: the division by the chunk's piece
-        // count was 4.5 of the 5.7 us a chunk took -- r5 phase stamps); idle lanes of a short chunk re-read piece 0 of their row
-        if (sbf) {
-            const int q0 = tid & 31, q = q0 < (kc >> 3) ? q0 : 0, rb = tid >> 5;
+    auto load_a = [&](auto SI, const int ci) {
+        constexpr int S = decltype(SI)::value;
+        const void* src; int ld, k0, kc; const u16x8_t* bp;
+        chunk(ci, src, ld, k0, kc, bp);
+        const int q = aq0 < (ABF ? kc >> 3 : kc >> 2) ? aq0 : 0;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(src) + ((size_t)k0 * (ABF ? 2 : 4) + (size_t)q * 16);
+        const size_t ldb = (size_t)ld * (ABF ? 2 : 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = min(row0 + rb + j * 16, a.M - 1);
-                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(src) + (size_t)row * ld + k0 + q * 8);
-                ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-            }
-        } else {
-            const int q0 = tid & 63, q = q0 < (kc >> 2) ? q0 : 0, rb = tid >> 6;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int row = min(row0 + rb + j * 8, a.M - 1);
-                ra[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (size_t)row * ld + k0 + q * 4);
-            }
+        for (int j = 0; j < NRA; ++j) {
+            const int row = min(row0 + arb + j * RPP, a.M - 1);
+            ra[S][j] = *reinterpret_cast<const u32x4_t*>(base + (size_t)row * ldb);
         }
     };
-    auto store_a = [&](const int ci) {
-        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-        chunk(ci, src, ld, k0, kc, bp, sbf);
-        if (sbf) {
-            const int q = tid & 31, rb = tid >> 5;
-            if (q < (kc >> 3)) {
+    auto store_a = [&](auto SI, const int ci) {
+        constexpr int S = decltype(SI)::value;
+        const void* src; int ld, k0, kc; const u16x8_t* bp;
+        chunk(ci, src, ld, k0, kc, bp);
+        if (aq0 < (ABF ? kc >> 3 : kc >> 2)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    *reinterpret_cast<uint4*>(As + (rb + j * 16) * LB_LD + q * 8) =
-                        make_uint4(__float_as_uint(ra[j].x), __float_as_uint(ra[j].y), __float_as_uint(ra[j].z), __float_as_uint(ra[j].w));
-            }
-        } else {
-            const int q = tid & 63, rb = tid >> 6;
-            if (q < (kc >> 2)) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    uint2 pk; pk.x = f2bf2(ra[j].x, ra[j].y); pk.y = f2bf2(ra[j].z, ra[j].w);
-                    *reinterpret_cast<uint2*>(As + (rb + j * 8) * LB_LD + q * 4) = pk;
+            for (int j = 0; j < NRA; ++j) {
+                if (ABF) {
+                    *reinterpret_cast<u32x4_t*>(As + S * LB_TILE + (arb + j * RPP) * LB_LD + aq0 * 8) = ra[S][j];
+                } else {
+                    uint2 pk;
+                    pk.x = f2bf2(__uint_as_float(ra[S][j][0]), __uint_as_float(ra[S][j][1]));
+                    pk.y = f2bf2(__uint_as_float(ra[S][j][2]), __uint_as_float(ra[S][j][3]));
+                    *reinterpret_cast<uint2*>(As + S * LB_TILE + (arb + j * RPP) * LB_LD + aq0 * 4) = pk;
                 }
             }
         }
     };
-    (void)NRA;
-    load_b(0, bv);
-    load_a(0);
-    LBS(1);
-    for (int ci = 0; ci < nch; ++ci) {
-        if (LB_ABL & 8) lds_barrier(); else __syncthreads();          // the previous chunk's readers are done
-        store_a(ci);
-        if (ci + 1 < nch) { if (!(LB_ABL & 4)) load_b(ci + 1, bn); if (!(LB_ABL & 2)) load_a(ci + 1); }
-        if (LB_ABL & 8) lds_barrier(); else __syncthreads();
-        if (ci < 5) LBS(2 + 2 * ci);
-        const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
-        chunk(ci, src, ld, k0, kc, bp, sbf);
+    auto multiply = [&](auto SI, const int ci) {
+        constexpr int S = decltype(SI)::value;
+        const void* src; int ld, k0, kc; const u16x8_t* bp;
+        chunk(ci, src, ld, k0, kc, bp);
         const int nks = kc >> 5;
-        const unsigned short* ar = As + (rh * 64 + c) * LB_LD + g4 * 8;
+        const unsigned short* ar = As + S * LB_TILE + (rh * 64 + c) * LB_LD + g4 * 8;
 #pragma unroll
         for (int u = 0; u < NKS; ++u) {
             if (u < nks && !(LB_ABL & 1)) {
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt)
-                    acc[rt] = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + rt * 16 * LB_LD + u * 32), bv[u], acc[rt]);
+                    acc[rt] = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + rt * 16 * LB_LD + u * 32), bq[S][u], acc[rt]);
             }
         }
-        if (ci + 1 < nch) {
-#pragma unroll
-            for (int u = 0; u < NKS; ++u) bv[u] = bn[u];
-        }
-        if (ci < 5) LBS(3 + 2 * ci);
+    };
+    // chunk ci sits in tile S (written before the last barrier); this half multiplies it and writes chunk ci + 1 to the OTHER tile, whose
+    // readers (chunk ci - 1) passed the last barrier too
+    auto half = [&](auto SI, auto SN, const int ci) {
+        store_a(SN, ci + 1);
+        load_a(SN, ci + 3);
+        multiply(SI, ci);
+        load_b(SI, ci + 2);
+        __syncthreads();
+        if (ci < 10) LBS(2 + ci);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    load_a(S0{}, 0); load_b(S0{}, 0);
+    load_a(S1{}, 1); load_b(S1{}, 1);
+    LBS(1);
+    store_a(S0{}, 0);
+    load_a(S0{}, 2);
+    __syncthreads();
+    for (int ci = 0; ci < nch; ci += 2) {
+        half(S0{}, S1{}, ci);
+        half(S1{}, S0{}, ci + 1);                                     // (behind the last chunk: nothing stored, nothing multiplied)
     }
     __syncthreads();                                                  // every wave is done reading the row tile: its space becomes the gate exchange
     float* gx = reinterpret_cast<float*>(smem);                       // [rh 2][rt 4][gate 4][lane 64][4]

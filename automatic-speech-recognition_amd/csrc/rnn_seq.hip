@@ -678,21 +678,22 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             *reinterpret_cast<f4v*>(xr + off) = lo;
             *reinterpret_cast<f4v*>(xr + off + 4) = hi;
         };
-        int have = 1;                                   // chunks of the x-projection known to be complete (a.xflag); chunk 0 was produced in
-                                                        // front of this launch in stream order (round 5: no set_word launch between the two)
+        int have_fr = a.xsc;                            // frames (from either end) of the x-projection known to be complete = chunks (a.xflag) x
+                                                        // a.xsc; chunk 0 was produced in front of this launch in stream order (round 5: no set_word
+                                                        // launch between the two).  Kept in FRAMES: `mm / a.xsc` was an integer division per step
         auto wait_chunk = [&](int st) __attribute__((always_inline)) {
             if (!a.xflag) return;
             const int mm = st < T - 1 - st ? st : T - 1 - st;
-            const int need = mm / a.xsc + 1;
-            if (need <= have) return;
+            if (mm < have_fr) return;
             int budget = a.spin < (1 << 16) ? a.spin : (1 << 16);     // ~0.1 s: a chunk is a sub-millisecond GEMM; if kernels of different
                                                                        // streams cannot overlap (a profiler that serialises them) fail fast
             for (;;) {
-                have = __hip_atomic_load(a.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (have >= need) break;
+                const long long hf = (long long)__hip_atomic_load(a.xflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) * a.xsc;
+                have_fr = hf > 0x7fffffffLL ? 0x7fffffff : (int)hf;
+                if (mm < have_fr) break;
                 if (--budget <= 0) {                   // the step is invalid from here on: report once, never wait again
                     if (a.status) a.status[0] = a.status_code;
-                    have = 0x7fffffff;
+                    have_fr = 0x7fffffff;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
@@ -1348,6 +1349,7 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
             }
         }
     int cur = 0;
+    int pleft = PG ? a.pstep : 0;                   // steps until the next publication of dZ progress (PG)
 #ifdef LAS_PROF
     const bool kprof = a.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     if (kprof) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); }
@@ -1585,7 +1587,8 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_ks_kernel(RnnArgs a) {
         KSTAMP(7);
         cur ^= 1;
         if constexpr (PG) {
-            if ((s + 1) % a.pstep == 0 || s + 1 == T) {              // (uniform: every wave of the workgroup takes the branch)
+            if (--pleft == 0 || s + 1 == T) {                        // every a.pstep steps (a countdown: `(s + 1) % a.pstep` was an integer division
+                pleft = a.pstep;                                      //  per step); uniform: every wave of the workgroup takes the branch
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's dZ stores of the steps so far have reached the XCD's L2 ...
                 __builtin_amdgcn_s_barrier();                          // ... and every other wave's of this member
                 if (tid == 0) {

@@ -63,6 +63,6 @@ for M in [int(v) for v in os.environ.get("MS", "256 1024").split()]:
             print("  %s: workgroup entry spread %.2f us; stamp: median (min .. max) us after the FIRST workgroup's entry" % (name, (st[:, 0].max() - t0) / 100))
             labels = {0: "entry", 1: "first loads issued", 12: "gates exchanged", 13: "done"}
             for k in used:
-                lab = labels.get(k, "chunk %d %s" % ((k - 2) // 2, "staged" if k % 2 == 0 else "multiplied"))
+                lab = labels.get(k, "chunk %d multiplied" % (k - 2))
                 v = (st[:, k] - t0) / 100
                 print("    %-22s %6.2f (%5.2f .. %5.2f)   in-workgroup since entry: %5.2f" % (lab, np.median(v), v.min(), v.max(), np.median((st[:, k] - st[:, 0]) / 100)))
