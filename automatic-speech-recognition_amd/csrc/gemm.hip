@@ -563,7 +563,7 @@ struct WgradArgs {
 // the BPTT sweep that is still producing dZ, window by window, instead of waiting for its end) -- the virtual row k' = b nf + i maps to frame
 // t0 + i of utterance b for all three operands; WIN = false is the whole-sequence kernel, unchanged.
 template <bool WIN>
-__global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
+__global__ __launch_bounds__(256, 4) void wgrad_tn_tr_kernel(WgradArgs g) {      // (4 waves per SIMD: 128 VGPRs -- at 130 the k-chunks of a tile run three to a CU instead of four)
     constexpr int BM = 128, BN = 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TR_TILE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
     const long long sb16 = 16LL * g.ldz, sb32 = 32LL * g.ldz;
     const int so = pk * TR_PITCH + pc * 2;
     u32x4_t ra[2], rb[2];
+    bool oa[2], ob[2];                                              // (the zeroing select waits for the load: applied when the piece is written to LDS, an iteration later)
     const u32x4_t zero = {0u, 0u, 0u, 0u};
     auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
@@ -610,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
                     src = gd.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
                 }
                 const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : gd.Z);
-                ra[u] = on ? va : zero;
+                ra[u] = va; oa[u] = on;
                 const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? gd.Z + kr * g.ldz + n0 + pc : gd.Z);
-                rb[u] = onb ? vb : zero;
+                rb[u] = vb; ob[u] = onb;
                 continue;
             }
             if (!hsrc) {
@@ -627,10 +628,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
                 src = gd.O + (on ? (long long)b * g.obs + (long long)tp * g.ldo : 0LL) + m0 + pc;
             }
             const u32x4_t va = *reinterpret_cast<const u32x4_t*>(on ? src : gd.Z);
-            ra[u] = on ? va : zero;
+            ra[u] = va; oa[u] = on;
             const bool onb = k < kend;
             const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(onb ? pb + u * sb16 : gd.Z);
-            rb[u] = onb ? vb : zero;
+            rb[u] = vb; ob[u] = onb;
         }
         pb += sb32;
     };
@@ -641,11 +642,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgradArgs g) {
         unsigned char* Bs = As + TR_TILE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<u32x4_t*>(As + so + u * 16 * TR_PITCH) = ra[u];
-            *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = rb[u];
+            *reinterpret_cast<u32x4_t*>(As + so + u * 16 * TR_PITCH) = oa[u] ? ra[u] : zero;
+            *reinterpret_cast<u32x4_t*>(Bs + so + u * 16 * TR_PITCH) = ob[u] ? rb[u] : zero;
         }
         __syncthreads();
-        if (k0 + 32 < kend) gload(k0 + 32);
+        gload(k0 + 32);                                             // unconditional (behind the last k-step every piece is off: one dummy address) -- behind an
+                                                                    // `if` the compiler ends the branch in s_waitcnt vmcnt(0) and the prefetch lands before the MFMAs
         u16x8_t a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 64 + i * 16, lane);

@@ -136,13 +136,7 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
                 }
             }
         };
-        load_b(0, bv);
-        load_a(0);
-        for (int ci = 0; ci < nch; ++ci) {
-            __syncthreads();                                              // the previous chunk's readers are done
-            store_a(ci);
-            if (ci + 1 < nch) { load_b(ci + 1, bn); load_a(ci + 1); }
-            __syncthreads();
+        auto multiply = [&](const int ci) {
             const void* src; int ld, k0, kc; const u16x8_t* bp; bool sbf;
             chunk(ci, src, ld, k0, kc, bp, sbf);
             const int nks = kc >> 5;
@@ -150,11 +144,25 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
     #pragma unroll
             for (int u = 0; u < LC_KC / 32; ++u)
                 if (u < nks) acc = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + u * 32), bv[u], acc);
-            if (ci + 1 < nch) {
+        };
+        load_b(0, bv);
+        load_a(0);
+        // every chunk but the last: its successor's loads are issued UNCONDITIONALLY (behind an `if (ci + 1 < nch)` the compiler ends the
+        // branch in s_waitcnt vmcnt(0): the prefetch was complete before the first MFMA of the chunk it was meant to hide behind)
+        for (int ci = 0; ci + 1 < nch; ++ci) {
+            __syncthreads();                                              // the previous chunk's readers are done
+            store_a(ci);
+            load_b(ci + 1, bn);
+            load_a(ci + 1);
+            __syncthreads();
+            multiply(ci);
     #pragma unroll
-                for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bn[u];
-            }
+            for (int u = 0; u < LC_KC / 32; ++u) bv[u] = bn[u];
         }
+        __syncthreads();
+        store_a(nch - 1);
+        __syncthreads();
+        multiply(nch - 1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) gates[rt][gt][lane][r] = acc[r];
