@@ -38,12 +38,14 @@ python3 tools/timeline.py "$(ls /tmp/kt_$P/*/*_results.db /tmp/kt_$P/*_results.d
 # trace, counter passes (HBM bytes, MFMA busy, waits) and bench object with the per-part timing / roofline
 rocprofv3 --kernel-trace --stats -d /tmp/kt_dec_$P -o b -- python3 bench.py --decode-only > gpurun_out/${P}_decode_kt.log 2>&1
 python3 tools/rocpd_summary.py "$(ls /tmp/kt_dec_$P/*/*_results.db /tmp/kt_dec_$P/*_results.db 2>/dev/null | head -1)" gpurun_out/${P}_decode_kernel_stats.csv > /dev/null 2>&1
+export LAS_ALLOW_SERIAL_STREAMS=1      # (the encoders' chunked x-projections: see above)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_dec_${P}_$c -o p -- python3 bench.py --decode-only > /tmp/pmc_dec_${P}_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   -d /tmp/pmc_dec_${P}_SQ -o p -- python3 bench.py --decode-only > /tmp/pmc_dec_${P}_SQ.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/${P}_decode /tmp/pmc_dec_${P}_FETCH_SIZE /tmp/pmc_dec_${P}_WRITE_SIZE /tmp/pmc_dec_${P}_SQ > gpurun_out/${P}_decode_pmc_summary.log 2>&1
+unset LAS_ALLOW_SERIAL_STREAMS
 python3 bench.py --decode-only > gpurun_out/${P}_decode_bench.json 2> /dev/null
 # ---- Speller loop kernels: phase stamps of one decode step (row workgroup 0 and product workgroup 0 on one clock)
 [ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps > gpurun_out/${P}_speller_phase_stamps.txt 2>&1
@@ -66,6 +68,12 @@ python3 tools/kernel_stats.py /tmp/kt_rnn_$P 3 gpurun_out/${P}_rnn_kernel_stats.
 # ---- round 5: the decode step at decode.py's batch (64 utterances x beam 16 = 1024 rows): consecutive kernels of replayed steps
 (cd /tmp && NUTT=64 rocprofv3 --kernel-trace --stats -d /tmp/kt_dec64_$P -o b -- python3 $OLDPWD/tools/probe_decode_step.py > $OLDPWD/gpurun_out/${P}_decode_b64_kt.log 2>&1)
 python3 tools/rocpd_summary.py "$(find /tmp/kt_dec64_$P -name '*_results.db' | head -1)" gpurun_out/${P}_decode_b64_kernel_stats.csv > /dev/null 2>&1
+# ---- round 5: the beam search's LSTM cell launches -- us per launch, the 128-row body's phase stamps (make ablf F=loss_opt D=-DLB_STAMP=1), the per-CU ingest
+# rate they are measured against, and a stream of batches with the next batch's encoders under the current search
+MS="256 1024" python3 tools/bench_cell_rows.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_cell_rows.txt
+[ -f automatic-speech-recognition_amd/lib/liblas_hip_ablf.so ] && MS=1024 LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_ablf.so STAMP=1 python3 tools/bench_cell_rows.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_cell_phase_stamps.txt
+[ -x tools/micro/bin/bench_ingest2 ] && tools/micro/bin/bench_ingest2 > gpurun_out/${P}_cu_ingest.txt 2>&1
+python3 tools/probe_decode_stream.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_decode_stream.txt
 # ---- round 5: are small launches on the chain what the profiler says they are?  (prepared sweeps vs self-packing, un-profiled, alternating)
 bash tools/ab_bench.sh LAS_NO_PREPARED_SWEEPS=0 LAS_NO_PREPARED_SWEEPS=1 3 60 > gpurun_out/${P}_ab_prepared.txt 2>&1
 python3 tools/probe_host_ahead.py > gpurun_out/${P}_host_ahead.txt 2>&1

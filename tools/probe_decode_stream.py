@@ -34,26 +34,11 @@ for NUTT in [int(x) for x in os.environ.get("NUTT", "16 32 64").split()]:
         t0 = time.perf_counter()
         for _ in bs.decode_batches(None, [utts] * NB): pass
         torch.cuda.synchronize(); stream.append(NB * NUTT / (time.perf_counter() - t0))
-    print("   one at a time:", ["%.0f" % v for v in one], "stream:", ["%.0f" % v for v in stream])
-    single = []
-    for rep in range(6):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        bs.decode_batch(None, utts)
-        torch.cuda.synchronize(); single.append(NUTT / (time.perf_counter() - t0))
-    print("   single calls:", ["%.0f" % v for v in single])
     one.sort(); stream.sort()
     print("%2d utterances per batch, %2d batches: one at a time %7.1f utt/s | decode_batches %7.1f utt/s (%+.1f %%)"
           % (NUTT, NB, one[2], stream[2], 100 * (stream[2] / one[2] - 1)), flush=True)
-    for rep in range(4):
-        torch.cuda.synchronize(); ts = [time.perf_counter()]
-        for _ in bs.decode_batches(None, [utts] * 8):
-            ts.append(time.perf_counter())
-        print("   per-batch ms:", ["%.1f" % ((b - a) * 1e3) for a, b in zip(ts, ts[1:])], flush=True)
-    import gc
-    gc.collect(); gc.disable()
-    for rep in range(6):
-        torch.cuda.synchronize(); ts = [time.perf_counter()]
-        for _ in bs.decode_batches(None, [utts] * 8):
-            ts.append(time.perf_counter())
-        print("   gc off, per-batch ms:", ["%.1f" % ((b - a) * 1e3) for a, b in zip(ts, ts[1:])], flush=True)
-    gc.enable()
+    # per-batch wall times of one stream: the first batch has nobody to hide its encoder under, the last one has no successor's encoder beside it
+    torch.cuda.synchronize(); ts = [time.perf_counter()]
+    for _ in bs.decode_batches(None, [utts] * 8):
+        ts.append(time.perf_counter())
+    print("   per-batch ms of a stream of 8:", " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(ts, ts[1:])), flush=True)
