@@ -322,12 +322,20 @@ __global__ __launch_bounds__(512) void lstm_cell_rows_big_kernel(LstmCellLaunch 
 // ... and two independent cells of 128-row workgroups in one grid (blockIdx.z as in the pair kernel above): at 240 VGPRs a CU holds one
 // workgroup, so the two problems run one behind the other -- but without the 32-row bodies' four rounds per problem (r5, M = 1024: 29 us
 // against the pair kernel's 35)
+template <bool BBF>                 // the second problem's rows: bf16 (the LM's state copies, h_out_bf16 of the step before) or fp32
 __global__ __launch_bounds__(512) void lstm_cell_rows_big_pair_kernel(LstmCellLaunch a, LstmCellLaunch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     if (blockIdx.z == 0) lstm_cell_rows_big_body<true, true>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
-    else                 lstm_cell_rows_big_body<false, false>(b, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+    else                 lstm_cell_rows_big_body<false, BBF>(b, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
 }
-constexpr int LB_MIN_ROWS = 384;          // from here on a launch of 32-row workgroups is more than one round of the 256 CUs per 512 units
+constexpr int LB_MIN_ROWS = 384;
+// the 128-row body takes ONE element type for all its rows: bf16 (x_bf16 / h_bf16) or fp32
+static inline int lb_rows_type(const LstmCellLaunch& a) {          // 1 bf16, 0 fp32, -1 mixed
+    const int xt = a.x ? (a.x_bf16 ? 1 : 0) : -1, ht = a.h ? (a.h_bf16 ? 1 : 0) : -1;
+    if (xt >= 0 && ht >= 0 && xt != ht) return -1;
+    return xt >= 0 ? xt : (ht >= 0 ? ht : 0);
+}
+static inline bool lb_serves(const LstmCellLaunch& a) { return a.M >= LB_MIN_ROWS && lb_rows_type(a) >= 0; }          // from here on a launch of 32-row workgroups is more than one round of the 256 CUs per 512 units
 template <typename K>
 static int lb_attr(K kern) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES); }
 
@@ -339,20 +347,24 @@ int las_lstm_cell_check(const LstmCellLaunch& a) {
     LAS_ARG(!a.xrows || a.ids, "las_lstm_cell_rows: xrows without ids");
     LAS_ARG(!a.h || (a.Wh && (a.ldh % 4) == 0 && (((uintptr_t)a.h) & 15) == 0), "las_lstm_cell_rows: h needs ldh %% 4 == 0, 16-byte alignment and Wh_packed");
     LAS_ARG((a.H % 32) == 0, "las_lstm_cell_rows: needs H %% 32 == 0");
+    LAS_ARG(!(a.h_bf16 || a.h_out_bf16) || lb_serves(a),
+            "las_lstm_cell_rows: bf16 h / h_out_bf16 are served by the 128-row workgroups only (M >= %d, h present and 16-byte rows, x absent or bf16)", LB_MIN_ROWS);
+    LAS_ARG(!a.h_bf16 || (a.ldh % 8) == 0, "las_lstm_cell_rows: bf16 h needs ldh %% 8 == 0");
     return 0;
 }
 
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
     if (int rc = las_lstm_cell_check(a)) return rc;
-    if (a.M >= LB_MIN_ROWS && !(a.x_bf16 && a.x && a.h)) {      // (the 128-row body takes one element type for all its rows)
+    if (lb_serves(a)) {
         static int attr = lb_attr(lstm_cell_rows_big_kernel<true, true>) | lb_attr(lstm_cell_rows_big_kernel<true, false>) |
                           lb_attr(lstm_cell_rows_big_kernel<false, true>) | lb_attr(lstm_cell_rows_big_kernel<false, false>);
         if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big) failed: %d", attr); return attr; }
         const dim3 gb(a.H / 16, cdiv(a.M, LB_ROWS));
-        if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else if (a.fast)        hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else if (a.x_bf16)      hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else                    hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        const bool abf = lb_rows_type(a) == 1;
+        if (a.fast && abf) hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else if (a.fast)   hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else if (abf)      hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
+        else               hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
         LAS_LAUNCHED();
         return 0;
     }
@@ -368,15 +380,16 @@ int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
 int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b, hipStream_t st) {
     if (int rc = las_lstm_cell_check(a)) return rc;
     if (int rc = las_lstm_cell_check(b)) return rc;
-    if (!(a.fast && a.x_bf16 && !b.fast && !b.x_bf16)) {             // not the pair the kernel is compiled for: two launches
+    if (!(a.fast && a.x_bf16 && !b.fast && !b.x_bf16 && !b.h_bf16) && !(lb_serves(a) && lb_rows_type(a) == 1 && a.fast && !b.fast && lb_serves(b))) {   // not a pair a kernel is compiled for: two launches
         if (int rc = las_lstm_cell_rows_launch(a, st)) return rc;
         return las_lstm_cell_rows_launch(b, st);
     }
-    if (a.M >= LB_MIN_ROWS && b.M >= LB_MIN_ROWS && !a.h) {
-        static int attr = lb_attr(lstm_cell_rows_big_pair_kernel);
+    if (lb_serves(a) && lb_rows_type(a) == 1 && lb_serves(b)) {
+        static int attr = lb_attr(lstm_cell_rows_big_pair_kernel<false>) | lb_attr(lstm_cell_rows_big_pair_kernel<true>);
         if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big_pair) failed: %d", attr); return attr; }
         const int bx = (a.H > b.H ? a.H : b.H) / 16, by = cdiv(a.M > b.M ? a.M : b.M, LB_ROWS);
-        hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
+        if (lb_rows_type(b) == 1) hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel<true>, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
+        else                      hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel<false>, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
         LAS_LAUNCHED();
         return 0;
     }
@@ -399,7 +412,7 @@ extern "C" int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids
     LstmCellLaunch a;
     a.x = x; a.x_bf16 = 0; a.ldx = ldx; a.I = x ? I : 0; a.ids = ids; a.id_shift = id_shift; a.xrows = xrows; a.h = h; a.ldh = ldh;
     a.Wx = Wx_packed; a.Wh = Wh_packed; a.bias = bias; a.c_prev = c_prev; a.fb = forget_bias; a.c_out = c_out; a.h_out = h_out;
-    a.gates_out = nullptr; a.M = M; a.H = H; a.fast = 0;
+    a.gates_out = nullptr; a.M = M; a.H = H; a.fast = 0; a.h_bf16 = 0; a.h_out_bf16 = nullptr;
     return las_lstm_cell_rows_launch(a, (hipStream_t)stream);
 }
 

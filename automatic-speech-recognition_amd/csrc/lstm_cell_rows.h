@@ -373,7 +373,9 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         const size_t o = (size_t)row * H + unit;
         const float cn = fmaf(pc_[k], gf, gi * gj);
         a.c_out[o] = cn;
-        a.h_out[o] = tanhx<FAST>(cn) * go;
+        const float hn = tanhx<FAST>(cn) * go;
+        a.h_out[o] = hn;
+        if (a.h_out_bf16) reinterpret_cast<unsigned short*>(a.h_out_bf16)[o] = (unsigned short)(f2bf2(hn, 0.f) & 0xffffu);   // (the staging's own conversion)
         if (a.gates_out && !LB_STAMP) {
             float* gp = a.gates_out + (size_t)row * 4 * H + unit;
             gp[0] = gi; gp[H] = gj; gp[2 * H] = gf; gp[3 * H] = go;

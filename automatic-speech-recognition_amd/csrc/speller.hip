@@ -3299,7 +3299,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
             LstmCellLaunch c;
             c.x = d.xbf; c.x_bf16 = 1; c.ldx = I0D; c.I = I0D; c.ids = nullptr; c.id_shift = 0; c.xrows = nullptr; c.h = nullptr; c.ldh = 0;
             c.Wx = packF; c.Wh = nullptr; c.bias = f->cellb[0]; c.c_prev = d.cs; c.fb = d.fb;
-            c.c_out = d.cs + (size_t)B * D; c.h_out = d.hs + (size_t)B * D; c.gates_out = d.gates; c.M = B; c.H = D; c.fast = 1;
+            c.c_out = d.cs + (size_t)B * D; c.h_out = d.hs + (size_t)B * D; c.gates_out = d.gates; c.M = B; c.H = D; c.fast = 1; c.h_bf16 = 0; c.h_out_bf16 = nullptr;
             if (int rc = f->companion ? las_lstm_cell_rows_launch2(c, *f->companion, st) : las_lstm_cell_rows_launch(c, st)) return rc;
             break;
         }

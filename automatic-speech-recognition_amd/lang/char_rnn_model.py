@@ -12,6 +12,7 @@ import logging
 import math
 import time
 
+import ctypes
 import numpy as np
 import torch
 
@@ -279,7 +280,17 @@ class CharRNN(object):
             plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
-    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0, project=True, layer0=None):
+    TWIN_MIN_ROWS = 384          # las_lstm_cell_rows serves bf16 state copies with its 128-row workgroups only (csrc/loss_opt.hip LB_MIN_ROWS)
+
+    def twins_ok(self, plan, N):
+        """True if every layer's step runs through las_lstm_cell_rows at N rows with 128-row workgroups: the cells can then read the
+        recurrent state (and the layer below's output) from bf16 copies a previous launch wrote (h_out_bf16) -- half the bytes of the
+        fp32 rows they would convert to bf16 anyway, bit-identical results."""
+        H = self.hidden_size
+        return ("packs" in plan and "wx" in plan and self.TWIN_MIN_ROWS <= N <= 1024 and H % 32 == 0 and self.embedding_size == 0
+                and all(pk[1] is not None for pk in plan["packs"][1:]))
+
+    def step_fused(self, plan, ids, c_prev, h_prev, logits, col0, id_shift=0, project=True, layer0=None, twins=None):
         """step_tensors for the device-resident beam search with half the launches: ids int32 [N] (LM id = max(ids - id_shift, 0):
         with id_shift = 2 the beam search's LAS ids are read as they are), the result is ACCUMULATED into
         logits[:, col0:col0 + V_lm] (+= lm_weight * lm_logits).  No one-hot, no concatenations: the input and recurrent halves
@@ -299,9 +310,13 @@ class CharRNN(object):
         cell_rows = skinny and H % 32 == 0 and (self.embedding_size == 0 or self.input_size % 32 == 0)
         with torch.no_grad():
             for l, (k, b) in enumerate(P["cells"]):
+                if l == 0 and twins is not None:
+                    twins["new"] = []
                 if l == 0 and layer0 is not None:
                     cs.append(layer0[0]); hs.append(layer0[1])
                     x = layer0[1]
+                    if twins is not None:
+                        twins["new"].append(twins["layer0"])
                     continue
                 k, b = k.detach(), b.detach()
                 I = k.shape[0] - H
@@ -311,6 +326,29 @@ class CharRNN(object):
                     x = P["embedding"].detach().index_select(0, lm_ids)
                 c_new = torch.empty(N, H, device=dev)
                 h_new = torch.empty(N, H, device=dev)
+                if cell_rows and twins is not None:
+                    # bf16 operand rows: the state copy of the step before (gathered with the fp32 state) and the layer below's new copy
+                    hh, ih = plan["packs"][l]
+                    hb_new = torch.empty(N, H, dtype=torch.bfloat16, device=dev)
+                    ca = _hip.LstmCellArgs()
+                    if rows:
+                        ca.x, ca.x_bf16, ca.ldx, ca.I = None, 0, 0, 0
+                        ca.ids, ca.id_shift, ca.xrows = ids.data_ptr(), int(id_shift), plan["wx"].data_ptr()
+                        ca.Wx = None
+                    else:
+                        ca.x, ca.x_bf16, ca.ldx, ca.I = twins["new"][l - 1].data_ptr(), 1, I, I
+                        ca.ids, ca.id_shift, ca.xrows = None, 0, None
+                        ca.Wx = ih.data_ptr()
+                    ca.h, ca.h_bf16, ca.ldh, ca.Wh = twins["prev"][l].data_ptr(), 1, H, hh.data_ptr()
+                    ca.bias, ca.c_prev, ca.fb = b.data_ptr(), c_prev[l].data_ptr(), 0.0
+                    ca.c_out, ca.h_out, ca.gates_out, ca.h_out_bf16 = c_new.data_ptr(), h_new.data_ptr(), None, hb_new.data_ptr()
+                    ca.M, ca.H, ca.fast = N, H, 0
+                    _hip.check(lib.las_lstm_cell_rows_args(ctypes.byref(ca), _hip.stream()), "las_lstm_cell_rows_args")
+                    twins["new"].append(hb_new)
+                    cs.append(c_new)
+                    hs.append(h_new)
+                    x = h_new
+                    continue
                 if cell_rows:                                    # the whole cell in one launch (las_lstm_cell_rows)
                     hh, ih = plan["packs"][l]
                     _hip.check(lib.las_lstm_cell_rows(None if rows else _hip.p(x), 0 if rows else I, 0 if rows else I,
@@ -345,7 +383,7 @@ class CharRNN(object):
                 self.project_fused(plan, x, logits, col0)
         return cs, hs
 
-    def first_cell_args(self, plan, ids, id_shift, c_prev, h_prev, c_out, h_out):
+    def first_cell_args(self, plan, ids, id_shift, c_prev, h_prev, c_out, h_out, hb_prev=None, hb_out=None):
         """las_lstm_cell_args (ctypes) of the FIRST layer's step for a one-hot LM in speed mode, or None when step_fused would not run
         that layer through las_lstm_cell_rows.  (ids, c_prev, h_prev, c_out, h_out: the tensors of every step -- fixed buffers.)"""
         P = self.params()
@@ -358,6 +396,8 @@ class CharRNN(object):
         a.h, a.ldh, a.Wx, a.Wh = h_prev.data_ptr(), H, None, plan["packs"][0][0].data_ptr()
         a.bias, a.c_prev, a.fb = P["cells"][0][1].detach().data_ptr(), c_prev.data_ptr(), 0.0
         a.c_out, a.h_out, a.gates_out, a.M, a.H, a.fast = c_out.data_ptr(), h_out.data_ptr(), None, N, H, 0
+        if hb_prev is not None:                                  # (twins_ok: the recurrent state from its bf16 copy, a copy of h' for the next readers)
+            a.h, a.h_bf16, a.h_out_bf16 = hb_prev.data_ptr(), 1, hb_out.data_ptr()
         return a
 
     def cell_args(self, plan, layer, x, c_prev, h_prev, c_out, h_out):

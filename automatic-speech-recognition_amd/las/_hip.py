@@ -26,7 +26,8 @@ class LstmCellArgs(Structure):
     """include/las_hip.h las_lstm_cell_args"""
     _fields_ = [("x", c_void_p), ("x_bf16", c_int), ("ldx", c_int), ("I", c_int), ("ids", c_void_p), ("id_shift", c_int), ("xrows", c_void_p),
                 ("h", c_void_p), ("ldh", c_int), ("Wx", c_void_p), ("Wh", c_void_p), ("bias", c_void_p), ("c_prev", c_void_p), ("fb", c_float),
-                ("c_out", c_void_p), ("h_out", c_void_p), ("gates_out", c_void_p), ("M", c_int), ("H", c_int), ("fast", c_int)]
+                ("c_out", c_void_p), ("h_out", c_void_p), ("gates_out", c_void_p), ("M", c_int), ("H", c_int), ("fast", c_int),
+                ("h_bf16", c_int), ("h_out_bf16", c_void_p)]
 
 
 class SpellerFwdArgs(Structure):

@@ -108,6 +108,7 @@ class BeamSearch(object):
         # decode_batch (round 5): the attention rows of FOUR hypotheses of an utterance in one workgroup (LAS_SPELLER_ROWS_SHARE4: Ws, keys and
         # encoder rows read once for the four) from this many hypothesis rows on (0 = never); bit-identical to one row per workgroup
         self.share_rows_from = int(os.environ.get("LAS_DECODE_SHARE_ROWS_FROM", "512"))
+        self.lm_state_copies = os.environ.get("LAS_NO_LM_STATE_COPIES") != "1"      # decode_batch (round 5): bf16 copies of the LM's state from 384 rows on
         self.steps_per_graph = int(os.environ.get("LAS_DECODE_STEPS_PER_GRAPH", "8"))   # search steps per captured HIP graph (one replay = that many steps)
         self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
         self.parallel_encoders = os.environ.get("LAS_NO_PARALLEL_ENCODERS") != "1"   # decode_batch: encoders of different lengths on several streams
@@ -369,6 +370,9 @@ class BeamSearch(object):
         k_align = len(st_in)
         st_in.append(alphas_hist[0]); st_out.append(align_prev)
         lm = self.lm if a.apply_lm else None
+        lm_w = np.float32(a.lm_weight) if lm is not None else None
+        lm_plan = lm.fusion_plan(lm_w) if lm is not None else None
+        lm_hb = None
         if lm is not None:
             Hl, NLl = lm.hidden_size, lm.num_layers
             lm_c = [torch.zeros(N, Hl, device=dev) for _ in range(NLl)]
@@ -376,6 +380,14 @@ class BeamSearch(object):
             k_lm = len(st_in)
             for l in range(NLl):
                 st_in += [lm_c[l], lm_h[l]]; st_out += [lm_c[l], lm_h[l]]          # inputs are re-pointed every step
+            # bf16 copies of the LM's recurrent state (round 5): from 384 rows on the cells read them -- and the layer below's copy -- instead
+            # of converting the fp32 rows while staging them (half the bytes through a CU that is bound by its ingest); the copies follow
+            # their hypotheses through the gather as rows of H / 2 floats.  Bit-identical: the copy is the staging's own rounding.
+            if self.lm_state_copies and prec == _hip.PREC_BF16 and not self.three_launches and lm.twins_ok(lm_plan, N):
+                lm_hb = [torch.zeros(N, Hl, dtype=torch.bfloat16, device=dev) for _ in range(NLl)]
+                k_tw = len(st_in)
+                for l in range(NLl):
+                    st_in.append(lm_hb[l].view(torch.float32)); st_out.append(lm_hb[l].view(torch.float32))
         ba = _hip.BeamLoopArgs()
         for name, t in (("logits", logits), ("score", score), ("length", length), ("nlive", nlive), ("nsel", nsel), ("done", done),
                         ("dec_step", dstep), ("step", step), ("hist_parent", hist_parent), ("hist_token", hist_token),
@@ -386,7 +398,6 @@ class BeamSearch(object):
         ba.start_id, ba.end_id, ba.ntens = self.start_id, self.end_id, len(st_in)
         for k, (ti, to) in enumerate(zip(st_in, st_out)):
             ba.state_in[k], ba.state_out[k], ba.state_width[k] = ti.data_ptr(), to.data_ptr(), ti.shape[-1]
-        lm_w = np.float32(a.lm_weight) if lm is not None else None
         mark("encoded")
         # the step's alignments land in a fixed buffer and are filed under the DEVICE step counter, so that one step is the
         # same sequence of launches with the same arguments every time: it is captured into a HIP graph after the first
@@ -414,7 +425,6 @@ class BeamSearch(object):
             _hip.check(rc, "las_speller_fwd")
             fa.flags |= _hip.SPELLER_REUSE_PREP      # enc / keys / weights are fixed for the search: their bf16 copies are made once
 
-        lm_plan = lm.fusion_plan(lm_w) if lm is not None else None
         # ---- the short form of a step (speed mode, one LSTM layer): the Speller call stops after its cell (LAS_SPELLER_NO_LOGITS: attention
         # rows + ONE cell launch) and the vocabulary projection -- the Speller's output layer and, concatenated along K, the LM's softmax
         # layer scaled by lm_weight and shifted to its token columns -- happens inside las_beam_loop_step: 5 launches per step instead of 8
@@ -440,7 +450,9 @@ class BeamSearch(object):
             ba.proj_h1, ba.proj_k1 = None, (lm.hidden_size if lm is not None else 0)
             if lm is not None:
                 lm0 = (torch.empty(N, lm.hidden_size, device=dev), torch.empty(N, lm.hidden_size, device=dev))
-                lm0_args = lm.first_cell_args(lm_plan, next_token, 2, lm_c[0], lm_h[0], lm0[0], lm0[1])
+                lm0_hb = torch.empty(N, lm.hidden_size, dtype=torch.bfloat16, device=dev) if lm_hb is not None else None
+                lm0_args = lm.first_cell_args(lm_plan, next_token, 2, lm_c[0], lm_h[0], lm0[0], lm0[1],
+                                              hb_prev=lm_hb[0] if lm_hb is not None else None, hb_out=lm0_hb)
                 lm1 = lm1_args = None
                 if self.three_launches and lm0_args is not None and NLl == 2:
                     lm1 = (torch.empty(N, lm.hidden_size, device=dev), torch.empty(N, lm.hidden_size, device=dev))
@@ -461,14 +473,22 @@ class BeamSearch(object):
                     # the LM's first layer depends on the tokens only: it rides with the Speller's cell as the second problem of one grid
                     fa.companion = ctypes.pointer(lm0_args)
                     mode["lm0"] = lm0
+                    mode["lm0_hb"] = lm0_hb
 
         def lm_cells():
             # evident intent of the (syntactically broken) branch at las/beam_search.py:109-116,131-135:
             # LM ids = LAS ids - 2, SOS (-> -1) fed as id 0; logits[:, 2:] += lm_weight * lm_logits
-            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False,
-                                           layer0=mode.get("lm0") if mode["fused"] else None)
+            layer0 = mode.get("lm0") if mode["fused"] else None
+            tw = None
+            if lm_hb is not None:
+                tw = {"prev": lm_hb, "layer0": mode.get("lm0_hb") if layer0 is not None else None}
+            cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False, layer0=layer0, twins=tw)
             for l in range(NLl):
                 ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
+                if tw is not None:
+                    ba.state_in[k_tw + l] = tw["new"][l].data_ptr()
+            if tw is not None:
+                cs_new = cs_new + tw["new"]                                       # (kept alive with the rest)
             if mode["fused"]:
                 ba.proj_h1 = hs_new[-1].data_ptr()
             held[:] = [cs_new, hs_new]                                            # alive until the gather has been enqueued

@@ -466,12 +466,16 @@ int las_lstm_cell_rows(const float* x, int ldx, int I, const int* ids, int id_sh
 typedef struct las_lstm_cell_args {
     const void* x; int x_bf16, ldx, I;
     const int* ids; int id_shift; const float* xrows;
-    const float* h; int ldh;
+    const void* h; int ldh;          /* fp32 rows, or bf16 rows when h_bf16 (below) */
     const void *Wx, *Wh;
     const float *bias, *c_prev;
     float fb;
     float *c_out, *h_out, *gates_out;
     int M, H, fast;
+    int h_bf16;                      /* (round 5) h holds bf16 rows: the copy a previous launch left in h_out_bf16.  Served by the 128-row
+                                        workgroups only (M >= 384, x absent or bf16 too): the beam search's LM cells at decode.py's batch */
+    void* h_out_bf16;                /* optional [M, H] bf16: h' rounded as the next launch's operand staging would round it (RNE) -- the
+                                        next layer's x and, gathered, the next step's h, at half the bytes */
 } las_lstm_cell_args;
 int las_lstm_cell_rows_args(const las_lstm_cell_args* a, void* stream);
 /* ... and its gradient, for training the RNNLM (lang/char_rnn_model.py:177-190, truncated BPTT over num_unrollings steps):

@@ -188,6 +188,22 @@ def test_a_stream_of_batches_with_overlapped_encoders_equals_one_batch_at_a_time
     _hip.check_status()
 
 
+def test_lm_state_copies_from_384_rows_on_change_nothing():
+    """From 384 hypothesis rows on decode_batch keeps bf16 copies of the LM's recurrent state (written by the cells, gathered with the
+    fp32 state) for the cells to read: 24 utterances x beam 16 = 384 rows with and without them must agree bit for bit."""
+    args, p0, plm, bs, _ = _setup("bf16")
+    utts = [synthetic_batch(1, 140 - 9 * (k % 4), 8, 30, seed=900 + k)[0] for k in range(24)]
+    assert bs.lm_state_copies
+    with_copies = bs.decode_batch(None, utts)
+    bs.lm_state_copies = False
+    without = bs.decode_batch(None, utts)
+    bs.lm_state_copies = True
+    for u, (a, b) in enumerate(zip(with_copies, without)):
+        assert [h.token_ids for h in a] == [h.token_ids for h in b], u
+        assert [float(h.log_prob) for h in a] == [float(h.log_prob) for h in b], u
+        assert torch.equal(a[-1].att[-1], b[-1].att[-1]), u
+
+
 def test_bf16_sixty_four_utterances_at_T_1274_match_the_bf16_oracle():
     """The geometry bench.py's decode `value` is quoted on since round 4: 64 utterances x beam 16 = 1024 hypothesis
     rows per step, T = 1274 frames (T' = 160), 2 x 512 LM fused in, one captured step replayed -- `lstm_cell_rows` at M = 1024, the

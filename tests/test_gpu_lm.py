@@ -97,3 +97,59 @@ def test_lstm_cell_rows_struct_entry_bf16_rows_fast_gates(M, I, H):
     c_t = c_prev.double() * gf + gi * gj
     assert (c1.double() - c_t).abs().max() < 2e-3 and (h1.double() - torch.tanh(c_t) * go).abs().max() < 2e-3
     assert (gt.double() - torch.cat([gi, gj, gf, go], 1)).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("M,onehot", [(384, False), (1024, False), (1024, True), (500, False)])
+def test_lstm_cell_rows_bf16_state_copies_are_bit_identical(M, onehot):
+    """Round 5: from 384 rows on the beam search's LM cells read their operand rows from bf16 copies (x = the layer below's h_out_bf16,
+    h = the gathered copy of the step before) instead of converting the fp32 rows while staging them.  The copy is the staging's own
+    rounding, so c' and h' must be BIT-identical to the fp32-row launch, and h_out_bf16 must be h' rounded to nearest even.  Below
+    384 rows (32-row workgroups) the options are refused."""
+    import ctypes
+    from las import _hip
+    dev, I, H, V, shift = "cuda", 512, 512, 28, 2
+    g = torch.Generator(device="cpu").manual_seed(M + 3)
+    kern = (torch.randn((V if onehot else I) + H, 4 * H, generator=g) * 0.06).to(dev)
+    bias = (torch.randn(4 * H, generator=g) * 0.1).to(dev)
+    x = torch.randn(M, I, generator=g).to(dev)
+    h = torch.randn(M, H, generator=g).to(dev)
+    c_prev = torch.randn(M, H, generator=g).to(dev)
+    ids = torch.randint(0, V + shift, (M,), generator=g).to(torch.int32).to(dev)
+    Ix = V if onehot else I
+    hh = _hip.skinny_pack(kern, H, 4 * H, row0=Ix)
+    ih = None if onehot else _hip.skinny_pack(kern, I, 4 * H)
+    wx = kern[:V].to(torch.bfloat16).to(torch.float32).contiguous()
+
+    def run(copies):
+        c1, h1 = torch.empty(M, H, device=dev), torch.empty(M, H, device=dev)
+        hb = torch.zeros(M, H, dtype=torch.bfloat16, device=dev)
+        a = _hip.LstmCellArgs()
+        xs, hs_ = (x.to(torch.bfloat16).contiguous(), h.to(torch.bfloat16).contiguous()) if copies else (x, h)
+        if onehot:
+            a.x, a.x_bf16, a.ldx, a.I, a.Wx = None, 0, 0, 0, None
+            a.ids, a.id_shift, a.xrows = ids.data_ptr(), shift, wx.data_ptr()
+        else:
+            a.x, a.x_bf16, a.ldx, a.I, a.Wx = xs.data_ptr(), int(copies), I, I, ih.data_ptr()
+            a.ids, a.id_shift, a.xrows = None, 0, None
+        a.h, a.h_bf16, a.ldh, a.Wh = hs_.data_ptr(), int(copies), H, hh.data_ptr()
+        a.bias, a.c_prev, a.fb = bias.data_ptr(), c_prev.data_ptr(), 0.0
+        a.c_out, a.h_out, a.gates_out, a.h_out_bf16, a.M, a.H, a.fast = c1.data_ptr(), h1.data_ptr(), None, hb.data_ptr(), M, H, 0
+        rc = _hip.lib().las_lstm_cell_rows_args(ctypes.byref(a), _hip.stream())
+        torch.cuda.synchronize()
+        return rc, c1, h1, hb, (xs, hs_)
+
+    rc0, c0, h0, hb0, _ = run(False)
+    rc1, c1, h1, hb1, _ = run(True)
+    assert rc0 == 0 and rc1 == 0
+    assert torch.equal(c0, c1) and torch.equal(h0, h1)
+    assert torch.equal(hb0, h0.to(torch.bfloat16)) and torch.equal(hb1, hb0)
+    # 32-row workgroups do not take the options
+    a = _hip.LstmCellArgs()
+    hs_ = h[:64].to(torch.bfloat16).contiguous()
+    c2, h2 = torch.empty(64, H, device=dev), torch.empty(64, H, device=dev)
+    a.x, a.x_bf16, a.ldx, a.I, a.Wx = None, 0, 0, 0, None
+    a.ids, a.id_shift, a.xrows = ids.data_ptr(), shift, wx.data_ptr()
+    a.h, a.h_bf16, a.ldh, a.Wh = hs_.data_ptr(), 1, H, hh.data_ptr()
+    a.bias, a.c_prev, a.fb = bias.data_ptr(), c_prev.data_ptr(), 0.0
+    a.c_out, a.h_out, a.gates_out, a.h_out_bf16, a.M, a.H, a.fast = c2.data_ptr(), h2.data_ptr(), None, None, 64, H, 0
+    assert _hip.lib().las_lstm_cell_rows_args(ctypes.byref(a), _hip.stream()) < 0
