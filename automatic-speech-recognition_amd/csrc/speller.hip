@@ -863,6 +863,9 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
 // recurrent state, so every load is issued when the kernel starts and only arithmetic sits on the dependent
 // chain; LDS-only barriers keep the loads in flight (a __syncthreads() would drain vmcnt at every phase).
 // ------------------------------------------------------------------------------------------------
+#ifndef LAS_LOC_WS_EARLY
+#define LAS_LOC_WS_EARLY 1        // location-aware forward rows: 1 = the Ws fragments, 2 = also the keys, requested in FRONT of the conv (0: behind it, with the rest)
+#endif
 #ifdef LAS_ROW_STAMPS   // development aid (tools/micro/bench_rows.hip): phase timestamps of workgroup 0
 __device__ unsigned long long g_stamps[32];
 #define STAMPX(i) do { if (tid == 0 && b == 0) g_stamps[i] = wall_clock64(); } while (0)
@@ -934,6 +937,25 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V, U = a.U;
     const int S = D, GD = G * D, I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (S + 1) >> 1, Tp2 = (Tp + 1) >> 1;
 
+    uint4 w8[8];
+    if (LOC && LAS_LOC_WS_EARLY) {
+        // (experiment) the query projection's Ws fragments in front of the conv: they are the first bulk operand the step consumes
+        const int a4c_ = a4 < A4 ? a4 : A4 - 1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
+            w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(size_t)kpc * A4 + a4c_];
+        }
+    }
+    uint4 k8[NK];
+    if (LOC && LAS_LOC_WS_EARLY > 1) {
+        const int a8c_ = a8 < A8 ? a8 : A8 - 1;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c_];
+        }
+    }
     if (LOC) {
         // f = conv1d(alpha_{t-1}): nothing in it depends on the gates of step t-1, so it runs while they are on their way -- and
         // BEFORE the step's bulk loads are issued: behind them their 60 destination registers are live and the conv's 40 spill.  The
@@ -974,18 +996,20 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     int tok = a.tok_in[(size_t)tc * B + b];
     const int len = a.enc_len[b];
     const int a4c = a4 < A4 ? a4 : A4 - 1, a8c = a8 < A8 ? a8 : A8 - 1, h4c = h4 < H4 ? h4 : H4 - 1;
-    uint4 w8[8];
+    if (!(LOC && LAS_LOC_WS_EARLY)) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
-        w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : (size_t)kpc * A4 + a4c];
+        for (int u = 0; u < 8; ++u) {
+            const int kp = kg + 32 * u, kpc = kp < S2 ? kp : S2 - 1;
+            w8[u] = reinterpret_cast<const uint4*>(a.Wsbf2)[(LAS_ABL_SP & 1) ? (size_t)(tid & 63) : (size_t)kpc * A4 + a4c];
+        }
     }
     const float4 u40 = reinterpret_cast<const float4*>(a.u)[a8c * 2], u41 = reinterpret_cast<const float4*>(a.u)[a8c * 2 + 1];
-    uint4 k8[NK];
+    if (!(LOC && LAS_LOC_WS_EARLY > 1)) {
 #pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1024) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
+        for (int u = 0; u < NK; ++u) {
+            const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
+            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1024) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
+        }
     }
     constexpr int NEL = LOOP ? EncRes<NE, LOC>::N : 0;      // encoder slabs resident in LDS (loop kernels): see EncRes
     constexpr int NER = NE - NEL > 0 ? NE - NEL : 1;
