@@ -155,8 +155,12 @@ class BeamSearch(object):
         # share one of the four queues with the launch stream or an auxiliary stream and its kernels would run in line with theirs
         es = _hip.aux_streams(dev)["comm"]
 
+        first_launch = [True]
+
         def launch(xs_list):
-            es.wait_stream(main)             # (everything queued so far: the first call's weight shadows, a caller's weight update)
+            if first_launch[0]:              # (everything queued so far: a caller's weight update.  Later launches must NOT wait for the launch
+                es.wait_stream(main)         #  stream -- they are issued while the current batch's search steps are queued on it)
+                first_launch[0] = False
             with torch.cuda.stream(es):
                 pre = self._run_encoders(sess, xs_list)
             ev = torch.cuda.Event()
@@ -172,11 +176,15 @@ class BeamSearch(object):
         first = next(it, None)
         cur = launch(first) if first is not None else None
         while cur is not None:
-            nxt = next(it, None)
-            nxt = launch(nxt) if nxt is not None else None
+            box = []
+
+            def prepare_next():              # runs inside decode_batch, behind the first `sync_every` search steps' launches: the host's part
+                nxt_xs = next(it, None)      # of the next batch (stacking the utterances, the copy to the device, the encoder launches)
+                box.append(launch(nxt_xs) if nxt_xs is not None else None)     # happens while the device is searching
             main.wait_event(cur[2])
-            yield self.decode_batch(sess, cur[0], sync_every, _pre=cur[1])
-            cur = nxt
+            res = self.decode_batch(sess, cur[0], sync_every, _pre=cur[1], _after_launch=prepare_next)
+            yield res
+            cur = box[0]
 
     def _run_encoders(self, sess, xs_list):
         """The encoders of a batch of utterances on the CURRENT stream, without waiting for the device (the encoded lengths are host
@@ -271,7 +279,7 @@ class BeamSearch(object):
                 encode_group(us)
         return encs, enc_lens, dec_steps, h_one
 
-    def decode_batch(self, sess, xs_list, sync_every=32, _pre=None):
+    def decode_batch(self, sess, xs_list, sync_every=32, _pre=None, _after_launch=None):
         """Beam search for several utterances at once (what decode.py's loop over utterances, decode.py:131-149, becomes on
         one GPU): xs_list = [(audio [1,T_u,feat_dim,3], audiolen [1]), ...] -> [list of BeamState (ascending), ...].
 
@@ -558,8 +566,12 @@ class BeamSearch(object):
                 steps_run = min(t, Umax)
                 if t >= next_check:                                                     # the only host wait inside the loop
                     next_check += sync_every
+                    if _after_launch is not None:                                       # (decode_batches: the next batch's host work and encoder
+                        _after_launch(); _after_launch = None                          #  launches, while the device runs the steps enqueued so far)
                     if bool(done.all()):
                         break
+        if _after_launch is not None:
+            _after_launch()
         del keep
         mark("searched")
         # ---- the back pointers are walked on the device (las_beam_backtrack); one read-back, then the reference's host-side objects

@@ -22,6 +22,8 @@ las = LAS(args, Listener, Speller, tok.token_to_id)
 lm = CharRNN(False, 1, 1, 28, 512, embedding_size=0, num_layers=2, store=st)
 lm.params(); las.build_variables()
 bs = BeamSearch(args, las, tok.token_to_id, lm)
+import gc
+gc.collect(); gc.freeze()          # as decode.py does: a full collection walks the model's objects (30-60 ms) every few batches otherwise
 for NUTT in [int(x) for x in os.environ.get("NUTT", "16 32 64").split()]:
     utts = [synthetic_batch(1, 1274, 8, 30, seed=100 + k)[0] for k in range(NUTT)]
     NB = max(6, 256 // NUTT)
