@@ -116,6 +116,7 @@ class BeamSearch(object):
         self.measure = os.environ.get("LAS_DECODE_TIMING") == "1"         # decode_batch leaves its phase / per-part timing in last_timing
         self.last_timing = None
         self._capture_stream = None
+        self._tail_stream = None            # decode_batches: a batch's back-tracking and read-back run here, beside the next batch's search
 
     # -- model calls (the reference's sess.run wrappers, las/beam_search.py:203-246) -------------------
     def _get_encode(self, sess, audio, audiolen):
@@ -175,16 +176,28 @@ class BeamSearch(object):
         it = iter(batches)
         first = next(it, None)
         cur = launch(first) if first is not None else None
+        pending = None                       # the previous batch's back-tracking / read-back / host objects, not yet run
         while cur is not None:
-            box = []
+            box, out = [], []
 
-            def prepare_next():              # runs inside decode_batch, behind the first `sync_every` search steps' launches: the host's part
-                nxt_xs = next(it, None)      # of the next batch (stacking the utterances, the copy to the device, the encoder launches)
-                box.append(launch(nxt_xs) if nxt_xs is not None else None)     # happens while the device is searching
+            def between(pending=pending):
+                # runs inside decode_batch, behind the launches of its first `sync_every` search steps, i.e. while the device is searching:
+                # the host's part of the NEXT batch (stacking the utterances, the copy to the device, the encoder launches on `es`) and
+                # everything behind the PREVIOUS batch's search (on the tail stream)
+                nxt_xs = next(it, None)
+                box.append(launch(nxt_xs) if nxt_xs is not None else None)
+                if pending is not None:
+                    out.append(pending())
             main.wait_event(cur[2])
-            res = self.decode_batch(sess, cur[0], sync_every, _pre=cur[1], _after_launch=prepare_next)
-            yield res
+            pending = self.decode_batch(sess, cur[0], sync_every, _pre=cur[1], _after_launch=between, _defer=True)
+            if out:
+                yield out[0]
+            if not callable(pending):        # (LAS_DECODE_TIMING: decode_batch measured its phases and returned the results)
+                yield pending
+                pending = None
             cur = box[0]
+        if pending is not None:
+            yield pending()
 
     def _run_encoders(self, sess, xs_list):
         """The encoders of a batch of utterances on the CURRENT stream, without waiting for the device (the encoded lengths are host
@@ -279,7 +292,7 @@ class BeamSearch(object):
                 encode_group(us)
         return encs, enc_lens, dec_steps, h_one
 
-    def decode_batch(self, sess, xs_list, sync_every=32, _pre=None, _after_launch=None):
+    def decode_batch(self, sess, xs_list, sync_every=32, _pre=None, _after_launch=None, _defer=False):
         """Beam search for several utterances at once (what decode.py's loop over utterances, decode.py:131-149, becomes on
         one GPU): xs_list = [(audio [1,T_u,feat_dim,3], audiolen [1]), ...] -> [list of BeamState (ascending), ...].
 
@@ -528,7 +541,7 @@ class BeamSearch(object):
         # the last replay may run past the bound.
         K = max(1, int(self.steps_per_graph))
         with torch.no_grad():
-            t, next_check = 0, sync_every
+            t, next_check = 0, sync_every * (2 if _after_launch is not None else 1)     # (the host work done at the first check wants ~6 ms of queued steps)
             while t < Umax:
                 if graph is not None:
                     graph.replay()
@@ -574,6 +587,54 @@ class BeamSearch(object):
             _after_launch()
         del keep
         mark("searched")
+        if _defer and not self.measure:
+            # decode_batches: everything behind the search -- back-tracking, the alignment gather, the read-back, the host objects -- as a
+            # closure that runs on a side stream behind THIS point of the launch stream: the caller launches the next batch's search first and
+            # calls it while the device is busy with that (the read-back waits for the side stream only).  This batch's tensors live in the
+            # closure until then.
+            ev = torch.cuda.Event()
+            ev.record()
+            if self._tail_stream is None:
+                self._tail_stream = torch.cuda.Stream()
+
+            alive = (hist_parent, hist_token, hist_slot, hist_score, hist_n, sel_t, sel_j, nsel, score, length, nlive, done, dstep, step,
+                     src_row, next_token)                 # `ba` holds their addresses
+
+            def finish(alive=alive):
+                ts_ = self._tail_stream
+                ts_.wait_event(ev)
+                with torch.cuda.stream(ts_):
+                    return self._decode_tail(dev, n, selcap, Umax, i32, ba, lib, alphas_hist, Tps, mark)
+            return finish
+        results = self._decode_tail(dev, n, selcap, Umax, i32, ba, lib, alphas_hist, Tps, mark)
+        mark("done")
+        parts = {}
+        if tm:        # device time of the three parts of a decode step (HIP events, 50 eager repetitions each, after the search)
+            step.zero_()
+            for name, fn in (("speller", speller_part), ("lm", lm_part if lm is not None else None), ("beam", beam_part)):
+                if fn is None:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.no_grad():
+                    fn(); e0.record()
+                    for _ in range(50):
+                        fn()
+                        if name == "beam":
+                            step.zero_()
+                    e1.record()
+                torch.cuda.synchronize(dev)
+                parts[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
+            ks = list(tm)
+            self.last_timing = {ks[i + 1]: round(tm[ks[i + 1]] - tm[ks[i]], 4) for i in range(len(ks) - 1)}
+            self.last_timing.update(steps=steps_run, rows=N, frames=Tp, graph=graph is not None, parts_us=parts)
+            if self.args.verbose > 0:
+                print("decode_batch timing (s):", self.last_timing)
+        return results
+
+    def _decode_tail(self, dev, n, selcap, Umax, i32, ba, lib, alphas_hist, Tps, mark):
+        """What follows a search (decode_batch; on the current stream): the back pointers are walked on the device (las_beam_backtrack), one
+        read-back, then the reference's host-side objects (las/beam_search.py:136-158, :297-312)."""
+        import ctypes
         # ---- the back pointers are walked on the device (las_beam_backtrack); one read-back, then the reference's host-side objects
         W = n * selcap
         w_ids = torch.zeros(W, Umax, **i32)
@@ -608,28 +669,6 @@ class BeamSearch(object):
                 w, ln_ = int(ws[i]), int(lens[ws[i]])
                 results[u].append(BeamState((self.start_id, ids_h[w, :ln_]), np.float32(sc_h[w]),
                                             _AttRows(g_att, int(of[i]), ln_ + 1, Tps[u]), None, None))
-        mark("done")
-        parts = {}
-        if tm:        # device time of the three parts of a decode step (HIP events, 50 eager repetitions each, after the search)
-            step.zero_()
-            for name, fn in (("speller", speller_part), ("lm", lm_part if lm is not None else None), ("beam", beam_part)):
-                if fn is None:
-                    continue
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                with torch.no_grad():
-                    fn(); e0.record()
-                    for _ in range(50):
-                        fn()
-                        if name == "beam":
-                            step.zero_()
-                    e1.record()
-                torch.cuda.synchronize(dev)
-                parts[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
-            ks = list(tm)
-            self.last_timing = {ks[i + 1]: round(tm[ks[i + 1]] - tm[ks[i]], 4) for i in range(len(ks) - 1)}
-            self.last_timing.update(steps=steps_run, rows=N, frames=Tp, graph=graph is not None, parts_us=parts)
-            if self.args.verbose > 0:
-                print("decode_batch timing (s):", self.last_timing)
         return results
 
     def restore_las(self, sess, save_path, restore_epoch):
