@@ -22,6 +22,13 @@ __device__ __forceinline__ bool bless(const BKey& a, const BKey& b) {   // a < b
     return a.v < b.v;
 }
 
+#ifdef LAS_BEAM_STAMPS   // development aid (make ablf F=beam D=-DLAS_BEAM_STAMPS; tools/probe_beam_stamps.py): 100 MHz phase stamps of utterance 0's workgroup
+__device__ unsigned long long g_beam_stamps[16];
+#define BSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 0) g_beam_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int las_dev_beam_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_beam_stamps), sizeof(g_beam_stamps)); }
+#else
+#define BSTAMP(i)
+#endif
 // The `beam` best candidates of one utterance, best first, into L.picks[] (LDS); returns how many exist.  Called by all 256 threads.
 //
 // Up to 512 candidates (beam x V of a char model): a candidate becomes two sortable integers -- KA = order(norm) (32 bits) and
@@ -69,9 +76,13 @@ template <int NS>
 __device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const unsigned long long (&KB)[NS], const int (&ci)[NS],
                                                 const float (&cl)[NS], const int (&cv)[NS], const unsigned on, const int beam, const int lane,
                                                 BeamLds& L, const int obase) {
+    // (ballots through the builtin: hip's __ballot materialises the predicate as an integer and compares it again -- v_cmp, s_and, s_nop,
+    //  v_cndmask, v_cmp, s_bcnt1 per count, ~170 cycles per probe of two slots: r5 stamps, the 64 probes of the two levels were 5.4 us of a
+    //  14.5 us launch.  The slots' validity as wave masks, one compare + s_and + s_bcnt1 per count.)
+    unsigned long long onm[NS];
     int nvalid = 0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) nvalid += __popcll(__ballot((on >> s) & 1u));
+    for (int s = 0; s < NS; ++s) { onm[s] = __builtin_amdgcn_ballot_w64(((on >> s) & 1u) != 0); nvalid += __builtin_popcountll(onm[s]); }
     const int need = nvalid < beam ? nvalid : beam;
     if (need == 0) return 0;
     unsigned TA = 0;
@@ -79,7 +90,7 @@ __device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const 
         const unsigned probe = TA | (1u << b);
         int cnt = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) cnt += __popcll(__ballot(((on >> s) & 1u) && KA[s] >= probe));
+        for (int s = 0; s < NS; ++s) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(KA[s] >= probe) & onm[s]);
         if (cnt >= need) TA = probe;                     // uniform (ballots)
     }
     int gt = 0, eq = 0;
@@ -88,7 +99,7 @@ __device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const 
     for (int s = 0; s < NS; ++s) {
         const bool o = (on >> s) & 1u;
         if (o && KA[s] == TA) tie |= 1u << s;
-        gt += __popcll(__ballot(o && KA[s] > TA)); eq += __popcll(__ballot((tie >> s) & 1u));
+        gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(o && KA[s] > TA)); eq += __builtin_popcountll(__builtin_amdgcn_ballot_w64(((tie >> s) & 1u) != 0));
     }
     unsigned long long TB = 0;
     if (eq > need - gt) {                                // equal normalised scores at the threshold: the (need - gt) largest KB of the ties
@@ -96,7 +107,7 @@ __device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const 
             const unsigned long long probe = TB | (1ull << b);
             int cnt = 0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) cnt += __popcll(__ballot(((tie >> s) & 1u) && KB[s] >= probe));
+            for (int s = 0; s < NS; ++s) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(((tie >> s) & 1u) && KB[s] >= probe));
             if (cnt >= need - gt) TB = probe;
         }
     }
@@ -105,7 +116,7 @@ __device__ __forceinline__ int beam_wave_select(const unsigned (&KA)[NS], const 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const bool sel = ((on >> s) & 1u) && (KA[s] > TA || (KA[s] == TA && KB[s] >= TB));
-        const unsigned long long m = __ballot(sel);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
         if (sel) {
             const int pos = base + __popcll(m & lt);
             L.ka[pos] = KA[s]; L.kb[pos] = KB[s]; L.ci[pos] = ci[s]; L.cl[pos] = cl[s]; L.cv[pos] = cv[s];
@@ -133,21 +144,36 @@ __device__ __forceinline__ int beam_rank(const float* lg, const float* sc, const
                     ci[s] = k.i; cl[s] = k.l; cv[s] = k.v;
                 }
             }
+            BSTAMP(7);
             const int n = beam_wave_select<2>(KA, KB, ci, cl, cv, on, beam, lane, L, w * 64);
             if (lane == 0) L.cnt[w] = n;
+            BSTAMP(8);
         }
         __syncthreads();
-        if (w == 0) {   // level 2: the survivors (wave s's list = slot s), then the winners' order
-            unsigned KA[4]; unsigned long long KB[4]; int ci[4], cv[4]; float cl[4];
-            unsigned on = 0;
+        BSTAMP(9);
+        if (w == 0) {   // level 2: the survivors, then the winners' order
+            int need;
+            if (4 * beam <= 64) {
+                // every wave kept <= beam survivors: all of them in ONE slot (lane = wave's list * beam + position), a quarter of the ballots
+                unsigned KA[1]; unsigned long long KB[1]; int ci[1], cv[1]; float cl[1];
+                const int sw = (lane >= beam) + (lane >= 2 * beam) + (lane >= 3 * beam), pos = lane - sw * beam;
+                const bool o = lane < 4 * beam && pos < L.cnt[sw];
+                const int e = sw * 64 + (o ? pos : 0);
+                KA[0] = L.ka[e]; KB[0] = L.kb[e]; ci[0] = L.ci[e]; cl[0] = L.cl[e]; cv[0] = L.cv[e];
+                need = beam_wave_select<1>(KA, KB, ci, cl, cv, o ? 1u : 0u, beam, lane, L, 256);
+            } else {    // (wave s's list = slot s)
+                unsigned KA[4]; unsigned long long KB[4]; int ci[4], cv[4]; float cl[4];
+                unsigned on = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bool o = lane < L.cnt[s];
-                const int e = s * 64 + (o ? lane : 0);
-                KA[s] = L.ka[e]; KB[s] = L.kb[e]; ci[s] = L.ci[e]; cl[s] = L.cl[e]; cv[s] = L.cv[e];
-                if (o) on |= 1u << s;
+                for (int s = 0; s < 4; ++s) {
+                    const bool o = lane < L.cnt[s];
+                    const int e = s * 64 + (o ? lane : 0);
+                    KA[s] = L.ka[e]; KB[s] = L.kb[e]; ci[s] = L.ci[e]; cl[s] = L.cl[e]; cv[s] = L.cv[e];
+                    if (o) on |= 1u << s;
+                }
+                need = beam_wave_select<4>(KA, KB, ci, cl, cv, on, beam, lane, L, 256);
             }
-            const int need = beam_wave_select<4>(KA, KB, ci, cl, cv, on, beam, lane, L, 256);
+            BSTAMP(10);
             // (one wave: its LDS writes are ordered before its later LDS reads; keep the compiler from moving them)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -156,9 +182,10 @@ __device__ __forceinline__ int beam_rank(const float* lg, const float* sc, const
                 const unsigned ma = L.ka[256 + lane];
                 const unsigned long long mb = L.kb[256 + lane];
                 int r = 0;
-                for (int q = 0; q < need; ++q) {
-                    const unsigned qa = L.ka[256 + q];
-                    const unsigned long long qb = L.kb[256 + q];
+                for (int q = 0; q < need; ++q) {         // winner q's key from lane q (a scalar broadcast: the LDS reads of this loop were 1.6 us)
+                    const unsigned qa = __builtin_amdgcn_readlane(ma, q);
+                    const unsigned long long qb = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((unsigned)(mb >> 32), q) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((unsigned)mb, q);
                     r += (qa > ma || (qa == ma && qb > mb)) ? 1 : 0;
                 }
                 const BKey k = {0.f, L.ci[256 + lane], L.cl[256 + lane], L.cv[256 + lane]};
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
     __shared__ int srcs[64];                                // fold_gather: the rows the utterance's new live slots continue (beam <= 64)
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
+    BSTAMP(0);
     // Every word the launch branches on, and (usual geometry) every operand of the in-kernel projection, is requested HERE, before the
     // first branch: the step counter, the utterance's done / bound / live words and then the projection's loads were four dependent
     // round trips in a row at the head of a 15 us launch (round 5).  All addresses are valid whatever the words turn out to be.
@@ -327,6 +355,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    BSTAMP(1);
     if (t >= a.Umax) { beam_finish(a); return; }
     if (u >= a.nutt) {                                    // filing workgroups: this step's row tensor (the alignments) under the DEVICE step counter
         const int nf = (int)gridDim.x - a.nutt;
@@ -394,10 +423,12 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
                 }
             }
         }
+        BSTAMP(2);
 #pragma unroll
         for (int i = 0; i < BEAM_PROJ_TILES; ++i)
             if (i < RT * CT) *reinterpret_cast<f32x4_t*>(&red[w][i][lane][0]) = acc[i];
         __syncthreads();
+        BSTAMP(3);
         for (int idx = tid; idx < RT * CT * 256; idx += 256) {        // C layout: (row r16, col c16) of a tile sits in lane (r16 / 4) * 16 + c16, register r16 % 4
             const int tile = idx >> 8, o = idx & 255, r16 = o >> 4, c16 = o & 15, l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
             const int rt = tile / CT, ct = tile - rt * CT, hr = rt * 16 + r16, col = ct * 16 + c16;
@@ -410,7 +441,9 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         __syncthreads();
         lg = lgs;
     }
+    BSTAMP(4);
     const int count = beam_rank(lg, sc_s, ln_s, nb, V, t, a.start_id, beam, L);
+    BSTAMP(5);
     if (tid < 64) {
     // the reference's bookkeeping (las/beam_search.py:147-152) in its iteration order = ascending rank (best last): lane j of the
     // first wave is pick j (beam <= 64); the positions of the retired / surviving picks in their lists are prefix counts of ballots
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     const float news = sc_s[k.i] + k.l;                  // (the old sums: the LDS copies, untouched by the stores below)
     const int newl = ln_s[k.i] + 1;
     const bool isend = act && v == a.end_id, live = act && !isend;
-    const unsigned long long mend = __ballot(isend), mlive = __ballot(live), below = (1ull << j) - 1ull;
+    const unsigned long long mend = __builtin_amdgcn_ballot_w64(isend), mlive = __builtin_amdgcn_ballot_w64(live), below = (1ull << j) - 1ull;
     const int ns0 = nsel_u;
     const int eidx = ns0 + __popcll(mend & below), lidx = __popcll(mlive & below);
     const int nl = __popcll(mlive);
@@ -451,6 +484,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         if (fin) a.done[u] = 1;
     }
     }
+    BSTAMP(6);
     if (a.gather) {
         __syncthreads();                                               // wave 0's src_row stores (workgroup scope) before the other waves read them
         beam_gather_rows(a, u, srcs);
