@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
     __shared__ int srcs[64];                                // fold_gather: the rows the utterance's new live slots continue (beam <= 64)
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
-    BSTAMP(0);
+#ifdef LAS_BEAM_STAMPS
+    const unsigned long long bs_e0 = wall_clock64();      // (written with stamp 1, for launches inside the step bound only: the replayed graph runs past it)
+#endif
     // Every word the launch branches on, and (usual geometry) every operand of the in-kernel projection, is requested HERE, before the
     // first branch: the step counter, the utterance's done / bound / live words and then the projection's loads were four dependent
     // round trips in a row at the head of a 15 us launch (round 5).  All addresses are valid whatever the words turn out to be.
@@ -355,7 +357,10 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    BSTAMP(1);
+#ifdef LAS_BEAM_STAMPS
+    const unsigned long long bs_e1 = wall_clock64();
+    if (t < a.Umax && threadIdx.x == 0 && blockIdx.x == 0) { g_beam_stamps[0] = bs_e0; g_beam_stamps[1] = bs_e1; }
+#endif
     if (t >= a.Umax) { beam_finish(a); return; }
     if (u >= a.nutt) {                                    // filing workgroups: this step's row tensor (the alignments) under the DEVICE step counter
         const int nf = (int)gridDim.x - a.nutt;
@@ -494,7 +499,41 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
 
 // rows of `ntens` state tensors follow their hypotheses: out[k][r] = in[k][src_row[r]] (r = global row), then t += 1.
 struct GatherDev { const float* in[16]; float* out[16]; int width[16]; int ntens; const int* src_row; int* step; int nrows; };
+// One workgroup per ROW, all tensors (round 5; before: one workgroup per (row, tensor) copying 4 bytes per lane): the row's source index is
+// read once, every tensor's piece of the row is requested before the first is stored (clamped addresses, predicated stores: no branch
+// around a load), 16 bytes per lane where the widths and addresses allow.
 __global__ __launch_bounds__(256) void beam_gather_kernel(GatherDev g) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int src = g.src_row[r];
+    bool vec = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < g.ntens) vec = vec && ((g.width[k] & 3) | ((size_t)g.in[k] & 15) | ((size_t)g.out[k] & 15)) == 0 && g.width[k] <= 1024;
+    if (vec) {
+        f32x4_t v[16];                                      // (native vectors and constant indices only: HIP's float4 array, or in[k < ntens ? k : 0],
+#pragma unroll                                          //  put the whole thing in scratch)
+        for (int k = 0; k < 16; ++k) {
+            const bool on = k < g.ntens;
+            const float* ip = on ? g.in[k] : g.in[0];
+            const int w = on ? g.width[k] : g.width[0], w4 = w >> 2;
+            v[k] = reinterpret_cast<const f32x4_t*>(ip + (size_t)src * w)[tid < w4 ? tid : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < g.ntens && tid < (g.width[k] >> 2)) reinterpret_cast<f32x4_t*>(g.out[k] + (size_t)r * g.width[k])[tid] = v[k];
+    } else {
+        for (int k = 0; k < g.ntens; ++k) {
+            const int w = g.width[k];
+            const float* ip = g.in[k] + (size_t)src * w;
+            float* op = g.out[k] + (size_t)r * w;
+            for (int i = tid; i < w; i += 256) op[i] = ip[i];
+        }
+    }
+    if (r == 0 && tid == 0) g.step[0] += 1;       // no workgroup of this kernel reads the counter
+}
+// ... and one workgroup per (row, tensor): few rows (a search over 16 utterances: 256) are latency-, not bandwidth-bound -- 7x the workgroups
+// spread over the chip finish sooner than 256 that each wait for their source index and then for seven pieces (56.6 against 55.0 us per step)
+__global__ __launch_bounds__(256) void beam_gather_rt_kernel(GatherDev g) {
     const int r = blockIdx.x, k = blockIdx.y;
     const int src = g.src_row[r];
     const int w = g.width[k];
@@ -554,7 +593,8 @@ extern "C" int las_beam_loop_step(const las_beam_loop_args* p, void* stream) {
             LAS_ARG(p->state_in[k] && p->state_out[k] && p->state_width[k] > 0, "las_beam_loop_step: bad state tensor %d", k);
             g.in[k] = p->state_in[k]; g.out[k] = p->state_out[k]; g.width[k] = p->state_width[k];
         }
-        hipLaunchKernelGGL(beam_gather_kernel, dim3(g.nrows, p->ntens), dim3(256), 0, st, g);      // ... and *step += 1
+        if (g.nrows >= 512) hipLaunchKernelGGL(beam_gather_kernel, dim3(g.nrows), dim3(256), 0, st, g);                // ... and *step += 1
+        else                hipLaunchKernelGGL(beam_gather_rt_kernel, dim3(g.nrows, p->ntens), dim3(256), 0, st, g);
         LAS_LAUNCHED();
     } else {
         hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(1), 0, st, p->step);
