@@ -397,20 +397,23 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         // their partial tiles meet in LDS; the ranking then reads the logits from LDS.  Saves two launches per decode step.
         __shared__ float red[4][BEAM_PROJ_TILES][64][4];
         __shared__ float lgs[BEAM_PROJ_TILES * 256];
+        // (the usual geometry's two accumulators are NOT elements of acc[]: the general path indexes that array with run-time tile numbers,
+        //  which puts it in scratch -- every MFMA of the usual path was a scratch load and a scratch store, r5 ISA)
         f32x4_t acc[BEAM_PROJ_TILES];
-#pragma unroll
-        for (int i = 0; i < BEAM_PROJ_TILES; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t ua0 = {0.f, 0.f, 0.f, 0.f}, ua1 = ua0;
         if (usual) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (w + 4 * j < KS) {
                     const u32x4_t pk = {f2bf2(xa[j][0].x, xa[j][0].y), f2bf2(xa[j][0].z, xa[j][0].w), f2bf2(xa[j][1].x, xa[j][1].y), f2bf2(xa[j][1].z, xa[j][1].w)};
                     const u16x8_t av = __builtin_bit_cast(u16x8_t, pk);
-                    acc[0] = mfma_bf16_16x16x32(av, bw[j][0], acc[0]);
-                    if (CT > 1) acc[1] = mfma_bf16_16x16x32(av, bw[j][1], acc[1]);
+                    ua0 = mfma_bf16_16x16x32(av, bw[j][0], ua0);
+                    if (CT > 1) ua1 = mfma_bf16_16x16x32(av, bw[j][1], ua1);
                 }
             }
-        } else
+        } else {
+#pragma unroll
+        for (int i = 0; i < BEAM_PROJ_TILES; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int ks = w; ks < KS; ks += 4) {
 #pragma unroll
             for (int rt = 0; rt < BEAM_PROJ_TILES; ++rt) {
@@ -428,10 +431,16 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
                 }
             }
         }
+        }
         BSTAMP(2);
+        if (usual) {
+            *reinterpret_cast<f32x4_t*>(&red[w][0][lane][0]) = ua0;
+            if (CT > 1) *reinterpret_cast<f32x4_t*>(&red[w][1][lane][0]) = ua1;
+        } else {
 #pragma unroll
-        for (int i = 0; i < BEAM_PROJ_TILES; ++i)
-            if (i < RT * CT) *reinterpret_cast<f32x4_t*>(&red[w][i][lane][0]) = acc[i];
+            for (int i = 0; i < BEAM_PROJ_TILES; ++i)
+                if (i < RT * CT) *reinterpret_cast<f32x4_t*>(&red[w][i][lane][0]) = acc[i];
+        }
         __syncthreads();
         BSTAMP(3);
         for (int idx = tid; idx < RT * CT * 256; idx += 256) {        // C layout: (row r16, col c16) of a tile sits in lane (r16 / 4) * 16 + c16, register r16 % 4
