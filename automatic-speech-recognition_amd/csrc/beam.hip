@@ -322,6 +322,7 @@ __device__ __forceinline__ void beam_gather_rows(const BeamLoopDev& a, const int
 __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     __shared__ BeamLds L;
     __shared__ int srcs[64];                                // fold_gather: the rows the utterance's new live slots continue (beam <= 64)
+    kernarg_warm<(int)sizeof(BeamLoopDev)>();
     const int u = blockIdx.x, tid = threadIdx.x, beam = a.beam, V = a.V;
 #ifdef LAS_BEAM_STAMPS
     const unsigned long long bs_e0 = wall_clock64();      // (written with stamp 1, for launches inside the step bound only: the replayed graph runs past it)
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
     // first branch: the step counter, the utterance's done / bound / live words and then the projection's loads were four dependent
     // round trips in a row at the head of a 15 us launch (round 5).  All addresses are valid whatever the words turn out to be.
     const int uc = u < a.nutt ? u : 0;
-    const int t = a.step[0];
+    // (the step counter through the VECTOR memory path: as a scalar load its miss -- the previous launch wrote it -- is waited for by the next
+    //  lgkmcnt(0) of the argument loads, in front of the projection's operands; r5 stamps)
+    const int t_v = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int done_u = a.done[uc], bound_u = a.dec_step[uc], live_u = a.nlive[uc], nsel_u = a.nsel[uc];
     // the live hypotheses' running sums and lengths: read by the ranking (per candidate) and again by the bookkeeping (per pick) -- one
     // round trip each, behind the projection; requested here, kept in LDS
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(256) void beam_loop_kernel(BeamLoopDev a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    const int t = __builtin_amdgcn_readfirstlane(t_v);
 #ifdef LAS_BEAM_STAMPS
     const unsigned long long bs_e1 = wall_clock64();
     if (t < a.Umax && threadIdx.x == 0 && blockIdx.x == 0) { g_beam_stamps[0] = bs_e0; g_beam_stamps[1] = bs_e1; }

@@ -45,6 +45,31 @@ __device__ __forceinline__ unsigned int f2bf2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// Touch every 64-byte line of the kernel's argument segment at entry (one scalar load per line, results unused).  The compiler loads
+// arguments lazily, in dependent batches (a batch, a branch, the next batch ...), and the first touch of a line is a miss all the way to
+// the segment's memory (~0.5-0.7 us each, r5 stamps: 2.1 us from a workgroup's entry to its first vector load with a 600-byte argument
+// struct); with the lines requested together up front the later batches hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d;
+    // (one block, ending in its own wait: the compiler does not know that an asm's scalar load is still in flight and would hand the
+    //  destination register to somebody else; the wait is the round trip the kernel's first argument batch waits for anyway)
+    if (BYTES <= 256)
+        asm volatile("s_load_dword %0, %1, 0x0\n s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d) : "s"(kp) : "memory");
+    else if (BYTES <= 512)
+        asm volatile("s_load_dword %0, %1, 0x0\n s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n"
+                     "s_load_dword %0, %1, 0x100\n s_load_dword %0, %1, 0x140\n s_load_dword %0, %1, 0x180\n s_load_dword %0, %1, 0x1c0\n s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d) : "s"(kp) : "memory");
+    else
+        asm volatile("s_load_dword %0, %1, 0x0\n s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n"
+                     "s_load_dword %0, %1, 0x100\n s_load_dword %0, %1, 0x140\n s_load_dword %0, %1, 0x180\n s_load_dword %0, %1, 0x1c0\n"
+                     "s_load_dword %0, %1, 0x200\n s_load_dword %0, %1, 0x240\n s_load_dword %0, %1, 0x280\n s_load_dword %0, %1, 0x2c0\n s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d) : "s"(kp) : "memory");
+    static_assert(BYTES <= 768, "kernarg_warm: argument struct larger than the lines it touches");
+}
+
 // D = A(16x32 bf16) . B(32x16 bf16) + C.  Lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15],
 // C/D[(l>>4)*4+r][l&15]  (cdna_hip_programming.md section 3).
 __device__ __forceinline__ f32x4_t mfma_bf16_16x16x32(u16x8_t a, u16x8_t b, f32x4_t c) {
