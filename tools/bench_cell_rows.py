@@ -12,7 +12,8 @@ lib = _hip.lib()
 g = torch.Generator().manual_seed(0)
 
 def timeit(fn, n=200):
-    fn(); torch.cuda.synchronize()
+    for _ in range(3): fn()                 # (the first launch of an instantiation sets its LDS attribute)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
