@@ -313,31 +313,58 @@ __global__ __launch_bounds__(512, 2) void lstm_cell_rows_pair_kernel(LstmCellLau
     else                 lstm_cell_rows_body<false, false, false>(b, As, gates, blockIdx.x, blockIdx.y * 32);
 }
 
-// 128-row workgroups (lstm_cell_rows_big_body): M >= LB_MIN_ROWS
-template <bool FAST, bool XBF>
+// the pipelined body (lstm_cell_rows_big_body): 128, 64 or 32 rows per workgroup, M >= LB_MIN_ROWS
+template <bool FAST, bool XBF, int ROWS>
 __global__ __launch_bounds__(512) void lstm_cell_rows_big_kernel(LstmCellLaunch a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
-    lstm_cell_rows_big_body<FAST, XBF>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+    lstm_cell_rows_big_body<FAST, XBF, ROWS>(a, lb_smem, blockIdx.x, blockIdx.y * ROWS);
 }
-// ... and two independent cells of 128-row workgroups in one grid (blockIdx.z as in the pair kernel above): at 240 VGPRs a CU holds one
-// workgroup, so the two problems run one behind the other -- but without the 32-row bodies' four rounds per problem (r5, M = 1024: 29 us
-// against the pair kernel's 35)
-template <bool BBF>                 // the second problem's rows: bf16 (the LM's state copies, h_out_bf16 of the step before) or fp32
+// ... and two independent cells in one grid (blockIdx.z as in the pair kernel above).  At 128 rows and 240 VGPRs a CU holds one workgroup
+// and the two problems run one behind the other -- but without the unpipelined 32-row bodies' four rounds per problem (r5, M = 1024: 29 us
+// against 35); at 32 / 64 rows the body needs few registers and both problems share a CU.
+template <bool BBF, int ROWS>       // the second problem's rows: bf16 (the LM's state copies, h_out_bf16 of the step before) or fp32
 __global__ __launch_bounds__(512) void lstm_cell_rows_big_pair_kernel(LstmCellLaunch a, LstmCellLaunch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
-    if (blockIdx.z == 0) lstm_cell_rows_big_body<true, true>(a, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
-    else                 lstm_cell_rows_big_body<false, BBF>(b, lb_smem, blockIdx.x, blockIdx.y * LB_ROWS);
+    if (blockIdx.z == 0) lstm_cell_rows_big_body<true, true, ROWS>(a, lb_smem, blockIdx.x, blockIdx.y * ROWS);
+    else                 lstm_cell_rows_big_body<false, BBF, ROWS>(b, lb_smem, blockIdx.x, blockIdx.y * ROWS);
 }
-constexpr int LB_MIN_ROWS = 384;
-// the 128-row body takes ONE element type for all its rows: bf16 (x_bf16 / h_bf16) or fp32
+constexpr int LB_MIN_ROWS = 128;          // below: the unpipelined 32-row body (a training batch's per-step fallback: M <= 48)
+static inline int lb_rows_for(int M) { return M > 512 ? 128 : (M > 256 ? 64 : 32); }   // the largest tile that still gives 256 CUs a workgroup each at H = 512
+// the pipelined body takes ONE element type for all its rows: bf16 (x_bf16 / h_bf16) or fp32
 static inline int lb_rows_type(const LstmCellLaunch& a) {          // 1 bf16, 0 fp32, -1 mixed
     const int xt = a.x ? (a.x_bf16 ? 1 : 0) : -1, ht = a.h ? (a.h_bf16 ? 1 : 0) : -1;
     if (xt >= 0 && ht >= 0 && xt != ht) return -1;
     return xt >= 0 ? xt : (ht >= 0 ? ht : 0);
 }
-static inline bool lb_serves(const LstmCellLaunch& a) { return a.M >= LB_MIN_ROWS && lb_rows_type(a) >= 0; }          // from here on a launch of 32-row workgroups is more than one round of the 256 CUs per 512 units
+static inline bool lb_serves(const LstmCellLaunch& a) { return a.M >= LB_MIN_ROWS && lb_rows_type(a) >= 0; }
 template <typename K>
-static int lb_attr(K kern) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES); }
+static int lb_attr(K kern, int rows) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lb_lds_bytes(rows)); }
+template <int ROWS>
+static int lb_launch(const LstmCellLaunch& a, hipStream_t st) {
+    static int attr = lb_attr(lstm_cell_rows_big_kernel<true, true, ROWS>, ROWS) | lb_attr(lstm_cell_rows_big_kernel<true, false, ROWS>, ROWS) |
+                      lb_attr(lstm_cell_rows_big_kernel<false, true, ROWS>, ROWS) | lb_attr(lstm_cell_rows_big_kernel<false, false, ROWS>, ROWS);
+    if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big) failed: %d", attr); return attr; }
+    const dim3 gb(a.H / 16, cdiv(a.M, ROWS));
+    constexpr int LDS = lb_lds_bytes(ROWS);
+    const bool abf = lb_rows_type(a) == 1;
+    if (a.fast && abf) hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, true, ROWS>), gb, dim3(512), LDS, st, a);
+    else if (a.fast)   hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, false, ROWS>), gb, dim3(512), LDS, st, a);
+    else if (abf)      hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, true, ROWS>), gb, dim3(512), LDS, st, a);
+    else               hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, false, ROWS>), gb, dim3(512), LDS, st, a);
+    LAS_LAUNCHED();
+    return 0;
+}
+template <int ROWS>
+static int lb_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b, hipStream_t st) {
+    static int attr = lb_attr(lstm_cell_rows_big_pair_kernel<false, ROWS>, ROWS) | lb_attr(lstm_cell_rows_big_pair_kernel<true, ROWS>, ROWS);
+    if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big_pair) failed: %d", attr); return attr; }
+    const int bx = (a.H > b.H ? a.H : b.H) / 16, by = cdiv(a.M > b.M ? a.M : b.M, ROWS);
+    constexpr int LDS = lb_lds_bytes(ROWS);
+    if (lb_rows_type(b) == 1) hipLaunchKernelGGL((lstm_cell_rows_big_pair_kernel<true, ROWS>), dim3(bx, by, 2), dim3(512), LDS, st, a, b);
+    else                      hipLaunchKernelGGL((lstm_cell_rows_big_pair_kernel<false, ROWS>), dim3(bx, by, 2), dim3(512), LDS, st, a, b);
+    LAS_LAUNCHED();
+    return 0;
+}
 
 int las_lstm_cell_check(const LstmCellLaunch& a) {
     LAS_ARG((a.x || a.h) && a.bias && a.c_prev && a.c_out && a.h_out && a.M > 0 && a.H > 0, "las_lstm_cell_rows: bad arguments");
@@ -348,25 +375,18 @@ int las_lstm_cell_check(const LstmCellLaunch& a) {
     LAS_ARG(!a.h || (a.Wh && (a.ldh % 4) == 0 && (((uintptr_t)a.h) & 15) == 0), "las_lstm_cell_rows: h needs ldh %% 4 == 0, 16-byte alignment and Wh_packed");
     LAS_ARG((a.H % 32) == 0, "las_lstm_cell_rows: needs H %% 32 == 0");
     LAS_ARG(!(a.h_bf16 || a.h_out_bf16) || lb_serves(a),
-            "las_lstm_cell_rows: bf16 h / h_out_bf16 are served by the 128-row workgroups only (M >= %d, h present and 16-byte rows, x absent or bf16)", LB_MIN_ROWS);
+            "las_lstm_cell_rows: bf16 h / h_out_bf16 are served by the pipelined body only (M >= %d, one element type for x and h)", LB_MIN_ROWS);
     LAS_ARG(!a.h_bf16 || (a.ldh % 8) == 0, "las_lstm_cell_rows: bf16 h needs ldh %% 8 == 0");
     return 0;
 }
 
 int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
     if (int rc = las_lstm_cell_check(a)) return rc;
-    if (lb_serves(a)) {
-        static int attr = lb_attr(lstm_cell_rows_big_kernel<true, true>) | lb_attr(lstm_cell_rows_big_kernel<true, false>) |
-                          lb_attr(lstm_cell_rows_big_kernel<false, true>) | lb_attr(lstm_cell_rows_big_kernel<false, false>);
-        if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big) failed: %d", attr); return attr; }
-        const dim3 gb(a.H / 16, cdiv(a.M, LB_ROWS));
-        const bool abf = lb_rows_type(a) == 1;
-        if (a.fast && abf) hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else if (a.fast)   hipLaunchKernelGGL((lstm_cell_rows_big_kernel<true, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else if (abf)      hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, true>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        else               hipLaunchKernelGGL((lstm_cell_rows_big_kernel<false, false>), gb, dim3(512), LB_LDS_BYTES, st, a);
-        LAS_LAUNCHED();
-        return 0;
+    // (fp32 rows at <= 256 rows of x AND h -- the LM's second layer in a 16-utterance search: the unpipelined body's two 512-column chunks beat
+    //  eight pipelined 128-column chunks of 32 rows, 8.1 against 9.4 us)
+    if (lb_serves(a) && !(a.M <= 256 && lb_rows_type(a) == 0 && a.x && a.h && !a.h_out_bf16)) {
+        const int rows = lb_rows_for(a.M);
+        return rows == 128 ? lb_launch<128>(a, st) : (rows == 64 ? lb_launch<64>(a, st) : lb_launch<32>(a, st));
     }
     const dim3 grid(a.H / 16, cdiv(a.M, 32));
     if (a.fast && a.x_bf16) hipLaunchKernelGGL((lstm_cell_rows_kernel<true, true>), grid, dim3(512), 0, st, a);
@@ -385,13 +405,8 @@ int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b,
         return las_lstm_cell_rows_launch(b, st);
     }
     if (lb_serves(a) && lb_rows_type(a) == 1 && lb_serves(b)) {
-        static int attr = lb_attr(lstm_cell_rows_big_pair_kernel<false>) | lb_attr(lstm_cell_rows_big_pair_kernel<true>);
-        if (attr != 0) { las_set_error("hipFuncSetAttribute(lstm_cell_rows_big_pair) failed: %d", attr); return attr; }
-        const int bx = (a.H > b.H ? a.H : b.H) / 16, by = cdiv(a.M > b.M ? a.M : b.M, LB_ROWS);
-        if (lb_rows_type(b) == 1) hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel<true>, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
-        else                      hipLaunchKernelGGL(lstm_cell_rows_big_pair_kernel<false>, dim3(bx, by, 2), dim3(512), LB_LDS_BYTES, st, a, b);
-        LAS_LAUNCHED();
-        return 0;
+        const int rows = lb_rows_for(a.M > b.M ? a.M : b.M);
+        return rows == 128 ? lb_launch2<128>(a, b, st) : (rows == 64 ? lb_launch2<64>(a, b, st) : lb_launch2<32>(a, b, st));
     }
     const int gx = (a.H > b.H ? a.H : b.H) / 16, gy = cdiv(a.M > b.M ? a.M : b.M, 32);
     hipLaunchKernelGGL(lstm_cell_rows_pair_kernel, dim3(gx, gy, 2), dim3(512), 0, st, a, b);

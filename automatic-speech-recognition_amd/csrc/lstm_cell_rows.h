@@ -208,10 +208,11 @@ __device__ __forceinline__ void lstm_cell_rows_body(const LstmCellLaunch& a, uns
 #ifndef LB_ABL
 #define LB_ABL 0          // timing experiments (make ablf F=loss_opt D=-DLB_ABL=..): 1 no MFMAs, 2 no row loads after the first chunk, 4 no fragment loads after the first, 8 LDS-only barriers
 #endif
-constexpr int LB_KC = 128, LB_LD = LB_KC + 8, LB_ROWS = 128;
-constexpr int LB_TILE = LB_ROWS * LB_LD;                // bf16 elements of one staged row tile
-constexpr int LB_LDS_BYTES = 2 * LB_TILE * 2;          // 69,632 bytes: two row tiles (chunk c is multiplied from one while chunk c + 1 is written to the
-                                                       // other: one barrier per chunk); the gate exchange [2][4][4][64][4] floats = 32 KB reuses the first
+constexpr int LB_KC = 128, LB_LD = LB_KC + 8;
+// ROWS per workgroup: 128, 64 or 32 (the launcher picks the largest that still gives the 256 CUs a workgroup each: 1024 rows -> 128, 512 -> 64,
+// 256 -> 32).  LDS: two row tiles of ROWS x (128 + 8) bf16 (chunk c is multiplied from one while chunk c + 1 is written to the other: one
+// barrier per chunk); the gate exchange [2][ROWS / 32][4][64][4] floats reuses the first
+constexpr int lb_lds_bytes(int rows) { return 2 * rows * LB_LD * 2; }
 
 // ABF: the rows (x and / or h) are bf16; otherwise fp32.  One element type per launch: a type switch inside the chunk loop is a branch
 // around loads, and the compiler ends every such branch in s_waitcnt vmcnt(0) -- which is what the first version of this body did at the end
@@ -219,9 +220,11 @@ constexpr int LB_LDS_BYTES = 2 * LB_TILE * 2;          // 69,632 bytes: two row 
 // time + multiply time, 2.7 / 3.6 us per 256 columns of K).  Here every load of the loop is unconditional (chunks behind the last are the
 // last one again, K steps and pieces behind a short chunk's end re-read its first), K moves in chunks of 128 through TWO register stages:
 // the rows of chunk c + 2 are requested when chunk c's have been written to LDS, its weight fragments when chunk c has been multiplied.
-template <bool FAST, bool ABF>
+template <bool FAST, bool ABF, int ROWS>
 __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a, unsigned char* smem, const int ub, const int row0) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g4 = lane >> 4, c = lane & 15;
+    static_assert(ROWS == 32 || ROWS == 64 || ROWS == 128, "rows per workgroup");
+    constexpr int RTW = ROWS / 32, LB_TILE = ROWS * LB_LD;             // 16-row tiles per wave (8 waves = 4 gates x 2 row halves); bf16 elements of a staged tile
     const int gt = w & 3, rh = w >> 2;
     const int H = a.H, ct = gt * (H >> 4) + ub;
     if (ub * 16 >= H || row0 >= a.M) return;
@@ -235,27 +238,27 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
 #endif
     LBS(0);
     // operands of the gate math at the end of the launch, requested here (see lstm_cell_rows_body): the thread's unit is the same for its
-    // four elements (rows tid / 16 + 32 k)
+    // RTW elements (rows tid / 16 + 32 k)
     const int eunit_ = ub * 16 + (tid & 15);
-    float pb_[4], pc_[4];
-    int pid_[4];
+    float pb_[4], pc_[RTW];
+    int pid_[RTW];
 #pragma unroll
     for (int g = 0; g < 4; ++g) pb_[g] = a.bias[g * H + eunit_];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RTW; ++k) {
         const int erow = min(row0 + ((tid + k * 512) >> 4), a.M - 1);
         pc_[k] = a.c_prev[(size_t)erow * H + eunit_];
         pid_[k] = a.xrows ? a.ids[erow] : 0;
     }
     __builtin_amdgcn_sched_barrier(0);
     unsigned short* As = reinterpret_cast<unsigned short*>(smem);
-    f32x4_t acc[4];
+    f32x4_t acc[RTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RTW; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int KSx = a.x ? a.I >> 5 : 0, KSh = a.h ? H >> 5 : 0;
     constexpr int NKS = LB_KC / 32;                                       // k-steps per chunk
     const int ncx = (KSx + NKS - 1) / NKS, nch = ncx + (KSh + NKS - 1) / NKS;
-    constexpr int NRA = ABF ? 4 : 8;                                      // 16-byte pieces of a chunk's rows per thread
+    constexpr int NRA = ABF ? ROWS / 32 : ROWS / 16;                      // 16-byte pieces of a chunk's rows per thread
     constexpr int PPR = ABF ? LB_KC / 8 : LB_KC / 4;                      // 16-byte pieces per row and chunk
     constexpr int RPP = 512 / PPR;                                        // rows per pass of the 512 threads
     u16x8_t bq[2][NKS];
@@ -315,12 +318,12 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         const void* src; int ld, k0, kc; const u16x8_t* bp;
         chunk(ci, src, ld, k0, kc, bp);
         const int nks = kc >> 5;
-        const unsigned short* ar = As + S * LB_TILE + (rh * 64 + c) * LB_LD + g4 * 8;
+        const unsigned short* ar = As + S * LB_TILE + (rh * (ROWS / 2) + c) * LB_LD + g4 * 8;
 #pragma unroll
         for (int u = 0; u < NKS; ++u) {
             if (u < nks && !(LB_ABL & 1)) {
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
+                for (int rt = 0; rt < RTW; ++rt)
                     acc[rt] = mfma_bf16_16x16x32(*reinterpret_cast<const u16x8_t*>(ar + rt * 16 * LB_LD + u * 32), bq[S][u], acc[rt]);
             }
         }
@@ -348,17 +351,17 @@ __device__ __forceinline__ void lstm_cell_rows_big_body(const LstmCellLaunch& a,
         half(S1{}, S0{}, ci + 1);                                     // (behind the last chunk: nothing stored, nothing multiplied)
     }
     __syncthreads();                                                  // every wave is done reading the row tile: its space becomes the gate exchange
-    float* gx = reinterpret_cast<float*>(smem);                       // [rh 2][rt 4][gate 4][lane 64][4]
+    float* gx = reinterpret_cast<float*>(smem);                       // [rh 2][rt RTW][gate 4][lane 64][4]
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4_t*>(gx + ((((rh * 4 + rt) * 4 + gt) * 64 + lane) << 2)) = acc[rt];
+    for (int rt = 0; rt < RTW; ++rt) *reinterpret_cast<f32x4_t*>(gx + ((((rh * RTW + rt) * 4 + gt) * 64 + lane) << 2)) = acc[rt];
     __syncthreads();
     LBS(12);
-    // gate math: element (row r of the 128, unit u of the 16); MFMA C layout: (row r16, col u) of a tile sits in lane (r16 / 4) * 16 + u, register r16 % 4
+    // gate math: element (row r of the ROWS, unit u of the 16); MFMA C layout: (row r16, col u) of a tile sits in lane (r16 / 4) * 16 + u, register r16 % 4
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RTW; ++k) {
         const int idx = tid + k * 512, r = idx >> 4, u = idx & 15, row = row0 + r;
         if (row >= a.M) continue;
-        const int r16 = r & 15, l2 = (r16 >> 2) * 16 + u, reg = r16 & 3, unit = ub * 16 + u, tile = (r >> 6) * 4 + ((r >> 4) & 3);
+        const int r16 = r & 15, l2 = (r16 >> 2) * 16 + u, reg = r16 & 3, unit = ub * 16 + u, tile = (r / (ROWS / 2)) * RTW + ((r >> 4) % RTW);
         float z[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) z[g] = gx[(((tile * 4 + g) * 64 + l2) << 2) + reg] + pb_[g];
