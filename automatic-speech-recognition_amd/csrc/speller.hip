@@ -871,9 +871,12 @@ __device__ unsigned long long g_stamps[32];
 #define STAMPX(i) do { if (tid == 0 && b == 0) g_stamps[i] = wall_clock64(); } while (0)
 #define STAMPQ(i) g_stamps[i] = wall_clock64()
 #define STAMPL(v) g_stamps[31] = (v)
+#define STAMPB(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int las_dev_row_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
 #else
 #define STAMPX(i)
 #define STAMPQ(i)
+#define STAMPB(i)
 #define STAMPL(v)
 #endif
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -1278,6 +1281,7 @@ static size_t beam_rows4_lds(const DecDev& a) {
 }
 template <int NE>
 __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
+    STAMPB(0);
     constexpr bool FAST = true;
     constexpr int R = BR4, NK = (16 * NE + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1301,6 +1305,16 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
     const int dd = tid < D ? tid : D - 1;
     const int len = a.enc_len[b0];
     const int a4c = a4 < A4 ? a4 : A4 - 1, a8c = a8 < A8 ? a8 : A8 - 1, h4c = h4 < H4 ? h4 : H4 - 1;
+    // (the four states first: loads return in issue order, and the states are what the first phase waits for -- behind the 170 KB of Ws and
+    //  keys they arrived 2 us later; r5 stamps)
+    float s0[R];
+    int tok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int b = b0 + r < B ? b0 + r : B - 1;
+        s0[r] = a.hs[(size_t)b * D + dd];
+        tok[r] = a.tok_in[b];
+    }
     uint4 w8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1314,14 +1328,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
         k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b0 * Tp + ttc) * A8 + a8c];
     }
-    float s0[R];
-    int tok[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int b = b0 + r < B ? b0 + r : B - 1;
-        s0[r] = a.hs[(size_t)b * D + dd];
-        tok[r] = a.tok_in[b];
-    }
+    STAMPB(1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {        // the states entering the step (hs slot 0: keep_state0)
         const float h = tid < D ? s0[r] : 0.f;
@@ -1332,6 +1339,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         }
     }
     lds_barrier();
+    STAMPB(2);
     {   // query projections q_r = s_r . Ws: the Ws fragments are read once for the four states
         float acc[R][4];
 #pragma unroll
@@ -1354,13 +1362,8 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         }
     }
     lds_barrier();
+    STAMPB(3);
     // the encoder rows for the context (the Ws registers are free now), consumed after the softmax -- once for the four rows
-    uint4 e8[NE];
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int tp = fg + 8 * u, tpc = tp < Tp2 ? tp : Tp2 - 1;
-        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b0 * Tp2 + tpc) * H4 + h4c];
-    }
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;
     for (int i = tid; i < R * A; i += RNT) {
         const int r = i / A, col = i - r * A;
@@ -1370,6 +1373,15 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         qv[r * SA + col] = q;
     }
     lds_barrier();
+    // ... requested HERE, behind the reduction that half the waves execute: in front of it the 160 KB of requests of all 16 waves sat in the
+    // CU's issue queue and the reducing waves behind them (r5 stamps: 4.3 us for a 16-term sum); they land under the energies
+    uint4 e8[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int tp = fg + 8 * u, tpc = tp < Tp2 ? tp : Tp2 - 1;
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b0 * Tp2 + tpc) * H4 + h4c];
+    }
+    STAMPB(4);
     {   // energies: a frame's keys are unpacked once and meet the four queries
         const float um = a8 < A8 ? 1.f : 0.f;
         const float u8[8] = {u40.x * um, u40.y * um, u40.z * um, u40.w * um, u41.x * um, u41.y * um, u41.z * um, u41.w * um};
@@ -1382,11 +1394,10 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
             for (int r = 0; r < R; ++r) {
                 float part = 0.f;
                 if (tt < len && tt < Tp) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(&qv[r * SA + a8c * 8]), q1 = *reinterpret_cast<const float4*>(&qv[r * SA + a8c * 8 + 4]);
+                    const float q8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};      // (lanes past the attention width: u8 = 0)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float q = a8 < A8 ? qv[r * SA + a8 * 8 + e] : 0.f;
-                        part = fmaf(u8[e], tanhx<FAST>(k[e] + q), part);
-                    }
+                    for (int e = 0; e < 8; ++e) part = fmaf(u8[e], tanhx<FAST>(k[e] + q8[e]), part);
                 }
                 part = sub16_sum(part);
                 if (a8 == 0 && tt < Tp) ev[r * ST + tt] = (tt < len) ? part : -1e8f;   // replace-mask, las/layers.py:205-207
@@ -1394,6 +1405,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         }
     }
     lds_barrier();
+    STAMPB(5);
     if (wv < 2 * R) {   // softmax: waves 2r, 2r + 1 own row r (as waves 0-1 own the single row of pf_fwd_row)
         const int r = wv >> 1, t2 = tid & 127;
         float ev_[NK];
@@ -1416,6 +1428,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         }
     }
     lds_barrier();
+    STAMPB(6);
     {   // contexts: the encoder rows in registers meet the four alignments
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1431,6 +1444,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
         }
     }
     lds_barrier();
+    STAMPB(7);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (b0 + r >= B) break;
@@ -1455,6 +1469,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
             xb[E + Hd + tid] = f2bf(v);
         }
     }
+    STAMPB(8);
 }
 
 // Round 5, beam search (las/beam_search.py:94-158 is ONE loop): the attention rows of a search step and ANOTHER cell step that depends on
