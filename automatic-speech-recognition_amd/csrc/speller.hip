@@ -1119,7 +1119,11 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     // barrier (phase stamps: 1.32 us for a 16-term sum).  LAS_E8_LATE: the loads are issued in NK portions between the frames of
     // the energies phase instead, where the other waves of a SIMD have transcendental work to cover a wave that waits to issue.
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
-    if (!LAS_E8_LATE && (NEL == 0 || !LAS_E8_EARLY)) {
+    // The per-step kernel (!LOOP: a beam search's 256 rows on 256 CUs at once, not a training batch's 48) requests them BEHIND the
+    // reduction: with every CU of the chip asking for its 164 KB at the same moment the reducing waves waited 4.6 us behind the requests
+    // (r5 stamps, tools/probe_pf_stamps.py); the rows then land under the energies.
+    constexpr bool E8_BEHIND = !LOOP && NEL == 0 && !LAS_E8_LATE;
+    if (!E8_BEHIND && !LAS_E8_LATE && (NEL == 0 || !LAS_E8_EARLY)) {
 #pragma unroll
         for (int u = NEL; u < NE; ++u) e8_load(u);
     }
@@ -1130,6 +1134,10 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
         L.qv[i] = q;
     }
     lds_barrier();
+    if (E8_BEHIND) {
+#pragma unroll
+        for (int u = NEL; u < NE; ++u) e8_load(u);
+    }
     STAMPX(4);
     {   // energies from the prefetched keys
         const float um = a8 < A8 ? 1.f : 0.f;        // lanes past the attention width carry clamped operands
