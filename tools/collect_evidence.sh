@@ -74,6 +74,9 @@ MS="256 1024" python3 tools/bench_cell_rows.py 2>&1 | grep -v amdgpu > gpurun_ou
 [ -f automatic-speech-recognition_amd/lib/liblas_hip_ablf.so ] && MS=1024 LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_ablf.so STAMP=1 python3 tools/bench_cell_rows.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_cell_phase_stamps.txt
 [ -x tools/micro/bin/bench_ingest2 ] && tools/micro/bin/bench_ingest2 > gpurun_out/${P}_cu_ingest.txt 2>&1
 [ -f automatic-speech-recognition_amd/lib/liblas_hip_beamst.so ] && LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_beamst.so python3 tools/probe_beam_stamps.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_beam_phase_stamps.txt   # make ablf F=beam D=-DLAS_BEAM_STAMPS S=beamst
+if [ -f automatic-speech-recognition_amd/lib/liblas_hip_rowst.so ]; then    # make ablf F=speller D=-DLAS_ROW_STAMPS S=rowst
+  (LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_rowst.so python3 tools/probe_pf_stamps.py; LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_rowst.so python3 tools/probe_rows4_stamps.py) 2>&1 | grep -v amdgpu > gpurun_out/${P}_rows_phase_stamps.txt
+fi
 python3 tools/probe_decode_stream.py 2>&1 | grep -v amdgpu > gpurun_out/${P}_decode_stream.txt
 # ---- round 5: are small launches on the chain what the profiler says they are?  (prepared sweeps vs self-packing, un-profiled, alternating)
 bash tools/ab_bench.sh LAS_NO_PREPARED_SWEEPS=0 LAS_NO_PREPARED_SWEEPS=1 3 60 > gpurun_out/${P}_ab_prepared.txt 2>&1
