@@ -300,8 +300,8 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     if parts:
         dom = max(parts, key=parts.get)
         byts = {"speller": sp_bytes, "lm": lm_bytes}.get(dom, 0)
-        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> (attention rows) + lstm_cell_rows_kernel<fast, bf16 x> (cell product + gate math); 256 rows",
-                                                          "lm": "lstm_cell_rows_kernel x2 (las_lstm_cell_rows: one launch per LM layer)",
+        roof = {"bound": "hbm", "part": dom, "kernels": {"speller": "dec_step_fwd_pf_kernel<1,10> (attention rows) + lstm_cell_rows_big_kernel<fast, bf16 rows, 32> (cell product + gate math; in the search itself one launch with the LM's first layer: lstm_cell_rows_big_pair_kernel); 256 rows",
+                                                          "lm": "lstm_cell_rows_big_kernel<exact, fp32 rows, 32> (layer 1) + lstm_cell_rows_kernel<exact, fp32> (layer 2): las_lstm_cell_rows, one launch per LM layer",
                                                           "beam": "beam_loop_kernel (both vocabulary projections + ranking + bookkeeping + alignment filing) + beam_gather_kernel"}[dom],
                 "us_per_decode_step": parts[dom], "algorithmic_bytes_per_step": int(byts),
                 "achieved": round(byts / (parts[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
