@@ -297,7 +297,6 @@ extern "C" int las_lstm_pointwise_rows(const float* z, const float* xrows, const
 // TF gate order i, j, f, o = column blocks of H), K = I + H contracted in chunks staged through LDS as bf16, 8 waves = 4 gates x
 // 2 row tiles, gates exchanged through LDS, then c' / h' written directly.  A one-hot first layer passes ids / xrows instead of x.
 // ------------------------------------------------------------------------------------------------
-#include <cstdlib>
 #include "lstm_cell_rows.h"
 
 template <bool FAST, bool XBF>
@@ -337,6 +336,11 @@ static inline int lb_rows_type(const LstmCellLaunch& a) {          // 1 bf16, 0 
     if (xt >= 0 && ht >= 0 && xt != ht) return -1;
     return xt >= 0 ? xt : (ht >= 0 ? ht : 0);
 }
+static int g_lb_rows = 0, g_lb_pair_rows = 0;        // 0: the launcher's choice
+#ifdef LAS_DEV   // development builds only (make prof): A/B switches, not part of the shipping library
+extern "C" void las_dev_lstm_cell_rows(int rows) { g_lb_rows = (rows == 32 || rows == 64 || rows == 128) ? rows : 0; }
+extern "C" void las_dev_lstm_cell_pair_rows(int rows) { g_lb_pair_rows = (rows == 32 || rows == 64 || rows == 128) ? rows : 0; }
+#endif
 static inline bool lb_serves(const LstmCellLaunch& a) { return a.M >= LB_MIN_ROWS && lb_rows_type(a) >= 0; }
 template <typename K>
 static int lb_attr(K kern, int rows) { return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lb_lds_bytes(rows)); }
@@ -386,8 +390,7 @@ int las_lstm_cell_rows_launch(const LstmCellLaunch& a, hipStream_t st) {
     // (fp32 rows at <= 256 rows of x AND h -- the LM's second layer in a 16-utterance search: the unpipelined body's two 512-column chunks beat
     //  eight pipelined 128-column chunks of 32 rows, 8.1 against 9.4 us)
     if (lb_serves(a) && !(a.M <= 256 && lb_rows_type(a) == 0 && a.x && a.h && !a.h_out_bf16)) {
-        static const int force = getenv("LAS_DEV_LB_ROWS") ? atoi(getenv("LAS_DEV_LB_ROWS")) : 0;                // (timing experiments)
-        const int rows = force ? force : lb_rows_for(a.M);
+        const int rows = g_lb_rows ? g_lb_rows : lb_rows_for(a.M);
         return rows == 128 ? lb_launch<128>(a, st) : (rows == 64 ? lb_launch<64>(a, st) : lb_launch<32>(a, st));
     }
     const dim3 grid(a.H / 16, cdiv(a.M, 32));
@@ -407,11 +410,10 @@ int las_lstm_cell_rows_launch2(const LstmCellLaunch& a, const LstmCellLaunch& b,
         return las_lstm_cell_rows_launch(b, st);
     }
     if (lb_serves(a) && lb_rows_type(a) == 1 && lb_serves(b)) {
-        static const int force = getenv("LAS_DEV_LB_PAIR_ROWS") ? atoi(getenv("LAS_DEV_LB_PAIR_ROWS")) : 0;      // (timing experiments)
         // (two problems: 64-row tiles also at 1024 rows -- at 100-120 VGPRs both problems' workgroups share a CU and cover each other's
         //  round trips, 18.1-18.4 against 18.6-18.7 ms per 211-step search; at 128 rows and 140-180 VGPRs they run one behind the other)
         const int mm = a.M > b.M ? a.M : b.M;
-        const int rows = force ? force : (mm > 256 ? 64 : 32);
+        const int rows = g_lb_pair_rows ? g_lb_pair_rows : (mm > 256 ? 64 : 32);
         return rows == 128 ? lb_launch2<128>(a, b, st) : (rows == 64 ? lb_launch2<64>(a, b, st) : lb_launch2<32>(a, b, st));
     }
     const int gx = (a.H > b.H ? a.H : b.H) / 16, gy = cdiv(a.M > b.M ? a.M : b.M, 32);

@@ -216,7 +216,8 @@ def lib():
         # register-transposing kernel instead of the LDS-transposing one
         for env, sym in (("LAS_DEV_KK_BIG", "las_dev_gemm_kk_big"), ("LAS_DEV_ZGROUP", "las_dev_gemm_zgroup"),
                          ("LAS_DEV_TN_TR", "las_dev_gemm_tn_tr"), ("LAS_DEV_F32_VALU", "las_dev_gemm_f32_valu"),
-                         ("LAS_DEV_F32_FAST_LD", "las_dev_gemm_f32_fast_ld")):
+                         ("LAS_DEV_F32_FAST_LD", "las_dev_gemm_f32_fast_ld"), ("LAS_DEV_LB_ROWS", "las_dev_lstm_cell_rows"),
+                         ("LAS_DEV_LB_PAIR_ROWS", "las_dev_lstm_cell_pair_rows")):
             if os.environ.get(env) is not None and hasattr(l, sym):
                 getattr(l, sym)(int(os.environ[env]))
         _lib = l
