@@ -280,7 +280,7 @@ class CharRNN(object):
             plan["swp"] = _hip.skinny_pack(plan["sw"], H, self.vocab_size)
         return plan
 
-    TWIN_MIN_ROWS = 384          # (las_lstm_cell_rows serves bf16 state copies from 128 rows on; below 384 the two extra gather tensors cost what the cells save)
+    TWIN_MIN_ROWS = 384          # (las_lstm_cell_rows serves bf16 state copies from 128 rows on; at 256 rows they measured neutral)
 
     def twins_ok(self, plan, N):
         """True if every layer's step runs through las_lstm_cell_rows at N rows with 128-row workgroups: the cells can then read the

@@ -399,16 +399,20 @@ class BeamSearch(object):
             lm_c = [torch.zeros(N, Hl, device=dev) for _ in range(NLl)]
             lm_h = [torch.zeros(N, Hl, device=dev) for _ in range(NLl)]
             k_lm = len(st_in)
-            for l in range(NLl):
-                st_in += [lm_c[l], lm_h[l]]; st_out += [lm_c[l], lm_h[l]]          # inputs are re-pointed every step
             # bf16 copies of the LM's recurrent state (round 5): from 384 rows on the cells read them -- and the layer below's copy -- instead
             # of converting the fp32 rows while staging them (half the bytes through a CU that is bound by its ingest); the copies follow
-            # their hypotheses through the gather as rows of H / 2 floats.  Bit-identical: the copy is the staging's own rounding.
+            # their hypotheses through the gather as rows of H / 2 floats -- INSTEAD of the fp32 h rows, which nobody reads then (the
+            # projection takes the step's fresh h).  Bit-identical: the copy is the staging's own rounding.
             if self.lm_state_copies and prec == _hip.PREC_BF16 and not self.three_launches and lm.twins_ok(lm_plan, N):
                 lm_hb = [torch.zeros(N, Hl, dtype=torch.bfloat16, device=dev) for _ in range(NLl)]
+                for l in range(NLl):
+                    st_in.append(lm_c[l]); st_out.append(lm_c[l])                  # inputs are re-pointed every step
                 k_tw = len(st_in)
                 for l in range(NLl):
                     st_in.append(lm_hb[l].view(torch.float32)); st_out.append(lm_hb[l].view(torch.float32))
+            else:
+                for l in range(NLl):
+                    st_in += [lm_c[l], lm_h[l]]; st_out += [lm_c[l], lm_h[l]]
         ba = _hip.BeamLoopArgs()
         for name, t in (("logits", logits), ("score", score), ("length", length), ("nlive", nlive), ("nsel", nsel), ("done", done),
                         ("dec_step", dstep), ("step", step), ("hist_parent", hist_parent), ("hist_token", hist_token),
@@ -505,9 +509,10 @@ class BeamSearch(object):
                 tw = {"prev": lm_hb, "layer0": mode.get("lm0_hb") if layer0 is not None else None}
             cs_new, hs_new = lm.step_fused(lm_plan, next_token, lm_c, lm_h, logits, 2, id_shift=2, project=False, layer0=layer0, twins=tw)
             for l in range(NLl):
-                ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
                 if tw is not None:
-                    ba.state_in[k_tw + l] = tw["new"][l].data_ptr()
+                    ba.state_in[k_lm + l], ba.state_in[k_tw + l] = cs_new[l].data_ptr(), tw["new"][l].data_ptr()
+                else:
+                    ba.state_in[k_lm + 2 * l], ba.state_in[k_lm + 2 * l + 1] = cs_new[l].data_ptr(), hs_new[l].data_ptr()
             if tw is not None:
                 cs_new = cs_new + tw["new"]                                       # (kept alive with the rest)
             if mode["fused"]:
