@@ -914,6 +914,9 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
 #ifndef LAS_E8_LATE
 #define LAS_E8_LATE 0
 #endif
+#ifndef LAS_E8_BEHIND_LOOP
+#define LAS_E8_BEHIND_LOOP 1      // the loop kernels' streamed encoder slabs are requested behind the query reduction too (bench_fused: 10.2-10.4 -> 10.0-10.1 us per forward step)
+#endif
 #ifndef LAS_E8_EARLY
 #define LAS_E8_EARLY 0      // (the streamed slabs requested at the head of the step instead of behind the query projection: 10.2 vs 10.0 us, 6 spilled VGPRs)
 #endif
@@ -1122,7 +1125,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     // The per-step kernel (!LOOP: a beam search's 256 rows on 256 CUs at once, not a training batch's 48) requests them BEHIND the
     // reduction: with every CU of the chip asking for its 164 KB at the same moment the reducing waves waited 4.6 us behind the requests
     // (r5 stamps, tools/probe_pf_stamps.py); the rows then land under the energies.
-    constexpr bool E8_BEHIND = !LOOP && NEL == 0 && !LAS_E8_LATE;
+    constexpr bool E8_BEHIND = ((!LOOP && NEL == 0) || (LOOP && LAS_E8_BEHIND_LOOP)) && !LAS_E8_LATE;
     if (!E8_BEHIND && !LAS_E8_LATE && (NEL == 0 || !LAS_E8_EARLY)) {
 #pragma unroll
         for (int u = NEL; u < NE; ++u) e8_load(u);
