@@ -420,9 +420,23 @@ __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
-__device__ __forceinline__ float sub16_sum(float v) {  // sum over a 16-lane group
+// sum over a 16-lane group (a DPP row), in every lane.  Row rotations by 8, 4, 2, 1 on the VALU's data-parallel path instead of four
+// __shfl_xor = four ds_bpermute round trips through the LDS queue (a dependent chain of ~100-cycle operations at the end of every frame group
+// of the energies): BIT-identical to the xor butterfly -- after the step with distance d every lane equals its partner at distance d
+// (a + b == b + a), so the value a rotation by d / 2 brings is the value the xor partner holds.
+#ifndef LAS_SUB16_DPP
+#define LAS_SUB16_DPP 1
+#endif
+__device__ __forceinline__ float sub16_sum(float v) {
+#if LAS_SUB16_DPP
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));     // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));     // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));     // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));     // row_ror:1
+#else
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+#endif
     return v;
 }
 // the speed mode's operand copies in one launch: job y = plain bf16 copy of n elements (R == 0) or row-pair interleaved copy of
