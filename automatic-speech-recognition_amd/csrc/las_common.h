@@ -93,14 +93,23 @@ template <bool FAST> __device__ __forceinline__ float sigm(float x) { return FAS
 template <bool FAST> __device__ __forceinline__ float tanhx(float x) { return FAST ? tanh_fast(x) : tanh_acc(x); }
 
 // ---- wave / block reductions (wave = 64) --------------------------------------------------------
+// a lane's value through the VALU's data-parallel path (DPP) instead of a ds_bpermute round trip through the LDS queue: row rotations
+// (0x120 + n: lane i of a 16-lane row reads lane (i + n) % 16) and quad permutations (four 2-bit selectors)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1>(v); }       // quad_perm [1,0,3,2] == __shfl_xor(v, 1)
+// The xor butterfly's steps 32 and 16 cross the rows (ds_bpermute); after them the four rows hold the same 16 values, and the steps 8, 4,
+// 2, 1 are row rotations: after the step with distance d every lane equals its partner at distance d (a op b == b op a), so what a
+// rotation by d / 2 brings is what the xor partner holds -- bit-identical to the all-xor form, four LDS round trips fewer.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);
+    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); v = fmaxf(v, dpp_f<0x121>(v));
     return v;
 }
 // block-wide sum for blockDim.x == NT (multiple of 64); red must hold NT/64 floats. All threads get the result.

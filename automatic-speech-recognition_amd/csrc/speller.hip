@@ -915,7 +915,8 @@ __device__ __forceinline__ float2 h22f(unsigned u) { const h16x2_t v = __builtin
 // four adjacent lanes (columns col .. col+3, col % 4 == 0 in the first) -> one granule of 4 bf16
 __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const size_t row_gran, const int col, const float v, const unsigned tag,
                                           const bool local) {
-    const float v1 = __shfl_down(v, 1, 64), v2 = __shfl_down(v, 2, 64), v3 = __shfl_down(v, 3, 64);
+    // (every caller's col is tid + a multiple of 4: the four lanes are one DPP quad; quad_perm [1,2,3,3] / [2,3,3,3] / [3,3,3,3])
+    const float v1 = dpp_f<0xF9>(v), v2 = dpp_f<0xFE>(v), v3 = dpp_f<0xFF>(v);
     if (!(col & 3)) granule16_store(rs, (unsigned)((row_gran + (col >> 2)) * 16), tag, f2bf2(v, v1), f2bf2(v2, v3), local);
 }
 // Where the row kernels issue the bulk loads that are consumed two phases later (measured with tools/micro/bench_fused.hip,
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             }
             a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid] = h;
         }
-        const float hn = __shfl_xor(h, 1, 64);
+        const float hn = lane_xor1(h);
         if (tid < D) {
             L.s_state[tid] = h;
             if (!(tid & 1)) sp[tid >> 1] = f2bf2(h, (tid + 1 < D) ? hn : 0.f);
@@ -1357,7 +1358,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {        // the states entering the step (hs slot 0: keep_state0)
         const float h = tid < D ? s0[r] : 0.f;
-        const float hn = __shfl_xor(h, 1, 64);
+        const float hn = lane_xor1(h);
         if (tid < D) {
             s_state[r * SD + tid] = h;
             if (!(tid & 1)) sp[r * SS + (tid >> 1)] = f2bf2(h, (tid + 1 < D) ? hn : 0.f);
@@ -1630,7 +1631,7 @@ __device__ __forceinline__ void loop_product(const LoopProd& p, const int U, con
             const int ct = j * TPW + tl, col = ct * 16 + c16, orow = r16 * 8 + x;
             const bool valid = r16 < Rx && ct < p.nct && col < p.N;
             if (!(LAS_ABL_SP & 4) && p.bias && valid) v += p.bias[col];
-            const float nb = __shfl_xor(v, 1, 64);
+            const float nb = lane_xor1(v);
             if (valid) {
                 if (p.C && !(LAS_ABL_SP & 64)) p.C[(long long)step * p.c_step + (long long)orow * p.ldc + col] = v;
                 if (!(c16 & 1))
@@ -2621,7 +2622,7 @@ __device__ __forceinline__ void pf_bwd_row(const DecDev& a, const int t_att, con
 #pragma unroll
                 for (int w = 0; w < RNW; ++w) sacc += L.scr[w * 2 * A + tid];
             }
-            const float nb = __shfl_xor(sacc, 1, 64);
+            const float nb = lane_xor1(sacc);
             if (tid < A) {
                 a.dQ[((size_t)t * B + b) * A + tid] = sacc;
                 if (!(tid & 1)) dqp[tid >> 1] = f2bf2(sacc, nb);
