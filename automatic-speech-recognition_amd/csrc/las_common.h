@@ -99,16 +99,35 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_f<0xB1>(v); }       // quad_perm [1,0,3,2] == __shfl_xor(v, 1)
-// The xor butterfly's steps 32 and 16 cross the rows (ds_bpermute); after them the four rows hold the same 16 values, and the steps 8, 4,
+// v[i] + v[i ^ 32] / v[i ^ 16] in every lane without the LDS: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half (the odd
+// rows) of one register with the lower half (the even rows) of another -- of two copies of v that leaves (lower, lower) and (upper, upper),
+// whose sum is the xor step's sum in every lane (a + b == b + a): bit-identical to v + __shfl_xor(v, 32 / 16)
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// The xor butterfly's steps 32 and 16 cross the rows (lane swaps, below); after them the four rows hold the same 16 values, and the steps 8, 4,
 // 2, 1 are row rotations: after the step with distance d every lane equals its partner at distance d (a op b == b op a), so what a
 // rotation by d / 2 brings is what the xor partner holds -- bit-identical to the all-xor form, four LDS round trips fewer.
 __device__ __forceinline__ float wave_sum(float v) {
-    v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);
+    v = xor32_sum(v); v = xor16_sum(v);
     v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = xor32_max(v); v = xor16_max(v);
     v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); v = fmaxf(v, dpp_f<0x121>(v));
     return v;
 }

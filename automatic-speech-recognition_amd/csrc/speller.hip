@@ -743,8 +743,8 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {          // the 4 k-groups of this wave
-                acc[e] += __shfl_xor(acc[e], 16, 64);
-                acc[e] += __shfl_xor(acc[e], 32, 64);
+                acc[e] = xor16_sum(acc[e]);
+                acc[e] = xor32_sum(acc[e]);
             }
             if (lane < 16) {
                 float4* o = reinterpret_cast<float4*>(L.scr + wv * A + a0 * 8);
@@ -1126,7 +1126,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             acc[2] = dot2bf(w8[u].z, s2, acc[2]); acc[3] = dot2bf(w8[u].w, s2, acc[3]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], 32, 64);
+        for (int e = 0; e < 4; ++e) acc[e] = xor32_sum(acc[e]);
         if (lane < 32 && a4 < A4) reinterpret_cast<float4*>(L.scr + wv * A)[a4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     lds_barrier();
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[r][e] += __shfl_xor(acc[r][e], 32, 64);
+            for (int e = 0; e < 4; ++e) acc[r][e] = xor32_sum(acc[r][e]);
             if (lane < 32 && a4 < A4) reinterpret_cast<float4*>(scr + ((size_t)r * RNW + wv) * A)[a4] = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
         }
     }
@@ -2206,8 +2206,8 @@ __global__ __launch_bounds__(RNT) void dec_step_bwd_bf_kernel(DecDev a, int t_at
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = dq_acc[j][e], w = du_acc[j][e];
-                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                w += __shfl_xor(w, 16, 64); w += __shfl_xor(w, 32, 64);
+                v = xor16_sum(v); v = xor32_sum(v);
+                w = xor16_sum(w); w = xor32_sum(w);
                 if (lane < 16 && a0 < A8) {
                     L.scr[wv * 2 * A + a0 * 8 + e] = v;
                     L.scr[wv * 2 * A + A + a0 * 8 + e] = w;
