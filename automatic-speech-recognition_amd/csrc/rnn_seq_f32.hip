@@ -207,14 +207,14 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_fwd_mf32_kernel(RnnArgs a) {
             // publish: the thread of unit position j with (j & 4) == 0 carries units j and j + 4 of its row (lane + 4 holds the other)
             const unsigned slot_off = (unsigned)((s & 1) * P) * GPM * 16u, tag = (unsigned)(s + 1);
             if (CELL == LAS_CELL_LSTM) {
-                const float hn = __shfl_down(hv[0], 4, 64);
+                const float hn = dpp_f<0x104>(hv[0]);                       // row_shl:4 -- lane i reads lane i + 4 of its row (no LDS round trip)
                 if (!(ej & 4))
                     granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (ej >> 3) * 64 + (ej & 3) * 16 + er) * 16u, tag,
                                     __float_as_uint(hv[0]), __float_as_uint(hn), local);
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const float hn = __shfl_down(hv[nt], 4, 64);
+                    const float hn = dpp_f<0x104>(hv[nt]);
                     if (!(ej & 4))
                         granule16_store(xrs, slot_off + (unsigned)(pm * GPM + (nt * 2 + (ej >> 3)) * 64 + (ej & 3) * 16 + er) * 16u, tag,
                                         __float_as_uint(hv[nt]), __float_as_uint(hn), local);
@@ -430,7 +430,9 @@ __global__ __launch_bounds__(256, 1) void rnn_seq_bwd_mf32_kernel(RnnArgs a) {
         for (int q = 0; q < TPM; ++q) {
             // this thread's row: even rows are the granules' first value.  partner lane = the other row of the pair (tid ^ 16)
             const float mine = (er & 1) ? sb[q] : sa[q], give = (er & 1) ? sa[q] : sb[q];
-            const float got = __shfl_xor(give, 16, 64);
+            // the partner row's value without the LDS: of two copies of `give`, v_permlane16_swap leaves (even rows, even rows) and (odd rows, odd rows)
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(give), __float_as_uint(give), false, false);
+            const float got = __uint_as_float((threadIdx.x & 16) ? sw[0] : sw[1]);
             const float se = (er & 1) ? got : mine, so = (er & 1) ? mine : got;     // even-position partners' sum, odd-position partners' sum
             dhr[q] = own[(q * 4 + (er & 3)) * PT + (er >> 2) * 16 + ej] + (se + so);
         }
