@@ -157,9 +157,9 @@ __device__ __forceinline__ void row_logits(const DecDev& a, const float* __restr
     if (tid == 0) a.tok_out[(size_t)(t - 1) * B + b] = greedy_tok;
 }
 
-__device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane half-wave
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float sub32_sum(float v) {  // sum over a 32-lane half-wave: the xor butterfly 16, 8, 4, 2, 1 without the LDS (las_common.h)
+    v = xor16_sum(v);
+    v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);
     return v;
 }
 
