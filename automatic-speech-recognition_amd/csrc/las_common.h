@@ -110,6 +110,16 @@ __device__ __forceinline__ float xor16_sum(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// the xor partner's value itself (not a combination): of the swap's two results one is the lane's own half, the other the partner's
+__device__ __forceinline__ unsigned xor32_get(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xor16_get(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16) ? r[0] : r[1];
+}
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ float xor32_max(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));

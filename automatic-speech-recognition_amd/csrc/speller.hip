@@ -101,12 +101,15 @@ __device__ __forceinline__ float gumbel_noise(unsigned long long seed, int t, in
 
 // argmax with first-index tie-break across the block; all threads receive the index
 __device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* redi) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    // the 64-lane butterfly 32, 16, 8, 4, 2, 1 without the LDS: lane swaps for the cross-row steps, row rotations for the rest (the combine
+    // is symmetric -- both partners keep the same (value, index) -- so a rotation by d / 2 brings what the xor partner at distance d / 2 holds)
+    auto take = [&](const float ov, const int oi) { if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } };
+    { const float ov = __uint_as_float(xor32_get(__float_as_uint(v))); const int oi = (int)xor32_get((unsigned)i); take(ov, oi); }
+    { const float ov = __uint_as_float(xor16_get(__float_as_uint(v))); const int oi = (int)xor16_get((unsigned)i); take(ov, oi); }
+    { const float ov = dpp_f<0x128>(v); const int oi = (int)dpp_u<0x128>((unsigned)i); take(ov, oi); }
+    { const float ov = dpp_f<0x124>(v); const int oi = (int)dpp_u<0x124>((unsigned)i); take(ov, oi); }
+    { const float ov = dpp_f<0x122>(v); const int oi = (int)dpp_u<0x122>((unsigned)i); take(ov, oi); }
+    { const float ov = dpp_f<0x121>(v); const int oi = (int)dpp_u<0x121>((unsigned)i); take(ov, oi); }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = i; }
     __syncthreads();
@@ -135,7 +138,11 @@ __device__ __forceinline__ void row_logits(const DecDev& a, const float* __restr
         const int v = tid / tpv, part = tid - v * tpv, vc = v < V ? v : V - 1;
         float acc = 0.f;
         for (int d = part; d < D; d += tpv) acc = fmaf(opnd<FAST>(h[d]), opnd<FAST>(a.Wv[(size_t)d * V + vc]), acc);
-        for (int o = tpv >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (tpv == 16) {       // (char vocabularies at 1024 threads: a 16-lane group = a DPP row, the butterfly 8, 4, 2, 1 as row rotations -- sub16_sum)
+            acc += dpp_f<0x128>(acc); acc += dpp_f<0x124>(acc); acc += dpp_f<0x122>(acc); acc += dpp_f<0x121>(acc);
+        } else {
+            for (int o = tpv >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        }
         if (part == 0 && v < V) {
             acc += a.bv[v];
             lrow[v] = acc;
