@@ -3186,6 +3186,9 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
 
 #define GEMM_OK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
+static thread_local int g_last_variant[2] = {0, 0};
+extern "C" int las_speller_last_variant(int which) { return g_last_variant[which ? 1 : 0]; }
+
 // speed mode, additive attention: the row kernels read bf16 copies of Ws / keys / encoder rows (made once per call)
 static bool bf_rows_ok(const DecDev& d) {
     return !(d.flags & LAS_SPELLER_NO_BF_ROWS) && d.mode == LAS_ATT_ADD && (d.A % 8) == 0 && (d.Hd % 8) == 0 && d.A <= 256;
@@ -3309,6 +3312,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
             if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)f->act_save + act_save_f_offset(U, B, d.Tp, d.A));
         } else LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
     }
+    g_last_variant[0] = (loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
+                        (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (d.mode == LAS_ATT_LOC ? LAS_SPELLER_RAN_LOC : 0);
     if (d.flags & LAS_SPELLER_NO_LOGITS)
         LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
                 "speller: LAS_SPELLER_NO_LOGITS needs U = 1, one LSTM layer, speed mode with the prefetching row kernels, D and E + Hd + D multiples of 32");
@@ -3455,6 +3460,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     // feeds granules to the rows, which is what makes the single-buffered exchange safe); the embedding columns of dXin0 are
     // one tall contraction after the loop (part 2)
     const bool loop = locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B));
+    if (part & 1)
+        g_last_variant[1] = (loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
+                            (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (loc ? LAS_SPELLER_RAN_LOC : 0);
     if ((loop || pf) && bk->f.act_save) {   // (the rows check the header: only what a forward of the same family left is used)
         d.actS = (unsigned*)bk->f.act_save;
         if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)bk->f.act_save + act_save_f_offset(U, B, Tp, A));   // f of every step: kept by the forward rows, or recomputed into the same place

@@ -128,6 +128,7 @@ _SIGS = {
     "las_speller_fwd": (c_int, [POINTER(SpellerFwdArgs), c_void_p]),
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
     "las_speller_bwd_part": (c_int, [POINTER(SpellerBwdArgs), c_int, c_void_p]),
+    "las_speller_last_variant": (c_int, [c_int]),
     "las_ce_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "las_ce_loss": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -182,7 +183,7 @@ _SIGS = {
 }
 
 
-ABI_VERSION = 500      # include/las_hip.h LAS_HIP_ABI_VERSION
+ABI_VERSION = 600      # include/las_hip.h LAS_HIP_ABI_VERSION
 
 
 def declared_symbols():
@@ -905,3 +906,17 @@ def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
                                        c_void_p(whh_bw.data_ptr() + 4 * wb_off), ldw, p(out), ld_out, out_bstride,
                                        p(cstate), p(dout), ld_dout, dout_bstride, forget_bias, p(db_fw), p(db_bw),
                                        fl, p(status_word(gates.device)), p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db")
+
+
+SPELLER_FAMILIES = ((1, "loop"), (2, "pf_rows"), (4, "bf_rows"), (8, "f32_rows"), (16, "skinny_cell0"), (32, "loc"), (64, "skinny_upper_cells"))
+
+
+def speller_last_variant():
+    """{'fwd': [...], 'bwd': [...]}: the kernel families that served this thread's last las_speller_fwd / las_speller_bwd_part(1)
+    (las_speller_last_variant; bench.py and the tests name the family a number or a parity statement belongs to)."""
+    l = lib()
+    out = {}
+    for name, which in (("fwd", 0), ("bwd", 1)):
+        m = int(l.las_speller_last_variant(which))
+        out[name] = [n for bit, n in SPELLER_FAMILIES if m & bit]
+    return out

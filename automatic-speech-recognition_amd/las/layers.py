@@ -388,10 +388,20 @@ def _prepare_sweeps(st):
         jobs.append((r["cell"], r["H"], B, key[-1], r["wf"], r["wb"], r["ldw"], r["off"], r["off"], r["ws"]))
     # on the side stream, ordered behind the START of the step (= behind the optimiser step that changed the weights), beside the step's
     # head on the launch stream: ~65 MB of packs and clears that nothing on the chain waits for until the first sweep
-    ev = _STEP_START[0]
+    # (the event only orders the prepare behind the weight change of the epoch it was recorded in.  A step whose own
+    #  begin_step event was never consumed -- a store's first step builds its shadows one by one -- leaves it behind; a request from
+    #  OUTSIDE a train step (eval or decode right after that step) must not use it: the prepare would pack W_hh in front of
+    #  las_clip_adam.  A stale or missing event is replaced by one recorded NOW on the launch stream, i.e. behind the optimiser.)
+    ev, epoch = _STEP_START[0] if _STEP_START[0] is not None else (None, -1)
     _STEP_START[0] = None
-    if ev is not None and _hip.streams_overlap(jobs[0][4].device):
+    if _hip.streams_overlap(jobs[0][4].device):
+        if ev is None or epoch != st.weights_epoch:
+            ev = torch.cuda.Event()
+            ev.record()
+            VARIANTS["prepare_behind_now"] += 1
         with _hip.on_side_stream(after=ev):
+            for j in jobs:
+                j[-1].record_stream(_hip.side_stream())       # (allocated on the launch stream, written here)
             _hip.rnn_seq_prepare(jobs)
             st.seq_prep_done = torch.cuda.Event()
             st.seq_prep_done.record()
@@ -474,7 +484,7 @@ def _flag_ring(dev):
 # tool that serialises kernels -- the same kernel instances, nothing overlapped).  Tests and bench.py assert / print it: the variant
 # that is timed must be the variant that is tested.
 VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side": 0, "sweeps_fwd": 0, "sweeps_bwd": 0, "serial": 0, "flag_fills": 0,
-            "prepared_sweeps": 0, "tail_windows": 0, "tail_follow": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
+            "prepared_sweeps": 0, "tail_windows": 0, "tail_follow": 0, "prepare_behind_now": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
 
 
 def begin_step(dev):
@@ -487,8 +497,9 @@ def begin_step(dev):
     ring = _flag_ring(dev)
     ring[0].zero_()
     ring[1], ring[2], ring[3] = 0, _RING, True
-    _STEP_START[0] = torch.cuda.Event()
-    _STEP_START[0].record()
+    ev = torch.cuda.Event()
+    ev.record()
+    _STEP_START[0] = (ev, V.default_store().weights_epoch)
 
 
 def _k64(k):

@@ -33,11 +33,17 @@ class VariableStore:
         self.seq_recipes = {}     # (W_hh pointers, cell, H, pass) -> how to prepare that sweep's workspace (las.layers._prepare_sweeps)
         self.seq_ready = {}       # ... -> batch rows it has been prepared for since the weights last changed (consumed by ONE sweep)
         self.seq_prep_done = None  # event behind the side-stream prepare launch until the launch stream has waited for it
+        self.weights_epoch = 0    # counts weights_changed() calls: an ordering event is only good for the epoch it was recorded in
 
     def weights_changed(self, storage_moved=False):
         """Everything derived from the parameter VALUES is stale (optimiser step, load); storage_moved: their addresses too (flatten)."""
+        self.weights_epoch += 1
         self.shadows.clear()
         self.seq_ready.clear()
+        if self.seq_prep_done is not None and storage_moved:
+            # a side-stream prepare may still be writing the workspaces that are dropped below: the launch stream (whose later
+            # allocations may reuse those blocks) waits for it first
+            torch.cuda.current_stream().wait_event(self.seq_prep_done)
         self.seq_prep_done = None
         if storage_moved:
             self.shadow_recipes.clear()

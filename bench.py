@@ -52,6 +52,12 @@ def bench_args(cell, config=1):
               scheduled_sampling=True, vocab_size=30)
     if config == 3:
         kw.update(mode="loc", loc_kernel_size=201, loc_num_channels=10, vocab_size=5000, unit="subword")
+    if config == "run_sh":
+        # the reference's own recipe (run.sh:59-76 + the defaults it leaves alone, las/arguments.py:109-137): CNN listener with four
+        # BLSTM-512, location-aware attention K = 201 / C = 10, two 1024-unit decoder cells, subword vocabulary
+        kw.update(enc_type="cnn", enc_units=512, num_enc_layers=4, num_enc_channels=32, dec_units=1024, num_dec_layers=2,
+                  embedding_size=256, attention_size=128, mode="loc", loc_kernel_size=201, loc_num_channels=10, vocab_size=5000,
+                  unit="subword", lr=1e-4, scheduled_sampling=False)
     return make_args(**kw)
 
 
@@ -398,7 +404,7 @@ def train_loop_bench(las, dev, a, value, steps=20, warmup=4):
     return out
 
 
-def side_step_bench(dev, cell, dtype, config, B, T, steps=5, warmup=2, stack=1, seed=0):
+def side_step_bench(dev, cell, dtype, config, B, T, steps=5, warmup=2, stack=1, seed=0, global_step=None):
     """ms per train step of ANOTHER configuration than the headline's, reported beside it (same protocol: synthetic batch resident in
     HBM, warm-up, timed steps between synchronisations).  stack = k: k bucket batches of B rows as one step (LAS.train_stacked)."""
     from helpers import synthetic_batch
@@ -420,9 +426,14 @@ def side_step_bench(dev, cell, dtype, config, B, T, steps=5, warmup=2, stack=1, 
         y = torch.cat([torch.nn.functional.pad(b[1][0], (0, W - b[1][0].shape[1])) for b in batches], 0)
         batches = [((audio, np.concatenate([b[0][1] for b in batches])), (y, np.concatenate([b[1][1] for b in batches])))]
     xs, ys = batches[0]
+    st = V.default_store()
+    if global_step is not None:                          # scheduled sampling ACTIVE: the schedule reads the global step (las/las.py:177-183)
+        st.global_step = global_step
     for _ in range(warmup):
         las.train(xs, ys)
     torch.cuda.synchronize()
+    if global_step is not None:
+        st.global_step = global_step
     t0 = time.perf_counter()
     for _ in range(steps):
         las.train(xs, ys)
@@ -430,8 +441,26 @@ def side_step_bench(dev, cell, dtype, config, B, T, steps=5, warmup=2, stack=1, 
     dt = time.perf_counter() - t0
     las.check_status()
     n = int(xs[0].shape[0])
-    return {"cell": cell, "dtype": dtype, "rows": n, "frames": T, "dec_steps": int(ys[1].max()), "ms_per_step": round(dt / steps * 1e3, 3),
-            "value": round(n * steps / dt, 1), "unit": "utterances/s", "steps": steps, "schedule": dict(las.last_variants)}
+    out = {"cell": cell, "dtype": dtype, "rows": n, "frames": T, "dec_steps": int(ys[1].max()), "ms_per_step": round(dt / steps * 1e3, 3),
+           "value": round(n * steps / dt, 1), "unit": "utterances/s", "steps": steps, "schedule": dict(las.last_variants)}
+    if global_step is not None:
+        tok = las.speller.last_tokens_in
+        out["teacher_forcing_rate"] = round(float(las.speller._scheduled_sampling(global_step)), 4)
+        out["global_step"] = int(global_step)
+        out["sampled_steps_last"] = int((tok[1:, 0] != ys[0][0, :tok.shape[0] - 1].to(tok.dtype)).sum()) if tok is not None else None
+    sv = _hip_speller_variant()
+    if sv is not None:
+        out["speller_kernels"] = sv
+    return out
+
+
+def _hip_speller_variant():
+    """Which kernel family served the Speller of the last step (las_speller_last_variant: a bit mask the library keeps per call)."""
+    try:
+        from las import _hip
+        return _hip.speller_last_variant()
+    except Exception:
+        return None
 
 
 def side_legs(dev, a, value):
@@ -452,6 +481,25 @@ def side_legs(dev, a, value):
     leg("config3", lambda: dict(side_step_bench(dev, a.cell, a.dtype, 3, B, T), workload="BASELINE configs[3], one rank: V=5000, location-aware K=201 C=10"))
     leg("cell_rnn", lambda: {"bf16": side_step_bench(dev, "rnn", "bf16", 1, B, T), "f32": side_step_bench(dev, "rnn", "f32", 1, B, T, steps=3, warmup=1),
                              "note": "BasicRNNCell recurrences (the reference as written); the headline is BasicLSTMCell, as BASELINE.json's north star names"})
+
+    def run_sh():
+        r = {"workload": "the reference's recipe run.sh:59-76: --enc_type cnn (default) --enc_units 512 --num_enc_layers 4 --dec_units 1024 "
+                         "--num_dec_layers 2 --embedding_size 256 --attention_size 128 --mode loc (K=201, C=10), V=5000; bucket B=%d T=%d (T'=319)" % (B, T)}
+        r["rnn"] = side_step_bench(dev, "rnn", a.dtype, "run_sh", B, T)      # BasicRNNCell: what las/las.py:191-199 builds
+        r["lstm"] = side_step_bench(dev, "lstm", a.dtype, "run_sh", B, T)
+        r["ms_per_step"] = r["rnn"]["ms_per_step"]
+        return r
+    leg("run_sh", run_sh)
+
+    def sampling():
+        args0 = bench_args(a.cell)
+        mid = (args0.warmup_step + args0.max_step) // 2
+        r = dict(side_step_bench(dev, a.cell, a.dtype, 1, B, T, steps=10, warmup=3, global_step=mid),
+                 workload="BASELINE configs[2] on one rank with scheduled sampling ACTIVE: the global step set into the middle of the linear decay "
+                          "(las/las.py:177-183), so that a share of the decode steps draw their input token on the device (in-loop logits + Gumbel arg-max)")
+        r["vs_teacher_forcing"] = round(r["ms_per_step"] / (1e3 * B / value), 3)
+        return r
+    leg("config2_sampling", sampling)
 
     def stacked():
         r = {}
@@ -527,6 +575,8 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--frames", type=int, default=1274)
     ap.add_argument("--config", type=int, default=1, choices=[1, 3], help="BASELINE.json configs[] index (1 = headline, 3 = subword + location-aware)")
+    ap.add_argument("--only-leg", default=None, choices=["run_sh", "run_sh_rnn", "run_sh_lstm", "config2_sampling"],
+                    help="run ONE side leg alone and print its JSON object (for rocprofv3 kernel traces of that leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-train-loop", action="store_true")
@@ -580,6 +630,18 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         dp = DataParallel()
 
+    if a.only_leg:
+        if a.only_leg.startswith("run_sh"):
+            cells = ("rnn", "lstm") if a.only_leg == "run_sh" else (a.only_leg.split("_")[-1],)
+            out = {c: side_step_bench(dev, c, a.dtype, "run_sh", a.batch, a.frames, steps=a.steps, warmup=a.warmup) for c in cells}
+        else:
+            args0 = bench_args(a.cell)
+            out = side_step_bench(dev, a.cell, a.dtype, 1, a.batch, a.frames, steps=a.steps, warmup=a.warmup,
+                                  global_step=(args0.warmup_step + args0.max_step) // 2)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({a.only_leg: out}), flush=True)
+        return
     if a.decode_only:
         out = decode_bench(dev, a.cell, a.dtype)
         sys.stdout.flush()

@@ -37,7 +37,7 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
 enum { LAS_ATT_ADD = 0, LAS_ATT_LOC = 1 };      /* las/las.py:44-49 */
 enum { LAS_DT_F32 = 0, LAS_DT_BF16 = 1 };       /* element type of a tensor in HBM (see las_gemm_kk) */
 
-#define LAS_HIP_ABI_VERSION 500      /* bumped whenever an argument struct or a signature changes: las_version() of a library
+#define LAS_HIP_ABI_VERSION 600      /* bumped whenever an argument struct or a signature changes: las_version() of a library
                                         built from another header differs, and the Python loader refuses it */
 int         las_version(void);
 const char* las_last_error(void);
@@ -374,6 +374,17 @@ int las_speller_bwd(const las_speller_bwd_args* a, void* stream);
  *   part 2 = every parameter gradient (reads what part 1 left in `ws`, `gates`, `xin0`, `hs`; may run on another
  *            stream ordered after part 1);   part 3 = both (= las_speller_bwd). */
 int las_speller_bwd_part(const las_speller_bwd_args* a, int part, void* stream);
+/* Which kernel family served the calling thread's LAST las_speller_fwd (which = 0) / las_speller_bwd* part 1 (which = 1): a bit mask.  The
+ * reference has ONE Speller graph (las/las.py:72-160); this library picks among several kernel families by geometry, and a caller (bench.py,
+ * the tests) must be able to say which one a number or a parity statement belongs to. */
+enum { LAS_SPELLER_RAN_LOOP = 1,       /* the whole decode / gradient loop in one launch (dec_loop_*_kernel) */
+       LAS_SPELLER_RAN_PF_ROWS = 2,    /* per-step launches, prefetching bf16 row kernels */
+       LAS_SPELLER_RAN_BF_ROWS = 4,    /* per-step launches, generic bf16 row kernels */
+       LAS_SPELLER_RAN_F32_ROWS = 8,   /* per-step launches, fp32-operand row kernels (parity mode; speed mode outside the other families' geometry) */
+       LAS_SPELLER_RAN_SKINNY = 16,    /* layer 0's per-step cell product: pre-packed bf16 MFMA fragments (las_skinny_gemm_bf16) */
+       LAS_SPELLER_RAN_LOC = 32,       /* location-aware attention */
+       LAS_SPELLER_RAN_UPPER_SKINNY = 64 };  /* layers >= 1: per-step cell products on pre-packed bf16 fragments (round 6) */
+int las_speller_last_variant(int which);
 
 /* ------------------------------------------------------------------------------------------
  * K8  LAS._get_loss (las/las.py:320-333) + label_smoothing (las/utils.py:5-12), forward and

@@ -227,8 +227,15 @@ def _oracle_fns(xs, p0, args, cell, lm, hoist=True):
     NL = args.num_dec_layers
     po = O.to_torch(p0)
     with torch.no_grad():
-        x = torch.tensor(xs[0]).reshape(1, -1, 39)
-        h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)
+        if str(args.enc_type).lower() == "cnn":
+            # inference: every batch normalisation reads its moving statistics (a fresh model: mean 0, variance 1)
+            class _Fresh(dict):
+                def __missing__(self, k):
+                    return torch.tensor(1.0 if k.endswith("moving_variance") else 0.0)
+            h, el = O.cnn_listener(torch.tensor(xs[0]), xs[1], po, args, cell, False, buffers=_Fresh())
+        else:
+            x = torch.tensor(xs[0]).reshape(1, -1, 39)
+            h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)
         keys = O.project_keys(h, po)                  # (f32 mode: h @ Wh)
         emb = po["embedding/embedding_matrix"]
 

@@ -130,3 +130,30 @@ def test_bench_architecture_full_T_with_scheduled_sampling_bf16():
     assert errs["logits"] < 4e-3 and errs["alphas"] < 1e-3                  # measured r2: 4.6e-4 / 2.1e-5 / 7.6e-4
     for n, e in ge.items():
         assert e < 5e-3, (n, e)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_config3_location_aware_full_T_full_U(prec):
+    """the location-aware loops were oracle-checked for at most 12 decode steps; the timed configs[3] leg runs
+    U = 191, where alpha_{t-1} feeds the conv of every following step (las/layers.py:295-296).  BASELINE configs[3] at B = 4, T = 1274,
+    the whole label length (U ~ 190), V = 5000, K = 201 / C = 10 -- the one-launch LOC loop kernels in speed mode, the per-step rows in
+    parity mode -- with the tolerances of the additive full-T rows."""
+    V = 5000
+    args = bench_arch(mode="loc", loc_kernel_size=201, loc_num_channels=10, vocab_size=V, unit="subword")
+    xs, ys = synthetic_batch(4, 1274, 256, V, seed=31, min_frac=0.834)
+    U = int(ys[1].max())
+    assert 150 < U <= 200
+    r = train_step_pair(args, "lstm", prec, xs, ys, seed=5)
+    assert r["alphas"].shape[-1] == 160 and r["logits"].shape[-1] == V
+    tol = FULL_T_TOL[(prec, "lstm")]
+    errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(), alphas=(r["alphas"] - r["alphas_o"]).abs().max().item(),
+                loss=abs(r["loss"] - r["loss_o"]) / max(1.0, abs(r["loss_o"])))
+    ge = grad_errors(r)
+    worst = max(ge, key=ge.get)
+    _log("config3_full_T_full_U", dict(prec=prec, cell="lstm", B=4, T=1274, U=U, worst_grad=worst, worst_grad_err=ge[worst], **errs))
+    print("configs[3] full T / full U %s: logits %.2e alphas %.2e loss %.2e worst grad %s %.2e" % (
+        prec, errs["logits"], errs["alphas"], errs["loss"], worst, ge[worst]))
+    for k, v in errs.items():
+        assert v < tol[k], (k, v)
+    for n, e in ge.items():
+        assert e < tol["grad"], (n, e)

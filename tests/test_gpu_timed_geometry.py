@@ -158,3 +158,42 @@ def test_three_b48_steps_are_bit_reproducible_and_independent_of_the_hand_overs(
     # after three Adam steps (lr 1e-3, sign-like updates of near-zero gradients) parameters may differ by a few lr at most
     assert (f1 - f3).abs().max().item() <= 6.5e-3
     assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(l1, l3)), (l1, l3)
+
+
+def test_train_eval_train_uses_the_updated_recurrent_weights():
+    """a store's FIRST train step builds its shadows one by one and leaves the begin_step event unconsumed; an
+    inference right after it (outside any train step) triggers las_rnn_seq_prepare on the side stream -- which must be ordered behind
+    las_clip_adam, not behind that stale event, or the next step's eight sweeps run on W_hh packs made from the weights of BEFORE the
+    update.  The sequence train -> inference -> train -> train must equal, bit for bit, the same sequence with every sweep packing
+    for itself (PREPARED_SWEEPS off), at a small geometry (the hazard is in the host logic, not in the size)."""
+    from las import layers as L
+    from oracle import las_oracle as O
+    args = bench_arch()
+    xs, ys = synthetic_batch(8, 320, 40, 30, seed=5, min_frac=0.9)
+    p0 = O.init_params(args, seed=4, cell="lstm")
+
+    def run(prepared):
+        saved = L.PREPARED_SWEEPS
+        L.PREPARED_SWEEPS = prepared
+        try:
+            las, st = _fresh(args, p0)
+            losses, used = [], []
+            losses.append(float(las.train(xs, ys)[0]))
+            used.append(dict(las.last_variants))
+            _, y_hat = las.inference(xs)                   # no begin_step: the prepare it triggers must wait for the optimiser
+            losses.append(float(las.train(xs, ys)[0]))
+            used.append(dict(las.last_variants))
+            losses.append(float(las.train(xs, ys)[0]))
+            used.append(dict(las.last_variants))
+            torch.cuda.synchronize()
+            las.check_status()
+            return losses, st.flat.clone(), y_hat.cpu(), used
+        finally:
+            L.PREPARED_SWEEPS = saved
+
+    l_ref, f_ref, y_ref, _ = run(False)
+    l_new, f_new, y_new, used = run(True)
+    assert used[2]["prepared_sweeps"] > 0, used          # the prepared path really ran in the steps after the inference
+    assert torch.equal(y_ref, y_new)
+    assert l_ref == l_new, (l_ref, l_new)
+    assert torch.equal(f_ref, f_new), "parameters differ: max %.3e" % (f_ref - f_new).abs().max().item()
