@@ -3090,9 +3090,10 @@ __global__ __launch_bounds__(256) void emb_grad_kernel(const int* tok, const flo
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+#include "speller_wide.h"
 
 struct BwdWs {
-    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dlocwP, dlocbP, dWf, dV, fcS, dfcS, gemm, total;
+    size_t packF, packB, xbf, dgbf, granX, granF, granG, granB, xccs, wsbf, wsbf2, keysbf, encbf, encbf2, dE, embp, dHl, dH, dC, dXin0, Q, dQ, duRows, dAext, tmp, dlocw, dlocb, dlocwP, dlocbP, dWf, dV, fcS, dfcS, wide, gemm, total;
 };
 static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int G, int Kc, int C) {
     BwdWs w; size_t o = 0;
@@ -3132,6 +3133,7 @@ static BwdWs bwd_layout(int B, int Tp, int Hd, int A, int D, int NL, int E, int 
     w.dfcS = o;   o += align256(C > 0 ? (size_t)U * B * Tp * C * f : 0);
     w.dlocwP = o; o += align256(C > 0 ? (size_t)B * DLW_SPLIT * Kc * C * f : 0);      // dlocw_mfma_kernel: one partial per (utterance, step slice); written whole
     w.dlocbP = o; o += align256(C > 0 ? (size_t)B * DLW_SPLIT * C * f : 0);
+    w.wide = o;   o += align256(wide_layout(B, Tp, A, D, NL, G, C).total);             // speller_wide.h: packs, operand rows, per-step scratch
     w.gemm = o;
     size_t big = (size_t)I0D * G * D;                 // largest split-K target (dcellW[0])
     if ((size_t)D * V > big) big = (size_t)D * V;
@@ -3273,6 +3275,8 @@ static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st)
     return 0;
 }
 
+#include "speller_wide_host.h"
+
 template <int CELL, bool FAST>
 static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t st) {
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
@@ -3296,24 +3300,33 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     const bool skinny = FAST && f->ws && f->ws_bytes >= wl_.embp && (I0D % 8) == 0 && las_skinny_ok(B, I0D, GD, I0D, d.xin0);
     void* packF = skinny ? (char*)f->ws + wl_.packF : nullptr;
     if (skinny) d.xbf = (unsigned short*)((char*)f->ws + wl_.xbf);
-    const bool bfrows = skinny && bf_rows_ok(d);
-    const bool pf = bfrows && pf_rows_ok(d);
-    const bool locloop = skinny && loc_loop_ok(d, G);
+    bool bfrows = skinny && bf_rows_ok(d);
+    bool pf = bfrows && pf_rows_ok(d);
+    bool locloop = skinny && loc_loop_ok(d, G);
+    bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
+    // round 6: geometries outside the loop kernels' (the reference's run.sh recipe: two 1024-unit layers, T' = 319, location-aware) take
+    // the wide path (speller_wide.h) instead of the per-utterance fp32-operand rows
+    const bool wide = wide_selected<FAST>(d, f->ws && f->ws_bytes >= wl_.gemm, skinny, loop, pf);
+    if (wide) bfrows = pf = locloop = loop = false;
     const size_t lds_bf = bf_lds_bytes(d);
-    if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);   // (loop launches: 96 KB attribute)
+    if (bfrows || locloop || (wide && FAST)) {
+        if (!wide) LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller: row state does not fit LDS (%zu bytes)", lds_bf);   // (loop launches: 96 KB attribute)
         GEMM_OK(make_bf_copies(d, (char*)f->ws, wl_, st));
     }
     if (skinny && !(d.flags & LAS_SPELLER_REUSE_PREP)) GEMM_OK(las_skinny_pack(f->cellW[0], GD, I0D, GD, 0, packF, st));
-    const bool loop = locloop || (pf && loop_ok(d, GD, I0D, LOOP_TPW_F, LOOP_KW_F));
     if (f->act_save) {   // the prefetching rows keep their attention activations for the gradient rows; any other kernel family leaves the header cleared
-        if (FAST && (loop || pf) && U > 1) {
+        if (wide && d.mode == LAS_ATT_LOC && U > 1) {   // the wide path keeps the conv outputs f only (its own header word)
+            LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
+            d.actS = (unsigned*)f->act_save;
+            d.fcSave = (float*)((char*)f->act_save + act_save_f_offset(U, B, d.Tp, d.A));
+        } else if (FAST && (loop || pf) && U > 1) {
             d.actS = (unsigned*)f->act_save;
             if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)f->act_save + act_save_f_offset(U, B, d.Tp, d.A));
         } else LAS_HIP(hipMemsetAsync(f->act_save, 0, 4, st));
     }
-    g_last_variant[0] = (loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
-                        (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (d.mode == LAS_ATT_LOC ? LAS_SPELLER_RAN_LOC : 0);
+    g_last_variant[0] = (wide ? LAS_SPELLER_RAN_WIDE : loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
+                        (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (d.mode == LAS_ATT_LOC ? LAS_SPELLER_RAN_LOC : 0) |
+                        (wide && FAST && NL > 1 ? LAS_SPELLER_RAN_UPPER_SKINNY : 0);
     if (d.flags & LAS_SPELLER_NO_LOGITS)
         LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
                 "speller: LAS_SPELLER_NO_LOGITS needs U = 1, one LSTM layer, speed mode with the prefetching row kernels, D and E + Hd + D multiples of 32");
@@ -3332,7 +3345,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
         LAS_LOOP_LAUNCH(dec_loop_fwd_kernel, CELL, d.Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }
-    for (int t = 0; t <= U && !loop; ++t) {
+    if (wide) GEMM_OK((wide_fwd_steps<CELL, FAST>(f, d, wl_, packF, st)));
+    for (int t = 0; t <= U && !loop && !wide; ++t) {
         // (t == U only finishes the last cell [+ logits]: the prefetching kernel would issue a whole step's bulk loads first --
         //  the generic bf16 row kernel loads on demand and returns after the cell; half of a beam-search step's Speller time)
         if (pf && t == 0 && f->companion_rows && (d.flags & LAS_SPELLER_NO_LOGITS)) {
@@ -3447,13 +3461,15 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     const bool skinny = FAST && (GD % 8) == 0 && las_skinny_ok(B, GD, I0D, GD, d.gates);
     void* packB = base + w.packB;
     if (skinny) d.dgbf = (unsigned short*)(base + w.dgbf);
-    const bool bfrows = skinny && bf_rows_ok(d);
-    const bool pf = bfrows && pf_rows_ok(d);
-    const bool locloop = skinny && loc_loop_ok(d, G);
+    bool bfrows = skinny && bf_rows_ok(d);
+    bool pf = bfrows && pf_rows_ok(d);
+    bool locloop = skinny && loc_loop_ok(d, G);
+    const bool wide = wide_selected<FAST>(d, true, skinny, locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B)), pf);
+    if (wide) bfrows = pf = locloop = false;
     const size_t lds_bf = bf_lds_bytes(d);
-    if (bfrows || locloop) {
-        LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
-        if (part & 1) GEMM_OK(make_bf_copies(d, base, w, st));
+    if (bfrows || locloop || wide) {
+        if (!wide) LAS_ARG(lds_bf <= (locloop ? 128 : 64) * 1024, "speller bwd: row state does not fit LDS (%zu bytes)", lds_bf);
+        if ((part & 1) && (FAST || !wide)) GEMM_OK(make_bf_copies(d, base, w, st));
         d.dE = (float*)(base + w.dE);
     }
     // the whole loop in one launch: the in-loop product covers the chain columns [E, I0D) only (every product workgroup then
@@ -3461,9 +3477,9 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
     // one tall contraction after the loop (part 2)
     const bool loop = locloop || (pf && loop_ok(d, Hd + D, GD, LOOP_TPW_B, LOOP_KW_B));
     if (part & 1)
-        g_last_variant[1] = (loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
-                            (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (loc ? LAS_SPELLER_RAN_LOC : 0);
-    if ((loop || pf) && bk->f.act_save) {   // (the rows check the header: only what a forward of the same family left is used)
+        g_last_variant[1] = (wide ? LAS_SPELLER_RAN_WIDE : loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
+                            (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (loc ? LAS_SPELLER_RAN_LOC : 0) | (wide && FAST && NL > 1 ? LAS_SPELLER_RAN_UPPER_SKINNY : 0);
+    if ((loop || pf || (wide && loc)) && bk->f.act_save) {   // (the rows check the header: only what a forward of the same family left is used)
         d.actS = (unsigned*)bk->f.act_save;
         if (d.mode == LAS_ATT_LOC) d.fcSave = (float*)((char*)bk->f.act_save + act_save_f_offset(U, B, Tp, A));   // f of every step: kept by the forward rows, or recomputed into the same place
     }
@@ -3499,7 +3515,8 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         LAS_LOOP_LAUNCH(dec_loop_bwd_kernel, CELL, Tp, locloop, dim3(8 * (d.lp.pn + d.lp.R)), lds_lp, st, d);
         LAS_LAUNCHED();
     }
-    for (int t = U - 1; t >= -1 && !loop; --t) {
+    if (wide) GEMM_OK((wide_bwd_steps<CELL, FAST>(bk, d, w, base, packB, dHl, tmp, gws, gws_bytes, st)));
+    for (int t = U - 1; t >= -1 && !loop && !wide; --t) {
         DecDev ds = d;
         if (t + 1 < U) ds.rec[0] = d.dXin0 + (size_t)(t + 1) * B * I0D;
         const int ta = (t + 1 < U) ? t + 1 : -1;
@@ -3530,7 +3547,8 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         }
     }
 
-    if (locloop) {  // keys gradient with the conv term in the pre-activation; the same pass leaves the Wf-gradient partials
+    if (wide) {}    // (wide_bwd_steps ran its own keys kernel)
+    else if (locloop) {  // keys gradient with the conv term in the pre-activation; the same pass leaves the Wf-gradient partials
         hipLaunchKernelGGL(dkeys_loc_kernel, dim3(cdiv(Tp, 8), B), dim3(256), 0, st, d, bk->d_keys);
         LAS_LAUNCHED();
     } else if (bfrows) {   // keys gradient: contraction over the steps, every (utterance, frame) independent
@@ -3590,7 +3608,7 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         GEMM_OK(las_colsum(epart, EMB_CHUNKS, V * E, V * E, 1.f, bk->demb, gws, gws_bytes, st));
     }
     bool loc_rows = loc;                           // the per-utterance rows dlocwRows / dlocbRows hold the filter / bias gradient
-    if (locloop) {  // filter / bias gradient from the saved d f rows of every step
+    if (locloop || (wide && loc)) {  // filter / bias gradient from the saved d f rows of every step
         const int nks = (Tp + 31) / 32, nmt = (d.Kc + 15) / 16;
         const size_t lds = (size_t)(((nks * 32 + 16 * nmt + 8 + 3) & ~3) + 16 * (nks * 32 + 4) + 256) * sizeof(float);
         if (nmt <= 16 && lds <= 64 * 1024) {
@@ -3610,7 +3628,10 @@ static int speller_bwd_impl(const las_speller_bwd_args* bk, DecDev d, int part, 
         GEMM_OK(las_colsum(d.dlocwRows, B, d.Kc * d.C, d.Kc * d.C, 1.f, bk->dloc_w, gws, gws_bytes, st));
         GEMM_OK(las_colsum(d.dlocbRows, B, d.C, d.C, 1.f, bk->dloc_b, gws, gws_bytes, st));
     }
-    if (loc) {
+    if (loc && wide) {
+        GEMM_OK(las_colsum((const float*)(base + w.wide + wide_layout(B, Tp, A, D, NL, G, d.C).dWfW), B * cdiv(Tp, 8), d.C * A, d.C * A, 1.f, bk->dWf, gws,
+                           gws_bytes, st));
+    } else if (loc) {
         GEMM_OK(las_colsum(d.dWfRows, B * RNG, d.C * A, d.C * A, 1.f, bk->dWf, gws, gws_bytes, st));
     }
     return 0;

@@ -1,0 +1,735 @@
+// speller_wide.h -- the Speller decode loop (reference las/las.py:72-160) and its gradient for geometries OUTSIDE the one the one-launch loop
+// kernels are built around (one decoder layer, D <= 512, T' <= 224): in particular the reference's own recipe, run.sh:59-76 -- a
+// MultiRNNCell of TWO 1024-unit cells whose concatenated states are the attention query (S = 2048, las/las.py:185-199), T' = 319 frames
+// behind the CNN listener, location-aware attention (las/layers.py:281-311).  Included by speller.hip (one translation unit).
+//
+// Round 5 served such calls with the generic row kernels: ONE workgroup per utterance pulls Ws (S x A fp32 = 1 MB), the keys and the
+// encoder rows of its utterance through one CU at every step (61 us forward / 174 us backward per decode step at B = 48: 48 of 256 CUs, each
+// bound by its ~50-80 GB/s of ingest), and the cells of layers >= 1 through the general GEMM (53 us for a 48-row product).  Here a step is a
+// short chain of launches that each fill the machine:
+//     forward   state rows (finish the top cell of step t-1 [+ in-loop logits])  ->  q = s . Ws for all rows (skinny MFMA product, Ws
+//               fragments read once per step instead of once per row)  ->  energies (+ location conv) on (frame slice, utterance)
+//               workgroups with the slices' softmax statistics  ->  alignment + context on (column slice, utterance) workgroups, which
+//               also leave the cell input row  ->  one skinny product per layer with a pointwise launch between them
+//     backward  d alpha on (frame slice, utterance)  ->  d energy, dq / du partials, d f  ->  dq, the conv's transpose  ->  d s = dq . Ws^T
+//               (skinny)  ->  per layer: gate gradient, skinny product with the transposed fragments
+// Keys / Wf / filter gradients are contracted over the steps after the loop (from dE, Q, f, d f of every step), as in the loop kernels.
+// Arithmetic: speed mode = the loop kernels' ("bf rows": keys kept in bf16, q / context / cell products on bf16 operands with fp32
+// accumulation, everything else fp32); parity mode = fp32 throughout (the same kernels with FAST = false, accurate transcendentals).
+#pragma once
+
+constexpr int WIDE_MAX_SPLIT = 8;
+#define LAS_ACT_MAGIC_WIDE 0x4c415357u      // act_save header: the wide forward kept the conv outputs f of every step
+
+struct WideDev {
+    int nsplit, fper;          // frame slices per utterance, frames per slice
+    int hsplit, h4per;         // context column slices per utterance, 4-column chunks per slice
+    float* qbuf;               // [B, A]      q = s . Ws of the current step (forward)
+    float* ebuf;               // [B, Tp]     energies (forward) / d alpha (backward)
+    float* stat;               // [B, nsplit, 2] softmax statistics (forward); [B, nsplit] partial alpha . d alpha (backward)
+    float *pdq, *pdu;          // [B, nsplit, A] partial dq / du of the frame slices
+    unsigned short* sbf;       // [B, S]      state rows, bf16 (speed mode: A operand of the query product)
+    float* sf;                 // [B, S]      ... fp32 (parity mode)
+    unsigned short* xu;        // [B, 2D]     [h_{l-1, t+1} ; h_{l, t}] bf16: A operand of an upper layer's cell product
+    unsigned short* dqbf;      // [B, A]
+    unsigned short* dgu;       // [B, G D]    gate gradient rows of an upper layer, bf16
+    float* dS;                 // [B, S]      dq . Ws^T
+    float* dWfW;               // [B, ceil(Tp / 8), C, A]  Wf-gradient partials of the after-loop keys kernel (written whole)
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+// (1) one workgroup per utterance: finish the TOP layer's cell of step t-1 [+ vocabulary projection, arg-max, Gumbel draw], resolve the
+//     token entering step t, leave the concatenated state row s_t = [h_0 ; ... ; h_{NL-1}] for the query product.
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, int t) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hl = sm;                          // [D]
+    float* red = sm + ((a.D + 3) & ~3);      // [32]
+    int* redi = reinterpret_cast<int*>(red + 32);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int B = a.B, D = a.D, NL = a.NL, U = a.U, S = D * NL, TOP = NL - 1, GD = G * D;
+    int greedy_tok = 1, sample_tok = 1;
+    if (t > 0) {
+        float* gp = a.gates + (((size_t)TOP * U + (t - 1)) * B + b) * GD;
+        float* hnew = a.hs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+        for (int d = tid; d < D; d += RNT) {
+            float h;
+            if (CELL == LAS_CELL_LSTM) {
+                const float* cprev = a.cs + (((size_t)TOP * (U + 1) + (t - 1)) * B + b) * D;
+                float* cnew = a.cs + (((size_t)TOP * (U + 1) + t) * B + b) * D;
+                const float gi = sigm<FAST>(gp[d]), gj = tanhx<FAST>(gp[D + d]);
+                const float gf = sigm<FAST>(gp[2 * D + d] + a.fb), go = sigm<FAST>(gp[3 * D + d]);
+                const float c = cprev[d] * gf + gi * gj;
+                h = tanhx<FAST>(c) * go;
+                gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+                cnew[d] = c;
+            } else {
+                h = tanhx<FAST>(gp[d]);
+            }
+            hnew[d] = h;
+            hl[d] = h;
+        }
+        __syncthreads();
+        if (a.step_logits) row_logits<FAST>(a, hl, t, b, tid, red, redi, greedy_tok, sample_tok);
+    }
+    if (t >= U) return;
+    int tok = a.tok_in[(size_t)t * B + b];
+    if (tok == -1) tok = greedy_tok;
+    else if (tok == -2) tok = sample_tok;
+    if (tid == 0) a.tok_in[(size_t)t * B + b] = tok;
+    for (int i = tid; i < S; i += RNT) {
+        const int l = i / D, d = i - l * D;
+        const float v = (l == TOP && t > 0) ? hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
+        if (FAST) w.sbf[(size_t)b * S + i] = f2bf(v);
+        else w.sf[(size_t)b * S + i] = v;
+    }
+}
+
+// f[t', c] = bias[c] + sum_k prev_align[t' + k - pad] w[k, c] for the frames [t0, t0 + nf) of one utterance (conv1d, SAME, cross-correlation:
+// las/layers.py:295-296) -> fc [nf, C] in LDS.  aprev [Tp] and locw [Kc, C] are in LDS; part: nf C ksplit floats of scratch.
+__device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* aprev, const float* locw, float* fc, float* part, int t0, int nf, int tid) {
+    const int Tp = a.Tp, C = a.C, Kc = a.Kc, pad = (Kc - 1) / 2, items = nf * C;
+    int ks = items > 0 ? RNT / items : 1;
+    ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    const int kper = (Kc + ks - 1) / ks;
+    for (int i = tid; i < items * ks; i += RNT) {
+        const int kc = i / items, it = i - kc * items, fr = it / C, c = it - fr * C, tt = t0 + fr;
+        int k0 = kc * kper, k1 = k0 + kper < Kc ? k0 + kper : Kc;
+        if (k0 < pad - tt) k0 = pad - tt;                       // taps that meet a frame: 0 <= tt + k - pad < Tp
+        if (k1 > Tp + pad - tt) k1 = Tp + pad - tt;
+        float acc = kc == 0 ? a.loc_b[c] : 0.f;
+        for (int k = k0; k < k1; ++k) acc = fmaf(aprev[tt + k - pad], locw[k * C + c], acc);
+        part[i] = acc;
+    }
+    __syncthreads();
+    for (int it = tid; it < items; it += RNT) {
+        float acc = part[it];
+        for (int kc = 1; kc < ks; ++kc) acc += part[kc * items + it];
+        fc[it] = acc;
+    }
+    __syncthreads();
+}
+
+struct WideLds { float *aprev, *locw, *wfl, *fc, *dfc, *qv, *ev, *red, *part; };
+// part: the conv's tap-slice partials (< max(RNT, fper C) floats), later the 32 frame groups' dq / du partials (RNG A)
+__host__ __device__ __forceinline__ size_t wide_part_floats(int A, int fper, int C) {
+    size_t n = (size_t)RNG * A;
+    if (C > 0 && (size_t)RNT > n) n = RNT;
+    if (C > 0 && (size_t)fper * C > n) n = (size_t)fper * C;
+    return (n + 3) & ~(size_t)3;
+}
+__device__ __forceinline__ WideLds wide_carve(float* sm, const DecDev& a, int fper) {
+    auto u4 = [](int x) { return (x + 3) & ~3; };
+    WideLds L; float* p = sm;
+    const bool loc = a.mode == LAS_ATT_LOC;
+    L.qv = p; p += u4(a.A);
+    L.ev = p; p += u4(fper);
+    L.red = p; p += 64;
+    L.aprev = p; p += loc ? u4(a.Tp) : 0;
+    L.locw = p; p += loc ? u4(a.Kc * a.C) : 0;
+    L.wfl = p; p += loc ? u4(a.C * a.A) : 0;
+    L.fc = p; p += loc ? u4(fper * a.C) : 0;
+    L.dfc = p; p += loc ? u4(fper * a.C) : 0;
+    L.part = p;
+    return L;
+}
+static size_t wide_lds_bytes(const DecDev& a, int fper) {
+    auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const bool loc = a.mode == LAS_ATT_LOC;
+    size_t n = u4(a.A) + u4(fper) + 64;
+    if (loc) n += u4(a.Tp) + u4((size_t)a.Kc * a.C) + u4((size_t)a.C * a.A) + 2 * u4((size_t)fper * a.C);
+    return (n + wide_part_floats(a.A, fper, loc ? a.C : 0)) * sizeof(float) + 64;
+}
+
+// keys [b, tt, 4 a4 .. 4 a4 + 3] in the arithmetic of the mode
+template <bool FAST>
+__device__ __forceinline__ float4 wide_key4(const DecDev& a, int b, int tt, int a4) {
+    if (FAST) {
+        const uint2 v = reinterpret_cast<const uint2*>(a.keysbf + ((size_t)b * a.Tp + tt) * a.A)[a4];
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+    return reinterpret_cast<const float4*>(a.keys + ((size_t)b * a.Tp + tt) * a.A)[a4];
+}
+
+// (2) energies of the frames [s fper, (s + 1) fper) of utterance b: e = u . tanh(keys + q [+ f . Wf]), -1e8 replace-mask, and the
+//     slice's softmax statistics (max, sum of exp).  grid (nsplit, B).
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const WideLds L = wide_carve(sm, a, w.fper);
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+    for (int i = tid; i < A; i += RNT) L.qv[i] = w.qbuf[(size_t)b * A + i];
+    if (LOC) {
+        for (int i = tid; i < Tp; i += RNT)
+            L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+        for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
+        for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
+    }
+    __syncthreads();
+    if (nf <= 0) { if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; } return; }
+    if (LOC) {
+        wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, t0, nf, tid);
+        if (a.fcSave) {              // kept for the gradient loop and the after-loop filter / keys gradients
+            float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
+            for (int i = tid; i < nf * C; i += RNT) fs[i] = L.fc[i];
+            if (a.actS && t == 0 && b == 0 && s == 0 && tid == 0) a.actS[0] = LAS_ACT_MAGIC_WIDE;
+        }
+    }
+    const int len = a.enc_len[b];
+    const int sl = tid & 31, grp = tid >> 5;
+    for (int fr = grp; fr < nf; fr += RNG) {
+        const int tt = t0 + fr;
+        float part = 0.f;
+        for (int a4 = sl; a4 < A / 4; a4 += 32) {
+            const float4 k4 = wide_key4<FAST>(a, b, tt, a4);
+            const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+            const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+            float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+            if (LOC) {
+                for (int c = 0; c < C; ++c) {
+                    const float f = L.fc[fr * C + c];
+                    const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                    p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+                }
+            }
+            part += u4.x * tanhx<FAST>(p.x) + u4.y * tanhx<FAST>(p.y) + u4.z * tanhx<FAST>(p.z) + u4.w * tanhx<FAST>(p.w);
+        }
+        const float e = sub32_sum(part);
+        if (sl == 0) {
+            const float em = (tt < len) ? e : -1e8f;           // replace-mask, las/layers.py:205-207
+            L.ev[fr] = em;
+            w.ebuf[(size_t)b * Tp + tt] = em;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < nf; i += RNT) m = fmaxf(m, L.ev[i]);
+    m = block_max<RNT>(m, L.red);
+    float ssum = 0.f;
+    for (int i = tid; i < nf; i += RNT) ssum += expf(L.ev[i] - m);
+    ssum = block_sum<RNT>(ssum, L.red);
+    if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = m; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = ssum; }
+}
+
+// (3) alignment (softmax over all frames from the slices' statistics), the context columns [4 c0, 4 c1) of utterance b, and the cell input
+//     row [emb(token) ; context ; h_0] (fp32 for the weight gradients, bf16 as the product's A operand).  grid (hsplit, B).
+template <bool FAST>
+__global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hs_ = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, D = a.D, E = a.E, V = a.V, U = a.U, I0D = E + Hd + D, H4 = Hd / 4;
+    float* al = sm;                                  // [Tp] alignment (speed mode: rounded to bf16, the contraction's operand)
+    float* part = sm + ((Tp + 3) & ~3);              // [ng][h4per] float4
+    float m = -INFINITY;
+    for (int s = 0; s < w.nsplit; ++s) m = fmaxf(m, w.stat[((size_t)b * w.nsplit + s) * 2]);
+    float l = 0.f;
+    for (int s = 0; s < w.nsplit; ++s) {
+        const float ms = w.stat[((size_t)b * w.nsplit + s) * 2], ls = w.stat[((size_t)b * w.nsplit + s) * 2 + 1];
+        if (ls > 0.f) l += ls * expf(ms - m);
+    }
+    const float inv = 1.0f / l;
+    float* arow = a.alphas + ((size_t)t * B + b) * Tp;
+    for (int i = tid; i < Tp; i += RNT) {
+        const float v = expf(w.ebuf[(size_t)b * Tp + i] - m) * inv;
+        if (hs_ == 0) arow[i] = v;
+        al[i] = FAST ? bf2f(f2bf(v)) : v;
+    }
+    __syncthreads();
+    const int len = a.enc_len[b];
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
+    const int c0 = hs_ * w.h4per, nch = (H4 - c0 < w.h4per ? H4 - c0 : w.h4per);
+    const int ng = RNT / w.h4per;
+    const int g = tid / w.h4per, ch = tid - g * w.h4per;
+    if (nch > 0) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < ng && ch < nch) {
+            int tt = g;
+            for (; tt + 3 * ng < lim; tt += 4 * ng) {          // four independent loads in flight
+                float4 e4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tu = tt + u * ng;
+                    if (FAST) {
+                        const uint2 v = reinterpret_cast<const uint2*>(a.encbf + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
+                        e4[u] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+                    } else e4[u] = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float av = al[tt + u * ng];
+                    acc.x = fmaf(av, e4[u].x, acc.x); acc.y = fmaf(av, e4[u].y, acc.y); acc.z = fmaf(av, e4[u].z, acc.z); acc.w = fmaf(av, e4[u].w, acc.w);
+                }
+            }
+            for (; tt < lim; tt += ng) {
+                float4 e4;
+                if (FAST) {
+                    const uint2 v = reinterpret_cast<const uint2*>(a.encbf + ((size_t)b * Tp + tt) * Hd)[c0 + ch];
+                    e4 = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+                } else e4 = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd)[c0 + ch];
+                const float av = al[tt];
+                acc.x = fmaf(av, e4.x, acc.x); acc.y = fmaf(av, e4.y, acc.y); acc.z = fmaf(av, e4.z, acc.z); acc.w = fmaf(av, e4.w, acc.w);
+            }
+            reinterpret_cast<float4*>(part)[g * w.h4per + ch] = acc;
+        }
+    }
+    __syncthreads();
+    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
+    unsigned short* xb = FAST ? a.xbf + (size_t)b * I0D : nullptr;
+    for (int i = tid; i < nch * 4; i += RNT) {
+        const int chq = i >> 2, e = i & 3;
+        float cv = 0.f;
+        for (int gg = 0; gg < ng; ++gg) cv += part[(gg * w.h4per + chq) * 4 + e];
+        const int col = (c0 + chq) * 4 + e;
+        xrow[E + col] = cv;
+        if (FAST) xb[E + col] = f2bf(cv);
+    }
+    if (hs_ == 0) {
+        const int tok = a.tok_in[(size_t)t * B + b];
+        for (int i = tid; i < E; i += RNT) {
+            const float v = (a.emb[(size_t)tok * E + i] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + i] : 0.f)) *
+                            (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+            xrow[i] = v;
+            if (FAST) xb[i] = f2bf(v);
+        }
+        for (int i = tid; i < D; i += RNT) {
+            const float v = a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + i];
+            xrow[E + Hd + i] = v;
+            if (FAST) xb[E + Hd + i] = f2bf(v);
+        }
+    }
+}
+
+// gate nonlinearity of layer `layer` (< TOP) at step t, and the bf16 input row of the layer above: [h_{layer, t+1} ; h_{layer+1, t}]
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void wide_pointwise_fwd_kernel(DecDev a, WideDev w, int layer, int t) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const int b = blockIdx.x, B = a.B, D = a.D, U = a.U, GD = G * D;
+    float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;
+    float* hnew = a.hs + (((size_t)layer * (U + 1) + t + 1) * B + b) * D;
+    const float* hup = a.hs + (((size_t)(layer + 1) * (U + 1) + t) * B + b) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float h;
+        if (CELL == LAS_CELL_LSTM) {
+            const float* cprev = a.cs + (((size_t)layer * (U + 1) + t) * B + b) * D;
+            float* cnew = a.cs + (((size_t)layer * (U + 1) + t + 1) * B + b) * D;
+            const float gi = sigm<FAST>(gp[d]), gj = tanhx<FAST>(gp[D + d]);
+            const float gf = sigm<FAST>(gp[2 * D + d] + a.fb), go = sigm<FAST>(gp[3 * D + d]);
+            const float c = cprev[d] * gf + gi * gj;
+            h = tanhx<FAST>(c) * go;
+            gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+            cnew[d] = c;
+        } else {
+            h = tanhx<FAST>(gp[d]);
+        }
+        hnew[d] = h;
+        if (FAST) {
+            w.xu[(size_t)b * 2 * D + d] = f2bf(h);
+            w.xu[(size_t)b * 2 * D + D + d] = f2bf(hup[d]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// (1) d alpha[t'] = dctx . enc[b, t', :] (+ what step t+1's location conv sent back) for the frames of slice s, and the slice's part of
+//     alpha . d alpha.  grid (nsplit, B).
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dctx = sm;                                  // [Hd]
+    float* red = sm + ((a.Hd + 3) & ~3);               // [32]
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, Hd = a.Hd, E = a.E, U = a.U, I0D = E + Hd + a.D;
+    const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+    const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D + E;
+    for (int i = tid; i < Hd; i += RNT) dctx[i] = FAST ? bf2f(f2bf(dxr[i])) : dxr[i];
+    __syncthreads();
+    const int sl = tid & 31, grp = tid >> 5;
+    float dot = 0.f;
+    for (int fr = grp; fr < nf; fr += RNG) {
+        const int tt = t0 + fr;
+        float acc = 0.f;
+        if (FAST) {
+            for (int h8 = sl; h8 < Hd / 8; h8 += 32) {
+                const uint4 v = reinterpret_cast<const uint4*>(a.encbf + ((size_t)b * Tp + tt) * Hd)[h8];
+                float e[8];
+                unpack8(v, e);
+                const float4 d0 = reinterpret_cast<const float4*>(dctx)[2 * h8], d1 = reinterpret_cast<const float4*>(dctx)[2 * h8 + 1];
+                acc += d0.x * e[0] + d0.y * e[1] + d0.z * e[2] + d0.w * e[3] + d1.x * e[4] + d1.y * e[5] + d1.z * e[6] + d1.w * e[7];
+            }
+        } else {
+            for (int h4 = sl; h4 < Hd / 4; h4 += 32) {
+                const float4 e = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd)[h4];
+                const float4 d4 = reinterpret_cast<const float4*>(dctx)[h4];
+                acc += d4.x * e.x + d4.y * e.y + d4.z * e.z + d4.w * e.w;
+            }
+        }
+        float v = sub32_sum(acc);
+        if (sl == 0) {
+            if (LOC && t + 1 < U) v += a.dAext[(size_t)b * Tp + tt];
+            w.ebuf[(size_t)b * Tp + tt] = v;
+            dot = fmaf(a.alphas[((size_t)t * B + b) * Tp + tt], v, dot);
+        }
+    }
+    dot = block_sum<RNT>(dot, red);
+    if (tid == 0) w.stat[(size_t)b * w.nsplit + s] = dot;
+}
+
+// (2) d energy of the slice's frames (kept for the after-loop keys gradient), the energies' backward: partial dq / du over the slice, and
+//     d f[t', c] = sum_a dv[a] Wf[c, a] (kept for the conv's transpose and the filter gradient).  grid (nsplit, B).
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const WideLds L = wide_carve(sm, a, w.fper);
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+    float* dfc = L.dfc;
+    for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
+    const bool havef = LOC && a.actS && a.fcSave && a.actS[0] == LAS_ACT_MAGIC_WIDE;     // the forward kept f of every step
+    if (LOC) {
+        for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
+        if (!havef) {
+            for (int i = tid; i < Tp; i += RNT)
+                L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+            for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
+        }
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int q = 0; q < w.nsplit; ++q) dot += w.stat[(size_t)b * w.nsplit + q];
+    if (nf > 0) {
+        if (LOC) {
+            if (havef) {
+                const float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
+                for (int i = tid; i < nf * C; i += RNT) L.fc[i] = fs[i];
+            } else {
+                wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, t0, nf, tid);
+                if (a.fcSave) {      // the after-loop keys / Wf gradient reads f of every step
+                    float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
+                    for (int i = tid; i < nf * C; i += RNT) fs[i] = L.fc[i];
+                }
+            }
+        }
+        for (int i = tid; i < nf; i += RNT) {
+            const int tt = t0 + i;
+            const float de = a.alphas[((size_t)t * B + b) * Tp + tt] * (w.ebuf[(size_t)b * Tp + tt] - dot);    // 0 where masked: alpha = 0
+            L.ev[i] = de;
+            a.dE[((size_t)t * B + b) * Tp + tt] = de;
+        }
+    }
+    __syncthreads();
+    const int sl = tid & 31, grp = tid >> 5;
+    float du_acc[8], dq_acc[8];                    // A <= 256: at most two float4 per lane
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { du_acc[i] = 0.f; dq_acc[i] = 0.f; }
+    for (int fr = grp; fr < nf; fr += RNG) {
+        const int tt = t0 + fr;
+        const float de = L.ev[fr];
+        float4 dvs[2];
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int a4 = sl + 32 * slot;
+            dvs[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a4 >= A / 4) continue;
+            const float4 k4 = wide_key4<FAST>(a, b, tt, a4);
+            const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+            const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
+            float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+            if (LOC) {
+                for (int c = 0; c < C; ++c) {
+                    const float f = L.fc[fr * C + c];
+                    const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                    p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
+                }
+            }
+            const float vx = tanhx<FAST>(p.x), vy = tanhx<FAST>(p.y), vz = tanhx<FAST>(p.z), vw = tanhx<FAST>(p.w);
+            const float4 dv = make_float4(de * u4.x * (1.f - vx * vx), de * u4.y * (1.f - vy * vy), de * u4.z * (1.f - vz * vz), de * u4.w * (1.f - vw * vw));
+            du_acc[slot * 4 + 0] += de * vx; du_acc[slot * 4 + 1] += de * vy; du_acc[slot * 4 + 2] += de * vz; du_acc[slot * 4 + 3] += de * vw;
+            dq_acc[slot * 4 + 0] += dv.x; dq_acc[slot * 4 + 1] += dv.y; dq_acc[slot * 4 + 2] += dv.z; dq_acc[slot * 4 + 3] += dv.w;
+            dvs[slot] = dv;
+        }
+        if (LOC) {
+            for (int c = 0; c < C; ++c) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int a4 = sl + 32 * slot;
+                    if (a4 < A / 4) {
+                        const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                        s1 += dvs[slot].x * w4.x + dvs[slot].y * w4.y + dvs[slot].z * w4.z + dvs[slot].w * w4.w;
+                    }
+                }
+                s1 = sub32_sum(s1);
+                if (sl == 0) dfc[fr * C + c] = s1;
+            }
+        }
+    }
+    // the 32 frame groups' partials of dq, then du, through LDS in fixed order
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int a4 = sl + 32 * slot;
+            if (a4 < A / 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = pass == 0 ? dq_acc[slot * 4 + e] : du_acc[slot * 4 + e];
+            }
+        }
+        __syncthreads();
+        float* out = (pass == 0 ? w.pdq : w.pdu) + ((size_t)b * w.nsplit + s) * A;
+        for (int i = tid; i < A; i += RNT) {
+            float v = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < RNG; ++g8) v += L.part[g8 * A + i];
+            out[i] = v;
+        }
+    }
+    if (LOC && nf > 0 && a.dfcSave) {
+        float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + t0) * C;
+        for (int i = tid; i < nf * C; i += RNT) ds[i] = dfc[i];
+    }
+}
+
+// (3) one workgroup per utterance: dq = sum of the slices' partials (-> dQ of the step, bf16 operand row of d s = dq . Ws^T), du, and the
+//     conv's transpose d alpha_{t-1}[src] = sum_k sum_c d f[src - k + pad, c] w[k, c] from the step's d f rows.
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    for (int i = tid; i < A; i += RNT) {
+        float dq = 0.f, du = 0.f;
+        for (int s = 0; s < w.nsplit; ++s) {
+            dq += w.pdq[((size_t)b * w.nsplit + s) * A + i];
+            du += w.pdu[((size_t)b * w.nsplit + s) * A + i];
+        }
+        a.dQ[((size_t)t * B + b) * A + i] = dq;
+        if (FAST) w.dqbf[(size_t)b * A + i] = f2bf(dq);
+        a.duRows[(size_t)b * A + i] += du;
+    }
+    if (LOC && t > 0) {
+        float* dfc = sm;                                   // [Tp, C]
+        float* locw = dfc + ((Tp * C + 3) & ~3);           // [Kc, C]
+        float* part = locw + ((a.Kc * C + 3) & ~3);        // [NKC, Tp]
+        const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
+        for (int i = tid; i < Tp * C; i += RNT) dfc[i] = ds[i];
+        for (int i = tid; i < a.Kc * C; i += RNT) locw[i] = a.loc_w[i];
+        __syncthreads();
+        const int pad = (a.Kc - 1) / 2;
+        const int NKC = RNT / Tp > 0 ? (RNT / Tp < 8 ? RNT / Tp : 8) : 1;
+        const int kper = (a.Kc + NKC - 1) / NKC;
+        for (int i = tid; i < NKC * Tp; i += RNT) {
+            const int kc = i / Tp, src = i - kc * Tp;
+            int k0 = kc * kper, k1 = k0 + kper < a.Kc ? k0 + kper : a.Kc;
+            if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
+            if (k1 > src + pad + 1) k1 = src + pad + 1;
+            float acc = 0.f;
+            for (int k = k0; k < k1; ++k) {
+                const float* dr = dfc + (src - k + pad) * C;
+                const float* wr = locw + k * C;
+                for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
+            }
+            part[i] = acc;
+        }
+        __syncthreads();
+        for (int src = tid; src < Tp; src += RNT) {
+            float acc = 0.f;
+            for (int kc = 0; kc < NKC; ++kc) acc += part[kc * Tp + src];
+            a.dAext[(size_t)b * Tp + src] = acc;
+        }
+    }
+}
+static size_t wide_dq_lds_bytes(const DecDev& a) {
+    if (a.mode != LAS_ATT_LOC) return 64;
+    auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const int NKC = RNT / a.Tp > 0 ? (RNT / a.Tp < 8 ? RNT / a.Tp : 8) : 1;
+    return (u4((size_t)a.Tp * a.C) + u4((size_t)a.Kc * a.C) + (size_t)NKC * a.Tp) * sizeof(float) + 64;
+}
+
+// (4) gate backward of `layer` at step t: dh = [recurrent gradient from step t+1] + [d s of step t+1's attention] + extra (top layer:
+//     dlogits . Wv^T of step t; below: the input gradient of the layer above, same step) -> d(pre-activation) over the saved gates, fp32
+//     (weight gradients after the loop) and bf16 (the step's product).
+template <int CELL, bool FAST>
+__global__ __launch_bounds__(256) void wide_cell_bwd_kernel(DecDev a, WideDev w, int layer, int t, const float* rec, int rec_ld, int rec_off,
+                                                            const float* dS, const float* extra, int extra_ld, unsigned short* gb_) {
+    constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
+    const int b = blockIdx.x, B = a.B, D = a.D, U = a.U, GD = G * D, S = D * a.NL;
+    float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;
+    float* dCr = a.dC + ((size_t)layer * B + b) * D;
+    unsigned short* gb = gb_ ? gb_ + (size_t)b * GD : nullptr;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float dh = extra[(size_t)b * extra_ld + d];
+        if (rec) dh += rec[(size_t)b * rec_ld + rec_off + d];
+        if (dS) dh += dS[(size_t)b * S + layer * D + d];
+        if (CELL == LAS_CELL_LSTM) {
+            const float gi = gp[d], gj = gp[D + d], gf = gp[2 * D + d], go = gp[3 * D + d];
+            const float c = a.cs[(((size_t)layer * (U + 1) + t + 1) * B + b) * D + d];
+            const float cp = a.cs[(((size_t)layer * (U + 1) + t) * B + b) * D + d];
+            const float tc = tanhx<FAST>(c);
+            const float dc = dCr[d] + dh * go * (1.f - tc * tc);
+            dCr[d] = dc * gf;
+            const float di = dc * gj * gi * (1.f - gi), dj = dc * gi * (1.f - gj * gj);
+            const float df = dc * cp * gf * (1.f - gf), dO = dh * tc * go * (1.f - go);
+            gp[d] = di; gp[D + d] = dj; gp[2 * D + d] = df; gp[3 * D + d] = dO;
+            if (gb) { gb[d] = f2bf(di); gb[D + d] = f2bf(dj); gb[2 * D + d] = f2bf(df); gb[3 * D + d] = f2bf(dO); }
+        } else {
+            const float h = a.hs[(((size_t)layer * (U + 1) + t + 1) * B + b) * D + d];
+            const float dp = dh * (1.f - h * h);
+            gp[d] = dp;
+            if (gb) gb[d] = f2bf(dp);
+        }
+    }
+}
+
+// After the loop: dKeys[b, t', :] += sum_t dE[t, b, t'] u (1 - tanh^2(keys + Q[t] [+ f[t] . Wf])), and in the same pass the Wf gradient
+// partial of (utterance b, 8 frames): dWfW[b][slice][c][a] = sum_{t, t' in slice} f[t, b, t', c] dv[t, b, t', a]  (written whole; reduced
+// over the slices by las_colsum).  workgroup = (8 frames, utterance), 32 lanes x float4 over the attention dim (A <= 256: two slots).
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(256) void wide_dkeys_kernel(DecDev a, WideDev w, float* __restrict__ dKeys) {
+    constexpr int LC = LOC ? 16 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wf = sm;                                    // [C, A]
+    float* part = sm + ((a.C * a.A + 3) & ~3);         // [8][C][A]
+    const int b = blockIdx.y, fr = threadIdx.x >> 5, tt = blockIdx.x * 8 + fr, sl = threadIdx.x & 31;
+    const int B = a.B, Tp = a.Tp, A = a.A, U = a.U, C = a.C;
+    if (LOC) {
+        for (int i = threadIdx.x; i < C * A; i += 256) wf[i] = a.Wf[i];
+        __syncthreads();
+    }
+    const int ttc = tt < Tp ? tt : Tp - 1;
+    for (int slot = 0; slot < 2; ++slot) {
+        const int a4 = sl + 32 * slot;
+        const bool on = tt < Tp && a4 < A / 4;
+        const int a4c = a4 < A / 4 ? a4 : A / 4 - 1;
+        if (slot == 1 && A / 4 <= 32) break;
+        const float4 k4 = wide_key4<FAST>(a, b, ttc, a4c);
+        const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4c];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dwf[LC];
+#pragma unroll
+        for (int c = 0; c < LC; ++c) dwf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+        for (int t = 0; t < U; ++t) {
+            const float de = a.dE[((size_t)t * B + b) * Tp + ttc];
+            const float4 q4 = reinterpret_cast<const float4*>(a.Q + ((size_t)t * B + b) * A)[a4c];
+            float p0 = k4.x + q4.x, p1 = k4.y + q4.y, p2 = k4.z + q4.z, p3 = k4.w + q4.w;
+            float f[LC];
+            if (LOC) {
+                const float* fr_ = a.fcSave + (((size_t)t * B + b) * Tp + ttc) * C;
+#pragma unroll
+                for (int c = 0; c < LC; ++c) f[c] = c < C ? fr_[c] : 0.f;
+#pragma unroll
+                for (int c = 0; c < LC; ++c) {
+                    if (c < C) {
+                        const float4 w4 = reinterpret_cast<const float4*>(wf + c * A)[a4c];
+                        p0 = fmaf(f[c], w4.x, p0); p1 = fmaf(f[c], w4.y, p1); p2 = fmaf(f[c], w4.z, p2); p3 = fmaf(f[c], w4.w, p3);
+                    }
+                }
+            }
+            const float v0 = tanhx<FAST>(p0), v1 = tanhx<FAST>(p1), v2 = tanhx<FAST>(p2), v3 = tanhx<FAST>(p3);
+            const float4 dv = make_float4(de * u4.x * (1.f - v0 * v0), de * u4.y * (1.f - v1 * v1), de * u4.z * (1.f - v2 * v2), de * u4.w * (1.f - v3 * v3));
+            acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
+            if (LOC) {
+#pragma unroll
+                for (int c = 0; c < LC; ++c) {
+                    dwf[c].x = fmaf(f[c], dv.x, dwf[c].x); dwf[c].y = fmaf(f[c], dv.y, dwf[c].y);
+                    dwf[c].z = fmaf(f[c], dv.z, dwf[c].z); dwf[c].w = fmaf(f[c], dv.w, dwf[c].w);
+                }
+            }
+        }
+        if (on) {
+            float4* dk = reinterpret_cast<float4*>(dKeys + ((size_t)b * Tp + tt) * A) + a4;
+            float4 o = *dk;
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            *dk = o;
+        }
+        if (LOC) {
+            if (a4 < A / 4) {
+#pragma unroll
+                for (int c = 0; c < LC; ++c) {
+                    if (c < C) {
+                        const float4 v = on ? dwf[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        reinterpret_cast<float4*>(part + ((size_t)fr * C + c) * A)[a4] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (LOC) {
+        __syncthreads();
+        float* out = w.dWfW + ((size_t)b * gridDim.x + blockIdx.x) * C * A;
+        for (int i = threadIdx.x; i < C * A; i += 256) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) s_ += part[(size_t)g8 * C * A + i];
+            out[i] = s_;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct WideWs { size_t packWs, packWsT, packU[LAS_MAX_NL], packUB[LAS_MAX_NL], srow, xu, dqbf, dgu, qbuf, ebuf, stat, pdq, pdu, dS, dWfW, total; };
+static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
+    WideWs w; size_t o = 0;
+    const size_t S = (size_t)D * NL, GD = (size_t)G * D;
+    w.packWs = o;  o += align256(las_skinny_pack_bytes((int)S, A));
+    w.packWsT = o; o += align256(las_skinny_pack_bytes(A, (int)S));
+    for (int l = 0; l < LAS_MAX_NL; ++l) {
+        w.packU[l] = o;  o += (l >= 1 && l < NL) ? align256(las_skinny_pack_bytes(2 * D, (int)GD)) : 0;
+        w.packUB[l] = o; o += (l >= 1 && l < NL) ? align256(las_skinny_pack_bytes((int)GD, 2 * D)) : 0;
+    }
+    w.srow = o;  o += align256((size_t)B * S * 4);
+    w.xu = o;    o += align256((size_t)B * 2 * D * 2);
+    w.dqbf = o;  o += align256((size_t)B * A * 2);
+    w.dgu = o;   o += align256((size_t)B * GD * 2);
+    w.qbuf = o;  o += align256((size_t)B * A * 4);
+    w.ebuf = o;  o += align256((size_t)B * Tp * 4);
+    w.stat = o;  o += align256((size_t)B * WIDE_MAX_SPLIT * 2 * 4);
+    w.pdq = o;   o += align256((size_t)B * WIDE_MAX_SPLIT * A * 4);
+    w.pdu = o;   o += align256((size_t)B * WIDE_MAX_SPLIT * A * 4);
+    w.dS = o;    o += align256((size_t)B * S * 4);
+    w.dWfW = o;  o += align256(C > 0 ? (size_t)B * cdiv(Tp, 8) * C * A * 4 : 0);
+    w.total = o;
+    return w;
+}
+
+// the geometry the wide kernels serve (any number of layers / widths the Speller accepts)
+static bool wide_geom_ok(const DecDev& d) {
+    if (d.U < 2 || (d.A % 8) || (d.Hd % 8) || (d.D % 8) || (d.E % 8) || d.A > 256) return false;
+    if (d.mode == LAS_ATT_LOC && (d.C < 1 || d.C > 16)) return false;
+    return true;
+}
+static void wide_split(const DecDev& d, WideDev& w) {
+    int ns = las_device_cus() / (d.B > 0 ? d.B : 1);
+    ns = ns < 1 ? 1 : (ns > WIDE_MAX_SPLIT ? WIDE_MAX_SPLIT : ns);
+    if (ns > cdiv(d.Tp, 8)) ns = cdiv(d.Tp, 8);
+    w.fper = cdiv(d.Tp, ns);
+    w.nsplit = cdiv(d.Tp, w.fper);
+    int hs = las_device_cus() / (d.B > 0 ? d.B : 1);
+    hs = hs < 1 ? 1 : (hs > 8 ? 8 : hs);
+    const int H4 = d.Hd / 4;
+    if (hs > H4) hs = H4;
+    w.h4per = cdiv(H4, hs);
+    if (w.h4per > RNT) w.h4per = RNT;
+    w.hsplit = cdiv(H4, w.h4per);
+}
+static void wide_fill(const DecDev& d, WideDev& w, char* base, const WideWs& L) {
+    wide_split(d, w);
+    w.qbuf = (float*)(base + L.qbuf); w.ebuf = (float*)(base + L.ebuf); w.stat = (float*)(base + L.stat);
+    w.pdq = (float*)(base + L.pdq); w.pdu = (float*)(base + L.pdu);
+    w.sbf = (unsigned short*)(base + L.srow); w.sf = (float*)(base + L.srow);
+    w.xu = (unsigned short*)(base + L.xu); w.dqbf = (unsigned short*)(base + L.dqbf); w.dgu = (unsigned short*)(base + L.dgu);
+    w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW);
+}
+template <class K> static int wide_lds_attr(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}

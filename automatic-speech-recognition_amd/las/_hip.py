@@ -599,6 +599,7 @@ class _timed:
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS, SEQ_F32_VALU, SEQ_PREPARED = 1, 2, 4, 8, 16, 32, 64
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS, SPELLER_ROWS_SHARE4 = 1, 2, 4, 8, 16, 32
+SPELLER_WIDE, SPELLER_NO_WIDE = 64, 128      # csrc/speller_wide.h: force / forbid the wide per-step path (LAS_SPELLER_WIDE=1 / LAS_NO_WIDE=1)
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
                  "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_ALLOW_SERIAL_STREAMS=1)",
@@ -629,7 +630,8 @@ def _flags_from_env():
     if e("LAS_SPIN_LOG2"):
         f |= seq_spin_log2(e("LAS_SPIN_LOG2"))
     g = (SPELLER_NO_PF_ROWS if e("LAS_NO_PF_ROWS") == "1" else 0) | (SPELLER_NO_BF_ROWS if e("LAS_NO_BF_ROWS") == "1" else 0) | \
-        (SPELLER_NO_FUSED_STEP if e("LAS_NO_FUSED_STEP") == "1" else 0)
+        (SPELLER_NO_FUSED_STEP if e("LAS_NO_FUSED_STEP") == "1" else 0) | (SPELLER_WIDE if e("LAS_SPELLER_WIDE") == "1" else 0) | \
+        (SPELLER_NO_WIDE if e("LAS_NO_WIDE") == "1" else 0)
     return f, g
 
 
@@ -908,7 +910,7 @@ def rnn_seq_bwd(cell, prec, B, T, H, gates, whh_fw, whh_bw, ldw, out, ld_out, ou
                                        fl, p(status_word(gates.device)), p(ws), ws.numel(), stream()), "las_rnn_seq_bwd_db")
 
 
-SPELLER_FAMILIES = ((1, "loop"), (2, "pf_rows"), (4, "bf_rows"), (8, "f32_rows"), (16, "skinny_cell0"), (32, "loc"), (64, "skinny_upper_cells"))
+SPELLER_FAMILIES = ((1, "loop"), (2, "pf_rows"), (4, "bf_rows"), (8, "f32_rows"), (16, "skinny_cell0"), (32, "loc"), (64, "skinny_upper_cells"), (128, "wide"))
 
 
 def speller_last_variant():

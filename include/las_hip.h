@@ -313,6 +313,11 @@ enum { LAS_SPELLER_ROWS_SHARE4 = 32 };  /* (with LAS_SPELLER_NO_LOGITS; round 5)
                                            (beam search: the hypotheses of one utterance are consecutive rows, beam % 4 == 0): the attention rows of
                                            four hypotheses run in one workgroup that reads Ws, the keys and the encoder rows once -- a quarter of
                                            the step's L2 traffic; bit-identical to one row per workgroup.  B % 4 == 0, tokens >= 0. */
+enum { LAS_SPELLER_WIDE = 64,           /* (round 6) take the wide per-step path (csrc/speller_wide.h: the query projection as one product over all rows, energies and
+                                           context on (slice, utterance) workgroups, every layer's cell product on pre-packed MFMA fragments) wherever its
+                                           geometry allows, also in parity mode; by default it serves the speed mode's multi-layer and location-aware calls
+                                           outside the one-launch loop kernels' geometry (e.g. run.sh's 2 x 1024 decoder at T' = 319) */
+       LAS_SPELLER_NO_WIDE = 128 };     /* never take it (round 5's per-utterance row kernels) */
 #define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
@@ -383,7 +388,8 @@ enum { LAS_SPELLER_RAN_LOOP = 1,       /* the whole decode / gradient loop in on
        LAS_SPELLER_RAN_F32_ROWS = 8,   /* per-step launches, fp32-operand row kernels (parity mode; speed mode outside the other families' geometry) */
        LAS_SPELLER_RAN_SKINNY = 16,    /* layer 0's per-step cell product: pre-packed bf16 MFMA fragments (las_skinny_gemm_bf16) */
        LAS_SPELLER_RAN_LOC = 32,       /* location-aware attention */
-       LAS_SPELLER_RAN_UPPER_SKINNY = 64 };  /* layers >= 1: per-step cell products on pre-packed bf16 fragments (round 6) */
+       LAS_SPELLER_RAN_UPPER_SKINNY = 64,    /* layers >= 1: per-step cell products on pre-packed bf16 fragments (round 6) */
+       LAS_SPELLER_RAN_WIDE = 128 };         /* the wide per-step path (csrc/speller_wide.h, round 6) */
 int las_speller_last_variant(int which);
 
 /* ------------------------------------------------------------------------------------------

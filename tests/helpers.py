@@ -73,6 +73,21 @@ def loc_loop_eligible(args, B, Tp, U, cell="lstm", cus=256):
     return bool(geom and conv and I0D % 8 == 0 and GD % 8 == 0 and B <= 1024 and loop(GD, I0D, 5, 3) and loop(Hd + D, GD, 3, 4))
 
 
+def wide_eligible(args, U, forced=False):
+    """mirror of csrc/speller_wide_host.h wide_selected (speed mode): multi-layer and location-aware training calls (U >= 2, workspace
+    given) outside the one-launch loop kernels' geometry run the wide per-step path, whose arithmetic is the loop kernels' ('bf' rows);
+    `forced`: LAS_SPELLER_WIDE is set (every call whose geometry allows it)"""
+    if U is None or U < 2:
+        return False
+    D, A, E = args.dec_units, args.attention_size, args.embedding_size
+    Hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
+    if A % 8 or Hd % 8 or D % 8 or E % 8 or A > 256:
+        return False
+    if args.mode == "loc" and not (1 <= args.loc_num_channels <= 16):
+        return False
+    return bool(forced or args.num_dec_layers >= 2 or args.mode == "loc")
+
+
 def oracle_mode_for(args, prec, B=None, Tp=None, U=None, cell="lstm"):
     """The oracle arithmetic mode that restates what the HIP path runs for this configuration (oracle.set_precision):
     speed mode rounds every contraction operand to bf16; with additive attention the Speller row kernels also keep
@@ -82,8 +97,11 @@ def oracle_mode_for(args, prec, B=None, Tp=None, U=None, cell="lstm"):
         return ("f32", "bf", False)
     I0D = args.embedding_size + (2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units) + args.dec_units
     hd = 2 * args.enc_units if str(args.enc_type).lower() == "pblstm" else args.enc_units
+    from las import _hip
+    forced = bool(_hip.speller_flags & _hip.SPELLER_WIDE)
+    no_wide = bool(_hip.speller_flags & _hip.SPELLER_NO_WIDE)
     bf_rows = (args.mode == "add" and I0D % 8 == 0 and args.attention_size % 8 == 0 and hd % 8 == 0) or \
-        loc_loop_eligible(args, B, Tp, U, cell)
+        loc_loop_eligible(args, B, Tp, U, cell) or (not no_wide and wide_eligible(args, U, forced))
     # the listener keeps its activations in HBM as bf16 when the MFMA sweeps serve the hidden size
     store = args.enc_units in (64, 128, 256, 512)
     return ("bf16", "bf" if bf_rows else "f32", store)
@@ -131,7 +149,7 @@ def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None,
                 tokens_in=las.speller.last_tokens_in.cpu())
 
 
-def oracle_grads(args, cell, mode, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm"):
+def oracle_grads(args, cell, mode, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", full=False):
     """Gradients (and logits) of the oracle's train step in an explicit arithmetic mode (a set_precision tuple): the second oracle run a
     test needs to measure the ORACLE's own sensitivity to the arithmetic on an input (f32 mode against the bf16-emulating mode)."""
     import torch
@@ -141,11 +159,13 @@ def oracle_grads(args, cell, mode, xs, ys, seed=11, coins=None, sampled=None, en
     try:
         po = O.to_torch(p0, requires_grad=True)
         zeros = {k: torch.zeros_like(v) for k, v in po.items()}
-        _, logits_o, _, g_o, *_ = O.train_step(po, zeros, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
-                                               (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, coins=coins,
-                                               sampled=None if sampled is None else torch.tensor(sampled))
+        loss_o, logits_o, alphas_o, g_o, *_ = O.train_step(po, zeros, {k: torch.zeros_like(v) for k, v in po.items()}, 0,
+                                                           (torch.tensor(xs[0]), xs[1]), (torch.tensor(ys[0]), ys[1]), args, cell, coins=coins,
+                                                           sampled=None if sampled is None else torch.tensor(sampled))
     finally:
         O.set_precision("f32")
+    if full:
+        return g_o, logits_o, alphas_o, float(loss_o)
     return g_o, logits_o
 
 
@@ -232,7 +252,7 @@ def _oracle_fns(xs, p0, args, cell, lm, hoist=True):
             class _Fresh(dict):
                 def __missing__(self, k):
                     return torch.tensor(1.0 if k.endswith("moving_variance") else 0.0)
-            h, el = O.cnn_listener(torch.tensor(xs[0]), xs[1], po, args, cell, False, buffers=_Fresh())
+            h, el = O.cnn_listener(torch.tensor(xs[0]), xs[1], po, args, cell, False, buffers=_Fresh(fresh=True))   # (non-empty: the oracle replaces a falsy dict)
         else:
             x = torch.tensor(xs[0]).reshape(1, -1, 39)
             h, el = O.pblstm_listener(x, xs[1], po, args.num_enc_layers, cell)

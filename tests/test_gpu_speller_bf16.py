@@ -49,8 +49,8 @@ def _run(flags, NL, D, A, Hd2, B, Tp, U, mixed, loc=None):
         grads["enc"] = enc.grad.detach().cpu().clone()
         # oracle, bf16-operand mode; fp32-operand rows (flag 2) keep query / keys / context in fp32
         p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
-        from helpers import loc_loop_eligible
-        bf_rows = not (flags & 2) and (loc is None or loc_loop_eligible(args, B, Tp, U))
+        from helpers import loc_loop_eligible, wide_eligible
+        bf_rows = not (flags & 2) and (loc is None or loc_loop_eligible(args, B, Tp, U) or wide_eligible(args, U))
         O.set_precision("bf16", "bf" if bf_rows else "f32")
         try:
             po = O.to_torch(p0, requires_grad=True)
