@@ -3188,7 +3188,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
 
 #define GEMM_OK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
-static thread_local int g_last_variant[2] = {0, 0};
+static int g_last_variant[2] = {0, 0};     // (process-wide: a backward pass runs on the autograd engine's thread)
 extern "C" int las_speller_last_variant(int which) { return g_last_variant[which ? 1 : 0]; }
 
 // speed mode, additive attention: the row kernels read bf16 copies of Ws / keys / encoder rows (made once per call)

@@ -44,6 +44,7 @@ struct WideDev {
 //     token entering step t, leave the concatenated state row s_t = [h_0 ; ... ; h_{NL-1}] for the query product.
 template <int CELL, bool FAST>
 __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hl = sm;                          // [D]
@@ -90,12 +91,12 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
 
 // f[t', c] = bias[c] + sum_k prev_align[t' + k - pad] w[k, c] for the frames [t0, t0 + nf) of one utterance (conv1d, SAME, cross-correlation:
 // las/layers.py:295-296) -> fc [nf, C] in LDS.  aprev [Tp] and locw [Kc, C] are in LDS; part: nf C ksplit floats of scratch.
+__device__ __forceinline__ int wide_conv_ks(int Kc) { return Kc >= 64 ? 8 : 1; }      // tap slices per (frame, channel) output
 __device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* aprev, const float* locw, float* fc, float* part, int t0, int nf, int tid) {
     const int Tp = a.Tp, C = a.C, Kc = a.Kc, pad = (Kc - 1) / 2, items = nf * C;
-    int ks = items > 0 ? RNT / items : 1;
-    ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    const int ks = wide_conv_ks(Kc);
     const int kper = (Kc + ks - 1) / ks;
-    for (int i = tid; i < items * ks; i += RNT) {
+    for (int i = tid; i < items * ks; i += RNT) {         // (round 6: 640 outputs x 201 serial taps on 640 of 1024 threads was 10 of the kernel's 18 us)
         const int kc = i / items, it = i - kc * items, fr = it / C, c = it - fr * C, tt = t0 + fr;
         int k0 = kc * kper, k1 = k0 + kper < Kc ? k0 + kper : Kc;
         if (k0 < pad - tt) k0 = pad - tt;                       // taps that meet a frame: 0 <= tt + k - pad < Tp
@@ -114,11 +115,10 @@ __device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* ap
 }
 
 struct WideLds { float *aprev, *locw, *wfl, *fc, *dfc, *qv, *ev, *red, *part; };
-// part: the conv's tap-slice partials (< max(RNT, fper C) floats), later the 32 frame groups' dq / du partials (RNG A)
+// part: the conv's tap-slice partials (8 fper C floats), later the 32 frame groups' dq / du partials (RNG A)
 __host__ __device__ __forceinline__ size_t wide_part_floats(int A, int fper, int C) {
     size_t n = (size_t)RNG * A;
-    if (C > 0 && (size_t)RNT > n) n = RNT;
-    if (C > 0 && (size_t)fper * C > n) n = (size_t)fper * C;
+    if (C > 0 && (size_t)8 * fper * C > n) n = (size_t)8 * fper * C;
     return (n + 3) & ~(size_t)3;
 }
 __device__ __forceinline__ WideLds wide_carve(float* sm, const DecDev& a, int fper) {
@@ -158,6 +158,7 @@ __device__ __forceinline__ float4 wide_key4(const DecDev& a, int b, int tt, int 
 //     slice's softmax statistics (max, sum of exp).  grid (nsplit, B).
 template <bool FAST, bool LOC>
 __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const WideLds L = wide_carve(sm, a, w.fper);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
 //     row [emb(token) ; context ; h_0] (fp32 for the weight gradients, bf16 as the product's A operand).  grid (hsplit, B).
 template <bool FAST>
 __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hs_ = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, D = a.D, E = a.E, V = a.V, U = a.U, I0D = E + Hd + D, H4 = Hd / 4;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
 // gate nonlinearity of layer `layer` (< TOP) at step t, and the bf16 input row of the layer above: [h_{layer, t+1} ; h_{layer+1, t}]
 template <int CELL, bool FAST>
 __global__ __launch_bounds__(256) void wide_pointwise_fwd_kernel(DecDev a, WideDev w, int layer, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     const int b = blockIdx.x, B = a.B, D = a.D, U = a.U, GD = G * D;
     float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256) void wide_pointwise_fwd_kernel(DecDev a, WideD
 //     alpha . d alpha.  grid (nsplit, B).
 template <bool FAST, bool LOC>
 __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dctx = sm;                                  // [Hd]
     float* red = sm + ((a.Hd + 3) & ~3);               // [32]
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
 //     d f[t', c] = sum_a dv[a] Wf[c, a] (kept for the conv's transpose and the filter gradient).  grid (nsplit, B).
 template <bool FAST, bool LOC>
 __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const WideLds L = wide_carve(sm, a, w.fper);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -497,59 +502,67 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
     }
 }
 
-// (3) one workgroup per utterance: dq = sum of the slices' partials (-> dQ of the step, bf16 operand row of d s = dq . Ws^T), du, and the
-//     conv's transpose d alpha_{t-1}[src] = sum_k sum_c d f[src - k + pad, c] w[k, c] from the step's d f rows.
+// (3) dq = sum of the slices' partials (-> dQ of the step, bf16 operand row of d s = dq . Ws^T) and du (slice 0 of an utterance), and the
+//     conv's transpose d alpha_{t-1}[src] = sum_k sum_c d f[src - k + pad, c] w[k, c] for the source frames of slice s from the step's d f
+//     rows.  grid (nsplit, B)  (first version: one workgroup per utterance -- 319 x 201 x 10 multiply-adds on 48 CUs, 31.7 us per step).
 template <bool FAST, bool LOC>
 __global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.x, tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
-    for (int i = tid; i < A; i += RNT) {
-        float dq = 0.f, du = 0.f;
-        for (int s = 0; s < w.nsplit; ++s) {
-            dq += w.pdq[((size_t)b * w.nsplit + s) * A + i];
-            du += w.pdu[((size_t)b * w.nsplit + s) * A + i];
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    if (s == 0) {
+        for (int i = tid; i < A; i += RNT) {
+            float dq = 0.f, du = 0.f;
+            for (int q = 0; q < w.nsplit; ++q) {
+                dq += w.pdq[((size_t)b * w.nsplit + q) * A + i];
+                du += w.pdu[((size_t)b * w.nsplit + q) * A + i];
+            }
+            a.dQ[((size_t)t * B + b) * A + i] = dq;
+            if (FAST) w.dqbf[(size_t)b * A + i] = f2bf(dq);
+            a.duRows[(size_t)b * A + i] += du;
         }
-        a.dQ[((size_t)t * B + b) * A + i] = dq;
-        if (FAST) w.dqbf[(size_t)b * A + i] = f2bf(dq);
-        a.duRows[(size_t)b * A + i] += du;
     }
     if (LOC && t > 0) {
-        float* dfc = sm;                                   // [Tp, C]
-        float* locw = dfc + ((Tp * C + 3) & ~3);           // [Kc, C]
-        float* part = locw + ((a.Kc * C + 3) & ~3);        // [NKC, Tp]
-        const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
-        for (int i = tid; i < Tp * C; i += RNT) dfc[i] = ds[i];
-        for (int i = tid; i < a.Kc * C; i += RNT) locw[i] = a.loc_w[i];
+        const int Kc = a.Kc, pad = (Kc - 1) / 2;
+        const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+        if (nf <= 0) return;
+        // d f rows that reach the slice's source frames: src - k + pad for k in [0, Kc)
+        const int lo = t0 - (Kc - 1 - pad) > 0 ? t0 - (Kc - 1 - pad) : 0, hi = t0 + nf + pad < Tp ? t0 + nf + pad : Tp;
+        float* dfc = sm;                                         // [hi - lo, C]
+        float* locw = dfc + (((w.fper + Kc) * C + 3) & ~3);      // [Kc, C]
+        float* part = locw + ((Kc * C + 3) & ~3);                // [NKC, nf]
+        const float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + lo) * C;
+        for (int i = tid; i < (hi - lo) * C; i += RNT) dfc[i] = ds[i];
+        for (int i = tid; i < Kc * C; i += RNT) locw[i] = a.loc_w[i];
         __syncthreads();
-        const int pad = (a.Kc - 1) / 2;
-        const int NKC = RNT / Tp > 0 ? (RNT / Tp < 8 ? RNT / Tp : 8) : 1;
-        const int kper = (a.Kc + NKC - 1) / NKC;
-        for (int i = tid; i < NKC * Tp; i += RNT) {
-            const int kc = i / Tp, src = i - kc * Tp;
-            int k0 = kc * kper, k1 = k0 + kper < a.Kc ? k0 + kper : a.Kc;
+        int NKC = RNT / nf;
+        NKC = NKC < 1 ? 1 : (NKC > 16 ? 16 : NKC);
+        const int kper = (Kc + NKC - 1) / NKC;
+        for (int i = tid; i < NKC * nf; i += RNT) {
+            const int kc = i / nf, src = t0 + (i - kc * nf);
+            int k0 = kc * kper, k1 = k0 + kper < Kc ? k0 + kper : Kc;
             if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
             if (k1 > src + pad + 1) k1 = src + pad + 1;
             float acc = 0.f;
             for (int k = k0; k < k1; ++k) {
-                const float* dr = dfc + (src - k + pad) * C;
+                const float* dr = dfc + (src - k + pad - lo) * C;
                 const float* wr = locw + k * C;
                 for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
             }
             part[i] = acc;
         }
         __syncthreads();
-        for (int src = tid; src < Tp; src += RNT) {
+        for (int j = tid; j < nf; j += RNT) {
             float acc = 0.f;
-            for (int kc = 0; kc < NKC; ++kc) acc += part[kc * Tp + src];
-            a.dAext[(size_t)b * Tp + src] = acc;
+            for (int kc = 0; kc < NKC; ++kc) acc += part[kc * nf + j];
+            a.dAext[(size_t)b * Tp + t0 + j] = acc;
         }
     }
 }
-static size_t wide_dq_lds_bytes(const DecDev& a) {
+static size_t wide_dq_lds_bytes(const DecDev& a, int fper) {
     if (a.mode != LAS_ATT_LOC) return 64;
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
-    const int NKC = RNT / a.Tp > 0 ? (RNT / a.Tp < 8 ? RNT / a.Tp : 8) : 1;
-    return (u4((size_t)a.Tp * a.C) + u4((size_t)a.Kc * a.C) + (size_t)NKC * a.Tp) * sizeof(float) + 64;
+    return (u4((size_t)(fper + a.Kc) * a.C) + u4((size_t)a.Kc * a.C) + (size_t)16 * fper + 4) * sizeof(float) + 64;
 }
 
 // (4) gate backward of `layer` at step t: dh = [recurrent gradient from step t+1] + [d s of step t+1's attention] + extra (top layer:
@@ -558,6 +571,7 @@ static size_t wide_dq_lds_bytes(const DecDev& a) {
 template <int CELL, bool FAST>
 __global__ __launch_bounds__(256) void wide_cell_bwd_kernel(DecDev a, WideDev w, int layer, int t, const float* rec, int rec_ld, int rec_off,
                                                             const float* dS, const float* extra, int extra_ld, unsigned short* gb_) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     constexpr int G = CELL == LAS_CELL_LSTM ? 4 : 1;
     const int b = blockIdx.x, B = a.B, D = a.D, U = a.U, GD = G * D, S = D * a.NL;
     float* gp = a.gates + (((size_t)layer * U + t) * B + b) * GD;

@@ -89,18 +89,18 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     }
     const size_t lds_a = (size_t)(((Hd + 3) & ~3) + 64) * sizeof(float) + 64;
     const size_t lds_e = wide_lds_bytes(d, w.fper);
-    const size_t lds_q = wide_dq_lds_bytes(d);
+    const size_t lds_q = wide_dq_lds_bytes(d, w.fper);
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
             if (loc) {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
                 WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
-                WIDE_LAUNCH((wide_dq_kernel<FAST, true>), dim3(B), dim3(RNT), lds_q, st, d, w, ta);
+                WIDE_LAUNCH((wide_dq_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_q, st, d, w, ta);
             } else {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
                 WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
-                WIDE_LAUNCH((wide_dq_kernel<FAST, false>), dim3(B), dim3(RNT), lds_q, st, d, w, ta);
+                WIDE_LAUNCH((wide_dq_kernel<FAST, false>), dim3(1, B), dim3(RNT), lds_q, st, d, w, ta);
             }
             if (ta > 0) {    // d s_{t+1} = dq . Ws^T: the gradient of every layer's state that entered step t + 1
                 if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, nullptr, st));

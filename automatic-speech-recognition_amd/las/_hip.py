@@ -915,7 +915,7 @@ SPELLER_FAMILIES = ((1, "loop"), (2, "pf_rows"), (4, "bf_rows"), (8, "f32_rows")
 
 def speller_last_variant():
     """{'fwd': [...], 'bwd': [...]}: the kernel families that served this thread's last las_speller_fwd / las_speller_bwd_part(1)
-    (las_speller_last_variant; bench.py and the tests name the family a number or a parity statement belongs to)."""
+    (las_speller_last_variant, process-wide; bench.py and the tests name the family a number or a parity statement belongs to)."""
     l = lib()
     out = {}
     for name, which in (("fwd", 0), ("bwd", 1)):

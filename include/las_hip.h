@@ -379,7 +379,7 @@ int las_speller_bwd(const las_speller_bwd_args* a, void* stream);
  *   part 2 = every parameter gradient (reads what part 1 left in `ws`, `gates`, `xin0`, `hs`; may run on another
  *            stream ordered after part 1);   part 3 = both (= las_speller_bwd). */
 int las_speller_bwd_part(const las_speller_bwd_args* a, int part, void* stream);
-/* Which kernel family served the calling thread's LAST las_speller_fwd (which = 0) / las_speller_bwd* part 1 (which = 1): a bit mask.  The
+/* Which kernel family served the process's LAST las_speller_fwd (which = 0) / las_speller_bwd* part 1 (which = 1): a bit mask.  The
  * reference has ONE Speller graph (las/las.py:72-160); this library picks among several kernel families by geometry, and a caller (bench.py,
  * the tests) must be able to say which one a number or a parity statement belongs to. */
 enum { LAS_SPELLER_RAN_LOOP = 1,       /* the whole decode / gradient loop in one launch (dec_loop_*_kernel) */

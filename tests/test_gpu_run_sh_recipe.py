@@ -68,6 +68,13 @@ def test_run_sh_recipe_train_step_matches_oracle(cell, prec):
     errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(), alphas=(r["alphas"] - r["alphas_o"]).abs().max().item(),
                 loss=abs(r["loss"] - r["loss_o"]) / max(1.0, abs(r["loss_o"])))
     ge = grad_errors(r)
+    # A dense bias in front of a batch normalisation (las/layers.py:155-161: dense -> relu(bn(.))) has an IDENTICALLY ZERO gradient -- the
+    # normalisation removes any per-channel shift -- so what either side holds there is the rounding noise of a cancelling sum (oracle ~1e-7;
+    # speed mode, where the summed d(pre-activation) rows live in HBM as bf16: ~5e-4).  Held to an absolute bound, not to a ratio of two noises.
+    for n in [k for k in ge if k.startswith("Listener/blstm_") and k.endswith("/dense/bias")]:
+        assert float(r["g_o"][n].abs().max()) < 1e-5 and float(r["grads"][n].abs().max()) < (1e-5 if prec == "f32" else 5e-3), (n, float(r["grads"][n].abs().max()))
+        del ge[n]
+        r["names"] = [k for k in r["names"] if k != n]
     worst = max(ge, key=ge.get)
     agree = (r["logits"].argmax(-1) == r["logits_o"].argmax(-1)).float().mean().item()
     rec = dict(prec=prec, cell=cell, B=4, T=1274, Tp=319, U=U, worst_grad=worst, worst_grad_err=ge[worst], token_agreement=agree,

@@ -3,7 +3,7 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-LAS_PARITY_LOG=$PWD/gpurun_out/r6b_parity.jsonl timeout 1500 python3 -m pytest tests/test_gpu_speller_wide.py tests/test_gpu_run_sh_recipe.py "tests/test_gpu_speller_bf16.py::test_bf16_row_kernels_match_oracle" tests/test_gpu_speller_bf16.py::test_location_aware_loop_kernels_match_oracle -q -rs -s -x 2>&1 | grep -v amdgpu.ids > gpurun_out/r6b_pytest.log
+LAS_PARITY_LOG=$PWD/gpurun_out/r6b_parity.jsonl timeout 1500 python3 -m pytest tests/test_gpu_run_sh_recipe.py "tests/test_gpu_speller_bf16.py::test_bf16_row_kernels_match_oracle" tests/test_gpu_speller_bf16.py::test_location_aware_loop_kernels_match_oracle -q -rs -s 2>&1 | grep -v amdgpu.ids > gpurun_out/r6b_pytest.log
 tail -60 gpurun_out/r6b_pytest.log
 timeout 600 python3 bench.py --only-leg run_sh --steps 5 --warmup 2 > gpurun_out/r6b_run_sh.json 2> gpurun_out/r6b_run_sh.err; cat gpurun_out/r6b_run_sh.json; tail -3 gpurun_out/r6b_run_sh.err
 for c in rnn lstm; do
