@@ -187,10 +187,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ thet
                                                         float* __restrict__ m, float* __restrict__ v, long long n,
                                                         const float* __restrict__ sumsq, float clip, float lr_t, float b1,
                                                         float b2, float eps, const int* __restrict__ status,
-                                                        const float* __restrict__ guard) {
+                                                        const float* __restrict__ guard, int* __restrict__ applied) {
     // a recurrent sweep of this step reported a time-out (status) -- on this rank or, through the all-reduced guard slot, on
     // any rank: the gradients are garbage, leave theta / m / v alone (uniform branch: every thread reads the same words)
     if ((status && status[0] != 0) || (guard && guard[0] != 0.f)) return;
+    if (applied && blockIdx.x == 0 && threadIdx.x == 0) applied[0] += 1;      // (one launch at a time per parameter bucket: no atomic needed)
     float gs = 1.f;
     if (clip > 0.f) {   // g * clip / max(norm, clip)   
         const float nrm = sqrtf(sumsq[0]);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ thet
 }
 
 extern "C" int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n, const float* sumsq, float clip,
-                             float lr_t, float beta1, float beta2, float eps, const int* status, const float* guard, void* stream) {
+                             float lr_t, float beta1, float beta2, float eps, const int* status, const float* guard, int* applied, void* stream) {
     LAS_ARG(theta && g && m && v && n >= 0, "las_clip_adam: bad arguments");
     LAS_ARG(clip <= 0.f || sumsq, "las_clip_adam: clipping needs sumsq");
     LAS_ARG(((((uintptr_t)theta) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
@@ -232,7 +233,7 @@ extern "C" int las_clip_adam(float* theta, const float* g, float* m, float* v, l
     int nb = cdiv(n / 4 + 1, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(clip_adam_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, sumsq, clip, lr_t,
-                       beta1, beta2, eps, status, guard);
+                       beta1, beta2, eps, status, guard, applied);
     LAS_LAUNCHED();
     return 0;
 }

@@ -173,7 +173,7 @@ class CharRNN(object):
             wss = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
             _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(wss), wss.numel(), _hip.stream()), "las_sumsq")
             _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n, _hip.p(sumsq),
-                                         self.max_grad_norm, lr_t, b1, b2, eps, None, None, _hip.stream()), "las_clip_adam")
+                                         self.max_grad_norm, lr_t, b1, b2, eps, None, None, None, _hip.stream()), "las_clip_adam")
             st.weights_changed()
             self.global_step += 1
         return mean_loss, new_state

@@ -135,7 +135,7 @@ _SIGS = {
     "las_sumsq_workspace_bytes": (c_size_t, [c_longlong]),
     "las_sumsq": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_size_t, c_void_p]),
     "las_clip_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float, c_float,
-                              c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+                              c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "las_build_shadows": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_word": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "las_wait_announce": (c_int, [c_void_p, c_int, c_int, c_void_p]),
@@ -768,20 +768,23 @@ def check_status(dev=None):
 _probe = {}
 
 
-def poll_status(dev):
+def poll_status(dev, raise_on_error=True):
     """Non-blocking companion of check_status for callers that never wait for the device (LAS.train called in a loop
     without reading the loss): enqueue a copy of the status word to pinned host memory; when an EARLIER probe has
-    completed with a non-zero code, raise.  A timeout is therefore reported at most a couple of steps late."""
+    completed with a non-zero code, raise (or, raise_on_error=False, return the code: LAS.train then re-runs the lost steps,
+    LAS._recover).  A timeout is therefore reported at most a couple of steps late.  Returns 0 when nothing is known to be wrong."""
     key = _devkey(dev)
     if key not in _status:
-        return
+        return 0
     pr = _probe.get(key)
     if pr is not None and pr[1].query():
         code = int(pr[0][0])
         if code:
-            _status[key].zero_()
             _probe.pop(key, None)
-            raise RuntimeError("liblas_hip recurrent sweep failed on %s (status %d): %s" % (key, code, SEQ_STATUS.get(code, "unknown")))
+            if not raise_on_error:
+                return code                      # (the word stays set: the device keeps skipping updates until the caller has recovered)
+            _status[key].zero_()
+            raise RuntimeError(status_message(key, code))
         pr = None
     if pr is None:
         pin = torch.zeros(2, dtype=torch.int32).pin_memory()
@@ -789,6 +792,19 @@ def poll_status(dev):
         pin.copy_(_status[key], non_blocking=True)
         ev.record()
         _probe[key] = (pin, ev)
+    return 0
+
+
+def status_message(key, code):
+    return "liblas_hip recurrent sweep failed on %s (status %d): %s" % (key, code, SEQ_STATUS.get(code, "unknown"))
+
+
+def clear_status(dev):
+    """Zero the device's status word (after the caller has dealt with what it reported) and forget any probe in flight."""
+    key = _devkey(dev)
+    if key in _status:
+        _status[key].zero_()
+    _probe.pop(key, None)
 
 
 def rnn_seq_ws(cell, prec, H, B, dev):

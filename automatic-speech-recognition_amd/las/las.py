@@ -21,6 +21,7 @@ from las.parallel import sampling_seed
 from las.utils import convert_idx_to_token_tensor
 
 SOS_ID = 1  # tf.ones(...) look-up at reference las/las.py:81
+RECOVER_STEPS = os.environ.get("LAS_NO_STEP_RECOVERY") != "1"     # LAS.train re-runs steps lost to a residency time-out (single process)
 
 
 class Listener:
@@ -546,6 +547,14 @@ class LAS:
         self.dp = None            # optional las.parallel.DataParallel (set by train.py)
         self.last = {}
         self.last_variants = {}   # layers.VARIANTS of the last train step: which cross-stream hand-overs it used
+        import collections
+        self._recent = collections.deque(maxlen=6)   # (global step, batch) of the newest steps: what _recover can re-run
+        self._pending_status = 0
+        self._step_ends = collections.deque()        # events at the ends of the newest steps (bounds the host's run-ahead)
+        self._fallback_until = -1  # global step up to which steps run on las.layers.fallback_schedule (set by _recover)
+        self._backoff = 16
+        self._warned_recover = False
+        self.recovered_steps = 0  # steps re-run after a time-out status (tests / logs)
 
     # -- helpers -----------------------------------------------------------------------------------
     @staticmethod
@@ -614,10 +623,79 @@ class LAS:
 
         Returns (loss, train_op, global_step, logits, alphas, summaries, sample_rate) -- `train_op`
         is None (the update has already been applied), `summaries` a dict of the quantities the
-        reference attaches to tf.summary (las/las.py:292-299)."""
+        reference attaches to tf.summary (las/las.py:292-299).
+
+        Round 6: a recurrent sweep or a one-launch Speller loop whose workgroups were not all resident (a
+        neighbour on the device: a monitoring agent's kernel, a user's second stream) reports through the status word, and the
+        device skips that step's update and -- the word is sticky -- every later one.  Instead of raising, a single-process run
+        re-runs the lost steps: the first of them on the schedule that needs no co-residency (per-step Speller launches, no
+        cross-stream hand-overs), the others as usual -- see _recover."""
+        out = self._train_step(xs, ys, coins, sampled)
+        code = self._pending_status
+        self._pending_status = 0
+        if code:
+            out = self._recover(code) or out
+        return out
+
+    def _recover(self, code):
+        """The device reported a time-out (`code`) some steps ago.  Everything it has been asked to do since then was computed
+        but NOT applied (las_clip_adam's guard; the status word stays set until the host clears it), and `store.applied` counts the
+        updates that were: the first lost step is the `applied`-th optimiser launch.  Re-run from there on the batches kept in
+        `_recent`, on the fall-back schedule (las.layers.fallback_schedule: per-step Speller launches, no cross-stream hand-overs --
+        nothing that needs every CU or a partner stream), and STAY on it for `_backoff` steps (a neighbour that was there once is
+        probably still there; the back-off doubles with every recovery, up to 4096 steps) before the fast schedule is tried again.
+        Returns the result of the newest re-run step.  Raises (as rounds 1-5 did) when the lost step is older than what was kept, or
+        when a step fails on the fall-back schedule too."""
+        import warnings
+        dev = self._device()
+        st = V.default_store()
+        torch.cuda.synchronize(dev)
+        msg = _hip.status_message(str(dev), code)
+        n_applied = int(st.applied.item()) - st.adam_base if st.applied is not None else -1
+        first = st.adam_launches[n_applied] if 0 <= n_applied < len(st.adam_launches) else None
+        todo = [e for e in self._recent if first is not None and e[0] >= first]
+        _hip.clear_status(dev)
+        on_fallback = first is not None and first < self._fallback_until
+        if not todo or todo[0][0] != first or on_fallback:
+            raise RuntimeError(msg + " -- the cluster workgroups were not all resident (shared / partitioned GPU?); the lost step could "
+                               "not be re-run (%s)" % ("it was already on the fall-back schedule" if on_fallback else "its batch is no longer held"))
+        if not self._warned_recover:
+            self._warned_recover = True
+            warnings.warn(msg + " -- re-running %d step(s) from global step %d on the per-step kernels (no co-residency needed) and staying "
+                          "on them for %d steps.  Another kernel was resident on the device; this warning is printed once."
+                          % (len(todo), first, self._backoff))
+        self.recovered_steps += len(todo)
+        st.global_step = first
+        st.adam_launches = st.adam_launches[:n_applied]
+        self._recent.clear()
+        self._fallback_until = first + self._backoff
+        self._backoff = min(2 * self._backoff, 4096)
+        out = None
+        for gs, xs, ys, coins, sampled in todo:
+            out = self._train_step(xs, ys, coins, sampled)
+        torch.cuda.synchronize(dev)                  # the re-run steps must have gone through before anything is built on them
+        self._pending_status = 0
+        code2 = int(_hip.status_word(dev)[0].item())
+        if code2:
+            _hip.clear_status(dev)
+            raise RuntimeError(_hip.status_message(str(dev), code2) + " -- again, on the fall-back schedule: the device cannot hold the "
+                               "recurrent sweeps' clusters beside what else is running on it")
+        return out
+
+    def _train_step(self, xs, ys, coins=None, sampled=None):
+        with L.fallback_schedule(V.default_store().global_step < self._fallback_until):
+            return self._train_step_impl(xs, ys, coins, sampled)
+
+    def _train_step_impl(self, xs, ys, coins=None, sampled=None):
         dev = self._device()
         st = V.default_store()
         self.build_variables()
+        if self.dp is None and RECOVER_STEPS:
+            # the host may run ahead of the device, but not further than _recover can reach back: wait for the end of the step four
+            # steps ago (normally long past -- the host is one or two steps ahead -- so this costs nothing; behind a time-out, whose
+            # bounded polls take a second to drain, it keeps the host from enqueueing hundreds of steps that will all be skipped)
+            if len(self._step_ends) >= 4:
+                self._step_ends.popleft().synchronize()
         audio, audiolen = xs
         y, tokenlen = ys
         audio = self._to_dev(audio, dev, torch.float32)
@@ -632,6 +710,15 @@ class LAS:
         # ... and on the auxiliary ("chain") stream: a dozen tiny kernels (0.1 ms back to back) that only the Speller and the
         # backward pass need run next to the first Listener sweep instead of in front of it
         with _hip.on_chain_stream():
+            if self.dp is None and RECOVER_STEPS:
+                # what _recover needs to re-run this step: the batch as it is NOW.  A caller may hand in device tensors that it overwrites
+                # a few steps later (las.input_pipeline.DeviceFeeder keeps a ring of three device slots): those are copied -- here, on the
+                # auxiliary stream beside the first Listener sweep, off the dependency chain; tensors this call made itself are held as is
+                a_hold = audio.clone() if (torch.is_tensor(xs[0]) and xs[0].is_cuda) else audio
+                y_hold = y.clone() if (torch.is_tensor(ys[0]) and ys[0].is_cuda) else y
+                self._recent.append((st.global_step, (a_hold, np.array(torch.as_tensor(audiolen).cpu(), copy=True)),
+                                     (y_hold, np.array(torch.as_tensor(tokenlen).cpu(), copy=True)),
+                                     None if coins is None else np.array(coins, copy=True), None if sampled is None else np.array(torch.as_tensor(sampled).cpu(), copy=True)))
             st.zero_grad()
             n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
             n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local
@@ -693,7 +780,14 @@ class LAS:
                                            global_step=st.global_step)
         with _hip.roctx_range("clip + adam"):
             self._apply_adam(st, lr)
-        _hip.poll_status(dev)                         # a sweep exchange timeout of an earlier step surfaces here
+        # a sweep / Speller-loop time-out of an earlier step surfaces here: raised under data parallelism (the ranks would have to agree
+        # on what to re-run), handed to train() otherwise
+        recover = self.dp is None and RECOVER_STEPS
+        self._pending_status = _hip.poll_status(dev, raise_on_error=not recover)
+        if recover:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._step_ends.append(ev)
         st.global_step += 1
         sample_rate = self.speller._scheduled_sampling()
         summaries = {"loss": loss_val, "global_step": st.global_step, "lr": lr}
@@ -712,9 +806,15 @@ class LAS:
         if clip > 0:
             ws = _hip.workspace(dev, lib.las_sumsq_workspace_bytes(n), "sumsq")
             _hip.check(lib.las_sumsq(_hip.p(st.flat_grad), n, _hip.p(sumsq), _hip.p(ws), ws.numel(), _hip.stream()), "las_sumsq")
+        if st.applied is None:
+            st.applied = torch.zeros(1, dtype=torch.int32, device=dev)
+            st.adam_launches, st.adam_base = [], 0
+        if len(st.adam_launches) >= 4096:                            # (bounded bookkeeping: the device counter keeps counting)
+            st.adam_launches, st.adam_base = st.adam_launches[2048:], st.adam_base + 2048
+        st.adam_launches.append(st.global_step)
         _hip.check(lib.las_clip_adam(_hip.p(st.flat), _hip.p(st.flat_grad), _hip.p(st.adam_m), _hip.p(st.adam_v), n,
                                      _hip.p(sumsq), clip if clip > 0 else 0.0, lr_t, beta1, beta2, eps,
-                                     _hip.p(_hip.status_word(dev)), _hip.p(st.guard), _hip.stream()),
+                                     _hip.p(_hip.status_word(dev)), _hip.p(st.guard), _hip.p(st.applied), _hip.stream()),
                    "las_clip_adam")
         st.weights_changed()                          # bf16 weight shadows / prepared sweep workspaces are rebuilt from the updated masters
         self.last_grad_sumsq = sumsq
@@ -746,8 +846,16 @@ class LAS:
         return self.train((audio, audiolen), (y, tokenlen), coins=coins, sampled=sampled)
 
     def check_status(self):
-        """Synchronising check that no recurrent sweep reported an exchange timeout (raises RuntimeError)."""
-        _hip.check_status(self._device())
+        """Synchronising check that no recurrent sweep / Speller loop reported a time-out: the lost steps are re-run (_recover; single
+        process) or RuntimeError is raised."""
+        dev = self._device()
+        if self.dp is None and RECOVER_STEPS and self._recent:
+            torch.cuda.synchronize(dev)
+            code = int(_hip.status_word(dev)[0].item())
+            if code:
+                self._recover(code)
+            return
+        _hip.check_status(dev)
 
     def sample_texts(self):
         """The HYP / REF strings the reference builds for its text summaries (las/las.py:286-289)."""

@@ -487,6 +487,30 @@ VARIANTS = {"xproj_chunks": 0, "dense_chunks": 0, "dout_chunks": 0, "hold_side":
             "prepared_sweeps": 0, "tail_windows": 0, "tail_follow": 0, "prepare_behind_now": 0}     # prepared_sweeps: sweeps that found their pack + clean exchange state ready (las_rnn_seq_prepare; from a model's second step on: all)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def fallback_schedule(on=True):
+    """The schedule LAS._recover re-runs a lost step on: nothing in it needs workgroups of DIFFERENT launches (or more workgroups than a
+    busy device can place at once) to be co-resident -- the Speller as per-step launches (LAS_SPELLER_NO_FUSED_STEP: the prefetching rows /
+    the wide path, same arithmetic family as the loop kernels), every x-projection and upstream gradient complete in front of its sweep
+    (no chunk hand-overs across streams), no held side stream, sweeps packing for themselves.  The recurrent sweeps themselves keep
+    their clusters (2-8 workgroups each on 48-60 of the 256 CUs: they fit beside a neighbour; the hand-overs are what a stalled
+    partner stream breaks)."""
+    global XPROJ_CHUNK_STEPS, DOUT_CHUNK_ROWS, HOLD_SIDE, PREPARED_SWEEPS, TAIL_WINDOW
+    if not on:
+        yield
+        return
+    saved = (XPROJ_CHUNK_STEPS, DOUT_CHUNK_ROWS, HOLD_SIDE, PREPARED_SWEEPS, TAIL_WINDOW, _hip.speller_flags)
+    XPROJ_CHUNK_STEPS, DOUT_CHUNK_ROWS, HOLD_SIDE, PREPARED_SWEEPS, TAIL_WINDOW = 0, 0, False, False, 0
+    _hip.speller_flags = _hip.speller_flags | _hip.SPELLER_NO_FUSED_STEP
+    try:
+        yield
+    finally:
+        XPROJ_CHUNK_STEPS, DOUT_CHUNK_ROWS, HOLD_SIDE, PREPARED_SWEEPS, TAIL_WINDOW, _hip.speller_flags = saved
+
+
 def begin_step(dev):
     """Called by LAS.train at the start of a step (all streams of the previous step joined): ONE fill zeroes the whole ring of
     hand-over words instead of one 5 us fill in front of every sweep and every chunked dense product (11 per step, on the chain)."""

@@ -34,6 +34,9 @@ class VariableStore:
         self.seq_ready = {}       # ... -> batch rows it has been prepared for since the weights last changed (consumed by ONE sweep)
         self.seq_prep_done = None  # event behind the side-stream prepare launch until the launch stream has waited for it
         self.weights_epoch = 0    # counts weights_changed() calls: an ordering event is only good for the epoch it was recorded in
+        self.applied = None       # device int: optimiser updates the device really applied (las_clip_adam skips a step whose status word is set)
+        self.adam_launches = []   # global_step of the las_clip_adam launches number adam_base, adam_base + 1, ... (bounded: LAS._apply_adam)
+        self.adam_base = 0
 
     def weights_changed(self, storage_moved=False):
         """Everything derived from the parameter VALUES is stale (optimiser step, load); storage_moved: their addresses too (flatten)."""

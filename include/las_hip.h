@@ -420,6 +420,10 @@ int las_ce_loss(const float* logits, long long sb, long long st, const int* y, i
  * status / guard (either may be NULL): device words checked by the kernel itself -- when status[0] != 0 (a recurrent sweep
  * of this step reported an exchange time-out, LAS_SEQ_STATUS_*) or guard[0] != 0 (the same, summed over the data-parallel
  * ranks with the gradient bucket) the update is SKIPPED: theta, m, v keep their values, no host synchronisation needed.
+ * applied (may be NULL; round 6): a device int that the kernel increments when -- and only when -- it DOES apply the update.  The status
+ * word is sticky until the host clears it, so after a time-out every later step is skipped too: when the host finally notices (its
+ * polls are asynchronous), applied[0] tells it exactly which step was the first one lost, and LAS.train re-runs from there
+ * (las/las.py LAS._recover).
  */
 /* Stream-ordered, BOUNDED wait on a device word: work enqueued behind it on `stream` starts once *word == value or after
  * max_us microseconds.  A scheduling aid (never a correctness dependency): the weight-gradient GEMMs of a side stream are
@@ -454,7 +458,7 @@ size_t las_sumsq_workspace_bytes(long long n);
 int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream);
 int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
                   const float* sumsq, float clip, float lr_t, float beta1, float beta2, float eps,
-                  const int* status, const float* guard, void* stream);
+                  const int* status, const float* guard, int* applied, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * R1  one BasicLSTMCell step of the char RNNLM used for shallow fusion (lang/char_rnn_model.py:57-66 with
