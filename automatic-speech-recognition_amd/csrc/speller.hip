@@ -54,6 +54,7 @@ struct LoopProd {
 
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
+    int row_group;         // > 0: rows u rg .. u rg + rg - 1 share enc / keys (beam search: one utterance's hypotheses) -> XCD-local row workgroups
     LoopProd lp;
     float fb;
     unsigned long long seed;
@@ -1289,11 +1290,27 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     STAMPX(8);
 }
 
+// Round 6: a beam search's hypothesis rows u rg .. u rg + rg - 1 read the SAME keys and encoder rows (205 KB per
+// utterance at the bench geometry).  Workgroup i is dispatched to XCD i % 8, each XCD has its own L2, and with row = workgroup id an
+// utterance's 16 rows landed on all 8 XCDs: every L2 fetched every utterance's operands at every step (54 MB per launch at 256 rows against
+// 3.3 MB of distinct operands, r5_decode_pmc.json).  Here utterance u lives on XCD u % 8: row-workgroup j (with `off` workgroups in front
+// of it in the grid) serves row (x + 8 k) rg + r with x = (j + off) % 8, k = (j / 8) / rg, r = (j / 8) % rg -- a bijection onto the rows
+// when the grid holds 8 rg ceil(nutt / 8) row workgroups (the ones whose utterance does not exist leave at once).  -1: no row.
+__device__ __forceinline__ int xcd_local_row(int j, int off, int rg, int nrows) {
+    if (rg <= 0) return j < nrows ? j : -1;
+    const int x = (j + off) & 7, slot = j >> 3, k = slot / rg, r = slot - k * rg;
+    const int b = (x + 8 * k) * rg + r;
+    return b < nrows ? b : -1;
+}
+static int xcd_local_grid(int nrows, int rg) { return rg > 0 ? 8 * rg * cdiv(nrows / rg, 8) : nrows; }
+
 template <int CELL, int NE>
 __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_kernel(DecDev a, int t) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float ccar = 0.f;
-    pf_fwd_row<CELL, NE, false>(a, t, blockIdx.x, threadIdx.x, sm, ccar, false);
+    const int b = xcd_local_row(blockIdx.x, 0, a.row_group, a.B);
+    if (b < 0) return;
+    pf_fwd_row<CELL, NE, false>(a, t, b, threadIdx.x, sm, ccar, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1324,7 +1341,9 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
     const int h4 = tid & 127, fg = tid >> 7;           // context:  128 lanes x 4 columns per frame pair
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, A = a.A, D = a.D, E = a.E, V = a.V;
     const int I0D = E + Hd + D, A8 = A >> 3, A4 = A >> 2, H4 = Hd >> 2, S2 = (D + 1) >> 1, Tp2 = (Tp + 1) >> 1;
-    const int b0 = blockIdx.x * R;
+    const int g0 = xcd_local_row(blockIdx.x, 0, a.row_group / R, B / R);       // (a group of four rows = one "row" of the mapping)
+    if (g0 < 0) return;
+    const int b0 = g0 * R;
     auto u4 = [](int x) { return (x + 3) & ~3; };
     float* s_state = sm;                                                          // [R][D]
     unsigned* sp = reinterpret_cast<unsigned*>(s_state + R * u4(D));              // [R][S2] packed state pairs
@@ -1521,7 +1540,9 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_pf_lm_kernel(DecDev a, int t
         return;
     }
     float ccar = 0.f;
-    pf_fwd_row<CELL, NE, false>(a, t, (int)blockIdx.x - nlm, threadIdx.x, sm, ccar, false);
+    const int b = xcd_local_row((int)blockIdx.x - nlm, nlm, a.row_group, a.B);
+    if (b < 0) return;
+    pf_fwd_row<CELL, NE, false>(a, t, b, threadIdx.x, sm, ccar, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3172,6 +3193,7 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.B = f->B; d.Tp = f->Tp; d.Hd = f->Hd; d.A = f->A; d.D = f->D; d.NL = f->NL; d.E = f->E; d.V = f->V; d.U = f->U;
     d.mode = f->mode; d.Kc = f->mode == LAS_ATT_LOC ? f->Kc : 0; d.C = f->mode == LAS_ATT_LOC ? f->C : 0;
     d.step_logits = f->step_logits; d.flags = f->flags; d.fb = f->forget_bias; d.seed = f->seed;
+    d.row_group = (f->row_group > 0 && f->B % f->row_group == 0) ? f->row_group : 0;
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
@@ -3356,10 +3378,10 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
             LAS_ARG(!lm.fast && !lm.x_bf16, "las_speller_fwd: companion_rows must be an exact (fast = 0) cell with fp32 rows");
             const int nlm = (lm.H / 16) * cdiv(lm.M, 32);
             const size_t ldsc = lds_bf > (size_t)PF_LM_LDS ? lds_bf : (size_t)PF_LM_LDS;
-            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 8>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
-            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 10>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
-            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 12>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
-            else                  hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 14>), dim3(nlm + B), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 8>), dim3(nlm + xcd_local_grid(B, d.row_group)), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 10>), dim3(nlm + xcd_local_grid(B, d.row_group)), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 12>), dim3(nlm + xcd_local_grid(B, d.row_group)), dim3(RNT), ldsc, st, d, t, lm, nlm);
+            else                  hipLaunchKernelGGL((dec_step_fwd_pf_lm_kernel<CELL, 14>), dim3(nlm + xcd_local_grid(B, d.row_group)), dim3(RNT), ldsc, st, d, t, lm, nlm);
         }
         else if (pf && t == 0 && U == 1 && f->keep_state0 && (d.flags & LAS_SPELLER_ROWS_SHARE4) && (d.flags & LAS_SPELLER_NO_LOGITS)) {
             // beam-search step over many rows: four hypotheses of an utterance per workgroup, shared operands read once
@@ -3370,16 +3392,16 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
                                (int)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_beam_rows4_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             LAS_ARG(attr4 == 0 && l4 <= 128 * 1024, "speller: hipFuncSetAttribute(dec_beam_rows4_kernel) failed (%d) or the rows' state does not fit LDS (%zu)", attr4, l4);
             LAS_ARG((B % BR4) == 0 && d.tok_in, "speller: LAS_SPELLER_ROWS_SHARE4 needs a row count that is a multiple of 4");
-            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_beam_rows4_kernel<8>), dim3(B / BR4), dim3(RNT), l4, st, d);
-            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_beam_rows4_kernel<10>), dim3(B / BR4), dim3(RNT), l4, st, d);
-            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_beam_rows4_kernel<12>), dim3(B / BR4), dim3(RNT), l4, st, d);
-            else                  hipLaunchKernelGGL((dec_beam_rows4_kernel<14>), dim3(B / BR4), dim3(RNT), l4, st, d);
+            if (d.Tp <= 128)      hipLaunchKernelGGL((dec_beam_rows4_kernel<8>), dim3(xcd_local_grid(B / BR4, d.row_group / BR4)), dim3(RNT), l4, st, d);
+            else if (d.Tp <= 160) hipLaunchKernelGGL((dec_beam_rows4_kernel<10>), dim3(xcd_local_grid(B / BR4, d.row_group / BR4)), dim3(RNT), l4, st, d);
+            else if (d.Tp <= 192) hipLaunchKernelGGL((dec_beam_rows4_kernel<12>), dim3(xcd_local_grid(B / BR4, d.row_group / BR4)), dim3(RNT), l4, st, d);
+            else                  hipLaunchKernelGGL((dec_beam_rows4_kernel<14>), dim3(xcd_local_grid(B / BR4, d.row_group / BR4)), dim3(RNT), l4, st, d);
         }
         else if (pf && t == U)          hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
-        else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(B), dim3(RNT), lds_bf, st, d, t);
-        else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(B), dim3(RNT), lds_bf, st, d, t);
-        else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(B), dim3(RNT), lds_bf, st, d, t);
-        else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(B), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 128)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 8>), dim3(xcd_local_grid(B, d.row_group)), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 160)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 10>), dim3(xcd_local_grid(B, d.row_group)), dim3(RNT), lds_bf, st, d, t);
+        else if (pf && d.Tp <= 192)     hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 12>), dim3(xcd_local_grid(B, d.row_group)), dim3(RNT), lds_bf, st, d, t);
+        else if (pf)                    hipLaunchKernelGGL((dec_step_fwd_pf_kernel<CELL, 14>), dim3(xcd_local_grid(B, d.row_group)), dim3(RNT), lds_bf, st, d, t);
         else if (bfrows && d.A <= 128)  hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 1>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (bfrows)                hipLaunchKernelGGL((dec_step_fwd_bf_kernel<CELL, 2>), dim3(B), dim3(RNT), lds_bf, st, d, t);
         else if (d.mode == LAS_ATT_LOC) hipLaunchKernelGGL((dec_step_fwd_kernel<CELL, FAST, true>), dim3(B), dim3(RNT), lds, st, d, t);

@@ -37,7 +37,7 @@ def restore_lm(lm, save_path):
     """reference decode.py:41-53: restore the LM's variables (this build: a torch-saved {name: array} dictionary written
     by train_lm.py; the names are the reference's TF variable names under the `lm` scope)."""
     import torch
-    sd = torch.load(save_path, map_location="cpu", weights_only=False)
+    sd = torch.load(save_path, map_location="cpu", weights_only=True)
     lm.params()                                     # create the variables, then overwrite them
     lm.store.load({k: v for k, v in sd["params"].items() if k.startswith(lm.scope + "/")})
     logging.info("Rnnlm restored: {}".format(save_path))

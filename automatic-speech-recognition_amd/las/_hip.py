@@ -42,7 +42,7 @@ class SpellerFwdArgs(Structure):
         ("logits", c_void_p), ("alphas", c_void_p), ("align0", c_void_p), ("emb_mask", c_void_p), ("emb_noise", c_void_p),
         ("hs", c_void_p), ("cs", c_void_p), ("gates", c_void_p), ("xin0", c_void_p), ("act_save", c_void_p),
         ("ws", c_void_p), ("ws_bytes", c_size_t), ("status", c_void_p), ("companion", POINTER(LstmCellArgs)),
-        ("companion_rows", POINTER(LstmCellArgs))]
+        ("companion_rows", POINTER(LstmCellArgs)), ("row_group", c_int)]
 
 
 class BeamLoopArgs(Structure):

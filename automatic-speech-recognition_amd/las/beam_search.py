@@ -108,6 +108,7 @@ class BeamSearch(object):
         # decode_batch (round 5): the attention rows of FOUR hypotheses of an utterance in one workgroup (LAS_SPELLER_ROWS_SHARE4: Ws, keys and
         # encoder rows read once for the four) from this many hypothesis rows on (0 = never); bit-identical to one row per workgroup
         self.share_rows_from = int(os.environ.get("LAS_DECODE_SHARE_ROWS_FROM", "512"))
+        self.xcd_local_rows = os.environ.get("LAS_NO_XCD_LOCAL_ROWS") != "1"       # decode_batch (round 6): an utterance's hypothesis rows on one XCD
         self.lm_state_copies = os.environ.get("LAS_NO_LM_STATE_COPIES") != "1"      # decode_batch (round 5): bf16 copies of the LM's state from 384 rows on
         self.steps_per_graph = int(os.environ.get("LAS_DECODE_STEPS_PER_GRAPH", "8"))   # search steps per captured HIP graph (one replay = that many steps)
         self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
@@ -429,6 +430,8 @@ class BeamSearch(object):
         # (eager) step and replayed -- the loop is bound by the host's launch rate otherwise (5-8 launches and their Python glue per step)
         alphas_cur = torch.zeros(N, Tp, device=dev)
         fa.alphas = alphas_cur.data_ptr()
+        # rows u beam .. (u + 1) beam - 1 are the hypotheses of utterance u (same enc / keys): the row launches keep them on one XCD
+        fa.row_group = beam if self.xcd_local_rows else 0
         ba.state_in[k_align] = alphas_cur.data_ptr()
         ba.file_in, ba.file_out, ba.file_width = alphas_cur.data_ptr(), alphas_hist.data_ptr(), Tp
         held = []

@@ -208,7 +208,7 @@ def main(argv=None):
     trainer.params()
     logging.info('Model size (number of parameters): %s\n', store.num_params())
     if init_model:
-        sd = torch.load(init_model, map_location="cpu", weights_only=False)
+        sd = torch.load(init_model, map_location="cpu", weights_only=True)     # (tensors, ints and dicts of them: a checkpoint path must never run pickled code)
         store.load_state_dict(sd)
         trainer.global_step = int(sd.get("global_step", 0))
 
@@ -236,7 +236,7 @@ def main(argv=None):
     logging.info('Latest model is saved in %s', latest)
     logging.info('Evaluate the best model on test set')
     if best_model:
-        store.load_state_dict(torch.load(best_model, map_location="cpu", weights_only=False))
+        store.load_state_dict(torch.load(best_model, map_location="cpu", weights_only=True))
     run.write(test_ppl=float(sweep("test")))
 
 

@@ -187,6 +187,24 @@ def recorded_traffic(kernel_prefix):
     return None
 
 
+def recorded_decode_traffic():
+    """{kernel: memory-side bytes per launch} of the decode step's Speller launches from the newest profiles/*_decode_pmc.json that was
+    recorded from THIS csrc/speller.hip (FETCH_SIZE x2 + WRITE_SIZE, separate passes; tools/pmc_summary.py), else None."""
+    import glob
+    try:
+        src = os.path.join(ROOT, "automatic-speech-recognition_amd", "csrc", "speller.hip")
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_decode_pmc.json")), reverse=True):
+            rec = json.load(open(path))
+            if rec.get("speller_sha16") != sha:
+                continue
+            return {k: v["hbm_bytes_per_launch"] for k, v in rec["kernels"].items()
+                    if k.startswith(("dec_step_fwd_pf", "dec_beam_rows4", "lstm_cell_rows", "beam_")) and "hbm_bytes_per_launch" in v}
+    except Exception:
+        pass
+    return None
+
+
 def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
     """BASELINE configs[4]: beam search (beam 16) + char RNNLM shallow fusion on synthetic T=1274 utterances, bench
     architecture, device-resident batched loop (BeamSearch.decode_batch).  Random-init weights: hypotheses do not end
@@ -312,7 +330,13 @@ def decode_bench(dev, cell, dtype, nutt=16, beam=16, T=1274):
                 "us_per_decode_step": parts[dom], "algorithmic_bytes_per_step": int(byts),
                 "achieved": round(byts / (parts[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(byts / (parts[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "latency-bound: one decode step is a chain of 5 dependent launches over %d rows (8-13 us each in the replayed graph)" % N}
+                # counter bytes (FETCH_SIZE x2 + WRITE_SIZE per launch) of the step's Speller / LM / pruning kernels, beside the algorithmic
+                # figure above: what the launches really pull through the fabric (the attention rows moved 12-16x their
+                # distinct operands; round 6 keeps an utterance's hypothesis rows on one XCD)
+                "traffic": recorded_decode_traffic(),
+                "note": "latency-bound: one decode step is a chain of 5 dependent launches over %d rows (8-13 us each in the replayed graph); "
+                        "traffic = memory-side bytes per launch from the recorded rocprofv3 --pmc passes when they were made from this "
+                        "csrc/speller.hip, else null" % N}
     # `value`: the rate of what decode.py does by default since round 4 -- 64 utterances per device-resident batch (1024 hypothesis rows per
     # step); `at_16_utterances`: rounds 1-3's geometry (256 rows), with the per-step parts and the roofline that were measured there
     at16 = round(nutt / dt, 2)

@@ -355,6 +355,11 @@ typedef struct {
                                       one-hot input) launched as extra workgroups of the attention-row launch.  With the LM's SECOND layer as
                                       `companion` and the state gather inside las_beam_loop_step (fold_gather) a search step is three
                                       dependent launches: rows + LM 1, Speller cell + LM 2, beam. */
+    int row_group;                 /* optional (0 = none; round 6): rows g row_group .. (g + 1) row_group - 1 have IDENTICAL enc / keys / enc_len -- a beam
+                                      search's hypotheses of one utterance (las/beam_search.py:216 tiles the encoder output over them).  The
+                                      per-step attention-row launches then place an utterance's rows on ONE XCD (workgroup id -> row mapping,
+                                      csrc/speller.hip xcd_local_row), so that its keys and encoder rows enter one L2 instead of eight.
+                                      B % row_group == 0, else ignored.  Results do not depend on it. */
 } las_speller_fwd_args;
 size_t las_speller_workspace_bytes(int B, int Tp, int Hd, int A, int D, int NL, int E, int V, int U, int cell);
 size_t las_speller_act_save_bytes(int U, int B, int Tp, int A, int C);   /* C = location-aware channels (0: additive attention) */

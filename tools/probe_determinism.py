@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Two optimiser steps from identical weights, run twice: is the SECOND step's gradient bit-identical between the runs?  Over the schedule
+knobs (sweep flags, hand-overs, fused tanh gradient ...) and three token sources (on-device scheduled sampling / host-supplied samples /
+teacher forcing).  Round 6 finding: everything is bit-reproducible at 128 / 256 listener units and at the bench geometry (BIG=1); with 64-unit
+sweeps AND on-device sampling the second step differs by ~2e-6 in the two bottom layers' gradients (gone with LAS_SEQ_NO_HELPER_WAVES or
+with the fused tanh gradient off; not root-caused).   H=64|128|256 T=<frames> BIG=1 FEW=1 python tools/probe_determinism.py"""
+import os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "automatic-speech-recognition_amd"), os.path.join(ROOT, "tests"), ROOT):
+    sys.path.insert(0, p)
+import torch, numpy as np
+from helpers import make_args, synthetic_batch
+from las import _hip, layers as L, variables as V
+from las.las import LAS, Listener, Speller
+from oracle import las_oracle as O
+warnings.simplefilter("ignore")
+if os.environ.get("BIG"):
+    args = make_args(enc_units=256, num_enc_layers=3, dec_units=512, num_dec_layers=1, embedding_size=128, attention_size=128, mode="add",
+                     lr=1e-3, grad_clip=5.0, label_smoothing=True, vocab_size=30, scheduled_sampling=True, warmup_step=0, max_step=8)
+    xs, ys = synthetic_batch(48, 1274, 256, 30, seed=0, min_frac=0.834)
+else:
+    args = make_args(enc_units=int(os.environ.get("H", "64")), num_enc_layers=2, dec_units=128, num_dec_layers=1, embedding_size=64, attention_size=64, mode="add",
+                     lr=1e-3, grad_clip=5.0, label_smoothing=True, vocab_size=30, scheduled_sampling=True, warmup_step=0, max_step=8)
+    xs, ys = synthetic_batch(8, int(os.environ.get("T", "96")), 24, 30, seed=43, min_frac=0.8)
+p0 = O.init_params(args, seed=2, cell="lstm")
+U = int(ys[1].max())
+coins = np.random.RandomState(0).rand(U) < 0.5
+sampled_host = np.random.RandomState(1).randint(3, 30, size=(len(xs[1]), U)).astype(np.int32)
+
+def two(seq_flags=0, sampled=None, coins=coins, **knobs):
+    L.set_cell("lstm"); L.set_precision("bf16")
+    saved = {k: getattr(L, k) for k in knobs}
+    sf = _hip.seq_flags
+    for k, v in knobs.items(): setattr(L, k, v)
+    _hip.seq_flags = seq_flags
+    try:
+        st = V.reset_default_store(device="cuda"); st.load(p0)
+        las = LAS(args, Listener, Speller, {})
+        for k in range(2):
+            st.global_step = 3
+            las.train(xs, ys, coins=coins, sampled=sampled)
+            torch.cuda.synchronize()
+        return st.flat_grad.clone()
+    finally:
+        for k, v in saved.items(): setattr(L, k, v)
+        _hip.seq_flags = sf
+
+cases = [("default on-device sampling", {}), ("host-supplied samples", dict(sampled=sampled_host)),
+         ("teacher", dict(coins=np.ones(U, bool))),
+         ("seq NO_KSPLIT", dict(seq_flags=2)), ("seq AGENT_GRANULES", dict(seq_flags=1)), ("seq NO_WARMERS", dict(seq_flags=16)),
+         ("seq NO_HELPER_WAVES", dict(seq_flags=4)), ("seq ROWS16", dict(seq_flags=8)),
+         ("TAIL_TWO_STREAMS off", dict(TAIL_TWO_STREAMS=False)), ("FUSE_TANH_GRAD off", dict(FUSE_TANH_GRAD=False)),
+         ("DENSE_CHUNKS off", dict(DENSE_CHUNKS=False)), ("TAIL_ONE_LAUNCH off", dict(TAIL_ONE_LAUNCH=False)), ("WGRAD_ONE_PASS off", dict(WGRAD_ONE_PASS=False))]
+if os.environ.get("FEW"):
+    cases = cases[:3]
+for name, kw in cases:
+    worst = 0.0
+    for rep in range(4):
+        a = two(**kw); b = two(**kw)
+        worst = max(worst, (a - b).abs().max().item())
+    print("%-32s worst |dg| over 4 pairs: %.3e" % (name, worst), flush=True)
