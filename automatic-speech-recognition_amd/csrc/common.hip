@@ -120,3 +120,110 @@ extern "C" int las_set_word(int* word, int value, void* stream) {
     LAS_LAUNCHED();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input dropout of a bidirectional layer (reference las/layers.py:37-47: fw_cell and bw_cell each sit in their own
+// DropoutWrapper(input_keep_prob = 1 - rate), i.e. the two directions see INDEPENDENT Bernoulli masks of the same input, scaled by
+// 1 / keep).  Until round 5 this was two torch.nn.functional.dropout launches + a zero-pad + a bf16 cast per direction; here the two
+// operand blocks of the directions' x-projections leave ONE launch, already in the product's layout (bf16, K padded with zero columns to a
+// multiple of `kpad`), and the masks are never stored: element i of direction d keeps its value iff the 16-bit slice of
+// splitmix64(seed, d, i / 4) that belongs to it is below keep x 65536 -- the backward launch regenerates them from the same counter.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long drop_bits(unsigned long long seed, int dir, unsigned long long quad) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (2 * quad + (unsigned long long)dir + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void dropout_pair_fwd_kernel(const TI* __restrict__ x, long long rows, int K, int ldx, TO* __restrict__ yf,
+                                                               TO* __restrict__ yb, int ldy, unsigned long long seed, unsigned thr, float scale) {
+    const long long quads_per_row = ldy / 4, total = rows * quads_per_row;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const long long r = q / quads_per_row;
+        const int c0 = (int)(q - r * quads_per_row) * 4;
+        const unsigned long long quad = (unsigned long long)r * ((K + 3) / 4) + (c0 >> 2);       // (counter over the UNPADDED block: the mask of an element does not depend on the padding)
+        const unsigned long long bf = drop_bits(seed, 0, quad), bb = drop_bits(seed, 1, quad);
+        float vf[4], vb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            float v = 0.f;
+            if (c < K) {
+                if (sizeof(TI) == 2) v = bf2f(((const unsigned short*)x)[r * ldx + c]);
+                else v = ((const float*)x)[r * ldx + c];
+            }
+            vf[e] = ((unsigned)(bf >> (16 * e)) & 0xffffu) < thr ? v * scale : 0.f;
+            vb[e] = ((unsigned)(bb >> (16 * e)) & 0xffffu) < thr ? v * scale : 0.f;
+        }
+        if (sizeof(TO) == 2) {
+            reinterpret_cast<uint2*>((unsigned short*)yf + r * ldy + c0)[0] = make_uint2(f2bf2(vf[0], vf[1]), f2bf2(vf[2], vf[3]));
+            reinterpret_cast<uint2*>((unsigned short*)yb + r * ldy + c0)[0] = make_uint2(f2bf2(vb[0], vb[1]), f2bf2(vb[2], vb[3]));
+        } else {
+            reinterpret_cast<float4*>((float*)yf + r * ldy + c0)[0] = make_float4(vf[0], vf[1], vf[2], vf[3]);
+            reinterpret_cast<float4*>((float*)yb + r * ldy + c0)[0] = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        }
+    }
+}
+// dx[r, c] = scale (m_fw[r, c] gf[r, c] + m_bw[r, c] gb[r, c])
+template <typename TG, typename TO>
+__global__ __launch_bounds__(256) void dropout_pair_bwd_kernel(const TG* __restrict__ gf, const TG* __restrict__ gb, int ldg, long long rows, int K,
+                                                               TO* __restrict__ dx, int lddx, unsigned long long seed, unsigned thr, float scale) {
+    const long long quads_per_row = (K + 3) / 4, total = rows * quads_per_row;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const long long r = q / quads_per_row;
+        const int c0 = (int)(q - r * quads_per_row) * 4;
+        const unsigned long long bf = drop_bits(seed, 0, (unsigned long long)q), bb = drop_bits(seed, 1, (unsigned long long)q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            if (c >= K) break;
+            float a, b;
+            if (sizeof(TG) == 2) { a = bf2f(((const unsigned short*)gf)[r * ldg + c]); b = bf2f(((const unsigned short*)gb)[r * ldg + c]); }
+            else { a = ((const float*)gf)[r * ldg + c]; b = ((const float*)gb)[r * ldg + c]; }
+            const float v = ((((unsigned)(bf >> (16 * e)) & 0xffffu) < thr ? a : 0.f) + (((unsigned)(bb >> (16 * e)) & 0xffffu) < thr ? b : 0.f)) * scale;
+            if (sizeof(TO) == 2) ((unsigned short*)dx)[r * lddx + c] = f2bf(v);
+            else ((float*)dx)[r * lddx + c] = v;
+        }
+    }
+}
+static unsigned drop_threshold(float keep) {
+    const double t = (double)keep * 65536.0 + 0.5;
+    return t >= 65536.0 ? 65536u : (t <= 0.0 ? 0u : (unsigned)t);
+}
+extern "C" int las_dropout_pair_fwd(const void* x, int x_dt, long long rows, int K, int ldx, void* y_fw, void* y_bw, int y_dt, int ldy,
+                                    float keep, unsigned long long seed, void* stream) {
+    LAS_ARG(x && y_fw && y_bw && rows >= 0 && K > 0 && ldx >= K && ldy >= K && (ldy % 4) == 0, "las_dropout_pair_fwd: bad arguments (ldy must be a multiple of 4 and >= K)");
+    LAS_ARG(keep > 0.f && keep <= 1.f, "las_dropout_pair_fwd: keep probability %g outside (0, 1]", keep);
+    if (rows == 0) return 0;
+    int nb = cdiv(rows * (ldy / 4), 256);
+    if (nb > 8192) nb = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned thr = drop_threshold(keep);
+    const float scale = 1.0f / keep;
+    typedef unsigned short u16;
+#define DF(TI, TO) hipLaunchKernelGGL((dropout_pair_fwd_kernel<TI, TO>), dim3(nb), dim3(256), 0, st, (const TI*)x, rows, K, ldx, (TO*)y_fw, (TO*)y_bw, ldy, seed, thr, scale)
+    if (x_dt == LAS_DT_BF16) { if (y_dt == LAS_DT_BF16) DF(u16, u16); else DF(u16, float); }
+    else { if (y_dt == LAS_DT_BF16) DF(float, u16); else DF(float, float); }
+#undef DF
+    LAS_LAUNCHED();
+    return 0;
+}
+extern "C" int las_dropout_pair_bwd(const void* g_fw, const void* g_bw, int g_dt, int ldg, long long rows, int K, void* dx, int dx_dt, int lddx,
+                                    float keep, unsigned long long seed, void* stream) {
+    LAS_ARG(g_fw && g_bw && dx && rows >= 0 && K > 0 && ldg >= K && lddx >= K, "las_dropout_pair_bwd: bad arguments");
+    LAS_ARG(keep > 0.f && keep <= 1.f, "las_dropout_pair_bwd: keep probability %g outside (0, 1]", keep);
+    if (rows == 0) return 0;
+    int nb = cdiv(rows * ((K + 3) / 4), 256);
+    if (nb > 8192) nb = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned thr = drop_threshold(keep);
+    const float scale = 1.0f / keep;
+    typedef unsigned short u16;
+#define DB(TG, TO) hipLaunchKernelGGL((dropout_pair_bwd_kernel<TG, TO>), dim3(nb), dim3(256), 0, st, (const TG*)g_fw, (const TG*)g_bw, ldg, rows, K, (TO*)dx, lddx, seed, thr, scale)
+    if (g_dt == LAS_DT_BF16) { if (dx_dt == LAS_DT_BF16) DB(u16, u16); else DB(u16, float); }
+    else { if (dx_dt == LAS_DT_BF16) DB(float, u16); else DB(float, float); }
+#undef DB
+    LAS_LAUNCHED();
+    return 0;
+}

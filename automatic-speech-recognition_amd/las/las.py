@@ -716,9 +716,8 @@ class LAS:
                 # auxiliary stream beside the first Listener sweep, off the dependency chain; tensors this call made itself are held as is
                 a_hold = audio.clone() if (torch.is_tensor(xs[0]) and xs[0].is_cuda) else audio
                 y_hold = y.clone() if (torch.is_tensor(ys[0]) and ys[0].is_cuda) else y
-                self._recent.append((st.global_step, (a_hold, np.array(torch.as_tensor(audiolen).cpu(), copy=True)),
-                                     (y_hold, np.array(torch.as_tensor(tokenlen).cpu(), copy=True)),
-                                     None if coins is None else np.array(coins, copy=True), None if sampled is None else np.array(torch.as_tensor(sampled).cpu(), copy=True)))
+                hostcopy = lambda v: None if v is None else (v.detach().cpu().numpy().copy() if torch.is_tensor(v) else np.array(v, copy=True))
+                self._recent.append((st.global_step, (a_hold, hostcopy(audiolen)), (y_hold, hostcopy(tokenlen)), hostcopy(coins), hostcopy(sampled)))
             st.zero_grad()
             n_local = (y[:, :dec_steps] != 0).sum().to(torch.float32)
             n_total = self.dp.all_reduce_scalar(n_local) if self.dp is not None else n_local

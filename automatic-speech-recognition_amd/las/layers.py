@@ -1005,21 +1005,81 @@ def blstm(inputs, cell_units, dropout_rate, is_training, scope="blstm"):
     return outputs, states
 
 
+DROPOUT_KERNEL = os.environ.get("LAS_NO_DROPOUT_KERNEL") != "1"     # input dropout of both directions in one launch (las_dropout_pair_fwd)
+
+
+class _DropoutPair(torch.autograd.Function):
+    """The two directions' independently masked copies of a recurrent layer's input (las/layers.py:37-47), as the x-projection's operand
+    blocks: [.., K] -> two [.., ld] tensors (bf16 or fp32; columns K .. ld - 1 zero).  Masks are a counter-based function of
+    (seed, direction, element) and are regenerated in backward (las_dropout_pair_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, keep, seed, out_bf16, ld):
+        shp = x.shape
+        K = shp[-1]
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if x2.dtype not in (torch.float32, torch.bfloat16):
+            x2 = x2.float()
+        rows = x2.shape[0]
+        odt = torch.bfloat16 if out_bf16 else torch.float32
+        yf = torch.empty(rows, ld, device=x.device, dtype=odt)
+        yb = torch.empty(rows, ld, device=x.device, dtype=odt)
+        dt = lambda t: _hip.DT_BF16 if t.dtype == torch.bfloat16 else _hip.DT_F32
+        _hip.check(_hip.lib().las_dropout_pair_fwd(_hip.p(x2), dt(x2), rows, K, K, _hip.p(yf), _hip.p(yb), dt(yf), ld, float(keep), int(seed),
+                                                   _hip.stream()), "las_dropout_pair_fwd")
+        ctx.cfg = (float(keep), int(seed), K, ld, x.dtype, tuple(shp))
+        return yf.view(*shp[:-1], ld), yb.view(*shp[:-1], ld)
+
+    @staticmethod
+    def backward(ctx, gf, gb):
+        keep, seed, K, ld, xdt, shp = ctx.cfg
+        if gb.dtype != gf.dtype:
+            gb = gb.to(gf.dtype)
+        if gf.dtype not in (torch.float32, torch.bfloat16):
+            gf, gb = gf.float(), gb.float()
+        gf2, gb2 = gf.reshape(-1, gf.shape[-1]).contiguous(), gb.reshape(-1, gb.shape[-1]).contiguous()
+        rows = gf2.shape[0]
+        dx = torch.empty(rows, K, device=gf.device, dtype=xdt if xdt in (torch.float32, torch.bfloat16) else torch.float32)
+        dt = lambda t: _hip.DT_BF16 if t.dtype == torch.bfloat16 else _hip.DT_F32
+        _hip.check(_hip.lib().las_dropout_pair_bwd(_hip.p(gf2), _hip.p(gb2), dt(gf2), gf2.shape[-1], rows, K, _hip.p(dx), dt(dx), K, keep, seed,
+                                                   _hip.stream()), "las_dropout_pair_bwd")
+        return dx.view(shp), None, None, None, None
+
+
+def _dropout_seed():
+    """a fresh 62-bit seed from torch's CPU generator (reproducible under torch.manual_seed; no device round trip)"""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+
+
 def _blstm_full(inputs, cell_units, dropout_rate, is_training, scope="blstm", pad_even=False):
     """blstm() plus the already-concatenated [B,T(+pad),2H] buffer the kernels wrote (the
     tf.concat(rnn_out, -1) of las/layers.py:69,81 is free: both directions share one tensor)."""
     _hip.require_gpu(inputs)
     x_bw = None
+    I_true = inputs.shape[-1]
     if is_training is True and dropout_rate:
         # DropoutWrapper(input_keep_prob=1-rate) around fw_cell AND around bw_cell (las/layers.py:37-47): each direction
         # draws its own fresh Bernoulli mask on the cell INPUT at every time step, scaled by 1/keep (SURVEY App. A.5).
         # The input projection is hoisted over all t, so the per-step masks of a direction are one mask over [B,T,I]
         # (torch RNG: plumbing, the masks are not on the MFMA path).
-        x_bw = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
-        inputs = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
+        if DROPOUT_KERNEL:
+            # round 6: both directions' masked operand blocks in ONE launch, already bf16 / zero-padded to the product's K where the speed
+            # mode's sweeps serve this layer (was: 2 x F.dropout + 2 x pad + 2 x cast); masks from a counter, regenerated in backward
+            I_ = inputs.shape[-1]
+            speed = _prec() == _hip.PREC_BF16 and _hip.rnn_seq_io_dtype(_cellid(_CFG["cell"]), _hip.PREC_BF16, int(cell_units)) == torch.bfloat16
+            ld = _k64(I_) if speed else (I_ + 3) // 4 * 4
+            x_fw, x_bw = _DropoutPair.apply(inputs, 1.0 - float(dropout_rate), _dropout_seed(), speed, ld)
+            if not speed and ld != I_:
+                x_fw, x_bw = x_fw[..., :I_], x_bw[..., :I_]
+            inputs = x_fw
+        else:
+            x_bw = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
+            inputs = torch.nn.functional.dropout(inputs, p=float(dropout_rate), training=True)
     cell = _CFG["cell"]
     H = int(cell_units)
-    I = inputs.shape[-1]
+    I = I_true                                  # (the dropout launch may already have padded the operand blocks to the product's K)
     kfw, bfw, kbw, bbw = _blstm_params(scope, I, H, cell)
     after_blstm = _PARAMS.pop("after_blstm", False)
     _PARAMS["blstm"] = (kfw, bfw, kbw, bbw)

@@ -459,6 +459,17 @@ typedef struct las_shadow_desc {
 } las_shadow_desc;
 int las_build_shadows(const las_shadow_desc* descs_dev, int n, int max_tiles, void* stream);
 
+/* Input dropout of a bidirectional recurrent layer (las/layers.py:37-47: fw_cell and bw_cell in separate DropoutWrappers, input_keep_prob =
+ * 1 - dropout_rate): ONE launch leaves the two directions' operand blocks y_fw / y_bw [rows, ldy] = x * mask_d / keep with INDEPENDENT
+ * Bernoulli(keep) masks, in fp32 or bf16 (x_dt / y_dt: LAS_DT_*), columns K .. ldy - 1 zero (the product's K padding; ldy % 4 == 0).  The
+ * masks are a counter-based function of (seed, direction, row, column) -- 16 bits of a splitmix64 word per element -- and are never stored:
+ * las_dropout_pair_bwd regenerates them,  dx = (mask_fw * g_fw + mask_bw * g_bw) / keep  (g_*: [rows, ldg], the first K columns).
+ * (tf.nn.dropout draws from TF's Philox stream; the reference fixes no seed, so only the distribution is contractual.) */
+int las_dropout_pair_fwd(const void* x, int x_dt, long long rows, int K, int ldx, void* y_fw, void* y_bw, int y_dt, int ldy,
+                         float keep, unsigned long long seed, void* stream);
+int las_dropout_pair_bwd(const void* g_fw, const void* g_bw, int g_dt, int ldg, long long rows, int K, void* dx, int dx_dt, int lddx,
+                         float keep, unsigned long long seed, void* stream);
+
 size_t las_sumsq_workspace_bytes(long long n);
 int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream);
 int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,

@@ -183,21 +183,25 @@ def test_a_reported_timeout_keeps_the_optimiser_from_using_the_step():
     status = torch.zeros(2, dtype=torch.int32, device="cuda")
     guard = torch.zeros(1, device="cuda")
 
+    applied = torch.zeros(1, dtype=torch.int32, device="cuda")
+
     def adam():
         _hip.check(_hip.lib().las_clip_adam(_hip.p(th), _hip.p(g), _hip.p(m), _hip.p(v), n, _hip.p(sumsq), 5.0, 1e-3, 0.9, 0.999, 1e-8,
-                                            _hip.p(status), _hip.p(guard), _hip.stream()), "las_clip_adam")
+                                            _hip.p(status), _hip.p(guard), _hip.p(applied), _hip.stream()), "las_clip_adam")
         torch.cuda.synchronize()
 
     status[0] = 2
     adam()
-    assert torch.equal(th, th0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+    assert torch.equal(th, th0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0 and int(applied) == 0
     status[0] = 0; guard[0] = 1.0                                   # another rank's time-out (summed guard slot)
     adam()
-    assert torch.equal(th, th0) and float(m.abs().max()) == 0
+    assert torch.equal(th, th0) and float(m.abs().max()) == 0 and int(applied) == 0
     guard[0] = 0.0
     adam()
-    assert not torch.equal(th, th0) and float(m.abs().max()) > 0
-    # end to end: a step whose status word is set leaves the store untouched; the step after the raise trains again
+    assert not torch.equal(th, th0) and float(m.abs().max()) > 0 and int(applied) == 1      # (round 6: the device counts the updates it applied)
+    # end to end: a step whose status word is set leaves the store untouched.  With the step recovery off (rounds 1-5) the next check
+    # raises and the step after the raise trains again; with it on (round 6, the default) the check RE-RUNS the lost step
+    from las import las as LL
     args = make_args(enc_units=64, num_enc_layers=1, dec_units=64, num_dec_layers=1, embedding_size=32, attention_size=32, lr=1e-3)
     L.set_cell("lstm"); L.set_precision("bf16")
     st = V.reset_default_store(device="cuda", seed=4)
@@ -206,12 +210,29 @@ def test_a_reported_timeout_keeps_the_optimiser_from_using_the_step():
     las.build_variables()
     _hip.check_status()
     before = st.flat.clone()
-    _hip.status_word(st.flat.device)[0] = 1                         # as a timed-out forward sweep would leave it
+    saved = LL.RECOVER_STEPS
+    LL.RECOVER_STEPS = False
+    try:
+        _hip.status_word(st.flat.device)[0] = 1                     # as a timed-out forward sweep would leave it
+        las.train(xs, ys)
+        torch.cuda.synchronize()
+        assert torch.equal(st.flat, before) and float(st.adam_m.abs().max()) == 0
+        with pytest.raises(RuntimeError, match="status 1"):
+            las.check_status()
+    finally:
+        LL.RECOVER_STEPS = saved
+    st = V.reset_default_store(device="cuda", seed=4)
+    las = LAS(args, Listener, Speller, {})
+    las.build_variables()
+    _hip.status_word(st.flat.device)[0] = 1
     las.train(xs, ys)
     torch.cuda.synchronize()
-    assert torch.equal(st.flat, before) and float(st.adam_m.abs().max()) == 0
-    with pytest.raises(RuntimeError, match="status 1"):
-        las.check_status()
+    assert torch.equal(st.flat, before) and float(st.adam_m.abs().max()) == 0 and st.global_step == 1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        las.check_status()                                          # finds the word, re-runs the lost step on the fall-back schedule
+    assert las.recovered_steps == 1 and st.global_step == 1 and not torch.equal(st.flat, before) and float(st.adam_m.abs().max()) > 0
     las.train(xs, ys)
     torch.cuda.synchronize()
     las.check_status()
