@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256 * RT, 1) void rnn_seq_fwd_bf16_kernel(RnnArgs a
 // LDS ring with coalesced 16-byte stores.  The compute waves touch global memory only for the exchange granules.  One
 // LDS barrier per step still orders everything.  (A single helper wave does not work: its ~80 memory instructions per
 // step take longer than the compute chain, and the barrier then waits for it.)
-// Rows past the end of a ragged batch tile alias the last valid row (identical loads, identical stores).
+// Rows past the end of a ragged batch tile alias the last valid row for their LOADS; they store nothing (round 6).
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
 // L2 warmers.  Ablations (make abl ABL=32|64|128) showed that the bulk HBM traffic of a sweep costs the dependent chain
@@ -655,12 +655,18 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
         auto brow = [&](int row) { const int b = b0 + row; return (unsigned)(b < B ? b : B - 1); };
         unsigned xoff[NXH], coff[NCH], hoff[NCH];
         int xl[NXH], xo[NXH], co[NCH];
+        // Round 6: rows past the end of the batch still LOAD the last valid row's operands (clamped addresses, no branch in the load
+        // stream) but no longer STORE: up to RB - 1 lanes used to write "the same" results to that row's addresses, and in a train step the
+        // copies were found to differ from the real row by one bf16 ulp in a few dozen saved gates (tools/probe_determinism.py: B = 5 / 8
+        // of a 16-row tile, 64 units; the last store to land decided what BPTT read -- a run-to-run difference of 2e-6 in the gradients)
+        unsigned xst = 0, cst_ = 0;                    // bit ii: the slot's row exists -> its results are stored
 #pragma unroll
         for (int ii = 0; ii < NXH; ++ii) {             // gate slice: x-projection in, activated gates out (same addresses)
             const int idx = (ii * NHW + hw) * 64 + lane, row = idx / GR8, f = (idx % GR8) * 8;
             xoff[ii] = brow(row) * (unsigned)(T * 2 * GH) + dir * GH + (f / UPM) * H + pm * UPM + (f % UPM);
             xl[ii] = row * XP + f;
             xo[ii] = row * OP + f;
+            xst |= (b0 + row < B ? 1u : 0u) << ii;
         }
 #pragma unroll
         for (int ii = 0; ii < NCH; ++ii) {
@@ -668,6 +674,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             coff[ii] = brow(row) * (unsigned)(T * 2 * H) + dir * H + pm * UPM + u;
             hoff[ii] = brow(row) * (unsigned)a.obs + dir * H + pm * UPM + u;
             co[ii] = row * OP + u;
+            cst_ |= (b0 + row < B ? 1u : 0u) << ii;
         }
         auto gframe = [&](int s) { if (LAS_ABL & 128) s &= 1; if (LAS_ABL & 256) s &= 15; if (LAS_ABL & 1024) s = (s & 15) * 64; return a.gates16 + (long long)(t0 + s * tstep) * 2 * GH; };     // uniform frame bases
         auto cframe = [&](int s) { if (LAS_ABL & 128) s &= 1; if (LAS_ABL & 256) s &= 15; if (LAS_ABL & 1024) s = (s & 15) * 64; return a.cstate16 + (long long)(t0 + s * tstep) * 2 * H; };
@@ -744,10 +751,11 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
                 for (int ii = 0; ii < NXH; ++ii) {
                     const u32x2_t lo = pack4(orr + xo[ii]), hi = pack4(orr + xo[ii] + 4);
                     const u32x4_t pk = {lo.x, lo.y, hi.x, hi.y};
-                    *(gu4*)(gb + xoff[ii]) = pk;
+                    if ((xst >> ii) & 1u) *(gu4*)(gb + xoff[ii]) = pk;
                 }
 #pragma unroll
                 for (int ii = 0; ii < NCH; ++ii) {
+                    if (!((cst_ >> ii) & 1u)) continue;
                     if (CE == 4) {
                         *(gu2*)(cb + coff[ii]) = pack4(orr + co[ii] + G * UPM);
                         *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii] + (G + 1) * UPM);
@@ -759,6 +767,7 @@ __global__ __launch_bounds__(512, 1) void rnn_seq_fwd_hw_kernel(RnnArgs a) {
             } else {
 #pragma unroll
                 for (int ii = 0; ii < NCH; ++ii) {
+                    if (!((cst_ >> ii) & 1u)) continue;
                     if (CE == 4) *(gu2*)(ob + hoff[ii]) = pack4(orr + co[ii]);
                     else         *(gu1*)(ob + hoff[ii]) = pack2(orr + co[ii]);
                 }
