@@ -83,4 +83,28 @@ bash tools/ab_bench.sh LAS_NO_PREPARED_SWEEPS=0 LAS_NO_PREPARED_SWEEPS=1 3 60 > 
 python3 tools/probe_host_ahead.py > gpurun_out/${P}_host_ahead.txt 2>&1
 # ---- eight ranks' host side on this box (one GPU: the steps run one rank at a time behind command-processor gates)
 timeout 900 python3 tools/host_time_ranks.py --ranks 8 --steps 4 --out gpurun_out/${P}_host_ranks_8.json > /dev/null 2>&1
+# ---- round 6: the reference's own recipe (run.sh:59-76) through the wide Speller path: kernel traces of both cells; the scheduled-sampling leg
+for c in rnn lstm; do
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_rs_${c}_$P -o b -- python3 bench.py --only-leg run_sh_$c --steps 5 --warmup 2 > gpurun_out/${P}_runsh_${c}_kt.log 2>&1
+  python3 tools/kernel_stats.py /tmp/kt_rs_${c}_$P 2 gpurun_out/${P}_runsh_${c}_kernel_stats.csv > /dev/null
+done
+cp gpurun_out/${P}_runsh_rnn_kernel_stats.csv gpurun_out/${P}_runsh_kernel_stats.csv 2>/dev/null
+LAS_NO_WIDE=1 python3 bench.py --only-leg run_sh --steps 3 --warmup 1 > gpurun_out/${P}_runsh_round5_kernels.json 2> /dev/null     # the same leg on round 5's per-utterance rows
+python3 bench.py --only-leg run_sh --steps 5 --warmup 2 > gpurun_out/${P}_runsh.json 2> /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kt_ss_$P -o b -- python3 bench.py --only-leg config2_sampling --steps 10 --warmup 3 > gpurun_out/${P}_sampling_kt.log 2>&1
+python3 tools/kernel_stats.py /tmp/kt_ss_$P 3 gpurun_out/${P}_sampling_kernel_stats.csv > /dev/null
+python3 bench.py --only-leg config2_sampling --steps 20 --warmup 5 > gpurun_out/${P}_sampling.json 2> /dev/null
+# ---- round 6: run-to-run determinism over the schedule knobs / token sources at the geometries where the duplicate stores were found, and the
+# sweeps repeated on identical inputs (alone and beside memory traffic on another stream)
+(for b in 5 8 16; do echo "B=$b"; B=$b python3 tools/probe_determinism.py; done; echo "bench geometry"; BIG=1 FEW=1 python3 tools/probe_determinism.py) 2>&1 | grep -v amdgpu > gpurun_out/${P}_determinism.txt
+(for b in 5 8 24; do CONC=1 B=$b python3 tools/probe_sweep_repeat.py; done) 2>&1 | grep -v amdgpu > gpurun_out/${P}_sweep_repeat.txt
+# ---- round 6: an utterance's hypothesis rows on one XCD (las_speller_fwd_args.row_group) against row = workgroup id, alternating runs
+(for i in 1 2 3; do for v in 0 1; do echo -n "LAS_NO_XCD_LOCAL_ROWS=$v "; LAS_NO_XCD_LOCAL_ROWS=$v python3 bench.py --decode-only 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())['decode']
+print('value', d['value'], 'value_b16', d['value_b16'], 'us_per_step', d['us_per_decode_step'], d['step_parts_us'])"; done; done) > gpurun_out/${P}_decode_xcd_ab.txt 2>&1
+# ---- round 6: what the step recovery's bookkeeping costs the headline (alternating)
+(for i in 1 2 3; do for v in 0 1; do echo -n "LAS_NO_STEP_RECOVERY=$v "; LAS_NO_STEP_RECOVERY=$v python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-decode --no-train-loop --no-side-legs 2>/dev/null | python3 -c "
+import json,sys
+print(json.loads(sys.stdin.read())['ms_per_step'])"; done; done) > gpurun_out/${P}_ab_recovery.txt 2>&1
 tail -c 600 gpurun_out/${P}_bench.json; echo; tail -3 gpurun_out/${P}_pmc_summary.log | cut -c1-300
