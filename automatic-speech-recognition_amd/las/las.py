@@ -21,7 +21,8 @@ from las.parallel import sampling_seed
 from las.utils import convert_idx_to_token_tensor
 
 SOS_ID = 1  # tf.ones(...) look-up at reference las/las.py:81
-RECOVER_STEPS = os.environ.get("LAS_NO_STEP_RECOVERY") != "1"     # LAS.train re-runs steps lost to a residency time-out (single process)
+RECOVER_STEPS = os.environ.get("LAS_NO_STEP_RECOVERY") != "1"     # LAS.train re-runs steps lost to a residency time-out
+DP_LAG = 3                                                          # data parallel: a step's all-reduced guard slot is looked at this many steps later
 
 
 class Listener:
@@ -551,6 +552,8 @@ class LAS:
         self._recent = collections.deque(maxlen=6)   # (global step, batch) of the newest steps: what _recover can re-run
         self._pending_status = 0
         self._step_ends = collections.deque()        # events at the ends of the newest steps (bounds the host's run-ahead)
+        self._in_recovery = False
+        self._guard_probes = collections.deque()     # data parallel: (global step, pinned copy of the all-reduced guard slot, event)
         self._fallback_until = -1  # global step up to which steps run on las.layers.fallback_schedule (set by _recover)
         self._backoff = 16
         self._warned_recover = False
@@ -637,7 +640,7 @@ class LAS:
             out = self._recover(code) or out
         return out
 
-    def _recover(self, code):
+    def _recover(self, code, first=None):
         """The device reported a time-out (`code`) some steps ago.  Everything it has been asked to do since then was computed
         but NOT applied (las_clip_adam's guard; the status word stays set until the host clears it), and `store.applied` counts the
         updates that were: the first lost step is the `applied`-th optimiser launch.  Re-run from there on the batches kept in
@@ -652,7 +655,11 @@ class LAS:
         torch.cuda.synchronize(dev)
         msg = _hip.status_message(str(dev), code)
         n_applied = int(st.applied.item()) - st.adam_base if st.applied is not None else -1
-        first = st.adam_launches[n_applied] if 0 <= n_applied < len(st.adam_launches) else None
+        if first is None:
+            first = st.adam_launches[n_applied] if 0 <= n_applied < len(st.adam_launches) else None
+        else:                                        # data parallel: the ranks agreed on the step (the first whose all-reduced guard was set)
+            n_applied = st.adam_launches.index(first) if first in st.adam_launches else -1
+            self._guard_probes.clear()
         todo = [e for e in self._recent if first is not None and e[0] >= first]
         _hip.clear_status(dev)
         on_fallback = first is not None and first < self._fallback_until
@@ -671,11 +678,15 @@ class LAS:
         self._fallback_until = first + self._backoff
         self._backoff = min(2 * self._backoff, 4096)
         out = None
-        for gs, xs, ys, coins, sampled in todo:
-            out = self._train_step(xs, ys, coins, sampled)
+        self._in_recovery = True
+        try:
+            for gs, xs, ys, coins, sampled in todo:
+                out = self._train_step(xs, ys, coins, sampled)
+        finally:
+            self._in_recovery = False
         torch.cuda.synchronize(dev)                  # the re-run steps must have gone through before anything is built on them
         self._pending_status = 0
-        code2 = int(_hip.status_word(dev)[0].item())
+        code2 = int(_hip.status_word(dev)[0].item()) if self.dp is None else int(float(st.guard[0].item()) != 0.0) * 3
         if code2:
             _hip.clear_status(dev)
             raise RuntimeError(_hip.status_message(str(dev), code2) + " -- again, on the fall-back schedule: the device cannot hold the "
@@ -683,6 +694,17 @@ class LAS:
         return out
 
     def _train_step(self, xs, ys, coins=None, sampled=None):
+        if RECOVER_STEPS and self.dp is not None and not self._in_recovery:
+            # data parallel: every rank looks at the ALL-REDUCED guard slot of the step DP_LAG steps back (a pinned copy enqueued behind
+            # that step's exchange; its event is long past in steady state) -- the same value on every rank, examined at the same call,
+            # so the ranks decide together and re-run in lock step
+            dev = self._device()
+            while len(self._guard_probes) > DP_LAG:
+                gs, pin, ev = self._guard_probes.popleft()
+                ev.synchronize()
+                if float(pin[0]) != 0.0:
+                    self._recover(int(_hip.status_word(dev)[0].item()) or 3, first=gs)
+                    break
         with L.fallback_schedule(V.default_store().global_step < self._fallback_until):
             return self._train_step_impl(xs, ys, coins, sampled)
 
@@ -690,7 +712,7 @@ class LAS:
         dev = self._device()
         st = V.default_store()
         self.build_variables()
-        if self.dp is None and RECOVER_STEPS:
+        if RECOVER_STEPS and self.dp is None:
             # the host may run ahead of the device, but not further than _recover can reach back: wait for the end of the step four
             # steps ago (normally long past -- the host is one or two steps ahead -- so this costs nothing; behind a time-out, whose
             # bounded polls take a second to drain, it keeps the host from enqueueing hundreds of steps that will all be skipped)
@@ -710,7 +732,7 @@ class LAS:
         # ... and on the auxiliary ("chain") stream: a dozen tiny kernels (0.1 ms back to back) that only the Speller and the
         # backward pass need run next to the first Listener sweep instead of in front of it
         with _hip.on_chain_stream():
-            if self.dp is None and RECOVER_STEPS:
+            if RECOVER_STEPS:
                 # what _recover needs to re-run this step: the batch as it is NOW.  A caller may hand in device tensors that it overwrites
                 # a few steps later (las.input_pipeline.DeviceFeeder keeps a ring of three device slots): those are copied -- here, on the
                 # auxiliary stream beside the first Listener sweep, off the dependency chain; tensors this call made itself are held as is
@@ -781,9 +803,16 @@ class LAS:
             self._apply_adam(st, lr)
         # a sweep / Speller-loop time-out of an earlier step surfaces here: raised under data parallelism (the ranks would have to agree
         # on what to re-run), handed to train() otherwise
-        recover = self.dp is None and RECOVER_STEPS
+        recover = RECOVER_STEPS
         self._pending_status = _hip.poll_status(dev, raise_on_error=not recover)
-        if recover:
+        if recover and self.dp is not None:
+            self._pending_status = 0                    # (data parallel: the guard probes decide, for every rank at once)
+            pin = torch.zeros(1, dtype=torch.float32).pin_memory()
+            pin.copy_(st.guard, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._guard_probes.append((st.global_step, pin, ev))
+        elif recover:
             ev = torch.cuda.Event()
             ev.record()
             self._step_ends.append(ev)
@@ -848,7 +877,15 @@ class LAS:
         """Synchronising check that no recurrent sweep / Speller loop reported a time-out: the lost steps are re-run (_recover; single
         process) or RuntimeError is raised."""
         dev = self._device()
-        if self.dp is None and RECOVER_STEPS and self._recent:
+        if RECOVER_STEPS and self._recent and self.dp is not None:
+            torch.cuda.synchronize(dev)
+            while self._guard_probes:                    # (the same probes, in the same order, on every rank)
+                gs, pin, ev = self._guard_probes.popleft()
+                if float(pin[0]) != 0.0:
+                    self._recover(int(_hip.status_word(dev)[0].item()) or 3, first=gs)
+                    break
+            return
+        if RECOVER_STEPS and self._recent:
             torch.cuda.synchronize(dev)
             code = int(_hip.status_word(dev)[0].item())
             if code:

@@ -131,3 +131,54 @@ def test_rccl_world1_flat_bucket_all_reduce_and_train_step():
     xs, ys = synthetic_batch(6, 40, 8, 30, seed=11)
     loss = float(las.train(xs, ys)[0])
     assert abs(float(line[0].split()[1]) - loss) < 1e-5
+
+
+def _worker_lost_step(rank, world, port, out_path, lose):
+    """six lock-step steps; with `lose`, rank 1's status word is set in front of step 1 (a timed-out Speller loop / sweep on ONE rank)"""
+    for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from las.parallel import DataParallel
+    from las import _hip
+    _hip.speller_flags = _hip.SPELLER_NO_FUSED_STEP      # (two processes share the test box's one GPU: see _worker)
+    args, las, st = _setup("lstm", "bf16")
+    las.dp = DataParallel()
+    las.build_variables()
+    las.dp.broadcast_(st.flat)
+    warnings.simplefilter("ignore")
+    for k in range(6):
+        if lose and k == 1 and rank == 1:
+            torch.cuda.synchronize()
+            _hip.status_word("cuda")[0] = 3
+        xs, ys = synthetic_batch(6, 40 + 8 * k, 8, 30, seed=11 + k)
+        sl = slice(rank, None, world)
+        las.train((xs[0][sl], xs[1][sl]), (ys[0][sl], ys[1][sl]))
+    las.check_status()
+    torch.cuda.synchronize()
+    torch.save({"flat": st.flat.cpu(), "m": st.adam_m.cpu(), "gs": st.global_step, "recovered": las.recovered_steps}, out_path + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_step_lost_on_one_rank_is_rerun_by_all_ranks_in_lock_step(tmp_path):
+    """Round 6: the step recovery under data parallelism.  A time-out on ONE rank reaches every rank through the all-reduced guard slot
+    (every rank's las_clip_adam skips, and keeps skipping: the word is sticky).  The ranks must also DECIDE together: each looks at the
+    guard slot of the step three steps back -- the same number on every rank at the same call -- rewinds to that step and re-runs its own
+    held shards with the collectives in lock step.  Result: both replicas bit-identical to each other and to an undisturbed run (at this
+    size the fall-back schedule changes no arithmetic: the same per-step kernels, hand-overs not in play)."""
+    import torch.multiprocessing as mp
+    out = {}
+    for lose in (False, True):
+        path = str(tmp_path / ("dp_lost%d.pt" % lose))
+        mp.spawn(_worker_lost_step, args=(2, 29300 + (os.getpid() + 17 * lose) % 300, path, lose), nprocs=2, join=True)
+        out[lose] = (torch.load(path + ".0"), torch.load(path + ".1"))
+    for lose in (False, True):
+        a, b = out[lose]
+        assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["m"], b["m"]) and a["gs"] == b["gs"] == 6
+        assert a["recovered"] == b["recovered"] == (4 if lose else 0), (a["recovered"], b["recovered"])
+    assert torch.equal(out[False][0]["flat"], out[True][0]["flat"]) and torch.equal(out[False][0]["m"], out[True][0]["m"])
