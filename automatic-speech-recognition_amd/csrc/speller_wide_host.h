@@ -10,15 +10,17 @@
         LAS_LAUNCHED();                                                                                    \
     } while (0)
 
-// which calls the wide path serves: forced by LAS_SPELLER_WIDE wherever the geometry allows; by default the speed mode's multi-layer and
-// location-aware calls that the one-launch loop kernels do not take (until round 5: the per-utterance fp32-operand row kernels)
+// which calls the wide path serves: forced by LAS_SPELLER_WIDE wherever the geometry allows; by default the multi-layer and location-aware
+// calls that the one-launch loop kernels do not take (until round 5: the per-utterance fp32-operand row kernels) -- in BOTH modes: in parity
+// mode it is 62.4 against 85.2 ms (run.sh recipe, rnn cells), 90.0 against 112.3 (lstm), 50.4 against 58.2 (configs[3]); the one-layer
+// additive geometry keeps the per-utterance rows there (42.9 against 44.7 ms on the wide path)
 template <bool FAST>
 static bool wide_selected(const DecDev& d, bool have_ws, bool skinny, bool loop, bool pf) {
     if ((d.flags & LAS_SPELLER_NO_WIDE) || !have_ws || !wide_geom_ok(d)) return false;
     if (FAST && !skinny) return false;
     if (d.flags & LAS_SPELLER_WIDE) return true;
-    if (d.flags & LAS_SPELLER_NO_BF_ROWS) return false;         // (the caller asked for the fp32-operand rows)
-    return FAST && !loop && !pf && (d.NL >= 2 || d.mode == LAS_ATT_LOC);
+    if (FAST && (d.flags & LAS_SPELLER_NO_BF_ROWS)) return false;         // (the caller asked for the fp32-operand rows in speed mode)
+    return !loop && !pf && (d.NL >= 2 || d.mode == LAS_ATT_LOC);
 }
 
 template <int CELL, bool FAST>

@@ -315,7 +315,7 @@ enum { LAS_SPELLER_ROWS_SHARE4 = 32 };  /* (with LAS_SPELLER_NO_LOGITS; round 5)
                                            the step's L2 traffic; bit-identical to one row per workgroup.  B % 4 == 0, tokens >= 0. */
 enum { LAS_SPELLER_WIDE = 64,           /* (round 6) take the wide per-step path (csrc/speller_wide.h: the query projection as one product over all rows, energies and
                                            context on (slice, utterance) workgroups, every layer's cell product on pre-packed MFMA fragments) wherever its
-                                           geometry allows, also in parity mode; by default it serves the speed mode's multi-layer and location-aware calls
+                                           geometry allows; by default it serves the multi-layer and location-aware calls of both modes
                                            outside the one-launch loop kernels' geometry (e.g. run.sh's 2 x 1024 decoder at T' = 319) */
        LAS_SPELLER_NO_WIDE = 128 };     /* never take it (round 5's per-utterance row kernels) */
 #define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */

@@ -63,8 +63,9 @@ def test_run_sh_recipe_train_step_matches_oracle(cell, prec):
     r = train_step_pair(args, cell, prec, xs, ys, seed=17, enc_type="cnn")
     fam = _hip.speller_last_variant()
     assert r["alphas"].shape[-1] == 319 and r["logits"].shape[-1] == V
+    assert "wide" in fam["fwd"] and "wide" in fam["bwd"], fam                  # (both modes: csrc/speller_wide_host.h wide_selected)
     if prec == "bf16":
-        assert "wide" in fam["fwd"] and "wide" in fam["bwd"] and "skinny_upper_cells" in fam["fwd"], fam       # the family bench.py's run_sh leg times
+        assert "skinny_upper_cells" in fam["fwd"], fam                         # the family bench.py's run_sh leg times
     errs = dict(logits=(r["logits"] - r["logits_o"]).abs().max().item(), alphas=(r["alphas"] - r["alphas_o"]).abs().max().item(),
                 loss=abs(r["loss"] - r["loss_o"]) / max(1.0, abs(r["loss_o"])))
     ge = grad_errors(r)

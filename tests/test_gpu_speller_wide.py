@@ -18,7 +18,7 @@ from helpers import make_args, wide_eligible
 pytestmark = pytest.mark.gpu
 
 
-def _run(flags, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=None, V=30, dropout=0.0):
+def _run(flags, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=None, V=30, dropout=0.0, add_vn=False, oracle=True):
     from las import _hip, layers as L, variables as Vs
     from las.las import Speller
     from oracle import las_oracle as O
@@ -32,6 +32,8 @@ def _run(flags, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=None, V=30, dr
                          vocab_size=V, enc_type="cnn")                       # (enc_type cnn: the Speller's hidden_dim is enc_units)
         if loc is not None:
             args.mode, args.loc_kernel_size, args.loc_num_channels = "loc", loc[0], loc[1]
+        args.dropout_rate, args.add_vn = dropout, add_vn
+        torch.manual_seed(1234)                          # (the embedding dropout mask / variational noise come from torch's generator)
         sp = Speller(args)
         rng = np.random.RandomState(1)
         enc_np = rng.randn(B, Tp, Hd).astype(np.float32) * 0.5
@@ -55,6 +57,8 @@ def _run(flags, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=None, V=30, dr
         grads = {n: st.vars[n].grad.detach().cpu().clone() for n in st.order}
         grads["enc"] = enc.grad.detach().cpu().clone()
         p0 = {n: st.vars[n].detach().cpu().numpy() for n in st.order}
+        if not oracle:
+            return dict(logits=logits.detach().cpu(), alphas=alphas.detach().cpu(), grads=grads, fam=fam)
         if prec == "bf16":
             wide = not (flags & _hip.SPELLER_NO_WIDE) and wide_eligible(args, U, bool(flags & _hip.SPELLER_WIDE))
             O.set_precision("bf16", "bf" if (wide or args.mode == "add") else "f32")
@@ -89,6 +93,12 @@ def _check(r, tl, ta, tg):
     return el, worst
 
 
+MORE_ROWS = [
+    # more utterances than a quarter of the machine's CUs: fewer slices per utterance (B = 96: two frame slices; B = 300: one)
+    ("lstm", 2, 64, 32, 32, 32, 96, 40, 4, False, (7, 3)),
+    ("rnn", 2, 64, 32, 64, 32, 300, 23, 3, True, None),
+]
+
 SHAPES = [
     # cell, NL,  D,   A,  Hd,  E,  B, Tp,  U, mixed, loc
     ("lstm", 1, 64, 32, 32, 32, 3, 21, 5, False, None),            # the smallest: one layer, additive
@@ -102,7 +112,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shape", SHAPES + MORE_ROWS)
 def test_wide_path_parity_mode_matches_the_fp32_oracle(shape):
     from las import _hip
     cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc = shape
@@ -164,3 +174,22 @@ def test_wide_path_greedy_inference_resolves_tokens_on_the_device():
         _hip.speller_flags = saved
     assert (logits.cpu() - lo).abs().max().item() < 5e-4
     assert torch.equal(y_hat.cpu(), yo)
+
+
+@pytest.mark.parametrize("dropout,add_vn", [(0.5, False), (0.0, True), (0.3, True)])
+def test_wide_path_with_embedding_dropout_and_variational_noise_equals_the_per_utterance_rows(dropout, add_vn):
+    """tf.layers.dropout on the embedded input token (las/las.py:107-108) and --add_vn's per-look-up noise on the embedding matrix
+    (las/las.py:164-166) reach the wide path's cell input rows as they reach the row kernels': the same masks / noise (torch generator seeded
+    alike) through both families, parity mode, two layers, location-aware."""
+    from las import _hip
+    shape = ("lstm", 2, 128, 64, 64, 64, 5, 70, 6, False, (7, 3))
+    cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc = shape
+    a = _run(_hip.SPELLER_WIDE, "f32", cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=loc, dropout=dropout, add_vn=add_vn, oracle=False)
+    b = _run(_hip.SPELLER_NO_WIDE, "f32", cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=loc, dropout=dropout, add_vn=add_vn, oracle=False)
+    c = _run(_hip.SPELLER_NO_WIDE, "f32", cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=loc, oracle=False)
+    assert "wide" in a["fam"]["fwd"] and "wide" not in b["fam"]["fwd"]
+    assert (a["logits"] - b["logits"]).abs().max().item() < 2e-5 and (a["alphas"] - b["alphas"]).abs().max().item() < 2e-6
+    assert (b["logits"] - c["logits"]).abs().max().item() > 1e-3           # (the masks / the noise really were applied)
+    for n in a["grads"]:
+        scale = max(b["grads"][n].abs().max().item(), 1e-3)
+        assert (a["grads"][n] - b["grads"][n]).abs().max().item() / scale < 5e-4, n
