@@ -5,6 +5,12 @@
 #include <stddef.h>
 #include "../../include/las_hip.h"
 
+// gfx950 only: v_permlane32_swap / v_permlane16_swap, v_cvt_pk_bf16_f32, v_mfma_f32_16x16x32_bf16 and ds_read_b64_tr_b16 are
+// used unconditionally -- there is no other target and no fallback path to keep in step with
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liblas_hip.so is written for gfx950 (MI355X / CDNA4) only"
+#endif
+
 // ---- error reporting (thread-local message, negative return codes) ----------------------------
 void las_set_error(const char* fmt, ...);
 int las_device_cus();   // compute units of the current device (cached)
@@ -131,6 +137,9 @@ __device__ __forceinline__ float xor16_max(float v) {
 // The xor butterfly's steps 32 and 16 cross the rows (lane swaps, below); after them the four rows hold the same 16 values, and the steps 8, 4,
 // 2, 1 are row rotations: after the step with distance d every lane equals its partner at distance d (a op b == b op a), so what a
 // rotation by d / 2 brings is what the xor partner holds -- bit-identical to the all-xor form, four LDS round trips fewer.
+// PRECONDITION of wave_sum / wave_max / block_argmax and the xor*_ helpers: EVERY lane of the wave is active.  The lane swaps skip inactive
+// lanes and a DPP read of a disabled lane returns 0 (bound_ctrl): under divergence the result would be silently different.  Every caller
+// reaches them on uniform control flow (lanes without a value contribute the operation's identity instead of branching around the call).
 __device__ __forceinline__ float wave_sum(float v) {
     v = xor32_sum(v); v = xor16_sum(v);
     v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);

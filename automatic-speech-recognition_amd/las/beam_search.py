@@ -178,6 +178,15 @@ class BeamSearch(object):
         first = next(it, None)
         cur = launch(first) if first is not None else None
         pending = None                       # the previous batch's back-tracking / read-back / host objects, not yet run
+        try:
+            yield from self._decode_batches_loop(sess, it, cur, launch, main, sync_every)
+        finally:
+            # a consumer that stops early, or a batch that raises, must not leave the next batch's encoders running into tensors
+            # nobody holds: the launch stream waits for everything that was put on the encoder stream
+            main.wait_stream(es)
+
+    def _decode_batches_loop(self, sess, it, cur, launch, main, sync_every):
+        pending = None
         while cur is not None:
             box, out = [], []
 
