@@ -129,6 +129,11 @@ _SIGS = {
     "las_speller_bwd": (c_int, [POINTER(SpellerBwdArgs), c_void_p]),
     "las_speller_bwd_part": (c_int, [POINTER(SpellerBwdArgs), c_int, c_void_p]),
     "las_speller_last_variant": (c_int, [c_int]),
+    "las_bn_workspace_bytes": (c_size_t, [c_longlong, c_int]),
+    "las_bn_relu_fwd": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "las_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
     "las_dropout_pair_fwd": (c_int, [c_void_p, c_int, c_longlong, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_ulonglong, c_void_p]),
     "las_dropout_pair_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_void_p, c_int, c_int, c_float, ctypes.c_ulonglong, c_void_p]),
     "las_ce_loss_workspace_bytes": (c_size_t, [c_int, c_int]),

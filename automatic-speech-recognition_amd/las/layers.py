@@ -1156,9 +1156,53 @@ def _same_pad(n, k=3, s=2):
     return total // 2, total - total // 2
 
 
-def bn(inputs, is_training, scope="batch_normalization"):
+BN_KERNEL = os.environ.get("LAS_NO_BN_KERNEL") != "1"        # training-mode batch norm (+ ReLU) through las_bn_relu_fwd / _bwd (round 6)
+
+
+class _BNReLU(torch.autograd.Function):
+    """[relu](batch_norm(x2d)) in training mode: las_bn_relu_fwd / las_bn_relu_bwd (statistics + apply; reduce + apply)."""
+
+    @staticmethod
+    def forward(ctx, x2d, gamma, beta, mov_mean, mov_var, relu):
+        rows, C = x2d.shape
+        dev = x2d.device
+        stats = torch.empty(2, C, device=dev)
+        y = torch.empty_like(x2d)
+        lib = _hip.lib()
+        ws = _hip.workspace(dev, lib.las_bn_workspace_bytes(rows, C), "bn")
+        _hip.check(lib.las_bn_relu_fwd(_hip.p(x2d), rows, C, _hip.p(gamma), _hip.p(beta), 1e-3, _hip.p(stats[0]), _hip.p(stats[1]), _hip.p(mov_mean),
+                                       _hip.p(mov_var), 0.01, int(relu), _hip.p(y), _hip.p(ws), ws.numel(), _hip.stream()), "las_bn_relu_fwd")
+        ctx.save_for_backward(x2d, y, gamma, stats)
+        ctx.relu = bool(relu)
+        ctx.params = (_PARAMS.get("bn_gamma"), _PARAMS.get("bn_beta"))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, y, gamma, stats = ctx.saved_tensors
+        rows, C = x2d.shape
+        dev = x2d.device
+        dy = dy.contiguous()
+        if dy.dtype != torch.float32:
+            dy = dy.float()
+        dx = torch.empty_like(x2d)
+        gp, bp = ctx.params
+        direct = _direct_ok(gp) and _direct_ok(bp)
+        dg = gp.grad if direct else torch.zeros(C, device=dev)
+        db = bp.grad if direct else torch.zeros(C, device=dev)
+        lib = _hip.lib()
+        ws = _hip.workspace(dev, lib.las_bn_workspace_bytes(rows, C), "bn")
+        _hip.check(lib.las_bn_relu_bwd(_hip.p(x2d), _hip.p(y), _hip.p(dy), rows, C, _hip.p(gamma), _hip.p(stats[0]), _hip.p(stats[1]), int(ctx.relu),
+                                       _hip.p(dx), _hip.p(dg), _hip.p(db), _hip.p(ws), ws.numel(), _hip.stream()), "las_bn_relu_bwd")
+        if direct:
+            return dx, None, None, None, None, None
+        return dx, dg, db, None, None, None
+
+
+def bn(inputs, is_training, scope="batch_normalization", relu=False):
     """tf.layers.batch_normalization over the last axis (reference las/layers.py:114-116; momentum 0.99, eps 1e-3,
-    gamma=1, beta=0 -- SURVEY App. A.12).  Moving statistics live in the store's buffers."""
+    gamma=1, beta=0 -- SURVEY App. A.12).  Moving statistics live in the store's buffers.  relu: the ReLU the reference puts behind it
+    (las/layers.py:108,161), fused into the same passes in training mode."""
     st = V.default_store()
     C = inputs.shape[-1]
     gamma = st.get(scope + "/gamma", (C,), init=lambda rng, shp: __import__("numpy").ones(shp))
@@ -1169,7 +1213,16 @@ def bn(inputs, is_training, scope="batch_normalization"):
         mean = st.buffers[scope + "/moving_mean"] = mean.to(inputs.device)
         var = st.buffers[scope + "/moving_variance"] = var.to(inputs.device)
     x2 = inputs.reshape(-1, C)
+    if BN_KERNEL and bool(is_training) and x2.is_cuda and x2.dtype == torch.float32 and C % 4 == 0 and x2.shape[0] > 1:
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        _PARAMS["bn_gamma"], _PARAMS["bn_beta"] = gamma, beta
+        y = _BNReLU.apply(x2, gamma, beta, mean, var, bool(relu))
+        _PARAMS.pop("bn_gamma", None); _PARAMS.pop("bn_beta", None)
+        return y.view(inputs.shape)
     y = torch.nn.functional.batch_norm(x2, mean, var, gamma, beta, training=bool(is_training), momentum=0.01, eps=1e-3)
+    if relu:
+        y = torch.relu(y)
     return y.view(inputs.shape)
 
 
@@ -1189,7 +1242,7 @@ def conv2d(inputs, output_dim, k_h=3, k_w=3, d_h=2, d_w=2, stddev=1, name="conv2
     y = torch.nn.functional.conv2d(x, w.permute(3, 2, 0, 1), b, stride=(d_h, d_w))
     y = y.permute(0, 2, 3, 1)                                        # back to NHWC
     if apply_bn:
-        y = bn(y, is_training, scope=name + "/batch_normalization")
+        return bn(y, is_training, scope=name + "/batch_normalization", relu=True)
     return torch.relu(y)
 
 
@@ -1217,9 +1270,9 @@ def CNNLayer(inputs, audiolen, num_enc_layers, feat_dim, cell_units, num_channel
                         st.get(sc + "/dense/bias", (enc_units,), init="zeros"))
         if apply_bn:
             enc_out = bn(enc_out, is_training, scope=sc + "/batch_normalization")
-            enc_out = torch.relu(bn(enc_out, is_training, scope=sc + "/batch_normalization_1"))
+            enc_out = bn(enc_out, is_training, scope=sc + "/batch_normalization_1", relu=True)
         else:
-            enc_out = torch.relu(bn(enc_out, is_training, scope=sc + "/batch_normalization"))
+            enc_out = bn(enc_out, is_training, scope=sc + "/batch_normalization", relu=True)
     return enc_out, enc_state, audiolen
 
 

@@ -470,6 +470,18 @@ int las_dropout_pair_fwd(const void* x, int x_dt, long long rows, int K, int ldx
 int las_dropout_pair_bwd(const void* g_fw, const void* g_bw, int g_dt, int ldg, long long rows, int K, void* dx, int dx_dt, int lddx,
                          float keep, unsigned long long seed, void* stream);
 
+/* tf.layers.batch_normalization over the last axis of a [rows, C] block in TRAINING mode, with the ReLU the CNN listener puts behind it
+ * (las/layers.py:114-116,155-161; momentum 0.99 -> `momentum` 0.01 here, epsilon 1e-3):
+ *   fwd: mean / rstd [C] = batch statistics (biased variance; kept by the caller for backward), y = [relu](gamma (x - mean) rstd + beta);
+ *        moving_mean / moving_var (both or neither): m = (1 - momentum) m + momentum {mean, unbiased variance}   (UPDATE_OPS, las/las.py:272)
+ *   bwd: dx; dgamma / dbeta (either may be NULL) are ACCUMULATED (+=).  relu: y is the forward's output (its sign is the mask).
+ * C % 4 == 0, 16-byte aligned pointers, ws >= las_bn_workspace_bytes(rows, C).  Deterministic (fixed-order reductions, no atomics). */
+size_t las_bn_workspace_bytes(long long rows, int C);
+int las_bn_relu_fwd(const float* x, long long rows, int C, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                    float* moving_mean, float* moving_var, float momentum, int relu, float* y, void* ws, size_t ws_bytes, void* stream);
+int las_bn_relu_bwd(const float* x, const float* y, const float* dy, long long rows, int C, const float* gamma, const float* mean,
+                    const float* rstd, int relu, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 size_t las_sumsq_workspace_bytes(long long n);
 int las_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, void* stream);
 int las_clip_adam(float* theta, const float* g, float* m, float* v, long long n,
