@@ -1604,11 +1604,15 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
 // Grid (column tile, 16-row tile): every workgroup reads ONE 16-row slab of A (fp32, or bf16 written by the producer
 // kernel) and one column tile of fragments -- 37+37 KB at K=1152 instead of 221+37 KB for the all-rows form above.
 // 8 waves split K with every load in flight at once, then an LDS reduction of the 8 partial tiles.
-template <bool ABF>
+// EPI (round 6, the wide Speller path's tanh cells): the epilogue is the BasicRNNCell itself -- h = tanh(acc + bias) -- written as fp32 to
+// `eh` (the saved state the gradient loop reads) and as bf16 into up to two operand rows of the NEXT products (the layer above's [x ; h]
+// row, the query projection's state row): the gate-math launch between two dependent products disappears.
+struct SkinnyEpi { float* eh; int ldh; unsigned short* b0; int ld0; unsigned short* b1; int ld1; };
+template <bool ABF, bool EPI = false>
 __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
                                                              float* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                             int accumulate) {
+                                                             int accumulate, SkinnyEpi epi = SkinnyEpi{}) {
     constexpr int NW = 8;
     __shared__ float red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -1661,8 +1665,16 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) v += red[ww][l2][reg];
             if (bias) v += bias[col];
-            if (accumulate) v += C[(long long)orow * ldc + col];
-            C[(long long)orow * ldc + col] = v;
+            if (EPI) {
+                const float h = tanh_fast(v);
+                epi.eh[(long long)orow * epi.ldh + col] = h;
+                const unsigned short hb = f2bf(h);
+                if (epi.b0) epi.b0[(long long)orow * epi.ld0 + col] = hb;
+                if (epi.b1) epi.b1[(long long)orow * epi.ld1 + col] = hb;
+            } else {
+                if (accumulate) v += C[(long long)orow * ldc + col];
+                C[(long long)orow * ldc + col] = v;
+            }
         }
     }
 }
@@ -1686,6 +1698,17 @@ int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const v
     return 0;
 }
 
+
+// h = tanh(bf16(A) . packed + bias) -> eh [M, N] fp32 (ldh), and its bf16 copy into b0 / b1 (either may be null; element (r, c) at r ld + c)
+int las_skinny_gemm_bf16_tanh(const unsigned short* A, int lda, int M, int K, const void* packed, int N, const float* bias, float* eh, int ldh,
+                              unsigned short* b0, int ld0, unsigned short* b1, int ld1, hipStream_t st) {
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    SkinnyEpi e{eh, ldh, b0, ld0, b1, ld1};
+    hipLaunchKernelGGL((skinny_rows_kernel<true, true>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, (float*)nullptr, 0, bias, 0, e);
+    LAS_LAUNCHED();
+    return 0;
+}
 
 // ---- C ABI of the skinny-M product (include/las_hip.h): weights packed once, then C[M,N] (+)= bf16(A[M,K]) . bf16(W) + bias per call
 extern "C" size_t las_gemm_skinny_pack_bytes(int K, int N) { return K > 0 && N > 0 ? las_skinny_pack_bytes(K, N) : 0; }

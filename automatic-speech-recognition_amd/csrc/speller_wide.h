@@ -86,6 +86,8 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
         const float v = (l == TOP && t > 0) ? hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
         if (FAST) w.sbf[(size_t)b * S + i] = f2bf(v);
         else w.sf[(size_t)b * S + i] = v;
+        // step 0 of the tanh-epilogue chain (speller_wide_host.h): the upper layers' recurrent halves [. ; h_{l,0}] of their first operand rows
+        if (FAST && t == 0 && l >= 1 && l == 1) w.xu[(size_t)b * 2 * D + D + d] = f2bf(v);
     }
 }
 
@@ -701,7 +703,7 @@ static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
         w.packUB[l] = o; o += (l >= 1 && l < NL) ? align256(las_skinny_pack_bytes((int)GD, 2 * D)) : 0;
     }
     w.srow = o;  o += align256((size_t)B * S * 4);
-    w.xu = o;    o += align256((size_t)B * 2 * D * 2);
+    w.xu = o;    o += align256((size_t)2 * B * 2 * D * 2);          // two rows per utterance: the tanh-epilogue products alternate (a product writes the NEXT step's half while it reads this step's)
     w.dqbf = o;  o += align256((size_t)B * A * 2);
     w.dgu = o;   o += align256((size_t)B * GD * 2);
     w.qbuf = o;  o += align256((size_t)B * A * 4);

@@ -39,8 +39,12 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
     const size_t lds_s = (size_t)(((D + 3) & ~3) + 64) * sizeof(float) + 64;
     const size_t lds_e = wide_lds_bytes(d, w.fper);
     const size_t lds_c = (size_t)(((d.Tp + 3) & ~3) + 4 * RNT) * sizeof(float) + 64;
+    // tanh cells, speed mode, tokens known in advance (no in-loop logits): the cell IS the product's epilogue (las_skinny_gemm_bf16_tanh:
+    // h = tanh(. + bias) -> the saved state, and as bf16 straight into the operand rows of the products that read it next), so the state
+    // launch (after step 0) and the gate launches between the layers' products drop out of the chain: 7 -> 5 dependent launches per step
+    const bool epi = FAST && CELL == LAS_CELL_RNN && !d.step_logits && NL <= 2;
     for (int t = 0; t <= U; ++t) {
-        WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
+        if (!epi || t == 0) WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
         if (t == U) break;
         if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.sbf, S, B, S, wb + WL.packWs, A, w.qbuf, A, nullptr, st));
         else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, w.sf, S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
@@ -48,6 +52,20 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
         else     WIDE_LAUNCH((wide_energy_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
         WIDE_LAUNCH((wide_context_kernel<FAST>), dim3(w.hsplit, B), dim3(RNT), lds_c, st, d, w, t);
         float* g0 = d.gates + ((size_t)0 * U + t) * B * GD;
+        if (epi) {
+            // layer 0: h_{0,t+1} -> hs[0][t+1]; bf16 into the layer above's [x ; h] row (multi-layer) and into the state row of step t+1
+            // (two operand-row buffers for layer 1, alternating per step: its product reads [h_{0,t+1} ; h_{1,t}] from buffer t % 2 while its
+            //  epilogue leaves h_{1,t+1} in the upper half of buffer (t + 1) % 2 -- in one buffer a column tile would overwrite what another
+            //  tile's K walk still reads)
+            unsigned short* xu_cur = w.xu + (size_t)(t & 1) * B * 2 * D;
+            unsigned short* xu_nxt = w.xu + (size_t)((t + 1) & 1) * B * 2 * D;
+            GEMM_OK(las_skinny_gemm_bf16_tanh(d.xbf, I0D, B, I0D, packF, GD, f->cellb[0], d.hs + ((size_t)0 * (U + 1) + t + 1) * B * D, D,
+                                              NL > 1 ? xu_cur : nullptr, 2 * D, w.sbf, S, st));
+            if (NL == 2)
+                GEMM_OK(las_skinny_gemm_bf16_tanh(xu_cur, 2 * D, B, 2 * D, wb + WL.packU[1], GD, f->cellb[1], d.hs + ((size_t)1 * (U + 1) + t + 1) * B * D, D,
+                                                  xu_nxt + D, 2 * D, w.sbf + D, S, st));
+            continue;
+        }
         if (FAST) {
             GEMM_OK(las_skinny_gemm_bf16(d.xbf, I0D, B, I0D, packF, GD, g0, GD, f->cellb[0], st));
         } else {

@@ -558,6 +558,7 @@ class LAS:
         self._backoff = 16
         self._warned_recover = False
         self.recovered_steps = 0  # steps re-run after a time-out status (tests / logs)
+        self.last_out = None      # what the newest train step returned -- of its RE-RUN when the step was lost and recovered
 
     # -- helpers -----------------------------------------------------------------------------------
     @staticmethod
@@ -638,6 +639,7 @@ class LAS:
         self._pending_status = 0
         if code:
             out = self._recover(code) or out
+        self.last_out = out               # (check_status may replace it: what train() returned for a step that is lost later is not valid)
         return out
 
     def _recover(self, code, first=None):
@@ -882,14 +884,14 @@ class LAS:
             while self._guard_probes:                    # (the same probes, in the same order, on every rank)
                 gs, pin, ev = self._guard_probes.popleft()
                 if float(pin[0]) != 0.0:
-                    self._recover(int(_hip.status_word(dev)[0].item()) or 3, first=gs)
+                    self.last_out = self._recover(int(_hip.status_word(dev)[0].item()) or 3, first=gs) or self.last_out
                     break
             return
         if RECOVER_STEPS and self._recent:
             torch.cuda.synchronize(dev)
             code = int(_hip.status_word(dev)[0].item())
             if code:
-                self._recover(code)
+                self.last_out = self._recover(code) or self.last_out
             return
         _hip.check_status(dev)
 
