@@ -55,6 +55,7 @@ struct LoopProd {
 struct DecDev {
     int B, Tp, Hd, A, D, NL, E, V, U, mode, Kc, C, step_logits, flags;
     int row_group;         // > 0: rows u rg .. u rg + rg - 1 share enc / keys (beam search: one utterance's hypotheses) -> XCD-local row workgroups
+    int shared_ops;        // 1: enc / keys (and their bf16 copies) hold ONE block per group of row_group rows -- [B / row_group, Tp, .] -- not one per row
     LoopProd lp;
     float fb;
     unsigned long long seed;
@@ -949,6 +950,9 @@ __device__ __forceinline__ void put4_bf16(const __amdgpu_buffer_rsrc_t rs, const
 #ifndef LAS_ABL_SP
 #define LAS_ABL_SP 0   // development: bit mask of parts of the forward row to leave out (timing experiments only; make abl_sp ABL=<mask>)
 #endif
+// the operand block (keys / encoder rows) of row b: its own, or -- LAS_SPELLER_SHARED_OPERANDS -- its group's (the utterance's)
+__device__ __forceinline__ int op_row(const DecDev& a, const int b) { return a.shared_ops ? b / a.row_group : b; }
+
 template <int CELL, int NE, bool LOOP, bool LOC = false>
 __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const int b, const int tid, float* sm, float& ccar, const bool local) {
     static_assert(LOOP || !LOC, "location-aware attention is served by the loop kernels only (the per-step path is dec_step_fwd_kernel<.,.,true>)");
@@ -982,7 +986,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
             const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b * Tp + ttc) * A8 + a8c_];
+            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)(LOOP ? b : op_row(a, b)) * Tp + ttc) * A8 + a8c_];
         }
     }
     if (LOC) {
@@ -1024,6 +1028,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     const float s0 = a.hs[(size_t)b * D + dd];                       // initial state (used at t = 0)
     int tok = a.tok_in[(size_t)tc * B + b];
     const int len = a.enc_len[b];
+    const int bo = LOOP ? b : op_row(a, b);          // (a search's hypothesis rows may share their utterance's operand block)
     const int a4c = a4 < A4 ? a4 : A4 - 1, a8c = a8 < A8 ? a8 : A8 - 1, h4c = h4 < H4 ? h4 : H4 - 1;
     if (!(LOC && LAS_LOC_WS_EARLY)) {
 #pragma unroll
@@ -1037,7 +1042,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
             const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1024) ? (size_t)(tid & 63) : ((size_t)b * Tp + ttc) * A8 + a8c];
+            k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[(LAS_ABL_SP & 1024) ? (size_t)(tid & 63) : ((size_t)bo * Tp + ttc) * A8 + a8c];
         }
     }
     constexpr int NEL = LOOP ? EncRes<NE, LOC>::N : 0;      // encoder slabs resident in LDS (loop kernels): see EncRes
@@ -1046,7 +1051,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
     auto e8_load = [&](const int u) __attribute__((always_inline)) {
         const int tp = fg + 8 * u;
         const int tpc = tp < Tp2 ? tp : Tp2 - 1;
-        e8[u - NEL] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 2048) ? (size_t)(tid & 63) : ((size_t)b * Tp2 + tpc) * H4 + h4c];
+        e8[u - NEL] = reinterpret_cast<const uint4*>(a.encbf2)[(LAS_ABL_SP & 2048) ? (size_t)(tid & 63) : ((size_t)bo * Tp2 + tpc) * H4 + h4c];
     };
     if (NEL > 0 && LAS_E8_EARLY) {                            // the streamed slabs ride with the other bulk loads
 #pragma unroll
@@ -1378,7 +1383,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
         const int tt = grp + 64 * u, ttc = tt < Tp ? tt : Tp - 1;
-        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)b0 * Tp + ttc) * A8 + a8c];
+        k8[u] = reinterpret_cast<const uint4*>(a.keysbf)[((size_t)op_row(a, b0) * Tp + ttc) * A8 + a8c];
     }
     STAMPB(1);
 #pragma unroll
@@ -1431,7 +1436,7 @@ __global__ __launch_bounds__(RNT) void dec_beam_rows4_kernel(DecDev a) {
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
         const int tp = fg + 8 * u, tpc = tp < Tp2 ? tp : Tp2 - 1;
-        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)b0 * Tp2 + tpc) * H4 + h4c];
+        e8[u] = reinterpret_cast<const uint4*>(a.encbf2)[((size_t)op_row(a, b0) * Tp2 + tpc) * H4 + h4c];
     }
     STAMPB(4);
     {   // energies: a frame's keys are unpacked once and meet the four queries
@@ -3194,6 +3199,8 @@ static int fill_dev(const las_speller_fwd_args* f, DecDev& d) {
     d.mode = f->mode; d.Kc = f->mode == LAS_ATT_LOC ? f->Kc : 0; d.C = f->mode == LAS_ATT_LOC ? f->C : 0;
     d.step_logits = f->step_logits; d.flags = f->flags; d.fb = f->forget_bias; d.seed = f->seed;
     d.row_group = (f->row_group > 0 && f->B % f->row_group == 0) ? f->row_group : 0;
+    d.shared_ops = ((f->flags & LAS_SPELLER_SHARED_OPERANDS) && d.row_group > 0) ? 1 : 0;
+    LAS_ARG(!(f->flags & LAS_SPELLER_SHARED_OPERANDS) || d.row_group > 0, "speller: LAS_SPELLER_SHARED_OPERANDS needs row_group > 0 with B %% row_group == 0");
     d.enc = f->enc; d.keys = f->keys; d.enc_len = f->enc_len; d.Ws = f->Ws; d.u = f->u; d.emb = f->emb;
     d.Wv = f->Wv; d.bv = f->bv; d.loc_w = f->loc_w; d.loc_b = f->loc_b; d.Wf = f->Wf;
     d.tok_in = f->tokens_in; d.tok_out = f->tokens_out; d.align0 = f->align0; d.emb_mask = f->emb_mask; d.emb_noise = f->emb_noise; d.logits = f->logits; d.alphas = f->alphas;
@@ -3274,7 +3281,8 @@ static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st)
     unsigned short* wsb = (unsigned short*)(base + w.wsbf);
     unsigned short* kb = (unsigned short*)(base + w.keysbf);
     unsigned short* eb = (unsigned short*)(base + w.encbf);
-    const size_t nW = (size_t)d.D * d.NL * d.A, nK = (size_t)d.B * d.Tp * d.A, nE = (size_t)d.B * d.Tp * d.Hd;
+    const int nblk = d.shared_ops ? d.B / d.row_group : d.B;       // operand blocks: one per row, or one per group of rows
+    const size_t nW = (size_t)d.D * d.NL * d.A, nK = (size_t)nblk * d.Tp * d.A, nE = (size_t)nblk * d.Tp * d.Hd;
     if (d.flags & LAS_SPELLER_REUSE_PREP) {   // the caller vouches that an earlier call left the copies of the SAME tensors here
         d.Wsbf = wsb; d.keysbf = kb; d.encbf = eb;
         d.Wsbf2 = (unsigned short*)(base + w.wsbf2); d.encbf2 = (unsigned short*)(base + w.encbf2);
@@ -3290,7 +3298,7 @@ static int make_bf_copies(DecDev& d, char* base, const BwdWs& w, hipStream_t st)
     jobs.j[1] = {d.keys, kb, nK, 0, 0, 1};
     jobs.j[2] = {d.enc, eb, nE, 0, 0, 1};
     jobs.j[3] = {d.Ws, wsb2, 0, S, d.A, 1};
-    jobs.j[4] = {d.enc, eb2, 0, d.Tp, d.Hd, d.B};
+    jobs.j[4] = {d.enc, eb2, 0, d.Tp, d.Hd, nblk};
     hipLaunchKernelGGL(bf_copies_kernel, dim3(512, 5), dim3(256), 0, st, jobs);
     LAS_LAUNCHED();
     d.Wsbf = wsb; d.keysbf = kb; d.encbf = eb; d.Wsbf2 = wsb2; d.encbf2 = eb2;
@@ -3349,6 +3357,8 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
     g_last_variant[0] = (wide ? LAS_SPELLER_RAN_WIDE : loop ? LAS_SPELLER_RAN_LOOP : pf ? LAS_SPELLER_RAN_PF_ROWS : bfrows ? LAS_SPELLER_RAN_BF_ROWS : LAS_SPELLER_RAN_F32_ROWS) |
                         (skinny ? LAS_SPELLER_RAN_SKINNY : 0) | (d.mode == LAS_ATT_LOC ? LAS_SPELLER_RAN_LOC : 0) |
                         (wide && FAST && NL > 1 ? LAS_SPELLER_RAN_UPPER_SKINNY : 0);
+    LAS_ARG(!d.shared_ops || ((d.flags & LAS_SPELLER_NO_LOGITS) && pf && !loop && !wide && U == 1),
+            "speller: LAS_SPELLER_SHARED_OPERANDS is served by the search step's prefetching row kernels only (LAS_SPELLER_NO_LOGITS, U = 1)");
     if (d.flags & LAS_SPELLER_NO_LOGITS)
         LAS_ARG(CELL == LAS_CELL_LSTM && NL == 1 && U == 1 && skinny && pf && !loop && (D % 32) == 0 && (I0D % 32) == 0 && d.step_logits,
                 "speller: LAS_SPELLER_NO_LOGITS needs U = 1, one LSTM layer, speed mode with the prefetching row kernels, D and E + Hd + D multiples of 32");

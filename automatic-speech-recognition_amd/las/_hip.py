@@ -606,7 +606,7 @@ class _timed:
 # tools/ scripts keep working, and tests set `seq_flags` / `speller_flags` directly.
 SEQ_AGENT_GRANULES, SEQ_NO_KSPLIT, SEQ_NO_HELPER_WAVES, SEQ_ROWS16, SEQ_NO_WARMERS, SEQ_F32_VALU, SEQ_PREPARED = 1, 2, 4, 8, 16, 32, 64
 SPELLER_NO_PF_ROWS, SPELLER_NO_BF_ROWS, SPELLER_NO_FUSED_STEP, SPELLER_REUSE_PREP, SPELLER_NO_LOGITS, SPELLER_ROWS_SHARE4 = 1, 2, 4, 8, 16, 32
-SPELLER_WIDE, SPELLER_NO_WIDE = 64, 128      # csrc/speller_wide.h: force / forbid the wide per-step path (LAS_SPELLER_WIDE=1 / LAS_NO_WIDE=1)
+SPELLER_WIDE, SPELLER_NO_WIDE, SPELLER_SHARED_OPERANDS = 64, 128, 1 << 14      # csrc/speller_wide.h: force / forbid the wide per-step path (LAS_SPELLER_WIDE=1 / LAS_NO_WIDE=1)
 SEQ_STATUS = {1: "forward sweep: a cluster partner did not publish h within the spin bound (or a chunk of the x-projection did not "
                  "complete while the sweep was waiting for it: kernels of different streams must be able to overlap -- under a "
                  "tool that serialises kernels, e.g. rocprofv3 --pmc, set LAS_ALLOW_SERIAL_STREAMS=1)",

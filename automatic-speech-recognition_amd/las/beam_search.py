@@ -109,6 +109,7 @@ class BeamSearch(object):
         # encoder rows read once for the four) from this many hypothesis rows on (0 = never); bit-identical to one row per workgroup
         self.share_rows_from = int(os.environ.get("LAS_DECODE_SHARE_ROWS_FROM", "512"))
         self.xcd_local_rows = os.environ.get("LAS_NO_XCD_LOCAL_ROWS") != "1"       # decode_batch (round 6): an utterance's hypothesis rows on one XCD
+        self.shared_operands = os.environ.get("LAS_NO_SHARED_OPERANDS") != "1"    # ... and ONE copy of its keys / encoder rows for all of them (not np.tile's 16)
         self.lm_state_copies = os.environ.get("LAS_NO_LM_STATE_COPIES") != "1"      # decode_batch (round 5): bf16 copies of the LM's state from 384 rows on
         self.steps_per_graph = int(os.environ.get("LAS_DECODE_STEPS_PER_GRAPH", "8"))   # search steps per captured HIP graph (one replay = that many steps)
         self.ragged_encoder = os.environ.get("LAS_NO_RAGGED_ENCODER") != "1"        # decode_batch: one encoder pass over rows of different lengths
@@ -335,24 +336,36 @@ class BeamSearch(object):
         Tps = [h.shape[1] for h in encs]
         Tp, Hd = max(Tps), encs[0].shape[2]
         N = n * beam
-        enc_t = torch.zeros(N, Tp, Hd, device=dev)          # resident for the whole search; frames past T'_u are masked
-        keys_t = torch.zeros(N, Tp, A, device=dev)
+        # Round 6: ONE operand block per utterance, resident for the whole search (frames past T'_u are masked).  The reference feeds
+        # np.tile(h) -- a copy of the encoder output per hypothesis (las/beam_search.py:216) -- and so did rounds 1-5: 16 copies of every
+        # utterance's keys and encoder rows, each read through its own addresses at every step (54 MB per step at 256 rows, r5_decode_pmc.json).
+        # The search step's row kernels now take the utterance's block (LAS_SPELLER_SHARED_OPERANDS); the tiled copies are only made for
+        # the long form of the step (kernel families that index per row).
         Wh = P["Wh"].detach()
         if h_one is not None and h_one.shape[0] == n:
-            # every utterance in ONE encoder group (equal lengths): the hoisted key projection as one product and two broadcast copies
-            # instead of a product and two copies per utterance (192 launches, ~2 ms of a 64-utterance batch; the same k order per
-            # element: bit-identical)
-            hc = h_one.contiguous()
-            k_all = torch.empty(n, Tp, A, device=dev)
-            _hip.gemm(prec, hc, Wh, k_all, False, False, n * Tp, A, Hd, Hd, A, A)
-            enc_t.view(n, beam, Tp, Hd).copy_(hc.unsqueeze(1).expand(n, beam, Tp, Hd))
-            keys_t.view(n, beam, Tp, A).copy_(k_all.unsqueeze(1).expand(n, beam, Tp, A))
+            # every utterance in ONE encoder group (equal lengths): the hoisted key projection as one product
+            enc_u = h_one.contiguous()
+            keys_u = torch.empty(n, Tp, A, device=dev)
+            _hip.gemm(prec, enc_u, Wh, keys_u, False, False, n * Tp, A, Hd, Hd, A, A)
         else:
+            enc_u = torch.zeros(n, Tp, Hd, device=dev)
+            keys_u = torch.zeros(n, Tp, A, device=dev)
             for u, h in enumerate(encs):
                 k = torch.empty(1, Tps[u], A, device=dev)
                 _hip.gemm(prec, h.contiguous(), Wh, k, False, False, Tps[u], A, Hd, Hd, A, A)
-                enc_t[u * beam:(u + 1) * beam, :Tps[u]] = h
-                keys_t[u * beam:(u + 1) * beam, :Tps[u]] = k
+                enc_u[u, :Tps[u]] = h[0]
+                keys_u[u, :Tps[u]] = k[0]
+        tiled_ops = []
+
+        def tiled():
+            """the per-row copies [N, Tp, .] (made once, on demand)"""
+            if not tiled_ops:
+                enc_t = torch.empty(N, Tp, Hd, device=dev)
+                keys_t = torch.empty(N, Tp, A, device=dev)
+                enc_t.view(n, beam, Tp, Hd).copy_(enc_u.unsqueeze(1).expand(n, beam, Tp, Hd))
+                keys_t.view(n, beam, Tp, A).copy_(keys_u.unsqueeze(1).expand(n, beam, Tp, A))
+                tiled_ops.extend([enc_t, keys_t])
+            return tiled_ops
         enc_len_i32 = torch.tensor(np.repeat(np.asarray(enc_lens, np.float64), beam)).to(torch.int32).to(dev)
         Umax = max(max(dec_steps), 1)
         # ---- device-resident loop state
@@ -385,7 +398,7 @@ class BeamSearch(object):
         tokens_out = torch.zeros(1, N, **i32)
         Pd = {k: (v.detach() if torch.is_tensor(v) else [t.detach() for t in v]) for k, v in P.items()}
         fa = _hip.SpellerFwdArgs()
-        keep = _fill_fwd_args(fa, dims, Pd, enc_t, keys_t, enc_len_i32, next_token, tokens_out, bufs, True, 0, keep_state0=True,
+        keep = _fill_fwd_args(fa, dims, Pd, enc_u, keys_u, enc_len_i32, next_token, tokens_out, bufs, True, 0, keep_state0=True,
                               align0=align_prev)
         lib = _hip.lib()
         nbytes = lib.las_speller_workspace_bytes(N, Tp, Hd, A, D, NL, a.embedding_size, V_, 1, dims["cell"])
@@ -453,7 +466,8 @@ class BeamSearch(object):
                 # the library refuses the short form for this geometry (it needs its prefetching row kernels): the long form it is
                 mode["fused"] = False
                 mode.pop("three", None)
-                fa.flags &= ~(_hip.SPELLER_NO_LOGITS | _hip.SPELLER_ROWS_SHARE4)
+                fa.flags &= ~(_hip.SPELLER_NO_LOGITS | _hip.SPELLER_ROWS_SHARE4 | _hip.SPELLER_SHARED_OPERANDS)
+                fa.enc, fa.keys = (t.data_ptr() for t in tiled())       # (the long form's kernel families index enc / keys per row)
                 fa.companion = None
                 fa.companion_rows = None
                 ba.proj_w = None
@@ -470,6 +484,9 @@ class BeamSearch(object):
                       ((beam + 15) // 16) * ((V_ + 15) // 16) <= 8 and (lm is None or (lm.hidden_size % 32 == 0 and "packs" in lm_plan)))
         proj_keep = None
         mode["fused"] = fused_proj
+        shared = fused_proj and self.shared_operands and self.xcd_local_rows
+        if not shared:
+            fa.enc, fa.keys = (t.data_ptr() for t in tiled())          # np.tile(enc, beam) of the reference (las/beam_search.py:60-63), physically
         if fused_proj:
             Wcat, bcat = Pd["Wv"].contiguous(), Pd["bv"].clone()
             if lm is not None:
@@ -480,6 +497,8 @@ class BeamSearch(object):
             Wcat = Wcat.contiguous()
             proj_keep = (_hip.skinny_pack(Wcat, Wcat.shape[0], V_), bcat.contiguous())
             fa.flags |= _hip.SPELLER_NO_LOGITS
+            if shared:
+                fa.flags |= _hip.SPELLER_SHARED_OPERANDS     # enc / keys: one block per utterance (fa.row_group = beam rows share it)
             if self.share_rows_from and N >= self.share_rows_from and beam % 4 == 0 and a.mode == "add":
                 fa.flags |= _hip.SPELLER_ROWS_SHARE4         # rows 4g .. 4g+3 are hypotheses of ONE utterance: same enc / keys / length
             ba.proj_w, ba.proj_b = proj_keep[0].data_ptr(), proj_keep[1].data_ptr()

@@ -317,7 +317,11 @@ enum { LAS_SPELLER_WIDE = 64,           /* (round 6) take the wide per-step path
                                            context on (slice, utterance) workgroups, every layer's cell product on pre-packed MFMA fragments) wherever its
                                            geometry allows; by default it serves the multi-layer and location-aware calls of both modes
                                            outside the one-launch loop kernels' geometry (e.g. run.sh's 2 x 1024 decoder at T' = 319) */
-       LAS_SPELLER_NO_WIDE = 128 };     /* never take it (round 5's per-utterance row kernels) */
+       LAS_SPELLER_NO_WIDE = 128,       /* never take it (round 5's per-utterance row kernels) */
+       LAS_SPELLER_SHARED_OPERANDS = 1 << 14 };  /* (with row_group > 0 and LAS_SPELLER_NO_LOGITS: a beam search's step) enc and keys hold ONE block per
+                                           group of row_group rows -- enc [B / row_group, Tp, Hd], keys [B / row_group, Tp, A] -- instead of one copy per
+                                           hypothesis row (the reference feeds np.tile(h), las/beam_search.py:216: 16 copies of every utterance's
+                                           205 KB, each read through its own addresses -- 54 MB per step at 256 rows).  enc_len stays per row. */
 #define LAS_SPELLER_SPIN_LOG2(n) (((n) & 31) << 8)   /* tests: the loop kernels' poll budget is 2^n instead of 2^21 */
 typedef struct {
     int B, Tp, Hd, A, D, NL, E, V, U, cell, mode, prec, Kc, C, step_logits, keep_state0;
