@@ -896,11 +896,15 @@ __device__ unsigned long long g_stamps[32];
 #define STAMPL(v) g_stamps[31] = (v)
 #define STAMPB(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 extern "C" int las_dev_row_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+__device__ unsigned long long g_wstamps[64];      // the wide path's kernels (speller_wide.h), workgroup (0, 0): tools/probe_wide_stamps.py
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_wstamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int las_dev_wide_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(g_wstamps)); }
 #else
 #define STAMPX(i)
 #define STAMPQ(i)
 #define STAMPB(i)
 #define STAMPL(v)
+#define WSTAMP(i)
 #endif
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs (v_dot2c_f32_bf16)

@@ -92,20 +92,60 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
 }
 
 // f[t', c] = bias[c] + sum_k prev_align[t' + k - pad] w[k, c] for the frames [t0, t0 + nf) of one utterance (conv1d, SAME, cross-correlation:
-// las/layers.py:295-296) -> fc [nf, C] in LDS.  aprev [Tp] and locw [Kc, C] are in LDS; part: nf C ksplit floats of scratch.
-__device__ __forceinline__ int wide_conv_ks(int Kc) { return Kc >= 64 ? 8 : 1; }      // tap slices per (frame, channel) output
-__device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* aprev, const float* locw, float* fc, float* part, int t0, int nf, int tid) {
-    const int Tp = a.Tp, C = a.C, Kc = a.Kc, pad = (Kc - 1) / 2, items = nf * C;
-    const int ks = wide_conv_ks(Kc);
-    const int kper = (Kc + ks - 1) / ks;
-    for (int i = tid; i < items * ks; i += RNT) {         // (round 6: 640 outputs x 201 serial taps on 640 of 1024 threads was 10 of the kernel's 18 us)
-        const int kc = i / items, it = i - kc * items, fr = it / C, c = it - fr * C, tt = t0 + fr;
-        int k0 = kc * kper, k1 = k0 + kper < Kc ? k0 + kper : Kc;
-        if (k0 < pad - tt) k0 = pad - tt;                       // taps that meet a frame: 0 <= tt + k - pad < Tp
-        if (k1 > Tp + pad - tt) k1 = Tp + pad - tt;
-        float acc = kc == 0 ? a.loc_b[c] : 0.f;
-        for (int k = k0; k < k1; ++k) acc = fmaf(aprev[tt + k - pad], locw[k * C + c], acc);
-        part[i] = acc;
+// las/layers.py:295-296) -> fc [nf, C] in LDS.  `awin` is the slice's WINDOW of the previous alignment in LDS -- awin[j] = alpha_{t-1}[t0 - pad
+// + j], zero where that frame does not exist (wide_stage_awin) -- so that frame fr meets tap k at awin[fr + k] and no tap needs a bound;
+// locw [Kc + 8, C] in LDS (rows >= Kc are never multiplied in); part: nf C ksplit floats of scratch.
+// One thread = (tap slice, block of 8 consecutive frames, channel): the 8 + 8 window values of a chunk of 8 taps stay in registers (one new
+// value and one weight per 8 multiply-adds), every loop has a fixed trip count.  (Round 6, first version: one (tap slice, frame, channel)
+// output per thread item with two LDS reads per multiply-add in a loop the compiler could not unroll -- 6.9 of the energy kernel's 12.3 us,
+// profiles/r6_wide_phase_stamps.txt.)  Same taps per slice, same order within a slice, same order of the slices' sum as that version.
+__host__ __device__ __forceinline__ int wide_conv_ks(int Kc) { return Kc >= 64 ? 8 : 1; }      // tap slices per (frame, channel) output
+__host__ __device__ __forceinline__ int wide_conv_kper(int Kc) { const int ks = wide_conv_ks(Kc); return (Kc + ks - 1) / ks; }
+// floats of the window: the slice's frames rounded up to 8, plus every tap a thread may touch (its slice's start + its taps rounded up to 8)
+__host__ __device__ __forceinline__ int wide_awin_floats(int fper, int Kc) {
+    const int ks = wide_conv_ks(Kc), kper = wide_conv_kper(Kc);
+    return ((fper + 7) & ~7) + (ks - 1) * kper + ((kper + 7) & ~7) + 8;
+}
+__device__ __forceinline__ void wide_stage_awin(const DecDev& a, float* awin, int t, int b, int t0, int fper, int tid) {
+    const int Tp = a.Tp, pad = (a.Kc - 1) / 2, n = wide_awin_floats(fper, a.Kc);
+    const float* src = t > 0 ? a.alphas + ((size_t)(t - 1) * a.B + b) * Tp : (a.align0 ? a.align0 + (size_t)b * Tp : nullptr);
+    for (int j = tid; j < n; j += RNT) {
+        const int fr = t0 - pad + j;
+        awin[j] = (src && fr >= 0 && fr < Tp) ? src[fr] : 0.f;
+    }
+}
+__device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* awin, const float* locw, float* fc, float* part, int nf, int tid) {
+    const int C = a.C, Kc = a.Kc, items = nf * C;
+    const int ks = wide_conv_ks(Kc), kper = wide_conv_kper(Kc);
+    const int nfb = (nf + 7) >> 3, items8 = nfb * C;
+    for (int i = tid; i < items8 * ks; i += RNT) {
+        const int kc = i / items8, r = i - kc * items8, fb = r / C, c = r - fb * C;
+        const int k0 = kc * kper, kend = k0 + kper < Kc ? k0 + kper : Kc;
+        const float init = kc == 0 ? a.loc_b[c] : 0.f;
+        float acc[8], x[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j] = init; x[j] = awin[fb * 8 + k0 + j]; }
+        int k = k0;
+        for (; k + 8 <= kend; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x[8 + u] = awin[fb * 8 + k + 8 + u]; wv[u] = locw[(k + u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(x[j + u], wv[u], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = x[8 + j];
+        }
+        for (; k < kend; ++k) {                                // the slice's last taps (kper % 8 of them)
+            const float wv = locw[k * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(awin[fb * 8 + k + j], wv, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (fb * 8 + j < nf) part[kc * items + (fb * 8 + j) * C + c] = acc[j];
     }
     __syncthreads();
     for (int it = tid; it < items; it += RNT) {
@@ -130,8 +170,8 @@ __device__ __forceinline__ WideLds wide_carve(float* sm, const DecDev& a, int fp
     L.qv = p; p += u4(a.A);
     L.ev = p; p += u4(fper);
     L.red = p; p += 64;
-    L.aprev = p; p += loc ? u4(a.Tp) : 0;
-    L.locw = p; p += loc ? u4(a.Kc * a.C) : 0;
+    L.aprev = p; p += loc ? u4(wide_awin_floats(fper, a.Kc)) : 0;      // the slice's window of alpha_{t-1} (wide_stage_awin)
+    L.locw = p; p += loc ? u4((a.Kc + 8) * a.C) : 0;
     L.wfl = p; p += loc ? u4(a.C * a.A) : 0;
     L.fc = p; p += loc ? u4(fper * a.C) : 0;
     L.dfc = p; p += loc ? u4(fper * a.C) : 0;
@@ -142,7 +182,7 @@ static size_t wide_lds_bytes(const DecDev& a, int fper) {
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
     const bool loc = a.mode == LAS_ATT_LOC;
     size_t n = u4(a.A) + u4(fper) + 64;
-    if (loc) n += u4(a.Tp) + u4((size_t)a.Kc * a.C) + u4((size_t)a.C * a.A) + 2 * u4((size_t)fper * a.C);
+    if (loc) n += u4((size_t)wide_awin_floats(fper, a.Kc)) + u4((size_t)(a.Kc + 8) * a.C) + u4((size_t)a.C * a.A) + 2 * u4((size_t)fper * a.C);
     return (n + wide_part_floats(a.A, fper, loc ? a.C : 0)) * sizeof(float) + 64;
 }
 
@@ -166,23 +206,26 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+    WSTAMP(0);
     for (int i = tid; i < A; i += RNT) L.qv[i] = w.qbuf[(size_t)b * A + i];
     if (LOC) {
-        for (int i = tid; i < Tp; i += RNT)
-            L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+        wide_stage_awin(a, L.aprev, t, b, t0, w.fper, tid);
         for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
         for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
     }
     __syncthreads();
+    WSTAMP(1);
     if (nf <= 0) { if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; } return; }
     if (LOC) {
-        wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, t0, nf, tid);
+        wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, nf, tid);
+        WSTAMP(2);
         if (a.fcSave) {              // kept for the gradient loop and the after-loop filter / keys gradients
             float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
             for (int i = tid; i < nf * C; i += RNT) fs[i] = L.fc[i];
             if (a.actS && t == 0 && b == 0 && s == 0 && tid == 0) a.actS[0] = LAS_ACT_MAGIC_WIDE;
         }
     }
+    WSTAMP(3);
     const int len = a.enc_len[b];
     const int sl = tid & 31, grp = tid >> 5;
     for (int fr = grp; fr < nf; fr += RNG) {
@@ -210,6 +253,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
         }
     }
     __syncthreads();
+    WSTAMP(4);
     float m = -INFINITY;
     for (int i = tid; i < nf; i += RNT) m = fmaxf(m, L.ev[i]);
     m = block_max<RNT>(m, L.red);
@@ -217,6 +261,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
     for (int i = tid; i < nf; i += RNT) ssum += expf(L.ev[i] - m);
     ssum = block_sum<RNT>(ssum, L.red);
     if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = m; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = ssum; }
+    WSTAMP(5);
 }
 
 // (3) alignment (softmax over all frames from the slices' statistics), the context columns [4 c0, 4 c1) of utterance b, and the cell input
@@ -229,6 +274,7 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, D = a.D, E = a.E, V = a.V, U = a.U, I0D = E + Hd + D, H4 = Hd / 4;
     float* al = sm;                                  // [Tp] alignment (speed mode: rounded to bf16, the contraction's operand)
     float* part = sm + ((Tp + 3) & ~3);              // [ng][h4per] float4
+    WSTAMP(10);
     float m = -INFINITY;
     for (int s = 0; s < w.nsplit; ++s) m = fmaxf(m, w.stat[((size_t)b * w.nsplit + s) * 2]);
     float l = 0.f;
@@ -244,6 +290,7 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
         al[i] = FAST ? bf2f(f2bf(v)) : v;
     }
     __syncthreads();
+    WSTAMP(11);
     const int len = a.enc_len[b];
     const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
     const int c0 = hs_ * w.h4per, nch = (H4 - c0 < w.h4per ? H4 - c0 : w.h4per);
@@ -282,6 +329,7 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
         }
     }
     __syncthreads();
+    WSTAMP(12);
     float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
     unsigned short* xb = FAST ? a.xbf + (size_t)b * I0D : nullptr;
     for (int i = tid; i < nch * 4; i += RNT) {
@@ -306,6 +354,7 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
             if (FAST) xb[E + Hd + i] = f2bf(v);
         }
     }
+    WSTAMP(13);
 }
 
 // gate nonlinearity of layer `layer` (< TOP) at step t, and the bf16 input row of the layer above: [h_{layer, t+1} ; h_{layer+1, t}]
@@ -353,9 +402,11 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, E = a.E, U = a.U, I0D = E + Hd + a.D;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
+    WSTAMP(20);
     const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D + E;
     for (int i = tid; i < Hd; i += RNT) dctx[i] = FAST ? bf2f(f2bf(dxr[i])) : dxr[i];
     __syncthreads();
+    WSTAMP(21);
     const int sl = tid & 31, grp = tid >> 5;
     float dot = 0.f;
     for (int fr = grp; fr < nf; fr += RNG) {
@@ -383,8 +434,10 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
             dot = fmaf(a.alphas[((size_t)t * B + b) * Tp + tt], v, dot);
         }
     }
+    WSTAMP(22);
     dot = block_sum<RNT>(dot, red);
     if (tid == 0) w.stat[(size_t)b * w.nsplit + s] = dot;
+    WSTAMP(23);
 }
 
 // (2) d energy of the slice's frames (kept for the after-loop keys gradient), the energies' backward: partial dq / du over the slice, and
@@ -398,17 +451,18 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
     const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     float* dfc = L.dfc;
+    WSTAMP(30);
     for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
     const bool havef = LOC && a.actS && a.fcSave && a.actS[0] == LAS_ACT_MAGIC_WIDE;     // the forward kept f of every step
     if (LOC) {
         for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
         if (!havef) {
-            for (int i = tid; i < Tp; i += RNT)
-                L.aprev[i] = t > 0 ? a.alphas[((size_t)(t - 1) * B + b) * Tp + i] : (a.align0 ? a.align0[(size_t)b * Tp + i] : 0.f);
+            wide_stage_awin(a, L.aprev, t, b, t0, w.fper, tid);
             for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
         }
     }
     __syncthreads();
+    WSTAMP(31);
     float dot = 0.f;
     for (int q = 0; q < w.nsplit; ++q) dot += w.stat[(size_t)b * w.nsplit + q];
     if (nf > 0) {
@@ -417,7 +471,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
                 const float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
                 for (int i = tid; i < nf * C; i += RNT) L.fc[i] = fs[i];
             } else {
-                wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, t0, nf, tid);
+                wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, nf, tid);
                 if (a.fcSave) {      // the after-loop keys / Wf gradient reads f of every step
                     float* fs = a.fcSave + (((size_t)t * B + b) * Tp + t0) * C;
                     for (int i = tid; i < nf * C; i += RNT) fs[i] = L.fc[i];
@@ -432,6 +486,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
         }
     }
     __syncthreads();
+    WSTAMP(32);
     const int sl = tid & 31, grp = tid >> 5;
     float du_acc[8], dq_acc[8];                    // A <= 256: at most two float4 per lane
 #pragma unroll
@@ -478,6 +533,7 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
             }
         }
     }
+    WSTAMP(33);
     // the 32 frame groups' partials of dq, then du, through LDS in fixed order
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -498,9 +554,73 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
             out[i] = v;
         }
     }
+    WSTAMP(34);
     if (LOC && nf > 0 && a.dfcSave) {
         float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + t0) * C;
         for (int i = tid; i < nf * C; i += RNT) ds[i] = dfc[i];
+    }
+    WSTAMP(35);
+}
+
+// the transposed conv's tap-slice partials: part[kc, j] = sum over the taps k of slice kc, c ascending inside a tap, of rows[j - k + Kc + 1, c]
+// w[k, c] for the source frames j of the slice (rows: see wide_dq_kernel).  CT = C at compile time: one thread = (tap slice, 4 consecutive
+// source frames) with the 4 + 1 rows two taps need in registers -- per pair of taps one new row pair and two filter rows from LDS for 8 CT
+// multiply-adds (round 6, first version: one (tap slice, frame) per thread, 2 LDS reads per multiply-add: 6.5 of the kernel's 9 us); CT = 0:
+// any C, one (tap slice, frame) per thread.  Same taps per slice and the same order inside a slice in both.
+template <int CT>
+__device__ __forceinline__ void wide_convT_items(const float* rows, const float* locw, float* part, int nf, int Kc, int C, int NKC, int kper, int tid) {
+    if (CT > 0) {
+        const int nsb = (nf + 3) >> 2;
+        for (int i = tid; i < NKC * nsb; i += RNT) {
+            const int kc = i / nsb, sb = i - kc * nsb;
+            const int k0 = kc * kper, kend = k0 + kper < Kc ? k0 + kper : Kc;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float W[5][CT > 0 ? CT : 1];
+            const float* rb = rows + (size_t)(sb * 4 - k0 + Kc + 1) * CT;          // row of (source frame 4 sb, tap k0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) W[j + 1][c] = rb[j * CT + c];
+            for (int k = k0; k < kend; k += 2) {
+                float wa[CT > 0 ? CT : 1], wb[CT > 0 ? CT : 1];
+                const bool two = k + 1 < kend;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    W[0][c] = rb[c - CT];                                          // (source frame 4 sb, tap k + 1)
+                    wa[c] = locw[k * CT + c];
+                    const float wn = locw[(k + 1) * CT + c];                       // (row Kc of the filter's LDS copy is never used: `two`)
+                    wb[c] = two ? wn : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[j] = fmaf(W[j + 1][c], wa[c], acc[j]);
+                if (two) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[j] = fmaf(W[j][c], wb[c], acc[j]);
+                }
+                rb -= 2 * CT;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) { W[4][c] = W[2][c]; W[3][c] = W[1][c]; W[2][c] = W[0][c]; W[1][c] = rb[c]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sb * 4 + j < nf) part[kc * nf + sb * 4 + j] = acc[j];
+        }
+    } else {
+        for (int i = tid; i < NKC * nf; i += RNT) {
+            const int kc = i / nf, j = i - kc * nf;
+            const int k0 = kc * kper, kend = k0 + kper < Kc ? k0 + kper : Kc;
+            float acc = 0.f;
+            for (int k = k0; k < kend; ++k) {
+                const float* dr = rows + (size_t)(j - k + Kc + 1) * C;
+                const float* wr = locw + k * C;
+                for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
+            }
+            part[i] = acc;
+        }
     }
 }
 
@@ -512,6 +632,7 @@ __global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t
     extern __shared__ __attribute__((aligned(16))) float sm[];
     kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    WSTAMP(40);
     if (s == 0) {
         for (int i = tid; i < A; i += RNT) {
             float dq = 0.f, du = 0.f;
@@ -524,47 +645,44 @@ __global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t
             a.duRows[(size_t)b * A + i] += du;
         }
     }
+    WSTAMP(41);
     if (LOC && t > 0) {
         const int Kc = a.Kc, pad = (Kc - 1) / 2;
         const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
         if (nf <= 0) return;
-        // d f rows that reach the slice's source frames: src - k + pad for k in [0, Kc)
-        const int lo = t0 - (Kc - 1 - pad) > 0 ? t0 - (Kc - 1 - pad) : 0, hi = t0 + nf + pad < Tp ? t0 + nf + pad : Tp;
-        float* dfc = sm;                                         // [hi - lo, C]
-        float* locw = dfc + (((w.fper + Kc) * C + 3) & ~3);      // [Kc, C]
-        float* part = locw + ((Kc * C + 3) & ~3);                // [NKC, nf]
-        const float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + lo) * C;
-        for (int i = tid; i < (hi - lo) * C; i += RNT) dfc[i] = ds[i];
+        // d f rows that reach the slice's source frames, zero where the frame does not exist: local row rho <-> frame t0 + rho - (Kc + 1) + pad,
+        // so that source frame t0 + j meets tap k at row j - k + Kc + 1 and no tap needs a bound
+        const int nrows = ((nf + 3) & ~3) + Kc + 2;
+        float* rows = sm;                                                          // [nrows, C]
+        float* locw = rows + (((((w.fper + 3) & ~3) + Kc + 2) * C + 3) & ~3);      // [Kc + 2, C]
+        float* part = locw + (((Kc + 2) * C + 3) & ~3);                            // [NKC, nf]
+        const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
+        for (int i = tid; i < nrows * C; i += RNT) {
+            const int rho = i / C, fr = t0 + rho - (Kc + 1) + pad;
+            rows[i] = (fr >= 0 && fr < Tp) ? ds[(size_t)fr * C + (i - rho * C)] : 0.f;
+        }
         for (int i = tid; i < Kc * C; i += RNT) locw[i] = a.loc_w[i];
         __syncthreads();
+        WSTAMP(42);
         int NKC = RNT / nf;
         NKC = NKC < 1 ? 1 : (NKC > 16 ? 16 : NKC);
         const int kper = (Kc + NKC - 1) / NKC;
-        for (int i = tid; i < NKC * nf; i += RNT) {
-            const int kc = i / nf, src = t0 + (i - kc * nf);
-            int k0 = kc * kper, k1 = k0 + kper < Kc ? k0 + kper : Kc;
-            if (k0 < src + pad - (Tp - 1)) k0 = src + pad - (Tp - 1);        // 0 <= src - k + pad < Tp
-            if (k1 > src + pad + 1) k1 = src + pad + 1;
-            float acc = 0.f;
-            for (int k = k0; k < k1; ++k) {
-                const float* dr = dfc + (src - k + pad - lo) * C;
-                const float* wr = locw + k * C;
-                for (int c = 0; c < C; ++c) acc = fmaf(dr[c], wr[c], acc);
-            }
-            part[i] = acc;
-        }
+        if (C == 10) wide_convT_items<10>(rows, locw, part, nf, Kc, C, NKC, kper, tid);
+        else         wide_convT_items<0>(rows, locw, part, nf, Kc, C, NKC, kper, tid);
         __syncthreads();
+        WSTAMP(43);
         for (int j = tid; j < nf; j += RNT) {
             float acc = 0.f;
             for (int kc = 0; kc < NKC; ++kc) acc += part[kc * nf + j];
             a.dAext[(size_t)b * Tp + t0 + j] = acc;
         }
+        WSTAMP(44);
     }
 }
 static size_t wide_dq_lds_bytes(const DecDev& a, int fper) {
     if (a.mode != LAS_ATT_LOC) return 64;
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
-    return (u4((size_t)(fper + a.Kc) * a.C) + u4((size_t)a.Kc * a.C) + (size_t)16 * fper + 4) * sizeof(float) + 64;
+    return (u4((size_t)(((fper + 3) & ~3) + a.Kc + 2) * a.C) + u4((size_t)(a.Kc + 2) * a.C) + (size_t)16 * fper + 4) * sizeof(float) + 64;
 }
 
 // (4) gate backward of `layer` at step t: dh = [recurrent gradient from step t+1] + [d s of step t+1's attention] + extra (top layer:
