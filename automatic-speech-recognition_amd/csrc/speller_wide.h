@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
 // f[t', c] = bias[c] + sum_k prev_align[t' + k - pad] w[k, c] for the frames [t0, t0 + nf) of one utterance (conv1d, SAME, cross-correlation:
 // las/layers.py:295-296) -> fc [nf, C] in LDS.  `awin` is the slice's WINDOW of the previous alignment in LDS -- awin[j] = alpha_{t-1}[t0 - pad
 // + j], zero where that frame does not exist (wide_stage_awin) -- so that frame fr meets tap k at awin[fr + k] and no tap needs a bound;
-// locw [Kc + 8, C] in LDS (rows >= Kc are never multiplied in); part: nf C ksplit floats of scratch.
+// locw [Kc + 1, C] in LDS: the filter, and the bias as row Kc (wide_stage_filter); part: nf C ksplit floats of scratch.
 // One thread = (tap slice, block of 8 consecutive frames, channel): the 8 + 8 window values of a chunk of 8 taps stay in registers (one new
 // value and one weight per 8 multiply-adds), every loop has a fixed trip count.  (Round 6, first version: one (tap slice, frame, channel)
 // output per thread item with two LDS reads per multiply-add in a loop the compiler could not unroll -- 6.9 of the energy kernel's 12.3 us,
@@ -114,6 +114,10 @@ __device__ __forceinline__ void wide_stage_awin(const DecDev& a, float* awin, in
         awin[j] = (src && fr >= 0 && fr < Tp) ? src[fr] : 0.f;
     }
 }
+__device__ __forceinline__ void wide_stage_filter(const DecDev& a, float* locw, int tid) {
+    const int n = a.Kc * a.C;
+    for (int i = tid; i < n + a.C; i += RNT) locw[i] = i < n ? a.loc_w[i] : a.loc_b[i - n];
+}
 __device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* awin, const float* locw, float* fc, float* part, int nf, int tid) {
     const int C = a.C, Kc = a.Kc, items = nf * C;
     const int ks = wide_conv_ks(Kc), kper = wide_conv_kper(Kc);
@@ -121,7 +125,7 @@ __device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* aw
     for (int i = tid; i < items8 * ks; i += RNT) {
         const int kc = i / items8, r = i - kc * items8, fb = r / C, c = r - fb * C;
         const int k0 = kc * kper, kend = k0 + kper < Kc ? k0 + kper : Kc;
-        const float init = kc == 0 ? a.loc_b[c] : 0.f;
+        const float init = kc == 0 ? locw[Kc * C + c] : 0.f;                    // (the bias rides behind the filter's rows: wide_stage_filter)
         float acc[8], x[16];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[j] = init; x[j] = awin[fb * 8 + k0 + j]; }
@@ -157,9 +161,9 @@ __device__ __forceinline__ void wide_conv_slice(const DecDev& a, const float* aw
 }
 
 struct WideLds { float *aprev, *locw, *wfl, *fc, *dfc, *qv, *ev, *red, *part; };
-// part: the conv's tap-slice partials (8 fper C floats), later the 32 frame groups' dq / du partials (RNG A)
+// part: the conv's tap-slice partials (8 fper C floats), later the 32 frame groups' dq and du partials (2 RNG A)
 __host__ __device__ __forceinline__ size_t wide_part_floats(int A, int fper, int C) {
-    size_t n = (size_t)RNG * A;
+    size_t n = (size_t)2 * RNG * A;
     if (C > 0 && (size_t)8 * fper * C > n) n = (size_t)8 * fper * C;
     return (n + 3) & ~(size_t)3;
 }
@@ -198,24 +202,38 @@ __device__ __forceinline__ float4 wide_key4(const DecDev& a, int b, int tt, int 
 
 // (2) energies of the frames [s fper, (s + 1) fper) of utterance b: e = u . tanh(keys + q [+ f . Wf]), -1e8 replace-mask, and the
 //     slice's softmax statistics (max, sum of exp).  grid (nsplit, B).
-template <bool FAST, bool LOC>
+// CT: the conv's channel count at compile time (10, the reference's default: the per-channel loops unroll and their LDS reads pipeline -- as
+// runtime loops they were one LDS round trip per channel and frame) or 0 = any.
+template <bool FAST, bool LOC, int CT = 0>
 __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, int t) {
     kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const WideLds L = wide_carve(sm, a, w.fper);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    const int B = a.B, Tp = a.Tp, A = a.A, C = CT > 0 ? CT : a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     WSTAMP(0);
     for (int i = tid; i < A; i += RNT) L.qv[i] = w.qbuf[(size_t)b * A + i];
     if (LOC) {
         wide_stage_awin(a, L.aprev, t, b, t0, w.fper, tid);
-        for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
+        wide_stage_filter(a, L.locw, tid);
         for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
     }
     __syncthreads();
     WSTAMP(1);
     if (nf <= 0) { if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; } return; }
+    // 32 lanes per frame (lane sl: attention columns 4 sl .. 4 sl + 3 and 128 + 4 sl ..), 32 frames at a time.  The keys of a group's first two
+    // frames are requested in front of the conv: they do not depend on it, and behind it their latency was on the chain once per frame
+    const int sl = tid & 31, grp = tid >> 5, A4 = A / 4;
+    float4 kq[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot)
+            kq[p][slot] = (grp + p * RNG < nf && sl + 32 * slot < A4) ? wide_key4<FAST>(a, b, t0 + grp + p * RNG, sl + 32 * slot) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 uq[2];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) uq[slot] = sl + 32 * slot < A4 ? reinterpret_cast<const float4*>(a.u)[sl + 32 * slot] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOC) {
         wide_conv_slice(a, L.aprev, L.locw, L.fc, L.part, nf, tid);
         WSTAMP(2);
@@ -227,29 +245,43 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
     }
     WSTAMP(3);
     const int len = a.enc_len[b];
-    const int sl = tid & 31, grp = tid >> 5;
-    for (int fr = grp; fr < nf; fr += RNG) {
-        const int tt = t0 + fr;
-        float part = 0.f;
-        for (int a4 = sl; a4 < A / 4; a4 += 32) {
-            const float4 k4 = wide_key4<FAST>(a, b, tt, a4);
-            const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
-            const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
-            float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
-            if (LOC) {
-                for (int c = 0; c < C; ++c) {
-                    const float f = L.fc[fr * C + c];
-                    const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
-                    p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
-                }
-            }
-            part += u4.x * tanhx<FAST>(p.x) + u4.y * tanhx<FAST>(p.y) + u4.z * tanhx<FAST>(p.z) + u4.w * tanhx<FAST>(p.w);
+    for (int fr0 = grp; fr0 < nf; fr0 += 2 * RNG) {
+        if (fr0 != grp) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot)
+                    if (fr0 + p * RNG < nf && sl + 32 * slot < A4) kq[p][slot] = wide_key4<FAST>(a, b, t0 + fr0 + p * RNG, sl + 32 * slot);
         }
-        const float e = sub32_sum(part);
-        if (sl == 0) {
-            const float em = (tt < len) ? e : -1e8f;           // replace-mask, las/layers.py:205-207
-            L.ev[fr] = em;
-            w.ebuf[(size_t)b * Tp + tt] = em;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int fr = fr0 + p * RNG, tt = t0 + fr;
+            if (fr >= nf) break;
+            float part = 0.f;
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int a4 = sl + 32 * slot;
+                if (a4 >= A4) break;
+                const float4 k4 = kq[p][slot];
+                const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                const float4 u4 = uq[slot];
+                float4 p4 = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+                if (LOC) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float f = L.fc[fr * C + c];
+                        const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                        p4.x = fmaf(f, w4.x, p4.x); p4.y = fmaf(f, w4.y, p4.y); p4.z = fmaf(f, w4.z, p4.z); p4.w = fmaf(f, w4.w, p4.w);
+                    }
+                }
+                part += u4.x * tanhx<FAST>(p4.x) + u4.y * tanhx<FAST>(p4.y) + u4.z * tanhx<FAST>(p4.z) + u4.w * tanhx<FAST>(p4.w);
+            }
+            const float e = sub32_sum(part);
+            if (sl == 0) {
+                const float em = (tt < len) ? e : -1e8f;           // replace-mask, las/layers.py:205-207
+                L.ev[fr] = em;
+                w.ebuf[(size_t)b * Tp + tt] = em;
+            }
         }
     }
     __syncthreads();
@@ -275,6 +307,35 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
     float* al = sm;                                  // [Tp] alignment (speed mode: rounded to bf16, the contraction's operand)
     float* part = sm + ((Tp + 3) & ~3);              // [ng][h4per] float4
     WSTAMP(10);
+    // everything that does not depend on the alignment is requested first: the first four encoder rows of this thread's column chunk, and (slice
+    // 0) the embedding row and h_0 -- behind the softmax each of them was a memory round trip of its own on the launch's critical path
+    const int len = a.enc_len[b];
+    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
+    const int c0 = hs_ * w.h4per, nch = (H4 - c0 < w.h4per ? H4 - c0 : w.h4per);
+    const int ng = RNT / w.h4per;
+    const int g = tid / w.h4per, ch = tid - g * w.h4per;
+    const bool mine = nch > 0 && g < ng && ch < nch;
+    auto enc4 = [&](int tu) -> float4 {
+        if (FAST) {
+            const uint2 v = reinterpret_cast<const uint2*>(a.encbf + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
+            return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        }
+        return reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
+    };
+    const bool havepre = mine && g + 3 * ng < lim;
+    float4 pre[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pre[u] = havepre ? enc4(g + u * ng) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
+    unsigned short* xb = FAST ? a.xbf + (size_t)b * I0D : nullptr;
+    float ev = 0.f, hv = 0.f;
+    int tok = 0;
+    if (hs_ == 0) {
+        tok = a.tok_in[(size_t)t * B + b];
+        if (tid < E) ev = (a.emb[(size_t)tok * E + tid] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + tid] : 0.f)) *
+                          (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + tid] : 1.f);
+        if (tid < D) hv = a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid];
+    }
     float m = -INFINITY;
     for (int s = 0; s < w.nsplit; ++s) m = fmaxf(m, w.stat[((size_t)b * w.nsplit + s) * 2]);
     float l = 0.f;
@@ -291,47 +352,36 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
     }
     __syncthreads();
     WSTAMP(11);
-    const int len = a.enc_len[b];
-    const int lim = len > 0 ? (len < Tp ? len : Tp) : Tp;   // alpha is exactly 0 beyond len (exp underflow)
-    const int c0 = hs_ * w.h4per, nch = (H4 - c0 < w.h4per ? H4 - c0 : w.h4per);
-    const int ng = RNT / w.h4per;
-    const int g = tid / w.h4per, ch = tid - g * w.h4per;
-    if (nch > 0) {
+    if (mine) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < ng && ch < nch) {
-            int tt = g;
-            for (; tt + 3 * ng < lim; tt += 4 * ng) {          // four independent loads in flight
-                float4 e4[4];
+        int tt = g;
+        if (havepre) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int tu = tt + u * ng;
-                    if (FAST) {
-                        const uint2 v = reinterpret_cast<const uint2*>(a.encbf + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
-                        e4[u] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-                    } else e4[u] = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tu) * Hd)[c0 + ch];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float av = al[tt + u * ng];
-                    acc.x = fmaf(av, e4[u].x, acc.x); acc.y = fmaf(av, e4[u].y, acc.y); acc.z = fmaf(av, e4[u].z, acc.z); acc.w = fmaf(av, e4[u].w, acc.w);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const float av = al[tt + u * ng];
+                acc.x = fmaf(av, pre[u].x, acc.x); acc.y = fmaf(av, pre[u].y, acc.y); acc.z = fmaf(av, pre[u].z, acc.z); acc.w = fmaf(av, pre[u].w, acc.w);
             }
-            for (; tt < lim; tt += ng) {
-                float4 e4;
-                if (FAST) {
-                    const uint2 v = reinterpret_cast<const uint2*>(a.encbf + ((size_t)b * Tp + tt) * Hd)[c0 + ch];
-                    e4 = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-                } else e4 = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd)[c0 + ch];
-                const float av = al[tt];
-                acc.x = fmaf(av, e4.x, acc.x); acc.y = fmaf(av, e4.y, acc.y); acc.z = fmaf(av, e4.z, acc.z); acc.w = fmaf(av, e4.w, acc.w);
-            }
-            reinterpret_cast<float4*>(part)[g * w.h4per + ch] = acc;
+            tt += 4 * ng;
         }
+        for (; tt + 3 * ng < lim; tt += 4 * ng) {          // four independent loads in flight
+            float4 e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e4[u] = enc4(tt + u * ng);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float av = al[tt + u * ng];
+                acc.x = fmaf(av, e4[u].x, acc.x); acc.y = fmaf(av, e4[u].y, acc.y); acc.z = fmaf(av, e4[u].z, acc.z); acc.w = fmaf(av, e4[u].w, acc.w);
+            }
+        }
+        for (; tt < lim; tt += ng) {
+            const float4 e4 = enc4(tt);
+            const float av = al[tt];
+            acc.x = fmaf(av, e4.x, acc.x); acc.y = fmaf(av, e4.y, acc.y); acc.z = fmaf(av, e4.z, acc.z); acc.w = fmaf(av, e4.w, acc.w);
+        }
+        reinterpret_cast<float4*>(part)[g * w.h4per + ch] = acc;
     }
     __syncthreads();
     WSTAMP(12);
-    float* xrow = a.xin0 + ((size_t)t * B + b) * I0D;
-    unsigned short* xb = FAST ? a.xbf + (size_t)b * I0D : nullptr;
     for (int i = tid; i < nch * 4; i += RNT) {
         const int chq = i >> 2, e = i & 3;
         float cv = 0.f;
@@ -341,15 +391,14 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
         if (FAST) xb[E + col] = f2bf(cv);
     }
     if (hs_ == 0) {
-        const int tok = a.tok_in[(size_t)t * B + b];
         for (int i = tid; i < E; i += RNT) {
-            const float v = (a.emb[(size_t)tok * E + i] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + i] : 0.f)) *
-                            (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
+            const float v = i == tid ? ev : (a.emb[(size_t)tok * E + i] + (a.emb_noise ? a.emb_noise[((size_t)t * V + tok) * E + i] : 0.f)) *
+                                           (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + i] : 1.f);
             xrow[i] = v;
             if (FAST) xb[i] = f2bf(v);
         }
         for (int i = tid; i < D; i += RNT) {
-            const float v = a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + i];
+            const float v = i == tid ? hv : a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + i];
             xrow[E + Hd + i] = v;
             if (FAST) xb[E + Hd + i] = f2bf(v);
         }
@@ -403,36 +452,64 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, E = a.E, U = a.U, I0D = E + Hd + a.D;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     WSTAMP(20);
+    // 32 lanes per frame, 32 frames at a time; the encoder rows of a group's first two frames (up to 4 x 16 bytes per lane and frame: Hd <= 1024
+    // in speed mode, 512 in parity mode) are requested in front of the staging barrier -- they do not depend on d context
+    const int sl = tid & 31, grp = tid >> 5;
+    constexpr int NP = 4;
+    const int nvec = FAST ? Hd / 8 : Hd / 4;           // 16-byte pieces of a row
+    uint4 pre[2][NP];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int fr = grp + p * RNG, h = sl + 32 * q;
+            pre[p][q] = make_uint4(0u, 0u, 0u, 0u);
+            if (fr < nf && h < nvec)
+                pre[p][q] = FAST ? reinterpret_cast<const uint4*>(a.encbf + ((size_t)b * Tp + t0 + fr) * Hd)[h]
+                                 : reinterpret_cast<const uint4*>(a.enc + ((size_t)b * Tp + t0 + fr) * Hd)[h];
+        }
     const float* dxr = a.dXin0 + ((size_t)t * B + b) * I0D + E;
     for (int i = tid; i < Hd; i += RNT) dctx[i] = FAST ? bf2f(f2bf(dxr[i])) : dxr[i];
     __syncthreads();
     WSTAMP(21);
-    const int sl = tid & 31, grp = tid >> 5;
     float dot = 0.f;
-    for (int fr = grp; fr < nf; fr += RNG) {
-        const int tt = t0 + fr;
-        float acc = 0.f;
+    auto piece = [&](const uint4 v, const int h) -> float {          // one 16-byte piece of an encoder row against d context
         if (FAST) {
-            for (int h8 = sl; h8 < Hd / 8; h8 += 32) {
-                const uint4 v = reinterpret_cast<const uint4*>(a.encbf + ((size_t)b * Tp + tt) * Hd)[h8];
-                float e[8];
-                unpack8(v, e);
-                const float4 d0 = reinterpret_cast<const float4*>(dctx)[2 * h8], d1 = reinterpret_cast<const float4*>(dctx)[2 * h8 + 1];
-                acc += d0.x * e[0] + d0.y * e[1] + d0.z * e[2] + d0.w * e[3] + d1.x * e[4] + d1.y * e[5] + d1.z * e[6] + d1.w * e[7];
-            }
-        } else {
-            for (int h4 = sl; h4 < Hd / 4; h4 += 32) {
-                const float4 e = reinterpret_cast<const float4*>(a.enc + ((size_t)b * Tp + tt) * Hd)[h4];
-                const float4 d4 = reinterpret_cast<const float4*>(dctx)[h4];
-                acc += d4.x * e.x + d4.y * e.y + d4.z * e.z + d4.w * e.w;
-            }
+            float e[8];
+            unpack8(v, e);
+            const float4 d0 = reinterpret_cast<const float4*>(dctx)[2 * h], d1 = reinterpret_cast<const float4*>(dctx)[2 * h + 1];
+            return d0.x * e[0] + d0.y * e[1] + d0.z * e[2] + d0.w * e[3] + d1.x * e[4] + d1.y * e[5] + d1.z * e[6] + d1.w * e[7];
         }
+        const float4 d4 = reinterpret_cast<const float4*>(dctx)[h];
+        return d4.x * __uint_as_float(v.x) + d4.y * __uint_as_float(v.y) + d4.z * __uint_as_float(v.z) + d4.w * __uint_as_float(v.w);
+    };
+    auto row16 = [&](int tt, int h) -> uint4 {
+        return FAST ? reinterpret_cast<const uint4*>(a.encbf + ((size_t)b * Tp + tt) * Hd)[h] : reinterpret_cast<const uint4*>(a.enc + ((size_t)b * Tp + tt) * Hd)[h];
+    };
+    auto finish = [&](float acc, int tt) {
         float v = sub32_sum(acc);
         if (sl == 0) {
             if (LOC && t + 1 < U) v += a.dAext[(size_t)b * Tp + tt];
             w.ebuf[(size_t)b * Tp + tt] = v;
             dot = fmaf(a.alphas[((size_t)t * B + b) * Tp + tt], v, dot);
         }
+    };
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int fr = grp + p * RNG, tt = t0 + fr;
+        if (fr >= nf) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (sl + 32 * q < nvec) acc += piece(pre[p][q], sl + 32 * q);
+        for (int h = sl + 32 * NP; h < nvec; h += 32) acc += piece(row16(tt, h), h);
+        finish(acc, tt);
+    }
+    for (int fr = grp + 2 * RNG; fr < nf; fr += RNG) {
+        const int tt = t0 + fr;
+        float acc = 0.f;
+        for (int h = sl; h < nvec; h += 32) acc += piece(row16(tt, h), h);
+        finish(acc, tt);
     }
     WSTAMP(22);
     dot = block_sum<RNT>(dot, red);
@@ -442,23 +519,34 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
 
 // (2) d energy of the slice's frames (kept for the after-loop keys gradient), the energies' backward: partial dq / du over the slice, and
 //     d f[t', c] = sum_a dv[a] Wf[c, a] (kept for the conv's transpose and the filter gradient).  grid (nsplit, B).
-template <bool FAST, bool LOC>
+template <bool FAST, bool LOC, int CT = 0>
 __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev w, int t) {
     kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const WideLds L = wide_carve(sm, a, w.fper);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    const int B = a.B, Tp = a.Tp, A = a.A, C = CT > 0 ? CT : a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     float* dfc = L.dfc;
     WSTAMP(30);
+    // the keys of a group's first two frames are requested first (32 lanes per frame, as in the forward kernel)
+    const int sl = tid & 31, grp = tid >> 5, A4 = A / 4;
+    float4 kq[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot)
+            kq[p][slot] = (grp + p * RNG < nf && sl + 32 * slot < A4) ? wide_key4<FAST>(a, b, t0 + grp + p * RNG, sl + 32 * slot) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 uq[2];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) uq[slot] = sl + 32 * slot < A4 ? reinterpret_cast<const float4*>(a.u)[sl + 32 * slot] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < A; i += RNT) L.qv[i] = a.Q[((size_t)t * B + b) * A + i];
     const bool havef = LOC && a.actS && a.fcSave && a.actS[0] == LAS_ACT_MAGIC_WIDE;     // the forward kept f of every step
     if (LOC) {
         for (int i = tid; i < C * A; i += RNT) L.wfl[i] = a.Wf[i];
         if (!havef) {
             wide_stage_awin(a, L.aprev, t, b, t0, w.fper, tid);
-            for (int i = tid; i < a.Kc * C; i += RNT) L.locw[i] = a.loc_w[i];
+            wide_stage_filter(a, L.locw, tid);
         }
     }
     __syncthreads();
@@ -487,72 +575,86 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
     }
     __syncthreads();
     WSTAMP(32);
-    const int sl = tid & 31, grp = tid >> 5;
     float du_acc[8], dq_acc[8];                    // A <= 256: at most two float4 per lane
 #pragma unroll
     for (int i = 0; i < 8; ++i) { du_acc[i] = 0.f; dq_acc[i] = 0.f; }
-    for (int fr = grp; fr < nf; fr += RNG) {
-        const int tt = t0 + fr;
-        const float de = L.ev[fr];
-        float4 dvs[2];
+    for (int fr0 = grp; fr0 < nf; fr0 += 2 * RNG) {
+        if (fr0 != grp) {
 #pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {
-            const int a4 = sl + 32 * slot;
-            dvs[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a4 >= A / 4) continue;
-            const float4 k4 = wide_key4<FAST>(a, b, tt, a4);
-            const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
-            const float4 u4 = reinterpret_cast<const float4*>(a.u)[a4];
-            float4 p = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
-            if (LOC) {
-                for (int c = 0; c < C; ++c) {
-                    const float f = L.fc[fr * C + c];
-                    const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
-                    p.x = fmaf(f, w4.x, p.x); p.y = fmaf(f, w4.y, p.y); p.z = fmaf(f, w4.z, p.z); p.w = fmaf(f, w4.w, p.w);
-                }
-            }
-            const float vx = tanhx<FAST>(p.x), vy = tanhx<FAST>(p.y), vz = tanhx<FAST>(p.z), vw = tanhx<FAST>(p.w);
-            const float4 dv = make_float4(de * u4.x * (1.f - vx * vx), de * u4.y * (1.f - vy * vy), de * u4.z * (1.f - vz * vz), de * u4.w * (1.f - vw * vw));
-            du_acc[slot * 4 + 0] += de * vx; du_acc[slot * 4 + 1] += de * vy; du_acc[slot * 4 + 2] += de * vz; du_acc[slot * 4 + 3] += de * vw;
-            dq_acc[slot * 4 + 0] += dv.x; dq_acc[slot * 4 + 1] += dv.y; dq_acc[slot * 4 + 2] += dv.z; dq_acc[slot * 4 + 3] += dv.w;
-            dvs[slot] = dv;
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot)
+                    if (fr0 + p * RNG < nf && sl + 32 * slot < A4) kq[p][slot] = wide_key4<FAST>(a, b, t0 + fr0 + p * RNG, sl + 32 * slot);
         }
-        if (LOC) {
-            for (int c = 0; c < C; ++c) {
-                float s1 = 0.f;
 #pragma unroll
-                for (int slot = 0; slot < 2; ++slot) {
-                    const int a4 = sl + 32 * slot;
-                    if (a4 < A / 4) {
+        for (int p = 0; p < 2; ++p) {
+            const int fr = fr0 + p * RNG;
+            if (fr >= nf) break;
+            const float de = L.ev[fr];
+            float4 dvs[2];
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int a4 = sl + 32 * slot;
+                dvs[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a4 >= A4) continue;
+                const float4 k4 = kq[p][slot];
+                const float4 q4 = reinterpret_cast<const float4*>(L.qv)[a4];
+                const float4 u4 = uq[slot];
+                float4 p4 = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
+                if (LOC) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float f = L.fc[fr * C + c];
                         const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
-                        s1 += dvs[slot].x * w4.x + dvs[slot].y * w4.y + dvs[slot].z * w4.z + dvs[slot].w * w4.w;
+                        p4.x = fmaf(f, w4.x, p4.x); p4.y = fmaf(f, w4.y, p4.y); p4.z = fmaf(f, w4.z, p4.z); p4.w = fmaf(f, w4.w, p4.w);
                     }
                 }
-                s1 = sub32_sum(s1);
-                if (sl == 0) dfc[fr * C + c] = s1;
+                const float vx = tanhx<FAST>(p4.x), vy = tanhx<FAST>(p4.y), vz = tanhx<FAST>(p4.z), vw = tanhx<FAST>(p4.w);
+                const float4 dv = make_float4(de * u4.x * (1.f - vx * vx), de * u4.y * (1.f - vy * vy), de * u4.z * (1.f - vz * vz), de * u4.w * (1.f - vw * vw));
+                du_acc[slot * 4 + 0] += de * vx; du_acc[slot * 4 + 1] += de * vy; du_acc[slot * 4 + 2] += de * vz; du_acc[slot * 4 + 3] += de * vw;
+                dq_acc[slot * 4 + 0] += dv.x; dq_acc[slot * 4 + 1] += dv.y; dq_acc[slot * 4 + 2] += dv.z; dq_acc[slot * 4 + 3] += dv.w;
+                dvs[slot] = dv;
+            }
+            if (LOC) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float s1 = 0.f;
+#pragma unroll
+                    for (int slot = 0; slot < 2; ++slot) {
+                        const int a4 = sl + 32 * slot;
+                        if (a4 < A4) {
+                            const float4 w4 = reinterpret_cast<const float4*>(L.wfl + (size_t)c * A)[a4];
+                            s1 += dvs[slot].x * w4.x + dvs[slot].y * w4.y + dvs[slot].z * w4.z + dvs[slot].w * w4.w;
+                        }
+                    }
+                    s1 = sub32_sum(s1);
+                    if (sl == 0) dfc[fr * C + c] = s1;
+                }
             }
         }
     }
     WSTAMP(33);
-    // the 32 frame groups' partials of dq, then du, through LDS in fixed order
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
+    // the 32 frame groups' partials of dq and du through LDS, summed in fixed order (groups ascending): dq by threads 0 .. A - 1, du by the
+    // next A (one trip; round 6, first version: two trips with four barriers).  (Nobody has touched `part` since the conv's own barriers.)
+    float* pq = L.part;
+    float* pu = L.part + (size_t)RNG * A;
 #pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {
-            const int a4 = sl + 32 * slot;
-            if (a4 < A / 4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) L.part[grp * A + a4 * 4 + e] = pass == 0 ? dq_acc[slot * 4 + e] : du_acc[slot * 4 + e];
-            }
+    for (int slot = 0; slot < 2; ++slot) {
+        const int a4 = sl + 32 * slot;
+        if (a4 < A4) {
+            reinterpret_cast<float4*>(pq + (size_t)grp * A)[a4] = make_float4(dq_acc[slot * 4], dq_acc[slot * 4 + 1], dq_acc[slot * 4 + 2], dq_acc[slot * 4 + 3]);
+            reinterpret_cast<float4*>(pu + (size_t)grp * A)[a4] = make_float4(du_acc[slot * 4], du_acc[slot * 4 + 1], du_acc[slot * 4 + 2], du_acc[slot * 4 + 3]);
         }
-        __syncthreads();
-        float* out = (pass == 0 ? w.pdq : w.pdu) + ((size_t)b * w.nsplit + s) * A;
-        for (int i = tid; i < A; i += RNT) {
-            float v = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * A; i += RNT) {
+        const bool second = i >= A;
+        const int col = second ? i - A : i;
+        const float* src = second ? pu : pq;
+        float v = 0.f;
 #pragma unroll
-            for (int g8 = 0; g8 < RNG; ++g8) v += L.part[g8 * A + i];
-            out[i] = v;
-        }
+        for (int g8 = 0; g8 < RNG; ++g8) v += src[g8 * A + col];
+        ((second ? w.pdu : w.pdq) + ((size_t)b * w.nsplit + s) * A)[col] = v;
     }
     WSTAMP(34);
     if (LOC && nf > 0 && a.dfcSave) {

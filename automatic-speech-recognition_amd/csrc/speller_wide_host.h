@@ -48,7 +48,8 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
         if (t == U) break;
         if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.sbf, S, B, S, wb + WL.packWs, A, w.qbuf, A, nullptr, st));
         else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, w.sf, S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
-        if (loc) WIDE_LAUNCH((wide_energy_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
+        if (loc && d.C == 10) WIDE_LAUNCH((wide_energy_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
+        else if (loc) WIDE_LAUNCH((wide_energy_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
         else     WIDE_LAUNCH((wide_energy_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
         WIDE_LAUNCH((wide_context_kernel<FAST>), dim3(w.hsplit, B), dim3(RNT), lds_c, st, d, w, t);
         float* g0 = d.gates + ((size_t)0 * U + t) * B * GD;
@@ -115,7 +116,8 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
             if (loc) {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
-                WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
+                if (d.C == 10) WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
+                else           WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
                 WIDE_LAUNCH((wide_dq_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_q, st, d, w, ta);
             } else {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
