@@ -1608,11 +1608,19 @@ bool las_skinny_ok(int M, int K, int N, int lda, const void* A) {
 // `eh` (the saved state the gradient loop reads) and as bf16 into up to two operand rows of the NEXT products (the layer above's [x ; h]
 // row, the query projection's state row): the gate-math launch between two dependent products disappears.
 struct SkinnyEpi { float* eh; int ldh; unsigned short* b0; int ld0; unsigned short* b1; int ld1; };
-template <bool ABF, bool EPI = false>
+// EPI = 2 (round 6, the wide path's reverse loop with tanh cells): the columns [c0, c0 + D) of the product are one layer's share of d h, and the
+// epilogue is that layer's gate gradient -- d h = the product's value, the recurrent gradient `sa` and the attention's `sb`, summed in the order of
+// wide_cell_bwd_kernel (vlast: sa + sb + value, the top layer behind d s = dq . Ws^T; else value + sa + sb, a lower layer behind the layer
+// above's product), times 1 - h^2 -> fp32 into the saved gates, bf16 into the operand row of the layer's own product.  The other columns are
+// stored as usual.  The gate launch between two dependent products disappears.
+struct SkinnyEpiB { const float* h; int ldh; const float* sa; int lda; const float* sb; int ldb; int vlast; int c0; int D; float* gp; int ldg;
+                    unsigned short* gb; int ldgb; };
+struct SkinnyEpiNone {};
+template <bool ABF, int EPI = 0, class EpiT = SkinnyEpiNone>
 __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
                                                              float* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                             int accumulate, SkinnyEpi epi = SkinnyEpi{}) {
+                                                             int accumulate, EpiT ep = EpiT{}) {
     constexpr int NW = 8;
     __shared__ float red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -1665,13 +1673,32 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) v += red[ww][l2][reg];
             if (bias) v += bias[col];
-            if (EPI) {
+            bool done = false;
+            if constexpr (EPI == 2) {
+                const SkinnyEpiB& eb = ep;
+                if (col >= eb.c0 && col < eb.c0 + eb.D) {
+                    const int d = col - eb.c0;
+                    float dh;
+                    if (eb.vlast) { dh = eb.sa[(long long)orow * eb.lda + d]; if (eb.sb) dh += eb.sb[(long long)orow * eb.ldb + d]; dh += v; }
+                    else { dh = v; if (eb.sa) dh += eb.sa[(long long)orow * eb.lda + d]; if (eb.sb) dh += eb.sb[(long long)orow * eb.ldb + d]; }
+                    const float h = eb.h[(long long)orow * eb.ldh + d];
+                    const float dp = dh * (1.f - h * h);
+                    eb.gp[(long long)orow * eb.ldg + d] = dp;
+                    eb.gb[(long long)orow * eb.ldgb + d] = f2bf(dp);
+                    if (C) C[(long long)orow * ldc + col] = v;
+                    done = true;
+                }
+            }
+            if constexpr (EPI == 1) {
+                const SkinnyEpi& epi = ep;
                 const float h = tanh_fast(v);
                 epi.eh[(long long)orow * epi.ldh + col] = h;
                 const unsigned short hb = f2bf(h);
                 if (epi.b0) epi.b0[(long long)orow * epi.ld0 + col] = hb;
                 if (epi.b1) epi.b1[(long long)orow * epi.ld1 + col] = hb;
-            } else {
+                done = true;
+            }
+            if (!done) {
                 if (accumulate) v += C[(long long)orow * ldc + col];
                 C[(long long)orow * ldc + col] = v;
             }
@@ -1704,8 +1731,20 @@ int las_skinny_gemm_bf16_tanh(const unsigned short* A, int lda, int M, int K, co
                               unsigned short* b0, int ld0, unsigned short* b1, int ld1, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     SkinnyEpi e{eh, ldh, b0, ld0, b1, ld1};
-    hipLaunchKernelGGL((skinny_rows_kernel<true, true>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+    hipLaunchKernelGGL((skinny_rows_kernel<true, 1, SkinnyEpi>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
                        reinterpret_cast<const u16x8_t*>(packed), KS, N, (float*)nullptr, 0, bias, 0, e);
+    LAS_LAUNCHED();
+    return 0;
+}
+
+// C[M, N] = bf16(A) . packed (stored), and for the columns [c0, c0 + D) the tanh cell's gate gradient as the epilogue (SkinnyEpiB)
+int las_skinny_gemm_bf16_tanh_bwd(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, int c0, int D,
+                                  const float* h, int ldh, const float* sa, int lda_, const float* sb, int ldb, int vlast, float* gp, int ldg,
+                                  unsigned short* gb, int ldgb, hipStream_t st) {
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    SkinnyEpiB e{h, ldh, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb};
+    hipLaunchKernelGGL((skinny_rows_kernel<true, 2, SkinnyEpiB>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
     LAS_LAUNCHED();
     return 0;
 }

@@ -35,7 +35,22 @@ struct WideDev {
     unsigned short* dgu;       // [B, G D]    gate gradient rows of an upper layer, bf16
     float* dS;                 // [B, S]      dq . Ws^T
     float* dWfW;               // [B, ceil(Tp / 8), C, A]  Wf-gradient partials of the after-loop keys kernel (written whole)
+    unsigned long long* egran; // [B, Tp + 2 WIDE_MAX_SPLIT] {tag, value} granules of the fused attention launch (wide_attend_kernel): an utterance's
+                               // energies, then its slices' (max, sum of exp); tag = step + 1, zeroed per call
 };
+__host__ __device__ __forceinline__ int wide_gran_row(int Tp) { return Tp + 2 * WIDE_MAX_SPLIT; }
+
+// a granule another workgroup of this launch publishes: polled with a bound (las_speller_fwd_args.status reports a partner that never ran)
+__device__ __forceinline__ unsigned wide_poll(const DecDev& a, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag) {
+    u32x2_t g = granule8_load(rs, byte_off);
+    int budget = a.lp.budget;
+    while (g.x != tag) {
+        if (--budget == 0) { if (a.lp.status) a.lp.status[0] = LAS_SPELLER_STATUS_TIMEOUT; break; }
+        __builtin_amdgcn_s_sleep(2);
+        g = granule8_load(rs, byte_off);
+    }
+    return g.y;
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -204,12 +219,13 @@ __device__ __forceinline__ float4 wide_key4(const DecDev& a, int b, int tt, int 
 //     slice's softmax statistics (max, sum of exp).  grid (nsplit, B).
 // CT: the conv's channel count at compile time (10, the reference's default: the per-channel loops unroll and their LDS reads pipeline -- as
 // runtime loops they were one LDS round trip per channel and frame) or 0 = any.
-template <bool FAST, bool LOC, int CT = 0>
-__global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, int t) {
-    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// FUSED: the slice's energies and statistics leave as granules for the utterance's other workgroups of the SAME launch (wide_attend_kernel).
+template <bool FAST, bool LOC, int CT, bool FUSED>
+__device__ __forceinline__ void wide_energy_body(const DecDev& a, const WideDev& w, const int t, const int s, const int b, float* sm) {
     const WideLds L = wide_carve(sm, a, w.fper);
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t grs = granule_rsrc(w.egran);
+    const unsigned grow = (unsigned)b * (unsigned)wide_gran_row(a.Tp), gtag = (unsigned)t + 1u;
     const int B = a.B, Tp = a.Tp, A = a.A, C = CT > 0 ? CT : a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     WSTAMP(0);
@@ -221,7 +237,15 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
     }
     __syncthreads();
     WSTAMP(1);
-    if (nf <= 0) { if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; } return; }
+    if (nf <= 0) {
+        if (tid == 0) {
+            if (FUSED) {
+                granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(-INFINITY), false);
+                granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(0.f), false);
+            } else { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; }
+        }
+        return;
+    }
     // 32 lanes per frame (lane sl: attention columns 4 sl .. 4 sl + 3 and 128 + 4 sl ..), 32 frames at a time.  The keys of a group's first two
     // frames are requested in front of the conv: they do not depend on it, and behind it their latency was on the chain once per frame
     const int sl = tid & 31, grp = tid >> 5, A4 = A / 4;
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
             if (sl == 0) {
                 const float em = (tt < len) ? e : -1e8f;           // replace-mask, las/layers.py:205-207
                 L.ev[fr] = em;
-                w.ebuf[(size_t)b * Tp + tt] = em;
+                if (FUSED) granule8_store(grs, (grow + tt) * 8u, gtag, __float_as_uint(em), false);
+                else w.ebuf[(size_t)b * Tp + tt] = em;
             }
         }
     }
@@ -292,17 +317,26 @@ __global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, i
     float ssum = 0.f;
     for (int i = tid; i < nf; i += RNT) ssum += expf(L.ev[i] - m);
     ssum = block_sum<RNT>(ssum, L.red);
-    if (tid == 0) { w.stat[((size_t)b * w.nsplit + s) * 2] = m; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = ssum; }
+    if (tid == 0) {
+        if (FUSED) {
+            granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(m), false);
+            granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(ssum), false);
+        } else { w.stat[((size_t)b * w.nsplit + s) * 2] = m; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = ssum; }
+    }
     WSTAMP(5);
+}
+template <bool FAST, bool LOC, int CT = 0>
+__global__ __launch_bounds__(RNT) void wide_energy_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    wide_energy_body<FAST, LOC, CT, false>(a, w, t, (int)blockIdx.x, (int)blockIdx.y, sm);
 }
 
 // (3) alignment (softmax over all frames from the slices' statistics), the context columns [4 c0, 4 c1) of utterance b, and the cell input
 //     row [emb(token) ; context ; h_0] (fp32 for the weight gradients, bf16 as the product's A operand).  grid (hsplit, B).
-template <bool FAST>
-__global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, int t) {
-    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hs_ = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+template <bool FAST, bool FUSED>
+__device__ __forceinline__ void wide_context_body(const DecDev& a, const WideDev& w, const int t, const int hs_, const int b, float* sm) {
+    const int tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, D = a.D, E = a.E, V = a.V, U = a.U, I0D = E + Hd + D, H4 = Hd / 4;
     float* al = sm;                                  // [Tp] alignment (speed mode: rounded to bf16, the contraction's operand)
     float* part = sm + ((Tp + 3) & ~3);              // [ng][h4per] float4
@@ -336,17 +370,27 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
                           (a.emb_mask ? a.emb_mask[((size_t)t * B + b) * E + tid] : 1.f);
         if (tid < D) hv = a.hs[(((size_t)0 * (U + 1) + t) * B + b) * D + tid];
     }
+    if (FUSED) {      // the utterance's energies and slice statistics from this launch's other workgroups -> LDS (al: raw energies; part: statistics)
+        const __amdgpu_buffer_rsrc_t grs = granule_rsrc(w.egran);
+        const unsigned grow = (unsigned)b * (unsigned)wide_gran_row(Tp), gtag = (unsigned)t + 1u;
+        for (int i = tid; i < Tp + 2 * w.nsplit; i += RNT) {
+            const float v = __uint_as_float(wide_poll(a, grs, (grow + i) * 8u, gtag));
+            if (i < Tp) al[i] = v; else part[i - Tp] = v;
+        }
+        __syncthreads();
+    }
+    auto st = [&](int s, int j) -> float { return FUSED ? part[2 * s + j] : w.stat[((size_t)b * w.nsplit + s) * 2 + j]; };
     float m = -INFINITY;
-    for (int s = 0; s < w.nsplit; ++s) m = fmaxf(m, w.stat[((size_t)b * w.nsplit + s) * 2]);
+    for (int s = 0; s < w.nsplit; ++s) m = fmaxf(m, st(s, 0));
     float l = 0.f;
     for (int s = 0; s < w.nsplit; ++s) {
-        const float ms = w.stat[((size_t)b * w.nsplit + s) * 2], ls = w.stat[((size_t)b * w.nsplit + s) * 2 + 1];
+        const float ms = st(s, 0), ls = st(s, 1);
         if (ls > 0.f) l += ls * expf(ms - m);
     }
     const float inv = 1.0f / l;
     float* arow = a.alphas + ((size_t)t * B + b) * Tp;
     for (int i = tid; i < Tp; i += RNT) {
-        const float v = expf(w.ebuf[(size_t)b * Tp + i] - m) * inv;
+        const float v = expf((FUSED ? al[i] : w.ebuf[(size_t)b * Tp + i]) - m) * inv;
         if (hs_ == 0) arow[i] = v;
         al[i] = FAST ? bf2f(f2bf(v)) : v;
     }
@@ -404,6 +448,28 @@ __global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, 
         }
     }
     WSTAMP(13);
+}
+template <bool FAST>
+__global__ __launch_bounds__(RNT) void wide_context_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    wide_context_body<FAST, false>(a, w, t, (int)blockIdx.x, (int)blockIdx.y, sm);
+}
+
+// (2) + (3) as ONE launch: workgroup (s, b) computes the energies of frame slice s, publishes them and the slice's statistics as tagged
+// granules (write-through stores; the data is the flag), then -- as context slice s -- collects the utterance's energies from its peers and
+// goes on with the alignment and its context columns.  Every workgroup of an utterance must be resident for that (the host launches this
+// form only when max(nsplit, hsplit) B workgroups fit the device's compute units; a partner that never arrives ends the polls after
+// lp.budget rounds and is reported through the status word -- las.layers.fallback_schedule then re-runs the step with the two launches).
+// One kernel boundary (~4 us of launch ramp, drain and cold staging) per decode step becomes one hop through memory (~1.5 us).
+template <bool FAST, bool LOC, int CT = 0>
+__global__ __launch_bounds__(RNT) void wide_attend_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int s = blockIdx.x, b = blockIdx.y;
+    if (s < w.nsplit) wide_energy_body<FAST, LOC, CT, true>(a, w, t, s, b, sm);
+    __syncthreads();                                    // (the context phase re-uses the energies' LDS)
+    if (s < w.hsplit) wide_context_body<FAST, true>(a, w, t, s, b, sm);
 }
 
 // gate nonlinearity of layer `layer` (< TOP) at step t, and the bf16 input row of the layer above: [h_{layer, t+1} ; h_{layer+1, t}]
@@ -912,7 +978,7 @@ __global__ __launch_bounds__(256) void wide_dkeys_kernel(DecDev a, WideDev w, fl
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct WideWs { size_t packWs, packWsT, packU[LAS_MAX_NL], packUB[LAS_MAX_NL], srow, xu, dqbf, dgu, qbuf, ebuf, stat, pdq, pdu, dS, dWfW, total; };
+struct WideWs { size_t packWs, packWsT, packU[LAS_MAX_NL], packUB[LAS_MAX_NL], srow, xu, dqbf, dgu, qbuf, ebuf, stat, pdq, pdu, dS, dWfW, egran, total; };
 static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
     WideWs w; size_t o = 0;
     const size_t S = (size_t)D * NL, GD = (size_t)G * D;
@@ -933,6 +999,7 @@ static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
     w.pdu = o;   o += align256((size_t)B * WIDE_MAX_SPLIT * A * 4);
     w.dS = o;    o += align256((size_t)B * S * 4);
     w.dWfW = o;  o += align256(C > 0 ? (size_t)B * cdiv(Tp, 8) * C * A * 4 : 0);
+    w.egran = o; o += align256((size_t)B * wide_gran_row(Tp) * 8);
     w.total = o;
     return w;
 }
@@ -963,7 +1030,7 @@ static void wide_fill(const DecDev& d, WideDev& w, char* base, const WideWs& L) 
     w.pdq = (float*)(base + L.pdq); w.pdu = (float*)(base + L.pdu);
     w.sbf = (unsigned short*)(base + L.srow); w.sf = (float*)(base + L.srow);
     w.xu = (unsigned short*)(base + L.xu); w.dqbf = (unsigned short*)(base + L.dqbf); w.dgu = (unsigned short*)(base + L.dgu);
-    w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW);
+    w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW); w.egran = (unsigned long long*)(base + L.egran);
 }
 template <class K> static int wide_lds_attr(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;

@@ -43,15 +43,26 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
     // h = tanh(. + bias) -> the saved state, and as bf16 straight into the operand rows of the products that read it next), so the state
     // launch (after step 0) and the gate launches between the layers' products drop out of the chain: 7 -> 5 dependent launches per step
     const bool epi = FAST && CELL == LAS_CELL_RNN && !d.step_logits && NL <= 2;
+    // energies + alignment / context as one launch with an in-kernel hand-over (wide_attend_kernel): every workgroup of the grid resident at once
+    const int SP = w.nsplit > w.hsplit ? w.nsplit : w.hsplit;
+    const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)SP * B <= las_device_cus();
+    const size_t lds_f = lds_e > lds_c ? lds_e : lds_c;
+    if (fuse) LAS_HIP(hipMemsetAsync(w.egran, 0, (size_t)B * wide_gran_row(d.Tp) * 8, st));
     for (int t = 0; t <= U; ++t) {
         if (!epi || t == 0) WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
         if (t == U) break;
         if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.sbf, S, B, S, wb + WL.packWs, A, w.qbuf, A, nullptr, st));
         else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, w.sf, S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
-        if (loc && d.C == 10) WIDE_LAUNCH((wide_energy_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
-        else if (loc) WIDE_LAUNCH((wide_energy_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
-        else     WIDE_LAUNCH((wide_energy_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
-        WIDE_LAUNCH((wide_context_kernel<FAST>), dim3(w.hsplit, B), dim3(RNT), lds_c, st, d, w, t);
+        if (fuse) {
+            if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_kernel<FAST, true, 10>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
+            else if (loc) WIDE_LAUNCH((wide_attend_kernel<FAST, true>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
+            else          WIDE_LAUNCH((wide_attend_kernel<FAST, false>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
+        } else {
+            if (loc && d.C == 10) WIDE_LAUNCH((wide_energy_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
+            else if (loc) WIDE_LAUNCH((wide_energy_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
+            else     WIDE_LAUNCH((wide_energy_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
+            WIDE_LAUNCH((wide_context_kernel<FAST>), dim3(w.hsplit, B), dim3(RNT), lds_c, st, d, w, t);
+        }
         float* g0 = d.gates + ((size_t)0 * U + t) * B * GD;
         if (epi) {
             // layer 0: h_{0,t+1} -> hs[0][t+1]; bf16 into the layer above's [x ; h] row (multi-layer) and into the state row of step t+1
@@ -111,6 +122,10 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     const size_t lds_a = (size_t)(((Hd + 3) & ~3) + 64) * sizeof(float) + 64;
     const size_t lds_e = wide_lds_bytes(d, w.fper);
     const size_t lds_q = wide_dq_lds_bytes(d, w.fper);
+    // tanh cells, speed mode: a layer's gate gradient is the EPILOGUE of the product in front of it (las_skinny_gemm_bf16_tanh_bwd) -- the top
+    // layer's behind d s = dq . Ws^T, a lower layer's behind the product of the layer above -- so the gate launches drop out of the chain
+    // (8 -> 6 dependent launches per step at two layers; the first iteration, which has no d s, keeps the top layer's launch)
+    const bool bepi = FAST && CELL == LAS_CELL_RNN && NL <= 2;
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
@@ -125,7 +140,13 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
                 WIDE_LAUNCH((wide_dq_kernel<FAST, false>), dim3(1, B), dim3(RNT), lds_q, st, d, w, ta);
             }
             if (ta > 0) {    // d s_{t+1} = dq . Ws^T: the gradient of every layer's state that entered step t + 1
-                if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, nullptr, st));
+                if (bepi && t >= 0) {
+                    const float* recT = TOP == 0 ? d.dXin0 + (size_t)ta * B * I0D + E + Hd : tmp + (size_t)TOP * B * 2 * D + D;
+                    GEMM_OK(las_skinny_gemm_bf16_tanh_bwd(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, TOP * D, D,
+                                                          d.hs + ((size_t)TOP * (U + 1) + t + 1) * B * D, D, dHl + (size_t)t * B * D, D,
+                                                          recT, TOP == 0 ? I0D : 2 * D, 1, d.gates + ((size_t)TOP * U + t) * B * GD, GD,
+                                                          TOP == 0 ? d.dgbf : w.dgu, GD, st));
+                } else if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, nullptr, st));
                 else GEMM_OK(las_gemm(prec, 0, 1, B, S, A, 1.f, d.dQ + (size_t)ta * B * A, A, 0, d.Ws, A, 0, 0.f, w.dS, S, 0, nullptr, LAS_ACT_NONE, 1,
                                       0, 0, nullptr, 0, st));
             }
@@ -141,9 +162,11 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
             const float* extra = l == TOP ? dHl + (size_t)t * B * D : tmp + (size_t)(l + 1) * B * 2 * D;
             const int extra_ld = l == TOP ? D : 2 * D;
             unsigned short* gb = FAST ? (l == 0 ? d.dgbf : w.dgu) : nullptr;
-            hipLaunchKernelGGL((wide_cell_bwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, w, l, t, rec, rec_ld, rec_off,
-                               next ? (const float*)w.dS : (const float*)nullptr, extra, extra_ld, gb);
-            LAS_LAUNCHED();
+            if (!(bepi && (l < TOP || next))) {              // (else: done by the epilogue of the product in front)
+                hipLaunchKernelGGL((wide_cell_bwd_kernel<CELL, FAST>), dim3(B), dim3(256), 0, st, d, w, l, t, rec, rec_ld, rec_off,
+                                   next ? (const float*)w.dS : (const float*)nullptr, extra, extra_ld, gb);
+                LAS_LAUNCHED();
+            }
             const float* dG = d.gates + ((size_t)l * U + t) * B * GD;
             if (l == 0) {
                 if (FAST) GEMM_OK(las_skinny_gemm_bf16(d.dgbf, GD, B, GD, packB, I0D, d.dXin0 + (size_t)t * B * I0D, I0D, nullptr, st));
@@ -151,7 +174,14 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
                                       LAS_ACT_NONE, 1, 0, 0, gws, gws_bytes, st));
             } else {
                 float* tl = tmp + (size_t)l * B * 2 * D;
-                if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dgu, GD, B, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, nullptr, st));
+                if (bepi) {      // + the gate gradient of layer l - 1 (its d h: columns [0, D) of this product, + recurrent + attention shares)
+                    const int lb = l - 1;
+                    const float* recL = !next ? nullptr : (lb == 0 ? d.dXin0 + (size_t)ta * B * I0D + E + Hd : tmp + (size_t)lb * B * 2 * D + D);
+                    GEMM_OK(las_skinny_gemm_bf16_tanh_bwd(w.dgu, GD, B, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, 0, D,
+                                                          d.hs + ((size_t)lb * (U + 1) + t + 1) * B * D, D, recL, lb == 0 ? I0D : 2 * D,
+                                                          next ? (const float*)w.dS + (size_t)lb * D : (const float*)nullptr, S, 0,
+                                                          d.gates + ((size_t)lb * U + t) * B * GD, GD, lb == 0 ? d.dgbf : w.dgu, GD, st));
+                } else if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dgu, GD, B, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, nullptr, st));
                 else GEMM_OK(las_gemm(prec, 0, 1, B, 2 * D, GD, 1.f, dG, GD, 0, f->cellW[l], GD, 0, 0.f, tl, 2 * D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0,
                                       nullptr, 0, st));
             }
