@@ -41,9 +41,15 @@ struct WideDev {
 __host__ __device__ __forceinline__ int wide_gran_row(int Tp) { return Tp + 2 * WIDE_MAX_SPLIT; }
 
 // a granule another workgroup of this launch publishes: polled with a bound (las_speller_fwd_args.status reports a partner that never ran)
-__device__ __forceinline__ unsigned wide_poll(const DecDev& a, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag) {
+// The bound: a hand-over normally completes within microseconds, a partner kept off the machine by somebody else's kernel arrives when that
+// kernel ends -- 2^15 rounds (~50 ms) cover the latter; and once the call's status word is set (an earlier launch of this call gave up: the
+// step is lost and will be re-run) the following launches do not wait at all, so a lost step costs one bound, not one per decode step.
+__device__ __forceinline__ int wide_poll_budget(const DecDev& a) {
+    if (a.lp.status && __hip_atomic_load(a.lp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 1;
+    return a.lp.budget < (1 << 15) ? a.lp.budget : (1 << 15);
+}
+__device__ __forceinline__ unsigned wide_poll(const DecDev& a, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, int budget) {
     u32x2_t g = granule8_load(rs, byte_off);
-    int budget = a.lp.budget;
     while (g.x != tag) {
         if (--budget == 0) { if (a.lp.status) a.lp.status[0] = LAS_SPELLER_STATUS_TIMEOUT; break; }
         __builtin_amdgcn_s_sleep(2);
@@ -373,8 +379,9 @@ __device__ __forceinline__ void wide_context_body(const DecDev& a, const WideDev
     if (FUSED) {      // the utterance's energies and slice statistics from this launch's other workgroups -> LDS (al: raw energies; part: statistics)
         const __amdgpu_buffer_rsrc_t grs = granule_rsrc(w.egran);
         const unsigned grow = (unsigned)b * (unsigned)wide_gran_row(Tp), gtag = (unsigned)t + 1u;
+        const int budget = wide_poll_budget(a);
         for (int i = tid; i < Tp + 2 * w.nsplit; i += RNT) {
-            const float v = __uint_as_float(wide_poll(a, grs, (grow + i) * 8u, gtag));
+            const float v = __uint_as_float(wide_poll(a, grs, (grow + i) * 8u, gtag, budget));
             if (i < Tp) al[i] = v; else part[i - Tp] = v;
         }
         __syncthreads();

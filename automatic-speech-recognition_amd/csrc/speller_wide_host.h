@@ -42,7 +42,7 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
     // tanh cells, speed mode, tokens known in advance (no in-loop logits): the cell IS the product's epilogue (las_skinny_gemm_bf16_tanh:
     // h = tanh(. + bias) -> the saved state, and as bf16 straight into the operand rows of the products that read it next), so the state
     // launch (after step 0) and the gate launches between the layers' products drop out of the chain: 7 -> 5 dependent launches per step
-    const bool epi = FAST && CELL == LAS_CELL_RNN && !d.step_logits && NL <= 2;
+    const bool epi = FAST && CELL == LAS_CELL_RNN && !d.step_logits && NL <= 2 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);    // (the flag: every phase its own launch)
     // energies + alignment / context as one launch with an in-kernel hand-over (wide_attend_kernel): every workgroup of the grid resident at once
     const int SP = w.nsplit > w.hsplit ? w.nsplit : w.hsplit;
     const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)SP * B <= las_device_cus();
@@ -125,7 +125,7 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     // tanh cells, speed mode: a layer's gate gradient is the EPILOGUE of the product in front of it (las_skinny_gemm_bf16_tanh_bwd) -- the top
     // layer's behind d s = dq . Ws^T, a lower layer's behind the product of the layer above -- so the gate launches drop out of the chain
     // (8 -> 6 dependent launches per step at two layers; the first iteration, which has no d s, keeps the top layer's launch)
-    const bool bepi = FAST && CELL == LAS_CELL_RNN && NL <= 2;
+    const bool bepi = FAST && CELL == LAS_CELL_RNN && NL <= 2 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])

@@ -8,6 +8,8 @@ T' > 224, location-aware attention with any filter (reference las/las.py:72-160,
    d f, the after-loop keys / Wf / filter contractions), for both cells, both attention modes, 1-3 layers, ragged sizes, sampled tokens.
  * SPEED MODE, as selected by default: the same launches on bf16 operands against the oracle's bf16-row mode.
  * wide == not wide: the same call through round 5's per-utterance row kernels (LAS_SPELLER_NO_WIDE) in parity mode.
+ * fused == launch per phase: the fused attention launch (wide_attend_kernel: an in-kernel hand-over between an utterance's workgroups) and
+   the tanh cells as epilogues of their products, forward and backward, against LAS_SPELLER_NO_FUSED_STEP -- bit for bit.
 """
 import numpy as np
 import pytest
@@ -134,6 +136,40 @@ def test_wide_path_speed_mode_matches_the_bf16_row_oracle(shape):
         assert "wide" in r["fam"]["fwd"] and "wide" in r["fam"]["bwd"], r["fam"]
     el, worst = _check(r, 5e-3, 2e-3, 2e-2)
     print("wide bf16 %s: %s logits %.1e worst grad %s %.1e" % (shape[:4], r["fam"]["fwd"], el, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+@pytest.mark.parametrize("shape", [SHAPES[1], SHAPES[3], SHAPES[5], SHAPES[6], SHAPES[7], MORE_ROWS[0]])
+def test_wide_path_fused_launches_equal_one_launch_per_phase_bit_for_bit(shape, prec):
+    """wide_attend_kernel (energies -> granules -> alignment / context in ONE launch) and the tanh-cell epilogues of the skinny products
+    (las_skinny_gemm_bf16_tanh / _tanh_bwd) re-arrange launches, not arithmetic: the same operands in the same order."""
+    from las import _hip
+    cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc = shape
+    a = _run(_hip.SPELLER_WIDE, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=loc, oracle=False)
+    b = _run(_hip.SPELLER_WIDE | _hip.SPELLER_NO_FUSED_STEP, prec, cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc=loc, oracle=False)
+    assert "wide" in a["fam"]["fwd"] and "wide" in b["fam"]["fwd"] and "wide" in a["fam"]["bwd"] and "wide" in b["fam"]["bwd"]
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["alphas"], b["alphas"])
+    for n in a["grads"]:
+        assert torch.equal(a["grads"][n], b["grads"][n]), n
+
+
+def test_wide_fused_attention_poll_timeout_is_reported_and_the_next_call_is_clean():
+    """The in-kernel hand-over of wide_attend_kernel is bounded: with a poll budget of 2 (LAS_SPELLER_SPIN_LOG2(1)) some workgroup gives up on
+    its partners, the status word says so (the host raises at its next check; LAS.train would re-run the step on the launch-per-phase form),
+    every later launch of the call stops waiting, nothing hangs -- and the next call with the normal budget is clean and equals the
+    launch-per-phase form again."""
+    from las import _hip
+    # (T' = 21: three frame slices but eight context slices per utterance -- five workgroups of an utterance have no energies of their own
+    #  and poll at once, microseconds before the other three have staged the K = 201 filter, let alone published)
+    cell, NL, D, A, Hd, E, B, Tp, U, mixed, loc = "rnn", 2, 64, 32, 64, 32, 4, 21, 7, True, (201, 10)
+    with pytest.raises(RuntimeError, match="status 3"):
+        _run(_hip.SPELLER_WIDE | _hip.speller_spin_log2(1), "bf16", cell, NL, D, A, Hd, E, B, Tp, 12, mixed, loc=loc, oracle=False)
+    _hip.clear_status(torch.device("cuda"))
+    a = _run(_hip.SPELLER_WIDE, "bf16", cell, NL, D, A, Hd, E, B, Tp, 12, mixed, loc=loc, oracle=False)
+    b = _run(_hip.SPELLER_WIDE | _hip.SPELLER_NO_FUSED_STEP, "bf16", cell, NL, D, A, Hd, E, B, Tp, 12, mixed, loc=loc, oracle=False)
+    assert torch.equal(a["logits"], b["logits"])
+    for n in a["grads"]:
+        assert torch.equal(a["grads"][n], b["grads"][n]), n
 
 
 @pytest.mark.parametrize("shape", [SHAPES[1], SHAPES[3], SHAPES[5]])
