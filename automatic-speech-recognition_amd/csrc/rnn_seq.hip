@@ -1734,7 +1734,10 @@ static bool mfma_shape_ok(int H) { return H == 64 || H == 128 || H == 256 || H =
 static int pick_cluster(int cell, int H, int flags) {
     int P;
     if (cell == LAS_CELL_LSTM) P = H >= 512 ? 8 : (H >= 256 ? 4 : (H >= 128 ? 2 : 1));
-    else                       P = H >= 256 ? 2 : 1;     // (r4: the tanh cell at H = 256 on two CUs serves the 8-row helper-wave / K-split kernels: BPTT 1.77 -> 1.25 us per step)
+    else                       P = H >= 512 ? 4 : (H >= 256 ? 2 : 1);     // (r4: the tanh cell at H = 256 on two CUs serves the 8-row helper-wave / K-split kernels: BPTT 1.77 -> 1.25 us per step;
+                                                                          //  r6: H = 512 -- run.sh's listener -- on four: two members had 64 W_hh fragments per wave, too many for the helper-wave
+                                                                          //  kernel (32 in registers + 32 in LDS do not fit beside its rings), and swept on the plain kernel at 2.7 us per
+                                                                          //  step; run.sh's step 27.5 -> 24.8 ms)
     const int v = (flags >> 8) & 0xf;
     if (v == 1 || v == 2 || v == 4 || v == 8) P = v;
     return P;

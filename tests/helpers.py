@@ -154,6 +154,32 @@ def train_step_pair(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None,
                 tokens_in=las.speller.last_tokens_in.cpu())
 
 
+def hip_step(args, cell, prec, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", seq_flags=0):
+    """One LAS.train step through the C ABI alone (no oracle run), optionally with extra sweep flags (e.g. _hip.seq_p(2): another cluster
+    width = another, equally valid, summation order of the same operands): (gradients, logits, alignments, loss)."""
+    import torch
+    from las import _hip, layers as L, variables as V
+    from las.las import LAS, Listener, Speller
+    from oracle import las_oracle as O
+    p0 = O.init_params(args, seed=seed, cell=cell, enc_type=enc_type)
+    saved = _hip.seq_flags
+    _hip.seq_flags = saved | seq_flags
+    try:
+        L.set_cell(cell)
+        L.set_precision(prec)
+        st = V.reset_default_store(device="cuda")
+        st.load(p0)
+        las = LAS(args, Listener, Speller, {})
+        loss, _, gs, logits, alphas, summ, rate = las.train(xs, ys, coins=coins, sampled=sampled)
+        torch.cuda.synchronize()
+        las.check_status()
+        if las.recovered_steps:
+            loss, _, gs, logits, alphas, summ, rate = las.last_out
+        return {n: st.vars[n].grad.detach().cpu() for n in st.order}, logits.cpu(), alphas.cpu(), float(loss)
+    finally:
+        _hip.seq_flags = saved
+
+
 def oracle_grads(args, cell, mode, xs, ys, seed=11, coins=None, sampled=None, enc_type="pblstm", full=False):
     """Gradients (and logits) of the oracle's train step in an explicit arithmetic mode (a set_precision tuple): the second oracle run a
     test needs to measure the ORACLE's own sensitivity to the arithmetic on an input (f32 mode against the bf16-emulating mode)."""
