@@ -103,6 +103,24 @@ python3 bench.py --only-leg config2_sampling --steps 20 --warmup 5 > gpurun_out/
 import json,sys
 d=json.loads(sys.stdin.read())['decode']
 print('value', d['value'], 'value_b16', d['value_b16'], 'us_per_step', d['us_per_decode_step'], d['step_parts_us'])"; done; done) > gpurun_out/${P}_decode_xcd_ab.txt 2>&1
+# ---- round 6: ONE keys / encoder block per utterance for its hypothesis rows (LAS_SPELLER_SHARED_OPERANDS) against a tiled copy per row, alternating
+(for i in 1 2 3; do for v in 1 0; do echo -n "LAS_NO_SHARED_OPERANDS=$v "; LAS_NO_SHARED_OPERANDS=$v python3 bench.py --decode-only 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())['decode']
+print('value', d['value'], 'value_b16', d['value_b16'], 'us_per_step', d['us_per_decode_step'], d['step_parts_us'])"; done; done) > gpurun_out/${P}_decode_shared_ab.txt 2>&1
+# ---- round 6: the wide Speller path's attention kernels: phase stamps (make ablf F=speller D=-DLAS_ROW_STAMPS S=rowst), the fused launches against one
+# launch per phase, the listener's tanh sweeps on two / four members per direction (run.sh recipe, alternating)
+if [ -f automatic-speech-recognition_amd/lib/liblas_hip_rowst.so ]; then
+  (for c in rnn lstm; do CELL=$c LAS_LIB_PATH=automatic-speech-recognition_amd/lib/liblas_hip_rowst.so python3 tools/probe_wide_stamps.py; done) 2>&1 | grep -v amdgpu > gpurun_out/${P}_wide_phase_stamps.txt
+fi
+(for i in 1 2 3; do for v in 1 0; do echo -n "LAS_NO_FUSED_STEP=$v "; LAS_NO_FUSED_STEP=$v python3 bench.py --only-leg run_sh 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read())['run_sh']
+print({k: v['ms_per_step'] for k, v in r.items()})"; done; done) > gpurun_out/${P}_runsh_fused_ab.txt 2>&1
+(for i in 1 2 3; do for v in 2 4; do echo -n "LAS_SEQ_P=$v "; LAS_SEQ_P=$v python3 bench.py --only-leg run_sh_rnn 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read())['run_sh_rnn']
+print({k: v['ms_per_step'] for k, v in r.items()})"; done; done) > gpurun_out/${P}_runsh_cluster_width_ab.txt 2>&1
 # ---- round 6: what the step recovery's bookkeeping costs the headline (alternating)
 (for i in 1 2 3; do for v in 0 1; do echo -n "LAS_NO_STEP_RECOVERY=$v "; LAS_NO_STEP_RECOVERY=$v python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-decode --no-train-loop --no-side-legs 2>/dev/null | python3 -c "
 import json,sys

@@ -21,12 +21,15 @@ SECTIONS = [
     ("wide_context_kernel", 10, ["softmax over all frames -> LDS", "context columns (partials)", "partials summed, row written"]),
     ("wide_dalpha_kernel", 20, ["d context staged", "d alpha of the slice's frames", "alpha . d alpha summed, stored"]),
     ("wide_energy_bwd_kernel", 30, ["q / Wf staged", "f rows, d energy of the slice", "tanh recomputed, dq / du / d f partials",
-                                     "(barrier)", "partials through LDS, stored", "d f stored"]),
+                                     "partials through LDS, stored", "d f stored"]),
+    # (the reverse loop's LAST launch, step 0, has no conv transpose: its stamps 42.. are those of the launch before, printed relative to that launch's 41)
     ("wide_dq_kernel", 40, ["dq / du summed over the slices", "d f rows + filter staged", "conv transpose (tap slices)", "summed, stored"]),
 ]
 for name, base, labels in SECTIONS:
     print("%s; us since its first stamp:" % name)
     for i, lab in enumerate(labels):
         a, b = v[base + i], v[base + i + 1]
-        if a and b:
+        if a and b and b >= a:
             print("  %-52s %6.2f  (+%.2f)" % (lab, (b - v[base]) / 100.0, (b - a) / 100.0))
+        elif a and b:
+            print("  %-52s         (stale: stamped by an earlier launch)" % lab)
