@@ -29,7 +29,6 @@ unset LAS_ALLOW_SERIAL_STREAMS
 # the bench line comes AFTER the counter passes: bench.py takes the dominant kernel's HBM traffic from the newest profiles/*_pmc.json
 # that was recorded from this very csrc/rnn_seq.hip
 cp gpurun_out/${P}_pmc.json profiles/${P}_pmc.json 2>/dev/null
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> /dev/null             # the bench line exactly as the driver runs it
 LAS_PHASES=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-decode --no-train-loop > /dev/null 2> gpurun_out/${P}_phases.txt   # spans of the phases / sweeps (HIP events; their recording costs ~0.1 ms per step)
 python3 tools/prof_rnn.py > gpurun_out/${P}_phase_stamps.txt 2>&1
 python3 tools/prof_rnn_insitu.py > gpurun_out/${P}_phase_stamps_insitu.txt 2>&1          # the last BPTT sweep's split inside a whole step
@@ -46,7 +45,9 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
   -d /tmp/pmc_dec_${P}_SQ -o p -- python3 bench.py --decode-only > /tmp/pmc_dec_${P}_SQ.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/${P}_decode /tmp/pmc_dec_${P}_FETCH_SIZE /tmp/pmc_dec_${P}_WRITE_SIZE /tmp/pmc_dec_${P}_SQ > gpurun_out/${P}_decode_pmc_summary.log 2>&1
 unset LAS_ALLOW_SERIAL_STREAMS
+cp gpurun_out/${P}_decode_pmc.json profiles/${P}_decode_pmc.json 2>/dev/null          # (decode.roofline.traffic: the newest profiles/*_decode_pmc.json recorded from this csrc/speller.hip)
 python3 bench.py --decode-only > gpurun_out/${P}_decode_bench.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> /dev/null             # the bench line exactly as the driver runs it (behind BOTH counter passes it quotes)
 # ---- Speller loop kernels: phase stamps of one decode step (row workgroup 0 and product workgroup 0 on one clock)
 [ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps > gpurun_out/${P}_speller_phase_stamps.txt 2>&1
 [ -x tools/micro/bin/bench_fused_stamps ] && tools/micro/bin/bench_fused_stamps 0 loc > gpurun_out/${P}_speller_loc_phase_stamps.txt 2>&1

@@ -29,7 +29,9 @@ for name, base, labels in SECTIONS:
     print("%s; us since its first stamp:" % name)
     for i, lab in enumerate(labels):
         a, b = v[base + i], v[base + i + 1]
-        if a and b and b >= a:
+        if a and b and b >= a and a >= v[base]:
             print("  %-52s %6.2f  (+%.2f)" % (lab, (b - v[base]) / 100.0, (b - a) / 100.0))
+        elif a and b and b >= a:
+            print("  %-52s         (+%.2f, in the launch before)" % (lab, (b - a) / 100.0))
         elif a and b:
             print("  %-52s         (stale: stamped by an earlier launch)" % lab)
