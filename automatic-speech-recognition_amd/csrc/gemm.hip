@@ -1614,7 +1614,10 @@ struct SkinnyEpi { float* eh; int ldh; unsigned short* b0; int ld0; unsigned sho
 // above's product), times 1 - h^2 -> fp32 into the saved gates, bf16 into the operand row of the layer's own product.  The other columns are
 // stored as usual.  The gate launch between two dependent products disappears.
 struct SkinnyEpiB { const float* h; int ldh; const float* sa; int lda; const float* sb; int ldb; int vlast; int c0; int D; float* gp; int ldg;
-                    unsigned short* gb; int ldgb; };
+                    unsigned short* gb; int ldgb;
+                    // EPI = 3, the LSTM cell's gate gradient (wide_cell_bwd_kernel<LSTM>: gp holds the ACTIVATED gates [i | j | f | o] of the step and
+                    // receives their pre-activation gradients; c / cp: the cell state after / before the step; dC: the carried cell gradient, updated)
+                    const float* c; const float* cp; float* dC; int ldc_; };
 struct SkinnyEpiNone {};
 template <bool ABF, int EPI = 0, class EpiT = SkinnyEpiNone>
 __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
@@ -1689,6 +1692,29 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
                     done = true;
                 }
             }
+            if constexpr (EPI == 3) {
+                const SkinnyEpiB& eb = ep;
+                if (col >= eb.c0 && col < eb.c0 + eb.D) {
+                    const int d = col - eb.c0, D = eb.D;
+                    float dh;
+                    if (eb.vlast) { dh = eb.sa[(long long)orow * eb.lda + d]; if (eb.sb) dh += eb.sb[(long long)orow * eb.ldb + d]; dh += v; }
+                    else { dh = v; if (eb.sa) dh += eb.sa[(long long)orow * eb.lda + d]; if (eb.sb) dh += eb.sb[(long long)orow * eb.ldb + d]; }
+                    float* gp = eb.gp + (long long)orow * eb.ldg;
+                    const float gi = gp[d], gj = gp[D + d], gf = gp[2 * D + d], go = gp[3 * D + d];
+                    const float cc = eb.c[(long long)orow * eb.ldc_ + d], cp = eb.cp[(long long)orow * eb.ldc_ + d];
+                    const float tc = tanh_fast(cc);
+                    float* dCr = eb.dC + (long long)orow * eb.ldc_;
+                    const float dc = dCr[d] + dh * go * (1.f - tc * tc);
+                    dCr[d] = dc * gf;
+                    const float di = dc * gj * gi * (1.f - gi), dj = dc * gi * (1.f - gj * gj);
+                    const float df = dc * cp * gf * (1.f - gf), dO = dh * tc * go * (1.f - go);
+                    gp[d] = di; gp[D + d] = dj; gp[2 * D + d] = df; gp[3 * D + d] = dO;
+                    unsigned short* gb = eb.gb + (long long)orow * eb.ldgb;
+                    gb[d] = f2bf(di); gb[D + d] = f2bf(dj); gb[2 * D + d] = f2bf(df); gb[3 * D + d] = f2bf(dO);
+                    if (C) C[(long long)orow * ldc + col] = v;
+                    done = true;
+                }
+            }
             if constexpr (EPI == 1) {
                 const SkinnyEpi& epi = ep;
                 const float h = tanh_fast(v);
@@ -1738,11 +1764,24 @@ int las_skinny_gemm_bf16_tanh(const unsigned short* A, int lda, int M, int K, co
 }
 
 // C[M, N] = bf16(A) . packed (stored), and for the columns [c0, c0 + D) the tanh cell's gate gradient as the epilogue (SkinnyEpiB)
+// ... and the LSTM cell's (SkinnyEpiB: EPI = 3): gp = the step's activated gates [M, 4 D] in / their pre-activation gradients out, gb = the bf16 operand row
+// [M, 4 D], c / cp = the cell state after / before the step [M, D], dC = the carried cell-state gradient [M, D] (updated in place)
+int las_skinny_gemm_bf16_lstm_bwd(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, int c0, int D,
+                                  const float* sa, int lda_, const float* sb, int ldb, int vlast, float* gp, int ldg, unsigned short* gb, int ldgb,
+                                  const float* c, const float* cp, float* dC, int ldc_, hipStream_t st) {
+    const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
+    SkinnyEpiB e{nullptr, 0, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb, c, cp, dC, ldc_};
+    hipLaunchKernelGGL((skinny_rows_kernel<true, 3, SkinnyEpiB>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 int las_skinny_gemm_bf16_tanh_bwd(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, int c0, int D,
                                   const float* h, int ldh, const float* sa, int lda_, const float* sb, int ldb, int vlast, float* gp, int ldg,
                                   unsigned short* gb, int ldgb, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
-    SkinnyEpiB e{h, ldh, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb};
+    SkinnyEpiB e{h, ldh, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb, nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL((skinny_rows_kernel<true, 2, SkinnyEpiB>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
                        reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
     LAS_LAUNCHED();

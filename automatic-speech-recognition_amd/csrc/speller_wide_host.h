@@ -122,10 +122,22 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     const size_t lds_a = (size_t)(((Hd + 3) & ~3) + 64) * sizeof(float) + 64;
     const size_t lds_e = wide_lds_bytes(d, w.fper);
     const size_t lds_q = wide_dq_lds_bytes(d, w.fper);
-    // tanh cells, speed mode: a layer's gate gradient is the EPILOGUE of the product in front of it (las_skinny_gemm_bf16_tanh_bwd) -- the top
+    // speed mode: a layer's gate gradient is the EPILOGUE of the product in front of it (las_skinny_gemm_bf16_tanh_bwd / _lstm_bwd) -- the top
     // layer's behind d s = dq . Ws^T, a lower layer's behind the product of the layer above -- so the gate launches drop out of the chain
     // (8 -> 6 dependent launches per step at two layers; the first iteration, which has no d s, keeps the top layer's launch)
-    const bool bepi = FAST && CELL == LAS_CELL_RNN && NL <= 2 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);
+    const bool bepi = FAST && NL <= 2 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);
+    // (one call for both cells: the tanh cell reads h_{l,t+1}, the LSTM cell its activated gates, c_{l,t+1}, c_{l,t} and the carried d c)
+    auto gate_epilogue = [&](const unsigned short* Aop, int lda, int K, const void* pack, int N, float* Cout, int ldc, int c0, int layer, int t,
+                             const float* sa, int lda_, const float* sb, int ldb, int vlast) -> int {
+        float* gp = d.gates + ((size_t)layer * U + t) * B * GD;
+        unsigned short* gb = layer == 0 ? d.dgbf : w.dgu;
+        if (CELL == LAS_CELL_LSTM)
+            return las_skinny_gemm_bf16_lstm_bwd(Aop, lda, B, K, pack, N, Cout, ldc, c0, D, sa, lda_, sb, ldb, vlast, gp, GD, gb, GD,
+                                                 d.cs + ((size_t)layer * (U + 1) + t + 1) * B * D, d.cs + ((size_t)layer * (U + 1) + t) * B * D,
+                                                 d.dC + (size_t)layer * B * D, D, st);
+        return las_skinny_gemm_bf16_tanh_bwd(Aop, lda, B, K, pack, N, Cout, ldc, c0, D, d.hs + ((size_t)layer * (U + 1) + t + 1) * B * D, D,
+                                             sa, lda_, sb, ldb, vlast, gp, GD, gb, GD, st);
+    };
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
@@ -142,10 +154,8 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
             if (ta > 0) {    // d s_{t+1} = dq . Ws^T: the gradient of every layer's state that entered step t + 1
                 if (bepi && t >= 0) {
                     const float* recT = TOP == 0 ? d.dXin0 + (size_t)ta * B * I0D + E + Hd : tmp + (size_t)TOP * B * 2 * D + D;
-                    GEMM_OK(las_skinny_gemm_bf16_tanh_bwd(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, TOP * D, D,
-                                                          d.hs + ((size_t)TOP * (U + 1) + t + 1) * B * D, D, dHl + (size_t)t * B * D, D,
-                                                          recT, TOP == 0 ? I0D : 2 * D, 1, d.gates + ((size_t)TOP * U + t) * B * GD, GD,
-                                                          TOP == 0 ? d.dgbf : w.dgu, GD, st));
+                    GEMM_OK(gate_epilogue(w.dqbf, A, A, wb + WL.packWsT, S, w.dS, S, TOP * D, TOP, t, dHl + (size_t)t * B * D, D,
+                                          recT, TOP == 0 ? I0D : 2 * D, 1));
                 } else if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dqbf, A, B, A, wb + WL.packWsT, S, w.dS, S, nullptr, st));
                 else GEMM_OK(las_gemm(prec, 0, 1, B, S, A, 1.f, d.dQ + (size_t)ta * B * A, A, 0, d.Ws, A, 0, 0.f, w.dS, S, 0, nullptr, LAS_ACT_NONE, 1,
                                       0, 0, nullptr, 0, st));
@@ -177,10 +187,8 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
                 if (bepi) {      // + the gate gradient of layer l - 1 (its d h: columns [0, D) of this product, + recurrent + attention shares)
                     const int lb = l - 1;
                     const float* recL = !next ? nullptr : (lb == 0 ? d.dXin0 + (size_t)ta * B * I0D + E + Hd : tmp + (size_t)lb * B * 2 * D + D);
-                    GEMM_OK(las_skinny_gemm_bf16_tanh_bwd(w.dgu, GD, B, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, 0, D,
-                                                          d.hs + ((size_t)lb * (U + 1) + t + 1) * B * D, D, recL, lb == 0 ? I0D : 2 * D,
-                                                          next ? (const float*)w.dS + (size_t)lb * D : (const float*)nullptr, S, 0,
-                                                          d.gates + ((size_t)lb * U + t) * B * GD, GD, lb == 0 ? d.dgbf : w.dgu, GD, st));
+                    GEMM_OK(gate_epilogue(w.dgu, GD, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, 0, lb, t, recL, lb == 0 ? I0D : 2 * D,
+                                          next ? (const float*)w.dS + (size_t)lb * D : (const float*)nullptr, S, 0));
                 } else if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.dgu, GD, B, GD, wb + WL.packUB[l], 2 * D, tl, 2 * D, nullptr, st));
                 else GEMM_OK(las_gemm(prec, 0, 1, B, 2 * D, GD, 1.f, dG, GD, 0, f->cellW[l], GD, 0, 0.f, tl, 2 * D, 0, nullptr, LAS_ACT_NONE, 1, 0, 0,
                                       nullptr, 0, st));
