@@ -1732,6 +1732,88 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
     }
 }
 
+// ---- the LSTM cell of the wide Speller path's forward chain as ONE launch (round 6): z = bf16(A) . packed + bias for the FOUR gate column tiles of
+// 16 hidden units (TF's kernel layout [K, i | j | f | o]: column tile g D / 16 + ut of the same las_skinny_pack fragments -- no re-packing), then the
+// gate math of wide_pointwise_fwd_kernel / wide_state_kernel: the activated gates (what the gradient loop reads), c, h in fp32 and h in bf16 into up to
+// two operand rows of the products that read it next.  Grid (D / 16, 16-row tiles); 8 waves split K exactly as skinny_rows_kernel does and the partial
+// tiles are summed in the same order, so the pre-activations are the bits of the product-then-gate-launch form.  The A slab is read once for four
+// column tiles instead of four times (run.sh sizes, B = 48: 71 MB through the CUs per product instead of 113 MB), and the gate launch is gone.
+struct SkinnyLstm { const float* bias; float fb; const float* cprev; float* c; float* h; float* gates; unsigned short* b0; int ld0; unsigned short* b1; int ld1; };
+__global__ __launch_bounds__(512, 1) void skinny_lstm_kernel(const unsigned short* __restrict__ A, int lda, int M, int K, const u16x8_t* __restrict__ Bp,
+                                                             int KS, int D, SkinnyLstm e) {
+    constexpr int NW = 8;
+    __shared__ float red[NW][4][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int ut = blockIdx.x, mt = blockIdx.y, nut = D >> 4;
+    const int KSW = (KS + NW - 1) / NW;
+    const int ks0 = w * KSW, ks1 = min(KS, ks0 + KSW);
+    int row = mt * 16 + c;
+    if (row >= M) row = M - 1;                     // padded rows compute garbage that is never stored
+    f32x4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 4;
+    const unsigned short* ap = A + (long long)row * lda + g * 8;
+    for (int ks = ks0; ks < ks1; ks += UN) {
+        u16x8_t bv[UN][4], av[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = ks + u;
+            const bool on = kk < ks1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bv[u][q] = on ? Bp[((size_t)(q * nut + ut) * KS + kk) * 64 + lane] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            const bool ka = on && (kk * 32 + g * 8 + 8 <= K);
+            av[u] = ka ? *reinterpret_cast<const u16x8_t*>(ap + kk * 32) : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma_bf16_16x16x32(av[u], bv[u][q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][q][lane][r] = acc[q][r];
+    __syncthreads();
+    if (tid < 256) {
+        const int r16 = tid >> 4, c16 = tid & 15;
+        const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
+        const int orow = mt * 16 + r16, d = ut * 16 + c16;
+        if (orow < M) {
+            float z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) v += red[ww][q][l2][reg];
+                if (e.bias) v += e.bias[q * D + d];
+                z[q] = v;
+            }
+            const float gi = sigmoid_fast(z[0]), gj = tanh_fast(z[1]);
+            const float gf = sigmoid_fast(z[2] + e.fb), go = sigmoid_fast(z[3]);
+            const float cc = e.cprev[(long long)orow * D + d] * gf + gi * gj;
+            const float h = tanh_fast(cc) * go;
+            float* gp = e.gates + (long long)orow * 4 * D;
+            gp[d] = gi; gp[D + d] = gj; gp[2 * D + d] = gf; gp[3 * D + d] = go;
+            e.c[(long long)orow * D + d] = cc;
+            e.h[(long long)orow * D + d] = h;
+            const unsigned short hb = f2bf(h);
+            if (e.b0) e.b0[(long long)orow * e.ld0 + d] = hb;
+            if (e.b1) e.b1[(long long)orow * e.ld1 + d] = hb;
+        }
+    }
+}
+// A [M, K] bf16 (lda), packed = las_skinny_pack of the TF kernel [K, 4 D]; cprev / c / h [M, D], gates [M, 4 D] (activated i | j | f | o), b0 / b1 optional
+int las_skinny_lstm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int D, const float* bias, float fb, const float* cprev,
+                         float* c, float* h, float* gates, unsigned short* b0, int ld0, unsigned short* b1, int ld1, hipStream_t st) {
+    const int KS = cdiv(K, 32), MT = cdiv(M, 16);
+    SkinnyLstm e{bias, fb, cprev, c, h, gates, b0, ld0, b1, ld1};
+    hipLaunchKernelGGL(skinny_lstm_kernel, dim3(D / 16, MT), dim3(512), 0, st, A, lda, M, K, reinterpret_cast<const u16x8_t*>(packed), KS, D, e);
+    LAS_LAUNCHED();
+    return 0;
+}
+
 int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
                     hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);

@@ -251,6 +251,8 @@ int las_skinny_gemm_bf16_tanh_bwd(const unsigned short* A, int lda, int M, int K
 int las_skinny_gemm_bf16_lstm_bwd(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, int c0, int D,
                                   const float* sa, int lda_, const float* sb, int ldb, int vlast, float* gp, int ldg, unsigned short* gb, int ldgb,
                                   const float* c, const float* cp, float* dC, int ldc_, hipStream_t st);
+int las_skinny_lstm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int D, const float* bias, float fb, const float* cprev,
+                         float* c, float* h, float* gates, unsigned short* b0, int ld0, unsigned short* b1, int ld1, hipStream_t st);
 bool las_skinny_ok(int M, int K, int N, int lda, const void* A);
 
 // ---- one LSTM cell step for a block of rows in one launch (loss_opt.hip, C entry las_lstm_cell_rows): z = [x ; h] . kernel + bias from

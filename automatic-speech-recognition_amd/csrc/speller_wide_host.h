@@ -43,13 +43,16 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
     // h = tanh(. + bias) -> the saved state, and as bf16 straight into the operand rows of the products that read it next), so the state
     // launch (after step 0) and the gate launches between the layers' products drop out of the chain: 7 -> 5 dependent launches per step
     const bool epi = FAST && CELL == LAS_CELL_RNN && !d.step_logits && NL <= 2 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);    // (the flag: every phase its own launch)
+    // LSTM cells under the same conditions: product + gate math of a layer in ONE launch (las_skinny_lstm_bf16: the four gate column tiles of 16 units
+    // per workgroup), bf16 h straight into the operand rows -- 7 -> 4 dependent launches per forward step
+    const bool lepi = FAST && CELL == LAS_CELL_LSTM && !d.step_logits && NL <= 2 && (D % 16) == 0 && !(d.flags & LAS_SPELLER_NO_FUSED_STEP);
     // energies + alignment / context as one launch with an in-kernel hand-over (wide_attend_kernel): every workgroup of the grid resident at once
     const int SP = w.nsplit > w.hsplit ? w.nsplit : w.hsplit;
     const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)SP * B <= las_device_cus();
     const size_t lds_f = lds_e > lds_c ? lds_e : lds_c;
     if (fuse) LAS_HIP(hipMemsetAsync(w.egran, 0, (size_t)B * wide_gran_row(d.Tp) * 8, st));
     for (int t = 0; t <= U; ++t) {
-        if (!epi || t == 0) WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
+        if (!(epi || lepi) || t == 0) WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
         if (t == U) break;
         if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.sbf, S, B, S, wb + WL.packWs, A, w.qbuf, A, nullptr, st));
         else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, w.sf, S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
@@ -64,6 +67,18 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
             WIDE_LAUNCH((wide_context_kernel<FAST>), dim3(w.hsplit, B), dim3(RNT), lds_c, st, d, w, t);
         }
         float* g0 = d.gates + ((size_t)0 * U + t) * B * GD;
+        if (lepi) {      // (operand rows as for the tanh epilogue below)
+            unsigned short* xu_cur = w.xu + (size_t)(t & 1) * B * 2 * D;
+            unsigned short* xu_nxt = w.xu + (size_t)((t + 1) & 1) * B * 2 * D;
+            GEMM_OK(las_skinny_lstm_bf16(d.xbf, I0D, B, I0D, packF, D, f->cellb[0], d.fb, d.cs + ((size_t)0 * (U + 1) + t) * B * D,
+                                         d.cs + ((size_t)0 * (U + 1) + t + 1) * B * D, d.hs + ((size_t)0 * (U + 1) + t + 1) * B * D, g0,
+                                         NL > 1 ? xu_cur : nullptr, 2 * D, w.sbf, S, st));
+            if (NL == 2)
+                GEMM_OK(las_skinny_lstm_bf16(xu_cur, 2 * D, B, 2 * D, wb + WL.packU[1], D, f->cellb[1], d.fb, d.cs + ((size_t)1 * (U + 1) + t) * B * D,
+                                             d.cs + ((size_t)1 * (U + 1) + t + 1) * B * D, d.hs + ((size_t)1 * (U + 1) + t + 1) * B * D,
+                                             d.gates + ((size_t)1 * U + t) * B * GD, xu_nxt + D, 2 * D, w.sbf + D, S, st));
+            continue;
+        }
         if (epi) {
             // layer 0: h_{0,t+1} -> hs[0][t+1]; bf16 into the layer above's [x ; h] row (multi-layer) and into the state row of step t+1
             // (two operand-row buffers for layer 1, alternating per step: its product reads [h_{0,t+1} ; h_{1,t}] from buffer t % 2 while its
