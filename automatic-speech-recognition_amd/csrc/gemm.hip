@@ -1619,30 +1619,36 @@ struct SkinnyEpiB { const float* h; int ldh; const float* sa; int lda; const flo
                     // receives their pre-activation gradients; c / cp: the cell state after / before the step; dC: the carried cell gradient, updated)
                     const float* c; const float* cp; float* dC; int ldc_; };
 struct SkinnyEpiNone {};
-template <bool ABF, int EPI = 0, class EpiT = SkinnyEpiNone>
+// NT (round 6): column tiles per workgroup -- 2 when one tile each would be more workgroups than the device has CUs (the LSTM-sized products of the
+// wide path: 432 workgroups of 131 + 131 KB): the A slab is read once for both tiles and the grid fits the machine in one round.  Same sums.
+template <bool ABF, int EPI = 0, class EpiT = SkinnyEpiNone, int NT = 1>
 __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restrict__ Av, int lda, int M, int K,
                                                              const u16x8_t* __restrict__ Bp, int KS, int N,
                                                              float* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                              int accumulate, EpiT ep = EpiT{}) {
     constexpr int NW = 8;
-    __shared__ float red[NW][64][4];
+    __shared__ float red[NW][NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int ct = blockIdx.x, mt = blockIdx.y;
+    const int ct0 = blockIdx.x * NT, mt = blockIdx.y, nct = (N + 15) >> 4;
     const int KSW = (KS + NW - 1) / NW;
     const int ks0 = w * KSW, ks1 = min(KS, ks0 + KSW);
-    const u16x8_t* bp = Bp + (size_t)ct * KS * 64 + lane;
+    const u16x8_t* bp = Bp + (size_t)ct0 * KS * 64 + lane;
     int row = mt * 16 + c;
     if (row >= M) row = M - 1;                     // padded rows compute garbage that is never stored
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     constexpr int UN = 8;
     for (int ks = ks0; ks < ks1; ks += UN) {
-        u16x8_t bv[UN], av[UN];
+        u16x8_t bv[UN][NT], av[UN];
         float4 a0[UN], a1[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int kk = ks + u;
             const bool on = kk < ks1;
-            bv[u] = on ? bp[(size_t)kk * 64] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                bv[u][q] = (on && ct0 + q < nct) ? bp[((size_t)q * KS + kk) * 64] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
             const bool ka = on && (kk * 32 + g * 8 + 8 <= K);
             if (ABF) {
                 const unsigned short* ap = (const unsigned short*)Av + (long long)row * lda + g * 8;
@@ -1661,20 +1667,24 @@ __global__ __launch_bounds__(512, 1) void skinny_rows_kernel(const void* __restr
                 pk.z = f2bf2(a1[u].x, a1[u].y); pk.w = f2bf2(a1[u].z, a1[u].w);
                 av[u] = __builtin_bit_cast(u16x8_t, pk);
             }
-            acc = mfma_bf16_16x16x32(av[u], bv[u], acc);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[q] = mfma_bf16_16x16x32(av[u], bv[u][q], acc[q]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][q][lane][r] = acc[q][r];
     __syncthreads();
-    if (tid < 256) {
-        const int r16 = tid >> 4, c16 = tid & 15;
+    for (int i = tid; i < 256 * NT; i += 512) {
+        const int q = i >> 8, t8 = i & 255;
+        const int r16 = t8 >> 4, c16 = t8 & 15;
         const int l2 = (r16 >> 2) * 16 + c16, reg = r16 & 3;
-        const int orow = mt * 16 + r16, col = ct * 16 + c16;
+        const int orow = mt * 16 + r16, col = (ct0 + q) * 16 + c16;
         if (orow < M && col < N) {
             float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) v += red[ww][l2][reg];
+            for (int ww = 0; ww < NW; ++ww) v += red[ww][q][l2][reg];
             if (bias) v += bias[col];
             bool done = false;
             if constexpr (EPI == 2) {
@@ -1814,6 +1824,8 @@ int las_skinny_lstm_bf16(const unsigned short* A, int lda, int M, int K, const v
     return 0;
 }
 
+static int skinny_nt(int nct, int MT) { return ((long long)nct * MT > las_device_cus() && nct >= 2) ? 2 : 1; }     // column tiles per workgroup
+
 int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc, const float* bias,
                     hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
@@ -1827,8 +1839,12 @@ int las_skinny_gemm(const float* A, int lda, int M, int K, const void* packed, i
 int las_skinny_gemm_bf16(const unsigned short* A, int lda, int M, int K, const void* packed, int N, float* C, int ldc,
                          const float* bias, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
-    hipLaunchKernelGGL(skinny_rows_kernel<true>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
-                       reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, 0);
+    if (skinny_nt(nct, MT) == 2)
+        hipLaunchKernelGGL((skinny_rows_kernel<true, 0, SkinnyEpiNone, 2>), dim3(cdiv(nct, 2), MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                           reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, 0);
+    else
+        hipLaunchKernelGGL(skinny_rows_kernel<true>, dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                           reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, bias, 0);
     LAS_LAUNCHED();
     return 0;
 }
@@ -1853,6 +1869,10 @@ int las_skinny_gemm_bf16_lstm_bwd(const unsigned short* A, int lda, int M, int K
                                   const float* c, const float* cp, float* dC, int ldc_, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     SkinnyEpiB e{nullptr, 0, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb, c, cp, dC, ldc_};
+    if (skinny_nt(nct, MT) == 2)
+        hipLaunchKernelGGL((skinny_rows_kernel<true, 3, SkinnyEpiB, 2>), dim3(cdiv(nct, 2), MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                           reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
+    else
     hipLaunchKernelGGL((skinny_rows_kernel<true, 3, SkinnyEpiB>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
                        reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
     LAS_LAUNCHED();
@@ -1864,6 +1884,10 @@ int las_skinny_gemm_bf16_tanh_bwd(const unsigned short* A, int lda, int M, int K
                                   unsigned short* gb, int ldgb, hipStream_t st) {
     const int KS = cdiv(K, 32), nct = cdiv(N, 16), MT = cdiv(M, 16);
     SkinnyEpiB e{h, ldh, sa, lda_, sb, ldb, vlast, c0, D, gp, ldg, gb, ldgb, nullptr, nullptr, nullptr, 0};
+    if (skinny_nt(nct, MT) == 2)
+        hipLaunchKernelGGL((skinny_rows_kernel<true, 2, SkinnyEpiB, 2>), dim3(cdiv(nct, 2), MT), dim3(512), 0, st, (const void*)A, lda, M, K,
+                           reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
+    else
     hipLaunchKernelGGL((skinny_rows_kernel<true, 2, SkinnyEpiB>), dim3(nct, MT), dim3(512), 0, st, (const void*)A, lda, M, K,
                        reinterpret_cast<const u16x8_t*>(packed), KS, N, C, ldc, (const float*)nullptr, 0, e);
     LAS_LAUNCHED();
