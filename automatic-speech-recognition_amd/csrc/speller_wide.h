@@ -35,10 +35,15 @@ struct WideDev {
     unsigned short* dgu;       // [B, G D]    gate gradient rows of an upper layer, bf16
     float* dS;                 // [B, S]      dq . Ws^T
     float* dWfW;               // [B, ceil(Tp / 8), C, A]  Wf-gradient partials of the after-loop keys kernel (written whole)
+    unsigned long long* bgran; // [B, wide_bgran_row(Tp)] {tag, value} granules of the fused REVERSE attention launch; tag = step + 1, zeroed per call
     unsigned long long* egran; // [B, Tp + 2 WIDE_MAX_SPLIT] {tag, value} granules of the fused attention launch (wide_attend_kernel): an utterance's
                                // energies, then its slices' (max, sum of exp); tag = step + 1, zeroed per call
 };
 __host__ __device__ __forceinline__ int wide_gran_row(int Tp) { return Tp + 2 * WIDE_MAX_SPLIT; }
+// the fused reverse attention launch (wide_attend_bwd_kernel): per utterance WIDE_MAX_SPLIT granules of the slices' alpha . d alpha, then
+// [slice][dq | du][A <= 256] partials, then the step's d f rows [Tp][16]
+constexpr int WIDE_BG_PART = WIDE_MAX_SPLIT, WIDE_BG_DF = WIDE_MAX_SPLIT + WIDE_MAX_SPLIT * 2 * 256;
+__host__ __device__ __forceinline__ int wide_bgran_row(int Tp) { return WIDE_BG_DF + Tp * 16; }
 
 // a granule another workgroup of this launch publishes: polled with a bound (las_speller_fwd_args.status reports a partner that never ran)
 // The bound: a hand-over normally completes within microseconds, a partner kept off the machine by somebody else's kernel arrives when that
@@ -515,13 +520,11 @@ __global__ __launch_bounds__(256) void wide_pointwise_fwd_kernel(DecDev a, WideD
 // ------------------------------------------------------------------------------------------------
 // (1) d alpha[t'] = dctx . enc[b, t', :] (+ what step t+1's location conv sent back) for the frames of slice s, and the slice's part of
 //     alpha . d alpha.  grid (nsplit, B).
-template <bool FAST, bool LOC>
-__global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, int t) {
-    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+template <bool FAST, bool LOC, bool FUSED>
+__device__ __forceinline__ void wide_dalpha_body(const DecDev& a, const WideDev& w, const int t, const int s, const int b, float* sm) {
     float* dctx = sm;                                  // [Hd]
     float* red = sm + ((a.Hd + 3) & ~3);               // [32]
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int B = a.B, Tp = a.Tp, Hd = a.Hd, E = a.E, U = a.U, I0D = E + Hd + a.D;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     WSTAMP(20);
@@ -586,18 +589,27 @@ __global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, i
     }
     WSTAMP(22);
     dot = block_sum<RNT>(dot, red);
-    if (tid == 0) w.stat[(size_t)b * w.nsplit + s] = dot;
+    if (tid == 0) {
+        if (FUSED) granule8_store(granule_rsrc(w.bgran), ((unsigned)b * (unsigned)wide_bgran_row(Tp) + s) * 8u, (unsigned)t + 1u, __float_as_uint(dot), false);
+        else w.stat[(size_t)b * w.nsplit + s] = dot;
+    }
     WSTAMP(23);
+}
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_dalpha_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    wide_dalpha_body<FAST, LOC, false>(a, w, t, (int)blockIdx.x, (int)blockIdx.y, sm);
 }
 
 // (2) d energy of the slice's frames (kept for the after-loop keys gradient), the energies' backward: partial dq / du over the slice, and
 //     d f[t', c] = sum_a dv[a] Wf[c, a] (kept for the conv's transpose and the filter gradient).  grid (nsplit, B).
-template <bool FAST, bool LOC, int CT = 0>
-__global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev w, int t) {
-    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+template <bool FAST, bool LOC, int CT, bool FUSED>
+__device__ __forceinline__ void wide_energy_bwd_body(const DecDev& a, const WideDev& w, const int t, const int s, const int b, float* sm) {
     const WideLds L = wide_carve(sm, a, w.fper);
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t grs = granule_rsrc(w.bgran);
+    const unsigned grow = (unsigned)b * (unsigned)wide_bgran_row(a.Tp), gtag = (unsigned)t + 1u;
     const int B = a.B, Tp = a.Tp, A = a.A, C = CT > 0 ? CT : a.C;
     const int t0 = s * w.fper, nf = (Tp - t0 < w.fper ? Tp - t0 : w.fper);
     float* dfc = L.dfc;
@@ -625,7 +637,12 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
     __syncthreads();
     WSTAMP(31);
     float dot = 0.f;
-    for (int q = 0; q < w.nsplit; ++q) dot += w.stat[(size_t)b * w.nsplit + q];
+    if (FUSED) {      // the slices' alpha . d alpha from this launch's other workgroups (every lane polls the same few granules)
+        const int budget = wide_poll_budget(a);
+        for (int q = 0; q < w.nsplit; ++q) dot += __uint_as_float(wide_poll(a, grs, (grow + q) * 8u, gtag, budget));
+    } else {
+        for (int q = 0; q < w.nsplit; ++q) dot += w.stat[(size_t)b * w.nsplit + q];
+    }
     if (nf > 0) {
         if (LOC) {
             if (havef) {
@@ -727,14 +744,24 @@ __global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev 
         float v = 0.f;
 #pragma unroll
         for (int g8 = 0; g8 < RNG; ++g8) v += src[g8 * A + col];
-        ((second ? w.pdu : w.pdq) + ((size_t)b * w.nsplit + s) * A)[col] = v;
+        if (FUSED) granule8_store(grs, (grow + WIDE_BG_PART + (s * 2 + (second ? 1 : 0)) * 256 + col) * 8u, gtag, __float_as_uint(v), false);
+        else ((second ? w.pdu : w.pdq) + ((size_t)b * w.nsplit + s) * A)[col] = v;
     }
     WSTAMP(34);
     if (LOC && nf > 0 && a.dfcSave) {
         float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + t0) * C;
-        for (int i = tid; i < nf * C; i += RNT) ds[i] = dfc[i];
+        for (int i = tid; i < nf * C; i += RNT) {
+            ds[i] = dfc[i];
+            if (FUSED) { const int fr = i / C; granule8_store(grs, (grow + WIDE_BG_DF + (t0 + fr) * 16 + (i - fr * C)) * 8u, gtag, __float_as_uint(dfc[i]), false); }
+        }
     }
     WSTAMP(35);
+}
+template <bool FAST, bool LOC, int CT = 0>
+__global__ __launch_bounds__(RNT) void wide_energy_bwd_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    wide_energy_bwd_body<FAST, LOC, CT, false>(a, w, t, (int)blockIdx.x, (int)blockIdx.y, sm);
 }
 
 // the transposed conv's tap-slice partials: part[kc, j] = sum over the taps k of slice kc, c ascending inside a tap, of rows[j - k + Kc + 1, c]
@@ -802,18 +829,24 @@ __device__ __forceinline__ void wide_convT_items(const float* rows, const float*
 // (3) dq = sum of the slices' partials (-> dQ of the step, bf16 operand row of d s = dq . Ws^T) and du (slice 0 of an utterance), and the
 //     conv's transpose d alpha_{t-1}[src] = sum_k sum_c d f[src - k + pad, c] w[k, c] for the source frames of slice s from the step's d f
 //     rows.  grid (nsplit, B)  (first version: one workgroup per utterance -- 319 x 201 x 10 multiply-adds on 48 CUs, 31.7 us per step).
-template <bool FAST, bool LOC>
-__global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
-    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+template <bool FAST, bool LOC, bool FUSED>
+__device__ __forceinline__ void wide_dq_body(const DecDev& a, const WideDev& w, const int t, const int s, const int b, float* sm) {
+    const int tid = threadIdx.x, B = a.B, Tp = a.Tp, A = a.A, C = a.C;
+    const __amdgpu_buffer_rsrc_t grs = granule_rsrc(w.bgran);
+    const unsigned grow = (unsigned)b * (unsigned)wide_bgran_row(Tp), gtag = (unsigned)t + 1u;
+    const int budget = FUSED ? wide_poll_budget(a) : 0;
     WSTAMP(40);
     if (s == 0) {
         for (int i = tid; i < A; i += RNT) {
             float dq = 0.f, du = 0.f;
             for (int q = 0; q < w.nsplit; ++q) {
-                dq += w.pdq[((size_t)b * w.nsplit + q) * A + i];
-                du += w.pdu[((size_t)b * w.nsplit + q) * A + i];
+                if (FUSED) {
+                    dq += __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_PART + (q * 2) * 256 + i) * 8u, gtag, budget));
+                    du += __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_PART + (q * 2 + 1) * 256 + i) * 8u, gtag, budget));
+                } else {
+                    dq += w.pdq[((size_t)b * w.nsplit + q) * A + i];
+                    du += w.pdu[((size_t)b * w.nsplit + q) * A + i];
+                }
             }
             a.dQ[((size_t)t * B + b) * A + i] = dq;
             if (FAST) w.dqbf[(size_t)b * A + i] = f2bf(dq);
@@ -834,7 +867,8 @@ __global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t
         const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
         for (int i = tid; i < nrows * C; i += RNT) {
             const int rho = i / C, fr = t0 + rho - (Kc + 1) + pad;
-            rows[i] = (fr >= 0 && fr < Tp) ? ds[(size_t)fr * C + (i - rho * C)] : 0.f;
+            if (FUSED) rows[i] = (fr >= 0 && fr < Tp) ? __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_DF + fr * 16 + (i - rho * C)) * 8u, gtag, budget)) : 0.f;
+            else rows[i] = (fr >= 0 && fr < Tp) ? ds[(size_t)fr * C + (i - rho * C)] : 0.f;
         }
         for (int i = tid; i < Kc * C; i += RNT) locw[i] = a.loc_w[i];
         __syncthreads();
@@ -854,6 +888,29 @@ __global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t
         WSTAMP(44);
     }
 }
+template <bool FAST, bool LOC>
+__global__ __launch_bounds__(RNT) void wide_dq_kernel(DecDev a, WideDev w, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    wide_dq_body<FAST, LOC, false>(a, w, t, (int)blockIdx.x, (int)blockIdx.y, sm);
+}
+
+// (1) + (2) + (3) as ONE launch (the reverse counterpart of wide_attend_kernel): workgroup (s, b) computes d alpha of frame slice s and publishes the
+// slice's alpha . d alpha; collects the utterance's sum from its peers; d energy, dq / du partials and d f of the slice -- published as granules
+// (d f also stored plainly: the after-loop filter gradient reads it); then slice 0 sums the partials and every slice does its part of the conv's
+// transpose from its neighbours' d f rows.  Two hand-overs through memory instead of two kernel boundaries; same operands, same order.
+template <bool FAST, bool LOC, int CT = 0>
+__global__ __launch_bounds__(RNT) void wide_attend_bwd_kernel(DecDev a, WideDev w, int t) {
+    kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int s = blockIdx.x, b = blockIdx.y;
+    wide_dalpha_body<FAST, LOC, true>(a, w, t, s, b, sm);
+    __syncthreads();                                    // (the d alpha values of the slice travel through w.ebuf: stored above, read below by other lanes)
+    wide_energy_bwd_body<FAST, LOC, CT, true>(a, w, t, s, b, sm);
+    __syncthreads();
+    if (s == 0 || (LOC && t > 0)) wide_dq_body<FAST, LOC, true>(a, w, t, s, b, sm);
+}
+
 static size_t wide_dq_lds_bytes(const DecDev& a, int fper) {
     if (a.mode != LAS_ATT_LOC) return 64;
     auto u4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
@@ -985,7 +1042,7 @@ __global__ __launch_bounds__(256) void wide_dkeys_kernel(DecDev a, WideDev w, fl
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct WideWs { size_t packWs, packWsT, packU[LAS_MAX_NL], packUB[LAS_MAX_NL], srow, xu, dqbf, dgu, qbuf, ebuf, stat, pdq, pdu, dS, dWfW, egran, total; };
+struct WideWs { size_t packWs, packWsT, packU[LAS_MAX_NL], packUB[LAS_MAX_NL], srow, xu, dqbf, dgu, qbuf, ebuf, stat, pdq, pdu, dS, dWfW, egran, bgran, total; };
 static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
     WideWs w; size_t o = 0;
     const size_t S = (size_t)D * NL, GD = (size_t)G * D;
@@ -1007,6 +1064,7 @@ static WideWs wide_layout(int B, int Tp, int A, int D, int NL, int G, int C) {
     w.dS = o;    o += align256((size_t)B * S * 4);
     w.dWfW = o;  o += align256(C > 0 ? (size_t)B * cdiv(Tp, 8) * C * A * 4 : 0);
     w.egran = o; o += align256((size_t)B * wide_gran_row(Tp) * 8);
+    w.bgran = o; o += align256((size_t)B * wide_bgran_row(Tp) * 8);
     w.total = o;
     return w;
 }
@@ -1037,7 +1095,7 @@ static void wide_fill(const DecDev& d, WideDev& w, char* base, const WideWs& L) 
     w.pdq = (float*)(base + L.pdq); w.pdu = (float*)(base + L.pdu);
     w.sbf = (unsigned short*)(base + L.srow); w.sf = (float*)(base + L.srow);
     w.xu = (unsigned short*)(base + L.xu); w.dqbf = (unsigned short*)(base + L.dqbf); w.dgu = (unsigned short*)(base + L.dgu);
-    w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW); w.egran = (unsigned long long*)(base + L.egran);
+    w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW); w.egran = (unsigned long long*)(base + L.egran); w.bgran = (unsigned long long*)(base + L.bgran);
 }
 template <class K> static int wide_lds_attr(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;

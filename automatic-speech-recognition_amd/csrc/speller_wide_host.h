@@ -153,10 +153,18 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
         return las_skinny_gemm_bf16_tanh_bwd(Aop, lda, B, K, pack, N, Cout, ldc, c0, D, d.hs + ((size_t)layer * (U + 1) + t + 1) * B * D, D,
                                              sa, lda_, sb, ldb, vlast, gp, GD, gb, GD, st);
     };
+    // d alpha -> d energy -> dq as ONE launch with two in-kernel hand-overs (wide_attend_bwd_kernel), under the conditions of the forward one
+    const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)w.nsplit * B <= las_device_cus();
+    const size_t lds_f = lds_a > lds_e ? (lds_a > lds_q ? lds_a : lds_q) : (lds_e > lds_q ? lds_e : lds_q);
+    if (fuse) LAS_HIP(hipMemsetAsync(w.bgran, 0, (size_t)B * wide_bgran_row(Tp) * 8, st));
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
-            if (loc) {
+            if (fuse) {
+                if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
+                else if (loc) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
+                else          WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
+            } else if (loc) {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
                 if (d.C == 10) WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
                 else           WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
