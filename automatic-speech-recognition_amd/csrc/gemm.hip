@@ -43,13 +43,27 @@ __device__ __forceinline__ void tile_gload(TileRegs<ROWS, NT>& r, const float* _
                                            int mperiod, int mskip) {
     constexpr int NCH = ROWS * 8;
     constexpr int RQ = ROWS / 4;
-    (void)vec;
+    // `vec` (16-byte loads legal: base, leading dimension and batch stride multiples of 4 floats) with an extent that is a multiple of 4: a chunk is
+    // whole or empty, ONE 16-byte load from a clamped address (the per-element form had replaced the float4 path for every caller)
+    const bool v4k = vec && (Kend & 3) == 0 && (k0 & 3) == 0, v4r = vec && (R & 3) == 0 && (row0 & 3) == 0;
 #pragma unroll
     for (int i = 0; i < (NCH + NT - 1) / NT; ++i) {
         const int c = threadIdx.x + i * NT;
         const bool live = (NCH % NT == 0) || c < NCH;
         float e[4];
-        if (ks == 1) {  // contraction index contiguous in memory
+        if (ks == 1 && v4k) {
+            const int row = c >> 3, kq = (c & 7) * 4;
+            const int gr = row0 + row, gk = k0 + kq;
+            const bool on = live && gr < R && gk < Kend;
+            const float4 q = *reinterpret_cast<const float4*>(X + (long long)(on ? gr : 0) * rs + (on ? gk : 0));
+            e[0] = on ? q.x : 0.f; e[1] = on ? q.y : 0.f; e[2] = on ? q.z : 0.f; e[3] = on ? q.w : 0.f;
+        } else if (ks != 1 && v4r) {
+            const int k = c / RQ, rq = (c % RQ) * 4;
+            const int gr = row0 + rq, gk = k0 + k;
+            const bool on = live && gk < Kend && !(mperiod > 0 && (gk % mperiod) == mskip) && gr < R;
+            const float4 q = *reinterpret_cast<const float4*>(X + (long long)(on ? gk : 0) * ks + (on ? gr : 0));
+            e[0] = on ? q.x : 0.f; e[1] = on ? q.y : 0.f; e[2] = on ? q.z : 0.f; e[3] = on ? q.w : 0.f;
+        } else if (ks == 1) {  // contraction index contiguous in memory
             const int row = c >> 3, kq = (c & 7) * 4;
             const int gr = row0 + row, gk = k0 + kq;
             const float* p = X + (long long)(gr < R ? gr : 0) * rs;
