@@ -25,7 +25,9 @@ def test_eight_ranks_enqueue_a_step_in_less_than_half_its_device_time(tmp_path):
     queues alive the device time-slices them.  Round 4, 60 runs of the tool on the pool's boxes: on most boxes every run completes, on
     some a run in three ends with an exchange time-out in a sweep or a Speller loop (also in kernels round 4 did not touch; at times it looked tied
     to a kernel variant -- see DESIGN section 5 -- but every variant has failed on some box).  A time-out is reported by the status word,
-    nothing hangs; the attempt is repeated (at most five), and the test fails if none completes or the host numbers miss their bars."""
+    nothing hangs; the attempt is repeated (at most five), and the test fails if none completes or the host numbers miss their bars.
+    (The tool runs with the step recovery off: a recovery waits for the device, i.e. for the tool's closed gate, and the 30 s watchdog would be
+    reported as a host time -- round 6, seen in this suite on some boxes: rc = 0, max 30,275 ms.)"""
     out = str(tmp_path / "ranks.json")
     attempts = []
     path = os.environ.get("LAS_PARITY_LOG")
@@ -58,4 +60,4 @@ def test_eight_ranks_enqueue_a_step_in_less_than_half_its_device_time(tmp_path):
     assert rec["host_enqueue_ms"]["median"] < 0.6 * 14.8, rec
     # a hidden host synchronisation would show as the 30 s watchdog; a single step of one rank at 29 ms has been seen (round 5, eight
     # launch threads and the profiler's leftovers on 16 cores) and is scheduling noise, not a synchronisation: the bar is 1 s
-    assert rec["host_enqueue_ms"]["max"] < 1000.0, rec
+    assert rec["host_enqueue_ms"]["max"] < 1000.0, (rec, r.stderr[-6000:])      # (the tool dumps the launch threads' stacks after 10 s in one call: faulthandler)

@@ -18,6 +18,7 @@ A watchdog opens a gate that is still closed after 30 s, so a hidden host synchr
 """
 import argparse
 import ctypes
+import faulthandler
 import json
 import os
 import sys
@@ -44,6 +45,11 @@ def worker(rank, world, port, steps, B, T, out_path):
     # hand-over runs producers-first here ("force": the same kernel instances and the same number of launches -- the host cost that
     # is measured -- without cross-queue spin waits)
     os.environ["LAS_ALLOW_SERIAL_STREAMS"] = "force"
+    # Round 6: LAS.train RE-RUNS a step that lost its co-residency (LAS._recover) -- and the recovery waits for the device, i.e. for the closed gate:
+    # what this tool would then report is its own 30 s watchdog as a "host enqueue time" (seen inside the suite, where the pytest process is a
+    # ninth set of queues: rc = 0, max 30,275 ms).  Off here: a time-out ends the attempt with the documented error, as until round 5, and the
+    # caller repeats it.
+    os.environ["LAS_NO_STEP_RECOVERY"] = "1"
     from bench import bench_args, usable_cores
     from helpers import synthetic_batch
     from las import _hip, layers as L, variables as V
@@ -92,7 +98,9 @@ def worker(rank, world, port, steps, B, T, out_path):
         dog = threading.Timer(30.0, open_gate, args=(step,))
         dog.start()
         t0 = time.perf_counter()
+        faulthandler.dump_traceback_later(10.0, exit=False)        # a launch thread that blocks behind the closed gate says WHERE (stderr)
         las.train(xs, ys)                                          # all ranks at once: this is the host cost under contention
+        faulthandler.cancel_dump_traceback_later()
         host_ms.append((time.perf_counter() - t0) * 1e3)
         dist.barrier()
         for r in range(world):
