@@ -127,6 +127,13 @@ __device__ __forceinline__ int block_argmax(float v, int i, float* redv, int* re
 // Small vocabularies (char units: V = 30) left 994 of the 1024 threads idle behind 30 threads x D serial multiply-adds (~10 us per
 // decode step, every step of a beam search): now the largest power of two TPV <= min(RNT / V, 64) lanes share one logit (each sums
 // D / TPV terms, then a TPV-lane butterfly).  Large vocabularies (subword units, V = 5000) keep one thread per logit.
+// step_logits = 1: the logits of step t-1 are computed in the loop at every step (greedy inference; a search step).  2 (round 6, training with
+// scheduled sampling): only where the token ENTERING step t is resolved on the device (tokens_in < 0) -- 9.7 us on the dependent chain of a step
+// that a teacher-forced step does not need; the logits of ALL steps (the loss's) then come from the batched product behind the loop, as without
+// sampling, and tokens_out holds the greedy token of the sampled steps only.
+__device__ __forceinline__ bool logits_here(const DecDev& a, const int t, const int tok_raw) {
+    return a.step_logits == 1 || (a.step_logits == 2 && t < a.U && tok_raw < 0);
+}
 template <bool FAST>
 __device__ __forceinline__ void row_logits(const DecDev& a, const float* __restrict__ h, const int t, const int b, const int tid,
                                            float* red, int* redi, int& greedy_tok, int& sample_tok) {
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_kernel(DecDev a, int t) {
             L.hl[d] = h;
         }
         __syncthreads();
-        if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+        if (logits_here(a, t, t < U ? a.tok_in[(size_t)t * B + b] : 0)) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
             row_logits<FAST>(a, L.hl, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(RNT) void dec_step_fwd_bf_kernel(DecDev a, int t) {
             L.hl[d] = h;
         }
         __syncthreads();
-        if (a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+        if (logits_here(a, t, t < U ? a.tok_in[(size_t)t * B + b] : 0)) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
             row_logits<FAST>(a, L.hl, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
@@ -1116,7 +1123,7 @@ __device__ __forceinline__ void pf_fwd_row(const DecDev& a, const int t, const i
             if (!(tid & 1)) sp[tid >> 1] = f2bf2(h, (tid + 1 < D) ? hn : 0.f);
         }
         lds_barrier();
-        if (t > 0 && a.step_logits) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
+        if (t > 0 && logits_here(a, t, tok)) {  // vocab projection + argmax (+ Gumbel sample) of step t-1
             row_logits<FAST>(a, L.s_state, t, b, tid, L.red, L.redi, greedy_tok, sample_tok);
         }
     }
@@ -3449,7 +3456,7 @@ static int speller_fwd_impl(const las_speller_fwd_args* f, DecDev d, hipStream_t
                              f->cellW[l] + (size_t)D * GD, GD, 0, 1.f, gl, GD, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
         }
     }
-    if (!d.step_logits) {  // vocab projection of all steps at once (dense MFMA work): las/las.py:156-158
+    if (d.step_logits != 1) {  // vocab projection of all steps at once (dense MFMA work): las/las.py:156-158
         GEMM_OK(las_gemm(f->prec, 0, 0, U * B, V, D, 1.f, d.hs + ((size_t)(NL - 1) * (U + 1) + 1) * B * D, D, 0, d.Wv, V, 0,
                          0.f, d.logits, V, 0, d.bv, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
     }

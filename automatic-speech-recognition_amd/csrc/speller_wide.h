@@ -105,7 +105,7 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
             hl[d] = h;
         }
         __syncthreads();
-        if (a.step_logits) row_logits<FAST>(a, hl, t, b, tid, red, redi, greedy_tok, sample_tok);
+        if (logits_here(a, t, t < U ? a.tok_in[(size_t)t * B + b] : 0)) row_logits<FAST>(a, hl, t, b, tid, red, redi, greedy_tok, sample_tok);
     }
     if (t >= U) return;
     int tok = a.tok_in[(size_t)t * B + b];

@@ -348,7 +348,9 @@ class Speller:
                         tokens_in[idx] = -2
             # in-loop logits / draws are needed exactly when some step samples ON THE DEVICE (token -2): known on the host,
             # no read-back (a `.item()` here would make every scheduled-sampling step wait for the whole previous step)
-            step_logits = bool(U > 1 and not coins[:U - 1].all() and sampled is None)
+            # (2: only at the steps that sample -- a teacher-forced step keeps the projection, two arg-max and the draws off its chain; the loss's
+            #  logits come from the batched product behind the loop, as without sampling: las_hip.h)
+            step_logits = 2 if (U > 1 and not coins[:U - 1].all() and sampled is None) else False
         emb_mask = None
         if is_training and a.dropout_rate:
             # tf.layers.dropout on the embedded input token of every step (las/las.py:107-108); step 0's SOS

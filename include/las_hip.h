@@ -288,9 +288,11 @@ int las_rnn_seq_bwd_db_chunked(int cell, int prec, int B, int T, int H, void* ga
  *   teacher[:,t-1]).  -1 = greedy argmax of step t-1 (inference, las/las.py:111); -2 = a sample
  *   from Categorical(logits of step t-1) (scheduled sampling, las/las.py:101-105,170-175; Gumbel
  *   arg-max driven by `seed`).  Resolved tokens are written back in place.  Any negative entry
- *   requires step_logits=1.
+ *   requires step_logits=1 or 2.
  * Time-major internal results (the Python boundary returns [B,U,.] views):
  *   logits [U,B,V]   alphas [U,B,Tp]   tokens_out int32 [U,B] (argmax per step; step_logits=1 only)
+ *   step_logits=2 (training with scheduled sampling): in-loop logits + draws only at the steps whose entering token is device-resolved
+ *   (tokens_in < 0), every step's logits from the batched product behind the loop; tokens_out is written at those steps only.
  * Saved for backward (caller-allocated):
  *   hs  [NL,U+1,B,D]  h states (slot 0 = initial state: zeroed by the call, or supplied by the
  *       caller when keep_state0=1 -- single-step use by beam search)   cs [NL,U+1,B,D] (lstm)
