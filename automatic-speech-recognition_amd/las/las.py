@@ -258,6 +258,7 @@ class Speller:
                                    kernel_size=self.args.loc_kernel_size, num_channels=self.args.loc_num_channels,
                                    mode=self.args.mode)
         self.last_tokens_out = None
+        self.logits_every_step = False     # (tests: step_logits = 1 in training too -- the form before round 6's step_logits = 2)
         self.rank = 0              # data-parallel rank: per-rank sampling noise (set by LAS.train from las.dp)
 
     # -- variables ---------------------------------------------------------------------------------
@@ -350,7 +351,7 @@ class Speller:
             # no read-back (a `.item()` here would make every scheduled-sampling step wait for the whole previous step)
             # (2: only at the steps that sample -- a teacher-forced step keeps the projection, two arg-max and the draws off its chain; the loss's
             #  logits come from the batched product behind the loop, as without sampling: las_hip.h)
-            step_logits = 2 if (U > 1 and not coins[:U - 1].all() and sampled is None) else False
+            step_logits = (1 if self.logits_every_step else 2) if (U > 1 and not coins[:U - 1].all() and sampled is None) else False
         emb_mask = None
         if is_training and a.dropout_rate:
             # tf.layers.dropout on the embedded input token of every step (las/las.py:107-108); step 0's SOS

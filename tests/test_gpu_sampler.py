@@ -136,6 +136,45 @@ def test_on_device_sampling_step_matches_oracle_given_the_draws(prec, NL, flags)
         _hip.speller_flags = 0
 
 
+@pytest.mark.parametrize("prec,NL,flags", [("f32", 1, 0), ("bf16", 1, 0), ("bf16", 2, 0), ("bf16", 1, 4)])
+def test_logits_only_at_the_sampled_steps_draw_the_same_tokens_as_logits_at_every_step(prec, NL, flags):
+    """step_logits = 2 (round 6: in-loop logits and draws only where the entering token is device-resolved, the loss's logits from the batched
+    product behind the loop) against step_logits = 1 (in the loop at every step): the SAME tokens are drawn -- the draw sees the same in-loop
+    values -- the alignments are the same bits, and logits / gradients agree to the summation order of the projection."""
+    from las import _hip, variables as Vs
+    B, Tp, U, V = 5, 37, 12, 30
+    res = []
+    for every in (True, False):
+        sp, args = _speller(prec, D=64, A=32, H=32, NL=NL, V=V, flags=flags)
+        try:
+            sp.logits_every_step = every
+            st = Vs.default_store()
+            rng = np.random.RandomState(2)
+            enc = torch.tensor((rng.randn(B, Tp, 64) * 0.5).astype(np.float32), device="cuda", requires_grad=True)
+            enc_len = rng.randint(Tp // 2, Tp + 1, size=B)
+            y = rng.randint(3, V, size=(B, U))
+            coins = rng.rand(U) < 0.6
+            coins[0], coins[3] = False, True
+            w = torch.tensor(rng.randn(B, U, V).astype(np.float32))
+            logits, _, alphas = sp(enc, enc_len, U, teacher=y, is_training=True, coins=coins)
+            (logits * w.cuda()).sum().backward()
+            _hip.join_side_stream()
+            torch.cuda.synchronize()
+            _hip.check_status()
+            res.append((sp.last_tokens_in.cpu().clone(), logits.detach().cpu(), alphas.detach().cpu(), enc.grad.cpu().clone(),
+                        {n: st.vars[n].grad.detach().cpu().clone() for n in st.order}))
+        finally:
+            _hip.speller_flags = 0
+    (tok1, l1, a1, g1, p1), (tok2, l2, a2, g2, p2) = res
+    assert (tok1 >= 0).all() and torch.equal(tok1, tok2)
+    assert torch.equal(a1, a2)
+    tol = 1e-5 if prec == "f32" else 1e-3
+    assert (l1 - l2).abs().max().item() < tol * max(1.0, l1.abs().max().item())
+    assert (g1 - g2).abs().max().item() <= tol * max(g1.abs().max().item(), 1e-3)
+    for n in p1:
+        assert (p1[n] - p2[n]).abs().max().item() <= tol * max(p1[n].abs().max().item(), 1e-3), n
+
+
 @pytest.mark.parametrize("prec,flags", [("f32", 0), ("bf16", 0), ("bf16", 1)])
 def test_variational_noise_on_the_embedding_matrix(prec, flags):
     """--add_vn (reference las/las.py:164-166): every look-up adds a fresh N(0, 0.075) matrix to the WHOLE embedding matrix.
