@@ -26,6 +26,30 @@ int las_device_cus() {
     return cus;
 }
 
+// Are the workgroups of a 1-D grid dealt to the XCDs round-robin by their id (id % 8 = XCD: SPX mode on an eight-XCD part)?  Probed once per process:
+// 64 workgroups report their XCC_ID.  Kernels that keep a group of workgroups on one XCD by their ids use this to choose XCD-scope hand-overs
+// (served by that XCD's L2) over device-scope ones (write-through; correct anywhere).
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu);       // HW_REG_XCC_ID[3:0]
+}
+int las_xcd_round_robin() {
+    static int ok = [] {
+        int* d = nullptr;
+        int h[64];
+        if (hipMalloc(&d, sizeof(h)) != hipSuccess) return 0;
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, 0, d);
+        const bool got = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        if (!got) return 0;
+        for (int j = 0; j < 64; ++j) if (h[j] != h[j & 7]) return 0;
+        for (int a = 0; a < 8; ++a) for (int b = a + 1; b < 8; ++b) if (h[a] == h[b]) return 0;
+        return 1;
+    }();
+    return ok;
+}
+
+extern "C" int las_dev_xcd_round_robin() { return las_xcd_round_robin(); }     // (diagnostics: tools/probe_wide_stamps.py prints it)
+
 // Stream-ordered wait on a device word (bounded): everything enqueued behind it on `stream` starts only once *word == value
 // or max_us microseconds have passed.  A scheduling aid, never a correctness dependency: the host uses it to keep the
 // weight-gradient GEMMs of the side stream off the machine until the next recurrent sweep (LAS_SEQ_ANNOUNCE) is resident.

@@ -14,6 +14,7 @@
 // ---- error reporting (thread-local message, negative return codes) ----------------------------
 void las_set_error(const char* fmt, ...);
 int las_device_cus();   // compute units of the current device (cached)
+int las_xcd_round_robin();   // 1: workgroup id % 8 = XCD for 1-D grids on this device (probed once)
 
 #define LAS_ARG(cond, ...)                                   \
     do { if (!(cond)) { las_set_error(__VA_ARGS__); return -1; } } while (0)

@@ -33,13 +33,15 @@ struct WideDev {
     float* ebuf;               // [B, Tp]     energies (forward) / d alpha (backward)
     float* stat;               // [B, nsplit, 2] softmax statistics (forward); [B, nsplit] partial alpha . d alpha (backward)
     float *pdq, *pdu;          // [B, nsplit, A] partial dq / du of the frame slices
-    unsigned short* sbf;       // [B, S]      state rows, bf16 (speed mode: A operand of the query product)
-    float* sf;                 // [B, S]      ... fp32 (parity mode)
+    unsigned short* sbf;       // [B, S]      state rows: bf16 (speed mode: A operand of the query product) -- or fp32 in the same buffer (parity mode)
     unsigned short* xu;        // [B, 2D]     [h_{l-1, t+1} ; h_{l, t}] bf16: A operand of an upper layer's cell product
     unsigned short* dqbf;      // [B, A]
     unsigned short* dgu;       // [B, G D]    gate gradient rows of an upper layer, bf16
     float* dS;                 // [B, S]      dq . Ws^T
     float* dWfW;               // [B, ceil(Tp / 8), C, A]  Wf-gradient partials of the after-loop keys kernel (written whole)
+    int xcd_local;             // 1: the fused attention launches are 1-D grids that keep an utterance's slices on ONE XCD (workgroup j: XCD x = j % 8, k = j / 8,
+                               //    utterance (k / SP) 8 + x, slice k % SP) and hand over at XCD scope (sc0 stores into that XCD's L2); 0: (slice, utterance) grids, device scope
+    int sp;                    // slices per utterance of the fused launches (max(nsplit, hsplit) forward, nsplit reverse: set per launch)
     unsigned long long* bgran; // [B, wide_bgran_row(Tp)] {tag, value} granules of the fused REVERSE attention launch; tag = step + 1, zeroed per call
     unsigned long long* egran; // [B, Tp + 2 WIDE_MAX_SPLIT] {tag, value} granules of the fused attention launch (wide_attend_kernel): an utterance's
                                // energies, then its slices' (max, sum of exp); tag = step + 1, zeroed per call
@@ -50,6 +52,14 @@ __host__ __device__ __forceinline__ int wide_gran_row(int Tp) { return Tp + 2 * 
 constexpr int WIDE_BG_PART = WIDE_MAX_SPLIT, WIDE_BG_DF = WIDE_MAX_SPLIT + WIDE_MAX_SPLIT * 2 * 256;
 __host__ __device__ __forceinline__ int wide_bgran_row(int Tp) { return WIDE_BG_DF + Tp * 16; }
 
+// (slice, utterance) of a fused attention workgroup: from the 2-D grid, or from the XCD-local 1-D grid (see WideDev.xcd_local); b < 0: nothing to do
+__device__ __forceinline__ void wide_slice_of(const WideDev& w, const int B, int& s, int& b) {
+    if (!w.xcd_local) { s = blockIdx.x; b = blockIdx.y; return; }
+    const int j = blockIdx.x, x = j & 7, k = j >> 3;
+    s = k % w.sp;
+    b = (k / w.sp) * 8 + x;
+    if (b >= B) b = -1;
+}
 // a granule another workgroup of this launch publishes: polled with a bound (las_speller_fwd_args.status reports a partner that never ran)
 // The bound: a hand-over normally completes within microseconds, a partner kept off the machine by somebody else's kernel arrives when that
 // kernel ends -- 2^15 rounds (~50 ms) cover the latter; and once the call's status word is set (an earlier launch of this call gave up: the
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(RNT) void wide_state_kernel(DecDev a, WideDev w, in
         const int l = i / D, d = i - l * D;
         const float v = (l == TOP && t > 0) ? hl[d] : a.hs[(((size_t)l * (U + 1) + t) * B + b) * D + d];
         if (FAST) w.sbf[(size_t)b * S + i] = f2bf(v);
-        else w.sf[(size_t)b * S + i] = v;
+        else reinterpret_cast<float*>(w.sbf)[(size_t)b * S + i] = v;
         // step 0 of the tanh-epilogue chain (speller_wide_host.h): the upper layers' recurrent halves [. ; h_{l,0}] of their first operand rows
         if (FAST && t == 0 && l >= 1 && l == 1) w.xu[(size_t)b * 2 * D + D + d] = f2bf(v);
     }
@@ -256,8 +266,8 @@ __device__ __forceinline__ void wide_energy_body(const DecDev& a, const WideDev&
     if (nf <= 0) {
         if (tid == 0) {
             if (FUSED) {
-                granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(-INFINITY), false);
-                granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(0.f), false);
+                granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(-INFINITY), w.xcd_local != 0);
+                granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(0.f), w.xcd_local != 0);
             } else { w.stat[((size_t)b * w.nsplit + s) * 2] = -INFINITY; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = 0.f; }
         }
         return;
@@ -320,7 +330,7 @@ __device__ __forceinline__ void wide_energy_body(const DecDev& a, const WideDev&
             if (sl == 0) {
                 const float em = (tt < len) ? e : -1e8f;           // replace-mask, las/layers.py:205-207
                 L.ev[fr] = em;
-                if (FUSED) granule8_store(grs, (grow + tt) * 8u, gtag, __float_as_uint(em), false);
+                if (FUSED) granule8_store(grs, (grow + tt) * 8u, gtag, __float_as_uint(em), w.xcd_local != 0);
                 else w.ebuf[(size_t)b * Tp + tt] = em;
             }
         }
@@ -335,8 +345,8 @@ __device__ __forceinline__ void wide_energy_body(const DecDev& a, const WideDev&
     ssum = block_sum<RNT>(ssum, L.red);
     if (tid == 0) {
         if (FUSED) {
-            granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(m), false);
-            granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(ssum), false);
+            granule8_store(grs, (grow + Tp + 2 * s) * 8u, gtag, __float_as_uint(m), w.xcd_local != 0);
+            granule8_store(grs, (grow + Tp + 2 * s + 1) * 8u, gtag, __float_as_uint(ssum), w.xcd_local != 0);
         } else { w.stat[((size_t)b * w.nsplit + s) * 2] = m; w.stat[((size_t)b * w.nsplit + s) * 2 + 1] = ssum; }
     }
     WSTAMP(5);
@@ -483,7 +493,9 @@ template <bool FAST, bool LOC, int CT = 0>
 __global__ __launch_bounds__(RNT) void wide_attend_kernel(DecDev a, WideDev w, int t) {
     kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int s = blockIdx.x, b = blockIdx.y;
+    int s, b;
+    wide_slice_of(w, a.B, s, b);
+    if (b < 0) return;
     if (s < w.nsplit) wide_energy_body<FAST, LOC, CT, true>(a, w, t, s, b, sm);
     __syncthreads();                                    // (the context phase re-uses the energies' LDS)
     if (s < w.hsplit) wide_context_body<FAST, true>(a, w, t, s, b, sm);
@@ -595,7 +607,7 @@ __device__ __forceinline__ void wide_dalpha_body(const DecDev& a, const WideDev&
     WSTAMP(22);
     dot = block_sum<RNT>(dot, red);
     if (tid == 0) {
-        if (FUSED) granule8_store(granule_rsrc(w.bgran), ((unsigned)b * (unsigned)wide_bgran_row(Tp) + s) * 8u, (unsigned)t + 1u, __float_as_uint(dot), false);
+        if (FUSED) granule8_store(granule_rsrc(w.bgran), ((unsigned)b * (unsigned)wide_bgran_row(Tp) + s) * 8u, (unsigned)t + 1u, __float_as_uint(dot), w.xcd_local != 0);
         else w.stat[(size_t)b * w.nsplit + s] = dot;
     }
     WSTAMP(23);
@@ -749,7 +761,7 @@ __device__ __forceinline__ void wide_energy_bwd_body(const DecDev& a, const Wide
         float v = 0.f;
 #pragma unroll
         for (int g8 = 0; g8 < RNG; ++g8) v += src[g8 * A + col];
-        if (FUSED) granule8_store(grs, (grow + WIDE_BG_PART + (s * 2 + (second ? 1 : 0)) * 256 + col) * 8u, gtag, __float_as_uint(v), false);
+        if (FUSED) granule8_store(grs, (grow + WIDE_BG_PART + (s * 2 + (second ? 1 : 0)) * 256 + col) * 8u, gtag, __float_as_uint(v), w.xcd_local != 0);
         else ((second ? w.pdu : w.pdq) + ((size_t)b * w.nsplit + s) * A)[col] = v;
     }
     WSTAMP(34);
@@ -757,7 +769,7 @@ __device__ __forceinline__ void wide_energy_bwd_body(const DecDev& a, const Wide
         float* ds = a.dfcSave + (((size_t)t * B + b) * Tp + t0) * C;
         for (int i = tid; i < nf * C; i += RNT) {
             ds[i] = dfc[i];
-            if (FUSED) { const int fr = i / C; granule8_store(grs, (grow + WIDE_BG_DF + (t0 + fr) * 16 + (i - fr * C)) * 8u, gtag, __float_as_uint(dfc[i]), false); }
+            if (FUSED) { const int fr = i / C; granule8_store(grs, (grow + WIDE_BG_DF + (t0 + fr) * 16 + (i - fr * C)) * 8u, gtag, __float_as_uint(dfc[i]), w.xcd_local != 0); }
         }
     }
     WSTAMP(35);
@@ -908,7 +920,9 @@ template <bool FAST, bool LOC, int CT = 0>
 __global__ __launch_bounds__(RNT) void wide_attend_bwd_kernel(DecDev a, WideDev w, int t) {
     kernarg_warm<(int)(sizeof(DecDev) + sizeof(WideDev))>();
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int s = blockIdx.x, b = blockIdx.y;
+    int s, b;
+    wide_slice_of(w, a.B, s, b);
+    if (b < 0) return;
     wide_dalpha_body<FAST, LOC, true>(a, w, t, s, b, sm);
     __syncthreads();                                    // (the d alpha values of the slice travel through w.ebuf: stored above, read below by other lanes)
     wide_energy_bwd_body<FAST, LOC, CT, true>(a, w, t, s, b, sm);
@@ -1096,9 +1110,10 @@ static void wide_split(const DecDev& d, WideDev& w) {
 }
 static void wide_fill(const DecDev& d, WideDev& w, char* base, const WideWs& L) {
     wide_split(d, w);
+    w.xcd_local = 0; w.sp = 0;
     w.qbuf = (float*)(base + L.qbuf); w.ebuf = (float*)(base + L.ebuf); w.stat = (float*)(base + L.stat);
     w.pdq = (float*)(base + L.pdq); w.pdu = (float*)(base + L.pdu);
-    w.sbf = (unsigned short*)(base + L.srow); w.sf = (float*)(base + L.srow);
+    w.sbf = (unsigned short*)(base + L.srow);
     w.xu = (unsigned short*)(base + L.xu); w.dqbf = (unsigned short*)(base + L.dqbf); w.dgu = (unsigned short*)(base + L.dgu);
     w.dS = (float*)(base + L.dS); w.dWfW = (float*)(base + L.dWfW); w.egran = (unsigned long long*)(base + L.egran); w.bgran = (unsigned long long*)(base + L.bgran);
 }

@@ -51,15 +51,20 @@ static int wide_fwd_steps(const las_speller_fwd_args* f, DecDev& d, const BwdWs&
     const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)SP * B <= las_device_cus();
     const size_t lds_f = lds_e > lds_c ? lds_e : lds_c;
     if (fuse) LAS_HIP(hipMemsetAsync(w.egran, 0, (size_t)B * wide_gran_row(d.Tp) * 8, st));
+    // an utterance's slices on one XCD (hand-overs through that XCD's L2) when the device deals workgroup ids to its XCDs round-robin and the
+    // padded 1-D grid still fits; LAS_SPELLER_NO_PF_ROWS -- a development switch this path has no other use for -- keeps the 2-D grid
+    w.sp = SP;
+    w.xcd_local = (fuse && las_xcd_round_robin() && (long long)SP * ((B + 7) / 8) * 8 <= las_device_cus() && !(d.flags & LAS_SPELLER_NO_PF_ROWS)) ? 1 : 0;
+    const dim3 grid_f = w.xcd_local ? dim3(SP * ((B + 7) / 8) * 8) : dim3(SP, B);
     for (int t = 0; t <= U; ++t) {
         if (!(epi || lepi) || t == 0) WIDE_LAUNCH((wide_state_kernel<CELL, FAST>), dim3(B), dim3(RNT), lds_s, st, d, w, t);
         if (t == U) break;
         if (FAST) GEMM_OK(las_skinny_gemm_bf16(w.sbf, S, B, S, wb + WL.packWs, A, w.qbuf, A, nullptr, st));
-        else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, w.sf, S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
+        else GEMM_OK(las_gemm(LAS_PREC_F32, 0, 0, B, A, S, 1.f, reinterpret_cast<const float*>(w.sbf), S, 0, d.Ws, A, 0, 0.f, w.qbuf, A, 0, nullptr, LAS_ACT_NONE, 1, 0, 0, nullptr, 0, st));
         if (fuse) {
-            if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_kernel<FAST, true, 10>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
-            else if (loc) WIDE_LAUNCH((wide_attend_kernel<FAST, true>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
-            else          WIDE_LAUNCH((wide_attend_kernel<FAST, false>), dim3(SP, B), dim3(RNT), lds_f, st, d, w, t);
+            if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_kernel<FAST, true, 10>), grid_f, dim3(RNT), lds_f, st, d, w, t);
+            else if (loc) WIDE_LAUNCH((wide_attend_kernel<FAST, true>), grid_f, dim3(RNT), lds_f, st, d, w, t);
+            else          WIDE_LAUNCH((wide_attend_kernel<FAST, false>), grid_f, dim3(RNT), lds_f, st, d, w, t);
         } else {
             if (loc && d.C == 10) WIDE_LAUNCH((wide_energy_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
             else if (loc) WIDE_LAUNCH((wide_energy_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, t);
@@ -157,13 +162,16 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     const bool fuse = !(d.flags & LAS_SPELLER_NO_FUSED_STEP) && (long long)w.nsplit * B <= las_device_cus();
     const size_t lds_f = lds_a > lds_e ? (lds_a > lds_q ? lds_a : lds_q) : (lds_e > lds_q ? lds_e : lds_q);
     if (fuse) LAS_HIP(hipMemsetAsync(w.bgran, 0, (size_t)B * wide_bgran_row(Tp) * 8, st));
+    w.sp = w.nsplit;
+    w.xcd_local = (fuse && las_xcd_round_robin() && (long long)w.nsplit * ((B + 7) / 8) * 8 <= las_device_cus() && !(d.flags & LAS_SPELLER_NO_PF_ROWS)) ? 1 : 0;
+    const dim3 grid_f = w.xcd_local ? dim3(w.nsplit * ((B + 7) / 8) * 8) : dim3(w.nsplit, B);
     for (int t = U - 1; t >= -1; --t) {
         const int ta = t + 1;
         if (ta < U) {    // attention backward of step t + 1 (its context gradient is in dXin0[t + 1])
             if (fuse) {
-                if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
-                else if (loc) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
-                else          WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, false>), dim3(w.nsplit, B), dim3(RNT), lds_f, st, d, w, ta);
+                if (loc && d.C == 10) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true, 10>), grid_f, dim3(RNT), lds_f, st, d, w, ta);
+                else if (loc) WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, true>), grid_f, dim3(RNT), lds_f, st, d, w, ta);
+                else          WIDE_LAUNCH((wide_attend_bwd_kernel<FAST, false>), grid_f, dim3(RNT), lds_f, st, d, w, ta);
             } else if (loc) {
                 WIDE_LAUNCH((wide_dalpha_kernel<FAST, true>), dim3(w.nsplit, B), dim3(RNT), lds_a, st, d, w, ta);
                 if (d.C == 10) WIDE_LAUNCH((wide_energy_bwd_kernel<FAST, true, 10>), dim3(w.nsplit, B), dim3(RNT), lds_e, st, d, w, ta);
