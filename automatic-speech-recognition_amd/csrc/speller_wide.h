@@ -975,9 +975,9 @@ __global__ __launch_bounds__(256) void wide_cell_bwd_kernel(DecDev a, WideDev w,
 // After the loop: dKeys[b, t', :] += sum_t dE[t, b, t'] u (1 - tanh^2(keys + Q[t] [+ f[t] . Wf])), and in the same pass the Wf gradient
 // partial of (utterance b, 8 frames): dWfW[b][slice][c][a] = sum_{t, t' in slice} f[t, b, t', c] dv[t, b, t', a]  (written whole; reduced
 // over the slices by las_colsum).  workgroup = (8 frames, utterance), 32 lanes x float4 over the attention dim (A <= 256: two slots).
-template <bool FAST, bool LOC>
+template <bool FAST, bool LOC, int CT = 0>
 __global__ __launch_bounds__(256) void wide_dkeys_kernel(DecDev a, WideDev w, float* __restrict__ dKeys) {
-    constexpr int LC = LOC ? 16 : 1;
+    constexpr int LC = LOC ? (CT > 0 ? CT : 16) : 1;       // channel slots in registers: C itself when it is known at compile time (10), else the most the path accepts
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wf = sm;                                    // [C, A]
     float* part = sm + ((a.C * a.A + 3) & ~3);         // [8][C][A]

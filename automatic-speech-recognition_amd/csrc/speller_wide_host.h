@@ -228,7 +228,8 @@ static int wide_bwd_steps(const las_speller_bwd_args* bk, DecDev& d, const BwdWs
     }
     {   // keys gradient (and the Wf-gradient partials) contracted over the steps
         const size_t lds_k = loc ? (size_t)(((d.C * A + 3) & ~3) + 8 * d.C * A) * sizeof(float) : 0;
-        if (loc) WIDE_LAUNCH((wide_dkeys_kernel<FAST, true>), dim3(cdiv(Tp, 8), B), dim3(256), lds_k, st, d, w, bk->d_keys);
+        if (loc && d.C == 10) WIDE_LAUNCH((wide_dkeys_kernel<FAST, true, 10>), dim3(cdiv(Tp, 8), B), dim3(256), lds_k, st, d, w, bk->d_keys);
+        else if (loc) WIDE_LAUNCH((wide_dkeys_kernel<FAST, true>), dim3(cdiv(Tp, 8), B), dim3(256), lds_k, st, d, w, bk->d_keys);
         else     WIDE_LAUNCH((wide_dkeys_kernel<FAST, false>), dim3(cdiv(Tp, 8), B), dim3(256), lds_k, st, d, w, bk->d_keys);
     }
     return 0;
