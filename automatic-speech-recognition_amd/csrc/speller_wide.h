@@ -52,6 +52,15 @@ __host__ __device__ __forceinline__ int wide_gran_row(int Tp) { return Tp + 2 * 
 constexpr int WIDE_BG_PART = WIDE_MAX_SPLIT, WIDE_BG_DF = WIDE_MAX_SPLIT + WIDE_MAX_SPLIT * 2 * 256;
 __host__ __device__ __forceinline__ int wide_bgran_row(int Tp) { return WIDE_BG_DF + Tp * 16; }
 
+// ... for a granule whose first load is already in flight / in a register (several polls issued together instead of one round trip after the other)
+__device__ __forceinline__ unsigned wide_poll_loaded(const DecDev& a, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, unsigned tag, int budget, u32x2_t g) {
+    while (g.x != tag) {
+        if (--budget <= 0) { if (a.lp.status) a.lp.status[0] = LAS_SPELLER_STATUS_TIMEOUT; break; }
+        __builtin_amdgcn_s_sleep(2);
+        g = granule8_load(rs, byte_off);
+    }
+    return g.y;
+}
 // (slice, utterance) of a fused attention workgroup: from the 2-D grid, or from the XCD-local 1-D grid (see WideDev.xcd_local); b < 0: nothing to do
 __device__ __forceinline__ void wide_slice_of(const WideDev& w, const int B, int& s, int& b) {
     if (!w.xcd_local) { s = blockIdx.x; b = blockIdx.y; return; }
@@ -656,7 +665,12 @@ __device__ __forceinline__ void wide_energy_bwd_body(const DecDev& a, const Wide
     float dot = 0.f;
     if (FUSED) {      // the slices' alpha . d alpha from this launch's other workgroups (every lane polls the same few granules)
         const int budget = wide_poll_budget(a);
-        for (int q = 0; q < w.nsplit; ++q) dot += __uint_as_float(wide_poll(a, grs, (grow + q) * 8u, gtag, budget));
+        u32x2_t g[WIDE_MAX_SPLIT];
+#pragma unroll
+        for (int q = 0; q < WIDE_MAX_SPLIT; ++q) g[q] = granule8_load(grs, (grow + (q < w.nsplit ? q : 0)) * 8u);
+#pragma unroll
+        for (int q = 0; q < WIDE_MAX_SPLIT; ++q)
+            if (q < w.nsplit) dot += __uint_as_float(wide_poll_loaded(a, grs, (grow + q) * 8u, gtag, budget, g[q]));
     } else {
         for (int q = 0; q < w.nsplit; ++q) dot += w.stat[(size_t)b * w.nsplit + q];
     }
@@ -856,11 +870,23 @@ __device__ __forceinline__ void wide_dq_body(const DecDev& a, const WideDev& w, 
     if (s == 0) {
         for (int i = tid; i < A; i += RNT) {
             float dq = 0.f, du = 0.f;
-            for (int q = 0; q < w.nsplit; ++q) {
-                if (FUSED) {
-                    dq += __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_PART + (q * 2) * 256 + i) * 8u, gtag, budget));
-                    du += __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_PART + (q * 2 + 1) * 256 + i) * 8u, gtag, budget));
-                } else {
+            if (FUSED) {
+                u32x2_t gq[WIDE_MAX_SPLIT], gu[WIDE_MAX_SPLIT];
+#pragma unroll
+                for (int q = 0; q < WIDE_MAX_SPLIT; ++q) {
+                    const int qc = q < w.nsplit ? q : 0;
+                    gq[q] = granule8_load(grs, (grow + WIDE_BG_PART + (qc * 2) * 256 + i) * 8u);
+                    gu[q] = granule8_load(grs, (grow + WIDE_BG_PART + (qc * 2 + 1) * 256 + i) * 8u);
+                }
+#pragma unroll
+                for (int q = 0; q < WIDE_MAX_SPLIT; ++q) {
+                    if (q < w.nsplit) {
+                        dq += __uint_as_float(wide_poll_loaded(a, grs, (grow + WIDE_BG_PART + (q * 2) * 256 + i) * 8u, gtag, budget, gq[q]));
+                        du += __uint_as_float(wide_poll_loaded(a, grs, (grow + WIDE_BG_PART + (q * 2 + 1) * 256 + i) * 8u, gtag, budget, gu[q]));
+                    }
+                }
+            } else {
+                for (int q = 0; q < w.nsplit; ++q) {
                     dq += w.pdq[((size_t)b * w.nsplit + q) * A + i];
                     du += w.pdu[((size_t)b * w.nsplit + q) * A + i];
                 }
@@ -882,10 +908,30 @@ __device__ __forceinline__ void wide_dq_body(const DecDev& a, const WideDev& w, 
         float* locw = rows + (((((w.fper + 3) & ~3) + Kc + 2) * C + 3) & ~3);      // [Kc + 2, C]
         float* part = locw + (((Kc + 2) * C + 3) & ~3);                            // [NKC, nf]
         const float* ds = a.dfcSave + ((size_t)t * B + b) * Tp * C;
-        for (int i = tid; i < nrows * C; i += RNT) {
-            const int rho = i / C, fr = t0 + rho - (Kc + 1) + pad;
-            if (FUSED) rows[i] = (fr >= 0 && fr < Tp) ? __uint_as_float(wide_poll(a, grs, (grow + WIDE_BG_DF + fr * 16 + (i - rho * C)) * 8u, gtag, budget)) : 0.f;
-            else rows[i] = (fr >= 0 && fr < Tp) ? ds[(size_t)fr * C + (i - rho * C)] : 0.f;
+        if (FUSED) {      // four granules per lane requested together, then checked
+            for (int i0 = tid; i0 < nrows * C; i0 += 4 * RNT) {
+                u32x2_t g[4];
+                unsigned off[4];
+                bool on[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * RNT, ic = i < nrows * C ? i : 0;
+                    const int rho = ic / C, fr = t0 + rho - (Kc + 1) + pad;
+                    on[k] = i < nrows * C && fr >= 0 && fr < Tp;
+                    off[k] = (grow + WIDE_BG_DF + (on[k] ? fr : 0) * 16 + (ic - rho * C)) * 8u;
+                    g[k] = granule8_load(grs, off[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * RNT;
+                    if (i < nrows * C) rows[i] = on[k] ? __uint_as_float(wide_poll_loaded(a, grs, off[k], gtag, budget, g[k])) : 0.f;
+                }
+            }
+        } else {
+            for (int i = tid; i < nrows * C; i += RNT) {
+                const int rho = i / C, fr = t0 + rho - (Kc + 1) + pad;
+                rows[i] = (fr >= 0 && fr < Tp) ? ds[(size_t)fr * C + (i - rho * C)] : 0.f;
+            }
         }
         for (int i = tid; i < Kc * C; i += RNT) locw[i] = a.loc_w[i];
         __syncthreads();
