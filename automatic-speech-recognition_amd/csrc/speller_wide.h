@@ -18,7 +18,7 @@
 // alignment / context are ONE launch (wide_attend_kernel) and so are d alpha -> d energy -> dq (wide_attend_bwd_kernel): an utterance's
 // workgroups hand their partial results to each other as tagged granules (bounded polls; the status word reports a partner that never ran);
 // and the cells and their gate gradients are epilogues of the skinny products (gemm.hip: las_skinny_gemm_bf16_tanh / _tanh_bwd / _lstm_bwd,
-// las_skinny_lstm_bf16).  8 dependent launches per decode step with tanh cells, 9 with LSTM cells, instead of 15 -- the same arithmetic.
+// las_skinny_lstm_bf16).  8 dependent launches per decode step (either cell) instead of 13 (tanh) or 15 (LSTM) -- the same arithmetic.
 // Arithmetic: speed mode = the loop kernels' ("bf rows": keys kept in bf16, q / context / cell products on bf16 operands with fp32
 // accumulation, everything else fp32); parity mode = fp32 throughout (the same kernels with FAST = false, accurate transcendentals).
 #pragma once
